@@ -1,0 +1,292 @@
+"""Generate tests/golden/*.npz by RUNNING THE UPSTREAM REFERENCE on CPU — TEST INFRASTRUCTURE.
+
+Run here only (the container that has /root/reference):   python oracle/gen_golden.py
+The committed outputs are DATA (inputs + the reference's outputs); no reference source,
+bytecode or text is stored. Vector ids follow SURVEY.md section 8c (G1..G8).
+
+Each fixture cites the reference call that produced it:
+  G1  Trainer.csr_norm(mean_flag=True)                  main.py:89-103
+  G2  MMSSL.forward, eval mode                          Models.py:171-220
+  G3  MMSSL.forward train mode (drop_rate=0) + backward Models.py:171-220
+  G4  Trainer.batched_contrastive_loss                  main.py:211-249
+  G5  Trainer.bpr_loss / feat_reg_loss_calculation      main.py:499-511, 252-257
+  G6  Data.sample()                                     utility/load_data.py:153-191
+  G7  test_torch (Recall/NDCG/precision/hit @ Ks)       utility/batch_test.py:112-169
+  G8  G-step loss assembly                              main.py:363-420
+"""
+import os
+import shutil
+import sys
+
+import numpy as np
+import scipy.sparse as sp
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import ref_shim  # noqa: E402
+import synth_data  # noqa: E402
+
+OUT = os.path.join(HERE, "..", "tests", "golden")
+TMP = "/tmp/mmssl_golden/"
+U, I, E, DV, DT, D, B = 160, 96, 1000, 32, 48, 64, 48
+
+
+def npy(t):
+    return t.detach().cpu().numpy()
+
+
+def cotangent(k, shape):
+    """Deterministic analytic cotangent for output k (recomputed, not stored, by the tests)."""
+    i = np.arange(shape[0], dtype=np.float64)[:, None]
+    j = np.arange(shape[1], dtype=np.float64)[None, :]
+    return np.sin(0.37 * i + 1.3 * j + 0.71 * k).astype(np.float32)
+
+
+def coo_triplets(csr):
+    c = csr.tocoo()
+    return c.row.astype(np.int64), c.col.astype(np.int64), c.data.astype(np.float32)
+
+
+def params_of(model):
+    sd = model.state_dict()
+    keep = ["image_trans.weight", "image_trans.bias", "text_trans.weight", "text_trans.bias",
+            "user_id_embedding.weight", "item_id_embedding.weight",
+            "weight_dict.w_q", "weight_dict.w_k", "weight_dict.w_v",
+            "weight_dict.w_self_attention_cat"]
+    return {"p." + k: npy(sd[k]) for k in keep}
+
+
+OUT_NAMES = ["ua", "ia", "image_item", "text_item", "image_user", "text_user",
+             "ua2", "ia2", "image_user_id", "text_user_id", "image_item_id", "text_item_id"]
+
+
+def main():
+    if os.path.isdir(TMP):
+        shutil.rmtree(TMP)
+    os.makedirs(OUT, exist_ok=True)
+    synth_data.write_dataset(TMP, "tiny", U, I, E, DV, DT, seed=1)
+    # copy the dataset itself as a fixture (json + npy + triplets): tests rebuild it on disk
+    ref = ref_shim.load(TMP, "tiny", ["--batch_size", str(B), "--drop_rate", "0.0"])
+    Models = sys.modules["Models"]
+    args = ref.args
+    margs = Models.args
+    dg = ref.data_generator
+
+    # ---------------- G6: sampler, must come first (fresh RNG state) ----------------
+    ref.set_seed(2022)
+    batches = [dg.sample() for _ in range(3)]
+    np.savez(os.path.join(OUT, "g6_sample.npz"),
+             users=np.array([b[0] for b in batches], np.int64),
+             pos=np.array([b[1] for b in batches], np.int64),
+             neg=np.array([b[2] for b in batches], np.int64), seed=2022, batch_size=B)
+    # B > n_users branch (random.choice path, load_data.py:156-157)
+    dg.batch_size = U + 37
+    ref.set_seed(7)
+    big = dg.sample()
+    dg.batch_size = B
+    np.savez(os.path.join(OUT, "g6_sample_big.npz"), users=np.array(big[0], np.int64),
+             pos=np.array(big[1], np.int64), neg=np.array(big[2], np.int64), seed=7,
+             batch_size=U + 37)
+
+    # dataset fixture (so tests can rebuild the on-disk dataset without synth code drift)
+    import json, pickle
+    ddir = os.path.join(TMP, "tiny")
+    tm = pickle.load(open(os.path.join(ddir, "train_mat"), "rb"))
+    r, c, v = coo_triplets(tm)
+
+    def flat(js):
+        ids, items, lens = [], [], []
+        for k, lst in js.items():
+            ids.append(int(k)); lens.append(len(lst)); items += lst
+        return np.array(ids, np.int64), np.array(lens, np.int64), np.array(items, np.int64)
+
+    ds = {}
+    for nm in ("train", "val", "test"):
+        a, b_, c_ = flat(json.load(open(os.path.join(ddir, nm + ".json"))))
+        ds[nm + "_uid"], ds[nm + "_len"], ds[nm + "_items"] = a, b_, c_
+    np.savez_compressed(os.path.join(OUT, "dataset_tiny.npz"), tm_row=r, tm_col=c, tm_val=v,
+                        image_feat=np.load(os.path.join(ddir, "image_feat.npy")),
+                        text_feat=np.load(os.path.join(ddir, "text_feat.npy")),
+                        n_users=U, n_items=I, **ds)
+
+    # ---------------- Trainer ----------------
+    ref.set_seed(2022)
+    tr = ref.Trainer(data_config={"n_users": dg.n_users, "n_items": dg.n_items})
+
+    # ---------------- G1: csr_norm ----------------
+    raw = tr.ui_graph_raw
+    n_ui = tr.csr_norm(raw, mean_flag=True).tocsr()
+    n_iu = tr.csr_norm(raw.T, mean_flag=True).tocsr()
+    # custom matrix with empty rows and non-unit values
+    rng = np.random.default_rng(5)
+    cm = sp.random(17, 11, density=0.2, random_state=3, format="csr", dtype=np.float32)
+    cm.data = (rng.random(cm.nnz).astype(np.float32) + 0.5)
+    cm = cm.tolil(); cm[4, :] = 0; cm[9, :] = 0; cm = cm.tocsr(); cm.eliminate_zeros()
+    n_cm = tr.csr_norm(cm, mean_flag=True).tocsr()
+    n_cm_sym = tr.csr_norm(cm, mean_flag=False).tocsr()
+    g1 = {}
+    for nm, m in (("raw", raw.tocsr()), ("ui", n_ui), ("iu", n_iu), ("cm", cm), ("cm_norm", n_cm),
+                  ("cm_sym", n_cm_sym)):
+        rr, cc, vv = coo_triplets(m)
+        g1[nm + "_row"], g1[nm + "_col"], g1[nm + "_val"] = rr, cc, vv
+        g1[nm + "_shape"] = np.array(m.shape, np.int64)
+    np.savez_compressed(os.path.join(OUT, "g1_csr_norm.npz"), **g1)
+
+    # ---------------- modal graph variants ----------------
+    def graph_pair(ui_csr):
+        ui = tr.matrix_to_tensor(tr.csr_norm(ui_csr, mean_flag=True))
+        iu = tr.matrix_to_tensor(tr.csr_norm(ui_csr.T, mean_flag=True))
+        return ui, iu
+
+    rngm = np.random.default_rng(11)
+    us = rngm.choice(U, size=B, replace=False)
+    sparse_img = sp.csr_matrix((np.ones(B, np.float32), (us, rngm.integers(0, I, B))), shape=(U, I))
+    sparse_txt = sp.csr_matrix((np.ones(B, np.float32), (us, rngm.integers(0, I, B))), shape=(U, I))
+    empty = sp.csr_matrix((np.zeros(0, np.float32), (np.zeros(0, int), np.zeros(0, int))), shape=(U, I))
+    variants = {
+        "full": (raw, raw),
+        "sparse": (sparse_img, sparse_txt),
+        "empty": (empty, empty),
+    }
+
+    def run_forward(model, modal, train_mode):
+        img_ui, img_iu = graph_pair(variants[modal][0])
+        txt_ui, txt_iu = graph_pair(variants[modal][1])
+        model.train(train_mode)
+        return model(tr.ui_graph, tr.iu_graph, img_ui, img_iu, txt_ui, txt_iu)
+
+    def modal_triplets(modal):
+        out = {}
+        for nm, m in (("img", variants[modal][0]), ("txt", variants[modal][1])):
+            rr, cc, vv = coo_triplets(m.tocsr())
+            out["modal_%s_row" % nm], out["modal_%s_col" % nm], out["modal_%s_val" % nm] = rr, cc, vv
+        return out
+
+    # ---------------- G2 / G3 ----------------
+    for tag, wsize, layers in (("g2_l1", [64, 64], 1), ("g3_l2", [64, 64, 64], 2)):
+        margs.layers = layers
+        torch.manual_seed(100 + layers)
+        model = ref.MMSSL(U, I, D, list(wsize), [0.1] * len(wsize), tr.image_feats, tr.text_feats)
+        P = params_of(model)
+        for modal in ("full", "sparse", "empty"):
+            with torch.no_grad():
+                outs = run_forward(model, modal, train_mode=False)
+            np.savez_compressed(
+                os.path.join(OUT, "g2_forward_%s_%s.npz" % (tag, modal)),
+                weight_size=np.array(wsize), layers=layers,
+                **P, **modal_triplets(modal), same_0_6=bool(outs[0] is outs[6]), same_1_7=bool(outs[1] is outs[7]),
+                **{"o." + n: npy(o) for n, o in zip(OUT_NAMES, outs) if n not in ("ua2", "ia2")})
+        # G3: train mode, drop_rate = 0 (args.drop_rate parsed as 0.0), backward of fixed scalar
+        for modal in ("full", "sparse"):
+            model.zero_grad()
+            outs = run_forward(model, modal, train_mode=True)
+            cots = [torch.from_numpy(cotangent(k, tuple(o.shape))) for k, o in enumerate(outs)]
+            # outs[0] is outs[6] and outs[1] is outs[7] (Models.py:220): cotangents add up
+            scalar = sum((o * c).sum() for o, c in zip(outs, cots))
+            scalar.backward()
+            grads = {}
+            for k, p in model.named_parameters():
+                if ("p." + k) in P and p.grad is not None:
+                    grads["g." + k] = npy(p.grad)
+            np.savez_compressed(
+                os.path.join(OUT, "g3_backward_%s_%s.npz" % (tag, modal)),
+                weight_size=np.array(wsize), layers=layers, scalar=float(scalar),
+                **P, **modal_triplets(modal),
+                **grads)
+    margs.layers = 1
+
+    # ---------------- G4: InfoNCE ----------------
+    g4 = {}
+    gen = torch.Generator().manual_seed(4)
+    cases = {
+        "n64": (torch.randn(64, D, generator=gen), torch.randn(64, D, generator=gen)),
+        "n1100_d32": (torch.randn(1100, 32, generator=gen) * 0.3, torch.randn(1100, 32, generator=gen) * 2.0),
+        "zero_z1": (torch.zeros(64, D), torch.randn(64, D, generator=gen)),
+        "n130_d128": (torch.randn(130, 128, generator=gen), torch.randn(130, 128, generator=gen)),
+    }
+    z = cases["n64"][0].clone(); z[5] = 0; z[17] = 0
+    cases["some_zero_rows"] = (z, cases["n64"][1].clone())
+    for nm, (z1, z2) in cases.items():
+        z1 = z1.clone().requires_grad_(True); z2 = z2.clone().requires_grad_(True)
+        loss = tr.batched_contrastive_loss(z1, z2)
+        loss.backward()
+        g4[nm + ".z1"], g4[nm + ".z2"] = npy(z1), npy(z2)
+        g4[nm + ".loss"] = np.float32(loss.item())
+        g4[nm + ".gz1"], g4[nm + ".gz2"] = npy(z1.grad), npy(z2.grad)
+    g4["tau"] = np.float32(args.tau)
+    np.savez_compressed(os.path.join(OUT, "g4_infonce.npz"), **g4)
+
+    # ---------------- G5: BPR + feat reg ----------------
+    gen = torch.Generator().manual_seed(5)
+    u = (torch.randn(B, D, generator=gen) * 0.2).requires_grad_(True)
+    p = (torch.randn(B, D, generator=gen) * 0.2).requires_grad_(True)
+    n = (torch.randn(B, D, generator=gen) * 0.2).requires_grad_(True)
+    mf, emb, reg = tr.bpr_loss(u, p, n)
+    (mf + emb).backward()
+    a = (torch.randn(I, D, generator=gen)).requires_grad_(True)
+    b = (torch.randn(I, D, generator=gen)).requires_grad_(True)
+    c = (torch.randn(U, D, generator=gen)).requires_grad_(True)
+    d = (torch.randn(U, D, generator=gen)).requires_grad_(True)
+    fr = tr.feat_reg_loss_calculation(a, b, c, d)
+    fr.backward()
+    np.savez_compressed(os.path.join(OUT, "g5_bpr_featreg.npz"), u=npy(u), p=npy(p), n=npy(n),
+                        mf=np.float32(mf.item()), emb=np.float32(emb.item()), reg=np.float32(reg),
+                        gu=npy(u.grad), gp=npy(p.grad), gn=npy(n.grad), batch_size=B, decay=tr.decay,
+                        fa=npy(a), fb=npy(b), fc=npy(c), fd=npy(d), feat_reg=np.float32(fr.item()),
+                        gfa=npy(a.grad), gfc=npy(c.grad), feat_reg_decay=args.feat_reg_decay, n_items=I)
+
+    # ---------------- G7: evaluation ----------------
+    gen = torch.Generator().manual_seed(9)
+    ua = torch.randn(U, D, generator=gen)
+    ia = torch.randn(I, D, generator=gen)
+    ia[7] = ia[3]  # force exact score ties (tie rule: lower item id first)
+    ia[50] = ia[3]
+    g7 = {"ua": npy(ua), "ia": npy(ia), "Ks": np.array(eval(args.Ks))}
+    for is_val, nm in ((True, "val"), (False, "test")):
+        users = list((dg.val_set if is_val else dg.test_set).keys())
+        res = ref.test_torch(ua, ia, users, is_val)
+        for k in ("precision", "recall", "ndcg", "hit_ratio"):
+            g7["%s.%s" % (nm, k)] = np.asarray(res[k], np.float64)
+        g7["%s.users" % nm] = np.array(users, np.int64)
+    np.savez_compressed(os.path.join(OUT, "g7_eval.npz"), **g7)
+
+    # ---------------- G8: G-step loss assembly (main.py:363-420), D frozen in eval ----------------
+    torch.manual_seed(8)
+    model = ref.MMSSL(U, I, D, [64, 64], [0.1, 0.1], tr.image_feats, tr.text_feats)
+    tr.model = model
+    tr.D.eval()
+    model.train()
+    ref.set_seed(2022)
+    users, pos, neg = dg.sample()
+    for modal in ("full", "empty"):
+        img_ui, img_iu = graph_pair(variants[modal][0])
+        txt_ui, txt_iu = graph_pair(variants[modal][1])
+        model.zero_grad()
+        (G_ua, G_ia, G_image_item, G_text_item, G_image_user, G_text_user, G_user_emb, _, G_image_user_id,
+         G_text_user_id, _, _) = model(tr.ui_graph, tr.iu_graph, img_ui, img_iu, txt_ui, txt_iu)
+        mf, emb, reg = tr.bpr_loss(G_ua[users], G_ia[pos], G_ia[neg])
+        G_image_u_sim = tr.u_sim_calculation(users, G_image_user, G_image_item)
+        G_text_u_sim = tr.u_sim_calculation(users, G_text_user, G_text_item)
+        feat = tr.feat_reg_loss_calculation(G_image_item, G_text_item, G_image_user, G_text_user)
+        cl1 = tr.batched_contrastive_loss(G_image_user_id[users], G_user_emb[users])
+        cl2 = tr.batched_contrastive_loss(G_text_user_id[users], G_user_emb[users])
+        G_lossf = -(tr.D(torch.cat((G_image_u_sim, G_text_u_sim), dim=0)).mean())
+        batch_loss = mf + emb + reg + feat + args.cl_rate * (cl1 + cl2) + args.G_rate * G_lossf
+        batch_loss.backward()
+        grads = {"g." + k: npy(p_.grad) for k, p_ in model.named_parameters()
+                 if ("p." + k) in params_of(model) and p_.grad is not None}
+        np.savez_compressed(
+            os.path.join(OUT, "g8_gstep_%s.npz" % modal), **params_of(model), **modal_triplets(modal),
+            **{"D." + k: npy(v_) for k, v_ in tr.D.state_dict().items()},
+            users=np.array(users, np.int64), pos=np.array(pos, np.int64), neg=np.array(neg, np.int64),
+            mf=np.float32(mf.item()), emb=np.float32(emb.item()), feat=np.float32(feat.item()),
+            cl1=np.float32(cl1.item()), cl2=np.float32(cl2.item()), G_lossf=np.float32(G_lossf.item()),
+            batch_loss=np.float32(batch_loss.item()), cl_rate=args.cl_rate, G_rate=args.G_rate, **grads)
+
+    for f in sorted(os.listdir(OUT)):
+        print("%9d  %s" % (os.path.getsize(os.path.join(OUT, f)), f))
+
+
+if __name__ == "__main__":
+    main()

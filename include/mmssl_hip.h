@@ -1,0 +1,175 @@
+/*
+ * mmssl_hip.h — C ABI of libmmssl_hip.so: the MI355X (gfx950 / CDNA4) kernels behind the
+ * MMSSL hot path (modality-aware GCN message passing, per-modality projection,
+ * L2-normalise, InfoNCE and BPR losses).
+ *
+ * The upstream reference (HKUDS/MMSSL) has NO native/FFI interface: the path sits behind
+ * PyTorch op call sites. Each entry point below therefore names the reference CALL SITE
+ * it replaces (paths relative to /root/reference/MMSSL/). A maintainer binds these with
+ * ctypes from torch.autograd.Function wrappers — see INTEGRATION.md and
+ * mmssl_amd/_lib.py.
+ *
+ * Conventions
+ *   - return 0 on success; <0 = MMSSL_E_* (bad argument / unsupported); >0 = hipError_t.
+ *   - nothing throws across the ABI; no torch / C++ types in signatures.
+ *   - every dense buffer is CALLER-owned device memory, row-major contiguous fp32,
+ *     16-byte aligned; indices are int32 (graphs) or int64 (batch indices, like the
+ *     reference's python ints -> LongTensor). Only `mmssl_graph` is library-owned.
+ *   - all compute entry points are asynchronous on the passed hipStream_t (`stream`,
+ *     e.g. torch.cuda.current_stream().cuda_stream); they never allocate, never
+ *     synchronise and are hipGraph-capturable. mmssl_graph_create/destroy are
+ *     synchronous set-up calls.
+ *   - "workspace" arguments are scratch the caller allocates once (size from the
+ *     matching *_workspace_bytes call) and may reuse across calls on the same stream.
+ */
+#ifndef MMSSL_HIP_H
+#define MMSSL_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MMSSL_ABI_VERSION 1
+
+#define MMSSL_E_BADARG   (-1)   /* null pointer, negative size, malformed CSR ...   */
+#define MMSSL_E_UNSUPP   (-2)   /* feature width d not in {32,64,128,256} etc.      */
+#define MMSSL_E_WORKSPACE (-3)  /* workspace too small                               */
+
+int mmssl_abi_version(void);
+/* Human-readable text for a return code of this library (static storage). */
+const char* mmssl_strerror(int code);
+
+/* ------------------------------------------------------------------------------------
+ * Graph plan  — replaces the torch sparse COO handles the reference builds on the host
+ *   Trainer.csr_norm -> matrix_to_tensor / sparse_mx_to_torch_sparse_tensor
+ *   (main.py:89-112, 513-520; rebuilt per batch at main.py:378-397).
+ * Input is the HOST CSR the reference's scipy code produces (values already normalised).
+ * The plan holds, on the device of the current HIP context: the CSR (edges packed as
+ * {col,val} pairs), its transpose (for backward: torch autograd's A^T . gradY), and a
+ * degree-balanced work list (short rows -> one 16-lane group each, long rows split into
+ * <=128-nnz wave tasks with a deterministic second-stage sum).
+ * nnz == 0 is legal (the reference's "empty modal graph" state).
+ * ---------------------------------------------------------------------------------- */
+typedef struct mmssl_graph mmssl_graph;
+
+int mmssl_graph_create(const int32_t* rowptr, const int32_t* col, const float* val,
+                       int32_t rows, int32_t cols, int64_t nnz, void* stream,
+                       mmssl_graph** out);
+int mmssl_graph_destroy(mmssl_graph* g);
+/* info[0..7] = rows, cols, nnz, group_items, wave_items, multi_rows, partial_slots,
+ *              same five for the transpose in info[8..12] (info has 16 slots). */
+int mmssl_graph_info(const mmssl_graph* g, int64_t info[16]);
+/* Copy the device-resident transposed CSR back to host buffers (tests / debugging). */
+int mmssl_graph_export_transpose(const mmssl_graph* g, int32_t* t_rowptr, int32_t* t_col,
+                                 float* t_val, void* stream);
+
+/* Host-only planning helpers (pure CPU, no device needed) — exported so the host logic
+ * is testable without a GPU; mmssl_graph_create uses exactly these. */
+int mmssl_csr_validate_host(const int32_t* rowptr, const int32_t* col, int32_t rows,
+                            int32_t cols, int64_t nnz);
+int mmssl_csr_transpose_host(const int32_t* rowptr, const int32_t* col, const float* val,
+                             int32_t rows, int32_t cols, int64_t nnz, int32_t* t_rowptr,
+                             int32_t* t_col, float* t_val);
+/* counts[0..3] = group_items, wave_items, multi_rows, partial_slots */
+int mmssl_plan_count_host(const int32_t* rowptr, int32_t rows, int64_t counts[4]);
+/* items are int32 quadruples {row, edge_begin, edge_end, slot(-1 = direct)};
+ * multi are quadruples {row, first_slot, n_slots, 0}. */
+int mmssl_plan_fill_host(const int32_t* rowptr, int32_t rows, int32_t* group_items,
+                         int32_t* wave_items, int32_t* multi);
+
+/* ------------------------------------------------------------------------------------
+ * SpMM  Y[R,d] = op(A) . X[C,d]   — replaces torch.sparse.mm / torch.mm(sparse, dense)
+ *   MMSSL.mm (Models.py:69-73) call sites Models.py:177-186 and the GCN propagation
+ *   Models.py:201-211; transpose=1 is the autograd backward gradX = A^T . gradY.
+ * epilogue: MMSSL_EPI_NONE, or MMSSL_EPI_SOFTMAX = row softmax over the d features fused
+ *   into the store (the last GCN layer, Models.py:202-204).
+ * d in {32, 64, 128, 256}.
+ * ---------------------------------------------------------------------------------- */
+#define MMSSL_EPI_NONE    0
+#define MMSSL_EPI_SOFTMAX 1
+
+size_t mmssl_spmm_workspace_bytes(const mmssl_graph* g, int transpose, int d);
+int mmssl_spmm_f32(const mmssl_graph* g, int transpose, const float* X, int d, float* Y,
+                   int epilogue, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Row kernels
+ *   mmssl_l2norm_rows*: F.normalize(x, p=2, dim=1) = x / max(||x||, eps)
+ *     (Models.py:196-197, 217-218; main.py:212-213) and its backward.
+ *     Y = alpha * normalize(X) + (Base ? Base : 0)   (alpha/Base fuse the "+ rate *"
+ *     adds at Models.py:196-197,217-218).
+ *   mmssl_softmax_rows_bwd: gX = Y * (gY - sum(gY*Y)) (backward of Models.py:203-204).
+ *   mmssl_sumsq: sum of squares of a flat buffer -> out[0] (feat_reg main.py:252-257,
+ *     BPR regulariser main.py:503); deterministic two-stage reduction.
+ * ---------------------------------------------------------------------------------- */
+int mmssl_l2norm_rows_f32(const float* X, const float* Base, float alpha, int64_t rows, int d,
+                          float eps, float* Y, void* stream);
+int mmssl_l2norm_rows_bwd_f32(const float* X, const float* gY, float alpha, int64_t rows, int d,
+                              float eps, float* gX, void* stream);
+int mmssl_softmax_rows_bwd_f32(const float* Y, const float* gY, int64_t rows, int d, float* gX,
+                               void* stream);
+size_t mmssl_sumsq_workspace_bytes(int64_t n);
+int mmssl_sumsq_f32(const float* X, int64_t n, float* out, void* workspace,
+                    size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Modality projection  Y[M,N] = dropout(F[M,K] . W[N,K]^T + b[N])
+ *   nn.Linear image_trans / text_trans + nn.Dropout (Models.py:28-29, 54, 173-174).
+ *   keep: optional uint8 [M,N] keep-mask (1 = keep); kept entries are scaled by `scale`
+ *   (= 1/(1-p)); keep == NULL means no dropout (eval mode). fp32 MFMA
+ *   (v_mfma_f32_32x32x2_f32), exact fp32. N % 4 == 0, N <= 256, K % 4 == 0.
+ *   mmssl_linear_wgrad: gW[N,K] = gY[M,N]^T . F[M,K], gb[N] = column sums of gY
+ *   (autograd of the same call site; gY already carries the dropout mask).
+ * ---------------------------------------------------------------------------------- */
+size_t mmssl_linear_workspace_bytes(int64_t M, int K, int N);   /* split-K partials */
+int mmssl_linear_f32(const float* F, const float* W, const float* b, const uint8_t* keep,
+                     float scale, int64_t M, int K, int N, float* Y, void* workspace,
+                     size_t workspace_bytes, void* stream);
+size_t mmssl_linear_wgrad_workspace_bytes(int64_t M, int K, int N);
+int mmssl_linear_wgrad_f32(const float* gY, const float* F, int64_t M, int K, int N, float* gW,
+                           float* gb, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * InfoNCE  — Trainer.batched_contrastive_loss + Trainer.sim (main.py:211-249)
+ *   loss = mean_i -log( e^{c12_ii/tau} / (sum_j e^{c11_ij/tau} + sum_j e^{c12_ij/tau}
+ *                        - e^{c11_ii/tau}) + 1e-8 ),  c = cosine of L2-normalised rows.
+ *   z1, z2: [n, d] raw (un-normalised) rows. The reference's 1024-row blocking is
+ *   mathematically the full-matrix formula; any n >= 1 is accepted.
+ *   fwd writes loss[0] and keeps what bwd needs in `workspace`; bwd(gloss) -> gz1, gz2.
+ *   d % 4 == 0, d <= 256.
+ * ---------------------------------------------------------------------------------- */
+size_t mmssl_infonce_workspace_bytes(int64_t n, int d);
+int mmssl_infonce_fwd_f32(const float* z1, const float* z2, int64_t n, int d, float tau,
+                          float* loss, void* workspace, size_t workspace_bytes, void* stream);
+int mmssl_infonce_bwd_f32(const float* z1, const float* z2, int64_t n, int d, float tau,
+                          const float* gloss, float* gz1, float* gz2, void* workspace,
+                          size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * BPR  — gathers (main.py:368-370) + Trainer.bpr_loss (main.py:499-511)
+ *   out3 = { mf_loss = -mean logsigmoid(u.p - u.n),
+ *            emb_loss = decay * 0.5*(|u|^2+|p|^2+|n|^2) / batch_size,
+ *            reg_loss = 0 }
+ *   Eu [U,d], Ei [I,d]; users/pos/neg: int64 [B] device indices, or all NULL for the
+ *   already-gathered form (row b of Eu / Ei_pos / Ei_neg; then Ei = pos rows and
+ *   `Ei_neg` = neg rows).  bwd accumulates (atomicAdd) g_mf*d(mf) + g_emb*d(emb) into
+ *   gEu / gEi, which the caller zero-fills (dense table gradients, like autograd's
+ *   index backward).
+ * ---------------------------------------------------------------------------------- */
+size_t mmssl_bpr_workspace_bytes(int64_t B);
+int mmssl_bpr_fwd_f32(const float* Eu, const float* Ei, const float* Ei_neg, const int64_t* users,
+                      const int64_t* pos, const int64_t* neg, int64_t B, int d, float decay,
+                      int64_t batch_size, float* out3, void* workspace, size_t workspace_bytes,
+                      void* stream);
+int mmssl_bpr_bwd_f32(const float* Eu, const float* Ei, const float* Ei_neg, const int64_t* users,
+                      const int64_t* pos, const int64_t* neg, int64_t B, int d, float decay,
+                      int64_t batch_size, const float* g_mf, const float* g_emb, float* gEu,
+                      float* gEi, float* gEi_neg, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MMSSL_HIP_H */

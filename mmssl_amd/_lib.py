@@ -1,0 +1,100 @@
+"""ctypes binding of libmmssl_hip.so (the C ABI declared in include/mmssl_hip.h).
+
+The library is REQUIRED: there is no eager / CPU fallback anywhere in this package. If
+the shared object is missing or a symbol cannot be resolved the import of the op fails
+loudly (RuntimeError) instead of silently computing something else.
+"""
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmmssl_hip.so")
+
+_i32p = POINTER(c_int32)
+_i64p = POINTER(c_int64)
+_f32p = POINTER(c_float)
+
+# name -> (restype, argtypes); mirrors include/mmssl_hip.h one to one
+SIGNATURES = {
+    "mmssl_abi_version": (c_int, []),
+    "mmssl_strerror": (c_char_p, [c_int]),
+    "mmssl_graph_create": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int64, c_void_p,
+                                   POINTER(c_void_p)]),
+    "mmssl_graph_destroy": (c_int, [c_void_p]),
+    "mmssl_graph_info": (c_int, [c_void_p, _i64p]),
+    "mmssl_graph_export_transpose": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "mmssl_csr_validate_host": (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int64]),
+    "mmssl_csr_transpose_host": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int64,
+                                         c_void_p, c_void_p, c_void_p]),
+    "mmssl_plan_count_host": (c_int, [c_void_p, c_int32, _i64p]),
+    "mmssl_plan_fill_host": (c_int, [c_void_p, c_int32, c_void_p, c_void_p, c_void_p]),
+    "mmssl_spmm_workspace_bytes": (c_size_t, [c_void_p, c_int, c_int]),
+    "mmssl_spmm_f32": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_size_t,
+                               c_void_p]),
+    "mmssl_l2norm_rows_f32": (c_int, [c_void_p, c_void_p, c_float, c_int64, c_int, c_float, c_void_p,
+                                      c_void_p]),
+    "mmssl_l2norm_rows_bwd_f32": (c_int, [c_void_p, c_void_p, c_float, c_int64, c_int, c_float, c_void_p,
+                                          c_void_p]),
+    "mmssl_softmax_rows_bwd_f32": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p]),
+    "mmssl_sumsq_workspace_bytes": (c_size_t, [c_int64]),
+    "mmssl_sumsq_f32": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "mmssl_linear_workspace_bytes": (c_size_t, [c_int64, c_int, c_int]),
+    "mmssl_linear_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int64, c_int, c_int,
+                                 c_void_p, c_void_p, c_size_t, c_void_p]),
+    "mmssl_linear_wgrad_workspace_bytes": (c_size_t, [c_int64, c_int, c_int]),
+    "mmssl_linear_wgrad_f32": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p,
+                                       c_void_p, c_size_t, c_void_p]),
+    "mmssl_infonce_workspace_bytes": (c_size_t, [c_int64, c_int]),
+    "mmssl_infonce_fwd_f32": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_float, c_void_p, c_void_p,
+                                      c_size_t, c_void_p]),
+    "mmssl_infonce_bwd_f32": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_float, c_void_p, c_void_p,
+                                      c_void_p, c_void_p, c_size_t, c_void_p]),
+    "mmssl_bpr_workspace_bytes": (c_size_t, [c_int64]),
+    "mmssl_bpr_fwd_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
+                                  c_int, c_float, c_int64, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "mmssl_bpr_bwd_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
+                                  c_int, c_float, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
+                                  c_void_p, c_void_p]),
+}
+
+_lib = None
+
+
+class MmsslError(RuntimeError):
+    pass
+
+
+def lib():
+    """The loaded library (loaded once). Raises if libmmssl_hip.so is absent: build it with
+    `python -m mmssl_amd.build` (or __graft_entry__.build())."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MmsslError("%s not found — the HIP extension is required (no fallback path). "
+                         "Run `python -m mmssl_amd.build`." % LIB_PATH)
+    L = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(L, name)
+        except AttributeError:
+            raise MmsslError("libmmssl_hip.so does not export %s (stale build?)" % name)
+        fn.restype = res
+        fn.argtypes = args
+    if L.mmssl_abi_version() != 1:
+        raise MmsslError("libmmssl_hip.so ABI version mismatch")
+    _lib = L
+    return L
+
+
+def check(code, what):
+    if code != 0:
+        msg = lib().mmssl_strerror(code)
+        raise MmsslError("%s failed: %s (code %d)" % (what, msg.decode() if msg else "?", code))
+
+
+def stream_ptr():
+    """hipStream_t of torch's current stream on the current device."""
+    import torch
+    return torch.cuda.current_stream().cuda_stream

@@ -1,0 +1,425 @@
+// Graph plan + CSR SpMM for gfx950 (MI355X).
+//
+// Replaces the reference's torch sparse COO handles and torch.sparse.mm call sites
+// (/root/reference/MMSSL/main.py:89-112,513-520; Models.py:69-73,177-186,201-211).
+//
+// Design (HBM/L2-bound gather, NOT reshaped into a GEMM):
+//   * d fp32 features per row are covered by LPR = d/4 lanes holding one float4 each, so a
+//     neighbour-row read is ONE coalesced 16-B-per-lane request (d=64: 16 lanes = 256 B);
+//     a wave64 therefore works on 64/LPR rows (or row slices) at once.
+//   * the {col,val} pairs of a row tile are read once, coalesced (lane j takes edge j of
+//     the tile), and broadcast inside the lane group with ds_bpermute; X gathers are
+//     issued 4 deep per lane.
+//   * load balance comes from the host-built plan: rows with <= kShortMax nnz are "group
+//     items" sorted by degree (longest first: LPT order, and the 4 rows sharing a wave
+//     have equal trip counts); longer rows are cut into wave items of <= kTaskNnz nnz whose
+//     partial sums are combined in a fixed order (bitwise reproducible, no float atomics).
+//   * the row softmax of the last GCN layer is fused into the store.
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "common.hpp"
+
+using namespace mmssl;
+
+namespace {
+
+int env_int(const char* name, int dflt) {
+  const char* s = getenv(name);
+  return (s && *s) ? atoi(s) : dflt;
+}
+int short_max() { static int v = std::max(1, env_int("MMSSL_PLAN_SHORT_MAX", 32)); return v; }
+int task_nnz() { static int v = std::max(short_max(), env_int("MMSSL_PLAN_TASK_NNZ", 128)); return v; }
+int plan_sort() { static int v = env_int("MMSSL_PLAN_SORT", 1); return v; }
+
+struct DirPlan {
+  int32_t rows = 0, cols = 0;
+  int64_t nnz = 0;
+  int32_t* rowptr = nullptr;  // [rows+1]   (device)
+  Edge* edges = nullptr;      // [nnz]
+  int4* gitems = nullptr;     // group items  {row, beg, end, -1}
+  int4* witems = nullptr;     // wave items   {row, beg, end, slot|-1}
+  int4* multi = nullptr;      // multi rows   {row, first_slot, n_slots, 0}
+  int64_t n_g = 0, n_w = 0, n_multi = 0, n_slots = 0;
+};
+
+void free_dir(DirPlan& p) {
+  if (p.rowptr) (void)hipFree(p.rowptr);
+  if (p.edges) (void)hipFree(p.edges);
+  if (p.gitems) (void)hipFree(p.gitems);
+  if (p.witems) (void)hipFree(p.witems);
+  if (p.multi) (void)hipFree(p.multi);
+  p = DirPlan();
+}
+
+template <typename T>
+int upload(T** dst, const T* src, size_t n) {
+  *dst = nullptr;
+  MMSSL_HIP_TRY(hipMalloc((void**)dst, std::max<size_t>(n, 1) * sizeof(T)));
+  if (n) MMSSL_HIP_TRY(hipMemcpy(*dst, src, n * sizeof(T), hipMemcpyHostToDevice));
+  return 0;
+}
+
+int build_dir(DirPlan& p, const int32_t* rowptr, const int32_t* col, const float* val, int32_t rows,
+              int32_t cols, int64_t nnz) {
+  p.rows = rows;
+  p.cols = cols;
+  p.nnz = nnz;
+  int64_t c[4];
+  int rc = mmssl_plan_count_host(rowptr, rows, c);
+  if (rc) return rc;
+  p.n_g = c[0]; p.n_w = c[1]; p.n_multi = c[2]; p.n_slots = c[3];
+  std::vector<int32_t> g((size_t)p.n_g * 4), w((size_t)p.n_w * 4), m((size_t)p.n_multi * 4);
+  rc = mmssl_plan_fill_host(rowptr, rows, g.data(), w.data(), m.data());
+  if (rc) return rc;
+  std::vector<Edge> e((size_t)nnz);
+  for (int64_t i = 0; i < nnz; ++i) { e[i].col = col[i]; e[i].val = val[i]; }
+  if ((rc = upload(&p.rowptr, rowptr, (size_t)rows + 1))) return rc;
+  if ((rc = upload(&p.edges, e.data(), (size_t)nnz))) return rc;
+  if ((rc = upload(&p.gitems, reinterpret_cast<const int4*>(g.data()), (size_t)p.n_g))) return rc;
+  if ((rc = upload(&p.witems, reinterpret_cast<const int4*>(w.data()), (size_t)p.n_w))) return rc;
+  if ((rc = upload(&p.multi, reinterpret_cast<const int4*>(m.data()), (size_t)p.n_multi))) return rc;
+  return 0;
+}
+
+}  // namespace
+
+struct mmssl_graph {
+  DirPlan fwd, bwd;
+};
+
+// ======================================================================================
+// host planning (pure CPU; exported for CPU-only tests)
+// ======================================================================================
+extern "C" int mmssl_csr_validate_host(const int32_t* rowptr, const int32_t* col, int32_t rows,
+                                       int32_t cols, int64_t nnz) {
+  if (rows < 0 || cols < 0 || nnz < 0 || !rowptr) return MMSSL_E_BADARG;
+  if (nnz > 0 && !col) return MMSSL_E_BADARG;
+  if (nnz > INT32_MAX) return MMSSL_E_UNSUPP;
+  if (rowptr[0] != 0 || rowptr[rows] != nnz) return MMSSL_E_BADARG;
+  for (int32_t r = 0; r < rows; ++r)
+    if (rowptr[r + 1] < rowptr[r]) return MMSSL_E_BADARG;
+  for (int64_t i = 0; i < nnz; ++i)
+    if (col[i] < 0 || col[i] >= cols) return MMSSL_E_BADARG;
+  return 0;
+}
+
+// Stable counting sort by column: within a transposed row, entries keep ascending source-row
+// order, so the backward's summation order is a pure function of the matrix.
+extern "C" int mmssl_csr_transpose_host(const int32_t* rowptr, const int32_t* col, const float* val,
+                                        int32_t rows, int32_t cols, int64_t nnz, int32_t* t_rowptr,
+                                        int32_t* t_col, float* t_val) {
+  if (!rowptr || !t_rowptr || (nnz > 0 && (!col || !val || !t_col || !t_val))) return MMSSL_E_BADARG;
+  std::fill(t_rowptr, t_rowptr + cols + 1, 0);
+  for (int64_t i = 0; i < nnz; ++i) t_rowptr[col[i] + 1]++;
+  for (int32_t c = 0; c < cols; ++c) t_rowptr[c + 1] += t_rowptr[c];
+  std::vector<int32_t> cur(t_rowptr, t_rowptr + cols);
+  for (int32_t r = 0; r < rows; ++r)
+    for (int32_t i = rowptr[r]; i < rowptr[r + 1]; ++i) {
+      const int32_t dst = cur[col[i]]++;
+      t_col[dst] = r;
+      t_val[dst] = val[i];
+    }
+  return 0;
+}
+
+extern "C" int mmssl_plan_count_host(const int32_t* rowptr, int32_t rows, int64_t counts[4]) {
+  if (!rowptr || !counts || rows < 0) return MMSSL_E_BADARG;
+  const int smax = short_max(), tn = task_nnz();
+  int64_t g = 0, w = 0, m = 0, s = 0;
+  for (int32_t r = 0; r < rows; ++r) {
+    const int64_t deg = rowptr[r + 1] - rowptr[r];
+    if (deg <= smax) {
+      ++g;
+    } else {
+      const int64_t t = (deg + tn - 1) / tn;
+      w += t;
+      if (t > 1) { ++m; s += t; }
+    }
+  }
+  counts[0] = g; counts[1] = w; counts[2] = m; counts[3] = s;
+  return 0;
+}
+
+extern "C" int mmssl_plan_fill_host(const int32_t* rowptr, int32_t rows, int32_t* gi, int32_t* wi,
+                                    int32_t* mi) {
+  if (!rowptr || rows < 0) return MMSSL_E_BADARG;
+  const int smax = short_max(), tn = task_nnz();
+  // group items: counting sort by degree, longest first (stable: ascending row id per degree)
+  std::vector<int64_t> start(smax + 2, 0);
+  if (plan_sort()) {
+    for (int32_t r = 0; r < rows; ++r) {
+      const int deg = rowptr[r + 1] - rowptr[r];
+      if (deg <= smax) start[smax - deg + 1]++;
+    }
+    for (int k = 0; k <= smax; ++k) start[k + 1] += start[k];
+  }
+  int64_t gseq = 0, w = 0, m = 0, slot = 0;
+  for (int32_t r = 0; r < rows; ++r) {
+    const int32_t beg = rowptr[r], end = rowptr[r + 1];
+    const int deg = end - beg;
+    if (deg <= smax) {
+      const int64_t pos = plan_sort() ? start[smax - deg]++ : gseq++;
+      int32_t* it = gi + pos * 4;
+      it[0] = r; it[1] = beg; it[2] = end; it[3] = -1;
+    } else {
+      const int32_t t = (deg + tn - 1) / tn;
+      if (t > 1) {
+        int32_t* mm = mi + m * 4;
+        mm[0] = r; mm[1] = (int32_t)slot; mm[2] = t; mm[3] = 0;
+        ++m;
+      }
+      for (int32_t k = 0; k < t; ++k) {
+        int32_t* it = wi + w * 4;
+        it[0] = r;
+        it[1] = beg + k * tn;
+        it[2] = std::min(end, beg + (k + 1) * tn);
+        it[3] = (t > 1) ? (int32_t)slot++ : -1;
+        ++w;
+      }
+    }
+  }
+  return 0;
+}
+
+// ======================================================================================
+// graph object
+// ======================================================================================
+extern "C" int mmssl_graph_create(const int32_t* rowptr, const int32_t* col, const float* val,
+                                  int32_t rows, int32_t cols, int64_t nnz, void* stream,
+                                  mmssl_graph** out) {
+  (void)stream;  // set-up is synchronous (hipMemcpy); the handle is usable on any stream afterwards
+  if (!out) return MMSSL_E_BADARG;
+  *out = nullptr;
+  int rc = mmssl_csr_validate_host(rowptr, col, rows, cols, nnz);
+  if (rc) return rc;
+  if (nnz > 0 && !val) return MMSSL_E_BADARG;
+  std::vector<int32_t> t_rowptr((size_t)cols + 1), t_col((size_t)nnz);
+  std::vector<float> t_val((size_t)nnz);
+  rc = mmssl_csr_transpose_host(rowptr, col, val, rows, cols, nnz, t_rowptr.data(), t_col.data(),
+                                t_val.data());
+  if (rc) return rc;
+  mmssl_graph* g = new (std::nothrow) mmssl_graph();
+  if (!g) return (int)hipErrorOutOfMemory;
+  rc = build_dir(g->fwd, rowptr, col, val, rows, cols, nnz);
+  if (!rc) rc = build_dir(g->bwd, t_rowptr.data(), t_col.data(), t_val.data(), cols, rows, nnz);
+  if (rc) {
+    free_dir(g->fwd);
+    free_dir(g->bwd);
+    delete g;
+    return rc;
+  }
+  *out = g;
+  return 0;
+}
+
+extern "C" int mmssl_graph_destroy(mmssl_graph* g) {
+  if (!g) return 0;
+  free_dir(g->fwd);
+  free_dir(g->bwd);
+  delete g;
+  return 0;
+}
+
+extern "C" int mmssl_graph_info(const mmssl_graph* g, int64_t info[16]) {
+  if (!g || !info) return MMSSL_E_BADARG;
+  std::memset(info, 0, 16 * sizeof(int64_t));
+  info[0] = g->fwd.rows; info[1] = g->fwd.cols; info[2] = g->fwd.nnz;
+  info[3] = g->fwd.n_g; info[4] = g->fwd.n_w; info[5] = g->fwd.n_multi; info[6] = g->fwd.n_slots;
+  info[8] = g->bwd.n_g; info[9] = g->bwd.n_w; info[10] = g->bwd.n_multi; info[11] = g->bwd.n_slots;
+  info[12] = short_max(); info[13] = task_nnz(); info[14] = plan_sort();
+  return 0;
+}
+
+extern "C" int mmssl_graph_export_transpose(const mmssl_graph* g, int32_t* t_rowptr, int32_t* t_col,
+                                            float* t_val, void* stream) {
+  if (!g || !t_rowptr) return MMSSL_E_BADARG;
+  MMSSL_HIP_TRY(hipStreamSynchronize(as_stream(stream)));
+  const DirPlan& p = g->bwd;
+  MMSSL_HIP_TRY(hipMemcpy(t_rowptr, p.rowptr, ((size_t)p.rows + 1) * sizeof(int32_t), hipMemcpyDeviceToHost));
+  if (p.nnz) {
+    if (!t_col || !t_val) return MMSSL_E_BADARG;
+    std::vector<Edge> e((size_t)p.nnz);
+    MMSSL_HIP_TRY(hipMemcpy(e.data(), p.edges, (size_t)p.nnz * sizeof(Edge), hipMemcpyDeviceToHost));
+    for (int64_t i = 0; i < p.nnz; ++i) { t_col[i] = e[i].col; t_val[i] = e[i].val; }
+  }
+  return 0;
+}
+
+// ======================================================================================
+// kernels
+// ======================================================================================
+namespace {
+
+// Accumulate sum_e val[e] * X[col[e], :] over edges [beg,end), visiting LPR-edge tiles
+// first_tile, first_tile+tile_stride, ...  One lane group (LPR lanes) per call; `lig` = lane in
+// group. Each lane holds 4 consecutive features (one float4).
+template <int LPR>
+__device__ __forceinline__ float4 gather_rows(const Edge* __restrict__ edges,
+                                              const float4* __restrict__ X, int beg, int end,
+                                              int first_tile, int tile_stride, int lig) {
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  const int n = end - beg;
+  for (int b0 = first_tile * LPR; b0 < n; b0 += tile_stride * LPR) {
+    const int e = b0 + lig;
+    Edge my;
+    my.col = -1;
+    my.val = 0.f;
+    if (e < n) my = edges[beg + e];            // coalesced: LPR consecutive 8-B pairs
+    // lanes past the end multiply the tile's FIRST column (one this row references anyway)
+    // by 0, so the 4-deep unrolled loop needs no per-load predicate.
+    const int pad = __shfl(my.col, 0, LPR);
+    if (my.col < 0) my.col = pad;
+    const int cnt = min(LPR, n - b0);
+    for (int k = 0; k < cnt; k += 4) {
+      const int c0 = __shfl(my.col, k + 0, LPR), c1 = __shfl(my.col, k + 1, LPR);
+      const int c2 = __shfl(my.col, k + 2, LPR), c3 = __shfl(my.col, k + 3, LPR);
+      const float v0 = __shfl(my.val, k + 0, LPR), v1 = __shfl(my.val, k + 1, LPR);
+      const float v2 = __shfl(my.val, k + 2, LPR), v3 = __shfl(my.val, k + 3, LPR);
+      const float4 x0 = X[(size_t)c0 * LPR + lig];
+      const float4 x1 = X[(size_t)c1 * LPR + lig];
+      const float4 x2 = X[(size_t)c2 * LPR + lig];
+      const float4 x3 = X[(size_t)c3 * LPR + lig];
+      acc = f4_fma(v0, x0, acc);
+      acc = f4_fma(v1, x1, acc);
+      acc = f4_fma(v2, x2, acc);
+      acc = f4_fma(v3, x3, acc);
+    }
+  }
+  return acc;
+}
+
+template <int LPR>
+__device__ __forceinline__ float4 row_softmax(float4 a) {
+  float m = fmaxf(fmaxf(a.x, a.y), fmaxf(a.z, a.w));
+  m = group_max<LPR>(m);
+  a.x = expf(a.x - m);
+  a.y = expf(a.y - m);
+  a.z = expf(a.z - m);
+  a.w = expf(a.w - m);
+  const float s = group_sum<LPR>((a.x + a.y) + (a.z + a.w));
+  a.x /= s;
+  a.y /= s;
+  a.z /= s;
+  a.w /= s;
+  return a;
+}
+
+// grid = n_wblocks (4 wave items each, heaviest first) + n_gblocks (256/LPR group items each)
+template <int LPR, int EPI>
+__global__ __launch_bounds__(kBlock) void spmm_kernel(const int4* __restrict__ gitems, int n_g,
+                                                      const int4* __restrict__ witems, int n_w,
+                                                      int n_wblocks, const Edge* __restrict__ edges,
+                                                      const float4* __restrict__ X,
+                                                      float4* __restrict__ Y,
+                                                      float4* __restrict__ partials) {
+  constexpr int GPW = kWave / LPR;   // lane groups per wave
+  constexpr int GPB = kBlock / LPR;  // lane groups per block
+  const int lane = threadIdx.x & 63;
+  const int lig = lane & (LPR - 1);
+  if ((int)blockIdx.x >= n_wblocks) {
+    const int gi = ((int)blockIdx.x - n_wblocks) * GPB + (int)threadIdx.x / LPR;
+    if (gi >= n_g) return;
+    const int4 it = gitems[gi];
+    float4 acc = gather_rows<LPR>(edges, X, it.y, it.z, 0, 1, lig);
+    if (EPI == MMSSL_EPI_SOFTMAX) acc = row_softmax<LPR>(acc);
+    Y[(size_t)it.x * LPR + lig] = acc;
+  } else {
+    const int wi = (int)blockIdx.x * 4 + ((int)threadIdx.x >> 6);
+    if (wi >= n_w) return;
+    const int4 it = witems[wi];
+    float4 acc = gather_rows<LPR>(edges, X, it.y, it.z, lane / LPR, GPW, lig);
+    acc.x = cross_group_sum<LPR>(acc.x);
+    acc.y = cross_group_sum<LPR>(acc.y);
+    acc.z = cross_group_sum<LPR>(acc.z);
+    acc.w = cross_group_sum<LPR>(acc.w);
+    if (it.w < 0) {
+      if (EPI == MMSSL_EPI_SOFTMAX) acc = row_softmax<LPR>(acc);
+      if (lane < LPR) Y[(size_t)it.x * LPR + lig] = acc;
+    } else if (lane < LPR) {
+      partials[(size_t)it.w * LPR + lig] = acc;
+    }
+  }
+}
+
+// second stage for rows cut into several wave items: fixed-order sum of their partial slots
+template <int LPR, int EPI>
+__global__ __launch_bounds__(kBlock) void spmm_multi_kernel(const int4* __restrict__ multi, int n_multi,
+                                                            const float4* __restrict__ partials,
+                                                            float4* __restrict__ Y) {
+  constexpr int GPB = kBlock / LPR;
+  const int lig = threadIdx.x & (LPR - 1);
+  const int mi = (int)blockIdx.x * GPB + (int)threadIdx.x / LPR;
+  if (mi >= n_multi) return;
+  const int4 it = multi[mi];
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int k = 0; k < it.z; ++k) {
+    const float4 p = partials[(size_t)(it.y + k) * LPR + lig];
+    acc.x += p.x;
+    acc.y += p.y;
+    acc.z += p.z;
+    acc.w += p.w;
+  }
+  if (EPI == MMSSL_EPI_SOFTMAX) acc = row_softmax<LPR>(acc);
+  Y[(size_t)it.x * LPR + lig] = acc;
+}
+
+template <int LPR, int EPI>
+int launch_spmm(const DirPlan& p, const float* X, float* Y, float* partials, hipStream_t s) {
+  constexpr int GPB = kBlock / LPR;
+  const int n_wblocks = (int)((p.n_w + 3) / 4);
+  const int n_gblocks = (int)((p.n_g + GPB - 1) / GPB);
+  if (n_wblocks + n_gblocks > 0) {
+    hipLaunchKernelGGL((spmm_kernel<LPR, EPI>), dim3(n_wblocks + n_gblocks), dim3(kBlock), 0, s,
+                       p.gitems, (int)p.n_g, p.witems, (int)p.n_w, n_wblocks, p.edges,
+                       reinterpret_cast<const float4*>(X), reinterpret_cast<float4*>(Y),
+                       reinterpret_cast<float4*>(partials));
+    MMSSL_LAUNCH_CHECK();
+  }
+  if (p.n_multi > 0) {
+    const int nb = (int)((p.n_multi + GPB - 1) / GPB);
+    hipLaunchKernelGGL((spmm_multi_kernel<LPR, EPI>), dim3(nb), dim3(kBlock), 0, s, p.multi,
+                       (int)p.n_multi, reinterpret_cast<const float4*>(partials),
+                       reinterpret_cast<float4*>(Y));
+    MMSSL_LAUNCH_CHECK();
+  }
+  return 0;
+}
+
+template <int LPR>
+int dispatch_epi(const DirPlan& p, const float* X, float* Y, float* partials, int epi, hipStream_t s) {
+  if (epi == MMSSL_EPI_NONE) return launch_spmm<LPR, MMSSL_EPI_NONE>(p, X, Y, partials, s);
+  if (epi == MMSSL_EPI_SOFTMAX) return launch_spmm<LPR, MMSSL_EPI_SOFTMAX>(p, X, Y, partials, s);
+  return MMSSL_E_BADARG;
+}
+
+}  // namespace
+
+extern "C" size_t mmssl_spmm_workspace_bytes(const mmssl_graph* g, int transpose, int d) {
+  if (!g || d <= 0) return 0;
+  const DirPlan& p = transpose ? g->bwd : g->fwd;
+  return (size_t)p.n_slots * (size_t)d * sizeof(float);
+}
+
+extern "C" int mmssl_spmm_f32(const mmssl_graph* g, int transpose, const float* X, int d, float* Y,
+                              int epilogue, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!g || !Y) return MMSSL_E_BADARG;
+  if (!supported_d(d)) return MMSSL_E_UNSUPP;
+  const DirPlan& p = transpose ? g->bwd : g->fwd;
+  if (p.rows == 0) return 0;
+  if (!X && p.nnz > 0) return MMSSL_E_BADARG;
+  if (((uintptr_t)X | (uintptr_t)Y | (uintptr_t)workspace) & 15) return MMSSL_E_BADARG;
+  const size_t need = (size_t)p.n_slots * (size_t)d * sizeof(float);
+  if (need > 0 && (!workspace || workspace_bytes < need)) return MMSSL_E_WORKSPACE;
+  hipStream_t s = as_stream(stream);
+  float* ws = reinterpret_cast<float*>(workspace);
+  switch (d) {
+    case 32: return dispatch_epi<8>(p, X, Y, ws, epilogue, s);
+    case 64: return dispatch_epi<16>(p, X, Y, ws, epilogue, s);
+    case 128: return dispatch_epi<32>(p, X, Y, ws, epilogue, s);
+    case 256: return dispatch_epi<64>(p, X, Y, ws, epilogue, s);
+  }
+  return MMSSL_E_UNSUPP;
+}

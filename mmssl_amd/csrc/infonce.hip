@@ -1,0 +1,433 @@
+// Fused InfoNCE (cross-modal contrastive) loss, forward + backward, for gfx950.
+// Replaces Trainer.sim + Trainer.batched_contrastive_loss
+// (/root/reference/MMSSL/main.py:211-249): ~12 small PyTorch launches per call and two
+// materialised n x n matrices become 3 (fwd) / 2 (bwd) launches with nothing n x n in memory.
+//
+//   n1 = z1/max(|z1|,eps), n2 = z2/max(|z2|,eps)
+//   r_ij = exp(n1_i.n1_j / tau), b_ij = exp(n1_i.n2_j / tau)
+//   D_i  = sum_{j!=i} r_ij + sum_j b_ij          (the reference adds r_ii then subtracts it)
+//   loss = mean_i -log(b_ii / D_i + 1e-8)
+//
+// Tiling: a 256-thread block owns a 32-row tile and walks 32-column tiles staged in LDS
+// (rows padded by 4 floats: ds_read_b128 conflict-free for d % 8 == 0). Dot tiles are plain
+// fp32 VALU FMAs (2x2 micro-tiles); the row log-sum-exp terms are reduced across the 16 lanes
+// that share a row with wavefront shuffles. Column ranges are split over blocks so that even
+// n = 1024 fills the chip; split partials are summed in a fixed order (deterministic).
+//
+// Backward (w_i = -(1/n) q_i/(q_i+1e-8), c_i = w_i/(D_i tau)):
+//   gn1_t = (w_t/tau) n2_t - sum_s c_t b_ts n2_s - sum_{s!=t} (c_t + c_s) r_ts n1_s
+//   gn2_t = (w_t/tau) n1_t - sum_s c_s b_st n1_s
+// followed by the F.normalize backward (incl. its g/eps branch for all-zero rows).
+#include "common.hpp"
+
+using namespace mmssl;
+
+namespace {
+
+constexpr int T = 32;        // tile edge (rows and columns)
+constexpr float kNormEps = 1e-12f;
+constexpr int CP = T + 4;    // padded row length of a coefficient tile
+
+__host__ __device__ inline int n_tiles(int64_t n) { return (int)((n + T - 1) / T); }
+
+// number of column splits: aim for >= ~512 blocks, at most one split per column tile
+inline int splits_for(int64_t n, int col_tiles) {
+  const int nt = n_tiles(n);
+  int cs = (512 + nt - 1) / nt;
+  if (cs > col_tiles) cs = col_tiles;
+  if (cs < 1) cs = 1;
+  return cs;
+}
+
+struct Layout {   // offsets in floats into the workspace
+  size_t n1, n2, inv1, inv2, pos, w, c, rows_part, loss, g1p, g2p, total;
+  int cs_f, cs_b;
+};
+
+inline Layout make_layout(int64_t n, int d) {
+  Layout L;
+  const int nt = n_tiles(n);
+  L.cs_f = splits_for(n, 2 * nt);   // forward walks 2*nt column tiles (n1 then n2)
+  L.cs_b = splits_for(n, nt);
+  size_t o = 0;
+  auto take = [&](size_t cnt) { size_t r = o; o += (cnt + 3) & ~(size_t)3; return r; };
+  L.n1 = take((size_t)n * d);
+  L.n2 = take((size_t)n * d);
+  L.inv1 = take(n); L.inv2 = take(n); L.pos = take(n); L.w = take(n); L.c = take(n);
+  L.rows_part = take((size_t)L.cs_f * n);
+  L.loss = take(4);
+  L.g1p = take((size_t)L.cs_b * n * d);
+  L.g2p = take((size_t)L.cs_b * n * d);
+  L.total = o;
+  return L;
+}
+
+// ---- prep: normalise both inputs, positive-pair cosine --------------------------------
+__global__ __launch_bounds__(kBlock) void prep_kernel(const float* __restrict__ z1,
+                                                      const float* __restrict__ z2, int64_t n, int d,
+                                                      float* __restrict__ n1, float* __restrict__ n2,
+                                                      float* __restrict__ inv1, float* __restrict__ inv2,
+                                                      float* __restrict__ pos) {
+  // one 16-lane group per row, lanes stride over the d/4 float4 chunks
+  const int lig = threadIdx.x & 15;
+  const int64_t r = (int64_t)blockIdx.x * (kBlock / 16) + threadIdx.x / 16;
+  if (r >= n) return;
+  const int nch = d >> 2;
+  const float4* a = reinterpret_cast<const float4*>(z1 + r * d);
+  const float4* b = reinterpret_cast<const float4*>(z2 + r * d);
+  float s1 = 0.f, s2 = 0.f, s12 = 0.f;
+  for (int k = lig; k < nch; k += 16) {
+    const float4 x = a[k], y = b[k];
+    s1 += f4_dot(x, x);
+    s2 += f4_dot(y, y);
+    s12 += f4_dot(x, y);
+  }
+  s1 = group_sum<16>(s1);
+  s2 = group_sum<16>(s2);
+  s12 = group_sum<16>(s12);
+  const float i1 = 1.f / fmaxf(sqrtf(s1), kNormEps);
+  const float i2 = 1.f / fmaxf(sqrtf(s2), kNormEps);
+  float4* o1 = reinterpret_cast<float4*>(n1 + r * d);
+  float4* o2 = reinterpret_cast<float4*>(n2 + r * d);
+  float p = 0.f;
+  for (int k = lig; k < nch; k += 16) {
+    float4 x = a[k], y = b[k];
+    x.x *= i1; x.y *= i1; x.z *= i1; x.w *= i1;
+    y.x *= i2; y.y *= i2; y.z *= i2; y.w *= i2;
+    o1[k] = x;
+    o2[k] = y;
+    p += f4_dot(x, y);
+  }
+  p = group_sum<16>(p);
+  if (lig == 0) {
+    inv1[r] = i1;
+    inv2[r] = i2;
+    pos[r] = p;
+  }
+}
+
+// stage a T x D tile (rows row0.., zero-filled past n) into LDS with row stride D+4
+template <int D>
+__device__ __forceinline__ void stage_tile(float* __restrict__ lds, const float* __restrict__ src,
+                                           int64_t row0, int64_t n) {
+  constexpr int S = D + 4;
+  constexpr int CH = D / 4;                 // float4 chunks per row
+  for (int idx = threadIdx.x; idx < T * CH; idx += kBlock) {
+    const int r = idx / CH, k = idx - r * CH;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (row0 + r < n) v = reinterpret_cast<const float4*>(src + (row0 + r) * D)[k];
+    *reinterpret_cast<float4*>(lds + r * S + k * 4) = v;
+  }
+}
+
+// 2x2 micro-tile of dot products: rows {ty, ty+16} of A x rows {tx, tx+16} of B
+template <int D>
+__device__ __forceinline__ void dot_2x2(const float* __restrict__ A, const float* __restrict__ B, int ty,
+                                        int tx, float (&o)[4]) {
+  constexpr int S = D + 4;
+  o[0] = o[1] = o[2] = o[3] = 0.f;
+#pragma unroll 4
+  for (int k = 0; k < D; k += 4) {
+    const float4 a0 = *reinterpret_cast<const float4*>(A + ty * S + k);
+    const float4 a1 = *reinterpret_cast<const float4*>(A + (ty + 16) * S + k);
+    const float4 b0 = *reinterpret_cast<const float4*>(B + tx * S + k);
+    const float4 b1 = *reinterpret_cast<const float4*>(B + (tx + 16) * S + k);
+    o[0] += f4_dot(a0, b0);
+    o[1] += f4_dot(a0, b1);
+    o[2] += f4_dot(a1, b0);
+    o[3] += f4_dot(a1, b1);
+  }
+}
+
+// ---- forward: partial denominators per (row, column split) ------------------------------
+template <int D>
+__global__ __launch_bounds__(kBlock) void fwd_tiles_kernel(const float* __restrict__ n1,
+                                                           const float* __restrict__ n2, int64_t n,
+                                                           float tau, int cs,
+                                                           float* __restrict__ rows_part) {
+  constexpr int S = D + 4;
+  __shared__ __attribute__((aligned(16))) float A[T * S];
+  __shared__ __attribute__((aligned(16))) float B[T * S];
+  const int nt = n_tiles(n);
+  const int ti = blockIdx.x % nt;
+  const int split = blockIdx.x / nt;
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const int64_t i0 = (int64_t)ti * T;
+  stage_tile<D>(A, n1, i0, n);
+  // column tiles 0..nt-1 come from n1 (reflexive), nt..2nt-1 from n2 (between)
+  const int per = (2 * nt + cs - 1) / cs;
+  const int c_beg = split * per, c_end = min(2 * nt, c_beg + per);
+  float acc0 = 0.f, acc1 = 0.f;     // rows ty and ty+16
+  const int64_t gi0 = i0 + ty, gi1 = i0 + ty + 16;
+  for (int ct = c_beg; ct < c_end; ++ct) {
+    const bool refl = ct < nt;
+    const int64_t j0 = (int64_t)(refl ? ct : ct - nt) * T;
+    __syncthreads();                 // A staged / previous B fully consumed
+    stage_tile<D>(B, refl ? n1 : n2, j0, n);
+    __syncthreads();
+    float dts[4];
+    dot_2x2<D>(A, B, ty, tx, dts);
+    const int64_t gj0 = j0 + tx, gj1 = j0 + tx + 16;
+    const float e00 = (gj0 < n && !(refl && gj0 == gi0)) ? expf(dts[0] / tau) : 0.f;
+    const float e01 = (gj1 < n && !(refl && gj1 == gi0)) ? expf(dts[1] / tau) : 0.f;
+    const float e10 = (gj0 < n && !(refl && gj0 == gi1)) ? expf(dts[2] / tau) : 0.f;
+    const float e11 = (gj1 < n && !(refl && gj1 == gi1)) ? expf(dts[3] / tau) : 0.f;
+    acc0 += e00 + e01;
+    acc1 += e10 + e11;
+  }
+  acc0 = group_sum<16>(acc0);        // the 16 lanes (tx) that share row ty
+  acc1 = group_sum<16>(acc1);
+  if (tx == 0) {
+    if (gi0 < n) rows_part[(size_t)split * n + gi0] = acc0;
+    if (gi1 < n) rows_part[(size_t)split * n + gi1] = acc1;
+  }
+}
+
+// ---- finalize: loss + per-row backward coefficients -----------------------------------------
+__global__ __launch_bounds__(kBlock) void finalize_kernel(const float* __restrict__ rows_part, int cs,
+                                                          const float* __restrict__ pos, int64_t n,
+                                                          float tau, float* __restrict__ w,
+                                                          float* __restrict__ c, float* __restrict__ loss) {
+  __shared__ float red[4];
+  float acc = 0.f;
+  for (int64_t i = threadIdx.x; i < n; i += kBlock) {
+    float Dn = 0.f;
+    for (int s = 0; s < cs; ++s) Dn += rows_part[(size_t)s * n + i];
+    const float q = expf(pos[i] / tau) / Dn;
+    acc += -logf(q + 1e-8f);
+    const float wi = -(q / (q + 1e-8f)) / (float)n;
+    w[i] = wi;
+    c[i] = wi / (Dn * tau);
+  }
+  const float t = block_sum_256(acc, red);
+  if (threadIdx.x == 0) loss[0] = t / (float)n;
+}
+
+// ---- backward tiles --------------------------------------------------------------------------
+template <int D>
+__global__ __launch_bounds__(kBlock) void bwd_tiles_kernel(const float* __restrict__ n1,
+                                                           const float* __restrict__ n2,
+                                                           const float* __restrict__ c, int64_t n,
+                                                           float tau, int cs, float* __restrict__ g1p,
+                                                           float* __restrict__ g2p) {
+  constexpr int S = D + 4;
+  constexpr int FPT = D / 16;        // output features per thread in the accumulate phase
+  __shared__ __attribute__((aligned(16))) float A1[T * S];
+  __shared__ __attribute__((aligned(16))) float A2[T * S];
+  __shared__ __attribute__((aligned(16))) float B1[T * S];
+  __shared__ __attribute__((aligned(16))) float B2[T * S];
+  __shared__ __attribute__((aligned(16))) float C1[T * CP];
+  __shared__ __attribute__((aligned(16))) float C2[T * CP];
+  __shared__ __attribute__((aligned(16))) float C3[T * CP];
+  const int nt = n_tiles(n);
+  const int tt = blockIdx.x % nt;
+  const int split = blockIdx.x / nt;
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const int64_t t0 = (int64_t)tt * T;
+  stage_tile<D>(A1, n1, t0, n);
+  stage_tile<D>(A2, n2, t0, n);
+  const int64_t gt0 = t0 + ty, gt1 = t0 + ty + 16;
+  const float ct0 = gt0 < n ? c[gt0] : 0.f;
+  const float ct1 = gt1 < n ? c[gt1] : 0.f;
+  float g1[2][FPT], g2[2][FPT];
+#pragma unroll
+  for (int f = 0; f < FPT; ++f) g1[0][f] = g1[1][f] = g2[0][f] = g2[1][f] = 0.f;
+  const int per = (nt + cs - 1) / cs;
+  const int s_beg = split * per, s_end = min(nt, s_beg + per);
+  for (int st = s_beg; st < s_end; ++st) {
+    const int64_t s0 = (int64_t)st * T;
+    __syncthreads();                 // previous tile's B*/C* fully consumed (and A* staged)
+    stage_tile<D>(B1, n1, s0, n);
+    stage_tile<D>(B2, n2, s0, n);
+    __syncthreads();
+    float s11[4], s12[4], s21[4];
+    dot_2x2<D>(A1, B1, ty, tx, s11);   // n1_t . n1_s
+    dot_2x2<D>(A1, B2, ty, tx, s12);   // n1_t . n2_s
+    dot_2x2<D>(A2, B1, ty, tx, s21);   // n2_t . n1_s
+    const int64_t gs0 = s0 + tx, gs1 = s0 + tx + 16;
+    const float cs0 = gs0 < n ? c[gs0] : 0.f;
+    const float cs1 = gs1 < n ? c[gs1] : 0.f;
+    // micro-tile order: [0]=(t0,s0) [1]=(t0,s1) [2]=(t1,s0) [3]=(t1,s1)
+    const bool v00 = gt0 < n && gs0 < n, v01 = gt0 < n && gs1 < n;
+    const bool v10 = gt1 < n && gs0 < n, v11 = gt1 < n && gs1 < n;
+    C1[ty * CP + tx] = v00 ? -ct0 * expf(s12[0] / tau) : 0.f;
+    C1[ty * CP + tx + 16] = v01 ? -ct0 * expf(s12[1] / tau) : 0.f;
+    C1[(ty + 16) * CP + tx] = v10 ? -ct1 * expf(s12[2] / tau) : 0.f;
+    C1[(ty + 16) * CP + tx + 16] = v11 ? -ct1 * expf(s12[3] / tau) : 0.f;
+    C2[ty * CP + tx] = (v00 && gt0 != gs0) ? -(ct0 + cs0) * expf(s11[0] / tau) : 0.f;
+    C2[ty * CP + tx + 16] = (v01 && gt0 != gs1) ? -(ct0 + cs1) * expf(s11[1] / tau) : 0.f;
+    C2[(ty + 16) * CP + tx] = (v10 && gt1 != gs0) ? -(ct1 + cs0) * expf(s11[2] / tau) : 0.f;
+    C2[(ty + 16) * CP + tx + 16] = (v11 && gt1 != gs1) ? -(ct1 + cs1) * expf(s11[3] / tau) : 0.f;
+    C3[ty * CP + tx] = v00 ? -cs0 * expf(s21[0] / tau) : 0.f;
+    C3[ty * CP + tx + 16] = v01 ? -cs1 * expf(s21[1] / tau) : 0.f;
+    C3[(ty + 16) * CP + tx] = v10 ? -cs0 * expf(s21[2] / tau) : 0.f;
+    C3[(ty + 16) * CP + tx + 16] = v11 ? -cs1 * expf(s21[3] / tau) : 0.f;
+    __syncthreads();
+    // accumulate: rows {ty, ty+16}, features [tx*FPT, tx*FPT+FPT)
+    //   g1[r] += C1[r][s]*n2_s + C2[r][s]*n1_s ;  g2[r] += C3[r][s]*n1_s
+#pragma unroll 2
+    for (int s = 0; s < T; s += 4) {
+      const float4 p0 = *reinterpret_cast<const float4*>(C1 + ty * CP + s);
+      const float4 p1 = *reinterpret_cast<const float4*>(C1 + (ty + 16) * CP + s);
+      const float4 q0 = *reinterpret_cast<const float4*>(C2 + ty * CP + s);
+      const float4 q1 = *reinterpret_cast<const float4*>(C2 + (ty + 16) * CP + s);
+      const float4 r0 = *reinterpret_cast<const float4*>(C3 + ty * CP + s);
+      const float4 r1 = *reinterpret_cast<const float4*>(C3 + (ty + 16) * CP + s);
+      const float pc0[4] = {p0.x, p0.y, p0.z, p0.w}, pc1[4] = {p1.x, p1.y, p1.z, p1.w};
+      const float qc0[4] = {q0.x, q0.y, q0.z, q0.w}, qc1[4] = {q1.x, q1.y, q1.z, q1.w};
+      const float rc0[4] = {r0.x, r0.y, r0.z, r0.w}, rc1[4] = {r1.x, r1.y, r1.z, r1.w};
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float* b1 = B1 + (s + u) * S + tx * FPT;
+        const float* b2 = B2 + (s + u) * S + tx * FPT;
+#pragma unroll
+        for (int f = 0; f < FPT; ++f) {
+          const float x1 = b1[f], x2 = b2[f];
+          g1[0][f] = fmaf(pc0[u], x2, fmaf(qc0[u], x1, g1[0][f]));
+          g1[1][f] = fmaf(pc1[u], x2, fmaf(qc1[u], x1, g1[1][f]));
+          g2[0][f] = fmaf(rc0[u], x1, g2[0][f]);
+          g2[1][f] = fmaf(rc1[u], x1, g2[1][f]);
+        }
+      }
+    }
+  }
+  const size_t base = (size_t)split * n * D;
+  if (gt0 < n) {
+#pragma unroll
+    for (int f = 0; f < FPT; ++f) {
+      g1p[base + gt0 * D + tx * FPT + f] = g1[0][f];
+      g2p[base + gt0 * D + tx * FPT + f] = g2[0][f];
+    }
+  }
+  if (gt1 < n) {
+#pragma unroll
+    for (int f = 0; f < FPT; ++f) {
+      g1p[base + gt1 * D + tx * FPT + f] = g1[1][f];
+      g2p[base + gt1 * D + tx * FPT + f] = g2[1][f];
+    }
+  }
+}
+
+// ---- backward finish: sum splits, diagonal terms, normalise-backward, scale by gloss ----------
+//   z -> nrm = z*inv: gz = inv*(gn - nrm*(nrm.gn))  if |z| >= eps, else gn/eps
+__global__ __launch_bounds__(kBlock) void bwd_finish_kernel(const float* __restrict__ z1,
+                                                            const float* __restrict__ z2,
+                                                            const float* __restrict__ n1,
+                                                            const float* __restrict__ n2,
+                                                            const float* __restrict__ inv1,
+                                                            const float* __restrict__ inv2,
+                                                            const float* __restrict__ w,
+                                                            const float* __restrict__ g1p,
+                                                            const float* __restrict__ g2p, int cs,
+                                                            int64_t n, int d, float tau,
+                                                            const float* __restrict__ gloss,
+                                                            float* __restrict__ gz1,
+                                                            float* __restrict__ gz2) {
+  const int lig = threadIdx.x & 15;
+  const int64_t r = (int64_t)blockIdx.x * (kBlock / 16) + threadIdx.x / 16;
+  if (r >= n) return;
+  const float gl = gloss[0];
+  const float wt = w[r] / tau;
+  const int nch = d >> 2;
+  // pass 1: gn (kept in the output buffers) and the two projections nrm.gn
+  float p1 = 0.f, p2 = 0.f;
+  for (int k = lig; k < nch; k += 16) {
+    const float4 a = reinterpret_cast<const float4*>(n1 + r * d)[k];
+    const float4 b = reinterpret_cast<const float4*>(n2 + r * d)[k];
+    float4 u = make_float4(wt * b.x, wt * b.y, wt * b.z, wt * b.w);
+    float4 v = make_float4(wt * a.x, wt * a.y, wt * a.z, wt * a.w);
+    for (int s = 0; s < cs; ++s) {
+      const float4 x = reinterpret_cast<const float4*>(g1p + ((size_t)s * n + r) * d)[k];
+      const float4 y = reinterpret_cast<const float4*>(g2p + ((size_t)s * n + r) * d)[k];
+      u.x += x.x; u.y += x.y; u.z += x.z; u.w += x.w;
+      v.x += y.x; v.y += y.y; v.z += y.z; v.w += y.w;
+    }
+    reinterpret_cast<float4*>(gz1 + r * d)[k] = u;
+    reinterpret_cast<float4*>(gz2 + r * d)[k] = v;
+    p1 += f4_dot(a, u);
+    p2 += f4_dot(b, v);
+  }
+  p1 = group_sum<16>(p1);
+  p2 = group_sum<16>(p2);
+  const float i1 = inv1[r], i2 = inv2[r];
+  // inv == 1/eps exactly when the row norm was clamped (|z| < eps): no projection term then
+  const bool clamp1 = i1 >= 1.f / kNormEps, clamp2 = i2 >= 1.f / kNormEps;
+  for (int k = lig; k < nch; k += 16) {
+    const float4 a = reinterpret_cast<const float4*>(n1 + r * d)[k];
+    const float4 b = reinterpret_cast<const float4*>(n2 + r * d)[k];
+    float4 u = reinterpret_cast<float4*>(gz1 + r * d)[k];
+    float4 v = reinterpret_cast<float4*>(gz2 + r * d)[k];
+    const float q1 = clamp1 ? 0.f : p1, q2 = clamp2 ? 0.f : p2;
+    const float m1 = gl * i1, m2 = gl * i2;
+    u = make_float4(m1 * (u.x - a.x * q1), m1 * (u.y - a.y * q1), m1 * (u.z - a.z * q1), m1 * (u.w - a.w * q1));
+    v = make_float4(m2 * (v.x - b.x * q2), m2 * (v.y - b.y * q2), m2 * (v.z - b.z * q2), m2 * (v.w - b.w * q2));
+    reinterpret_cast<float4*>(gz1 + r * d)[k] = u;
+    reinterpret_cast<float4*>(gz2 + r * d)[k] = v;
+  }
+  (void)z1;
+  (void)z2;
+}
+
+inline bool infonce_d_ok(int d) { return d == 32 || d == 64 || d == 128 || d == 256; }
+
+}  // namespace
+
+extern "C" size_t mmssl_infonce_workspace_bytes(int64_t n, int d) {
+  if (n <= 0 || !infonce_d_ok(d)) return 0;
+  return make_layout(n, d).total * sizeof(float);
+}
+
+extern "C" int mmssl_infonce_fwd_f32(const float* z1, const float* z2, int64_t n, int d, float tau,
+                                     float* loss, void* workspace, size_t workspace_bytes, void* stream) {
+  if (n <= 0 || !z1 || !z2 || !loss || !(tau > 0.f)) return MMSSL_E_BADARG;
+  if (!infonce_d_ok(d)) return MMSSL_E_UNSUPP;
+  const Layout L = make_layout(n, d);
+  if (!workspace || workspace_bytes < L.total * sizeof(float)) return MMSSL_E_WORKSPACE;
+  if (((uintptr_t)z1 | (uintptr_t)z2 | (uintptr_t)workspace) & 15) return MMSSL_E_BADARG;
+  float* ws = reinterpret_cast<float*>(workspace);
+  hipStream_t s = as_stream(stream);
+  const int nt = n_tiles(n);
+  const int rb = (int)((n + 15) / 16);
+  hipLaunchKernelGGL(prep_kernel, dim3(rb), dim3(kBlock), 0, s, z1, z2, n, d, ws + L.n1, ws + L.n2,
+                     ws + L.inv1, ws + L.inv2, ws + L.pos);
+  MMSSL_LAUNCH_CHECK();
+  const dim3 grid(nt * L.cs_f);
+  switch (d) {
+    case 32: hipLaunchKernelGGL((fwd_tiles_kernel<32>), grid, dim3(kBlock), 0, s, ws + L.n1, ws + L.n2, n, tau, L.cs_f, ws + L.rows_part); break;
+    case 64: hipLaunchKernelGGL((fwd_tiles_kernel<64>), grid, dim3(kBlock), 0, s, ws + L.n1, ws + L.n2, n, tau, L.cs_f, ws + L.rows_part); break;
+    case 128: hipLaunchKernelGGL((fwd_tiles_kernel<128>), grid, dim3(kBlock), 0, s, ws + L.n1, ws + L.n2, n, tau, L.cs_f, ws + L.rows_part); break;
+    case 256: hipLaunchKernelGGL((fwd_tiles_kernel<256>), grid, dim3(kBlock), 0, s, ws + L.n1, ws + L.n2, n, tau, L.cs_f, ws + L.rows_part); break;
+  }
+  MMSSL_LAUNCH_CHECK();
+  hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(kBlock), 0, s, ws + L.rows_part, L.cs_f, ws + L.pos, n, tau,
+                     ws + L.w, ws + L.c, loss);
+  MMSSL_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int mmssl_infonce_bwd_f32(const float* z1, const float* z2, int64_t n, int d, float tau,
+                                     const float* gloss, float* gz1, float* gz2, void* workspace,
+                                     size_t workspace_bytes, void* stream) {
+  if (n <= 0 || !z1 || !z2 || !gloss || !gz1 || !gz2 || !(tau > 0.f)) return MMSSL_E_BADARG;
+  if (!infonce_d_ok(d)) return MMSSL_E_UNSUPP;
+  const Layout L = make_layout(n, d);
+  if (!workspace || workspace_bytes < L.total * sizeof(float)) return MMSSL_E_WORKSPACE;
+  if (((uintptr_t)gz1 | (uintptr_t)gz2 | (uintptr_t)workspace) & 15) return MMSSL_E_BADARG;
+  float* ws = reinterpret_cast<float*>(workspace);
+  hipStream_t s = as_stream(stream);
+  const int nt = n_tiles(n);
+  const dim3 grid(nt * L.cs_b);
+  switch (d) {
+    case 32: hipLaunchKernelGGL((bwd_tiles_kernel<32>), grid, dim3(kBlock), 0, s, ws + L.n1, ws + L.n2, ws + L.c, n, tau, L.cs_b, ws + L.g1p, ws + L.g2p); break;
+    case 64: hipLaunchKernelGGL((bwd_tiles_kernel<64>), grid, dim3(kBlock), 0, s, ws + L.n1, ws + L.n2, ws + L.c, n, tau, L.cs_b, ws + L.g1p, ws + L.g2p); break;
+    case 128: hipLaunchKernelGGL((bwd_tiles_kernel<128>), grid, dim3(kBlock), 0, s, ws + L.n1, ws + L.n2, ws + L.c, n, tau, L.cs_b, ws + L.g1p, ws + L.g2p); break;
+    case 256: hipLaunchKernelGGL((bwd_tiles_kernel<256>), grid, dim3(kBlock), 0, s, ws + L.n1, ws + L.n2, ws + L.c, n, tau, L.cs_b, ws + L.g1p, ws + L.g2p); break;
+  }
+  MMSSL_LAUNCH_CHECK();
+  const int rb = (int)((n + 15) / 16);
+  hipLaunchKernelGGL(bwd_finish_kernel, dim3(rb), dim3(kBlock), 0, s, z1, z2, ws + L.n1, ws + L.n2,
+                     ws + L.inv1, ws + L.inv2, ws + L.w, ws + L.g1p, ws + L.g2p, L.cs_b, n, d, tau, gloss,
+                     gz1, gz2);
+  MMSSL_LAUNCH_CHECK();
+  return 0;
+}

@@ -1,0 +1,297 @@
+// Modality projection GEMM on the fp32 matrix cores of gfx950 (v_mfma_f32_32x32x2_f32:
+// exact fp32, 157 TF peak = the only MFMA use on this path; everything else is HBM-bound).
+// Replaces nn.Linear image_trans / text_trans + nn.Dropout and their autograd
+// (/root/reference/MMSSL/Models.py:28-29, 54, 173-174).
+//
+//   forward : Y[M,N]  = dropout(F[M,K] . W[N,K]^T + b)          (F streamed once from HBM)
+//   wgrad   : gW[N,K] = gY[M,N]^T . F[M,K],  gb[N] = colsum(gY)
+//
+// One kernel body: a 256-thread block (2x2 waves, one 32x32 MFMA accumulator each) owns a
+// 64x64 output tile and walks its reduction range in 32-deep slices. Operand slices are
+// fetched global->registers one slice ahead (full 128-B row segments), written to a
+// double-buffered k-major LDS image (row stride 65 floats: conflict-free ds_write_b32 of the
+// transposed slice and conflict-free ds_read_b32 of the MFMA fragments), one barrier per
+// slice. The reduction dimension is split over blockIdx.z so that >= ~4 blocks per CU exist
+// even for M = 18K; split partials are summed in a fixed order by a small epilogue kernel
+// that also applies bias + dropout (deterministic, no float atomics).
+#include "common.hpp"
+
+using namespace mmssl;
+
+namespace {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+constexpr int BT = 64;    // output tile edge
+constexpr int BK = 32;    // reduction slice
+constexpr int LD = 65;    // LDS row stride (floats)
+
+// DIRECT = false: operands are row-major [i][kk] (forward: F[M,K], W[N,K]) -> transposed into LDS
+// DIRECT = true : operands are row-major [kk][i] (wgrad: gY[M,N], F[M,K])  -> copied as is
+template <bool DIRECT>
+__device__ __forceinline__ void fetch_slice(const float* __restrict__ P, int64_t ld, int64_t i0, int64_t I,
+                                            int64_t kk0, int64_t kk_end, float4 (&r)[2]) {
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    r[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (!DIRECT) {
+      const int64_t i = i0 + (tid >> 3) + 32 * p;
+      const int64_t kk = kk0 + 4 * (tid & 7);
+      if (i < I && kk < kk_end) r[p] = *reinterpret_cast<const float4*>(P + i * ld + kk);
+    } else {
+      const int64_t kk = kk0 + (tid >> 4) + 16 * p;
+      const int64_t i = i0 + 4 * (tid & 15);
+      if (kk < kk_end && i < I) r[p] = *reinterpret_cast<const float4*>(P + kk * ld + i);
+    }
+  }
+}
+
+template <bool DIRECT>
+__device__ __forceinline__ void store_slice(float* __restrict__ S, const float4 (&r)[2]) {
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    if (!DIRECT) {
+      const int i = (tid >> 3) + 32 * p, k = 4 * (tid & 7);
+      S[(k + 0) * LD + i] = r[p].x;
+      S[(k + 1) * LD + i] = r[p].y;
+      S[(k + 2) * LD + i] = r[p].z;
+      S[(k + 3) * LD + i] = r[p].w;
+    } else {
+      const int k = (tid >> 4) + 16 * p, i = 4 * (tid & 15);
+      S[k * LD + i + 0] = r[p].x;
+      S[k * LD + i + 1] = r[p].y;
+      S[k * LD + i + 2] = r[p].z;
+      S[k * LD + i + 3] = r[p].w;
+    }
+  }
+}
+
+// C[split][i][j] (+)= sum_{kk in split} A(i,kk) * B(j,kk)
+template <bool DIRECT>
+__global__ __launch_bounds__(kBlock) void gemm64_kernel(const float* __restrict__ A, int64_t lda,
+                                                        const float* __restrict__ B, int64_t ldb, int64_t I,
+                                                        int64_t J, int64_t KK, int64_t kk_chunk,
+                                                        float* __restrict__ C, int64_t ldc,
+                                                        int64_t split_stride, const float* __restrict__ bias,
+                                                        const uint8_t* __restrict__ keep, float scale) {
+  __shared__ float As[2][BK * LD];
+  __shared__ float Bs[2][BK * LD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int64_t i0 = (int64_t)blockIdx.x * BT, j0 = (int64_t)blockIdx.y * BT;
+  const int64_t kk_beg = (int64_t)blockIdx.z * kk_chunk;
+  const int64_t kk_end = min(KK, kk_beg + kk_chunk);
+  const int nk = (int)((kk_end - kk_beg + BK - 1) / BK);
+  floatx16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  float4 ra[2], rb[2];
+  if (nk > 0) {
+    fetch_slice<DIRECT>(A, lda, i0, I, kk_beg, kk_end, ra);
+    fetch_slice<DIRECT>(B, ldb, j0, J, kk_beg, kk_end, rb);
+    store_slice<DIRECT>(As[0], ra);
+    store_slice<DIRECT>(Bs[0], rb);
+  }
+  __syncthreads();
+  const int frag = (lane >> 5) * LD + (lane & 31);
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) {   // next slice: global -> registers while this slice computes
+      fetch_slice<DIRECT>(A, lda, i0, I, kk_beg + (int64_t)(kt + 1) * BK, kk_end, ra);
+      fetch_slice<DIRECT>(B, ldb, j0, J, kk_beg + (int64_t)(kt + 1) * BK, kk_end, rb);
+    }
+    const float* as = As[buf] + frag + wm * 32;
+    const float* bs = Bs[buf] + frag + wn * 32;
+#pragma unroll
+    for (int s = 0; s < BK / 2; ++s) {
+      const float a = as[2 * s * LD];
+      const float b = bs[2 * s * LD];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+    }
+    if (kt + 1 < nk) {
+      store_slice<DIRECT>(As[buf ^ 1], ra);
+      store_slice<DIRECT>(Bs[buf ^ 1], rb);
+    }
+    __syncthreads();
+  }
+  // C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  const int64_t col = j0 + wn * 32 + (lane & 31);
+  float* Cp = C + (int64_t)blockIdx.z * split_stride;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int64_t row = i0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+    if (row < I && col < J) {
+      float v = acc[r];
+      if (bias) v += bias[col];
+      if (keep) v = keep[row * J + col] ? v * scale : 0.f;
+      Cp[row * ldc + col] = v;
+    }
+  }
+}
+
+// out[e] = epilogue(sum_s P[s][e]);  e = row*J + col
+__global__ __launch_bounds__(kBlock) void splitk_reduce_kernel(const float* __restrict__ P, int splits,
+                                                               int64_t total, int64_t J,
+                                                               const float* __restrict__ bias,
+                                                               const uint8_t* __restrict__ keep, float scale,
+                                                               float* __restrict__ out) {
+  const int64_t n4 = total >> 2;   // J % 4 == 0 -> total % 4 == 0
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n4; i += (int64_t)gridDim.x * kBlock) {
+    float4 v = reinterpret_cast<const float4*>(P)[i];
+    for (int s = 1; s < splits; ++s) {
+      const float4 x = reinterpret_cast<const float4*>(P + (int64_t)s * total)[i];
+      v.x += x.x; v.y += x.y; v.z += x.z; v.w += x.w;
+    }
+    const int64_t e = i << 2;
+    if (bias) {
+      const int64_t c = e % J;
+      v.x += bias[c]; v.y += bias[c + 1]; v.z += bias[c + 2]; v.w += bias[c + 3];
+    }
+    if (keep) {
+      const uchar4 k = reinterpret_cast<const uchar4*>(keep)[i];
+      v.x = k.x ? v.x * scale : 0.f;
+      v.y = k.y ? v.y * scale : 0.f;
+      v.z = k.z ? v.z * scale : 0.f;
+      v.w = k.w ? v.w * scale : 0.f;
+    }
+    reinterpret_cast<float4*>(out)[i] = v;
+  }
+}
+
+// column sums of G[M,N] (N <= 256): stage 1 -> part[blocks][N], stage 2 -> out[N]
+constexpr int kColsumBlocks = 256;
+__global__ __launch_bounds__(kBlock) void colsum_stage1(const float* __restrict__ G, int64_t M, int N,
+                                                        float* __restrict__ part) {
+  // thread t owns column t % N for rows (t / N) + k * (256 / N) of this block's row range
+  __shared__ float red[kBlock];
+  const int rows_per_pass = kBlock / N;
+  const int c = threadIdx.x % N, rr = threadIdx.x / N;
+  float acc = 0.f;
+  if (rr < rows_per_pass)
+    for (int64_t m = (int64_t)blockIdx.x * rows_per_pass + rr; m < M; m += (int64_t)gridDim.x * rows_per_pass)
+      acc += G[m * N + c];
+  red[threadIdx.x] = (rr < rows_per_pass) ? acc : 0.f;
+  __syncthreads();
+  if (threadIdx.x < N) {
+    float s = 0.f;
+    for (int r = 0; r < rows_per_pass; ++r) s += red[r * N + threadIdx.x];
+    part[(int64_t)blockIdx.x * N + threadIdx.x] = s;
+  }
+}
+__global__ __launch_bounds__(kBlock) void colsum_stage2(const float* __restrict__ part, int nparts, int N,
+                                                        float* __restrict__ out) {
+  const int c = threadIdx.x;
+  if (c >= N) return;
+  float s = 0.f;
+  for (int p = 0; p < nparts; ++p) s += part[(int64_t)p * N + c];
+  out[c] = s;
+}
+
+// split count: aim for >= ~4 blocks per CU, every split at least 4 slices deep
+inline int choose_splits(int64_t tiles, int64_t KK) {
+  const int64_t slices = (KK + BK - 1) / BK;
+  int64_t s = (1024 + tiles - 1) / tiles;
+  const int64_t max_s = slices / 4 > 0 ? slices / 4 : 1;
+  if (s > max_s) s = max_s;
+  if (s < 1) s = 1;
+  return (int)s;
+}
+inline int64_t chunk_for(int64_t KK, int splits) {
+  const int64_t slices = (KK + BK - 1) / BK;
+  return ((slices + splits - 1) / splits) * BK;
+}
+
+}  // namespace
+
+extern "C" size_t mmssl_linear_workspace_bytes(int64_t M, int K, int N) {
+  if (M <= 0 || K <= 0 || N <= 0) return 16;
+  const int64_t tiles = ((M + BT - 1) / BT) * ((N + BT - 1) / BT);
+  const int splits = choose_splits(tiles, K);
+  return splits > 1 ? (size_t)splits * (size_t)M * (size_t)N * sizeof(float) : 16;
+}
+
+extern "C" int mmssl_linear_f32(const float* F, const float* W, const float* b, const uint8_t* keep, float scale,
+                                int64_t M, int K, int N, float* Y, void* workspace, size_t workspace_bytes,
+                                void* stream) {
+  if (M < 0 || K <= 0 || N <= 0 || (M > 0 && (!F || !W || !Y))) return MMSSL_E_BADARG;
+  if ((K & 3) || (N & 3) || N > 256) return MMSSL_E_UNSUPP;
+  if (M == 0) return 0;
+  if (((uintptr_t)F | (uintptr_t)W | (uintptr_t)Y) & 15) return MMSSL_E_BADARG;
+  hipStream_t s = as_stream(stream);
+  const int64_t tm = (M + BT - 1) / BT, tn = (N + BT - 1) / BT;
+  const int splits = choose_splits(tm * tn, K);
+  const int64_t chunk = chunk_for(K, splits);
+  if (splits == 1) {
+    hipLaunchKernelGGL((gemm64_kernel<false>), dim3((unsigned)tm, (unsigned)tn, 1), dim3(kBlock), 0, s, F,
+                       (int64_t)K, W, (int64_t)K, M, (int64_t)N, (int64_t)K, chunk, Y, (int64_t)N, (int64_t)0, b,
+                       keep, scale);
+    MMSSL_LAUNCH_CHECK();
+    return 0;
+  }
+  const size_t need = (size_t)splits * (size_t)M * (size_t)N * sizeof(float);
+  if (!workspace || workspace_bytes < need) return MMSSL_E_WORKSPACE;
+  float* P = reinterpret_cast<float*>(workspace);
+  hipLaunchKernelGGL((gemm64_kernel<false>), dim3((unsigned)tm, (unsigned)tn, (unsigned)splits), dim3(kBlock), 0,
+                     s, F, (int64_t)K, W, (int64_t)K, M, (int64_t)N, (int64_t)K, chunk, P, (int64_t)N,
+                     (int64_t)M * N, (const float*)nullptr, (const uint8_t*)nullptr, 1.f);
+  MMSSL_LAUNCH_CHECK();
+  const int64_t total = M * N;
+  int64_t nb = (total / 4 + kBlock - 1) / kBlock;
+  nb = nb > 4096 ? 4096 : (nb < 1 ? 1 : nb);
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)nb), dim3(kBlock), 0, s, P, splits, total, (int64_t)N,
+                     b, keep, scale, Y);
+  MMSSL_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" size_t mmssl_linear_wgrad_workspace_bytes(int64_t M, int K, int N) {
+  if (M <= 0 || K <= 0 || N <= 0) return 16;
+  const int64_t tiles = ((N + BT - 1) / BT) * ((K + BT - 1) / BT);
+  const int splits = choose_splits(tiles, M);
+  const size_t part = splits > 1 ? (size_t)splits * (size_t)N * (size_t)K * sizeof(float) : 0;
+  return part + (size_t)kColsumBlocks * (size_t)N * sizeof(float) + 16;
+}
+
+extern "C" int mmssl_linear_wgrad_f32(const float* gY, const float* F, int64_t M, int K, int N, float* gW,
+                                      float* gb, void* workspace, size_t workspace_bytes, void* stream) {
+  if (M <= 0 || K <= 0 || N <= 0 || !gY || !F || !gW) return MMSSL_E_BADARG;
+  if ((K & 3) || (N & 3) || N > 256) return MMSSL_E_UNSUPP;
+  if (!workspace || workspace_bytes < mmssl_linear_wgrad_workspace_bytes(M, K, N)) return MMSSL_E_WORKSPACE;
+  hipStream_t s = as_stream(stream);
+  const int64_t tn = (N + BT - 1) / BT, tk = (K + BT - 1) / BT;
+  const int splits = choose_splits(tn * tk, M);
+  const int64_t chunk = chunk_for(M, splits);
+  float* ws = reinterpret_cast<float*>(workspace);
+  float* colpart = ws;                                   // [kColsumBlocks][N]
+  float* P = ws + (size_t)kColsumBlocks * N;             // [splits][N][K]
+  // gW[n][k] = sum_m gY[m][n] * F[m][k]: A = gY as [kk=m][i=n], B = F as [kk=m][j=k]
+  if (splits == 1) {
+    hipLaunchKernelGGL((gemm64_kernel<true>), dim3((unsigned)tn, (unsigned)tk, 1), dim3(kBlock), 0, s, gY,
+                       (int64_t)N, F, (int64_t)K, (int64_t)N, (int64_t)K, M, chunk, gW, (int64_t)K, (int64_t)0,
+                       (const float*)nullptr, (const uint8_t*)nullptr, 1.f);
+    MMSSL_LAUNCH_CHECK();
+  } else {
+    hipLaunchKernelGGL((gemm64_kernel<true>), dim3((unsigned)tn, (unsigned)tk, (unsigned)splits), dim3(kBlock),
+                       0, s, gY, (int64_t)N, F, (int64_t)K, (int64_t)N, (int64_t)K, M, chunk, P, (int64_t)K,
+                       (int64_t)N * K, (const float*)nullptr, (const uint8_t*)nullptr, 1.f);
+    MMSSL_LAUNCH_CHECK();
+    const int64_t total = (int64_t)N * K;
+    int64_t nb = (total / 4 + kBlock - 1) / kBlock;
+    nb = nb > 4096 ? 4096 : (nb < 1 ? 1 : nb);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)nb), dim3(kBlock), 0, s, P, splits, total, (int64_t)K,
+                       (const float*)nullptr, (const uint8_t*)nullptr, 1.f, gW);
+    MMSSL_LAUNCH_CHECK();
+  }
+  if (gb) {
+    const int rows_per_pass = kBlock / N;
+    int64_t nb = (M + rows_per_pass - 1) / rows_per_pass;
+    nb = nb > kColsumBlocks ? kColsumBlocks : nb;
+    hipLaunchKernelGGL(colsum_stage1, dim3((unsigned)nb), dim3(kBlock), 0, s, gY, M, N, colpart);
+    MMSSL_LAUNCH_CHECK();
+    hipLaunchKernelGGL(colsum_stage2, dim3(1), dim3(kBlock), 0, s, colpart, (int)nb, N, gb);
+    MMSSL_LAUNCH_CHECK();
+  }
+  return 0;
+}

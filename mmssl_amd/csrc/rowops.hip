@@ -1,0 +1,181 @@
+// Row-wise kernels: L2 normalise (+fused scale/add), its backward, softmax backward, sum of
+// squares. All HBM-bound streaming: one lane group (d/4 lanes, one float4 each) per row, so
+// every row access is a single coalesced request; reductions are wavefront shuffles.
+//
+// Reference call sites (/root/reference/MMSSL/): F.normalize at Models.py:196-197,217-218 and
+// main.py:212-213; softmax at Models.py:203-204; (x**2).sum() at main.py:252-257,503.
+#include "common.hpp"
+
+using namespace mmssl;
+
+namespace {
+
+// Y = alpha * X / max(||X||, eps) (+ Base)
+template <int LPR>
+__global__ __launch_bounds__(kBlock) void l2norm_fwd_kernel(const float4* __restrict__ X,
+                                                            const float4* __restrict__ Base,
+                                                            float alpha, int64_t rows, float eps,
+                                                            float4* __restrict__ Y) {
+  constexpr int GPB = kBlock / LPR;
+  const int lig = threadIdx.x & (LPR - 1);
+  const int64_t stride = (int64_t)gridDim.x * GPB;
+  for (int64_t r = (int64_t)blockIdx.x * GPB + threadIdx.x / LPR; r < rows; r += stride) {
+    const float4 x = X[r * LPR + lig];
+    const float ss = group_sum<LPR>(f4_dot(x, x));
+    const float s = alpha / fmaxf(sqrtf(ss), eps);
+    float4 y = make_float4(x.x * s, x.y * s, x.z * s, x.w * s);
+    if (Base) {
+      const float4 b = Base[r * LPR + lig];
+      y.x += b.x; y.y += b.y; y.z += b.z; y.w += b.w;
+    }
+    Y[r * LPR + lig] = y;
+  }
+}
+
+// y = alpha * x / den, den = max(norm, eps):
+//   norm >= eps : gx = alpha * (g / norm - x * (x.g) / norm^3)
+//   norm <  eps : gx = alpha * g / eps            (clamp_min passes no gradient to norm)
+template <int LPR>
+__global__ __launch_bounds__(kBlock) void l2norm_bwd_kernel(const float4* __restrict__ X,
+                                                            const float4* __restrict__ G,
+                                                            float alpha, int64_t rows, float eps,
+                                                            float4* __restrict__ GX) {
+  constexpr int GPB = kBlock / LPR;
+  const int lig = threadIdx.x & (LPR - 1);
+  const int64_t stride = (int64_t)gridDim.x * GPB;
+  for (int64_t r = (int64_t)blockIdx.x * GPB + threadIdx.x / LPR; r < rows; r += stride) {
+    const float4 x = X[r * LPR + lig];
+    const float4 g = G[r * LPR + lig];
+    const float ss = group_sum<LPR>(f4_dot(x, x));
+    const float xg = group_sum<LPR>(f4_dot(x, g));
+    const float norm = sqrtf(ss);
+    float a, b;  // gx = a*g - b*x
+    if (norm >= eps) {
+      a = alpha / norm;
+      b = alpha * xg / (norm * ss);
+    } else {
+      a = alpha / eps;
+      b = 0.f;
+    }
+    GX[r * LPR + lig] = make_float4(a * g.x - b * x.x, a * g.y - b * x.y, a * g.z - b * x.z,
+                                    a * g.w - b * x.w);
+  }
+}
+
+template <int LPR>
+__global__ __launch_bounds__(kBlock) void softmax_bwd_kernel(const float4* __restrict__ Yv,
+                                                             const float4* __restrict__ G,
+                                                             int64_t rows, float4* __restrict__ GX) {
+  constexpr int GPB = kBlock / LPR;
+  const int lig = threadIdx.x & (LPR - 1);
+  const int64_t stride = (int64_t)gridDim.x * GPB;
+  for (int64_t r = (int64_t)blockIdx.x * GPB + threadIdx.x / LPR; r < rows; r += stride) {
+    const float4 y = Yv[r * LPR + lig];
+    const float4 g = G[r * LPR + lig];
+    const float s = group_sum<LPR>(f4_dot(y, g));
+    GX[r * LPR + lig] = make_float4(y.x * (g.x - s), y.y * (g.y - s), y.z * (g.z - s), y.w * (g.w - s));
+  }
+}
+
+constexpr int kSumsqBlocks = 1024;
+
+__global__ __launch_bounds__(kBlock) void sumsq_stage1(const float* __restrict__ X, int64_t n,
+                                                       float* __restrict__ part) {
+  __shared__ float red[4];
+  const int64_t n4 = n >> 2;
+  const float4* X4 = reinterpret_cast<const float4*>(X);
+  float acc = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n4; i += (int64_t)gridDim.x * kBlock) {
+    const float4 v = X4[i];
+    acc += f4_dot(v, v);
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+    const float v = X[(n4 << 2) + threadIdx.x];
+    acc += v * v;
+  }
+  const float t = block_sum_256(acc, red);
+  if (threadIdx.x == 0) part[blockIdx.x] = t;
+}
+
+__global__ __launch_bounds__(kBlock) void sumsq_stage2(const float* __restrict__ part, int nparts,
+                                                       float* __restrict__ out) {
+  __shared__ float red[4];
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < nparts; i += kBlock) acc += part[i];
+  const float t = block_sum_256(acc, red);
+  if (threadIdx.x == 0) out[0] = t;
+}
+
+inline int row_grid(int64_t rows, int lpr) {
+  const int64_t gpb = kBlock / lpr;
+  const int64_t nb = (rows + gpb - 1) / gpb;
+  return (int)(nb < 1 ? 1 : (nb > 256 * 16 ? 256 * 16 : nb));
+}
+
+}  // namespace
+
+#define ROW_DISPATCH(KERNEL, ...)                                                                 \
+  switch (d) {                                                                                    \
+    case 32: hipLaunchKernelGGL((KERNEL<8>), dim3(row_grid(rows, 8)), dim3(kBlock), 0, s, __VA_ARGS__); break;    \
+    case 64: hipLaunchKernelGGL((KERNEL<16>), dim3(row_grid(rows, 16)), dim3(kBlock), 0, s, __VA_ARGS__); break;  \
+    case 128: hipLaunchKernelGGL((KERNEL<32>), dim3(row_grid(rows, 32)), dim3(kBlock), 0, s, __VA_ARGS__); break; \
+    case 256: hipLaunchKernelGGL((KERNEL<64>), dim3(row_grid(rows, 64)), dim3(kBlock), 0, s, __VA_ARGS__); break; \
+    default: return MMSSL_E_UNSUPP;                                                               \
+  }
+
+extern "C" int mmssl_l2norm_rows_f32(const float* X, const float* Base, float alpha, int64_t rows, int d,
+                                     float eps, float* Y, void* stream) {
+  if (rows < 0 || (rows > 0 && (!X || !Y))) return MMSSL_E_BADARG;
+  if (!supported_d(d)) return MMSSL_E_UNSUPP;
+  if (rows == 0) return 0;
+  hipStream_t s = as_stream(stream);
+  ROW_DISPATCH(l2norm_fwd_kernel, reinterpret_cast<const float4*>(X), reinterpret_cast<const float4*>(Base),
+               alpha, rows, eps, reinterpret_cast<float4*>(Y));
+  MMSSL_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int mmssl_l2norm_rows_bwd_f32(const float* X, const float* gY, float alpha, int64_t rows, int d,
+                                         float eps, float* gX, void* stream) {
+  if (rows < 0 || (rows > 0 && (!X || !gY || !gX))) return MMSSL_E_BADARG;
+  if (!supported_d(d)) return MMSSL_E_UNSUPP;
+  if (rows == 0) return 0;
+  hipStream_t s = as_stream(stream);
+  ROW_DISPATCH(l2norm_bwd_kernel, reinterpret_cast<const float4*>(X), reinterpret_cast<const float4*>(gY),
+               alpha, rows, eps, reinterpret_cast<float4*>(gX));
+  MMSSL_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int mmssl_softmax_rows_bwd_f32(const float* Y, const float* gY, int64_t rows, int d, float* gX,
+                                          void* stream) {
+  if (rows < 0 || (rows > 0 && (!Y || !gY || !gX))) return MMSSL_E_BADARG;
+  if (!supported_d(d)) return MMSSL_E_UNSUPP;
+  if (rows == 0) return 0;
+  hipStream_t s = as_stream(stream);
+  ROW_DISPATCH(softmax_bwd_kernel, reinterpret_cast<const float4*>(Y), reinterpret_cast<const float4*>(gY),
+               rows, reinterpret_cast<float4*>(gX));
+  MMSSL_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" size_t mmssl_sumsq_workspace_bytes(int64_t n) {
+  (void)n;
+  return (size_t)kSumsqBlocks * sizeof(float);
+}
+
+extern "C" int mmssl_sumsq_f32(const float* X, int64_t n, float* out, void* workspace, size_t workspace_bytes,
+                               void* stream) {
+  if (n < 0 || !out || (n > 0 && !X)) return MMSSL_E_BADARG;
+  if (((uintptr_t)X) & 15) return MMSSL_E_BADARG;
+  if (!workspace || workspace_bytes < mmssl_sumsq_workspace_bytes(n)) return MMSSL_E_WORKSPACE;
+  hipStream_t s = as_stream(stream);
+  int64_t nb = (n / 4 + kBlock - 1) / kBlock;
+  nb = nb < 1 ? 1 : (nb > kSumsqBlocks ? kSumsqBlocks : nb);
+  float* part = reinterpret_cast<float*>(workspace);
+  hipLaunchKernelGGL(sumsq_stage1, dim3((int)nb), dim3(kBlock), 0, s, X, n, part);
+  MMSSL_LAUNCH_CHECK();
+  hipLaunchKernelGGL(sumsq_stage2, dim3(1), dim3(kBlock), 0, s, part, (int)nb, out);
+  MMSSL_LAUNCH_CHECK();
+  return 0;
+}

@@ -1,0 +1,144 @@
+"""GraphPlan: the device-resident graph handle that replaces the reference's torch sparse
+COO tensors (reference MMSSL/main.py:105-112,513-520: scipy -> torch.sparse.FloatTensor).
+
+A plan owns (through libmmssl_hip.so) the CSR, its transpose (for autograd's A^T.gradY) and
+a degree-balanced work list; see include/mmssl_hip.h and mmssl_amd/csrc/graph.hip.
+"""
+import ctypes
+
+import numpy as np
+import scipy.sparse as sp
+import torch
+
+from . import _lib
+
+
+class GraphPlan:
+    """Sparse matrix A [rows, cols] (fp32 values) prepared for Y = A @ X on the GPU.
+
+    Build from a scipy sparse matrix (what Trainer.csr_norm returns) or from a torch sparse
+    COO tensor (the reference's handle type). The current CUDA device owns the plan.
+    """
+
+    def __init__(self, mat, device=None):
+        if isinstance(mat, torch.Tensor):
+            mat = _coo_tensor_to_scipy(mat)
+        csr = sp.csr_matrix(mat, dtype=np.float32)
+        csr.sum_duplicates()          # torch.sparse.mm sums duplicate coordinates too
+        csr.sort_indices()
+        self.shape = (int(csr.shape[0]), int(csr.shape[1]))
+        self.nnz = int(csr.nnz)
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        rowptr = np.ascontiguousarray(csr.indptr, dtype=np.int32)
+        col = np.ascontiguousarray(csr.indices, dtype=np.int32)
+        val = np.ascontiguousarray(csr.data, dtype=np.float32)
+        self._handle = ctypes.c_void_p()
+        self._ws = {}
+        with torch.cuda.device(self.device):
+            rc = _lib.lib().mmssl_graph_create(
+                rowptr.ctypes.data, col.ctypes.data if self.nnz else None,
+                val.ctypes.data if self.nnz else None, self.shape[0], self.shape[1], self.nnz,
+                _lib.stream_ptr(), ctypes.byref(self._handle))
+        _lib.check(rc, "mmssl_graph_create")
+
+    # -- reference-handle compatibility -------------------------------------------------
+    def _nnz(self):
+        return self.nnz
+
+    def size(self, dim=None):
+        return torch.Size(self.shape) if dim is None else self.shape[dim]
+
+    @property
+    def handle(self):
+        if not self._handle:
+            raise _lib.MmsslError("GraphPlan used after destroy")
+        return self._handle
+
+    def info(self):
+        buf = (ctypes.c_int64 * 16)()
+        _lib.check(_lib.lib().mmssl_graph_info(self.handle, buf), "mmssl_graph_info")
+        keys = ["rows", "cols", "nnz", "group_items", "wave_items", "multi_rows", "partial_slots", "_",
+                "t_group_items", "t_wave_items", "t_multi_rows", "t_partial_slots", "short_max",
+                "task_nnz", "sorted"]
+        return {k: int(v) for k, v in zip(keys, buf) if k != "_"}
+
+    def workspace(self, transpose, d):
+        """Scratch for the partial sums of rows cut into several wave tasks; cached per
+        (direction, d) so pointers stay stable under hipGraph replay."""
+        key = (bool(transpose), int(d))
+        ws = self._ws.get(key)
+        if ws is None:
+            nbytes = _lib.lib().mmssl_spmm_workspace_bytes(self.handle, int(bool(transpose)), int(d))
+            ws = torch.empty(max(nbytes // 4, 4), dtype=torch.float32, device=self.device)
+            self._ws[key] = ws
+        return ws
+
+    def export_transpose(self):
+        """(rowptr, col, val) numpy arrays of the device-resident transposed CSR (tests)."""
+        rows, cols = self.shape
+        t_rowptr = np.empty(cols + 1, np.int32)
+        t_col = np.empty(max(self.nnz, 1), np.int32)
+        t_val = np.empty(max(self.nnz, 1), np.float32)
+        with torch.cuda.device(self.device):
+            rc = _lib.lib().mmssl_graph_export_transpose(self.handle, t_rowptr.ctypes.data, t_col.ctypes.data,
+                                                         t_val.ctypes.data, _lib.stream_ptr())
+        _lib.check(rc, "mmssl_graph_export_transpose")
+        return t_rowptr, t_col[:self.nnz], t_val[:self.nnz]
+
+    def destroy(self):
+        if self._handle:
+            _lib.lib().mmssl_graph_destroy(self._handle)
+            self._handle = ctypes.c_void_p()
+            self._ws = {}
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+
+def _coo_tensor_to_scipy(t):
+    if not t.is_sparse:
+        raise TypeError("expected a torch sparse COO tensor")
+    t = t.detach().cpu()
+    idx = t._indices().numpy()
+    val = t._values().numpy().astype(np.float32)
+    return sp.coo_matrix((val, (idx[0], idx[1])), shape=tuple(t.shape)).tocsr()
+
+
+def as_plan(g):
+    """Accept the reference's handle type (torch sparse COO), a scipy matrix or a GraphPlan."""
+    return g if isinstance(g, GraphPlan) else GraphPlan(g)
+
+
+# ---------------------------------------------------------------------------------------
+# host-only planning helpers (no GPU needed): used by CPU tests of the host logic
+# ---------------------------------------------------------------------------------------
+def transpose_host(csr):
+    csr = sp.csr_matrix(csr, dtype=np.float32)
+    csr.sort_indices()
+    rows, cols = csr.shape
+    rowptr = np.ascontiguousarray(csr.indptr, np.int32)
+    col = np.ascontiguousarray(csr.indices, np.int32)
+    val = np.ascontiguousarray(csr.data, np.float32)
+    t_rowptr = np.empty(cols + 1, np.int32)
+    t_col = np.empty(max(csr.nnz, 1), np.int32)
+    t_val = np.empty(max(csr.nnz, 1), np.float32)
+    rc = _lib.lib().mmssl_csr_transpose_host(rowptr.ctypes.data, col.ctypes.data, val.ctypes.data, rows, cols,
+                                             csr.nnz, t_rowptr.ctypes.data, t_col.ctypes.data, t_val.ctypes.data)
+    _lib.check(rc, "mmssl_csr_transpose_host")
+    return t_rowptr, t_col[:csr.nnz], t_val[:csr.nnz]
+
+
+def plan_host(rowptr):
+    rowptr = np.ascontiguousarray(rowptr, np.int32)
+    rows = rowptr.shape[0] - 1
+    cnt = (ctypes.c_int64 * 4)()
+    _lib.check(_lib.lib().mmssl_plan_count_host(rowptr.ctypes.data, rows, cnt), "mmssl_plan_count_host")
+    g = np.zeros((max(cnt[0], 1), 4), np.int32)
+    w = np.zeros((max(cnt[1], 1), 4), np.int32)
+    m = np.zeros((max(cnt[2], 1), 4), np.int32)
+    _lib.check(_lib.lib().mmssl_plan_fill_host(rowptr.ctypes.data, rows, g.ctypes.data, w.ctypes.data,
+                                               m.ctypes.data), "mmssl_plan_fill_host")
+    return g[:cnt[0]], w[:cnt[1]], m[:cnt[2]], int(cnt[3])

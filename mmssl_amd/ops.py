@@ -1,0 +1,301 @@
+"""torch.autograd.Function wrappers over the C ABI (include/mmssl_hip.h).
+
+Every op launches hand-written HIP kernels from libmmssl_hip.so on torch's current stream;
+torch is only the allocator / stream / autograd tape. No op has an eager fallback: a CPU
+tensor or a missing library raises.
+
+Reference call sites are listed per op (paths relative to /root/reference/MMSSL/).
+"""
+import torch
+
+from . import _lib
+from .graph import GraphPlan
+
+EPI_NONE = 0
+EPI_SOFTMAX = 1
+_NORM_EPS = 1e-12        # F.normalize default eps
+
+
+def _chk(t, name):
+    if not (isinstance(t, torch.Tensor) and t.is_cuda):
+        raise _lib.MmsslError("%s must be a CUDA (HIP) tensor: this package has no CPU path" % name)
+    if t.dtype != torch.float32:
+        raise _lib.MmsslError("%s must be float32 (the reference computes in fp32)" % name)
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+# ---------------------------------------------------------------------------------------
+# SpMM                                    Models.py:69-73 (mm), :177-186, :201-211
+# ---------------------------------------------------------------------------------------
+def _spmm_raw(plan, transpose, X, epilogue):
+    rows = plan.shape[1] if transpose else plan.shape[0]
+    cols = plan.shape[0] if transpose else plan.shape[1]
+    if X.dim() != 2 or X.shape[0] != cols:
+        raise _lib.MmsslError("spmm: X has shape %s, expected [%d, d]" % (tuple(X.shape), cols))
+    d = X.shape[1]
+    Y = torch.empty((rows, d), dtype=torch.float32, device=X.device)
+    ws = plan.workspace(transpose, d)
+    rc = _lib.lib().mmssl_spmm_f32(plan.handle, int(transpose), _ptr(X), d, _ptr(Y), epilogue, _ptr(ws),
+                                   ws.numel() * 4, _lib.stream_ptr())
+    _lib.check(rc, "mmssl_spmm_f32")
+    return Y
+
+
+class _Spmm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, X, plan, transpose, epilogue):
+        X = _chk(X, "X")
+        Y = _spmm_raw(plan, transpose, X, epilogue)
+        ctx.plan, ctx.transpose, ctx.epilogue = plan, transpose, epilogue
+        if epilogue == EPI_SOFTMAX:
+            ctx.save_for_backward(Y)
+        return Y
+
+    @staticmethod
+    def backward(ctx, gY):
+        gY = _chk(gY, "gY")
+        if ctx.epilogue == EPI_SOFTMAX:
+            (Y,) = ctx.saved_tensors
+            gY = softmax_rows_bwd(Y, gY)
+        gX = _spmm_raw(ctx.plan, not ctx.transpose, gY, EPI_NONE)   # gradX = A^T . gradY
+        return gX, None, None, None
+
+
+def spmm(plan, X, epilogue=EPI_NONE, transpose=False):
+    """Y = A @ X (or A^T @ X), optionally with the row softmax fused into the store."""
+    if not isinstance(plan, GraphPlan):
+        raise _lib.MmsslError("spmm expects a GraphPlan (see mmssl_amd.graph.as_plan)")
+    return _Spmm.apply(X, plan, bool(transpose), int(epilogue))
+
+
+# ---------------------------------------------------------------------------------------
+# row kernels            F.normalize Models.py:196-197,217-218; main.py:212-213
+# ---------------------------------------------------------------------------------------
+def softmax_rows_bwd(Y, gY):
+    gX = torch.empty_like(Y)
+    rc = _lib.lib().mmssl_softmax_rows_bwd_f32(_ptr(Y), _ptr(gY), Y.shape[0], Y.shape[1], _ptr(gX),
+                                               _lib.stream_ptr())
+    _lib.check(rc, "mmssl_softmax_rows_bwd_f32")
+    return gX
+
+
+class _L2Norm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, X, base, alpha):
+        X = _chk(X, "X")
+        if base is not None:
+            base = _chk(base, "base")
+            if base.shape != X.shape:
+                raise _lib.MmsslError("l2norm: base shape mismatch")
+        Y = torch.empty_like(X)
+        rc = _lib.lib().mmssl_l2norm_rows_f32(_ptr(X), _ptr(base), float(alpha), X.shape[0], X.shape[1],
+                                              _NORM_EPS, _ptr(Y), _lib.stream_ptr())
+        _lib.check(rc, "mmssl_l2norm_rows_f32")
+        ctx.save_for_backward(X)
+        ctx.alpha = float(alpha)
+        ctx.has_base = base is not None
+        return Y
+
+    @staticmethod
+    def backward(ctx, gY):
+        (X,) = ctx.saved_tensors
+        gY = _chk(gY, "gY")
+        gX = None
+        if ctx.needs_input_grad[0]:
+            gX = torch.empty_like(X)
+            rc = _lib.lib().mmssl_l2norm_rows_bwd_f32(_ptr(X), _ptr(gY), ctx.alpha, X.shape[0], X.shape[1],
+                                                      _NORM_EPS, _ptr(gX), _lib.stream_ptr())
+            _lib.check(rc, "mmssl_l2norm_rows_bwd_f32")
+        return gX, (gY if ctx.has_base and ctx.needs_input_grad[1] else None), None
+
+
+def l2norm_rows(X, base=None, alpha=1.0):
+    """alpha * X / max(||X||_2, 1e-12) row-wise (+ base): F.normalize(X, p=2, dim=1) with the
+    reference's surrounding `base + rate * normalize(x)` fused in."""
+    return _L2Norm.apply(X, base, alpha)
+
+
+class _SumSq(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, X):
+        X = _chk(X, "X")
+        out = torch.empty((), dtype=torch.float32, device=X.device)
+        nb = _lib.lib().mmssl_sumsq_workspace_bytes(X.numel())
+        ws = torch.empty(nb // 4, dtype=torch.float32, device=X.device)
+        rc = _lib.lib().mmssl_sumsq_f32(_ptr(X), X.numel(), _ptr(out), _ptr(ws), nb, _lib.stream_ptr())
+        _lib.check(rc, "mmssl_sumsq_f32")
+        ctx.save_for_backward(X)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (X,) = ctx.saved_tensors
+        return X * (2.0 * g)
+
+
+def sumsq(X):
+    """(X**2).sum() with a deterministic two-stage reduction (main.py:252-257, 503)."""
+    return _SumSq.apply(X)
+
+
+# ---------------------------------------------------------------------------------------
+# modality projection          nn.Linear + nn.Dropout, Models.py:28-29,54,173-174
+# ---------------------------------------------------------------------------------------
+class _Linear(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, F_, W, b, keep, scale):
+        F_, W = _chk(F_, "F"), _chk(W, "W")
+        b = _chk(b, "b") if b is not None else None
+        M, K = F_.shape
+        N = W.shape[0]
+        if W.shape[1] != K:
+            raise _lib.MmsslError("linear: W is %s, expected [N, %d]" % (tuple(W.shape), K))
+        if keep is not None:
+            if keep.dtype != torch.uint8 or tuple(keep.shape) != (M, N) or not keep.is_cuda:
+                raise _lib.MmsslError("linear: keep mask must be uint8 [M, N] on the GPU")
+            keep = keep.contiguous()
+        Y = torch.empty((M, N), dtype=torch.float32, device=F_.device)
+        nb = _lib.lib().mmssl_linear_workspace_bytes(M, K, N)
+        ws = torch.empty(max(nb // 4, 4), dtype=torch.float32, device=F_.device)
+        rc = _lib.lib().mmssl_linear_f32(_ptr(F_), _ptr(W), _ptr(b), _ptr(keep), float(scale), M, K, N, _ptr(Y),
+                                         _ptr(ws), ws.numel() * 4, _lib.stream_ptr())
+        _lib.check(rc, "mmssl_linear_f32")
+        ctx.save_for_backward(F_, W, keep)
+        ctx.scale = float(scale)
+        ctx.has_bias = b is not None
+        return Y
+
+    @staticmethod
+    def backward(ctx, gY):
+        F_, W, keep = ctx.saved_tensors
+        gY = _chk(gY, "gY")
+        if keep is not None:
+            gY = gY * keep * ctx.scale            # dropout backward (elementwise, [M, 64])
+        M, K = F_.shape
+        N = W.shape[0]
+        gW = torch.empty_like(W)
+        gb = torch.empty(N, dtype=torch.float32, device=W.device)
+        nb = _lib.lib().mmssl_linear_wgrad_workspace_bytes(M, K, N)
+        ws = torch.empty(max(nb // 4, 4), dtype=torch.float32, device=W.device)
+        rc = _lib.lib().mmssl_linear_wgrad_f32(_ptr(gY), _ptr(F_), M, K, N, _ptr(gW), _ptr(gb), _ptr(ws), nb,
+                                               _lib.stream_ptr())
+        _lib.check(rc, "mmssl_linear_wgrad_f32")
+        if ctx.needs_input_grad[0]:
+            # the reference's raw features are constants (Models.py:46-47): no input gradient path
+            raise _lib.MmsslError("linear: gradient w.r.t. the feature matrix is not part of the hot path")
+        return None, gW, (gb if ctx.has_bias else None), None, None
+
+
+def linear(F_, W, b=None, keep=None, scale=1.0):
+    """dropout(F @ W^T + b) on fp32 MFMA; `keep` is a uint8 keep-mask (None = eval mode)."""
+    return _Linear.apply(F_, W, b, keep, scale)
+
+
+# ---------------------------------------------------------------------------------------
+# InfoNCE                       Trainer.sim + batched_contrastive_loss, main.py:211-249
+# ---------------------------------------------------------------------------------------
+class _InfoNCE(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, z1, z2, tau):
+        z1, z2 = _chk(z1, "z1"), _chk(z2, "z2")
+        if z1.shape != z2.shape or z1.dim() != 2:
+            raise _lib.MmsslError("infonce: z1/z2 must both be [n, d]")
+        n, d = z1.shape
+        nb = _lib.lib().mmssl_infonce_workspace_bytes(n, d)
+        if nb == 0:
+            raise _lib.MmsslError("infonce: unsupported shape n=%d d=%d" % (n, d))
+        ws = torch.empty(nb // 4, dtype=torch.float32, device=z1.device)
+        loss = torch.empty((), dtype=torch.float32, device=z1.device)
+        rc = _lib.lib().mmssl_infonce_fwd_f32(_ptr(z1), _ptr(z2), n, d, float(tau), _ptr(loss), _ptr(ws), nb,
+                                              _lib.stream_ptr())
+        _lib.check(rc, "mmssl_infonce_fwd_f32")
+        ctx.save_for_backward(z1, z2, ws)
+        ctx.tau = float(tau)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        z1, z2, ws = ctx.saved_tensors
+        n, d = z1.shape
+        g = g.contiguous().to(torch.float32)
+        gz1, gz2 = torch.empty_like(z1), torch.empty_like(z2)
+        rc = _lib.lib().mmssl_infonce_bwd_f32(_ptr(z1), _ptr(z2), n, d, ctx.tau, _ptr(g), _ptr(gz1), _ptr(gz2),
+                                              _ptr(ws), ws.numel() * 4, _lib.stream_ptr())
+        _lib.check(rc, "mmssl_infonce_bwd_f32")
+        return gz1, gz2, None
+
+
+def infonce(z1, z2, tau=0.5):
+    """The reference's batched_contrastive_loss(z1, z2) (its 1024-row blocking is exactly the
+    full-matrix formula)."""
+    return _InfoNCE.apply(z1, z2, tau)
+
+
+# ---------------------------------------------------------------------------------------
+# BPR                      gathers main.py:368-370 + Trainer.bpr_loss main.py:499-511
+# ---------------------------------------------------------------------------------------
+def _idx(t, name, device):
+    if t is None:
+        return None
+    if not isinstance(t, torch.Tensor):
+        t = torch.as_tensor(t, dtype=torch.int64)
+    t = t.to(device=device, dtype=torch.int64)
+    return t if t.is_contiguous() else t.contiguous()
+
+
+class _Bpr(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, Eu, Ei, Ein, users, pos, neg, decay, batch_size):
+        Eu, Ei = _chk(Eu, "Eu"), _chk(Ei, "Ei")
+        Ein = _chk(Ein, "Ei_neg") if Ein is not None else None
+        gathered = users is None
+        if gathered:
+            B = Eu.shape[0]
+            if Ein is None or Ei.shape != Eu.shape or Ein.shape != Eu.shape:
+                raise _lib.MmsslError("bpr: gathered form needs three [B, d] tensors")
+        else:
+            B = users.shape[0]
+        d = Eu.shape[1]
+        out = torch.empty(3, dtype=torch.float32, device=Eu.device)
+        nb = _lib.lib().mmssl_bpr_workspace_bytes(B)
+        ws = torch.empty(nb // 4, dtype=torch.float32, device=Eu.device)
+        rc = _lib.lib().mmssl_bpr_fwd_f32(_ptr(Eu), _ptr(Ei), _ptr(Ein), _ptr(users), _ptr(pos), _ptr(neg), B, d,
+                                          float(decay), int(batch_size), _ptr(out), _ptr(ws), nb,
+                                          _lib.stream_ptr())
+        _lib.check(rc, "mmssl_bpr_fwd_f32")
+        ctx.save_for_backward(Eu, Ei, Ein, users, pos, neg)
+        ctx.cfg = (B, d, float(decay), int(batch_size), gathered)
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        Eu, Ei, Ein, users, pos, neg = ctx.saved_tensors
+        B, d, decay, batch_size, gathered = ctx.cfg
+        g_out = g_out.contiguous().to(torch.float32)
+        g_mf, g_emb = g_out[0:1], g_out[1:2]       # views: adjacent floats of one buffer
+        gEu = torch.zeros_like(Eu)
+        gEi = torch.zeros_like(Ei)
+        gEin = torch.zeros_like(Ein) if gathered else None
+        rc = _lib.lib().mmssl_bpr_bwd_f32(_ptr(Eu), _ptr(Ei), _ptr(Ein), _ptr(users), _ptr(pos), _ptr(neg), B, d,
+                                          decay, batch_size, _ptr(g_mf), _ptr(g_emb), _ptr(gEu), _ptr(gEi),
+                                          _ptr(gEin), _lib.stream_ptr())
+        _lib.check(rc, "mmssl_bpr_bwd_f32")
+        return gEu, gEi, gEin, None, None, None, None, None
+
+
+def bpr_gather(Eu, Ei, users, pos, neg, decay, batch_size):
+    """Fused gather + BPR: (mf_loss, emb_loss) from the full tables and the int64 batch."""
+    dev = Eu.device
+    out = _Bpr.apply(Eu, Ei, None, _idx(users, "users", dev), _idx(pos, "pos", dev), _idx(neg, "neg", dev),
+                     decay, batch_size)
+    return out[0], out[1]
+
+
+def bpr(u, p, n, decay, batch_size):
+    """Trainer.bpr_loss on already-gathered [B, d] rows (the reference's signature)."""
+    out = _Bpr.apply(u, p, n, None, None, None, decay, batch_size)
+    return out[0], out[1]

@@ -202,7 +202,7 @@ def u_sim(users, user_final, item_final, ui_raw, batch_size):
     """Trainer.u_sim_calculation (main.py:283-298): masked, row-L2-normalised user x item
     scores (adjacent to the hot path; needed for the G-step assembly check)."""
     tu = user_final[users]
-    seen = torch.from_numpy(np.asarray(ui_raw[users].todense(), dtype=np.float32))
+    seen = torch.from_numpy(np.asarray(ui_raw[np.asarray(users)].todense(), dtype=np.float32))
     n_items = item_final.shape[0]
     chunks = []
     for a in range(0, n_items, batch_size):

@@ -1,0 +1,243 @@
+"""GPU parity tests: every C-ABI compute entry point (through the ctypes/autograd wrappers in
+mmssl_amd.ops) against the CPU oracle and the golden vectors captured from the reference.
+Run on the MI355X box with `pytest -m gpu`."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import torch
+
+import helpers as H
+import mmssl_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _ops():
+    from mmssl_amd import ops, graph
+    return ops, graph
+
+
+def _rand_graph(rows, cols, nnz_per_row, seed, heavy=(), empty=()):
+    rng = np.random.default_rng(seed)
+    r, c = [], []
+    for i in range(rows):
+        k = int(rng.integers(0, 2 * nnz_per_row + 1))
+        r += [i] * k
+        c += rng.choice(cols, size=min(k, cols), replace=False).tolist()[:k]
+    for (i, k) in heavy:
+        keep = [j for j in range(len(r)) if r[j] != i]
+        r = [r[j] for j in keep]; c = [c[j] for j in keep]
+        r += [i] * k
+        c += rng.choice(cols, size=k, replace=False).tolist()
+    m = sp.csr_matrix((rng.random(len(r)).astype(np.float32) + 0.1, (r, c)), shape=(rows, cols))
+    m = m.tolil()
+    for i in empty:
+        m[i, :] = 0
+    m = m.tocsr(); m.eliminate_zeros(); m.sort_indices()
+    return m
+
+
+@pytest.mark.parametrize("d", [32, 64, 128, 256])
+def test_spmm_forward_transpose_softmax(d):
+    ops, graph = _ops()
+    m = _rand_graph(700, 900, 6, seed=d, heavy=[(5, 33), (6, 128), (7, 129), (8, 700), (699, 400)], empty=[0, 3, 698])
+    plan = graph.GraphPlan(m)
+    info = plan.info()
+    assert info["multi_rows"] >= 2 and info["wave_items"] >= 5 and info["nnz"] == m.nnz
+    A = O.to_torch_sparse(m)
+    g = torch.Generator().manual_seed(1)
+    X = torch.randn(900, d, generator=g)
+    Y = ops.spmm(plan, X.to(DEV)).cpu()
+    ref = O.spmm(A, X)
+    assert H.rel_err(Y, ref) < 2e-6
+    assert float(Y[0].abs().max()) == 0.0 and float(Y[698].abs().max()) == 0.0   # empty rows -> exact zeros
+    Ys = ops.spmm(plan, X.to(DEV), epilogue=ops.EPI_SOFTMAX).cpu()
+    assert H.rel_err(Ys, torch.softmax(ref, -1)) < 2e-6
+    np.testing.assert_allclose(Ys[0].numpy(), np.full(d, 1.0 / d, np.float32), rtol=1e-6)
+    G = torch.randn(700, d, generator=g)
+    Yt = ops.spmm(plan, G.to(DEV), transpose=True).cpu()
+    assert H.rel_err(Yt, O.spmm(O.to_torch_sparse(m.T.tocsr()), G)) < 2e-6
+    # bitwise reproducible (fixed summation order, no float atomics)
+    assert torch.equal(ops.spmm(plan, X.to(DEV)).cpu(), Y)
+
+
+def test_spmm_empty_graph_and_export():
+    ops, graph = _ops()
+    empty = sp.csr_matrix((40, 30), dtype=np.float32)
+    plan = graph.GraphPlan(empty)
+    assert plan._nnz() == 0
+    Y = ops.spmm(plan, torch.randn(30, 64, device=DEV))
+    assert Y.shape == (40, 64) and float(Y.abs().max()) == 0.0
+    Yt = ops.spmm(plan, torch.randn(40, 64, device=DEV), transpose=True)
+    assert Yt.shape == (30, 64) and float(Yt.abs().max()) == 0.0
+    m = _rand_graph(200, 90, 5, seed=3, heavy=[(9, 80)])
+    plan = graph.GraphPlan(m)
+    rp, ci, va = plan.export_transpose()
+    ref = m.T.tocsr(); ref.sort_indices()
+    assert np.array_equal(rp, ref.indptr) and np.array_equal(ci, ref.indices) and np.array_equal(va, ref.data)
+
+
+def test_spmm_autograd_matches_oracle():
+    ops, graph = _ops()
+    m = _rand_graph(300, 260, 8, seed=11, heavy=[(4, 200)], empty=[2])
+    plan = graph.GraphPlan(m)
+    A = O.to_torch_sparse(m)
+    g = torch.Generator().manual_seed(2)
+    X0 = torch.randn(260, 64, generator=g)
+    C = torch.randn(300, 64, generator=g)
+    for epi in (False, True):
+        Xr = X0.clone().requires_grad_(True)
+        yr = O.spmm(A, Xr)
+        if epi:
+            yr = torch.softmax(yr, -1)
+        (yr * C).sum().backward()
+        Xg = X0.clone().to(DEV).requires_grad_(True)
+        yg = ops.spmm(plan, Xg, epilogue=ops.EPI_SOFTMAX if epi else ops.EPI_NONE)
+        (yg * C.to(DEV)).sum().backward()
+        assert H.rel_err(yg.detach().cpu(), yr.detach()) < 2e-6
+        assert H.rel_err(Xg.grad.cpu(), Xr.grad) < 5e-6
+
+
+def test_spmm_golden_graph():
+    """The reference-normalised tiny graphs (G1) through the HIP SpMM."""
+    ops, graph = _ops()
+    g1 = H.load("g1_csr_norm.npz")
+    for nm in ("ui", "iu"):
+        shp = tuple(g1[nm + "_shape"])
+        m = sp.csr_matrix((g1[nm + "_val"], (g1[nm + "_row"], g1[nm + "_col"])), shape=shp)
+        X = torch.randn(shp[1], 64, generator=torch.Generator().manual_seed(5))
+        Y = ops.spmm(graph.GraphPlan(m), X.to(DEV)).cpu()
+        assert H.rel_err(Y, O.spmm(O.to_torch_sparse(m), X)) < 2e-6
+
+
+@pytest.mark.parametrize("d", [32, 64, 128, 256])
+def test_l2norm_rows_and_backward(d):
+    ops, _ = _ops()
+    g = torch.Generator().manual_seed(d)
+    X0 = torch.randn(333, d, generator=g) * 3
+    X0[7] = 0
+    X0[100] = 1e-20
+    base0 = torch.randn(333, d, generator=g)
+    C = torch.randn(333, d, generator=g)
+    for use_base, alpha in ((False, 1.0), (True, 0.36)):
+        xr = X0.clone().requires_grad_(True)
+        br = base0.clone().requires_grad_(True)
+        yr = alpha * torch.nn.functional.normalize(xr, p=2, dim=1)
+        if use_base:
+            yr = br + yr
+        (yr * C).sum().backward()
+        xg = X0.clone().to(DEV).requires_grad_(True)
+        bg = base0.clone().to(DEV).requires_grad_(True)
+        yg = ops.l2norm_rows(xg, bg if use_base else None, alpha)
+        (yg * C.to(DEV)).sum().backward()
+        np.testing.assert_allclose(yg.detach().cpu().numpy(), yr.detach().numpy(), rtol=2e-6, atol=1e-7)
+        np.testing.assert_allclose(xg.grad.cpu().numpy(), xr.grad.numpy(), rtol=2e-5, atol=2e-6)
+        if use_base:
+            assert torch.equal(bg.grad.cpu(), C)
+
+
+def test_sumsq():
+    ops, _ = _ops()
+    for n in (1, 3, 4, 1023, 64 * 1000 + 2):
+        x = torch.randn(n, generator=torch.Generator().manual_seed(n)).requires_grad_(True)
+        xg = x.detach().to(DEV).requires_grad_(True)
+        s = ops.sumsq(xg)
+        ref = (x.double() ** 2).sum()
+        assert abs(float(s) - float(ref)) <= 2e-6 * float(ref) + 1e-12
+        (s * 0.5).backward()
+        np.testing.assert_allclose(xg.grad.cpu().numpy(), x.detach().numpy(), rtol=1e-6)
+
+
+@pytest.mark.parametrize("M,K,N", [(160, 32, 64), (1000, 128, 64), (777, 4096, 64), (96, 48, 64), (2049, 768, 128)])
+def test_linear_forward_and_wgrad(M, K, N):
+    ops, _ = _ops()
+    g = torch.Generator().manual_seed(M + K)
+    F_ = torch.randn(M, K, generator=g)
+    W = (torch.randn(N, K, generator=g) / K ** 0.5)
+    b = torch.randn(N, generator=g)
+    keep = (torch.rand(M, N, generator=g) >= 0.2).to(torch.uint8)
+    C = torch.randn(M, N, generator=g)
+    for mask in (None, keep):
+        Wr = W.clone().requires_grad_(True); br = b.clone().requires_grad_(True)
+        yr = torch.nn.functional.linear(F_, Wr, br)
+        if mask is not None:
+            yr = yr * mask * 1.25
+        (yr * C).sum().backward()
+        Wg = W.clone().to(DEV).requires_grad_(True); bg = b.clone().to(DEV).requires_grad_(True)
+        yg = ops.linear(F_.to(DEV), Wg, bg, None if mask is None else mask.to(DEV), 1.25 if mask is not None else 1.0)
+        (yg * C.to(DEV)).sum().backward()
+        tol = 3e-6 * max(1.0, (K / 128.0) ** 0.5)
+        assert H.rel_err(yg.detach().cpu(), yr.detach()) < tol
+        assert H.rel_err(Wg.grad.cpu(), Wr.grad) < tol * 3
+        assert H.rel_err(bg.grad.cpu(), br.grad) < tol * 3
+    # asymmetric check (transpose-detecting): identity-like W picks columns of F
+    Wi = torch.zeros(N, K); Wi[torch.arange(min(N, K)), torch.arange(min(N, K))] = 1.0
+    y = ops.linear(F_.to(DEV), Wi.to(DEV)).cpu()
+    assert torch.equal(y[:, :min(N, K)], F_[:, :min(N, K)])
+
+
+def test_infonce_golden_and_oracle():
+    ops, _ = _ops()
+    g = H.load("g4_infonce.npz")
+    tau = float(g["tau"])
+    names = sorted({k.split(".")[0] for k in g.files if "." in k})
+    for nm in names:
+        z1 = torch.from_numpy(g[nm + ".z1"]).to(DEV).requires_grad_(True)
+        z2 = torch.from_numpy(g[nm + ".z2"]).to(DEV).requires_grad_(True)
+        loss = ops.infonce(z1, z2, tau)
+        ref = float(g[nm + ".loss"])
+        assert abs(float(loss) - ref) <= 1e-5 * abs(ref), (nm, float(loss), ref)   # north_star: 1e-4 rel
+        loss.backward()
+        np.testing.assert_allclose(z1.grad.cpu().numpy(), g[nm + ".gz1"], rtol=2e-4, atol=2e-7, err_msg=nm)
+        np.testing.assert_allclose(z2.grad.cpu().numpy(), g[nm + ".gz2"], rtol=2e-4, atol=2e-7, err_msg=nm)
+    for n, d in ((1, 64), (5, 64), (33, 32), (1024, 64), (1500, 64), (300, 256)):
+        gen = torch.Generator().manual_seed(n)
+        a = torch.randn(n, d, generator=gen); b = torch.randn(n, d, generator=gen)
+        ar = a.clone().requires_grad_(True); br = b.clone().requires_grad_(True)
+        lr = O.infonce(ar, br, 0.5)
+        (lr * 1.7).backward()
+        ag = a.clone().to(DEV).requires_grad_(True); bg = b.clone().to(DEV).requires_grad_(True)
+        lg = ops.infonce(ag, bg, 0.5)
+        (lg * 1.7).backward()
+        assert abs(float(lg) - float(lr)) <= 1e-5 * abs(float(lr)) + 1e-7, (n, d)
+        assert H.rel_err(ag.grad.cpu(), ar.grad) < 2e-4, (n, d)
+        assert H.rel_err(bg.grad.cpu(), br.grad) < 2e-4, (n, d)
+
+
+def test_bpr_golden_and_gather():
+    ops, _ = _ops()
+    g = H.load("g5_bpr_featreg.npz")
+    u, p, n = (torch.from_numpy(g[k]).to(DEV).requires_grad_(True) for k in ("u", "p", "n"))
+    mf, emb = ops.bpr(u, p, n, float(g["decay"]), int(g["batch_size"]))
+    assert abs(float(mf) - float(g["mf"])) <= 1e-6 * abs(float(g["mf"]))
+    assert abs(float(emb) - float(g["emb"])) <= 1e-6 * abs(float(g["emb"]))
+    (mf + emb).backward()
+    for t, k in ((u, "gu"), (p, "gp"), (n, "gn")):
+        np.testing.assert_allclose(t.grad.cpu().numpy(), g[k], rtol=1e-5, atol=1e-9)
+    # fused-gather form vs oracle on full tables, with repeated items
+    gen = torch.Generator().manual_seed(3)
+    Eu = torch.randn(500, 64, generator=gen) * 0.3
+    Ei = torch.randn(200, 64, generator=gen) * 0.3
+    users = torch.randperm(500, generator=gen)[:128]
+    pos = torch.randint(0, 200, (128,), generator=gen)
+    neg = torch.randint(0, 200, (128,), generator=gen)
+    Eur = Eu.clone().requires_grad_(True); Eir = Ei.clone().requires_grad_(True)
+    mfr, embr, _ = O.bpr(Eur[users], Eir[pos], Eir[neg], 1e-5, 1024)
+    (mfr * 0.7 + embr * 3.0).backward()
+    Eug = Eu.clone().to(DEV).requires_grad_(True); Eig = Ei.clone().to(DEV).requires_grad_(True)
+    mfg, embg = ops.bpr_gather(Eug, Eig, users, pos, neg, 1e-5, 1024)
+    (mfg * 0.7 + embg * 3.0).backward()
+    assert abs(float(mfg) - float(mfr)) <= 2e-6 * abs(float(mfr))
+    assert abs(float(embg) - float(embr)) <= 2e-6 * abs(float(embr))
+    assert H.rel_err(Eug.grad.cpu(), Eur.grad) < 1e-5
+    assert H.rel_err(Eig.grad.cpu(), Eir.grad) < 1e-5
+
+
+def test_ops_refuse_cpu_tensors():
+    ops, graph = _ops()
+    from mmssl_amd._lib import MmsslError
+    with pytest.raises(MmsslError):
+        ops.l2norm_rows(torch.randn(4, 64))
+    with pytest.raises(MmsslError):
+        ops.infonce(torch.randn(4, 64), torch.randn(4, 64))

@@ -1,0 +1,20 @@
+"""Process-wide flag namespace (`args`), the counterpart of the reference's module-level
+`args = parse_args()` in Models.py:15 / main.py:34 / load_data.py:8 / batch_test.py:13.
+
+Importing this package never parses sys.argv (library-friendly); `mmssl_amd.main`'s entry point
+calls `configure(sys.argv[1:])`. Tests and embedding applications set attributes directly or
+call `configure([...])`.
+"""
+from .utility.parser import parse_args
+
+args = parse_args([])
+
+
+def configure(argv=None, **overrides):
+    """Re-parse flags IN PLACE (every module holds a reference to the same namespace)."""
+    new = parse_args(argv if argv is not None else [])
+    args.__dict__.clear()
+    args.__dict__.update(new.__dict__)
+    for k, v in overrides.items():
+        setattr(args, k, v)
+    return args

@@ -48,6 +48,10 @@ class GraphPlan:
     def size(self, dim=None):
         return torch.Size(self.shape) if dim is None else self.shape[dim]
 
+    def cuda(self, *a, **k):
+        """No-op (already device resident); lets reference-style `.cuda()` chains keep working."""
+        return self
+
     @property
     def handle(self):
         if not self._handle:

@@ -1,0 +1,305 @@
+"""`Trainer` / `set_seed` with the reference's interface and training-loop semantics
+(/root/reference/MMSSL/main.py:37-536), re-built around the HIP hot path:
+
+  * graphs are `GraphPlan`s (device CSR + transpose + balanced work list) instead of torch COO;
+  * `model(...)`, `bpr_loss`, `batched_contrastive_loss`, `feat_reg_loss_calculation` run on the
+    kernels of libmmssl_hip.so (see mmssl_amd/ops.py);
+  * the adversarial pieces (u_sim_calculation, Discriminator, gradient penalty, Gumbel noise)
+    are adjacent to the hot path and stay on stock PyTorch-ROCm ops.
+
+Loop quirks are reproduced, not fixed: two model forwards per batch, modal
+graphs rebuilt every T batches from the previous batch's top-k and EMPTY from the third batch
+on under the defaults, LambdaLR created but never stepped, AdamW over all model parameters.
+Not reproduced: the two dense U x I GPU copies of the train matrix that the reference allocates
+and never reads (main.py:59-60), dead methods that reference undefined attributes / dgl
+(main.py:114-209, 260-279).
+"""
+import math
+import os
+import pickle
+import random
+import sys
+from datetime import datetime
+from time import time
+
+import numpy as np
+import scipy.sparse as sp
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+import torch.optim as optim
+from torch import autograd
+
+from . import ops
+from .config import args, configure
+from .graph import GraphPlan
+from .Models import MMSSL, Discriminator
+from .utility import batch_test
+from .utility.logging import Logger
+
+
+def set_seed(seed):
+    np.random.seed(seed)
+    random.seed(seed)
+    torch.manual_seed(seed)
+    torch.cuda.manual_seed_all(seed)
+
+
+class Trainer(object):
+    def __init__(self, data_config):
+        self.task_name = "%s_%s_%s" % (datetime.now().strftime("%Y-%m-%d %H:%M:%S"), args.dataset, args.cf_model)
+        self.logger = Logger(filename=self.task_name, is_debug=args.debug)
+        self.logger.logging("PID: %d" % os.getpid())
+        self.logger.logging(str(args))
+
+        self.mess_dropout = eval(args.mess_dropout)
+        self.lr = args.lr
+        self.emb_dim = args.embed_size
+        self.batch_size = args.batch_size
+        self.weight_size = eval(args.weight_size)
+        self.n_layers = len(self.weight_size)
+        self.regs = eval(args.regs)
+        self.decay = self.regs[0]
+
+        base = args.data_path + args.dataset
+        self.image_feats = np.load(base + "/image_feat.npy")
+        self.text_feats = np.load(base + "/text_feat.npy")
+        self.image_feat_dim = self.image_feats.shape[-1]
+        self.text_feat_dim = self.text_feats.shape[-1]
+        with open(base + "/train_mat", "rb") as f:
+            self.ui_graph_raw = pickle.load(f).tocsr()
+        self.image_ui_index = {"x": [], "y": []}
+        self.text_ui_index = {"x": [], "y": []}
+        self.n_users, self.n_items = self.ui_graph_raw.shape
+        self.device = torch.device("cuda", torch.cuda.current_device())
+
+        self.ui_graph = self.matrix_to_tensor(self.csr_norm(self.ui_graph_raw, mean_flag=True))
+        self.iu_graph = self.matrix_to_tensor(self.csr_norm(self.ui_graph_raw.T, mean_flag=True))
+        self.image_ui_graph = self.text_ui_graph = self.ui_graph
+        self.image_iu_graph = self.text_iu_graph = self.iu_graph
+
+        self.model = MMSSL(self.n_users, self.n_items, self.emb_dim, self.weight_size, self.mess_dropout,
+                           self.image_feats, self.text_feats).cuda()
+        self.D = Discriminator(self.n_items).cuda()
+        self.D.apply(self.weights_init)
+        self.optim_D = optim.Adam(self.D.parameters(), lr=args.D_lr, betas=(0.5, 0.9))
+        self.optimizer_D = optim.AdamW([{"params": self.model.parameters()}], lr=self.lr)
+        self.scheduler_D = self.set_lr_scheduler()
+        self._seen_cache = (None, None)
+        if batch_test.data_generator is None:
+            batch_test.init_data()
+        self.data_generator = batch_test.data_generator
+
+    # ---- pieces with the reference's names ----------------------------------------------------
+    def set_lr_scheduler(self):
+        return optim.lr_scheduler.LambdaLR(self.optimizer_D, lr_lambda=lambda epoch: 0.96 ** (epoch / 50))
+
+    def csr_norm(self, csr_mat, mean_flag=False):
+        """diag((rowsum+1e-8)^-1/2) . A [. diag((colsum+1e-8)^-1/2)]  (main.py:89-103). Host/scipy,
+        like the reference; with mean_flag=True an edge (r, c) becomes 1/sqrt(deg(r))."""
+        def inv_sqrt(v):
+            v = np.power(np.asarray(v).flatten() + 1e-8, -0.5)
+            v[np.isinf(v)] = 0.0
+            return sp.diags(v)
+        left = inv_sqrt(csr_mat.sum(1))
+        if mean_flag:
+            return left * csr_mat
+        return left * csr_mat * inv_sqrt(csr_mat.sum(0))
+
+    def matrix_to_tensor(self, cur_matrix):
+        """scipy matrix -> device graph handle (the reference returns a torch COO tensor here)."""
+        return GraphPlan(cur_matrix)
+
+    def sparse_mx_to_torch_sparse_tensor(self, sparse_mx):
+        return GraphPlan(sparse_mx)
+
+    def weights_init(self, m):
+        if isinstance(m, nn.Linear):
+            nn.init.kaiming_normal_(m.weight)
+            m.bias.data.fill_(0)
+
+    def gradient_penalty(self, D, xr, xf):
+        lam = 0.3
+        xf, xr = xf.detach(), xr.detach()
+        alpha = torch.rand(args.batch_size * 2, 1, device=xr.device).expand_as(xr)
+        inter = (alpha * xr + (1 - alpha) * xf).requires_grad_()
+        out = D(inter)
+        grads = autograd.grad(outputs=out, inputs=inter, grad_outputs=torch.ones_like(out), create_graph=True,
+                              retain_graph=True, only_inputs=True)[0]
+        return ((grads.norm(2, dim=1) - 1) ** 2).mean() * lam
+
+    def sim(self, z1, z2):
+        return torch.mm(ops.l2norm_rows(z1), ops.l2norm_rows(z2).t())
+
+    def batched_contrastive_loss(self, z1, z2, batch_size=1024):
+        """main.py:218-249 in one fused kernel sequence; `batch_size` only shaped the reference's
+        memory blocking (the result is the full-matrix formula) and is ignored."""
+        return ops.infonce(z1, z2, args.tau)
+
+    def feat_reg_loss_calculation(self, g_item_image, g_item_text, g_user_image, g_user_text):
+        feat_reg = 0.5 * ops.sumsq(g_item_image) + 0.5 * ops.sumsq(g_item_text) \
+            + 0.5 * ops.sumsq(g_user_image) + 0.5 * ops.sumsq(g_user_text)
+        return args.feat_reg_decay * (feat_reg / self.n_items)
+
+    def bpr_loss(self, users, pos_items, neg_items):
+        """(mf_loss, emb_loss, reg_loss) from already-gathered [B, d] rows (main.py:499-511)."""
+        mf_loss, emb_loss = ops.bpr(users, pos_items, neg_items, self.decay, self.batch_size)
+        return mf_loss, emb_loss, 0.0
+
+    def _seen_rows(self, users):
+        """Dense 0/1 rows of the train matrix for this batch (the reference rebuilds and uploads
+        them in every u_sim_calculation call and once more for the Gumbel step)."""
+        key, val = self._seen_cache
+        if key is not users:
+            dense = np.asarray(self.ui_graph_raw[np.asarray(users)].todense(), dtype=np.float32)
+            val = torch.from_numpy(dense).to(self.device)
+            self._seen_cache = (users, val)
+        return val
+
+    def u_sim_calculation(self, users, user_final, item_final):
+        idx = torch.as_tensor(np.asarray(users), dtype=torch.int64, device=self.device)
+        sim = torch.mm(user_final[idx], item_final.t())
+        return F.normalize(sim * (1 - self._seen_rows(users)), p=2, dim=1)
+
+    def _graphs(self):
+        return (self.ui_graph, self.iu_graph, self.image_ui_graph, self.image_iu_graph, self.text_ui_graph,
+                self.text_iu_graph)
+
+    def test(self, users_to_test, is_val):
+        self.model.eval()
+        with torch.no_grad():
+            ua_embeddings, ia_embeddings, *rest = self.model(*self._graphs())
+        return batch_test.test_torch(ua_embeddings, ia_embeddings, users_to_test, is_val, data=self.data_generator)
+
+    # ---- one batch ----------------------------------------------------------------------------
+    def _discriminator_step(self, users):
+        with torch.no_grad():
+            ua, ia, img_item, txt_item, img_user, txt_user, *_ = self.model(*self._graphs())
+        ui_u_sim = self.u_sim_calculation(users, ua, ia).detach()
+        inputf = torch.cat((self.u_sim_calculation(users, img_user, img_item).detach(),
+                            self.u_sim_calculation(users, txt_user, txt_item).detach()), dim=0)
+        lossf = self.D(inputf).mean()
+        u_ui = self._seen_rows(users)
+        noise = torch.empty_like(u_ui).uniform_(0, 1)
+        u_ui = F.softmax(u_ui - args.log_log_scale * torch.log(-torch.log(noise + 1e-8) + 1e-8) / args.real_data_tau,
+                         dim=1)
+        u_ui = F.normalize(u_ui + ui_u_sim * args.ui_pre_scale, dim=1)
+        inputr = torch.cat((u_ui, u_ui), dim=0)
+        lossr = -self.D(inputr).mean()
+        gp = self.gradient_penalty(self.D, inputr, inputf.detach())
+        loss_D = lossr + lossf + args.gp_rate * gp
+        self.optim_D.zero_grad()
+        loss_D.backward()
+        self.optim_D.step()
+        return loss_D.detach()
+
+    def _maintain_modal_graphs(self, idx, users, img_sim, txt_sim):
+        """main.py:378-405: every T-th batch (idx != 0) rebuild the four modal graphs on the host from
+        the collected (user, top-k item) pairs and clear the lists; otherwise collect."""
+        k = int(self.n_items * args.m_topk_rate)
+        if idx % args.T == 0 and idx != 0:
+            shape = (self.n_users, self.n_items)
+            for name, store in (("image", self.image_ui_index), ("text", self.text_ui_index)):
+                tmp = sp.csr_matrix((np.ones(len(store["x"]), np.float32), (store["x"], store["y"])), shape=shape)
+                setattr(self, name + "_ui_graph", self.matrix_to_tensor(self.csr_norm(tmp, mean_flag=True)))
+                setattr(self, name + "_iu_graph", self.matrix_to_tensor(self.csr_norm(tmp.T, mean_flag=True)))
+            self.image_ui_index = {"x": [], "y": []}
+            self.text_ui_index = {"x": [], "y": []}
+        else:
+            rep = np.repeat(np.asarray(users, dtype=np.int64)[None, :], k, axis=0).reshape(-1).tolist() if k else []
+            # the reference tiles the whole user list k times (tensor.repeat(1, k)), not each user k times
+            for store, s in ((self.image_ui_index, img_sim), (self.text_ui_index, txt_sim)):
+                if k:
+                    _, ids = torch.topk(s, k, dim=-1)
+                    store["x"] += rep
+                    store["y"] += ids.cpu().view(-1).tolist()
+
+    def generator_losses(self, idx, users, pos_items, neg_items, keep_masks=None, maintain_graphs=True):
+        """The generator-step loss assembly (main.py:363-420) without the optimiser step."""
+        (G_ua, G_ia, G_img_item, G_txt_item, G_img_user, G_txt_user, G_user_emb, _, G_img_uid, G_txt_uid, _, _) = \
+            self.model(*self._graphs(), keep_masks=keep_masks)
+        dev = self.device
+        u_idx = torch.as_tensor(np.asarray(users), dtype=torch.int64, device=dev)
+        p_idx = torch.as_tensor(np.asarray(pos_items), dtype=torch.int64, device=dev)
+        n_idx = torch.as_tensor(np.asarray(neg_items), dtype=torch.int64, device=dev)
+        mf_loss, emb_loss = ops.bpr_gather(G_ua, G_ia, u_idx, p_idx, n_idx, self.decay, self.batch_size)
+        reg_loss = 0.0
+        G_img_sim = self.u_sim_calculation(users, G_img_user, G_img_item)
+        G_txt_sim = self.u_sim_calculation(users, G_txt_user, G_txt_item)
+        if maintain_graphs:
+            self._maintain_modal_graphs(idx, users, G_img_sim.detach(), G_txt_sim.detach())
+        feat_emb_loss = self.feat_reg_loss_calculation(G_img_item, G_txt_item, G_img_user, G_txt_user)
+        uemb = G_user_emb[u_idx]
+        cl1 = self.batched_contrastive_loss(G_img_uid[u_idx], uemb)
+        cl2 = self.batched_contrastive_loss(G_txt_uid[u_idx], uemb)
+        G_lossf = -(self.D(torch.cat((G_img_sim, G_txt_sim), dim=0)).mean())
+        batch_loss = mf_loss + emb_loss + reg_loss + feat_emb_loss + args.cl_rate * (cl1 + cl2) \
+            + args.G_rate * G_lossf
+        return dict(batch_loss=batch_loss, mf=mf_loss, emb=emb_loss, reg=reg_loss, feat=feat_emb_loss, cl1=cl1,
+                    cl2=cl2, G_lossf=G_lossf)
+
+    def _generator_step(self, idx, users, pos_items, neg_items):
+        L = self.generator_losses(idx, users, pos_items, neg_items)
+        self.optimizer_D.zero_grad()
+        L["batch_loss"].backward(retain_graph=False)
+        self.optimizer_D.step()
+        return L["batch_loss"], L["mf"], L["emb"], L["reg"], L["cl1"] + L["cl2"], L["G_lossf"]
+
+    # ---- training loop --------------------------------------------------------------------------
+    def train(self):
+        run_time = datetime.strftime(datetime.now(), "%Y_%m_%d__%H_%M_%S")
+        dg = self.data_generator
+        stopping_step, best_recall, test_ret = 0, 0, None
+        Ks = eval(args.Ks)
+        for epoch in range(args.epoch):
+            t1 = time()
+            loss = mf_loss = emb_loss = reg_loss = 0.0
+            n_batch = dg.n_train // args.batch_size + 1
+            for idx in range(n_batch):
+                self.model.train()
+                users, pos_items, neg_items = dg.sample()
+                self._discriminator_step(users)
+                bl, mf, emb, reg, _, _ = self._generator_step(idx, users, pos_items, neg_items)
+                loss += float(bl)
+                mf_loss += float(mf)
+                emb_loss += float(emb)
+                reg_loss += float(reg)
+            if math.isnan(loss):
+                self.logger.logging("ERROR: loss is nan.")
+                sys.exit()
+            t2 = time()
+            ret = self.test(list(dg.val_set.keys()), is_val=True)
+            t3 = time()
+            if args.verbose > 0:
+                self.logger.logging(
+                    "Epoch %d [%.1fs + %.1fs]: train==[%.5f=%.5f + %.5f + %.5f], recall=[%s], precision=[%s], "
+                    "hit=[%s], ndcg=[%s]" % (epoch, t2 - t1, t3 - t2, loss, mf_loss, emb_loss, reg_loss,
+                                             *(", ".join("%.5f" % v for v in ret[k])
+                                               for k in ("recall", "precision", "hit_ratio", "ndcg"))))
+            if ret["recall"][1] > best_recall:
+                best_recall = ret["recall"][1]
+                test_ret = self.test(list(dg.test_set.keys()), is_val=False)
+                self.logger.logging("Test_Recall@%d: %.5f,  precision=[%.5f], ndcg=[%.5f]" % (
+                    Ks[1], test_ret["recall"][1], test_ret["precision"][1], test_ret["ndcg"][1]))
+                stopping_step = 0
+            elif stopping_step < args.early_stopping_patience:
+                stopping_step += 1
+                self.logger.logging("#####Early stopping steps: %d #####" % stopping_step)
+            else:
+                self.logger.logging("#####Early stop! #####")
+                break
+        self.logger.logging(str(test_ret))
+        return best_recall, run_time
+
+
+def main(argv=None):
+    configure(sys.argv[1:] if argv is None else argv)
+    torch.cuda.set_device(args.gpu_id)
+    set_seed(args.seed)
+    dg = batch_test.init_data()
+    trainer = Trainer(data_config={"n_users": dg.n_users, "n_items": dg.n_items})
+    return trainer.train()
+
+
+if __name__ == "__main__":
+    main()

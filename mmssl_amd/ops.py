@@ -145,6 +145,18 @@ def sumsq(X):
 # ---------------------------------------------------------------------------------------
 # modality projection          nn.Linear + nn.Dropout, Models.py:28-29,54,173-174
 # ---------------------------------------------------------------------------------------
+def _linear_raw(F_, W, b, keep, scale):
+    M, K = F_.shape
+    N = W.shape[0]
+    Y = torch.empty((M, N), dtype=torch.float32, device=F_.device)
+    nb = _lib.lib().mmssl_linear_workspace_bytes(M, K, N)
+    ws = torch.empty(max(nb // 4, 4), dtype=torch.float32, device=F_.device)
+    rc = _lib.lib().mmssl_linear_f32(_ptr(F_), _ptr(W), _ptr(b), _ptr(keep), float(scale), M, K, N, _ptr(Y),
+                                     _ptr(ws), ws.numel() * 4, _lib.stream_ptr())
+    _lib.check(rc, "mmssl_linear_f32")
+    return Y
+
+
 class _Linear(torch.autograd.Function):
     @staticmethod
     def forward(ctx, F_, W, b, keep, scale):
@@ -158,12 +170,7 @@ class _Linear(torch.autograd.Function):
             if keep.dtype != torch.uint8 or tuple(keep.shape) != (M, N) or not keep.is_cuda:
                 raise _lib.MmsslError("linear: keep mask must be uint8 [M, N] on the GPU")
             keep = keep.contiguous()
-        Y = torch.empty((M, N), dtype=torch.float32, device=F_.device)
-        nb = _lib.lib().mmssl_linear_workspace_bytes(M, K, N)
-        ws = torch.empty(max(nb // 4, 4), dtype=torch.float32, device=F_.device)
-        rc = _lib.lib().mmssl_linear_f32(_ptr(F_), _ptr(W), _ptr(b), _ptr(keep), float(scale), M, K, N, _ptr(Y),
-                                         _ptr(ws), ws.numel() * 4, _lib.stream_ptr())
-        _lib.check(rc, "mmssl_linear_f32")
+        Y = _linear_raw(F_, W, b, keep, scale)
         ctx.save_for_backward(F_, W, keep)
         ctx.scale = float(scale)
         ctx.has_bias = b is not None
@@ -184,10 +191,14 @@ class _Linear(torch.autograd.Function):
         rc = _lib.lib().mmssl_linear_wgrad_f32(_ptr(gY), _ptr(F_), M, K, N, _ptr(gW), _ptr(gb), _ptr(ws), nb,
                                                _lib.stream_ptr())
         _lib.check(rc, "mmssl_linear_wgrad_f32")
+        gF = None
         if ctx.needs_input_grad[0]:
-            # the reference's raw features are constants (Models.py:46-47): no input gradient path
-            raise _lib.MmsslError("linear: gradient w.r.t. the feature matrix is not part of the hot path")
-        return None, gW, (gb if ctx.has_bias else None), None, None
+            # gF = gY @ W  ([M,N] x [N,K]); used by the small modality-fusion product (K = d).
+            # The raw feature matrices are constants in the reference (Models.py:46-47).
+            if K > 256:
+                raise _lib.MmsslError("linear: input gradient only supported for K <= 256")
+            gF = _linear_raw(gY, W.t().contiguous(), None, None, 1.0)
+        return gF, gW, (gb if ctx.has_bias else None), None, None
 
 
 def linear(F_, W, b=None, keep=None, scale=1.0):

@@ -1,0 +1,190 @@
+"""GPU parity of the assembled hot path (MMSSL.forward / backward, the generator-step loss,
+a short Trainer run) against golden vectors captured from the reference and the CPU oracle."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+import helpers as H
+import mmssl_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _configure(**kw):
+    from mmssl_amd import config
+    base = dict(drop_rate=0.0, batch_size=48, debug=True)
+    base.update(kw)
+    return config.configure([], **base)
+
+
+def _model(fx, layers, weight_size, feats):
+    from mmssl_amd.Models import MMSSL
+    _configure(layers=layers)
+    m = MMSSL(feats[2], feats[3], 64, list(weight_size), [0.1] * len(weight_size), feats[0], feats[1])
+    missing, unexpected = m.load_state_dict({k[2:]: torch.from_numpy(fx[k]) for k in fx.files if k.startswith("p.")},
+                                            strict=False)
+    assert not unexpected
+    return m.to(DEV)
+
+
+def _plans(fx, raw, U, I):
+    from mmssl_amd.graph import GraphPlan
+    from mmssl_amd import synth
+
+    def pair(m):
+        a, b = O.csr_norm(m, True), O.csr_norm(m.T, True)     # host graph prep == reference csr_norm
+        return GraphPlan(a), GraphPlan(b)
+    ui, iu = pair(raw)
+    a, b = pair(H.modal_raw(fx, "img", U, I))
+    c, d = pair(H.modal_raw(fx, "txt", U, I))
+    return ui, iu, a, b, c, d
+
+
+@pytest.mark.parametrize("tag,layers", [("g2_l1", 1), ("g3_l2", 2)])
+@pytest.mark.parametrize("modal", ["full", "sparse", "empty"])
+def test_forward_matches_reference(tag, layers, modal):
+    fx = H.load("g2_forward_%s_%s.npz" % (tag, modal))
+    d, raw, U, I = H.dataset()
+    m = _model(fx, layers, fx["weight_size"], (d["image_feat"], d["text_feat"], U, I)).eval()
+    with torch.no_grad():
+        outs = m(*_plans(fx, raw, U, I))
+    assert outs[0] is outs[6] and outs[1] is outs[7] and len(outs) == 12
+    for n, o in zip(H.OUT_NAMES, outs):
+        if n in ("ua2", "ia2"):
+            continue
+        ref = fx["o." + n]
+        # folded modality fusion differs from the literal 5-D form by <= ~4e-6
+        np.testing.assert_allclose(o.cpu().numpy(), ref, rtol=2e-5, atol=2e-5, err_msg=n)
+        assert H.rel_err(o.cpu(), ref) < 1e-4 or float(np.abs(ref).max()) == 0.0, n
+
+
+def test_forward_accepts_torch_sparse_graphs():
+    """Reference handle type (torch sparse COO) in, same result as GraphPlan in."""
+    fx = H.load("g2_forward_g2_l1_sparse.npz")
+    d, raw, U, I = H.dataset()
+    m = _model(fx, 1, fx["weight_size"], (d["image_feat"], d["text_feat"], U, I)).eval()
+    plans = _plans(fx, raw, U, I)
+    coo = [O.to_torch_sparse(O.csr_norm(x, True)) for x in
+           (raw, raw.T, H.modal_raw(fx, "img", U, I), H.modal_raw(fx, "img", U, I).T,
+            H.modal_raw(fx, "txt", U, I), H.modal_raw(fx, "txt", U, I).T)]
+    with torch.no_grad():
+        a = m(*plans)
+        b = m(*coo)
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+
+
+@pytest.mark.parametrize("tag,layers", [("g2_l1", 1), ("g3_l2", 2)])
+@pytest.mark.parametrize("modal", ["full", "sparse"])
+def test_backward_matches_reference(tag, layers, modal):
+    fx = H.load("g3_backward_%s_%s.npz" % (tag, modal))
+    d, raw, U, I = H.dataset()
+    m = _model(fx, layers, fx["weight_size"], (d["image_feat"], d["text_feat"], U, I)).train()
+    outs = m(*_plans(fx, raw, U, I))
+    scalar = sum((o * torch.from_numpy(H.cotangent(k, tuple(o.shape))).to(DEV)).sum() for k, o in enumerate(outs))
+    assert abs(float(scalar) - float(fx["scalar"])) <= 1e-4 * abs(float(fx["scalar"])) + 1e-3
+    scalar.backward()
+    named = dict(m.named_parameters())
+    checked = 0
+    for k in fx.files:
+        if not k.startswith("g."):
+            continue
+        name = k[2:]
+        if name == "weight_dict.w_q":     # numerical-noise-only gradient in the reference (|g| ~ 1e-9)
+            assert float(np.abs(fx[k]).max()) < 1e-5
+            continue
+        got = named[name].grad
+        assert got is not None, name
+        assert H.rel_err(got.cpu(), fx[k]) < 1e-4, (name, H.rel_err(got.cpu(), fx[k]))
+        checked += 1
+    assert checked >= 7
+
+
+def _trainer(tmp_path, **kw):
+    from mmssl_amd import config
+    from mmssl_amd.utility import batch_test
+    root = H.write_dataset_dir(str(tmp_path))
+    _configure(data_path=root, dataset="tiny", **kw)
+    batch_test.init_data()
+    from mmssl_amd.main import Trainer, set_seed
+    set_seed(2022)
+    return Trainer(data_config={})
+
+
+@pytest.mark.parametrize("modal", ["full", "empty"])
+def test_generator_step_assembly_matches_reference(tmp_path, modal):
+    fx = H.load("g8_gstep_%s.npz" % modal)
+    d, raw, U, I = H.dataset()
+    tr = _trainer(tmp_path)
+    tr.model.load_state_dict({k[2:]: torch.from_numpy(fx[k]) for k in fx.files if k.startswith("p.")}, strict=False)
+    tr.D.load_state_dict({k[2:]: torch.from_numpy(fx[k]) for k in fx.files if k.startswith("D.")})
+    tr.D.eval()
+    tr.model.train()
+    ui, iu, a, b, c, dd = _plans(fx, raw, U, I)
+    tr.image_ui_graph, tr.image_iu_graph, tr.text_ui_graph, tr.text_iu_graph = a, b, c, dd
+    L = tr.generator_losses(0, fx["users"].tolist(), fx["pos"].tolist(), fx["neg"].tolist(), maintain_graphs=False)
+    for k in ("mf", "emb", "feat", "cl1", "cl2", "G_lossf", "batch_loss"):
+        ref = float(fx[k])
+        assert abs(float(L[k]) - ref) <= 1e-4 * abs(ref), (k, float(L[k]), ref)     # north_star: 1e-4 relative
+    L["batch_loss"].backward()
+    named = dict(tr.model.named_parameters())
+    for k in fx.files:
+        if k.startswith("g.") and k != "g.weight_dict.w_q":
+            assert H.rel_err(named[k[2:]].grad.cpu(), fx[k]) < 2e-4, k
+
+
+def test_trainer_batches_and_empty_graph_steady_state(tmp_path):
+    """Three batches of the real loop: graphs rebuilt at idx=1 (k = int(96*1e-4) = 0 -> empty), so
+    from then on InfoNCE == -log(1/(2B-1)+1e-8); then a validation pass."""
+    tr = _trainer(tmp_path, drop_rate=0.2)
+    dg = tr.data_generator
+    cls = []
+    for idx in range(3):
+        tr.model.train()
+        users, pos, neg = dg.sample()
+        tr._discriminator_step(users)
+        bl, mf, emb, reg, cl, gl = tr._generator_step(idx, users, pos, neg)
+        assert math.isfinite(float(bl))
+        cls.append(float(cl))
+    assert tr.image_ui_graph._nnz() == 0 and tr.text_iu_graph._nnz() == 0
+    B = 48
+    assert abs(cls[2] - 2 * (-math.log(1.0 / (2 * B - 1) + 1e-8))) < 1e-4
+    ret = tr.test(list(dg.val_set.keys()), is_val=True)
+    assert ret["recall"].shape == (3,) and 0.0 <= ret["recall"][1] <= 1.0
+
+
+def test_train_step_with_injected_dropout_matches_oracle(tmp_path):
+    """Identical parameters + identical dropout masks -> same loss and gradients as the oracle
+    (dropout RNG streams cannot match across devices: SURVEY 7.2-6)."""
+    fx = H.load("g8_gstep_full.npz")
+    d, raw, U, I = H.dataset()
+    tr = _trainer(tmp_path, drop_rate=0.2)
+    tr.model.load_state_dict({k[2:]: torch.from_numpy(fx[k]) for k in fx.files if k.startswith("p.")}, strict=False)
+    tr.model.train()
+    gen = torch.Generator().manual_seed(1)
+    km = [(torch.rand(I, 64, generator=gen) >= 0.2) for _ in range(2)]
+    graphs = tuple(O.to_torch_sparse(O.csr_norm(x, True)) for x in (raw, raw.T, raw, raw.T, raw, raw.T))
+    P = H.params(fx, requires_grad=True)
+    cfg = O.Cfg(drop_rate=0.2, batch_size=48, layers=1, n_ui_layers=2)
+    o = O.forward(P, torch.from_numpy(d["image_feat"]), torch.from_numpy(d["text_feat"]), graphs, cfg,
+                  training=True, keep_masks=[k.float() for k in km])
+    users, pos, neg = (torch.from_numpy(fx[k]) for k in ("users", "pos", "neg"))
+    mf, emb, _ = O.bpr(o[0][users], o[1][pos], o[1][neg], 1e-5, 48)
+    ref = mf + emb + O.feat_reg(o[2], o[3], o[4], o[5], I, 1e-5) + 0.03 * (
+        O.infonce(o[8][users], o[6][users], 0.5) + O.infonce(o[9][users], o[6][users], 0.5))
+    ref.backward()
+    from mmssl_amd import ops
+    og = tr.model(*tr._graphs(), keep_masks=[k.to(torch.uint8).to(DEV) for k in km])
+    ug = users.to(DEV)
+    mfg, embg = ops.bpr_gather(og[0], og[1], ug, pos.to(DEV), neg.to(DEV), 1e-5, 48)
+    got = mfg + embg + tr.feat_reg_loss_calculation(og[2], og[3], og[4], og[5]) + 0.03 * (
+        tr.batched_contrastive_loss(og[8][ug], og[6][ug]) + tr.batched_contrastive_loss(og[9][ug], og[6][ug]))
+    assert abs(float(got) - float(ref)) <= 1e-4 * abs(float(ref))
+    got.backward()
+    named = dict(tr.model.named_parameters())
+    for k in ("image_trans.weight", "image_trans.bias", "text_trans.weight", "user_id_embedding.weight",
+              "item_id_embedding.weight", "weight_dict.w_self_attention_cat"):
+        assert H.rel_err(named[k].grad.cpu(), P[k].grad) < 2e-4, k

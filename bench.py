@@ -1,0 +1,288 @@
+#!/usr/bin/env python
+"""bench.py — the MMSSL hot path on N MI355X GPUs (one process per GPU).
+
+    python bench.py --gpus 1 --steps 50 --warmup 10
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path over one batch of synthetic input: MMSSL forward (V/T
+projection, modal + 3-layer GCN SpMM propagation, fusion) -> BPR + 2x InfoNCE + feature
+regulariser -> backward -> AdamW — the reference's generator step (main.py:363-429) without the
+adjacent GAN pieces. Inputs (graph, features, parameters, batch indices) are resident in HBM
+before the timed region. Workload at N=1: the Amazon-Baby shape BASELINE.json quotes the metric on
+(35598 x 18357, 256308 edges, V4096/T1024, d=64, B=1024), seeded synthetic data. At N>1 the graph is the
+same shape scaled N x (weak scaling) and row-sharded with RCCL all-gather before every
+propagation layer.
+
+metric = edge.layers/s: nonzeros summed over EVERY SpMM launch of the step (forward and
+backward) / step time, whole job. One JSON line is printed by rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0        # MI355X HBM3E spec (guides/MI355X_MICROARCH.md)
+
+
+def make_batches(raw, n_batches, B, seed):
+    """Synthetic BPR triples resident on the device: B distinct users, one of their items, one
+    item they did not interact with (vectorised stand-in for Data.sample(); the sampler itself is
+    host Python and outside the timed hot path)."""
+    rng = np.random.default_rng(seed)
+    U, I = raw.shape
+    indptr, indices = raw.indptr, raw.indices
+    active = np.nonzero(np.diff(indptr) > 0)[0]
+    out = []
+    for _ in range(n_batches):
+        users = rng.choice(active, size=B, replace=B > active.shape[0])
+        deg = indptr[users + 1] - indptr[users]
+        pos = indices[indptr[users] + (rng.random(B) * deg).astype(np.int64)]
+        neg = rng.integers(0, I, size=B)
+        for _ in range(8):      # rejection against the user's own items
+            bad = np.array([n in indices[indptr[u]:indptr[u + 1]] for u, n in zip(users, neg)])
+            if not bad.any():
+                break
+            neg[bad] = rng.integers(0, I, size=int(bad.sum()))
+        out.append((users.astype(np.int64), pos.astype(np.int64), neg.astype(np.int64)))
+    return out
+
+
+def build_single_gpu(a, dev):
+    from mmssl_amd import config, synth
+    from mmssl_amd.graph import GraphPlan
+    from mmssl_amd.hotpath import HotPathStep
+    from mmssl_amd.Models import MMSSL
+    import scipy.sparse as sp
+    U, I, E, dv, dt = synth.SHAPES[a.workload]
+    if a.workload == "synth":
+        raise SystemExit("the 'synth' stress shape is an 8-GPU configuration (use --gpus 8)")
+    config.configure([], embed_size=a.d, weight_size=str([a.d] * a.gcn_layers), batch_size=a.batch,
+                     drop_rate=0.2, layers=1)
+    raw = synth.interaction_matrix(U, I, E, seed=1)
+    ui, iu = synth.normalised_pair(raw)
+    plans = [GraphPlan(ui), GraphPlan(iu)]
+    # steady state of the reference loop: modal graphs are empty from the third batch on
+    e_ui = GraphPlan(sp.csr_matrix((U, I), dtype=np.float32))
+    e_iu = GraphPlan(sp.csr_matrix((I, U), dtype=np.float32))
+    graphs = (plans[0], plans[1], e_ui, e_iu, e_ui, e_iu)
+    torch.manual_seed(2022)
+    g = torch.Generator().manual_seed(7)
+    img = torch.randn(I, dv, generator=g).numpy()
+    txt = torch.randn(I, dt, generator=g).numpy()
+    model = MMSSL(U, I, a.d, [a.d] * a.gcn_layers, [0.1] * a.gcn_layers, img, txt).to(dev)
+    model.train()
+    step = HotPathStep(model, graphs, a.batch, decay=1e-5)
+    return step, raw, (ui, iu), plans
+
+
+def count_edge_layers(step):
+    from mmssl_amd import ops
+    ops.STATS.update(enabled=True, spmm_launches=0, edge_layers=0, spmm_bytes=0)
+    step.step()
+    torch.cuda.synchronize()
+    ops.STATS["enabled"] = False
+    return dict(ops.STATS)
+
+
+def spmm_roofline(plans, mats, d, iters=200):
+    """Average duration of the dominant kernel (the CSR SpMM, all four launch flavours of the
+    step: A_ui, A_iu and their transposes) from HIP events on the launch stream, against the
+    algorithmic bytes per launch (nnz*(8+4d) + rows*4d + (rows+1)*4)."""
+    from mmssl_amd import ops, synth
+    dev = "cuda"
+    ui, iu = mats
+    X = {ui.shape[1]: torch.randn(ui.shape[1], d, device=dev), ui.shape[0]: torch.randn(ui.shape[0], d, device=dev)}
+    launches = [(plans[0], False, ui), (plans[1], False, iu), (plans[0], True, ui.T.tocsr()), (plans[1], True, iu.T.tocsr())]
+    nbytes = [synth.spmm_bytes(m, d) for _, _, m in launches]
+    with torch.no_grad():
+        def one_round():
+            for (p, t, m) in launches:
+                ops.spmm(p, X[m.shape[1]], transpose=t)
+        for _ in range(10):
+            one_round()
+        g = torch.cuda.CUDAGraph()
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            torch.cuda.synchronize()
+            with torch.cuda.graph(g, stream=s):
+                for _ in range(10):
+                    one_round()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        g.replay()
+        e0.record()
+        for _ in range(iters // 10):
+            g.replay()
+        e1.record()
+        torch.cuda.synchronize()
+    n_launch = (iters // 10) * 10 * len(launches)
+    avg_us = e0.elapsed_time(e1) * 1e3 / n_launch
+    avg_bytes = float(np.mean(nbytes))
+    achieved = avg_bytes / avg_us * 1e-3      # GB/s
+    return {"bound": "hbm", "kernel": "spmm_kernel<16> (CSR SpMM d=%d)" % d, "achieved": round(achieved, 1),
+            "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
+            "avg_launch_us": round(avg_us, 2), "algorithmic_bytes_per_launch": int(avg_bytes),
+            "traffic": load_traffic()}
+
+
+def load_traffic():
+    """HBM bytes per SpMM launch from the committed rocprofv3 PMC pass (profiles/*_pmc.json), if any."""
+    p = os.path.join(ROOT, "profiles", "spmm_pmc.json")
+    if os.path.exists(p):
+        try:
+            return json.load(open(p)).get("hbm_bytes_per_launch")
+        except Exception:
+            return None
+    return None
+
+
+def cpu_baseline(a, raw, mats, budget_s=20.0):
+    """The CPU oracle (torch-CPU restatement of the reference path, 'port') on this box's host cores:
+    the same step (forward + losses + backward; torch COO sparse.mm like the reference), a bounded
+    number of iterations."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import mmssl_oracle as O
+    from mmssl_amd import synth
+    import scipy.sparse as sp
+    U, I, E, dv, dt = synth.SHAPES[a.workload]
+    torch.set_num_threads(os.cpu_count() or 1)
+    ui, iu = mats
+    A_ui, A_iu = O.to_torch_sparse(ui).coalesce(), O.to_torch_sparse(iu).coalesce()
+    e_ui = O.to_torch_sparse(sp.csr_matrix((U, I), dtype=np.float32))
+    e_iu = O.to_torch_sparse(sp.csr_matrix((I, U), dtype=np.float32))
+    graphs = (A_ui, A_iu, e_ui, e_iu, e_ui, e_iu)
+    g = torch.Generator().manual_seed(7)
+    d = a.d
+    img, txt = torch.randn(I, dv, generator=g), torch.randn(I, dt, generator=g)
+    P = {"image_trans.weight": torch.randn(d, dv) * 0.02, "image_trans.bias": torch.zeros(d),
+         "text_trans.weight": torch.randn(d, dt) * 0.02, "text_trans.bias": torch.zeros(d),
+         "user_id_embedding.weight": torch.randn(U, d) * 0.01, "item_id_embedding.weight": torch.randn(I, d) * 0.01,
+         "weight_dict.w_q": torch.randn(d, d) * 0.1, "weight_dict.w_self_attention_cat": torch.randn(4 * d, d) * 0.1}
+    for v in P.values():
+        v.requires_grad_(True)
+    cfg = O.Cfg(embed_size=d, n_ui_layers=a.gcn_layers, layers=1, drop_rate=0.2, batch_size=a.batch)
+    users, pos, neg = (torch.from_numpy(x) for x in make_batches(raw, 1, a.batch, 3)[0])
+    keep = [(torch.rand(I, d) >= 0.2).float() for _ in range(2)]
+    n_spmm = 2 * (4 + 2 * a.gcn_layers)     # nonzero-graph launches, forward + backward
+
+    def step():
+        for v in P.values():
+            v.grad = None
+        o = O.forward(P, img, txt, graphs, cfg, training=True, keep_masks=keep)
+        mf, emb, _ = O.bpr(o[0][users], o[1][pos], o[1][neg], 1e-5, a.batch)
+        loss = mf + emb + O.feat_reg(o[2], o[3], o[4], o[5], I, 1e-5) + 0.03 * (
+            O.infonce(o[8][users], o[6][users], 0.5) + O.infonce(o[9][users], o[6][users], 0.5))
+        loss.backward()
+    step()
+    t0 = time.time()
+    n = 0
+    while True:
+        step()
+        n += 1
+        if time.time() - t0 > budget_s or n >= 20:
+            break
+    dt_s = (time.time() - t0) / n
+    return {"value": round(n_spmm * raw.nnz / dt_s, 1), "unit": "edge.layers/s", "cores": torch.get_num_threads(),
+            "kind": "port", "ms_per_step": round(dt_s * 1e3, 1),
+            "sample": "%d steps of the same %s-shape step (fwd+losses+bwd, no optimiser) by oracle/mmssl_oracle.py "
+                      "on torch-CPU COO sparse.mm" % (n, a.workload)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--workload", default="baby")
+    ap.add_argument("--d", type=int, default=64)
+    ap.add_argument("--gcn-layers", type=int, default=3, dest="gcn_layers")
+    ap.add_argument("--batch", type=int, default=1024)
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit("--gpus %d needs the torch.distributed.run launcher (one rank per GPU)" % a.gpus)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    if world == 1:
+        step, raw, mats, plans = build_single_gpu(a, dev)
+        stats = count_edge_layers(step)
+        captured = (not a.no_graph) and step.capture()
+        edge_layers_total = stats["edge_layers"]
+        parallelism = "single"
+    else:
+        from mmssl_amd import dist as mdist
+        step, raw, mats, plans, stats = mdist.build_bench_step(a, rank, world, dev)
+        captured = False
+        edge_layers_total = stats["edge_layers_global"]
+        parallelism = "row-shard x%d (RCCL all-gather / reduce-scatter)" % world
+
+    batches = [tuple(torch.from_numpy(x).to(dev) for x in b)
+               for b in make_batches(raw, 8, a.batch, seed=2022)]
+
+    def run_steps(n):
+        for i in range(n):
+            step.set_batch(*batches[i % len(batches)])
+            step.run()
+
+    run_steps(a.warmup)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run_steps(a.steps)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    loss = float(step.loss)
+    ms = elapsed * 1e3 / a.steps
+    out = {
+        "metric": "edge.layers/s (nonzeros of every SpMM launch per hot-path step / step time)",
+        "value": round(edge_layers_total / (ms * 1e-3), 1), "unit": "edge.layers/s", "n_gpus": world,
+        "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 4), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "%s-shaped graph%s, d=%d, %d-layer GCN + V/T projection + InfoNCE x2 + BPR + "
+                               "feat-reg, fwd+bwd+AdamW, B=%d" % (
+                                   a.workload, "" if world == 1 else " x%d (weak)" % world, a.d, a.gcn_layers, a.batch),
+                   "n_users": int(raw.shape[0]), "n_items": int(raw.shape[1]), "n_edges": int(raw.nnz),
+                   "edge_layers_per_step": int(edge_layers_total), "spmm_launches_per_step": int(stats["spmm_launches"]),
+                   "launch": "hipGraph replay" if captured else "eager", "parallelism": parallelism,
+                   "final_loss": round(loss, 6)},
+    }
+    if rank == 0:
+        if world == 1:
+            out["roofline"] = spmm_roofline(plans, mats, a.d)
+            if not a.no_cpu_baseline:
+                out["cpu_baseline"] = cpu_baseline(a, raw, mats)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,86 @@
+"""The data-parallel hot path as ONE replayable unit: model forward -> BPR + InfoNCE x2 +
+feature regulariser -> backward -> AdamW, i.e. the generator step of the reference loop
+(/root/reference/MMSSL/main.py:363-429) without the adjacent adversarial pieces (Discriminator /
+u_sim / gradient penalty: SURVEY.md section 2 rows 3 and 7, out of the hot-path scope).
+
+All launches (hand-written HIP kernels through the C ABI + a few torch elementwise/optimizer
+kernels) go to one stream and can be captured once into a hipGraph and replayed, which removes
+the host launch gaps that dominate at these problem sizes (a Baby-shape SpMM is ~15 us).
+"""
+import torch
+
+from . import ops
+from .config import args
+
+
+class HotPathStep:
+    def __init__(self, model, graphs, batch_size, decay=1e-5, lr=None, capturable=True):
+        self.model = model
+        self.graphs = tuple(graphs)
+        self.batch_size = int(batch_size)
+        self.decay = float(decay)
+        dev = model.user_id_embedding.weight.device
+        self.users = torch.zeros(batch_size, dtype=torch.int64, device=dev)
+        self.pos = torch.zeros(batch_size, dtype=torch.int64, device=dev)
+        self.neg = torch.zeros(batch_size, dtype=torch.int64, device=dev)
+        self.optimizer = torch.optim.AdamW([{"params": model.parameters()}], lr=lr or args.lr,
+                                           capturable=capturable)
+        self.loss = torch.zeros((), device=dev)
+        self.parts = {}
+        self._graph = None
+
+    def set_batch(self, users, pos, neg):
+        """Device-to-device copies into the static index buffers (graph replays read these)."""
+        self.users.copy_(users, non_blocking=True)
+        self.pos.copy_(pos, non_blocking=True)
+        self.neg.copy_(neg, non_blocking=True)
+
+    def losses(self):
+        m = self.model
+        (ua, ia, img_item, txt_item, img_user, txt_user, uemb, _, img_uid, txt_uid, _, _) = m(*self.graphs)
+        mf, emb = ops.bpr_gather(ua, ia, self.users, self.pos, self.neg, self.decay, self.batch_size)
+        feat = args.feat_reg_decay * ((0.5 * ops.sumsq(img_item) + 0.5 * ops.sumsq(txt_item)
+                                       + 0.5 * ops.sumsq(img_user) + 0.5 * ops.sumsq(txt_user)) / m.n_items)
+        z2 = uemb[self.users]
+        cl1 = ops.infonce(img_uid[self.users], z2, args.tau)
+        cl2 = ops.infonce(txt_uid[self.users], z2, args.tau)
+        total = mf + emb + feat + args.cl_rate * (cl1 + cl2)
+        return total, dict(mf=mf, emb=emb, feat=feat, cl1=cl1, cl2=cl2)
+
+    def step(self):
+        self.optimizer.zero_grad(set_to_none=True)
+        total, parts = self.losses()
+        total.backward()
+        self.optimizer.step()
+        self.loss.copy_(total.detach())
+        return total
+
+    # ---- hipGraph capture ---------------------------------------------------------------------
+    def capture(self, warmup=3):
+        """Warm up on a side stream, then capture one full step. Returns True on success;
+        on failure the object stays usable in eager mode."""
+        self.model.train()
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        try:
+            with torch.cuda.stream(s):
+                for _ in range(warmup):
+                    self.step()
+            torch.cuda.current_stream().wait_stream(s)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self.step()
+            self._graph = g
+            return True
+        except Exception as e:       # pragma: no cover - depends on the runtime
+            self._graph = None
+            self.capture_error = repr(e)
+            torch.cuda.synchronize()
+            return False
+
+    def run(self):
+        if self._graph is not None:
+            self._graph.replay()
+        else:
+            self.step()

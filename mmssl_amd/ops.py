@@ -13,6 +13,8 @@ from .graph import GraphPlan
 
 EPI_NONE = 0
 EPI_SOFTMAX = 1
+# launch accounting for bench.py (edge.layers = nonzeros of every SpMM launch)
+STATS = {"enabled": False, "spmm_launches": 0, "edge_layers": 0, "spmm_bytes": 0}
 _NORM_EPS = 1e-12        # F.normalize default eps
 
 
@@ -37,6 +39,10 @@ def _spmm_raw(plan, transpose, X, epilogue):
     if X.dim() != 2 or X.shape[0] != cols:
         raise _lib.MmsslError("spmm: X has shape %s, expected [%d, d]" % (tuple(X.shape), cols))
     d = X.shape[1]
+    if STATS["enabled"]:
+        STATS["spmm_launches"] += 1
+        STATS["edge_layers"] += plan.nnz
+        STATS["spmm_bytes"] += plan.nnz * (8 + 4 * d) + rows * 4 * d + (rows + 1) * 4
     Y = torch.empty((rows, d), dtype=torch.float32, device=X.device)
     ws = plan.workspace(transpose, d)
     rc = _lib.lib().mmssl_spmm_f32(plan.handle, int(transpose), _ptr(X), d, _ptr(Y), epilogue, _ptr(ws),

@@ -200,7 +200,7 @@ def test_infonce_golden_and_oracle():
         ag = a.clone().to(DEV).requires_grad_(True); bg = b.clone().to(DEV).requires_grad_(True)
         lg = ops.infonce(ag, bg, 0.5)
         (lg * 1.7).backward()
-        assert abs(float(lg) - float(lr)) <= 1e-5 * abs(float(lr)) + 1e-7, (n, d)
+        assert abs(float(lg) - float(lr)) <= 1e-5 * abs(float(lr)) + 3e-7, (n, d)   # n=1: log(1+1e-8) noise
         assert H.rel_err(ag.grad.cpu(), ar.grad) < 2e-4, (n, d)
         assert H.rel_err(bg.grad.cpu(), br.grad) < 2e-4, (n, d)
 

@@ -197,6 +197,19 @@ def cpu_baseline(a, raw, mats, budget_s=20.0):
                       "on torch-CPU COO sparse.mm" % (n, a.workload)}
 
 
+def graph_capture_works(a):
+    """A failed hipGraph capture can take the process down (runtime abort), so it is tried in a
+    child process on a small shape first; on failure the bench falls back to eager launches."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--graph-probe", "--workload", "tiktok", "--d", str(a.d),
+           "--gcn-layers", str(a.gcn_layers), "--batch", str(a.batch)]
+    try:
+        r = subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=300)
+        return r.returncode == 0
+    except Exception:
+        return False
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -208,6 +221,7 @@ def main():
     ap.add_argument("--batch", type=int, default=1024)
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--graph-probe", action="store_true", help=argparse.SUPPRESS)
     a = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -225,7 +239,13 @@ def main():
     if world == 1:
         step, raw, mats, plans = build_single_gpu(a, dev)
         stats = count_edge_layers(step)
-        captured = (not a.no_graph) and step.capture()
+        if a.graph_probe:            # child process: does whole-step hipGraph capture + replay work here?
+            ok = step.capture()
+            if ok:
+                step.run()
+                torch.cuda.synchronize()
+            sys.exit(0 if ok else 3)
+        captured = (not a.no_graph) and graph_capture_works(a) and step.capture()
         edge_layers_total = stats["edge_layers"]
         parallelism = "single"
     else:

@@ -6,6 +6,11 @@ loudly (RuntimeError) instead of silently computing something else.
 """
 import ctypes
 import os
+
+# torch MUST be imported before libmmssl_hip.so is loaded: the torch wheel bundles its own HIP
+# runtime under the same SONAME (libamdhip64.so.7) as /opt/rocm's. Whichever is loaded first serves
+# both, and streams / device pointers are only interchangeable inside ONE runtime instance.
+import torch  # noqa: F401
 from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -96,5 +101,4 @@ def check(code, what):
 
 def stream_ptr():
     """hipStream_t of torch's current stream on the current device."""
-    import torch
     return torch.cuda.current_stream().cuda_stream

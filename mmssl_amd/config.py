@@ -18,3 +18,23 @@ def configure(argv=None, **overrides):
     for k, v in overrides.items():
         setattr(args, k, v)
     return args
+
+
+class HotCfg:
+    """The live hot-path flags as plain attributes (what the sharded model / step read)."""
+
+    def __init__(self, **over):
+        a = args
+        self.embed_size = a.embed_size
+        self.head_num = a.head_num
+        self.n_ui_layers = len(eval(a.weight_size))
+        self.drop_rate = float(a.drop_rate)
+        self.model_cat_rate = a.model_cat_rate
+        self.id_cat_rate = a.id_cat_rate
+        self.tau = a.tau
+        self.cl_rate = a.cl_rate
+        self.feat_reg_decay = a.feat_reg_decay
+        self.decay = eval(a.regs)[0]
+        self.batch_size = a.batch_size
+        for k, v in over.items():
+            setattr(self, k, v)

@@ -53,12 +53,14 @@ class HotPathStep:
         total.backward()
         self.optimizer.step()
         self.loss.copy_(total.detach())
-        return total
+        return total.detach()
 
     # ---- hipGraph capture ---------------------------------------------------------------------
     def capture(self, warmup=3):
-        """Warm up on a side stream, then capture one full step. Returns True on success;
-        on failure the object stays usable in eager mode."""
+        """Warm up and capture one full step ON THE SAME side stream (autograd's AccumulateGrad
+        nodes are bound to the stream of the first backward; capturing on another stream makes
+        them synchronise across streams inside the capture, which the HIP runtime rejects).
+        Returns True on success; the object stays usable in eager mode otherwise."""
         self.model.train()
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
@@ -66,11 +68,12 @@ class HotPathStep:
             with torch.cuda.stream(s):
                 for _ in range(warmup):
                     self.step()
-            torch.cuda.current_stream().wait_stream(s)
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            with torch.cuda.graph(g, stream=s):
                 self.step()
+            torch.cuda.current_stream().wait_stream(s)
+            torch.cuda.synchronize()
             self._graph = g
             return True
         except Exception as e:       # pragma: no cover - depends on the runtime

@@ -344,26 +344,40 @@ __global__ __launch_bounds__(kBlock) void spmm_kernel(const int4* __restrict__ g
   }
 }
 
-// second stage for rows cut into several wave items: fixed-order sum of their partial slots
+// second stage for rows cut into several wave items: one block per such row. Lane group g
+// adds slots g, g+GPB, ... (independent loads), the GPB group sums are combined through LDS in a
+// fixed order -> bitwise reproducible, and the serial depth is slots/GPB instead of slots.
 template <int LPR, int EPI>
 __global__ __launch_bounds__(kBlock) void spmm_multi_kernel(const int4* __restrict__ multi, int n_multi,
                                                             const float4* __restrict__ partials,
                                                             float4* __restrict__ Y) {
   constexpr int GPB = kBlock / LPR;
+  __shared__ float4 red[kBlock];
   const int lig = threadIdx.x & (LPR - 1);
-  const int mi = (int)blockIdx.x * GPB + (int)threadIdx.x / LPR;
-  if (mi >= n_multi) return;
-  const int4 it = multi[mi];
+  const int grp = threadIdx.x / LPR;
+  const int4 it = multi[blockIdx.x];
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int k = 0; k < it.z; ++k) {
+  for (int k = grp; k < it.z; k += GPB) {
     const float4 p = partials[(size_t)(it.y + k) * LPR + lig];
     acc.x += p.x;
     acc.y += p.y;
     acc.z += p.z;
     acc.w += p.w;
   }
-  if (EPI == MMSSL_EPI_SOFTMAX) acc = row_softmax<LPR>(acc);
-  Y[(size_t)it.x * LPR + lig] = acc;
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  if (grp == 0) {
+    const int used = it.z < GPB ? it.z : GPB;
+    for (int g = 1; g < used; ++g) {
+      const float4 p = red[g * LPR + lig];
+      acc.x += p.x;
+      acc.y += p.y;
+      acc.z += p.z;
+      acc.w += p.w;
+    }
+    if (EPI == MMSSL_EPI_SOFTMAX) acc = row_softmax<LPR>(acc);
+    Y[(size_t)it.x * LPR + lig] = acc;
+  }
 }
 
 template <int LPR, int EPI>
@@ -379,8 +393,7 @@ int launch_spmm(const DirPlan& p, const float* X, float* Y, float* partials, hip
     MMSSL_LAUNCH_CHECK();
   }
   if (p.n_multi > 0) {
-    const int nb = (int)((p.n_multi + GPB - 1) / GPB);
-    hipLaunchKernelGGL((spmm_multi_kernel<LPR, EPI>), dim3(nb), dim3(kBlock), 0, s, p.multi,
+    hipLaunchKernelGGL((spmm_multi_kernel<LPR, EPI>), dim3((unsigned)p.n_multi), dim3(kBlock), 0, s, p.multi,
                        (int)p.n_multi, reinterpret_cast<const float4*>(partials),
                        reinterpret_cast<float4*>(Y));
     MMSSL_LAUNCH_CHECK();

@@ -55,7 +55,7 @@ inline Layout make_layout(int64_t n, int d) {
   L.n2 = take((size_t)n * d);
   L.inv1 = take(n); L.inv2 = take(n); L.pos = take(n); L.w = take(n); L.c = take(n);
   L.rows_part = take((size_t)L.cs_f * n);
-  L.loss = take(4);
+  L.loss = take((size_t)(n + kBlock - 1) / kBlock + 4);
   L.g1p = take((size_t)L.cs_b * n * d);
   L.g2p = take((size_t)L.cs_b * n * d);
   L.total = o;
@@ -183,22 +183,32 @@ __global__ __launch_bounds__(kBlock) void fwd_tiles_kernel(const float* __restri
   }
 }
 
-// ---- finalize: loss + per-row backward coefficients -----------------------------------------
-__global__ __launch_bounds__(kBlock) void finalize_kernel(const float* __restrict__ rows_part, int cs,
-                                                          const float* __restrict__ pos, int64_t n,
-                                                          float tau, float* __restrict__ w,
-                                                          float* __restrict__ c, float* __restrict__ loss) {
+// ---- finalize: per-row backward coefficients (row-parallel) + loss (fixed-order two-stage sum) ----
+__global__ __launch_bounds__(kBlock) void finalize_rows_kernel(const float* __restrict__ rows_part, int cs,
+                                                               const float* __restrict__ pos, int64_t n,
+                                                               float tau, float* __restrict__ w,
+                                                               float* __restrict__ c,
+                                                               float* __restrict__ loss_part) {
   __shared__ float red[4];
-  float acc = 0.f;
-  for (int64_t i = threadIdx.x; i < n; i += kBlock) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  float li = 0.f;
+  if (i < n) {
     float Dn = 0.f;
     for (int s = 0; s < cs; ++s) Dn += rows_part[(size_t)s * n + i];
     const float q = expf(pos[i] / tau) / Dn;
-    acc += -logf(q + 1e-8f);
+    li = -logf(q + 1e-8f);
     const float wi = -(q / (q + 1e-8f)) / (float)n;
     w[i] = wi;
     c[i] = wi / (Dn * tau);
   }
+  const float t = block_sum_256(li, red);
+  if (threadIdx.x == 0) loss_part[blockIdx.x] = t;
+}
+__global__ __launch_bounds__(kBlock) void finalize_loss_kernel(const float* __restrict__ loss_part, int nparts,
+                                                               int64_t n, float* __restrict__ loss) {
+  __shared__ float red[4];
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < nparts; i += kBlock) acc += loss_part[i];
   const float t = block_sum_256(acc, red);
   if (threadIdx.x == 0) loss[0] = t / (float)n;
 }
@@ -399,8 +409,11 @@ extern "C" int mmssl_infonce_fwd_f32(const float* z1, const float* z2, int64_t n
     case 256: hipLaunchKernelGGL((fwd_tiles_kernel<256>), grid, dim3(kBlock), 0, s, ws + L.n1, ws + L.n2, n, tau, L.cs_f, ws + L.rows_part); break;
   }
   MMSSL_LAUNCH_CHECK();
-  hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(kBlock), 0, s, ws + L.rows_part, L.cs_f, ws + L.pos, n, tau,
-                     ws + L.w, ws + L.c, loss);
+  const int fb = (int)((n + kBlock - 1) / kBlock);
+  hipLaunchKernelGGL(finalize_rows_kernel, dim3(fb), dim3(kBlock), 0, s, ws + L.rows_part, L.cs_f, ws + L.pos, n,
+                     tau, ws + L.w, ws + L.c, ws + L.loss);
+  MMSSL_LAUNCH_CHECK();
+  hipLaunchKernelGGL(finalize_loss_kernel, dim3(1), dim3(kBlock), 0, s, ws + L.loss, fb, n, loss);
   MMSSL_LAUNCH_CHECK();
   return 0;
 }

@@ -131,18 +131,30 @@ __global__ __launch_bounds__(kBlock) void gemm64_kernel(const float* __restrict_
   }
 }
 
-// out[e] = epilogue(sum_s P[s][e]);  e = row*J + col
+// out[e] = epilogue(sum_s P[s][e]);  e = row*J + col.  Split loads are issued four at a time
+// (independent) so the loop is bandwidth- not latency-bound; the add order is fixed.
 __global__ __launch_bounds__(kBlock) void splitk_reduce_kernel(const float* __restrict__ P, int splits,
                                                                int64_t total, int64_t J,
                                                                const float* __restrict__ bias,
                                                                const uint8_t* __restrict__ keep, float scale,
                                                                float* __restrict__ out) {
   const int64_t n4 = total >> 2;   // J % 4 == 0 -> total % 4 == 0
+  const int64_t t4 = total >> 2;
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n4; i += (int64_t)gridDim.x * kBlock) {
-    float4 v = reinterpret_cast<const float4*>(P)[i];
-    for (int s = 1; s < splits; ++s) {
-      const float4 x = reinterpret_cast<const float4*>(P + (int64_t)s * total)[i];
-      v.x += x.x; v.y += x.y; v.z += x.z; v.w += x.w;
+    const float4* p = reinterpret_cast<const float4*>(P) + i;
+    float4 v = p[0];
+    int s = 1;
+    for (; s + 3 < splits; s += 4) {
+      const float4 a = p[(int64_t)s * t4], b = p[(int64_t)(s + 1) * t4];
+      const float4 c = p[(int64_t)(s + 2) * t4], d = p[(int64_t)(s + 3) * t4];
+      v.x = (((v.x + a.x) + b.x) + c.x) + d.x;
+      v.y = (((v.y + a.y) + b.y) + c.y) + d.y;
+      v.z = (((v.z + a.z) + b.z) + c.z) + d.z;
+      v.w = (((v.w + a.w) + b.w) + c.w) + d.w;
+    }
+    for (; s < splits; ++s) {
+      const float4 a = p[(int64_t)s * t4];
+      v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
     }
     const int64_t e = i << 2;
     if (bias) {
@@ -160,33 +172,42 @@ __global__ __launch_bounds__(kBlock) void splitk_reduce_kernel(const float* __re
   }
 }
 
-// column sums of G[M,N] (N <= 256): stage 1 -> part[blocks][N], stage 2 -> out[N]
-constexpr int kColsumBlocks = 256;
-__global__ __launch_bounds__(kBlock) void colsum_stage1(const float* __restrict__ G, int64_t M, int N,
-                                                        float* __restrict__ part) {
-  // thread t owns column t % N for rows (t / N) + k * (256 / N) of this block's row range
+// column sums of G[M,N] (N <= 256, N % 4 == 0): thread (c, rr) = (tid % N, tid / N) adds rows
+// rr, rr + R, ... of its block's range; the R row-groups are combined through LDS.
+//   stage 1 -> part[blocks][N];  stage 2 (one block, same scheme over the partials) -> out[N]
+constexpr int kColsumBlocks = 128;
+__device__ __forceinline__ void colsum_body(const float* __restrict__ G, int64_t row0, int64_t row_step,
+                                            int64_t M, int N, float* __restrict__ dst) {
   __shared__ float red[kBlock];
-  const int rows_per_pass = kBlock / N;
+  const int R = kBlock / N;
   const int c = threadIdx.x % N, rr = threadIdx.x / N;
-  float acc = 0.f;
-  if (rr < rows_per_pass)
-    for (int64_t m = (int64_t)blockIdx.x * rows_per_pass + rr; m < M; m += (int64_t)gridDim.x * rows_per_pass)
-      acc += G[m * N + c];
-  red[threadIdx.x] = (rr < rows_per_pass) ? acc : 0.f;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  if (rr < R) {
+    int64_t m = row0 + rr;
+    for (; m + 3 * row_step < M; m += 4 * row_step) {      // four independent loads in flight
+      a0 += G[m * N + c];
+      a1 += G[(m + row_step) * N + c];
+      a2 += G[(m + 2 * row_step) * N + c];
+      a3 += G[(m + 3 * row_step) * N + c];
+    }
+    for (; m < M; m += row_step) a0 += G[m * N + c];
+  }
+  red[threadIdx.x] = (a0 + a1) + (a2 + a3);
   __syncthreads();
   if (threadIdx.x < N) {
     float s = 0.f;
-    for (int r = 0; r < rows_per_pass; ++r) s += red[r * N + threadIdx.x];
-    part[(int64_t)blockIdx.x * N + threadIdx.x] = s;
+    for (int r = 0; r < R; ++r) s += red[r * N + threadIdx.x];
+    dst[threadIdx.x] = s;
   }
+}
+__global__ __launch_bounds__(kBlock) void colsum_stage1(const float* __restrict__ G, int64_t M, int N,
+                                                        float* __restrict__ part) {
+  const int R = kBlock / N;
+  colsum_body(G, (int64_t)blockIdx.x * R, (int64_t)gridDim.x * R, M, N, part + (int64_t)blockIdx.x * N);
 }
 __global__ __launch_bounds__(kBlock) void colsum_stage2(const float* __restrict__ part, int nparts, int N,
                                                         float* __restrict__ out) {
-  const int c = threadIdx.x;
-  if (c >= N) return;
-  float s = 0.f;
-  for (int p = 0; p < nparts; ++p) s += part[(int64_t)p * N + c];
-  out[c] = s;
+  colsum_body(part, 0, kBlock / N, nparts, N, out);
 }
 
 // split count: aim for >= ~4 blocks per CU, every split at least 4 slices deep
@@ -285,8 +306,8 @@ extern "C" int mmssl_linear_wgrad_f32(const float* gY, const float* F, int64_t M
     MMSSL_LAUNCH_CHECK();
   }
   if (gb) {
-    const int rows_per_pass = kBlock / N;
-    int64_t nb = (M + rows_per_pass - 1) / rows_per_pass;
+    const int R = kBlock / N;
+    int64_t nb = (M + R - 1) / R;
     nb = nb > kColsumBlocks ? kColsumBlocks : nb;
     hipLaunchKernelGGL(colsum_stage1, dim3((unsigned)nb), dim3(kBlock), 0, s, gY, M, N, colpart);
     MMSSL_LAUNCH_CHECK();

@@ -31,12 +31,18 @@ class HotPathStep:
         self.loss = torch.zeros((), device=dev)
         self.parts = {}
         self._graph = None
+        # ONE stream for everything this object launches (eager steps, capture, replays): autograd
+        # binds each parameter's AccumulateGrad node to the stream of its first backward, and a
+        # later capture on a different stream would have to synchronise across streams.
+        self.stream = torch.cuda.Stream(device=dev)
+        self.stream.wait_stream(torch.cuda.current_stream(dev))
 
     def set_batch(self, users, pos, neg):
         """Device-to-device copies into the static index buffers (graph replays read these)."""
-        self.users.copy_(users, non_blocking=True)
-        self.pos.copy_(pos, non_blocking=True)
-        self.neg.copy_(neg, non_blocking=True)
+        with torch.cuda.stream(self.stream):
+            self.users.copy_(users, non_blocking=True)
+            self.pos.copy_(pos, non_blocking=True)
+            self.neg.copy_(neg, non_blocking=True)
 
     def losses(self):
         m = self.model
@@ -51,6 +57,11 @@ class HotPathStep:
         return total, dict(mf=mf, emb=emb, feat=feat, cl1=cl1, cl2=cl2)
 
     def step(self):
+        """One eager step on this object's stream."""
+        with torch.cuda.stream(self.stream):
+            return self._step()
+
+    def _step(self):
         self.optimizer.zero_grad(set_to_none=True)
         total, parts = self.losses()
         total.backward()
@@ -65,17 +76,15 @@ class HotPathStep:
         them synchronise across streams inside the capture, which the HIP runtime rejects).
         Returns True on success; the object stays usable in eager mode otherwise."""
         self.model.train()
-        s = torch.cuda.Stream()
-        s.wait_stream(torch.cuda.current_stream())
+        s = self.stream
         try:
             with torch.cuda.stream(s):
                 for _ in range(warmup):
-                    self.step()
+                    self._step()
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, stream=s):
-                self.step()
-            torch.cuda.current_stream().wait_stream(s)
+                self._step()
             torch.cuda.synchronize()
             self._graph = g
             return True
@@ -86,7 +95,8 @@ class HotPathStep:
             return False
 
     def run(self):
-        if self._graph is not None:
-            self._graph.replay()
-        else:
-            self.step()
+        with torch.cuda.stream(self.stream):
+            if self._graph is not None:
+                self._graph.replay()
+            else:
+                self._step()

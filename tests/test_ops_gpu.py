@@ -201,6 +201,9 @@ def test_infonce_golden_and_oracle():
         lg = ops.infonce(ag, bg, 0.5)
         (lg * 1.7).backward()
         assert abs(float(lg) - float(lr)) <= 1e-5 * abs(float(lr)) + 3e-7, (n, d)   # n=1: log(1+1e-8) noise
+        if n == 1:      # mathematically zero gradient; the reference shows ~1e-9 rounding noise
+            assert float(ag.grad.abs().max()) < 1e-7 and float(bg.grad.abs().max()) < 1e-7
+            continue
         assert H.rel_err(ag.grad.cpu(), ar.grad) < 2e-4, (n, d)
         assert H.rel_err(bg.grad.cpu(), br.grad) < 2e-4, (n, d)
 

@@ -1,0 +1,34 @@
+"""Per-step kernel breakdown from a rocprofv3 --kernel-trace CSV (one hot-path step = the kernels
+between two consecutive bpr_fwd_kernel launches).   python tools/trace_step.py <kernel_trace.csv> [step_index]"""
+import collections
+import csv
+import sys
+
+
+def main(path, which=12):
+    rows = []
+    with open(path) as f:
+        for r in csv.DictReader(f):
+            rows.append((r["Kernel_Name"], int(r["Start_Timestamp"]), int(r["End_Timestamp"])))
+    rows.sort(key=lambda r: r[1])
+    idx = [i for i, r in enumerate(rows) if "bpr_fwd_kernel" in r[0]]
+    which = min(which, len(idx) - 2)
+    step = rows[idx[which]:idx[which + 1]]
+    tot = sum(e - s for _, s, e in step) / 1e3
+    wall = (step[-1][2] - step[0][1]) / 1e3
+    print("step %d: %d kernels, sum of kernel time %.1f us, first-start..last-end %.1f us" % (which, len(step), tot, wall))
+    agg = collections.OrderedDict()
+    for n, s, e in step:
+        k = n.replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0][:70]
+        if "at::native" in n:
+            k = "torch:" + n.split("at::native::")[1].split("<")[0][:40] + ("/" + n.split("at::native::")[2].split("<")[0][:30] if n.count("at::native::") > 1 else "")
+        a = agg.setdefault(k, [0, 0.0])
+        a[0] += 1
+        a[1] += (e - s) / 1e3
+    print("%9s %5s  %s" % ("us", "calls", "kernel"))
+    for k, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+        print("%9.1f %5d  %s" % (t, c, k))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 12)

@@ -1,0 +1,133 @@
+"""world_size 2 / 3 gloo tests of the row-sharded hot path (mmssl_amd.dist) on CPU: the N-rank loss
+and gradients must equal the single-process oracle on the same global inputs."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+for p in (ROOT, os.path.join(ROOT, "oracle"), HERE):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _global_problem(modal):
+    import helpers as H
+    import mmssl_oracle as O
+    fx = H.load("g8_gstep_%s.npz" % ("empty" if modal.startswith("empty") else "full"))
+    d, raw, U, I = H.dataset()
+    state = {k[2:]: torch.from_numpy(fx[k]) for k in fx.files if k.startswith("p.")}
+    users, pos, neg = (torch.from_numpy(fx[k]) for k in ("users", "pos", "neg"))
+    img_raw = H.modal_raw(fx, "img", U, I)
+    txt_raw = H.modal_raw(fx, "txt", U, I)
+    return fx, d, raw, U, I, state, users, pos, neg, img_raw, txt_raw
+
+
+def _worker(rank, world, port, modal, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    import mmssl_oracle as O
+    from mmssl_amd import dist as md
+    from oracle_backend import OracleBackend
+    fx, d, raw, U, I, state, users, pos, neg, img_raw, txt_raw = _global_problem(modal)
+    ush, ish = md.RowShard(U, world, rank), md.RowShard(I, world, rank)
+    bk = OracleBackend()
+    cfg = O.Cfg(drop_rate=0.0, batch_size=48, n_ui_layers=2)
+
+    def local_pair(m):
+        ui, iu = O.csr_norm(m, True), O.csr_norm(m.T, True)
+        return bk.make_graph(md.shard_graph(ui, ush, ish)), bk.make_graph(md.shard_graph(iu, ish, ush))
+    ui, iu = local_pair(raw)
+    a, b = local_pair(img_raw)
+    c, e = local_pair(txt_raw)
+    model = md.ShardedMMSSL(bk, cfg, ush, ish, state, d["image_feat"], d["text_feat"]).train()
+    step = md.ShardedHotPathStep(model, (ui, iu, a, b, c, e), 48, I, modal_empty=(modal == "empty_shortcut"),
+                                 optimizer=False)
+    step.set_batch(users, pos, neg)
+    total = step.backward()
+    torch.save({"loss": float(total), "ush": (ush.lo, ush.hi, ush.n), "ish": (ish.lo, ish.hi, ish.n),
+                "g": {n: p.grad.clone() if p.grad is not None else None for n, p in model.named_parameters()}},
+               os.path.join(out_dir, "r%d.pt" % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _reference(modal):
+    import mmssl_oracle as O
+    fx, d, raw, U, I, state, users, pos, neg, img_raw, txt_raw = _global_problem(modal)
+    P = {k: v.clone().requires_grad_(True) for k, v in state.items()}
+    cfg = O.Cfg(drop_rate=0.0, batch_size=48, n_ui_layers=2)
+    pair = lambda m: O.graph_pair(m)     # noqa: E731
+    ui, iu = pair(raw)
+    a, b = pair(img_raw)
+    c, e = pair(txt_raw)
+    o = O.forward(P, torch.from_numpy(d["image_feat"]), torch.from_numpy(d["text_feat"]), (ui, iu, a, b, c, e), cfg,
+                  training=False)
+    mf, emb, _ = O.bpr(o[0][users], o[1][pos], o[1][neg], cfg.decay, 48)
+    loss = mf + emb + O.feat_reg(o[2], o[3], o[4], o[5], I, cfg.feat_reg_decay) + cfg.cl_rate * (
+        O.infonce(o[8][users], o[6][users], cfg.tau) + O.infonce(o[9][users], o[6][users], cfg.tau))
+    loss.backward()
+    return float(loss), P
+
+
+@pytest.mark.parametrize("world,modal", [(2, "full"), (3, "full"), (2, "empty"), (2, "empty_shortcut")])
+def test_sharded_step_equals_single_process(tmp_path, world, modal):
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, modal, str(tmp_path)), nprocs=world, join=True)
+    ref_loss, P = _reference(modal)
+    outs = [torch.load(os.path.join(str(tmp_path), "r%d.pt" % r)) for r in range(world)]
+    for o in outs:
+        assert abs(o["loss"] - ref_loss) <= 2e-5 * abs(ref_loss), (o["loss"], ref_loss)
+
+    def rel(a, b):
+        return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+    # replicated parameters: identical (all-reduced) gradients on every rank == global gradient
+    for name, key in (("img_w", "image_trans.weight"), ("img_b", "image_trans.bias"), ("txt_w", "text_trans.weight"),
+                      ("txt_b", "text_trans.bias")):
+        for o in outs:
+            assert rel(o["g"][name], P[key].grad) < 1e-4, name
+    if modal == "full":
+        for o in outs:
+            assert rel(o["g"]["w_cat"], P["weight_dict.w_self_attention_cat"].grad) < 1e-4
+    # sharded tables: each rank holds the gradient rows it owns
+    for o in outs:
+        for name, key, sh in (("E_u", "user_id_embedding.weight", o["ush"]), ("E_i", "item_id_embedding.weight", o["ish"])):
+            lo, hi, n = sh
+            k = max(0, min(hi, n) - lo)
+            g = P[key].grad[lo:lo + k]
+            assert rel(o["g"][name][:k], g) < 1e-4, name
+            if k < hi - lo:      # padded rows never receive gradient
+                assert float(o["g"][name][k:].abs().max()) == 0.0
+
+
+def test_row_shard_and_graph_slicing():
+    import scipy.sparse as sp
+    from mmssl_amd import dist as md
+    m = sp.random(10, 7, density=0.4, random_state=1, format="csr", dtype=np.float32)
+    parts = []
+    for r in range(3):
+        rs, cs = md.RowShard(10, 3, r), md.RowShard(7, 3, r)
+        assert (rs.per, rs.n_pad, cs.per, cs.n_pad) == (4, 12, 3, 9)
+        g = md.shard_graph(m, rs, cs)
+        assert g.shape == (4, 9)
+        parts.append(g)
+    full = sp.vstack(parts).toarray()
+    assert np.array_equal(full[:10, :7], m.toarray()) and not full[10:].any() and not full[:, 7:].any()
+    t = torch.arange(20.).view(10, 2)
+    assert torch.equal(md.RowShard(10, 3, 2).slice_rows(t), torch.cat([t[8:], torch.zeros(2, 2)]))

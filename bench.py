@@ -224,6 +224,8 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph-probe", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--force-dist", action="store_true",
+                    help="use the row-sharded code path even with one rank (exercises RCCL + dist.py on 1 GPU)")
     a = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -234,11 +236,17 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
-    if world > 1:
+    sharded = world > 1 or a.force_dist
+    if sharded:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
-    if world == 1:
+    if not sharded:
         step, raw, mats, plans = build_single_gpu(a, dev)
         stats = count_edge_layers(step)
         if a.graph_probe:            # child process: does whole-step hipGraph capture + replay work here?
@@ -266,17 +274,17 @@ def main():
             step.run()
 
     run_steps(a.warmup)
-    if world > 1:
+    if sharded:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     run_steps(a.steps)
     torch.cuda.synchronize()
-    if world > 1:
+    if sharded:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if sharded:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -296,12 +304,12 @@ def main():
                    "final_loss": round(loss, 6)},
     }
     if rank == 0:
-        if world == 1:
+        if not sharded:
             out["roofline"] = spmm_roofline(plans, mats, a.d)
             if not a.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline(a, raw, mats)
         print(json.dumps(out))
-    if world > 1:
+    if sharded:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -136,17 +136,22 @@ int mmssl_linear_wgrad_f32(const float* gY, const float* F, int64_t M, int K, in
  * InfoNCE  — Trainer.batched_contrastive_loss + Trainer.sim (main.py:211-249)
  *   loss = mean_i -log( e^{c12_ii/tau} / (sum_j e^{c11_ij/tau} + sum_j e^{c12_ij/tau}
  *                        - e^{c11_ii/tau}) + 1e-8 ),  c = cosine of L2-normalised rows.
- *   z1, z2: [n, d] raw (un-normalised) rows. The reference's 1024-row blocking is
- *   mathematically the full-matrix formula; any n >= 1 is accepted.
- *   fwd writes loss[0] and keeps what bwd needs in `workspace`; bwd(gloss) -> gz1, gz2.
- *   d % 4 == 0, d <= 256.
+ *   z1, z2: raw (un-normalised) fp32 rows. idx == NULL: both are [n, d] and row i pairs with
+ *   row i (the reference's signature, called as f(table1[users], table2[users]), main.py:411-412).
+ *   idx != NULL (int64 [n], device): z1/z2 are whole tables and batch row i is table row idx[i] —
+ *   the gather is fused into the first kernel and the backward scatter-adds into the
+ *   caller-zeroed table gradients. The reference's 1024-row blocking is mathematically the
+ *   full-matrix formula; any n >= 1 is accepted.
+ *   fwd writes loss[0] and keeps what bwd needs in `workspace`; bwd(gloss) -> gz1, gz2 (either
+ *   may be NULL when that input needs no gradient).  d in {32, 64, 128, 256}.
  * ---------------------------------------------------------------------------------- */
 size_t mmssl_infonce_workspace_bytes(int64_t n, int d);
-int mmssl_infonce_fwd_f32(const float* z1, const float* z2, int64_t n, int d, float tau,
-                          float* loss, void* workspace, size_t workspace_bytes, void* stream);
-int mmssl_infonce_bwd_f32(const float* z1, const float* z2, int64_t n, int d, float tau,
-                          const float* gloss, float* gz1, float* gz2, void* workspace,
-                          size_t workspace_bytes, void* stream);
+int mmssl_infonce_fwd_f32(const float* z1, const float* z2, const int64_t* idx, int64_t n, int d,
+                          float tau, float* loss, void* workspace, size_t workspace_bytes,
+                          void* stream);
+int mmssl_infonce_bwd_f32(const int64_t* idx, int64_t n, int d, float tau, const float* gloss,
+                          float* gz1, float* gz2, void* workspace, size_t workspace_bytes,
+                          void* stream);
 
 /* ------------------------------------------------------------------------------------
  * BPR  — gathers (main.py:368-370) + Trainer.bpr_loss (main.py:499-511)

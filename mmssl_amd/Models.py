@@ -116,6 +116,17 @@ class MMSSL(nn.Module):
         w = (0.5 * fold).t().contiguous()                          # linear() takes [out, in]
         return ops.linear(emb_a + emb_b, w)
 
+    def _zeros(self, rows, like):
+        """Cached all-zero [rows, d] tensor (the value of A.E for an empty graph A)."""
+        key = (rows, like.shape[1], like.device)
+        z = self._zero_cache.get(key) if hasattr(self, "_zero_cache") else None
+        if z is None:
+            if not hasattr(self, "_zero_cache"):
+                self._zero_cache = {}
+            z = torch.zeros((rows, like.shape[1]), dtype=torch.float32, device=like.device)
+            self._zero_cache[key] = z
+        return z
+
     # ---- forward -----------------------------------------------------------------------------
     def forward(self, ui_graph, iu_graph, image_ui_graph, image_iu_graph, text_ui_graph, text_iu_graph,
                 keep_masks=None):
@@ -135,8 +146,8 @@ class MMSSL(nn.Module):
             else:
                 shape = (self.n_items, args.embed_size)
                 dev = self.image_trans.weight.device
-                km_img = (torch.rand(shape, device=dev) >= p).to(torch.uint8)
-                km_txt = (torch.rand(shape, device=dev) >= p).to(torch.uint8)
+                km_img = torch.empty(shape, dtype=torch.uint8, device=dev).bernoulli_(1.0 - p)   # 1 = keep
+                km_txt = torch.empty(shape, dtype=torch.uint8, device=dev).bernoulli_(1.0 - p)
         x_img = ops.linear(self.image_feats, self.image_trans.weight, self.image_trans.bias, km_img, scale)
         x_txt = ops.linear(self.text_feats, self.text_trans.weight, self.text_trans.bias, km_txt, scale)
 
@@ -146,21 +157,30 @@ class MMSSL(nn.Module):
         assert args.layers >= 1
         image_user_feats = ops.spmm(ui, x_img)
         image_item_feats = ops.spmm(iu, image_user_feats)
-        image_user_id = ops.spmm(img_ui, E_i)
-        image_item_id = ops.spmm(img_iu, E_u)
         text_user_feats = ops.spmm(ui, x_txt)
         text_item_feats = ops.spmm(iu, text_user_feats)
-        text_user_id = ops.spmm(txt_ui, E_i)
-        text_item_id = ops.spmm(txt_iu, E_u)
+        wcat = self.weight_dict["w_self_attention_cat"]
+        # Modal id views. An EMPTY modal graph (the reference's state from the third batch on,
+        # SURVEY 8a-3) makes A.E == 0, the fused view 0 and normalize(0) == 0, so u == E_u exactly:
+        # that branch is skipped; w_self_attention_cat still receives its exactly-zero gradient.
+        if img_ui.nnz == 0 and txt_ui.nnz == 0:
+            image_user_id = text_user_id = self._zeros(self.n_users, E_u)
+            u = ops.zero_grad_anchor(E_u, wcat)
+        else:
+            image_user_id = ops.spmm(img_ui, E_i)
+            text_user_id = ops.spmm(txt_ui, E_i)
+            u = ops.l2norm_rows(self._modality_fusion(image_user_id, text_user_id), E_u, args.id_cat_rate)
+        if img_iu.nnz == 0 and txt_iu.nnz == 0:
+            image_item_id = text_item_id = self._zeros(self.n_items, E_i)
+            i = ops.zero_grad_anchor(E_i, wcat)
+        else:
+            image_item_id = ops.spmm(img_iu, E_u)
+            text_item_id = ops.spmm(txt_iu, E_u)
+            i = ops.l2norm_rows(self._modality_fusion(image_item_id, text_item_id), E_i, args.id_cat_rate)
         self.embedding_dict["user"]["image"] = image_user_id
         self.embedding_dict["user"]["text"] = text_user_id
         self.embedding_dict["item"]["image"] = image_item_id
         self.embedding_dict["item"]["text"] = text_item_id
-
-        user_emb = self._modality_fusion(image_user_id, text_user_id)
-        item_emb = self._modality_fusion(image_item_id, text_item_id)
-        u = ops.l2norm_rows(user_emb, E_u, args.id_cat_rate)        # E + rate * normalize(.)
-        i = ops.l2norm_rows(item_emb, E_i, args.id_cat_rate)
 
         u_sum, i_sum = u, i
         for layer in range(self.n_ui_layers):

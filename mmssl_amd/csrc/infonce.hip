@@ -64,7 +64,8 @@ inline Layout make_layout(int64_t n, int d) {
 
 // ---- prep: normalise both inputs, positive-pair cosine --------------------------------
 __global__ __launch_bounds__(kBlock) void prep_kernel(const float* __restrict__ z1,
-                                                      const float* __restrict__ z2, int64_t n, int d,
+                                                      const float* __restrict__ z2,
+                                                      const int64_t* __restrict__ idx, int64_t n, int d,
                                                       float* __restrict__ n1, float* __restrict__ n2,
                                                       float* __restrict__ inv1, float* __restrict__ inv2,
                                                       float* __restrict__ pos) {
@@ -73,8 +74,9 @@ __global__ __launch_bounds__(kBlock) void prep_kernel(const float* __restrict__ 
   const int64_t r = (int64_t)blockIdx.x * (kBlock / 16) + threadIdx.x / 16;
   if (r >= n) return;
   const int nch = d >> 2;
-  const float4* a = reinterpret_cast<const float4*>(z1 + r * d);
-  const float4* b = reinterpret_cast<const float4*>(z2 + r * d);
+  const int64_t src = idx ? idx[r] : r;          // fused gather: row r of the batch = table row idx[r]
+  const float4* a = reinterpret_cast<const float4*>(z1 + src * d);
+  const float4* b = reinterpret_cast<const float4*>(z2 + src * d);
   float s1 = 0.f, s2 = 0.f, s12 = 0.f;
   for (int k = lig; k < nch; k += 16) {
     const float4 x = a[k], y = b[k];
@@ -320,62 +322,81 @@ __global__ __launch_bounds__(kBlock) void bwd_tiles_kernel(const float* __restri
 
 // ---- backward finish: sum splits, diagonal terms, normalise-backward, scale by gloss ----------
 //   z -> nrm = z*inv: gz = inv*(gn - nrm*(nrm.gn))  if |z| >= eps, else gn/eps
-__global__ __launch_bounds__(kBlock) void bwd_finish_kernel(const float* __restrict__ z1,
-                                                            const float* __restrict__ z2,
-                                                            const float* __restrict__ n1,
+// With a gather index the rows are scatter-ADDED (hardware fp32 atomics) into the caller-zeroed
+// table gradients; a NULL gz pointer skips that side (input that needs no gradient).
+__device__ __forceinline__ void put_row(float* __restrict__ g, int64_t row, int d, int k, float4 v, bool scatter) {
+  float* p = g + row * d + k * 4;
+  if (scatter) {
+    unsafeAtomicAdd(p + 0, v.x);
+    unsafeAtomicAdd(p + 1, v.y);
+    unsafeAtomicAdd(p + 2, v.z);
+    unsafeAtomicAdd(p + 3, v.w);
+  } else {
+    *reinterpret_cast<float4*>(p) = v;
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void bwd_finish_kernel(const float* __restrict__ n1,
                                                             const float* __restrict__ n2,
                                                             const float* __restrict__ inv1,
                                                             const float* __restrict__ inv2,
                                                             const float* __restrict__ w,
                                                             const float* __restrict__ g1p,
                                                             const float* __restrict__ g2p, int cs,
-                                                            int64_t n, int d, float tau,
-                                                            const float* __restrict__ gloss,
+                                                            const int64_t* __restrict__ idx, int64_t n, int d,
+                                                            float tau, const float* __restrict__ gloss,
                                                             float* __restrict__ gz1,
                                                             float* __restrict__ gz2) {
+  constexpr int MAXC = 4;                      // d <= 256 -> at most 4 float4 chunks per lane
   const int lig = threadIdx.x & 15;
   const int64_t r = (int64_t)blockIdx.x * (kBlock / 16) + threadIdx.x / 16;
   if (r >= n) return;
   const float gl = gloss[0];
   const float wt = w[r] / tau;
   const int nch = d >> 2;
-  // pass 1: gn (kept in the output buffers) and the two projections nrm.gn
+  float4 u[MAXC], v[MAXC], a[MAXC], b[MAXC];
   float p1 = 0.f, p2 = 0.f;
-  for (int k = lig; k < nch; k += 16) {
-    const float4 a = reinterpret_cast<const float4*>(n1 + r * d)[k];
-    const float4 b = reinterpret_cast<const float4*>(n2 + r * d)[k];
-    float4 u = make_float4(wt * b.x, wt * b.y, wt * b.z, wt * b.w);
-    float4 v = make_float4(wt * a.x, wt * a.y, wt * a.z, wt * a.w);
-    for (int s = 0; s < cs; ++s) {
-      const float4 x = reinterpret_cast<const float4*>(g1p + ((size_t)s * n + r) * d)[k];
-      const float4 y = reinterpret_cast<const float4*>(g2p + ((size_t)s * n + r) * d)[k];
-      u.x += x.x; u.y += x.y; u.z += x.z; u.w += x.w;
-      v.x += y.x; v.y += y.y; v.z += y.z; v.w += y.w;
+#pragma unroll
+  for (int t = 0; t < MAXC; ++t) {
+    const int k = lig + 16 * t;
+    if (k < nch) {
+      a[t] = reinterpret_cast<const float4*>(n1 + r * d)[k];
+      b[t] = reinterpret_cast<const float4*>(n2 + r * d)[k];
+      float4 uu = make_float4(wt * b[t].x, wt * b[t].y, wt * b[t].z, wt * b[t].w);
+      float4 vv = make_float4(wt * a[t].x, wt * a[t].y, wt * a[t].z, wt * a[t].w);
+      for (int s = 0; s < cs; ++s) {
+        const float4 x = reinterpret_cast<const float4*>(g1p + ((size_t)s * n + r) * d)[k];
+        const float4 y = reinterpret_cast<const float4*>(g2p + ((size_t)s * n + r) * d)[k];
+        uu.x += x.x; uu.y += x.y; uu.z += x.z; uu.w += x.w;
+        vv.x += y.x; vv.y += y.y; vv.z += y.z; vv.w += y.w;
+      }
+      u[t] = uu;
+      v[t] = vv;
+      p1 += f4_dot(a[t], uu);
+      p2 += f4_dot(b[t], vv);
     }
-    reinterpret_cast<float4*>(gz1 + r * d)[k] = u;
-    reinterpret_cast<float4*>(gz2 + r * d)[k] = v;
-    p1 += f4_dot(a, u);
-    p2 += f4_dot(b, v);
   }
   p1 = group_sum<16>(p1);
   p2 = group_sum<16>(p2);
   const float i1 = inv1[r], i2 = inv2[r];
   // inv == 1/eps exactly when the row norm was clamped (|z| < eps): no projection term then
-  const bool clamp1 = i1 >= 1.f / kNormEps, clamp2 = i2 >= 1.f / kNormEps;
-  for (int k = lig; k < nch; k += 16) {
-    const float4 a = reinterpret_cast<const float4*>(n1 + r * d)[k];
-    const float4 b = reinterpret_cast<const float4*>(n2 + r * d)[k];
-    float4 u = reinterpret_cast<float4*>(gz1 + r * d)[k];
-    float4 v = reinterpret_cast<float4*>(gz2 + r * d)[k];
-    const float q1 = clamp1 ? 0.f : p1, q2 = clamp2 ? 0.f : p2;
-    const float m1 = gl * i1, m2 = gl * i2;
-    u = make_float4(m1 * (u.x - a.x * q1), m1 * (u.y - a.y * q1), m1 * (u.z - a.z * q1), m1 * (u.w - a.w * q1));
-    v = make_float4(m2 * (v.x - b.x * q2), m2 * (v.y - b.y * q2), m2 * (v.z - b.z * q2), m2 * (v.w - b.w * q2));
-    reinterpret_cast<float4*>(gz1 + r * d)[k] = u;
-    reinterpret_cast<float4*>(gz2 + r * d)[k] = v;
+  const float q1 = (i1 >= 1.f / kNormEps) ? 0.f : p1;
+  const float q2 = (i2 >= 1.f / kNormEps) ? 0.f : p2;
+  const float m1 = gl * i1, m2 = gl * i2;
+  const int64_t dst = idx ? idx[r] : r;
+  const bool scatter = idx != nullptr;
+#pragma unroll
+  for (int t = 0; t < MAXC; ++t) {
+    const int k = lig + 16 * t;
+    if (k < nch) {
+      if (gz1)
+        put_row(gz1, dst, d, k, make_float4(m1 * (u[t].x - a[t].x * q1), m1 * (u[t].y - a[t].y * q1),
+                                            m1 * (u[t].z - a[t].z * q1), m1 * (u[t].w - a[t].w * q1)), scatter);
+      if (gz2)
+        put_row(gz2, dst, d, k, make_float4(m2 * (v[t].x - b[t].x * q2), m2 * (v[t].y - b[t].y * q2),
+                                            m2 * (v[t].z - b[t].z * q2), m2 * (v[t].w - b[t].w * q2)), scatter);
+    }
   }
-  (void)z1;
-  (void)z2;
 }
 
 inline bool infonce_d_ok(int d) { return d == 32 || d == 64 || d == 128 || d == 256; }
@@ -387,8 +408,9 @@ extern "C" size_t mmssl_infonce_workspace_bytes(int64_t n, int d) {
   return make_layout(n, d).total * sizeof(float);
 }
 
-extern "C" int mmssl_infonce_fwd_f32(const float* z1, const float* z2, int64_t n, int d, float tau,
-                                     float* loss, void* workspace, size_t workspace_bytes, void* stream) {
+extern "C" int mmssl_infonce_fwd_f32(const float* z1, const float* z2, const int64_t* idx, int64_t n, int d,
+                                     float tau, float* loss, void* workspace, size_t workspace_bytes,
+                                     void* stream) {
   if (n <= 0 || !z1 || !z2 || !loss || !(tau > 0.f)) return MMSSL_E_BADARG;
   if (!infonce_d_ok(d)) return MMSSL_E_UNSUPP;
   const Layout L = make_layout(n, d);
@@ -398,7 +420,7 @@ extern "C" int mmssl_infonce_fwd_f32(const float* z1, const float* z2, int64_t n
   hipStream_t s = as_stream(stream);
   const int nt = n_tiles(n);
   const int rb = (int)((n + 15) / 16);
-  hipLaunchKernelGGL(prep_kernel, dim3(rb), dim3(kBlock), 0, s, z1, z2, n, d, ws + L.n1, ws + L.n2,
+  hipLaunchKernelGGL(prep_kernel, dim3(rb), dim3(kBlock), 0, s, z1, z2, idx, n, d, ws + L.n1, ws + L.n2,
                      ws + L.inv1, ws + L.inv2, ws + L.pos);
   MMSSL_LAUNCH_CHECK();
   const dim3 grid(nt * L.cs_f);
@@ -418,10 +440,10 @@ extern "C" int mmssl_infonce_fwd_f32(const float* z1, const float* z2, int64_t n
   return 0;
 }
 
-extern "C" int mmssl_infonce_bwd_f32(const float* z1, const float* z2, int64_t n, int d, float tau,
-                                     const float* gloss, float* gz1, float* gz2, void* workspace,
-                                     size_t workspace_bytes, void* stream) {
-  if (n <= 0 || !z1 || !z2 || !gloss || !gz1 || !gz2 || !(tau > 0.f)) return MMSSL_E_BADARG;
+extern "C" int mmssl_infonce_bwd_f32(const int64_t* idx, int64_t n, int d, float tau, const float* gloss,
+                                     float* gz1, float* gz2, void* workspace, size_t workspace_bytes,
+                                     void* stream) {
+  if (n <= 0 || !gloss || (!gz1 && !gz2) || !(tau > 0.f)) return MMSSL_E_BADARG;
   if (!infonce_d_ok(d)) return MMSSL_E_UNSUPP;
   const Layout L = make_layout(n, d);
   if (!workspace || workspace_bytes < L.total * sizeof(float)) return MMSSL_E_WORKSPACE;
@@ -438,9 +460,8 @@ extern "C" int mmssl_infonce_bwd_f32(const float* z1, const float* z2, int64_t n
   }
   MMSSL_LAUNCH_CHECK();
   const int rb = (int)((n + 15) / 16);
-  hipLaunchKernelGGL(bwd_finish_kernel, dim3(rb), dim3(kBlock), 0, s, z1, z2, ws + L.n1, ws + L.n2,
-                     ws + L.inv1, ws + L.inv2, ws + L.w, ws + L.g1p, ws + L.g2p, L.cs_b, n, d, tau, gloss,
-                     gz1, gz2);
+  hipLaunchKernelGGL(bwd_finish_kernel, dim3(rb), dim3(kBlock), 0, s, ws + L.n1, ws + L.n2, ws + L.inv1,
+                     ws + L.inv2, ws + L.w, ws + L.g1p, ws + L.g2p, L.cs_b, idx, n, d, tau, gloss, gz1, gz2);
   MMSSL_LAUNCH_CHECK();
   return 0;
 }

@@ -47,12 +47,10 @@ class HotPathStep:
     def losses(self):
         m = self.model
         (ua, ia, img_item, txt_item, img_user, txt_user, uemb, _, img_uid, txt_uid, _, _) = m(*self.graphs)
-        mf, emb = ops.bpr_gather(ua, ia, self.users, self.pos, self.neg, self.decay, self.batch_size)
+        mf, emb, cl1, cl2 = ops.batch_losses(ua, ia, img_uid, txt_uid, self.users, self.pos, self.neg, self.decay,
+                                             self.batch_size, args.tau)
         feat = args.feat_reg_decay * ((0.5 * ops.sumsq(img_item) + 0.5 * ops.sumsq(txt_item)
                                        + 0.5 * ops.sumsq(img_user) + 0.5 * ops.sumsq(txt_user)) / m.n_items)
-        z2 = uemb[self.users]
-        cl1 = ops.infonce(img_uid[self.users], z2, args.tau)
-        cl2 = ops.infonce(txt_uid[self.users], z2, args.tau)
         total = mf + emb + feat + args.cl_rate * (cl1 + cl2)
         return total, dict(mf=mf, emb=emb, feat=feat, cl1=cl1, cl2=cl2)
 

@@ -215,41 +215,55 @@ def linear(F_, W, b=None, keep=None, scale=1.0):
 # ---------------------------------------------------------------------------------------
 # InfoNCE                       Trainer.sim + batched_contrastive_loss, main.py:211-249
 # ---------------------------------------------------------------------------------------
+def _infonce_fwd_raw(z1, z2, idx, tau):
+    n = z1.shape[0] if idx is None else idx.shape[0]
+    d = z1.shape[1]
+    nb = _lib.lib().mmssl_infonce_workspace_bytes(n, d)
+    if nb == 0:
+        raise _lib.MmsslError("infonce: unsupported shape n=%d d=%d" % (n, d))
+    ws = torch.empty(nb // 4, dtype=torch.float32, device=z1.device)
+    loss = torch.empty((), dtype=torch.float32, device=z1.device)
+    rc = _lib.lib().mmssl_infonce_fwd_f32(_ptr(z1), _ptr(z2), _ptr(idx), n, d, float(tau), _ptr(loss), _ptr(ws), nb,
+                                          _lib.stream_ptr())
+    _lib.check(rc, "mmssl_infonce_fwd_f32")
+    return loss, ws, n, d
+
+
+def _infonce_bwd_raw(idx, n, d, tau, g, gz1, gz2, ws):
+    rc = _lib.lib().mmssl_infonce_bwd_f32(_ptr(idx), n, d, float(tau), _ptr(g), _ptr(gz1), _ptr(gz2), _ptr(ws),
+                                          ws.numel() * 4, _lib.stream_ptr())
+    _lib.check(rc, "mmssl_infonce_bwd_f32")
+
+
 class _InfoNCE(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, z1, z2, tau):
+    def forward(ctx, z1, z2, idx, tau):
         z1, z2 = _chk(z1, "z1"), _chk(z2, "z2")
-        if z1.shape != z2.shape or z1.dim() != 2:
-            raise _lib.MmsslError("infonce: z1/z2 must both be [n, d]")
-        n, d = z1.shape
-        nb = _lib.lib().mmssl_infonce_workspace_bytes(n, d)
-        if nb == 0:
-            raise _lib.MmsslError("infonce: unsupported shape n=%d d=%d" % (n, d))
-        ws = torch.empty(nb // 4, dtype=torch.float32, device=z1.device)
-        loss = torch.empty((), dtype=torch.float32, device=z1.device)
-        rc = _lib.lib().mmssl_infonce_fwd_f32(_ptr(z1), _ptr(z2), n, d, float(tau), _ptr(loss), _ptr(ws), nb,
-                                              _lib.stream_ptr())
-        _lib.check(rc, "mmssl_infonce_fwd_f32")
-        ctx.save_for_backward(z1, z2, ws)
-        ctx.tau = float(tau)
+        if z1.dim() != 2 or z2.dim() != 2 or z1.shape[1] != z2.shape[1] or (idx is None and z1.shape != z2.shape):
+            raise _lib.MmsslError("infonce: z1/z2 must be [n, d] (or tables + idx)")
+        loss, ws, n, d = _infonce_fwd_raw(z1, z2, idx, tau)
+        ctx.save_for_backward(ws, idx)
+        ctx.cfg = (n, d, float(tau), z1.shape, z2.shape)
         return loss
 
     @staticmethod
     def backward(ctx, g):
-        z1, z2, ws = ctx.saved_tensors
-        n, d = z1.shape
+        ws, idx = ctx.saved_tensors
+        n, d, tau, s1, s2 = ctx.cfg
         g = g.contiguous().to(torch.float32)
-        gz1, gz2 = torch.empty_like(z1), torch.empty_like(z2)
-        rc = _lib.lib().mmssl_infonce_bwd_f32(_ptr(z1), _ptr(z2), n, d, ctx.tau, _ptr(g), _ptr(gz1), _ptr(gz2),
-                                              _ptr(ws), ws.numel() * 4, _lib.stream_ptr())
-        _lib.check(rc, "mmssl_infonce_bwd_f32")
-        return gz1, gz2, None
+        alloc = torch.zeros if idx is not None else torch.empty
+        gz1 = alloc(s1, dtype=torch.float32, device=ws.device) if ctx.needs_input_grad[0] else None
+        gz2 = alloc(s2, dtype=torch.float32, device=ws.device) if ctx.needs_input_grad[1] else None
+        if gz1 is not None or gz2 is not None:
+            _infonce_bwd_raw(idx, n, d, tau, g, gz1, gz2, ws)
+        return gz1, gz2, None, None
 
 
-def infonce(z1, z2, tau=0.5):
+def infonce(z1, z2, tau=0.5, idx=None):
     """The reference's batched_contrastive_loss(z1, z2) (its 1024-row blocking is exactly the
-    full-matrix formula)."""
-    return _InfoNCE.apply(z1, z2, tau)
+    full-matrix formula). With `idx` (int64 [n]) z1/z2 are whole tables and the
+    gather table[idx] is fused into the kernels (main.py:411-412 gathers both by `users`)."""
+    return _InfoNCE.apply(z1, z2, None if idx is None else _idx(idx, "idx", z1.device), tau)
 
 
 # ---------------------------------------------------------------------------------------
@@ -316,3 +330,76 @@ def bpr(u, p, n, decay, batch_size):
     """Trainer.bpr_loss on already-gathered [B, d] rows (the reference's signature)."""
     out = _Bpr.apply(u, p, n, None, None, None, decay, batch_size)
     return out[0], out[1]
+
+
+# ---------------------------------------------------------------------------------------
+# all batch losses in one autograd node          main.py:368-371, 411-412, 499-511
+# ---------------------------------------------------------------------------------------
+class _BatchLosses(torch.autograd.Function):
+    """(mf, emb, cl_img, cl_txt) from the full tables and the batch indices: fused-gather BPR and
+    two fused-gather InfoNCE calls that share the user table. The backward zero-fills each table
+    gradient ONCE and all three kernels scatter-add into it (instead of three dense gradients
+    summed by autograd)."""
+
+    @staticmethod
+    def forward(ctx, ua, ia, img_uid, txt_uid, users, pos, neg, decay, batch_size, tau):
+        ua, ia = _chk(ua, "ua"), _chk(ia, "ia")
+        img_uid, txt_uid = _chk(img_uid, "img_uid"), _chk(txt_uid, "txt_uid")
+        B, d = users.shape[0], ua.shape[1]
+        out = torch.empty(5, dtype=torch.float32, device=ua.device)     # mf, emb, reg(=0), cl_img, cl_txt
+        nb = _lib.lib().mmssl_bpr_workspace_bytes(B)
+        wsb = torch.empty(nb // 4, dtype=torch.float32, device=ua.device)
+        rc = _lib.lib().mmssl_bpr_fwd_f32(_ptr(ua), _ptr(ia), None, _ptr(users), _ptr(pos), _ptr(neg), B, d,
+                                          float(decay), int(batch_size), _ptr(out), _ptr(wsb), nb, _lib.stream_ptr())
+        _lib.check(rc, "mmssl_bpr_fwd_f32")
+        l1, ws1, n, _ = _infonce_fwd_raw(img_uid, ua, users, tau)
+        l2, ws2, n, _ = _infonce_fwd_raw(txt_uid, ua, users, tau)
+        out[3:4].copy_(l1.view(1))
+        out[4:5].copy_(l2.view(1))
+        ctx.save_for_backward(ua, ia, users, pos, neg, ws1, ws2)
+        ctx.cfg = (B, d, float(decay), int(batch_size), float(tau), img_uid.shape, txt_uid.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        ua, ia, users, pos, neg, ws1, ws2 = ctx.saved_tensors
+        B, d, decay, batch_size, tau, s_img, s_txt = ctx.cfg
+        g = g.contiguous().to(torch.float32)
+        g_ua = torch.zeros_like(ua)
+        g_ia = torch.zeros_like(ia)
+        rc = _lib.lib().mmssl_bpr_bwd_f32(_ptr(ua), _ptr(ia), None, _ptr(users), _ptr(pos), _ptr(neg), B, d, decay,
+                                          batch_size, _ptr(g[0:1]), _ptr(g[1:2]), _ptr(g_ua), _ptr(g_ia), None,
+                                          _lib.stream_ptr())
+        _lib.check(rc, "mmssl_bpr_bwd_f32")
+        g_img = torch.zeros(s_img, dtype=torch.float32, device=ua.device) if ctx.needs_input_grad[2] else None
+        g_txt = torch.zeros(s_txt, dtype=torch.float32, device=ua.device) if ctx.needs_input_grad[3] else None
+        _infonce_bwd_raw(users, B, d, tau, g[3:4], g_img, g_ua, ws1)
+        _infonce_bwd_raw(users, B, d, tau, g[4:5], g_txt, g_ua, ws2)
+        return g_ua, g_ia, g_img, g_txt, None, None, None, None, None, None
+
+
+def batch_losses(ua, ia, img_uid, txt_uid, users, pos, neg, decay, batch_size, tau):
+    """Returns (mf_loss, emb_loss, cl_img, cl_txt) — see _BatchLosses."""
+    dev = ua.device
+    out = _BatchLosses.apply(ua, ia, img_uid, txt_uid, _idx(users, "users", dev), _idx(pos, "pos", dev),
+                             _idx(neg, "neg", dev), decay, batch_size, tau)
+    return out[0], out[1], out[3], out[4]
+
+
+class _ZeroGradAnchor(torch.autograd.Function):
+    """Identity on `x` that also makes the result depend on `w` with an exactly-zero gradient
+    (used when a provably-zero branch of the reference graph is skipped, so that the optimiser
+    still sees a zero — not a missing — gradient for `w`, like the reference's autograd)."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        ctx.wshape, ctx.wdev = w.shape, w.device
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, torch.zeros(ctx.wshape, dtype=torch.float32, device=ctx.wdev)
+
+
+def zero_grad_anchor(x, w):
+    return _ZeroGradAnchor.apply(x, w)

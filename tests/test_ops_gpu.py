@@ -244,3 +244,40 @@ def test_ops_refuse_cpu_tensors():
         ops.l2norm_rows(torch.randn(4, 64))
     with pytest.raises(MmsslError):
         ops.infonce(torch.randn(4, 64), torch.randn(4, 64))
+
+
+def test_infonce_fused_gather_and_batch_losses():
+    """idx form of InfoNCE (gather fused, scatter-add backward) and the single-node batch losses
+    (BPR + 2x InfoNCE sharing one zero-filled table gradient) against the oracle."""
+    ops, _ = _ops()
+    gen = torch.Generator().manual_seed(21)
+    U, I, B, d = 700, 300, 256, 64
+    ua = torch.randn(U, d, generator=gen) * 0.5
+    ia = torch.randn(I, d, generator=gen) * 0.5
+    t_img = torch.randn(U, d, generator=gen)
+    t_txt = torch.randn(U, d, generator=gen)
+    t_txt[:50] = 0
+    users = torch.randperm(U, generator=gen)[:B]
+    pos = torch.randint(0, I, (B,), generator=gen)
+    neg = torch.randint(0, I, (B,), generator=gen)
+    w = torch.tensor([0.7, 3.0, 0.03, 0.05])
+    R = [x.clone().requires_grad_(True) for x in (ua, ia, t_img, t_txt)]
+    mf, emb, _ = O.bpr(R[0][users], R[1][pos], R[1][neg], 1e-5, 1024)
+    c1 = O.infonce(R[2][users], R[0][users], 0.5)
+    c2 = O.infonce(R[3][users], R[0][users], 0.5)
+    (w[0] * mf + w[1] * emb + w[2] * c1 + w[3] * c2).backward()
+    G = [x.clone().to(DEV).requires_grad_(True) for x in (ua, ia, t_img, t_txt)]
+    gmf, gemb, g1, g2 = ops.batch_losses(G[0], G[1], G[2], G[3], users.to(DEV), pos.to(DEV), neg.to(DEV), 1e-5, 1024, 0.5)
+    for got, ref in ((gmf, mf), (gemb, emb), (g1, c1), (g2, c2)):
+        assert abs(float(got) - float(ref)) <= 1e-5 * abs(float(ref)), (float(got), float(ref))
+    (w[0] * gmf + w[1] * gemb + w[2] * g1 + w[3] * g2).backward()
+    for a, b in zip(G, R):
+        assert H.rel_err(a.grad.cpu(), b.grad) < 2e-4
+    # idx form alone == gathered form
+    z1 = t_img.to(DEV).requires_grad_(True)
+    z2 = ua.to(DEV).requires_grad_(True)
+    l_idx = ops.infonce(z1, z2, 0.5, idx=users.to(DEV))
+    l_dense = ops.infonce(t_img[users].to(DEV), ua[users].to(DEV), 0.5)
+    assert float(l_idx) == float(l_dense)
+    l_idx.backward()
+    assert float(z1.grad[~torch.isin(torch.arange(U), users).to(DEV)].abs().max()) == 0.0

@@ -90,10 +90,18 @@ int mmssl_plan_fill_host(const int32_t* rowptr, int32_t rows, int32_t* group_ite
  * ---------------------------------------------------------------------------------- */
 #define MMSSL_EPI_NONE    0
 #define MMSSL_EPI_SOFTMAX 1
+/* extended (mmssl_spmm_ex_f32 only): the two epilogues that let the whole backward of the GCN
+ * chain (Models.py:199-214: layer mean + last-layer softmax) consist of SpMM launches alone */
+#define MMSSL_EPI_AXPY             2  /* Y = A.X + alpha * Z[row]                               */
+#define MMSSL_EPI_AXPY_SOFTMAX_BWD 3  /* t = A.X + alpha * Z[row]; Y = S[row]*(t - <t,S[row]>)  */
 
 size_t mmssl_spmm_workspace_bytes(const mmssl_graph* g, int transpose, int d);
 int mmssl_spmm_f32(const mmssl_graph* g, int transpose, const float* X, int d, float* Y,
                    int epilogue, void* workspace, size_t workspace_bytes, void* stream);
+/* Z, S: [rows_out, d] fp32 (NULL unless the epilogue reads them). */
+int mmssl_spmm_ex_f32(const mmssl_graph* g, int transpose, const float* X, int d, float* Y,
+                      int epilogue, const float* Z, float alpha, const float* S, void* workspace,
+                      size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Row kernels
@@ -109,8 +117,24 @@ int mmssl_l2norm_rows_f32(const float* X, const float* Base, float alpha, int64_
                           float eps, float* Y, void* stream);
 int mmssl_l2norm_rows_bwd_f32(const float* X, const float* gY, float alpha, int64_t rows, int d,
                               float eps, float* gX, void* stream);
-int mmssl_softmax_rows_bwd_f32(const float* Y, const float* gY, int64_t rows, int d, float* gX,
-                               void* stream);
+int mmssl_softmax_rows_bwd_f32(const float* Y, const float* gY, float scale, int64_t rows, int d,
+                               float* gX, void* stream);   /* gX = scale * Y*(gY - <gY,Y>) */
+/* Layer mean + modality fusion of the final embeddings (Models.py:213-218) in one pass:
+ *   out = inv * sum_k layers[k] + r * normalize(A) + r * normalize(B)
+ * `layers` is a HOST array of n_layers (<= 8) device pointers. If sumsq_part != NULL the kernel
+ * also leaves per-block partials of sum(|A|^2 + |B|^2) there (mmssl_layer_combine_blocks() floats)
+ * for the feature regulariser (main.py:252-257).
+ * bwd: gA = r * normalize_bwd(A, G) + c * A,  gB likewise,  gL = inv * G  (gL / c may be NULL;
+ * c = c_scale * c_dev[0], a device scalar: the incoming gradient of the sum of squares). */
+int mmssl_layer_combine_blocks(int64_t rows, int d);
+int mmssl_layer_combine_f32(const float* const* layers, int n_layers, float inv, const float* A,
+                            const float* B, float r, int64_t rows, int d, float eps, float* out,
+                            float* sumsq_part, void* stream);
+int mmssl_layer_combine_bwd_f32(const float* A, const float* B, const float* G, float r, float inv,
+                                const float* c_dev, float c_scale, int64_t rows, int d, float eps,
+                                float* gA, float* gB, float* gL, void* stream);
+/* out[0] = sum of `n` floats (fixed order, one block): second stage for the partials above. */
+int mmssl_sum_partials_f32(const float* part, int64_t n, float* out, void* stream);
 size_t mmssl_sumsq_workspace_bytes(int64_t n);
 int mmssl_sumsq_f32(const float* X, int64_t n, float* out, void* workspace,
                     size_t workspace_bytes, void* stream);

@@ -116,6 +116,16 @@ class MMSSL(nn.Module):
         w = (0.5 * fold).t().contiguous()                          # linear() takes [out, in]
         return ops.linear(emb_a + emb_b, w)
 
+    def feat_sumsq(self, g_item_image, g_item_text, g_user_image, g_user_text):
+        """|a|^2+|b|^2+|c|^2+|d|^2 for the feature regulariser. When the arguments are exactly the
+        four modal feature tensors of the latest forward, the value fused into that forward is
+        returned (same autograd graph); anything else is reduced explicitly."""
+        cached = getattr(self, "_feat_sumsq", None)
+        args4 = (g_item_image, g_item_text, g_user_image, g_user_text)
+        if cached is not None and all(a is b for a, b in zip(cached[1], args4)):
+            return cached[0]
+        return ops.sumsq(g_item_image) + ops.sumsq(g_item_text) + ops.sumsq(g_user_image) + ops.sumsq(g_user_text)
+
     def _zeros(self, rows, like):
         """Cached all-zero [rows, d] tensor (the value of A.E for an empty graph A)."""
         key = (rows, like.shape[1], like.device)
@@ -182,17 +192,11 @@ class MMSSL(nn.Module):
         self.embedding_dict["item"]["image"] = image_item_id
         self.embedding_dict["item"]["text"] = text_item_id
 
-        u_sum, i_sum = u, i
-        for layer in range(self.n_ui_layers):
-            epi = ops.EPI_SOFTMAX if layer == self.n_ui_layers - 1 else ops.EPI_NONE
-            u = ops.spmm(ui, i, epi)
-            i = ops.spmm(iu, u, epi)          # consumes the already-updated (softmaxed) users
-            u_sum = u_sum + u
-            i_sum = i_sum + i
-        inv = 1.0 / (self.n_ui_layers + 1)
-        r = args.model_cat_rate
-        u_g = ops.l2norm_rows(text_user_feats, ops.l2norm_rows(image_user_feats, u_sum * inv, r), r)
-        i_g = ops.l2norm_rows(text_item_feats, ops.l2norm_rows(image_item_feats, i_sum * inv, r), r)
+        # G-layer propagation, layer mean and "+ rate * normalize(modal feats)" as one fused node;
+        # its by-product `ss` is the feature regulariser's sum of squares (main.py:252-257).
+        u_g, i_g, ss = ops.propagate_fuse(ui, iu, u, i, image_user_feats, text_user_feats, image_item_feats,
+                                          text_item_feats, self.n_ui_layers, args.model_cat_rate)
+        self._feat_sumsq = (ss, (image_item_feats, text_item_feats, image_user_feats, text_user_feats))
         return (u_g, i_g, image_item_feats, text_item_feats, image_user_feats, text_user_feats, u_g, i_g,
                 image_user_id, text_user_id, image_item_id, text_item_id)
 

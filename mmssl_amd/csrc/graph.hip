@@ -307,6 +307,35 @@ __device__ __forceinline__ float4 row_softmax(float4 a) {
   return a;
 }
 
+// Store-side epilogues (row-local, fused into the SpMM):
+//   NONE              y = acc
+//   SOFTMAX           y = softmax(acc)                                   (last GCN layer, fwd)
+//   AXPY              y = acc + alpha * Z[row]                           (bwd: + layer-mean grad)
+//   AXPY_SOFTMAX_BWD  t = acc + alpha * Z[row];  y = S[row] * (t - <t, S[row]>)   (bwd through softmax)
+struct EpiArgs {
+  const float4* Z;
+  const float4* S;
+  float alpha;
+};
+
+template <int LPR, int EPI>
+__device__ __forceinline__ float4 apply_epilogue(float4 acc, int row, int lig, const EpiArgs& e) {
+  if (EPI == MMSSL_EPI_SOFTMAX) return row_softmax<LPR>(acc);
+  if (EPI == MMSSL_EPI_AXPY || EPI == MMSSL_EPI_AXPY_SOFTMAX_BWD) {
+    const float4 z = e.Z[(size_t)row * LPR + lig];
+    acc.x = fmaf(e.alpha, z.x, acc.x);
+    acc.y = fmaf(e.alpha, z.y, acc.y);
+    acc.z = fmaf(e.alpha, z.z, acc.z);
+    acc.w = fmaf(e.alpha, z.w, acc.w);
+  }
+  if (EPI == MMSSL_EPI_AXPY_SOFTMAX_BWD) {
+    const float4 y = e.S[(size_t)row * LPR + lig];
+    const float dot = group_sum<LPR>(f4_dot(acc, y));
+    acc = make_float4(y.x * (acc.x - dot), y.y * (acc.y - dot), y.z * (acc.z - dot), y.w * (acc.w - dot));
+  }
+  return acc;
+}
+
 // grid = n_wblocks (4 wave items each, heaviest first) + n_gblocks (256/LPR group items each)
 template <int LPR, int EPI>
 __global__ __launch_bounds__(kBlock) void spmm_kernel(const int4* __restrict__ gitems, int n_g,
@@ -314,7 +343,7 @@ __global__ __launch_bounds__(kBlock) void spmm_kernel(const int4* __restrict__ g
                                                       int n_wblocks, const Edge* __restrict__ edges,
                                                       const float4* __restrict__ X,
                                                       float4* __restrict__ Y,
-                                                      float4* __restrict__ partials) {
+                                                      float4* __restrict__ partials, EpiArgs epi) {
   constexpr int GPW = kWave / LPR;   // lane groups per wave
   constexpr int GPB = kBlock / LPR;  // lane groups per block
   const int lane = threadIdx.x & 63;
@@ -324,7 +353,7 @@ __global__ __launch_bounds__(kBlock) void spmm_kernel(const int4* __restrict__ g
     if (gi >= n_g) return;
     const int4 it = gitems[gi];
     float4 acc = gather_rows<LPR>(edges, X, it.y, it.z, 0, 1, lig);
-    if (EPI == MMSSL_EPI_SOFTMAX) acc = row_softmax<LPR>(acc);
+    acc = apply_epilogue<LPR, EPI>(acc, it.x, lig, epi);
     Y[(size_t)it.x * LPR + lig] = acc;
   } else {
     const int wi = (int)blockIdx.x * 4 + ((int)threadIdx.x >> 6);
@@ -336,7 +365,7 @@ __global__ __launch_bounds__(kBlock) void spmm_kernel(const int4* __restrict__ g
     acc.z = cross_group_sum<LPR>(acc.z);
     acc.w = cross_group_sum<LPR>(acc.w);
     if (it.w < 0) {
-      if (EPI == MMSSL_EPI_SOFTMAX) acc = row_softmax<LPR>(acc);
+      acc = apply_epilogue<LPR, EPI>(acc, it.x, lig, epi);
       if (lane < LPR) Y[(size_t)it.x * LPR + lig] = acc;
     } else if (lane < LPR) {
       partials[(size_t)it.w * LPR + lig] = acc;
@@ -350,7 +379,7 @@ __global__ __launch_bounds__(kBlock) void spmm_kernel(const int4* __restrict__ g
 template <int LPR, int EPI>
 __global__ __launch_bounds__(kBlock) void spmm_multi_kernel(const int4* __restrict__ multi, int n_multi,
                                                             const float4* __restrict__ partials,
-                                                            float4* __restrict__ Y) {
+                                                            float4* __restrict__ Y, EpiArgs epi) {
   constexpr int GPB = kBlock / LPR;
   __shared__ float4 red[kBlock];
   const int lig = threadIdx.x & (LPR - 1);
@@ -375,13 +404,14 @@ __global__ __launch_bounds__(kBlock) void spmm_multi_kernel(const int4* __restri
       acc.z += p.z;
       acc.w += p.w;
     }
-    if (EPI == MMSSL_EPI_SOFTMAX) acc = row_softmax<LPR>(acc);
+    acc = apply_epilogue<LPR, EPI>(acc, it.x, lig, epi);
     Y[(size_t)it.x * LPR + lig] = acc;
   }
 }
 
 template <int LPR, int EPI>
-int launch_spmm(const DirPlan& p, const float* X, float* Y, float* partials, hipStream_t s) {
+int launch_spmm(const DirPlan& p, const float* X, float* Y, float* partials, const EpiArgs& epi,
+                hipStream_t s) {
   constexpr int GPB = kBlock / LPR;
   const int n_wblocks = (int)((p.n_w + 3) / 4);
   const int n_gblocks = (int)((p.n_g + GPB - 1) / GPB);
@@ -389,22 +419,27 @@ int launch_spmm(const DirPlan& p, const float* X, float* Y, float* partials, hip
     hipLaunchKernelGGL((spmm_kernel<LPR, EPI>), dim3(n_wblocks + n_gblocks), dim3(kBlock), 0, s,
                        p.gitems, (int)p.n_g, p.witems, (int)p.n_w, n_wblocks, p.edges,
                        reinterpret_cast<const float4*>(X), reinterpret_cast<float4*>(Y),
-                       reinterpret_cast<float4*>(partials));
+                       reinterpret_cast<float4*>(partials), epi);
     MMSSL_LAUNCH_CHECK();
   }
   if (p.n_multi > 0) {
     hipLaunchKernelGGL((spmm_multi_kernel<LPR, EPI>), dim3((unsigned)p.n_multi), dim3(kBlock), 0, s, p.multi,
                        (int)p.n_multi, reinterpret_cast<const float4*>(partials),
-                       reinterpret_cast<float4*>(Y));
+                       reinterpret_cast<float4*>(Y), epi);
     MMSSL_LAUNCH_CHECK();
   }
   return 0;
 }
 
 template <int LPR>
-int dispatch_epi(const DirPlan& p, const float* X, float* Y, float* partials, int epi, hipStream_t s) {
-  if (epi == MMSSL_EPI_NONE) return launch_spmm<LPR, MMSSL_EPI_NONE>(p, X, Y, partials, s);
-  if (epi == MMSSL_EPI_SOFTMAX) return launch_spmm<LPR, MMSSL_EPI_SOFTMAX>(p, X, Y, partials, s);
+int dispatch_epi(const DirPlan& p, const float* X, float* Y, float* partials, int epi, const EpiArgs& e,
+                 hipStream_t s) {
+  switch (epi) {
+    case MMSSL_EPI_NONE: return launch_spmm<LPR, MMSSL_EPI_NONE>(p, X, Y, partials, e, s);
+    case MMSSL_EPI_SOFTMAX: return launch_spmm<LPR, MMSSL_EPI_SOFTMAX>(p, X, Y, partials, e, s);
+    case MMSSL_EPI_AXPY: return launch_spmm<LPR, MMSSL_EPI_AXPY>(p, X, Y, partials, e, s);
+    case MMSSL_EPI_AXPY_SOFTMAX_BWD: return launch_spmm<LPR, MMSSL_EPI_AXPY_SOFTMAX_BWD>(p, X, Y, partials, e, s);
+  }
   return MMSSL_E_BADARG;
 }
 
@@ -416,23 +451,37 @@ extern "C" size_t mmssl_spmm_workspace_bytes(const mmssl_graph* g, int transpose
   return (size_t)p.n_slots * (size_t)d * sizeof(float);
 }
 
-extern "C" int mmssl_spmm_f32(const mmssl_graph* g, int transpose, const float* X, int d, float* Y,
-                              int epilogue, void* workspace, size_t workspace_bytes, void* stream) {
+extern "C" int mmssl_spmm_ex_f32(const mmssl_graph* g, int transpose, const float* X, int d, float* Y,
+                                 int epilogue, const float* Z, float alpha, const float* S, void* workspace,
+                                 size_t workspace_bytes, void* stream) {
   if (!g || !Y) return MMSSL_E_BADARG;
   if (!supported_d(d)) return MMSSL_E_UNSUPP;
   const DirPlan& p = transpose ? g->bwd : g->fwd;
   if (p.rows == 0) return 0;
   if (!X && p.nnz > 0) return MMSSL_E_BADARG;
-  if (((uintptr_t)X | (uintptr_t)Y | (uintptr_t)workspace) & 15) return MMSSL_E_BADARG;
+  if ((epilogue == MMSSL_EPI_AXPY || epilogue == MMSSL_EPI_AXPY_SOFTMAX_BWD) && !Z) return MMSSL_E_BADARG;
+  if (epilogue == MMSSL_EPI_AXPY_SOFTMAX_BWD && !S) return MMSSL_E_BADARG;
+  if (((uintptr_t)X | (uintptr_t)Y | (uintptr_t)workspace | (uintptr_t)Z | (uintptr_t)S) & 15) return MMSSL_E_BADARG;
   const size_t need = (size_t)p.n_slots * (size_t)d * sizeof(float);
   if (need > 0 && (!workspace || workspace_bytes < need)) return MMSSL_E_WORKSPACE;
   hipStream_t s = as_stream(stream);
   float* ws = reinterpret_cast<float*>(workspace);
+  EpiArgs e;
+  e.Z = reinterpret_cast<const float4*>(Z);
+  e.S = reinterpret_cast<const float4*>(S);
+  e.alpha = alpha;
   switch (d) {
-    case 32: return dispatch_epi<8>(p, X, Y, ws, epilogue, s);
-    case 64: return dispatch_epi<16>(p, X, Y, ws, epilogue, s);
-    case 128: return dispatch_epi<32>(p, X, Y, ws, epilogue, s);
-    case 256: return dispatch_epi<64>(p, X, Y, ws, epilogue, s);
+    case 32: return dispatch_epi<8>(p, X, Y, ws, epilogue, e, s);
+    case 64: return dispatch_epi<16>(p, X, Y, ws, epilogue, e, s);
+    case 128: return dispatch_epi<32>(p, X, Y, ws, epilogue, e, s);
+    case 256: return dispatch_epi<64>(p, X, Y, ws, epilogue, e, s);
   }
   return MMSSL_E_UNSUPP;
+}
+
+extern "C" int mmssl_spmm_f32(const mmssl_graph* g, int transpose, const float* X, int d, float* Y,
+                              int epilogue, void* workspace, size_t workspace_bytes, void* stream) {
+  if (epilogue != MMSSL_EPI_NONE && epilogue != MMSSL_EPI_SOFTMAX) return MMSSL_E_BADARG;
+  return mmssl_spmm_ex_f32(g, transpose, X, d, Y, epilogue, nullptr, 0.f, nullptr, workspace, workspace_bytes,
+                           stream);
 }

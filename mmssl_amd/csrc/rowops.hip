@@ -64,7 +64,7 @@ __global__ __launch_bounds__(kBlock) void l2norm_bwd_kernel(const float4* __rest
 
 template <int LPR>
 __global__ __launch_bounds__(kBlock) void softmax_bwd_kernel(const float4* __restrict__ Yv,
-                                                             const float4* __restrict__ G,
+                                                             const float4* __restrict__ G, float scale,
                                                              int64_t rows, float4* __restrict__ GX) {
   constexpr int GPB = kBlock / LPR;
   const int lig = threadIdx.x & (LPR - 1);
@@ -73,8 +73,94 @@ __global__ __launch_bounds__(kBlock) void softmax_bwd_kernel(const float4* __res
     const float4 y = Yv[r * LPR + lig];
     const float4 g = G[r * LPR + lig];
     const float s = group_sum<LPR>(f4_dot(y, g));
-    GX[r * LPR + lig] = make_float4(y.x * (g.x - s), y.y * (g.y - s), y.z * (g.z - s), y.w * (g.w - s));
+    GX[r * LPR + lig] = make_float4(scale * y.x * (g.x - s), scale * y.y * (g.y - s), scale * y.z * (g.z - s),
+                                    scale * y.w * (g.w - s));
   }
+}
+
+// ---- layer mean + modality fusion (+ feature-regulariser partial sums) ----------------------
+constexpr int kMaxLayers = 8;
+struct LayerPtrs {
+  const float4* p[kMaxLayers];
+};
+
+// out = inv * sum_k L_k + r * A/max(|A|,eps) + r * B/max(|B|,eps);  part[block] = sum(|A|^2+|B|^2)
+template <int LPR>
+__global__ __launch_bounds__(kBlock) void combine_fwd_kernel(LayerPtrs L, int n_layers, float inv,
+                                                             const float4* __restrict__ A,
+                                                             const float4* __restrict__ B, float r, int64_t rows,
+                                                             float eps, float4* __restrict__ out,
+                                                             float* __restrict__ part) {
+  __shared__ float red[4];
+  constexpr int GPB = kBlock / LPR;
+  const int lig = threadIdx.x & (LPR - 1);
+  const int64_t stride = (int64_t)gridDim.x * GPB;
+  float ss = 0.f;
+  for (int64_t row = (int64_t)blockIdx.x * GPB + threadIdx.x / LPR; row < rows; row += stride) {
+    const int64_t o = row * LPR + lig;
+    float4 acc = L.p[0][o];
+    for (int k = 1; k < n_layers; ++k) {
+      const float4 v = L.p[k][o];
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    const float4 a = A[o], b = B[o];
+    const float sa = group_sum<LPR>(f4_dot(a, a));
+    const float sb = group_sum<LPR>(f4_dot(b, b));
+    const float ca = r / fmaxf(sqrtf(sa), eps), cb = r / fmaxf(sqrtf(sb), eps);
+    out[o] = make_float4(fmaf(inv, acc.x, fmaf(ca, a.x, cb * b.x)), fmaf(inv, acc.y, fmaf(ca, a.y, cb * b.y)),
+                         fmaf(inv, acc.z, fmaf(ca, a.z, cb * b.z)), fmaf(inv, acc.w, fmaf(ca, a.w, cb * b.w)));
+    if (lig == 0) ss += sa + sb;
+  }
+  if (part) {                       // uniform branch: every thread of the block takes it
+    const float t = block_sum_256(ss, red);
+    if (threadIdx.x == 0) part[blockIdx.x] = t;
+  }
+}
+
+// gA = r * normalize_bwd(A, G) + c * A ; gB likewise ; gL = inv * G
+template <int LPR>
+__global__ __launch_bounds__(kBlock) void combine_bwd_kernel(const float4* __restrict__ A,
+                                                             const float4* __restrict__ B,
+                                                             const float4* __restrict__ G, float r, float inv,
+                                                             const float* __restrict__ c_dev, float c_scale,
+                                                             int64_t rows, float eps, float4* __restrict__ gA,
+                                                             float4* __restrict__ gB, float4* __restrict__ gL) {
+  constexpr int GPB = kBlock / LPR;
+  const int lig = threadIdx.x & (LPR - 1);
+  const int64_t stride = (int64_t)gridDim.x * GPB;
+  const float c = c_dev ? c_scale * c_dev[0] : 0.f;
+  for (int64_t row = (int64_t)blockIdx.x * GPB + threadIdx.x / LPR; row < rows; row += stride) {
+    const int64_t o = row * LPR + lig;
+    const float4 g = G[o];
+    if (gL) gL[o] = make_float4(inv * g.x, inv * g.y, inv * g.z, inv * g.w);
+#pragma unroll
+    for (int which = 0; which < 2; ++which) {
+      const float4 x = which ? B[o] : A[o];
+      const float ss = group_sum<LPR>(f4_dot(x, x));
+      const float xg = group_sum<LPR>(f4_dot(x, g));
+      const float norm = sqrtf(ss);
+      float a, b;                     // r*normalize_bwd = a*g - b*x
+      if (norm >= eps) {
+        a = r / norm;
+        b = r * xg / (norm * ss);
+      } else {
+        a = r / eps;
+        b = 0.f;
+      }
+      const float4 y = make_float4(a * g.x - (b - c) * x.x, a * g.y - (b - c) * x.y, a * g.z - (b - c) * x.z,
+                                   a * g.w - (b - c) * x.w);
+      (which ? gB : gA)[o] = y;
+    }
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void sum_partials_kernel(const float* __restrict__ part, int64_t n,
+                                                              float* __restrict__ out) {
+  __shared__ float red[4];
+  float acc = 0.f;
+  for (int64_t i = threadIdx.x; i < n; i += kBlock) acc += part[i];
+  const float t = block_sum_256(acc, red);
+  if (threadIdx.x == 0) out[0] = t;
 }
 
 constexpr int kSumsqBlocks = 1024;
@@ -147,14 +233,14 @@ extern "C" int mmssl_l2norm_rows_bwd_f32(const float* X, const float* gY, float 
   return 0;
 }
 
-extern "C" int mmssl_softmax_rows_bwd_f32(const float* Y, const float* gY, int64_t rows, int d, float* gX,
-                                          void* stream) {
+extern "C" int mmssl_softmax_rows_bwd_f32(const float* Y, const float* gY, float scale, int64_t rows, int d,
+                                          float* gX, void* stream) {
   if (rows < 0 || (rows > 0 && (!Y || !gY || !gX))) return MMSSL_E_BADARG;
   if (!supported_d(d)) return MMSSL_E_UNSUPP;
   if (rows == 0) return 0;
   hipStream_t s = as_stream(stream);
   ROW_DISPATCH(softmax_bwd_kernel, reinterpret_cast<const float4*>(Y), reinterpret_cast<const float4*>(gY),
-               rows, reinterpret_cast<float4*>(gX));
+               scale, rows, reinterpret_cast<float4*>(gX));
   MMSSL_LAUNCH_CHECK();
   return 0;
 }
@@ -176,6 +262,51 @@ extern "C" int mmssl_sumsq_f32(const float* X, int64_t n, float* out, void* work
   hipLaunchKernelGGL(sumsq_stage1, dim3((int)nb), dim3(kBlock), 0, s, X, n, part);
   MMSSL_LAUNCH_CHECK();
   hipLaunchKernelGGL(sumsq_stage2, dim3(1), dim3(kBlock), 0, s, part, (int)nb, out);
+  MMSSL_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int mmssl_layer_combine_blocks(int64_t rows, int d) {
+  if (!supported_d(d) || rows <= 0) return 0;
+  return row_grid(rows, d / 4);
+}
+
+extern "C" int mmssl_layer_combine_f32(const float* const* layers, int n_layers, float inv, const float* A,
+                                       const float* B, float r, int64_t rows, int d, float eps, float* out,
+                                       float* sumsq_part, void* stream) {
+  if (rows < 0 || n_layers < 1 || n_layers > kMaxLayers || !layers || (rows > 0 && (!A || !B || !out)))
+    return MMSSL_E_BADARG;
+  if (!supported_d(d)) return MMSSL_E_UNSUPP;
+  if (rows == 0) return 0;
+  LayerPtrs L;
+  for (int k = 0; k < kMaxLayers; ++k)
+    L.p[k] = reinterpret_cast<const float4*>(k < n_layers ? layers[k] : layers[0]);
+  for (int k = 0; k < n_layers; ++k)
+    if (!layers[k]) return MMSSL_E_BADARG;
+  hipStream_t s = as_stream(stream);
+  ROW_DISPATCH(combine_fwd_kernel, L, n_layers, inv, reinterpret_cast<const float4*>(A),
+               reinterpret_cast<const float4*>(B), r, rows, eps, reinterpret_cast<float4*>(out), sumsq_part);
+  MMSSL_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int mmssl_layer_combine_bwd_f32(const float* A, const float* B, const float* G, float r, float inv,
+                                           const float* c_dev, float c_scale, int64_t rows, int d, float eps,
+                                           float* gA, float* gB, float* gL, void* stream) {
+  if (rows < 0 || (rows > 0 && (!A || !B || !G || !gA || !gB))) return MMSSL_E_BADARG;
+  if (!supported_d(d)) return MMSSL_E_UNSUPP;
+  if (rows == 0) return 0;
+  hipStream_t s = as_stream(stream);
+  ROW_DISPATCH(combine_bwd_kernel, reinterpret_cast<const float4*>(A), reinterpret_cast<const float4*>(B),
+               reinterpret_cast<const float4*>(G), r, inv, c_dev, c_scale, rows, eps,
+               reinterpret_cast<float4*>(gA), reinterpret_cast<float4*>(gB), reinterpret_cast<float4*>(gL));
+  MMSSL_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int mmssl_sum_partials_f32(const float* part, int64_t n, float* out, void* stream) {
+  if (n < 0 || !out || (n > 0 && !part)) return MMSSL_E_BADARG;
+  hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(kBlock), 0, as_stream(stream), part, n, out);
   MMSSL_LAUNCH_CHECK();
   return 0;
 }

@@ -49,8 +49,7 @@ class HotPathStep:
         (ua, ia, img_item, txt_item, img_user, txt_user, uemb, _, img_uid, txt_uid, _, _) = m(*self.graphs)
         mf, emb, cl1, cl2 = ops.batch_losses(ua, ia, img_uid, txt_uid, self.users, self.pos, self.neg, self.decay,
                                              self.batch_size, args.tau)
-        feat = args.feat_reg_decay * ((0.5 * ops.sumsq(img_item) + 0.5 * ops.sumsq(txt_item)
-                                       + 0.5 * ops.sumsq(img_user) + 0.5 * ops.sumsq(txt_user)) / m.n_items)
+        feat = (args.feat_reg_decay * 0.5 / m.n_items) * m.feat_sumsq(img_item, txt_item, img_user, txt_user)
         total = mf + emb + feat + args.cl_rate * (cl1 + cl2)
         return total, dict(mf=mf, emb=emb, feat=feat, cl1=cl1, cl2=cl2)
 

@@ -137,8 +137,7 @@ class Trainer(object):
         return ops.infonce(z1, z2, args.tau)
 
     def feat_reg_loss_calculation(self, g_item_image, g_item_text, g_user_image, g_user_text):
-        feat_reg = 0.5 * ops.sumsq(g_item_image) + 0.5 * ops.sumsq(g_item_text) \
-            + 0.5 * ops.sumsq(g_user_image) + 0.5 * ops.sumsq(g_user_text)
+        feat_reg = 0.5 * self.model.feat_sumsq(g_item_image, g_item_text, g_user_image, g_user_text)
         return args.feat_reg_decay * (feat_reg / self.n_items)
 
     def bpr_loss(self, users, pos_items, neg_items):

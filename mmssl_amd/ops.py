@@ -13,6 +13,8 @@ from .graph import GraphPlan
 
 EPI_NONE = 0
 EPI_SOFTMAX = 1
+EPI_AXPY = 2
+EPI_AXPY_SOFTMAX_BWD = 3
 # launch accounting for bench.py (edge.layers = nonzeros of every SpMM launch)
 STATS = {"enabled": False, "spmm_launches": 0, "edge_layers": 0, "spmm_bytes": 0}
 _NORM_EPS = 1e-12        # F.normalize default eps
@@ -33,7 +35,7 @@ def _ptr(t):
 # ---------------------------------------------------------------------------------------
 # SpMM                                    Models.py:69-73 (mm), :177-186, :201-211
 # ---------------------------------------------------------------------------------------
-def _spmm_raw(plan, transpose, X, epilogue):
+def _spmm_raw(plan, transpose, X, epilogue, Z=None, alpha=0.0, S=None):
     rows = plan.shape[1] if transpose else plan.shape[0]
     cols = plan.shape[0] if transpose else plan.shape[1]
     if X.dim() != 2 or X.shape[0] != cols:
@@ -45,9 +47,9 @@ def _spmm_raw(plan, transpose, X, epilogue):
         STATS["spmm_bytes"] += plan.nnz * (8 + 4 * d) + rows * 4 * d + (rows + 1) * 4
     Y = torch.empty((rows, d), dtype=torch.float32, device=X.device)
     ws = plan.workspace(transpose, d)
-    rc = _lib.lib().mmssl_spmm_f32(plan.handle, int(transpose), _ptr(X), d, _ptr(Y), epilogue, _ptr(ws),
-                                   ws.numel() * 4, _lib.stream_ptr())
-    _lib.check(rc, "mmssl_spmm_f32")
+    rc = _lib.lib().mmssl_spmm_ex_f32(plan.handle, int(transpose), _ptr(X), d, _ptr(Y), epilogue, _ptr(Z),
+                                      float(alpha), _ptr(S), _ptr(ws), ws.numel() * 4, _lib.stream_ptr())
+    _lib.check(rc, "mmssl_spmm_ex_f32")
     return Y
 
 
@@ -81,9 +83,9 @@ def spmm(plan, X, epilogue=EPI_NONE, transpose=False):
 # ---------------------------------------------------------------------------------------
 # row kernels            F.normalize Models.py:196-197,217-218; main.py:212-213
 # ---------------------------------------------------------------------------------------
-def softmax_rows_bwd(Y, gY):
+def softmax_rows_bwd(Y, gY, scale=1.0):
     gX = torch.empty_like(Y)
-    rc = _lib.lib().mmssl_softmax_rows_bwd_f32(_ptr(Y), _ptr(gY), Y.shape[0], Y.shape[1], _ptr(gX),
+    rc = _lib.lib().mmssl_softmax_rows_bwd_f32(_ptr(Y), _ptr(gY), float(scale), Y.shape[0], Y.shape[1], _ptr(gX),
                                                _lib.stream_ptr())
     _lib.check(rc, "mmssl_softmax_rows_bwd_f32")
     return gX
@@ -403,3 +405,87 @@ class _ZeroGradAnchor(torch.autograd.Function):
 
 def zero_grad_anchor(x, w):
     return _ZeroGradAnchor.apply(x, w)
+
+
+# ---------------------------------------------------------------------------------------
+# GCN propagation + layer mean + modality fusion as ONE autograd node       Models.py:199-218
+# ---------------------------------------------------------------------------------------
+import ctypes as _ct
+
+
+def _combine_fwd(layers, inv, A, B, r, part):
+    out = torch.empty_like(A)
+    arr = (_ct.c_void_p * len(layers))(*[t.data_ptr() for t in layers])
+    rc = _lib.lib().mmssl_layer_combine_f32(arr, len(layers), float(inv), _ptr(A), _ptr(B), float(r), A.shape[0],
+                                            A.shape[1], _NORM_EPS, _ptr(out), _ptr(part), _lib.stream_ptr())
+    _lib.check(rc, "mmssl_layer_combine_f32")
+    return out
+
+
+def _combine_bwd(A, B, G, r, inv, c_dev, c_scale, want_gL):
+    gA, gB = torch.empty_like(A), torch.empty_like(B)
+    gL = torch.empty_like(A) if want_gL else None
+    rc = _lib.lib().mmssl_layer_combine_bwd_f32(_ptr(A), _ptr(B), _ptr(G), float(r), float(inv), _ptr(c_dev),
+                                                float(c_scale), A.shape[0], A.shape[1], _NORM_EPS, _ptr(gA), _ptr(gB),
+                                                _ptr(gL), _lib.stream_ptr())
+    _lib.check(rc, "mmssl_layer_combine_bwd_f32")
+    return gA, gB, gL
+
+
+class _PropagateFuse(torch.autograd.Function):
+    """u_l = A_ui.i_{l-1}, i_l = A_iu.u_l (row softmax on the last layer), then
+         u_g = mean_l(u_l) + r*normalize(img_user) + r*normalize(txt_user)        (items alike)
+    plus ss = |img_user|^2+|txt_user|^2+|img_item|^2+|txt_item|^2 (the feature regulariser's sum,
+    a by-product of the same pass). Forward: 2G SpMM + 2 combine + 1 tiny reduce. Backward: 2 combine
+    + 1 softmax-bwd + 2G SpMM whose epilogues add the layer-mean gradient and apply the softmax
+    backward, so no separate accumulation / scaling kernels run."""
+
+    @staticmethod
+    def forward(ctx, u0, i0, img_user, txt_user, img_item, txt_item, ui, iu, n_layers, r):
+        u0, i0 = _chk(u0, "u0"), _chk(i0, "i0")
+        img_user, txt_user = _chk(img_user, "img_user"), _chk(txt_user, "txt_user")
+        img_item, txt_item = _chk(img_item, "img_item"), _chk(txt_item, "txt_item")
+        us, its = [u0], [i0]
+        u, i = u0, i0
+        for l in range(n_layers):
+            epi = EPI_SOFTMAX if l == n_layers - 1 else EPI_NONE
+            u = _spmm_raw(ui, False, i, epi)
+            i = _spmm_raw(iu, False, u, epi)
+            us.append(u)
+            its.append(i)
+        inv = 1.0 / (n_layers + 1)
+        d = u0.shape[1]
+        nbu = _lib.lib().mmssl_layer_combine_blocks(u0.shape[0], d)
+        nbi = _lib.lib().mmssl_layer_combine_blocks(i0.shape[0], d)
+        part = torch.empty(nbu + nbi, dtype=torch.float32, device=u0.device)
+        u_g = _combine_fwd(us, inv, img_user, txt_user, r, part[:nbu])
+        i_g = _combine_fwd(its, inv, img_item, txt_item, r, part[nbu:])
+        ss = torch.empty((), dtype=torch.float32, device=u0.device)
+        rc = _lib.lib().mmssl_sum_partials_f32(_ptr(part), nbu + nbi, _ptr(ss), _lib.stream_ptr())
+        _lib.check(rc, "mmssl_sum_partials_f32")
+        ctx.save_for_backward(img_user, txt_user, img_item, txt_item, us[-1], its[-1])
+        ctx.cfg = (ui, iu, n_layers, float(r), inv)
+        return u_g, i_g, ss
+
+    @staticmethod
+    def backward(ctx, Gu, Gi, g_ss):
+        img_user, txt_user, img_item, txt_item, uG, iG = ctx.saved_tensors
+        ui, iu, n_layers, r, inv = ctx.cfg
+        Gu, Gi = _chk(Gu, "Gu"), _chk(Gi, "Gi")
+        g_ss = g_ss.contiguous().to(torch.float32)
+        # d(ss)/dx = 2x; normalize-backward and the regulariser term share one pass over A, B
+        g_iu_, g_tu_, g_u0 = _combine_bwd(img_user, txt_user, Gu, r, inv, g_ss, 2.0, True)
+        g_ii_, g_ti_, _ = _combine_bwd(img_item, txt_item, Gi, r, inv, g_ss, 2.0, False)
+        # last layer: i_G only feeds the mean; u_G feeds the mean and A_iu.u_G
+        gi = softmax_rows_bwd(iG, Gi, inv)
+        gu = _spmm_raw(iu, True, gi, EPI_AXPY_SOFTMAX_BWD, Gu, inv, uG)
+        gi = _spmm_raw(ui, True, gu, EPI_AXPY, Gi, inv)            # total gradient of i_{G-1}
+        for _ in range(n_layers - 1):
+            gu = _spmm_raw(iu, True, gi, EPI_AXPY, Gu, inv)
+            gi = _spmm_raw(ui, True, gu, EPI_AXPY, Gi, inv)
+        return g_u0, gi, g_iu_, g_tu_, g_ii_, g_ti_, None, None, None, None
+
+
+def propagate_fuse(ui, iu, u0, i0, img_user, txt_user, img_item, txt_item, n_layers, r):
+    """(u_g, i_g, ss): see _PropagateFuse. `ui`, `iu` are GraphPlans."""
+    return _PropagateFuse.apply(u0, i0, img_user, txt_user, img_item, txt_item, ui, iu, int(n_layers), float(r))

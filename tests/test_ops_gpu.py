@@ -281,3 +281,37 @@ def test_infonce_fused_gather_and_batch_losses():
     assert float(l_idx) == float(l_dense)
     l_idx.backward()
     assert float(z1.grad[~torch.isin(torch.arange(U), users).to(DEV)].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("G", [1, 2, 3])
+def test_propagate_fuse_matches_oracle(G):
+    """The fused GCN node (2G SpMM + layer mean + modality fusion + regulariser sum; backward made
+    of epilogue-fused SpMMs only) vs the oracle's op-by-op autograd."""
+    ops, graph = _ops()
+    import torch.nn.functional as F
+    raw = _rand_graph(500, 330, 7, seed=40 + G, heavy=[(3, 200), (9, 40)], empty=[1])
+    raw.data[:] = 1.0
+    ui_m, iu_m = O.csr_norm(raw, True).tocsr(), O.csr_norm(raw.T, True).tocsr()
+    ui, iu = graph.GraphPlan(ui_m), graph.GraphPlan(iu_m)
+    A_ui, A_iu = O.to_torch_sparse(ui_m), O.to_torch_sparse(iu_m)
+    gen = torch.Generator().manual_seed(G)
+    U, I, d = 500, 330, 64
+    names = ["u0", "i0", "img_u", "txt_u", "img_i", "txt_i"]
+    base = [torch.randn(U, d, generator=gen), torch.randn(I, d, generator=gen), torch.randn(U, d, generator=gen),
+            torch.randn(U, d, generator=gen), torch.randn(I, d, generator=gen), torch.randn(I, d, generator=gen)]
+    base[2][5] = 0          # zero row through normalize
+    Cu, Ci = torch.randn(U, d, generator=gen), torch.randn(I, d, generator=gen)
+    R = [t.clone().requires_grad_(True) for t in base]
+    u_ref, i_ref = O.gcn_propagate(A_ui, A_iu, R[0], R[1], G)
+    u_ref = u_ref + 0.55 * F.normalize(R[2]) + 0.55 * F.normalize(R[3])
+    i_ref = i_ref + 0.55 * F.normalize(R[4]) + 0.55 * F.normalize(R[5])
+    ss_ref = sum((t ** 2).sum() for t in R[2:])
+    ((u_ref * Cu).sum() + (i_ref * Ci).sum() + 0.37 * ss_ref).backward()
+    Gt = [t.clone().to(DEV).requires_grad_(True) for t in base]
+    u_g, i_g, ss = ops.propagate_fuse(ui, iu, Gt[0], Gt[1], Gt[2], Gt[3], Gt[4], Gt[5], G, 0.55)
+    assert H.rel_err(u_g.detach().cpu(), u_ref.detach()) < 3e-6
+    assert H.rel_err(i_g.detach().cpu(), i_ref.detach()) < 3e-6
+    assert abs(float(ss) - float(ss_ref)) <= 2e-6 * float(ss_ref)
+    ((u_g * Cu.to(DEV)).sum() + (i_g * Ci.to(DEV)).sum() + 0.37 * ss).backward()
+    for n, a, b in zip(names, Gt, R):
+        assert H.rel_err(a.grad.cpu(), b.grad) < 2e-5, n

@@ -33,6 +33,11 @@ int env_int(const char* name, int dflt) {
 int short_max() { static int v = std::max(1, env_int("MMSSL_PLAN_SHORT_MAX", 32)); return v; }
 int task_nnz() { static int v = std::max(short_max(), env_int("MMSSL_PLAN_TASK_NNZ", 128)); return v; }
 int plan_sort() { static int v = env_int("MMSSL_PLAN_SORT", 1); return v; }
+// 1 (default) = rows cut into several wave items are combined by a small second kernel;
+// 0 = by the last-arriving wave inside the SpMM kernel (write-through partials + arrival ticket).
+// Measured on MI355X (Baby shape): two-stage 11.2 us per SpMM vs 12.1 us in-kernel (the serial
+// tail of the last arrivers costs more than the ~1.5 us launch boundary), fence-based 17.8 us.
+int two_stage() { static int v = env_int("MMSSL_SPMM_TWO_STAGE", 1); return v; }
 
 struct DirPlan {
   int32_t rows = 0, cols = 0;
@@ -42,6 +47,8 @@ struct DirPlan {
   int4* gitems = nullptr;     // group items  {row, beg, end, -1}
   int4* witems = nullptr;     // wave items   {row, beg, end, slot|-1}
   int4* multi = nullptr;      // multi rows   {row, first_slot, n_slots, 0}
+  int32_t* slot2multi = nullptr;  // [n_slots] -> index into `multi`
+  int32_t* arrivals = nullptr;    // [n_multi] arrival counters of the in-kernel combine (zero between launches)
   int64_t n_g = 0, n_w = 0, n_multi = 0, n_slots = 0;
 };
 
@@ -51,6 +58,8 @@ void free_dir(DirPlan& p) {
   if (p.gitems) (void)hipFree(p.gitems);
   if (p.witems) (void)hipFree(p.witems);
   if (p.multi) (void)hipFree(p.multi);
+  if (p.slot2multi) (void)hipFree(p.slot2multi);
+  if (p.arrivals) (void)hipFree(p.arrivals);
   p = DirPlan();
 }
 
@@ -81,6 +90,11 @@ int build_dir(DirPlan& p, const int32_t* rowptr, const int32_t* col, const float
   if ((rc = upload(&p.gitems, reinterpret_cast<const int4*>(g.data()), (size_t)p.n_g))) return rc;
   if ((rc = upload(&p.witems, reinterpret_cast<const int4*>(w.data()), (size_t)p.n_w))) return rc;
   if ((rc = upload(&p.multi, reinterpret_cast<const int4*>(m.data()), (size_t)p.n_multi))) return rc;
+  std::vector<int32_t> s2m((size_t)p.n_slots), zeros((size_t)p.n_multi, 0);
+  for (int64_t k = 0; k < p.n_multi; ++k)
+    for (int32_t j = 0; j < m[k * 4 + 2]; ++j) s2m[(size_t)m[k * 4 + 1] + j] = (int32_t)k;
+  if ((rc = upload(&p.slot2multi, s2m.data(), (size_t)p.n_slots))) return rc;
+  if ((rc = upload(&p.arrivals, zeros.data(), (size_t)p.n_multi))) return rc;
   return 0;
 }
 
@@ -343,7 +357,10 @@ __global__ __launch_bounds__(kBlock) void spmm_kernel(const int4* __restrict__ g
                                                       int n_wblocks, const Edge* __restrict__ edges,
                                                       const float4* __restrict__ X,
                                                       float4* __restrict__ Y,
-                                                      float4* __restrict__ partials, EpiArgs epi) {
+                                                      float4* __restrict__ partials, EpiArgs epi,
+                                                      const int4* __restrict__ multi,
+                                                      const int32_t* __restrict__ slot2multi,
+                                                      int32_t* __restrict__ arrivals) {
   constexpr int GPW = kWave / LPR;   // lane groups per wave
   constexpr int GPB = kBlock / LPR;  // lane groups per block
   const int lane = threadIdx.x & 63;
@@ -367,8 +384,57 @@ __global__ __launch_bounds__(kBlock) void spmm_kernel(const int4* __restrict__ g
     if (it.w < 0) {
       acc = apply_epilogue<LPR, EPI>(acc, it.x, lig, epi);
       if (lane < LPR) Y[(size_t)it.x * LPR + lig] = acc;
-    } else if (lane < LPR) {
-      partials[(size_t)it.w * LPR + lig] = acc;
+    } else {
+      if (arrivals == nullptr) {           // two-stage mode: spmm_multi_kernel combines
+        if (lane < LPR) partials[(size_t)it.w * LPR + lig] = acc;
+        return;
+      }
+      // ---- in-kernel combine by the LAST-arriving wave of this row (split-K arrival pattern) ----
+      // The 16*LPR-byte partial is stored WRITE-THROUGH (agent-scope relaxed atomic stores lower to
+      // `global_store ... sc1`), drained, then one lane takes a ticket: no release fence, so the
+      // other rows' dirty output lines stay in this XCD's L2. The last arriver re-reads every
+      // slot with sc1 loads (bypass the non-coherent L1) in a FIXED order, so the result does not
+      // depend on which wave happens to be last.
+      typedef unsigned long long u64;
+      u64* pw = reinterpret_cast<u64*>(partials);
+      if (lane < LPR) {
+        u64 lo, hi;
+        __builtin_memcpy(&lo, &acc.x, 8);
+        __builtin_memcpy(&hi, &acc.z, 8);
+        const size_t o = ((size_t)it.w * LPR + lig) * 2;
+        __hip_atomic_store(pw + o, lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(pw + o + 1, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const int m = slot2multi[it.w];
+      const int4 mr = multi[m];            // {row, first_slot, n_slots, 0}
+      int last = 0;
+      if (lane == 0) {
+        const int prev = __hip_atomic_fetch_add(arrivals + m, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        last = (prev == mr.z - 1);
+        if (last) __hip_atomic_store(arrivals + m, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-arm
+      }
+      last = __builtin_amdgcn_readfirstlane(last);
+      if (!last) return;
+      float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int k = lane / LPR; k < mr.z; k += GPW) {
+        const size_t o = ((size_t)(mr.y + k) * LPR + lig) * 2;
+        const u64 lo = __hip_atomic_load(pw + o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const u64 hi = __hip_atomic_load(pw + o + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        float2 a, b;
+        __builtin_memcpy(&a, &lo, 8);
+        __builtin_memcpy(&b, &hi, 8);
+        sum.x += a.x;
+        sum.y += a.y;
+        sum.z += b.x;
+        sum.w += b.y;
+      }
+      sum.x = cross_group_sum<LPR>(sum.x);
+      sum.y = cross_group_sum<LPR>(sum.y);
+      sum.z = cross_group_sum<LPR>(sum.z);
+      sum.w = cross_group_sum<LPR>(sum.w);
+      sum = apply_epilogue<LPR, EPI>(sum, mr.x, lig, epi);
+      if (lane < LPR) Y[(size_t)mr.x * LPR + lig] = sum;
     }
   }
 }
@@ -419,10 +485,11 @@ int launch_spmm(const DirPlan& p, const float* X, float* Y, float* partials, con
     hipLaunchKernelGGL((spmm_kernel<LPR, EPI>), dim3(n_wblocks + n_gblocks), dim3(kBlock), 0, s,
                        p.gitems, (int)p.n_g, p.witems, (int)p.n_w, n_wblocks, p.edges,
                        reinterpret_cast<const float4*>(X), reinterpret_cast<float4*>(Y),
-                       reinterpret_cast<float4*>(partials), epi);
+                       reinterpret_cast<float4*>(partials), epi, p.multi, p.slot2multi,
+                       two_stage() ? (int32_t*)nullptr : p.arrivals);
     MMSSL_LAUNCH_CHECK();
   }
-  if (p.n_multi > 0) {
+  if (p.n_multi > 0 && two_stage()) {
     hipLaunchKernelGGL((spmm_multi_kernel<LPR, EPI>), dim3((unsigned)p.n_multi), dim3(kBlock), 0, s, p.multi,
                        (int)p.n_multi, reinterpret_cast<const float4*>(partials),
                        reinterpret_cast<float4*>(Y), epi);

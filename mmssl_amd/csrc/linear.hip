@@ -14,6 +14,8 @@
 // slice. The reduction dimension is split over blockIdx.z so that >= ~4 blocks per CU exist
 // even for M = 18K; split partials are summed in a fixed order by a small epilogue kernel
 // that also applies bias + dropout (deterministic, no float atomics).
+#include <cstdlib>
+
 #include "common.hpp"
 
 using namespace mmssl;
@@ -213,6 +215,10 @@ __global__ __launch_bounds__(kBlock) void colsum_stage2(const float* __restrict_
 // split count: aim for >= ~4 blocks per CU, every split at least 4 slices deep
 inline int choose_splits(int64_t tiles, int64_t KK) {
   const int64_t slices = (KK + BK - 1) / BK;
+  if (const char* e = getenv("MMSSL_GEMM_SPLITS")) {      // tuning override (tools/gemm_sweep.py)
+    const int64_t f = atoi(e);
+    if (f >= 1) return (int)(f > slices ? slices : f);
+  }
   int64_t s = (1024 + tiles - 1) / tiles;
   const int64_t max_s = slices / 4 > 0 ? slices / 4 : 1;
   if (s > max_s) s = max_s;

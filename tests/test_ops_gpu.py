@@ -315,3 +315,33 @@ def test_propagate_fuse_matches_oracle(G):
     ((u_g * Cu.to(DEV)).sum() + (i_g * Ci.to(DEV)).sum() + 0.37 * ss).backward()
     for n, a, b in zip(names, Gt, R):
         assert H.rel_err(a.grad.cpu(), b.grad) < 2e-5, n
+
+
+@pytest.mark.parametrize("d", [64, 128])
+def test_spmm_inkernel_combine_stress(d):
+    """Rows cut into several wave items are combined by the last-arriving wave inside the kernel
+    (agent-scope release/acquire). Alternate inputs launch after launch, so a stale partial from the
+    previous launch (L1/L2 not refreshed) would show up as a wrong row; also check bit-reproducibility."""
+    ops, graph = _ops()
+    rng = np.random.default_rng(d)
+    heavy = [(int(r), int(k)) for r, k in zip(rng.choice(3000, 150, replace=False), rng.integers(140, 2500, 150))]
+    m = _rand_graph(3000, 2600, 5, seed=7, heavy=heavy)
+    plan = graph.GraphPlan(m)
+    assert plan.info()["multi_rows"] >= 140
+    A = O.to_torch_sparse(m)
+    gen = torch.Generator().manual_seed(0)
+    Xs = [torch.randn(2600, d, generator=gen) * (k + 1) for k in range(3)]
+    refs = [O.spmm(A, X) for X in Xs]
+    Xg = [X.to(DEV) for X in Xs]
+    first = {}
+    big = torch.empty(64 << 20, device=DEV)          # background traffic: evict / disturb caches
+    for it in range(24):
+        k = it % 3
+        if it % 5 == 0:
+            big.normal_()
+        Y = ops.spmm(plan, Xg[k])
+        Yc = Y.cpu()
+        assert H.rel_err(Yc, refs[k]) < 3e-6, (it, k)
+        if k in first:
+            assert torch.equal(Yc, first[k]), (it, k)
+        first[k] = Yc

@@ -267,6 +267,8 @@ def main():
 
     batches = [tuple(torch.from_numpy(x).to(dev) for x in b)
                for b in make_batches(raw, 8, a.batch, seed=2022)]
+    if not sharded:
+        batches = [(torch.stack(b),) for b in batches]          # packed [3, B]: one copy per step
 
     def run_steps(n):
         for i in range(n):

@@ -145,16 +145,25 @@ int mmssl_sumsq_f32(const float* X, int64_t n, float* out, void* workspace,
  *   keep: optional uint8 [M,N] keep-mask (1 = keep); kept entries are scaled by `scale`
  *   (= 1/(1-p)); keep == NULL means no dropout (eval mode). fp32 MFMA
  *   (v_mfma_f32_32x32x2_f32), exact fp32. N % 4 == 0, N <= 256, K % 4 == 0.
- *   mmssl_linear_wgrad: gW[N,K] = gY[M,N]^T . F[M,K], gb[N] = column sums of gY
- *   (autograd of the same call site; gY already carries the dropout mask).
+ *   mmssl_linear_wgrad: gW[N,K] = gYm[M,N]^T . F[M,K], gb[N] = column sums of gYm, where
+ *   gYm = gY * keep * scale is the dropout backward, applied while gY is fetched (keep == NULL:
+ *   gYm = gY). Autograd of the same call site.
  * ---------------------------------------------------------------------------------- */
 size_t mmssl_linear_workspace_bytes(int64_t M, int K, int N);   /* split-K partials */
 int mmssl_linear_f32(const float* F, const float* W, const float* b, const uint8_t* keep,
                      float scale, int64_t M, int K, int N, float* Y, void* workspace,
                      size_t workspace_bytes, void* stream);
 size_t mmssl_linear_wgrad_workspace_bytes(int64_t M, int K, int N);
-int mmssl_linear_wgrad_f32(const float* gY, const float* F, int64_t M, int K, int N, float* gW,
-                           float* gb, void* workspace, size_t workspace_bytes, void* stream);
+int mmssl_linear_wgrad_f32(const float* gY, const uint8_t* keep, float scale, const float* F,
+                           int64_t M, int K, int N, float* gW, float* gb, void* workspace,
+                           size_t workspace_bytes, void* stream);
+/* out = g * keep * scale over n (multiple of 4) elements: the dropout backward as one pass. */
+int mmssl_mask_scale_f32(const float* g, const uint8_t* keep, float scale, int64_t n, float* out,
+                         void* stream);
+/* total[0] = sum_k w[k] * terms[k] (k < n <= 16) + c * extra[0]: the scalar loss assembly of
+ * main.py:420 in one launch (terms / w / extra are device arrays; extra may be NULL). */
+int mmssl_loss_assemble_f32(const float* terms, const float* w, int n, const float* extra, float c,
+                            float* total, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * InfoNCE  — Trainer.batched_contrastive_loss + Trainer.sim (main.py:211-249)

@@ -165,24 +165,22 @@ class MMSSL(nn.Module):
         # the reference repeats this block args.layers times without feeding anything back
         # (Models.py:176-186): the result is that of one pass.
         assert args.layers >= 1
-        image_user_feats = ops.spmm(ui, x_img)
-        image_item_feats = ops.spmm(iu, image_user_feats)
-        text_user_feats = ops.spmm(ui, x_txt)
-        text_item_feats = ops.spmm(iu, text_user_feats)
         wcat = self.weight_dict["w_self_attention_cat"]
         # Modal id views. An EMPTY modal graph (the reference's state from the third batch on,
         # SURVEY 8a-3) makes A.E == 0, the fused view 0 and normalize(0) == 0, so u == E_u exactly:
         # that branch is skipped; w_self_attention_cat still receives its exactly-zero gradient.
-        if img_ui.nnz == 0 and txt_ui.nnz == 0:
+        users_empty = img_ui.nnz == 0 and txt_ui.nnz == 0
+        items_empty = img_iu.nnz == 0 and txt_iu.nnz == 0
+        if users_empty:
             image_user_id = text_user_id = self._zeros(self.n_users, E_u)
             u = ops.zero_grad_anchor(E_u, wcat)
         else:
             image_user_id = ops.spmm(img_ui, E_i)
             text_user_id = ops.spmm(txt_ui, E_i)
             u = ops.l2norm_rows(self._modality_fusion(image_user_id, text_user_id), E_u, args.id_cat_rate)
-        if img_iu.nnz == 0 and txt_iu.nnz == 0:
+        if items_empty:
             image_item_id = text_item_id = self._zeros(self.n_items, E_i)
-            i = ops.zero_grad_anchor(E_i, wcat)
+            i = E_i if users_empty else ops.zero_grad_anchor(E_i, wcat)    # one anchor is enough
         else:
             image_item_id = ops.spmm(img_iu, E_u)
             text_item_id = ops.spmm(txt_iu, E_u)
@@ -192,10 +190,10 @@ class MMSSL(nn.Module):
         self.embedding_dict["item"]["image"] = image_item_id
         self.embedding_dict["item"]["text"] = text_item_id
 
-        # G-layer propagation, layer mean and "+ rate * normalize(modal feats)" as one fused node;
-        # its by-product `ss` is the feature regulariser's sum of squares (main.py:252-257).
-        u_g, i_g, ss = ops.propagate_fuse(ui, iu, u, i, image_user_feats, text_user_feats, image_item_feats,
-                                          text_item_feats, self.n_ui_layers, args.model_cat_rate)
+        # modal SpMM chains, G-layer propagation, layer mean and "+ rate * normalize(modal feats)" as
+        # one fused node; its by-product `ss` is the feature regulariser's sum of squares (main.py:252-257)
+        (u_g, i_g, ss, image_item_feats, text_item_feats, image_user_feats, text_user_feats) = ops.propagate_fuse(
+            ui, iu, u, i, x_img, x_txt, self.n_ui_layers, args.model_cat_rate)
         self._feat_sumsq = (ss, (image_item_feats, text_item_feats, image_user_feats, text_user_feats))
         return (u_g, i_g, image_item_feats, text_item_feats, image_user_feats, text_user_feats, u_g, i_g,
                 image_user_id, text_user_id, image_item_id, text_item_id)

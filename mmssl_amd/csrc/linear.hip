@@ -30,9 +30,12 @@ constexpr int LD = 65;    // LDS row stride (floats)
 
 // DIRECT = false: operands are row-major [i][kk] (forward: F[M,K], W[N,K]) -> transposed into LDS
 // DIRECT = true : operands are row-major [kk][i] (wgrad: gY[M,N], F[M,K])  -> copied as is
+// `mk` (DIRECT only, may be NULL): uint8 keep-mask with the operand's layout; kept entries are scaled
+// by `ms`, dropped ones zeroed — the dropout backward applied to gY while it is fetched for wgrad.
 template <bool DIRECT>
 __device__ __forceinline__ void fetch_slice(const float* __restrict__ P, int64_t ld, int64_t i0, int64_t I,
-                                            int64_t kk0, int64_t kk_end, float4 (&r)[2]) {
+                                            int64_t kk0, int64_t kk_end, float4 (&r)[2],
+                                            const uint8_t* __restrict__ mk = nullptr, float ms = 1.f) {
   const int tid = threadIdx.x;
 #pragma unroll
   for (int p = 0; p < 2; ++p) {
@@ -44,7 +47,16 @@ __device__ __forceinline__ void fetch_slice(const float* __restrict__ P, int64_t
     } else {
       const int64_t kk = kk0 + (tid >> 4) + 16 * p;
       const int64_t i = i0 + 4 * (tid & 15);
-      if (kk < kk_end && i < I) r[p] = *reinterpret_cast<const float4*>(P + kk * ld + i);
+      if (kk < kk_end && i < I) {
+        r[p] = *reinterpret_cast<const float4*>(P + kk * ld + i);
+        if (mk) {
+          const uchar4 k = *reinterpret_cast<const uchar4*>(mk + kk * ld + i);
+          r[p].x = k.x ? r[p].x * ms : 0.f;
+          r[p].y = k.y ? r[p].y * ms : 0.f;
+          r[p].z = k.z ? r[p].z * ms : 0.f;
+          r[p].w = k.w ? r[p].w * ms : 0.f;
+        }
+      }
     }
   }
 }
@@ -77,7 +89,8 @@ __global__ __launch_bounds__(kBlock) void gemm64_kernel(const float* __restrict_
                                                         int64_t J, int64_t KK, int64_t kk_chunk,
                                                         float* __restrict__ C, int64_t ldc,
                                                         int64_t split_stride, const float* __restrict__ bias,
-                                                        const uint8_t* __restrict__ keep, float scale) {
+                                                        const uint8_t* __restrict__ keep, float scale,
+                                                        const uint8_t* __restrict__ maskA, float scaleA) {
   __shared__ float As[2][BK * LD];
   __shared__ float Bs[2][BK * LD];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -91,7 +104,7 @@ __global__ __launch_bounds__(kBlock) void gemm64_kernel(const float* __restrict_
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
   float4 ra[2], rb[2];
   if (nk > 0) {
-    fetch_slice<DIRECT>(A, lda, i0, I, kk_beg, kk_end, ra);
+    fetch_slice<DIRECT>(A, lda, i0, I, kk_beg, kk_end, ra, maskA, scaleA);
     fetch_slice<DIRECT>(B, ldb, j0, J, kk_beg, kk_end, rb);
     store_slice<DIRECT>(As[0], ra);
     store_slice<DIRECT>(Bs[0], rb);
@@ -101,7 +114,7 @@ __global__ __launch_bounds__(kBlock) void gemm64_kernel(const float* __restrict_
   for (int kt = 0; kt < nk; ++kt) {
     const int buf = kt & 1;
     if (kt + 1 < nk) {   // next slice: global -> registers while this slice computes
-      fetch_slice<DIRECT>(A, lda, i0, I, kk_beg + (int64_t)(kt + 1) * BK, kk_end, ra);
+      fetch_slice<DIRECT>(A, lda, i0, I, kk_beg + (int64_t)(kt + 1) * BK, kk_end, ra, maskA, scaleA);
       fetch_slice<DIRECT>(B, ldb, j0, J, kk_beg + (int64_t)(kt + 1) * BK, kk_end, rb);
     }
     const float* as = As[buf] + frag + wm * 32;
@@ -178,8 +191,14 @@ __global__ __launch_bounds__(kBlock) void splitk_reduce_kernel(const float* __re
 // rr, rr + R, ... of its block's range; the R row-groups are combined through LDS.
 //   stage 1 -> part[blocks][N];  stage 2 (one block, same scheme over the partials) -> out[N]
 constexpr int kColsumBlocks = 128;
+__device__ __forceinline__ float masked(const float* __restrict__ G, const uint8_t* __restrict__ mk, float ms,
+                                        int64_t o) {
+  const float v = G[o];
+  return mk ? (mk[o] ? v * ms : 0.f) : v;
+}
 __device__ __forceinline__ void colsum_body(const float* __restrict__ G, int64_t row0, int64_t row_step,
-                                            int64_t M, int N, float* __restrict__ dst) {
+                                            int64_t M, int N, float* __restrict__ dst,
+                                            const uint8_t* __restrict__ mk = nullptr, float ms = 1.f) {
   __shared__ float red[kBlock];
   const int R = kBlock / N;
   const int c = threadIdx.x % N, rr = threadIdx.x / N;
@@ -187,12 +206,12 @@ __device__ __forceinline__ void colsum_body(const float* __restrict__ G, int64_t
   if (rr < R) {
     int64_t m = row0 + rr;
     for (; m + 3 * row_step < M; m += 4 * row_step) {      // four independent loads in flight
-      a0 += G[m * N + c];
-      a1 += G[(m + row_step) * N + c];
-      a2 += G[(m + 2 * row_step) * N + c];
-      a3 += G[(m + 3 * row_step) * N + c];
+      a0 += masked(G, mk, ms, m * N + c);
+      a1 += masked(G, mk, ms, (m + row_step) * N + c);
+      a2 += masked(G, mk, ms, (m + 2 * row_step) * N + c);
+      a3 += masked(G, mk, ms, (m + 3 * row_step) * N + c);
     }
-    for (; m < M; m += row_step) a0 += G[m * N + c];
+    for (; m < M; m += row_step) a0 += masked(G, mk, ms, m * N + c);
   }
   red[threadIdx.x] = (a0 + a1) + (a2 + a3);
   __syncthreads();
@@ -203,9 +222,10 @@ __device__ __forceinline__ void colsum_body(const float* __restrict__ G, int64_t
   }
 }
 __global__ __launch_bounds__(kBlock) void colsum_stage1(const float* __restrict__ G, int64_t M, int N,
-                                                        float* __restrict__ part) {
+                                                        float* __restrict__ part,
+                                                        const uint8_t* __restrict__ mk, float ms) {
   const int R = kBlock / N;
-  colsum_body(G, (int64_t)blockIdx.x * R, (int64_t)gridDim.x * R, M, N, part + (int64_t)blockIdx.x * N);
+  colsum_body(G, (int64_t)blockIdx.x * R, (int64_t)gridDim.x * R, M, N, part + (int64_t)blockIdx.x * N, mk, ms);
 }
 __global__ __launch_bounds__(kBlock) void colsum_stage2(const float* __restrict__ part, int nparts, int N,
                                                         float* __restrict__ out) {
@@ -253,7 +273,7 @@ extern "C" int mmssl_linear_f32(const float* F, const float* W, const float* b, 
   if (splits == 1) {
     hipLaunchKernelGGL((gemm64_kernel<false>), dim3((unsigned)tm, (unsigned)tn, 1), dim3(kBlock), 0, s, F,
                        (int64_t)K, W, (int64_t)K, M, (int64_t)N, (int64_t)K, chunk, Y, (int64_t)N, (int64_t)0, b,
-                       keep, scale);
+                       keep, scale, (const uint8_t*)nullptr, 1.f);
     MMSSL_LAUNCH_CHECK();
     return 0;
   }
@@ -262,7 +282,7 @@ extern "C" int mmssl_linear_f32(const float* F, const float* W, const float* b, 
   float* P = reinterpret_cast<float*>(workspace);
   hipLaunchKernelGGL((gemm64_kernel<false>), dim3((unsigned)tm, (unsigned)tn, (unsigned)splits), dim3(kBlock), 0,
                      s, F, (int64_t)K, W, (int64_t)K, M, (int64_t)N, (int64_t)K, chunk, P, (int64_t)N,
-                     (int64_t)M * N, (const float*)nullptr, (const uint8_t*)nullptr, 1.f);
+                     (int64_t)M * N, (const float*)nullptr, (const uint8_t*)nullptr, 1.f, (const uint8_t*)nullptr, 1.f);
   MMSSL_LAUNCH_CHECK();
   const int64_t total = M * N;
   int64_t nb = (total / 4 + kBlock - 1) / kBlock;
@@ -281,8 +301,9 @@ extern "C" size_t mmssl_linear_wgrad_workspace_bytes(int64_t M, int K, int N) {
   return part + (size_t)kColsumBlocks * (size_t)N * sizeof(float) + 16;
 }
 
-extern "C" int mmssl_linear_wgrad_f32(const float* gY, const float* F, int64_t M, int K, int N, float* gW,
-                                      float* gb, void* workspace, size_t workspace_bytes, void* stream) {
+extern "C" int mmssl_linear_wgrad_f32(const float* gY, const uint8_t* keep, float scale, const float* F, int64_t M,
+                                      int K, int N, float* gW, float* gb, void* workspace,
+                                      size_t workspace_bytes, void* stream) {
   if (M <= 0 || K <= 0 || N <= 0 || !gY || !F || !gW) return MMSSL_E_BADARG;
   if ((K & 3) || (N & 3) || N > 256) return MMSSL_E_UNSUPP;
   if (!workspace || workspace_bytes < mmssl_linear_wgrad_workspace_bytes(M, K, N)) return MMSSL_E_WORKSPACE;
@@ -297,12 +318,12 @@ extern "C" int mmssl_linear_wgrad_f32(const float* gY, const float* F, int64_t M
   if (splits == 1) {
     hipLaunchKernelGGL((gemm64_kernel<true>), dim3((unsigned)tn, (unsigned)tk, 1), dim3(kBlock), 0, s, gY,
                        (int64_t)N, F, (int64_t)K, (int64_t)N, (int64_t)K, M, chunk, gW, (int64_t)K, (int64_t)0,
-                       (const float*)nullptr, (const uint8_t*)nullptr, 1.f);
+                       (const float*)nullptr, (const uint8_t*)nullptr, 1.f, keep, scale);
     MMSSL_LAUNCH_CHECK();
   } else {
     hipLaunchKernelGGL((gemm64_kernel<true>), dim3((unsigned)tn, (unsigned)tk, (unsigned)splits), dim3(kBlock),
                        0, s, gY, (int64_t)N, F, (int64_t)K, (int64_t)N, (int64_t)K, M, chunk, P, (int64_t)K,
-                       (int64_t)N * K, (const float*)nullptr, (const uint8_t*)nullptr, 1.f);
+                       (int64_t)N * K, (const float*)nullptr, (const uint8_t*)nullptr, 1.f, keep, scale);
     MMSSL_LAUNCH_CHECK();
     const int64_t total = (int64_t)N * K;
     int64_t nb = (total / 4 + kBlock - 1) / kBlock;
@@ -315,7 +336,7 @@ extern "C" int mmssl_linear_wgrad_f32(const float* gY, const float* F, int64_t M
     const int R = kBlock / N;
     int64_t nb = (M + R - 1) / R;
     nb = nb > kColsumBlocks ? kColsumBlocks : nb;
-    hipLaunchKernelGGL(colsum_stage1, dim3((unsigned)nb), dim3(kBlock), 0, s, gY, M, N, colpart);
+    hipLaunchKernelGGL(colsum_stage1, dim3((unsigned)nb), dim3(kBlock), 0, s, gY, M, N, colpart, keep, scale);
     MMSSL_LAUNCH_CHECK();
     hipLaunchKernelGGL(colsum_stage2, dim3(1), dim3(kBlock), 0, s, colpart, (int)nb, N, gb);
     MMSSL_LAUNCH_CHECK();

@@ -310,3 +310,50 @@ extern "C" int mmssl_sum_partials_f32(const float* part, int64_t n, float* out, 
   MMSSL_LAUNCH_CHECK();
   return 0;
 }
+
+namespace {
+__global__ void loss_assemble_kernel(const float* __restrict__ terms, const float* __restrict__ w, int n,
+                                     const float* __restrict__ extra, float c, float* __restrict__ total) {
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+    for (int k = 0; k < n; ++k) t += w[k] * terms[k];
+    if (extra) t += c * extra[0];
+    total[0] = t;
+  }
+}
+}  // namespace
+
+extern "C" int mmssl_loss_assemble_f32(const float* terms, const float* w, int n, const float* extra, float c,
+                                       float* total, void* stream) {
+  if (!terms || !w || !total || n < 0 || n > 16) return MMSSL_E_BADARG;
+  hipLaunchKernelGGL(loss_assemble_kernel, dim3(1), dim3(64), 0, as_stream(stream), terms, w, n, extra, c, total);
+  MMSSL_LAUNCH_CHECK();
+  return 0;
+}
+
+namespace {
+// out = g * keep * scale (dropout backward), 4 elements per thread
+__global__ __launch_bounds__(kBlock) void mask_scale_kernel(const float4* __restrict__ g,
+                                                            const uchar4* __restrict__ keep, float scale,
+                                                            int64_t n4, float4* __restrict__ out) {
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n4; i += (int64_t)gridDim.x * kBlock) {
+    const float4 v = g[i];
+    const uchar4 k = keep[i];
+    out[i] = make_float4(k.x ? v.x * scale : 0.f, k.y ? v.y * scale : 0.f, k.z ? v.z * scale : 0.f,
+                         k.w ? v.w * scale : 0.f);
+  }
+}
+}  // namespace
+
+extern "C" int mmssl_mask_scale_f32(const float* g, const uint8_t* keep, float scale, int64_t n, float* out,
+                                    void* stream) {
+  if (n < 0 || (n & 3) || (n > 0 && (!g || !keep || !out))) return MMSSL_E_BADARG;
+  if (n == 0) return 0;
+  int64_t nb = (n / 4 + kBlock - 1) / kBlock;
+  nb = nb > 4096 ? 4096 : nb;
+  hipLaunchKernelGGL(mask_scale_kernel, dim3((unsigned)nb), dim3(kBlock), 0, as_stream(stream),
+                     reinterpret_cast<const float4*>(g), reinterpret_cast<const uchar4*>(keep), scale, n / 4,
+                     reinterpret_cast<float4*>(out));
+  MMSSL_LAUNCH_CHECK();
+  return 0;
+}

@@ -20,9 +20,10 @@ class HotPathStep:
         self.batch_size = int(batch_size)
         self.decay = float(decay)
         dev = model.user_id_embedding.weight.device
-        self.users = torch.zeros(batch_size, dtype=torch.int64, device=dev)
-        self.pos = torch.zeros(batch_size, dtype=torch.int64, device=dev)
-        self.neg = torch.zeros(batch_size, dtype=torch.int64, device=dev)
+        self.batch = torch.zeros((3, batch_size), dtype=torch.int64, device=dev)     # users / pos / neg
+        self.users, self.pos, self.neg = self.batch[0], self.batch[1], self.batch[2]
+        # loss assembly weights for [mf, emb, reg, cl_img, cl_txt] (main.py:420 without the GAN term)
+        self.loss_w = torch.tensor([1.0, 1.0, 1.0, args.cl_rate, args.cl_rate], dtype=torch.float32, device=dev)
         # same update rule as the reference's optim.AdamW (main.py:76-80); `fused` = one kernel
         # for all parameters instead of ~16 foreach launches, `capturable` keeps the step counter
         # on the device so the step can live inside a hipGraph.
@@ -37,21 +38,24 @@ class HotPathStep:
         self.stream = torch.cuda.Stream(device=dev)
         self.stream.wait_stream(torch.cuda.current_stream(dev))
 
-    def set_batch(self, users, pos, neg):
+    def set_batch(self, users, pos=None, neg=None):
         """Device-to-device copies into the static index buffers (graph replays read these)."""
         with torch.cuda.stream(self.stream):
-            self.users.copy_(users, non_blocking=True)
-            self.pos.copy_(pos, non_blocking=True)
-            self.neg.copy_(neg, non_blocking=True)
+            if pos is None:                       # packed [3, B] batch: one device-to-device copy
+                self.batch.copy_(users, non_blocking=True)
+            else:
+                self.users.copy_(users, non_blocking=True)
+                self.pos.copy_(pos, non_blocking=True)
+                self.neg.copy_(neg, non_blocking=True)
 
     def losses(self):
         m = self.model
         (ua, ia, img_item, txt_item, img_user, txt_user, uemb, _, img_uid, txt_uid, _, _) = m(*self.graphs)
-        mf, emb, cl1, cl2 = ops.batch_losses(ua, ia, img_uid, txt_uid, self.users, self.pos, self.neg, self.decay,
-                                             self.batch_size, args.tau)
-        feat = (args.feat_reg_decay * 0.5 / m.n_items) * m.feat_sumsq(img_item, txt_item, img_user, txt_user)
-        total = mf + emb + feat + args.cl_rate * (cl1 + cl2)
-        return total, dict(mf=mf, emb=emb, feat=feat, cl1=cl1, cl2=cl2)
+        terms = ops.batch_losses_vec(ua, ia, img_uid, txt_uid, self.users, self.pos, self.neg, self.decay,
+                                     self.batch_size, args.tau)                 # [mf, emb, 0, cl_img, cl_txt]
+        ss = m.feat_sumsq(img_item, txt_item, img_user, txt_user)
+        total = ops.loss_assemble(terms, self.loss_w, ss, args.feat_reg_decay * 0.5 / m.n_items)
+        return total, dict(terms=terms, ss=ss)
 
     def step(self):
         """One eager step on this object's stream."""

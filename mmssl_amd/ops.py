@@ -188,16 +188,20 @@ class _Linear(torch.autograd.Function):
     def backward(ctx, gY):
         F_, W, keep = ctx.saved_tensors
         gY = _chk(gY, "gY")
-        if keep is not None:
-            gY = gY * keep * ctx.scale            # dropout backward (elementwise, [M, 64])
         M, K = F_.shape
         N = W.shape[0]
         gW = torch.empty_like(W)
         gb = torch.empty(N, dtype=torch.float32, device=W.device)
         nb = _lib.lib().mmssl_linear_wgrad_workspace_bytes(M, K, N)
         ws = torch.empty(max(nb // 4, 4), dtype=torch.float32, device=W.device)
-        rc = _lib.lib().mmssl_linear_wgrad_f32(_ptr(gY), _ptr(F_), M, K, N, _ptr(gW), _ptr(gb), _ptr(ws), nb,
-                                               _lib.stream_ptr())
+        if keep is not None:        # dropout backward: one pass (the in-fetch variant of wgrad measured slower)
+            gYm = torch.empty_like(gY)
+            rc = _lib.lib().mmssl_mask_scale_f32(_ptr(gY), _ptr(keep), ctx.scale, gY.numel(), _ptr(gYm),
+                                                 _lib.stream_ptr())
+            _lib.check(rc, "mmssl_mask_scale_f32")
+            gY = gYm
+        rc = _lib.lib().mmssl_linear_wgrad_f32(_ptr(gY), None, 1.0, _ptr(F_), M, K, N, _ptr(gW), _ptr(gb), _ptr(ws),
+                                               nb, _lib.stream_ptr())
         _lib.check(rc, "mmssl_linear_wgrad_f32")
         gF = None
         if ctx.needs_input_grad[0]:
@@ -205,7 +209,7 @@ class _Linear(torch.autograd.Function):
             # The raw feature matrices are constants in the reference (Models.py:46-47).
             if K > 256:
                 raise _lib.MmsslError("linear: input gradient only supported for K <= 256")
-            gF = _linear_raw(gY, W.t().contiguous(), None, None, 1.0)
+            gF = _linear_raw(gY, W.t().contiguous(), None, None, 1.0)      # gY already masked above
         return gF, gW, (gb if ctx.has_bias else None), None, None
 
 
@@ -217,14 +221,15 @@ def linear(F_, W, b=None, keep=None, scale=1.0):
 # ---------------------------------------------------------------------------------------
 # InfoNCE                       Trainer.sim + batched_contrastive_loss, main.py:211-249
 # ---------------------------------------------------------------------------------------
-def _infonce_fwd_raw(z1, z2, idx, tau):
+def _infonce_fwd_raw(z1, z2, idx, tau, loss=None):
     n = z1.shape[0] if idx is None else idx.shape[0]
     d = z1.shape[1]
     nb = _lib.lib().mmssl_infonce_workspace_bytes(n, d)
     if nb == 0:
         raise _lib.MmsslError("infonce: unsupported shape n=%d d=%d" % (n, d))
     ws = torch.empty(nb // 4, dtype=torch.float32, device=z1.device)
-    loss = torch.empty((), dtype=torch.float32, device=z1.device)
+    if loss is None:
+        loss = torch.empty((), dtype=torch.float32, device=z1.device)
     rc = _lib.lib().mmssl_infonce_fwd_f32(_ptr(z1), _ptr(z2), _ptr(idx), n, d, float(tau), _ptr(loss), _ptr(ws), nb,
                                           _lib.stream_ptr())
     _lib.check(rc, "mmssl_infonce_fwd_f32")
@@ -354,10 +359,8 @@ class _BatchLosses(torch.autograd.Function):
         rc = _lib.lib().mmssl_bpr_fwd_f32(_ptr(ua), _ptr(ia), None, _ptr(users), _ptr(pos), _ptr(neg), B, d,
                                           float(decay), int(batch_size), _ptr(out), _ptr(wsb), nb, _lib.stream_ptr())
         _lib.check(rc, "mmssl_bpr_fwd_f32")
-        l1, ws1, n, _ = _infonce_fwd_raw(img_uid, ua, users, tau)
-        l2, ws2, n, _ = _infonce_fwd_raw(txt_uid, ua, users, tau)
-        out[3:4].copy_(l1.view(1))
-        out[4:5].copy_(l2.view(1))
+        _, ws1, n, _ = _infonce_fwd_raw(img_uid, ua, users, tau, loss=out[3:4])     # written in place
+        _, ws2, n, _ = _infonce_fwd_raw(txt_uid, ua, users, tau, loss=out[4:5])
         ctx.save_for_backward(ua, ia, users, pos, neg, ws1, ws2)
         ctx.cfg = (B, d, float(decay), int(batch_size), float(tau), img_uid.shape, txt_uid.shape)
         return out
@@ -380,12 +383,42 @@ class _BatchLosses(torch.autograd.Function):
         return g_ua, g_ia, g_img, g_txt, None, None, None, None, None, None
 
 
+def batch_losses_vec(ua, ia, img_uid, txt_uid, users, pos, neg, decay, batch_size, tau):
+    """[mf_loss, emb_loss, 0, cl_img, cl_txt] as ONE tensor (see _BatchLosses / loss_assemble)."""
+    dev = ua.device
+    return _BatchLosses.apply(ua, ia, img_uid, txt_uid, _idx(users, "users", dev), _idx(pos, "pos", dev),
+                              _idx(neg, "neg", dev), decay, batch_size, tau)
+
+
 def batch_losses(ua, ia, img_uid, txt_uid, users, pos, neg, decay, batch_size, tau):
     """Returns (mf_loss, emb_loss, cl_img, cl_txt) — see _BatchLosses."""
-    dev = ua.device
-    out = _BatchLosses.apply(ua, ia, img_uid, txt_uid, _idx(users, "users", dev), _idx(pos, "pos", dev),
-                             _idx(neg, "neg", dev), decay, batch_size, tau)
+    out = batch_losses_vec(ua, ia, img_uid, txt_uid, users, pos, neg, decay, batch_size, tau)
     return out[0], out[1], out[3], out[4]
+
+
+class _LossAssemble(torch.autograd.Function):
+    """total = sum_k w[k] * terms[k] + c * extra   (main.py:420) in one launch; the backward is two
+    tiny scalings instead of the ~20 scalar autograd kernels of the op-by-op expression."""
+
+    @staticmethod
+    def forward(ctx, terms, w, extra, c):
+        total = torch.empty((), dtype=torch.float32, device=terms.device)
+        rc = _lib.lib().mmssl_loss_assemble_f32(_ptr(terms), _ptr(w), terms.numel(), _ptr(extra), float(c),
+                                                _ptr(total), _lib.stream_ptr())
+        _lib.check(rc, "mmssl_loss_assemble_f32")
+        ctx.save_for_backward(w)
+        ctx.c = float(c)
+        ctx.has_extra = extra is not None
+        return total
+
+    @staticmethod
+    def backward(ctx, g):
+        (w,) = ctx.saved_tensors
+        return g * w, None, (g * ctx.c if ctx.has_extra else None), None
+
+
+def loss_assemble(terms, w, extra=None, c=0.0):
+    return _LossAssemble.apply(_chk(terms, "terms"), _chk(w, "w"), extra, c)
 
 
 class _ZeroGradAnchor(torch.autograd.Function):
@@ -433,18 +466,22 @@ def _combine_bwd(A, B, G, r, inv, c_dev, c_scale, want_gL):
 
 
 class _PropagateFuse(torch.autograd.Function):
-    """u_l = A_ui.i_{l-1}, i_l = A_iu.u_l (row softmax on the last layer), then
+    """Everything after the projection, as one autograd node (Models.py:177-178,182-183,199-218):
+         img_user = A_ui.x_img, img_item = A_iu.img_user          (and the text pair)
+         u_l = A_ui.i_{l-1}, i_l = A_iu.u_l (row softmax on the last layer)
          u_g = mean_l(u_l) + r*normalize(img_user) + r*normalize(txt_user)        (items alike)
-    plus ss = |img_user|^2+|txt_user|^2+|img_item|^2+|txt_item|^2 (the feature regulariser's sum,
-    a by-product of the same pass). Forward: 2G SpMM + 2 combine + 1 tiny reduce. Backward: 2 combine
-    + 1 softmax-bwd + 2G SpMM whose epilogues add the layer-mean gradient and apply the softmax
-    backward, so no separate accumulation / scaling kernels run."""
+         ss  = |img_user|^2+|txt_user|^2+|img_item|^2+|txt_item|^2 (feature-regulariser sum)
+    Forward: 4 + 2G SpMM + 2 combine + 1 tiny reduce. Backward: 2 combine + 1 softmax-bwd + 4 + 2G SpMM
+    whose epilogues add the other gradient branch / the layer-mean gradient and apply the softmax
+    backward, so no separate accumulation or scaling kernels run."""
 
     @staticmethod
-    def forward(ctx, u0, i0, img_user, txt_user, img_item, txt_item, ui, iu, n_layers, r):
-        u0, i0 = _chk(u0, "u0"), _chk(i0, "i0")
-        img_user, txt_user = _chk(img_user, "img_user"), _chk(txt_user, "txt_user")
-        img_item, txt_item = _chk(img_item, "img_item"), _chk(txt_item, "txt_item")
+    def forward(ctx, u0, i0, x_img, x_txt, ui, iu, n_layers, r):
+        u0, i0, x_img, x_txt = _chk(u0, "u0"), _chk(i0, "i0"), _chk(x_img, "x_img"), _chk(x_txt, "x_txt")
+        img_user = _spmm_raw(ui, False, x_img, EPI_NONE)
+        img_item = _spmm_raw(iu, False, img_user, EPI_NONE)
+        txt_user = _spmm_raw(ui, False, x_txt, EPI_NONE)
+        txt_item = _spmm_raw(iu, False, txt_user, EPI_NONE)
         us, its = [u0], [i0]
         u, i = u0, i0
         for l in range(n_layers):
@@ -465,10 +502,10 @@ class _PropagateFuse(torch.autograd.Function):
         _lib.check(rc, "mmssl_sum_partials_f32")
         ctx.save_for_backward(img_user, txt_user, img_item, txt_item, us[-1], its[-1])
         ctx.cfg = (ui, iu, n_layers, float(r), inv)
-        return u_g, i_g, ss
+        return u_g, i_g, ss, img_item, txt_item, img_user, txt_user
 
     @staticmethod
-    def backward(ctx, Gu, Gi, g_ss):
+    def backward(ctx, Gu, Gi, g_ss, G_img_item, G_txt_item, G_img_user, G_txt_user):
         img_user, txt_user, img_item, txt_item, uG, iG = ctx.saved_tensors
         ui, iu, n_layers, r, inv = ctx.cfg
         Gu, Gi = _chk(Gu, "Gu"), _chk(Gi, "Gi")
@@ -476,16 +513,30 @@ class _PropagateFuse(torch.autograd.Function):
         # d(ss)/dx = 2x; normalize-backward and the regulariser term share one pass over A, B
         g_iu_, g_tu_, g_u0 = _combine_bwd(img_user, txt_user, Gu, r, inv, g_ss, 2.0, True)
         g_ii_, g_ti_, _ = _combine_bwd(img_item, txt_item, Gi, r, inv, g_ss, 2.0, False)
-        # last layer: i_G only feeds the mean; u_G feeds the mean and A_iu.u_G
+        # gradients that arrive on the modal outputs themselves (only if a caller used them elsewhere)
+        if G_img_item is not None:
+            g_ii_ = g_ii_ + G_img_item
+        if G_txt_item is not None:
+            g_ti_ = g_ti_ + G_txt_item
+        if G_img_user is not None:
+            g_iu_ = g_iu_ + G_img_user
+        if G_txt_user is not None:
+            g_tu_ = g_tu_ + G_txt_user
+        # modal chains: g(img_user) = A_iu^T g(img_item) + own branch (AXPY epilogue); g(x) = A_ui^T g(img_user)
+        g_x_img = _spmm_raw(ui, True, _spmm_raw(iu, True, g_ii_, EPI_AXPY, g_iu_, 1.0), EPI_NONE)
+        g_x_txt = _spmm_raw(ui, True, _spmm_raw(iu, True, g_ti_, EPI_AXPY, g_tu_, 1.0), EPI_NONE)
+        # GCN chain. last layer: i_G only feeds the mean; u_G feeds the mean and A_iu.u_G
         gi = softmax_rows_bwd(iG, Gi, inv)
         gu = _spmm_raw(iu, True, gi, EPI_AXPY_SOFTMAX_BWD, Gu, inv, uG)
         gi = _spmm_raw(ui, True, gu, EPI_AXPY, Gi, inv)            # total gradient of i_{G-1}
         for _ in range(n_layers - 1):
             gu = _spmm_raw(iu, True, gi, EPI_AXPY, Gu, inv)
             gi = _spmm_raw(ui, True, gu, EPI_AXPY, Gi, inv)
-        return g_u0, gi, g_iu_, g_tu_, g_ii_, g_ti_, None, None, None, None
+        return g_u0, gi, g_x_img, g_x_txt, None, None, None, None
 
 
-def propagate_fuse(ui, iu, u0, i0, img_user, txt_user, img_item, txt_item, n_layers, r):
-    """(u_g, i_g, ss): see _PropagateFuse. `ui`, `iu` are GraphPlans."""
-    return _PropagateFuse.apply(u0, i0, img_user, txt_user, img_item, txt_item, ui, iu, int(n_layers), float(r))
+def propagate_fuse(ui, iu, u0, i0, x_img, x_txt, n_layers, r):
+    """(u_g, i_g, ss, img_item, txt_item, img_user, txt_user): see _PropagateFuse. `ui`, `iu` are
+    GraphPlans; x_img / x_txt are the projected (and dropped-out) modality features [n_items, d]."""
+    out = _PropagateFuse.apply(u0, i0, x_img, x_txt, ui, iu, int(n_layers), float(r))
+    return out

@@ -285,8 +285,8 @@ def test_infonce_fused_gather_and_batch_losses():
 
 @pytest.mark.parametrize("G", [1, 2, 3])
 def test_propagate_fuse_matches_oracle(G):
-    """The fused GCN node (2G SpMM + layer mean + modality fusion + regulariser sum; backward made
-    of epilogue-fused SpMMs only) vs the oracle's op-by-op autograd."""
+    """The fused post-projection node (modal SpMM chains + 2G GCN SpMM + layer mean + modality fusion
+    + regulariser sum; backward made of epilogue-fused SpMMs only) vs the oracle's op-by-op autograd."""
     ops, graph = _ops()
     import torch.nn.functional as F
     raw = _rand_graph(500, 330, 7, seed=40 + G, heavy=[(3, 200), (9, 40)], empty=[1])
@@ -296,23 +296,27 @@ def test_propagate_fuse_matches_oracle(G):
     A_ui, A_iu = O.to_torch_sparse(ui_m), O.to_torch_sparse(iu_m)
     gen = torch.Generator().manual_seed(G)
     U, I, d = 500, 330, 64
-    names = ["u0", "i0", "img_u", "txt_u", "img_i", "txt_i"]
-    base = [torch.randn(U, d, generator=gen), torch.randn(I, d, generator=gen), torch.randn(U, d, generator=gen),
-            torch.randn(U, d, generator=gen), torch.randn(I, d, generator=gen), torch.randn(I, d, generator=gen)]
-    base[2][5] = 0          # zero row through normalize
+    names = ["u0", "i0", "x_img", "x_txt"]
+    base = [torch.randn(U, d, generator=gen), torch.randn(I, d, generator=gen), torch.randn(I, d, generator=gen),
+            torch.randn(I, d, generator=gen)]
     Cu, Ci = torch.randn(U, d, generator=gen), torch.randn(I, d, generator=gen)
+    Cx = torch.randn(U, d, generator=gen)
     R = [t.clone().requires_grad_(True) for t in base]
+    img_u = O.spmm(A_ui, R[2]); img_i = O.spmm(A_iu, img_u)
+    txt_u = O.spmm(A_ui, R[3]); txt_i = O.spmm(A_iu, txt_u)
     u_ref, i_ref = O.gcn_propagate(A_ui, A_iu, R[0], R[1], G)
-    u_ref = u_ref + 0.55 * F.normalize(R[2]) + 0.55 * F.normalize(R[3])
-    i_ref = i_ref + 0.55 * F.normalize(R[4]) + 0.55 * F.normalize(R[5])
-    ss_ref = sum((t ** 2).sum() for t in R[2:])
-    ((u_ref * Cu).sum() + (i_ref * Ci).sum() + 0.37 * ss_ref).backward()
+    u_ref = u_ref + 0.55 * F.normalize(img_u) + 0.55 * F.normalize(txt_u)
+    i_ref = i_ref + 0.55 * F.normalize(img_i) + 0.55 * F.normalize(txt_i)
+    ss_ref = (img_u ** 2).sum() + (txt_u ** 2).sum() + (img_i ** 2).sum() + (txt_i ** 2).sum()
+    # the modal outputs are also consumed directly (exercise the extra-gradient branch)
+    ((u_ref * Cu).sum() + (i_ref * Ci).sum() + 0.37 * ss_ref + (txt_u * Cx).sum()).backward()
     Gt = [t.clone().to(DEV).requires_grad_(True) for t in base]
-    u_g, i_g, ss = ops.propagate_fuse(ui, iu, Gt[0], Gt[1], Gt[2], Gt[3], Gt[4], Gt[5], G, 0.55)
+    u_g, i_g, ss, o_ii, o_ti, o_iu, o_tu = ops.propagate_fuse(ui, iu, Gt[0], Gt[1], Gt[2], Gt[3], G, 0.55)
     assert H.rel_err(u_g.detach().cpu(), u_ref.detach()) < 3e-6
     assert H.rel_err(i_g.detach().cpu(), i_ref.detach()) < 3e-6
+    assert H.rel_err(o_ii.detach().cpu(), img_i.detach()) < 3e-6 and H.rel_err(o_tu.detach().cpu(), txt_u.detach()) < 3e-6
     assert abs(float(ss) - float(ss_ref)) <= 2e-6 * float(ss_ref)
-    ((u_g * Cu.to(DEV)).sum() + (i_g * Ci.to(DEV)).sum() + 0.37 * ss).backward()
+    ((u_g * Cu.to(DEV)).sum() + (i_g * Ci.to(DEV)).sum() + 0.37 * ss + (o_tu * Cx.to(DEV)).sum()).backward()
     for n, a, b in zip(names, Gt, R):
         assert H.rel_err(a.grad.cpu(), b.grad) < 2e-5, n
 

@@ -8,5 +8,5 @@ gY = torch.randn(M, d, device="cuda"); gW = torch.empty_like(W); gb = torch.empt
 nb = _lib.lib().mmssl_linear_wgrad_workspace_bytes(M, K, d); ws = torch.empty(nb // 4, device="cuda")
 for _ in range(5):
     ops.linear(F_, W, b)
-    _lib.lib().mmssl_linear_wgrad_f32(gY.data_ptr(), F_.data_ptr(), M, K, d, gW.data_ptr(), gb.data_ptr(), ws.data_ptr(), nb, _lib.stream_ptr())
+    _lib.lib().mmssl_linear_wgrad_f32(gY.data_ptr(), None, 1.0, F_.data_ptr(), M, K, d, gW.data_ptr(), gb.data_ptr(), ws.data_ptr(), nb, _lib.stream_ptr())
 torch.cuda.synchronize()

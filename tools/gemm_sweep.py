@@ -12,7 +12,7 @@ for K in (4096, 1024):
     gY = torch.randn(M, d, device="cuda"); gW = torch.empty_like(W); gb = torch.empty(d, device="cuda")
     nb = _lib.lib().mmssl_linear_wgrad_workspace_bytes(M, K, d); ws = torch.empty(nb // 4, device="cuda")
     def fwd(): ops.linear(F_, W, b, keep, 1.25)
-    def wg(): _lib.lib().mmssl_linear_wgrad_f32(gY.data_ptr(), F_.data_ptr(), M, K, d, gW.data_ptr(), gb.data_ptr(), ws.data_ptr(), nb, _lib.stream_ptr())
+    def wg(): _lib.lib().mmssl_linear_wgrad_f32(gY.data_ptr(), None, 1.0, F_.data_ptr(), M, K, d, gW.data_ptr(), gb.data_ptr(), ws.data_ptr(), nb, _lib.stream_ptr())
     res = []
     for fn in (fwd, wg):
         for _ in range(5): fn()

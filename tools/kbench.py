@@ -110,7 +110,7 @@ def main():
                 ws = torch.empty(nb // 4, device=dev)
 
                 def wg():
-                    _lib.lib().mmssl_linear_wgrad_f32(gY.data_ptr(), F_.data_ptr(), I, K, d, gW.data_ptr(), gb.data_ptr(),
+                    _lib.lib().mmssl_linear_wgrad_f32(gY.data_ptr(), None, 1.0, F_.data_ptr(), I, K, d, gW.data_ptr(), gb.data_ptr(),
                                                       ws.data_ptr(), nb, _lib.stream_ptr())
                 report("linear %s wgrad K=%d" % (nm, K), timeit(wg, iters=50), by, fl)
                 del F_

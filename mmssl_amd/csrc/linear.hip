@@ -146,6 +146,131 @@ __global__ __launch_bounds__(kBlock) void gemm64_kernel(const float* __restrict_
   }
 }
 
+// ======================================================================================
+// v2 kernel: each wave owns a 64x64 output patch (2x2 MFMA tiles, four INDEPENDENT 32x32 accumulators),
+// so one A and one B fragment feed two MFMAs each (MFMA : ds_read = 1 : 1 instead of 1 : 2) and a
+// 32-deep slice carries 64 MFMAs (4096 pipe cycles) per wave between barriers instead of 16.
+// The 4 waves of a block are stacked along the LONG output dimension: 256x64 (forward: rows of F)
+// or 64x256 (wgrad: columns of gW). One LDS image per operand (~41 KB per block -> 3 blocks per CU),
+// next slice prefetched global->registers during the MFMA phase, two barriers per slice.
+// ======================================================================================
+template <bool DIRECT, int BT>
+__device__ __forceinline__ void fetch_tile(const float* __restrict__ P, int64_t ld, int64_t i0, int64_t I,
+                                           int64_t kk0, int64_t kk_end, float4 (&r)[BT / 32]) {
+  constexpr int NF = BT / 32;        // float4 per thread: BT * BK / (256 * 4)
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int p = 0; p < NF; ++p) {
+    r[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (!DIRECT) {
+      const int64_t i = i0 + (tid >> 3) + 32 * p;
+      const int64_t kk = kk0 + 4 * (tid & 7);
+      if (i < I && kk < kk_end) r[p] = *reinterpret_cast<const float4*>(P + i * ld + kk);
+    } else {
+      constexpr int LPRW = BT / 4;            // lanes per slice row
+      const int64_t kk = kk0 + tid / LPRW + (kBlock / LPRW) * p;
+      const int64_t i = i0 + 4 * (tid % LPRW);
+      if (kk < kk_end && i < I) r[p] = *reinterpret_cast<const float4*>(P + kk * ld + i);
+    }
+  }
+}
+
+template <bool DIRECT, int BT>
+__device__ __forceinline__ void store_tile(float* __restrict__ S, const float4 (&r)[BT / 32]) {
+  constexpr int NF = BT / 32;
+  constexpr int LD = BT + (DIRECT ? 4 : 1);
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int p = 0; p < NF; ++p) {
+    if (!DIRECT) {
+      const int i = (tid >> 3) + 32 * p, k = 4 * (tid & 7);
+      S[(k + 0) * LD + i] = r[p].x;
+      S[(k + 1) * LD + i] = r[p].y;
+      S[(k + 2) * LD + i] = r[p].z;
+      S[(k + 3) * LD + i] = r[p].w;
+    } else {
+      constexpr int LPRW = BT / 4;
+      const int k = tid / LPRW + (kBlock / LPRW) * p, i = 4 * (tid % LPRW);
+      *reinterpret_cast<float4*>(S + k * LD + i) = r[p];
+    }
+  }
+}
+
+template <bool DIRECT, int WM, int WN>
+__global__ __launch_bounds__(kBlock) void gemm_w64_kernel(const float* __restrict__ A, int64_t lda,
+                                                          const float* __restrict__ B, int64_t ldb, int64_t I,
+                                                          int64_t J, int64_t KK, int64_t kk_chunk,
+                                                          float* __restrict__ C, int64_t ldc, int64_t split_stride,
+                                                          const float* __restrict__ bias,
+                                                          const uint8_t* __restrict__ keep, float scale) {
+  static_assert(WM * WN == 4, "four waves per block");
+  constexpr int BTI = WM * 64, BTJ = WN * 64;
+  constexpr int LDI = BTI + (DIRECT ? 4 : 1), LDJ = BTJ + (DIRECT ? 4 : 1);
+  __shared__ __attribute__((aligned(16))) float As[BK * LDI];
+  __shared__ __attribute__((aligned(16))) float Bs[BK * LDJ];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int64_t i0 = (int64_t)blockIdx.x * BTI, j0 = (int64_t)blockIdx.y * BTJ;
+  const int64_t kk_beg = (int64_t)blockIdx.z * kk_chunk;
+  const int64_t kk_end = min(KK, kk_beg + kk_chunk);
+  const int nk = (int)((kk_end - kk_beg + BK - 1) / BK);
+  floatx16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+  float4 ra[BTI / 32], rb[BTJ / 32];
+  if (nk > 0) {
+    fetch_tile<DIRECT, BTI>(A, lda, i0, I, kk_beg, kk_end, ra);
+    fetch_tile<DIRECT, BTJ>(B, ldb, j0, J, kk_beg, kk_end, rb);
+    store_tile<DIRECT, BTI>(As, ra);
+    store_tile<DIRECT, BTJ>(Bs, rb);
+  }
+  __syncthreads();
+  const float* as = As + (lane >> 5) * LDI + wm * 64 + (lane & 31);
+  const float* bs = Bs + (lane >> 5) * LDJ + wn * 64 + (lane & 31);
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) {   // next slice: global -> registers while this slice is multiplied
+      fetch_tile<DIRECT, BTI>(A, lda, i0, I, kk_beg + (int64_t)(kt + 1) * BK, kk_end, ra);
+      fetch_tile<DIRECT, BTJ>(B, ldb, j0, J, kk_beg + (int64_t)(kt + 1) * BK, kk_end, rb);
+    }
+#pragma unroll
+    for (int s = 0; s < BK / 2; ++s) {
+      const float a0 = as[2 * s * LDI], a1 = as[2 * s * LDI + 32];
+      const float b0 = bs[2 * s * LDJ], b1 = bs[2 * s * LDJ + 32];
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+    }
+    __syncthreads();                       // every wave is done reading this slice
+    if (kt + 1 < nk) {
+      store_tile<DIRECT, BTI>(As, ra);
+      store_tile<DIRECT, BTJ>(Bs, rb);
+    }
+    __syncthreads();
+  }
+  float* Cp = C + (int64_t)blockIdx.z * split_stride;
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const int64_t col = j0 + wn * 64 + b * 32 + (lane & 31);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t row = i0 + wm * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (row < I && col < J) {
+          float v = acc[a][b][r];
+          if (bias) v += bias[col];
+          if (keep) v = keep[row * J + col] ? v * scale : 0.f;
+          Cp[row * ldc + col] = v;
+        }
+      }
+    }
+}
+
 // out[e] = epilogue(sum_s P[s][e]);  e = row*J + col.  Split loads are issued four at a time
 // (independent) so the loop is bandwidth- not latency-bound; the add order is fixed.
 __global__ __launch_bounds__(kBlock) void splitk_reduce_kernel(const float* __restrict__ P, int splits,
@@ -232,6 +357,29 @@ __global__ __launch_bounds__(kBlock) void colsum_stage2(const float* __restrict_
   colsum_body(part, 0, kBlock / N, nparts, N, out);
 }
 
+// 1 (default): 64x64 block tile, 32x32 per wave.  2: 64x64 per wave (gemm_w64_kernel).
+// Measured on MI355X (Baby image projection, K=4096): v1 132 / 127 us (fwd / wgrad), v2 139 / 126 us:
+// both sit at ~75 TF because the limiter is the bulk-synchronous load -> wait -> MFMA cadence
+// (tools/overlap_probe.py), not the LDS:MFMA ratio.
+inline int gemm_version() {
+  static int v = getenv("MMSSL_GEMM_V") ? atoi(getenv("MMSSL_GEMM_V")) : 1;
+  return v;
+}
+// v2: ~3 blocks of 41 KB LDS per CU
+inline int choose_splits_v2(int64_t tiles, int64_t KK) {
+  const int64_t slices = (KK + BK - 1) / BK;
+  if (const char* e = getenv("MMSSL_GEMM_SPLITS")) {
+    const int64_t f = atoi(e);
+    if (f >= 1) return (int)(f > slices ? slices : f);
+  }
+  static const int target = getenv("MMSSL_GEMM_TARGET_BLOCKS") ? atoi(getenv("MMSSL_GEMM_TARGET_BLOCKS")) : 768;
+  int64_t s = (target + tiles - 1) / tiles;
+  const int64_t max_s = slices / 4 > 0 ? slices / 4 : 1;
+  if (s > max_s) s = max_s;
+  if (s < 1) s = 1;
+  return (int)s;
+}
+
 // split count: aim for >= ~4 blocks per CU, every split at least 4 slices deep
 inline int choose_splits(int64_t tiles, int64_t KK) {
   const int64_t slices = (KK + BK - 1) / BK;
@@ -254,8 +402,9 @@ inline int64_t chunk_for(int64_t KK, int splits) {
 
 extern "C" size_t mmssl_linear_workspace_bytes(int64_t M, int K, int N) {
   if (M <= 0 || K <= 0 || N <= 0) return 16;
-  const int64_t tiles = ((M + BT - 1) / BT) * ((N + BT - 1) / BT);
-  const int splits = choose_splits(tiles, K);
+  const bool v2 = gemm_version() == 2;
+  const int64_t tiles = v2 ? ((M + 255) / 256) * ((N + 63) / 64) : ((M + BT - 1) / BT) * ((N + BT - 1) / BT);
+  const int splits = v2 ? choose_splits_v2(tiles, K) : choose_splits(tiles, K);
   return splits > 1 ? (size_t)splits * (size_t)M * (size_t)N * sizeof(float) : 16;
 }
 
@@ -267,6 +416,32 @@ extern "C" int mmssl_linear_f32(const float* F, const float* W, const float* b, 
   if (M == 0) return 0;
   if (((uintptr_t)F | (uintptr_t)W | (uintptr_t)Y) & 15) return MMSSL_E_BADARG;
   hipStream_t s = as_stream(stream);
+  if (gemm_version() == 2) {
+    const int64_t tm2 = (M + 255) / 256, tn2 = (N + 63) / 64;
+    const int sp = choose_splits_v2(tm2 * tn2, K);
+    const int64_t ch = chunk_for(K, sp);
+    if (sp == 1) {
+      hipLaunchKernelGGL((gemm_w64_kernel<false, 4, 1>), dim3((unsigned)tm2, (unsigned)tn2, 1), dim3(kBlock), 0, s, F,
+                         (int64_t)K, W, (int64_t)K, M, (int64_t)N, (int64_t)K, ch, Y, (int64_t)N, (int64_t)0, b, keep,
+                         scale);
+      MMSSL_LAUNCH_CHECK();
+      return 0;
+    }
+    const size_t need2 = (size_t)sp * (size_t)M * (size_t)N * sizeof(float);
+    if (!workspace || workspace_bytes < need2) return MMSSL_E_WORKSPACE;
+    float* P2 = reinterpret_cast<float*>(workspace);
+    hipLaunchKernelGGL((gemm_w64_kernel<false, 4, 1>), dim3((unsigned)tm2, (unsigned)tn2, (unsigned)sp), dim3(kBlock),
+                       0, s, F, (int64_t)K, W, (int64_t)K, M, (int64_t)N, (int64_t)K, ch, P2, (int64_t)N,
+                       (int64_t)M * N, (const float*)nullptr, (const uint8_t*)nullptr, 1.f);
+    MMSSL_LAUNCH_CHECK();
+    const int64_t total2 = M * N;
+    int64_t nb2 = (total2 / 4 + kBlock - 1) / kBlock;
+    nb2 = nb2 > 4096 ? 4096 : (nb2 < 1 ? 1 : nb2);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)nb2), dim3(kBlock), 0, s, P2, sp, total2, (int64_t)N, b,
+                       keep, scale, Y);
+    MMSSL_LAUNCH_CHECK();
+    return 0;
+  }
   const int64_t tm = (M + BT - 1) / BT, tn = (N + BT - 1) / BT;
   const int splits = choose_splits(tm * tn, K);
   const int64_t chunk = chunk_for(K, splits);
@@ -295,8 +470,10 @@ extern "C" int mmssl_linear_f32(const float* F, const float* W, const float* b, 
 
 extern "C" size_t mmssl_linear_wgrad_workspace_bytes(int64_t M, int K, int N) {
   if (M <= 0 || K <= 0 || N <= 0) return 16;
-  const int64_t tiles = ((N + BT - 1) / BT) * ((K + BT - 1) / BT);
-  const int splits = choose_splits(tiles, M);
+  // large enough for either kernel version (the masked-fetch form always uses v1)
+  const int s1 = choose_splits(((N + BT - 1) / BT) * ((K + BT - 1) / BT), M);
+  const int s2 = choose_splits_v2(((N + 63) / 64) * ((K + 255) / 256), M);
+  const int splits = s1 > s2 ? s1 : s2;
   const size_t part = splits > 1 ? (size_t)splits * (size_t)N * (size_t)K * sizeof(float) : 0;
   return part + (size_t)kColsumBlocks * (size_t)N * sizeof(float) + 16;
 }
@@ -308,12 +485,28 @@ extern "C" int mmssl_linear_wgrad_f32(const float* gY, const uint8_t* keep, floa
   if ((K & 3) || (N & 3) || N > 256) return MMSSL_E_UNSUPP;
   if (!workspace || workspace_bytes < mmssl_linear_wgrad_workspace_bytes(M, K, N)) return MMSSL_E_WORKSPACE;
   hipStream_t s = as_stream(stream);
-  const int64_t tn = (N + BT - 1) / BT, tk = (K + BT - 1) / BT;
-  const int splits = choose_splits(tn * tk, M);
+  const bool v2 = gemm_version() == 2 && keep == nullptr;
+  const int64_t tn = v2 ? (N + 63) / 64 : (N + BT - 1) / BT, tk = v2 ? (K + 255) / 256 : (K + BT - 1) / BT;
+  const int splits = v2 ? choose_splits_v2(tn * tk, M) : choose_splits(tn * tk, M);
   const int64_t chunk = chunk_for(M, splits);
   float* ws = reinterpret_cast<float*>(workspace);
   float* colpart = ws;                                   // [kColsumBlocks][N]
   float* P = ws + (size_t)kColsumBlocks * N;             // [splits][N][K]
+  if (v2) {
+    float* dst = splits == 1 ? gW : P;
+    hipLaunchKernelGGL((gemm_w64_kernel<true, 1, 4>), dim3((unsigned)tn, (unsigned)tk, (unsigned)splits), dim3(kBlock),
+                       0, s, gY, (int64_t)N, F, (int64_t)K, (int64_t)N, (int64_t)K, M, chunk, dst, (int64_t)K,
+                       splits == 1 ? (int64_t)0 : (int64_t)N * K, (const float*)nullptr, (const uint8_t*)nullptr, 1.f);
+    MMSSL_LAUNCH_CHECK();
+    if (splits > 1) {
+      const int64_t total = (int64_t)N * K;
+      int64_t nb = (total / 4 + kBlock - 1) / kBlock;
+      nb = nb > 4096 ? 4096 : (nb < 1 ? 1 : nb);
+      hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)nb), dim3(kBlock), 0, s, P, splits, total, (int64_t)K,
+                         (const float*)nullptr, (const uint8_t*)nullptr, 1.f, gW);
+      MMSSL_LAUNCH_CHECK();
+    }
+  } else
   // gW[n][k] = sum_m gY[m][n] * F[m][k]: A = gY as [kk=m][i=n], B = F as [kk=m][j=k]
   if (splits == 1) {
     hipLaunchKernelGGL((gemm64_kernel<true>), dim3((unsigned)tn, (unsigned)tk, 1), dim3(kBlock), 0, s, gY,

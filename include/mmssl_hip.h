@@ -185,6 +185,17 @@ int mmssl_infonce_fwd_f32(const float* z1, const float* z2, const int64_t* idx, 
 int mmssl_infonce_bwd_f32(const int64_t* idx, int64_t n, int d, float tau, const float* gloss,
                           float* gz1, float* gz2, void* workspace, size_t workspace_bytes,
                           void* stream);
+/* Batched form: n_problems (<= 4) losses that SHARE z2 and differ in z1 — the reference evaluates the
+ * loss once per modality against the same user embeddings (main.py:411-412). One set of launches for
+ * all problems; z1s / gz1s are HOST arrays of device pointers, losses / gloss device arrays
+ * [n_problems]; gz2 receives the sum over the problems. */
+size_t mmssl_infonce_multi_workspace_bytes(int n_problems, int64_t n, int d);
+int mmssl_infonce_multi_fwd_f32(const float* const* z1s, const float* z2, const int64_t* idx,
+                                int n_problems, int64_t n, int d, float tau, float* losses,
+                                void* workspace, size_t workspace_bytes, void* stream);
+int mmssl_infonce_multi_bwd_f32(const int64_t* idx, int n_problems, int64_t n, int d, float tau,
+                                const float* gloss, float* const* gz1s, float* gz2, void* workspace,
+                                size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * BPR  — gathers (main.py:368-370) + Trainer.bpr_loss (main.py:499-511)

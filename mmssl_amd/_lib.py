@@ -65,6 +65,11 @@ SIGNATURES = {
                                       c_size_t, c_void_p]),
     "mmssl_infonce_bwd_f32": (c_int, [c_void_p, c_int64, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p,
                                       c_size_t, c_void_p]),
+    "mmssl_infonce_multi_workspace_bytes": (c_size_t, [c_int, c_int64, c_int]),
+    "mmssl_infonce_multi_fwd_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int, c_float, c_void_p,
+                                            c_void_p, c_size_t, c_void_p]),
+    "mmssl_infonce_multi_bwd_f32": (c_int, [c_void_p, c_int, c_int64, c_int, c_float, c_void_p, c_void_p, c_void_p,
+                                            c_void_p, c_size_t, c_void_p]),
     "mmssl_bpr_workspace_bytes": (c_size_t, [c_int64]),
     "mmssl_bpr_fwd_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
                                   c_int, c_float, c_int64, c_void_p, c_void_p, c_size_t, c_void_p]),

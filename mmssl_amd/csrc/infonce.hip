@@ -63,12 +63,24 @@ inline Layout make_layout(int64_t n, int d) {
 }
 
 // ---- prep: normalise both inputs, positive-pair cosine --------------------------------
-__global__ __launch_bounds__(kBlock) void prep_kernel(const float* __restrict__ z1,
-                                                      const float* __restrict__ z2,
+constexpr int kMaxProblems = 4;
+struct Z1Ptrs {          // per-problem first operand (forward) / its gradient (backward)
+  const float* z1[kMaxProblems];
+  float* gz1[kMaxProblems];
+};
+
+// blockIdx.y = problem: problems share z2 and differ in z1 (the reference calls the loss once per
+// modality with the same user embeddings, main.py:411-412); each has its own workspace slice.
+__global__ __launch_bounds__(kBlock) void prep_kernel(Z1Ptrs Z, const float* __restrict__ z2,
                                                       const int64_t* __restrict__ idx, int64_t n, int d,
-                                                      float* __restrict__ n1, float* __restrict__ n2,
-                                                      float* __restrict__ inv1, float* __restrict__ inv2,
-                                                      float* __restrict__ pos) {
+                                                      float* __restrict__ ws, size_t ws_stride, Layout L) {
+  const float* __restrict__ z1 = Z.z1[blockIdx.y];
+  float* __restrict__ wsp = ws + (size_t)blockIdx.y * ws_stride;
+  float* __restrict__ n1 = wsp + L.n1;
+  float* __restrict__ n2 = wsp + L.n2;
+  float* __restrict__ inv1 = wsp + L.inv1;
+  float* __restrict__ inv2 = wsp + L.inv2;
+  float* __restrict__ pos = wsp + L.pos;
   // one 16-lane group per row, lanes stride over the d/4 float4 chunks
   const int lig = threadIdx.x & 15;
   const int64_t r = (int64_t)blockIdx.x * (kBlock / 16) + threadIdx.x / 16;
@@ -143,10 +155,12 @@ __device__ __forceinline__ void dot_2x2(const float* __restrict__ A, const float
 
 // ---- forward: partial denominators per (row, column split) ------------------------------
 template <int D>
-__global__ __launch_bounds__(kBlock) void fwd_tiles_kernel(const float* __restrict__ n1,
-                                                           const float* __restrict__ n2, int64_t n,
-                                                           float tau, int cs,
-                                                           float* __restrict__ rows_part) {
+__global__ __launch_bounds__(kBlock) void fwd_tiles_kernel(const float* __restrict__ ws, size_t ws_stride,
+                                                           Layout L, int64_t n, float tau, int cs) {
+  const float* __restrict__ wsp = ws + (size_t)blockIdx.y * ws_stride;
+  const float* __restrict__ n1 = wsp + L.n1;
+  const float* __restrict__ n2 = wsp + L.n2;
+  float* __restrict__ rows_part = const_cast<float*>(wsp) + L.rows_part;
   constexpr int S = D + 4;
   __shared__ __attribute__((aligned(16))) float A[T * S];
   __shared__ __attribute__((aligned(16))) float B[T * S];
@@ -186,11 +200,14 @@ __global__ __launch_bounds__(kBlock) void fwd_tiles_kernel(const float* __restri
 }
 
 // ---- finalize: per-row backward coefficients (row-parallel) + loss (fixed-order two-stage sum) ----
-__global__ __launch_bounds__(kBlock) void finalize_rows_kernel(const float* __restrict__ rows_part, int cs,
-                                                               const float* __restrict__ pos, int64_t n,
-                                                               float tau, float* __restrict__ w,
-                                                               float* __restrict__ c,
-                                                               float* __restrict__ loss_part) {
+__global__ __launch_bounds__(kBlock) void finalize_rows_kernel(float* __restrict__ ws, size_t ws_stride, Layout L,
+                                                               int cs, int64_t n, float tau) {
+  float* __restrict__ wsp = ws + (size_t)blockIdx.y * ws_stride;
+  const float* __restrict__ rows_part = wsp + L.rows_part;
+  const float* __restrict__ pos = wsp + L.pos;
+  float* __restrict__ w = wsp + L.w;
+  float* __restrict__ c = wsp + L.c;
+  float* __restrict__ loss_part = wsp + L.loss;
   __shared__ float red[4];
   const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   float li = 0.f;
@@ -206,22 +223,27 @@ __global__ __launch_bounds__(kBlock) void finalize_rows_kernel(const float* __re
   const float t = block_sum_256(li, red);
   if (threadIdx.x == 0) loss_part[blockIdx.x] = t;
 }
-__global__ __launch_bounds__(kBlock) void finalize_loss_kernel(const float* __restrict__ loss_part, int nparts,
-                                                               int64_t n, float* __restrict__ loss) {
+__global__ __launch_bounds__(kBlock) void finalize_loss_kernel(const float* __restrict__ ws, size_t ws_stride,
+                                                               Layout L, int nparts, int64_t n,
+                                                               float* __restrict__ loss) {
+  const float* __restrict__ loss_part = ws + (size_t)blockIdx.y * ws_stride + L.loss;
   __shared__ float red[4];
   float acc = 0.f;
   for (int i = threadIdx.x; i < nparts; i += kBlock) acc += loss_part[i];
   const float t = block_sum_256(acc, red);
-  if (threadIdx.x == 0) loss[0] = t / (float)n;
+  if (threadIdx.x == 0) loss[blockIdx.y] = t / (float)n;
 }
 
 // ---- backward tiles --------------------------------------------------------------------------
 template <int D>
-__global__ __launch_bounds__(kBlock) void bwd_tiles_kernel(const float* __restrict__ n1,
-                                                           const float* __restrict__ n2,
-                                                           const float* __restrict__ c, int64_t n,
-                                                           float tau, int cs, float* __restrict__ g1p,
-                                                           float* __restrict__ g2p) {
+__global__ __launch_bounds__(kBlock) void bwd_tiles_kernel(float* __restrict__ ws, size_t ws_stride, Layout L,
+                                                           int64_t n, float tau, int cs) {
+  float* __restrict__ wsp = ws + (size_t)blockIdx.y * ws_stride;
+  const float* __restrict__ n1 = wsp + L.n1;
+  const float* __restrict__ n2 = wsp + L.n2;
+  const float* __restrict__ c = wsp + L.c;
+  float* __restrict__ g1p = wsp + L.g1p;
+  float* __restrict__ g2p = wsp + L.g2p;
   constexpr int S = D + 4;
   constexpr int FPT = D / 16;        // output features per thread in the accumulate phase
   __shared__ __attribute__((aligned(16))) float A1[T * S];
@@ -336,65 +358,78 @@ __device__ __forceinline__ void put_row(float* __restrict__ g, int64_t row, int 
   }
 }
 
-__global__ __launch_bounds__(kBlock) void bwd_finish_kernel(const float* __restrict__ n1,
-                                                            const float* __restrict__ n2,
-                                                            const float* __restrict__ inv1,
-                                                            const float* __restrict__ inv2,
-                                                            const float* __restrict__ w,
-                                                            const float* __restrict__ g1p,
-                                                            const float* __restrict__ g2p, int cs,
-                                                            const int64_t* __restrict__ idx, int64_t n, int d,
-                                                            float tau, const float* __restrict__ gloss,
-                                                            float* __restrict__ gz1,
+__global__ __launch_bounds__(kBlock) void bwd_finish_kernel(const float* __restrict__ ws, size_t ws_stride, Layout L,
+                                                            int P, int cs, const int64_t* __restrict__ idx,
+                                                            int64_t n, int d, float tau,
+                                                            const float* __restrict__ gloss, Z1Ptrs Z,
                                                             float* __restrict__ gz2) {
   constexpr int MAXC = 4;                      // d <= 256 -> at most 4 float4 chunks per lane
   const int lig = threadIdx.x & 15;
   const int64_t r = (int64_t)blockIdx.x * (kBlock / 16) + threadIdx.x / 16;
   if (r >= n) return;
-  const float gl = gloss[0];
-  const float wt = w[r] / tau;
   const int nch = d >> 2;
-  float4 u[MAXC], v[MAXC], a[MAXC], b[MAXC];
-  float p1 = 0.f, p2 = 0.f;
-#pragma unroll
-  for (int t = 0; t < MAXC; ++t) {
-    const int k = lig + 16 * t;
-    if (k < nch) {
-      a[t] = reinterpret_cast<const float4*>(n1 + r * d)[k];
-      b[t] = reinterpret_cast<const float4*>(n2 + r * d)[k];
-      float4 uu = make_float4(wt * b[t].x, wt * b[t].y, wt * b[t].z, wt * b[t].w);
-      float4 vv = make_float4(wt * a[t].x, wt * a[t].y, wt * a[t].z, wt * a[t].w);
-      for (int s = 0; s < cs; ++s) {
-        const float4 x = reinterpret_cast<const float4*>(g1p + ((size_t)s * n + r) * d)[k];
-        const float4 y = reinterpret_cast<const float4*>(g2p + ((size_t)s * n + r) * d)[k];
-        uu.x += x.x; uu.y += x.y; uu.z += x.z; uu.w += x.w;
-        vv.x += y.x; vv.y += y.y; vv.z += y.z; vv.w += y.w;
-      }
-      u[t] = uu;
-      v[t] = vv;
-      p1 += f4_dot(a[t], uu);
-      p2 += f4_dot(b[t], vv);
-    }
-  }
-  p1 = group_sum<16>(p1);
-  p2 = group_sum<16>(p2);
-  const float i1 = inv1[r], i2 = inv2[r];
-  // inv == 1/eps exactly when the row norm was clamped (|z| < eps): no projection term then
-  const float q1 = (i1 >= 1.f / kNormEps) ? 0.f : p1;
-  const float q2 = (i2 >= 1.f / kNormEps) ? 0.f : p2;
-  const float m1 = gl * i1, m2 = gl * i2;
   const int64_t dst = idx ? idx[r] : r;
   const bool scatter = idx != nullptr;
+  float4 vsum[MAXC];                           // gz2 of this row, summed over the problems
 #pragma unroll
-  for (int t = 0; t < MAXC; ++t) {
-    const int k = lig + 16 * t;
-    if (k < nch) {
-      if (gz1)
-        put_row(gz1, dst, d, k, make_float4(m1 * (u[t].x - a[t].x * q1), m1 * (u[t].y - a[t].y * q1),
-                                            m1 * (u[t].z - a[t].z * q1), m1 * (u[t].w - a[t].w * q1)), scatter);
-      if (gz2)
-        put_row(gz2, dst, d, k, make_float4(m2 * (v[t].x - b[t].x * q2), m2 * (v[t].y - b[t].y * q2),
-                                            m2 * (v[t].z - b[t].z * q2), m2 * (v[t].w - b[t].w * q2)), scatter);
+  for (int t = 0; t < MAXC; ++t) vsum[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int p = 0; p < P; ++p) {
+    const float* __restrict__ wsp = ws + (size_t)p * ws_stride;
+    const float* __restrict__ n1 = wsp + L.n1;
+    const float* __restrict__ n2 = wsp + L.n2;
+    const float* __restrict__ g1p = wsp + L.g1p;
+    const float* __restrict__ g2p = wsp + L.g2p;
+    const float gl = gloss[p];
+    const float wt = wsp[L.w + r] / tau;
+    float4 u[MAXC], v[MAXC], a[MAXC], b[MAXC];
+    float p1 = 0.f, p2 = 0.f;
+#pragma unroll
+    for (int t = 0; t < MAXC; ++t) {
+      const int k = lig + 16 * t;
+      if (k < nch) {
+        a[t] = reinterpret_cast<const float4*>(n1 + r * d)[k];
+        b[t] = reinterpret_cast<const float4*>(n2 + r * d)[k];
+        float4 uu = make_float4(wt * b[t].x, wt * b[t].y, wt * b[t].z, wt * b[t].w);
+        float4 vv = make_float4(wt * a[t].x, wt * a[t].y, wt * a[t].z, wt * a[t].w);
+        for (int s = 0; s < cs; ++s) {
+          const float4 x = reinterpret_cast<const float4*>(g1p + ((size_t)s * n + r) * d)[k];
+          const float4 y = reinterpret_cast<const float4*>(g2p + ((size_t)s * n + r) * d)[k];
+          uu.x += x.x; uu.y += x.y; uu.z += x.z; uu.w += x.w;
+          vv.x += y.x; vv.y += y.y; vv.z += y.z; vv.w += y.w;
+        }
+        u[t] = uu;
+        v[t] = vv;
+        p1 += f4_dot(a[t], uu);
+        p2 += f4_dot(b[t], vv);
+      }
+    }
+    p1 = group_sum<16>(p1);
+    p2 = group_sum<16>(p2);
+    const float i1 = wsp[L.inv1 + r], i2 = wsp[L.inv2 + r];
+    // inv == 1/eps exactly when the row norm was clamped (|z| < eps): no projection term then
+    const float q1 = (i1 >= 1.f / kNormEps) ? 0.f : p1;
+    const float q2 = (i2 >= 1.f / kNormEps) ? 0.f : p2;
+    const float m1 = gl * i1, m2 = gl * i2;
+    float* __restrict__ gz1 = Z.gz1[p];
+#pragma unroll
+    for (int t = 0; t < MAXC; ++t) {
+      const int k = lig + 16 * t;
+      if (k < nch) {
+        if (gz1)
+          put_row(gz1, dst, d, k, make_float4(m1 * (u[t].x - a[t].x * q1), m1 * (u[t].y - a[t].y * q1),
+                                              m1 * (u[t].z - a[t].z * q1), m1 * (u[t].w - a[t].w * q1)), scatter);
+        vsum[t].x += m2 * (v[t].x - b[t].x * q2);
+        vsum[t].y += m2 * (v[t].y - b[t].y * q2);
+        vsum[t].z += m2 * (v[t].z - b[t].z * q2);
+        vsum[t].w += m2 * (v[t].w - b[t].w * q2);
+      }
+    }
+  }
+  if (gz2) {
+#pragma unroll
+    for (int t = 0; t < MAXC; ++t) {
+      const int k = lig + 16 * t;
+      if (k < nch) put_row(gz2, dst, d, k, vsum[t], scatter);
     }
   }
 }
@@ -403,65 +438,111 @@ inline bool infonce_d_ok(int d) { return d == 32 || d == 64 || d == 128 || d == 
 
 }  // namespace
 
+namespace {
+
+int infonce_fwd_impl(const float* const* z1s, const float* z2, const int64_t* idx, int P, int64_t n, int d,
+                     float tau, float* losses, void* workspace, size_t workspace_bytes, void* stream) {
+  if (P < 1 || P > kMaxProblems || n <= 0 || !z1s || !z2 || !losses || !(tau > 0.f)) return MMSSL_E_BADARG;
+  if (!infonce_d_ok(d)) return MMSSL_E_UNSUPP;
+  const Layout L = make_layout(n, d);
+  if (!workspace || workspace_bytes < (size_t)P * L.total * sizeof(float)) return MMSSL_E_WORKSPACE;
+  Z1Ptrs Z;
+  for (int p = 0; p < kMaxProblems; ++p) {
+    Z.z1[p] = p < P ? z1s[p] : nullptr;
+    Z.gz1[p] = nullptr;
+    if (p < P && (!z1s[p] || ((uintptr_t)z1s[p] & 15))) return MMSSL_E_BADARG;
+  }
+  if (((uintptr_t)z2 | (uintptr_t)workspace) & 15) return MMSSL_E_BADARG;
+  float* ws = reinterpret_cast<float*>(workspace);
+  hipStream_t s = as_stream(stream);
+  const int nt = n_tiles(n);
+  const int rb = (int)((n + 15) / 16);
+  hipLaunchKernelGGL(prep_kernel, dim3(rb, P), dim3(kBlock), 0, s, Z, z2, idx, n, d, ws, L.total, L);
+  MMSSL_LAUNCH_CHECK();
+  const dim3 grid(nt * L.cs_f, P);
+  switch (d) {
+    case 32: hipLaunchKernelGGL((fwd_tiles_kernel<32>), grid, dim3(kBlock), 0, s, ws, L.total, L, n, tau, L.cs_f); break;
+    case 64: hipLaunchKernelGGL((fwd_tiles_kernel<64>), grid, dim3(kBlock), 0, s, ws, L.total, L, n, tau, L.cs_f); break;
+    case 128: hipLaunchKernelGGL((fwd_tiles_kernel<128>), grid, dim3(kBlock), 0, s, ws, L.total, L, n, tau, L.cs_f); break;
+    case 256: hipLaunchKernelGGL((fwd_tiles_kernel<256>), grid, dim3(kBlock), 0, s, ws, L.total, L, n, tau, L.cs_f); break;
+  }
+  MMSSL_LAUNCH_CHECK();
+  const int fb = (int)((n + kBlock - 1) / kBlock);
+  hipLaunchKernelGGL(finalize_rows_kernel, dim3(fb, P), dim3(kBlock), 0, s, ws, L.total, L, L.cs_f, n, tau);
+  MMSSL_LAUNCH_CHECK();
+  hipLaunchKernelGGL(finalize_loss_kernel, dim3(1, P), dim3(kBlock), 0, s, ws, L.total, L, fb, n, losses);
+  MMSSL_LAUNCH_CHECK();
+  return 0;
+}
+
+int infonce_bwd_impl(const int64_t* idx, int P, int64_t n, int d, float tau, const float* gloss,
+                     float* const* gz1s, float* gz2, void* workspace, size_t workspace_bytes, void* stream) {
+  if (P < 1 || P > kMaxProblems || n <= 0 || !gloss || !(tau > 0.f)) return MMSSL_E_BADARG;
+  if (!infonce_d_ok(d)) return MMSSL_E_UNSUPP;
+  const Layout L = make_layout(n, d);
+  if (!workspace || workspace_bytes < (size_t)P * L.total * sizeof(float)) return MMSSL_E_WORKSPACE;
+  Z1Ptrs Z;
+  bool any = gz2 != nullptr;
+  for (int p = 0; p < kMaxProblems; ++p) {
+    Z.z1[p] = nullptr;
+    Z.gz1[p] = (p < P && gz1s) ? gz1s[p] : nullptr;
+    any = any || Z.gz1[p];
+    if ((uintptr_t)Z.gz1[p] & 15) return MMSSL_E_BADARG;
+  }
+  if (!any) return MMSSL_E_BADARG;
+  if (((uintptr_t)gz2 | (uintptr_t)workspace) & 15) return MMSSL_E_BADARG;
+  float* ws = reinterpret_cast<float*>(workspace);
+  hipStream_t s = as_stream(stream);
+  const int nt = n_tiles(n);
+  const dim3 grid(nt * L.cs_b, P);
+  switch (d) {
+    case 32: hipLaunchKernelGGL((bwd_tiles_kernel<32>), grid, dim3(kBlock), 0, s, ws, L.total, L, n, tau, L.cs_b); break;
+    case 64: hipLaunchKernelGGL((bwd_tiles_kernel<64>), grid, dim3(kBlock), 0, s, ws, L.total, L, n, tau, L.cs_b); break;
+    case 128: hipLaunchKernelGGL((bwd_tiles_kernel<128>), grid, dim3(kBlock), 0, s, ws, L.total, L, n, tau, L.cs_b); break;
+    case 256: hipLaunchKernelGGL((bwd_tiles_kernel<256>), grid, dim3(kBlock), 0, s, ws, L.total, L, n, tau, L.cs_b); break;
+  }
+  MMSSL_LAUNCH_CHECK();
+  const int rb = (int)((n + 15) / 16);
+  hipLaunchKernelGGL(bwd_finish_kernel, dim3(rb), dim3(kBlock), 0, s, ws, L.total, L, P, L.cs_b, idx, n, d, tau, gloss,
+                     Z, gz2);
+  MMSSL_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // namespace
+
 extern "C" size_t mmssl_infonce_workspace_bytes(int64_t n, int d) {
   if (n <= 0 || !infonce_d_ok(d)) return 0;
   return make_layout(n, d).total * sizeof(float);
 }
 
+extern "C" size_t mmssl_infonce_multi_workspace_bytes(int n_problems, int64_t n, int d) {
+  if (n_problems < 1 || n_problems > kMaxProblems) return 0;
+  return (size_t)n_problems * mmssl_infonce_workspace_bytes(n, d);
+}
+
 extern "C" int mmssl_infonce_fwd_f32(const float* z1, const float* z2, const int64_t* idx, int64_t n, int d,
                                      float tau, float* loss, void* workspace, size_t workspace_bytes,
                                      void* stream) {
-  if (n <= 0 || !z1 || !z2 || !loss || !(tau > 0.f)) return MMSSL_E_BADARG;
-  if (!infonce_d_ok(d)) return MMSSL_E_UNSUPP;
-  const Layout L = make_layout(n, d);
-  if (!workspace || workspace_bytes < L.total * sizeof(float)) return MMSSL_E_WORKSPACE;
-  if (((uintptr_t)z1 | (uintptr_t)z2 | (uintptr_t)workspace) & 15) return MMSSL_E_BADARG;
-  float* ws = reinterpret_cast<float*>(workspace);
-  hipStream_t s = as_stream(stream);
-  const int nt = n_tiles(n);
-  const int rb = (int)((n + 15) / 16);
-  hipLaunchKernelGGL(prep_kernel, dim3(rb), dim3(kBlock), 0, s, z1, z2, idx, n, d, ws + L.n1, ws + L.n2,
-                     ws + L.inv1, ws + L.inv2, ws + L.pos);
-  MMSSL_LAUNCH_CHECK();
-  const dim3 grid(nt * L.cs_f);
-  switch (d) {
-    case 32: hipLaunchKernelGGL((fwd_tiles_kernel<32>), grid, dim3(kBlock), 0, s, ws + L.n1, ws + L.n2, n, tau, L.cs_f, ws + L.rows_part); break;
-    case 64: hipLaunchKernelGGL((fwd_tiles_kernel<64>), grid, dim3(kBlock), 0, s, ws + L.n1, ws + L.n2, n, tau, L.cs_f, ws + L.rows_part); break;
-    case 128: hipLaunchKernelGGL((fwd_tiles_kernel<128>), grid, dim3(kBlock), 0, s, ws + L.n1, ws + L.n2, n, tau, L.cs_f, ws + L.rows_part); break;
-    case 256: hipLaunchKernelGGL((fwd_tiles_kernel<256>), grid, dim3(kBlock), 0, s, ws + L.n1, ws + L.n2, n, tau, L.cs_f, ws + L.rows_part); break;
-  }
-  MMSSL_LAUNCH_CHECK();
-  const int fb = (int)((n + kBlock - 1) / kBlock);
-  hipLaunchKernelGGL(finalize_rows_kernel, dim3(fb), dim3(kBlock), 0, s, ws + L.rows_part, L.cs_f, ws + L.pos, n,
-                     tau, ws + L.w, ws + L.c, ws + L.loss);
-  MMSSL_LAUNCH_CHECK();
-  hipLaunchKernelGGL(finalize_loss_kernel, dim3(1), dim3(kBlock), 0, s, ws + L.loss, fb, n, loss);
-  MMSSL_LAUNCH_CHECK();
-  return 0;
+  const float* z1s[1] = {z1};
+  return infonce_fwd_impl(z1s, z2, idx, 1, n, d, tau, loss, workspace, workspace_bytes, stream);
 }
 
 extern "C" int mmssl_infonce_bwd_f32(const int64_t* idx, int64_t n, int d, float tau, const float* gloss,
                                      float* gz1, float* gz2, void* workspace, size_t workspace_bytes,
                                      void* stream) {
-  if (n <= 0 || !gloss || (!gz1 && !gz2) || !(tau > 0.f)) return MMSSL_E_BADARG;
-  if (!infonce_d_ok(d)) return MMSSL_E_UNSUPP;
-  const Layout L = make_layout(n, d);
-  if (!workspace || workspace_bytes < L.total * sizeof(float)) return MMSSL_E_WORKSPACE;
-  if (((uintptr_t)gz1 | (uintptr_t)gz2 | (uintptr_t)workspace) & 15) return MMSSL_E_BADARG;
-  float* ws = reinterpret_cast<float*>(workspace);
-  hipStream_t s = as_stream(stream);
-  const int nt = n_tiles(n);
-  const dim3 grid(nt * L.cs_b);
-  switch (d) {
-    case 32: hipLaunchKernelGGL((bwd_tiles_kernel<32>), grid, dim3(kBlock), 0, s, ws + L.n1, ws + L.n2, ws + L.c, n, tau, L.cs_b, ws + L.g1p, ws + L.g2p); break;
-    case 64: hipLaunchKernelGGL((bwd_tiles_kernel<64>), grid, dim3(kBlock), 0, s, ws + L.n1, ws + L.n2, ws + L.c, n, tau, L.cs_b, ws + L.g1p, ws + L.g2p); break;
-    case 128: hipLaunchKernelGGL((bwd_tiles_kernel<128>), grid, dim3(kBlock), 0, s, ws + L.n1, ws + L.n2, ws + L.c, n, tau, L.cs_b, ws + L.g1p, ws + L.g2p); break;
-    case 256: hipLaunchKernelGGL((bwd_tiles_kernel<256>), grid, dim3(kBlock), 0, s, ws + L.n1, ws + L.n2, ws + L.c, n, tau, L.cs_b, ws + L.g1p, ws + L.g2p); break;
-  }
-  MMSSL_LAUNCH_CHECK();
-  const int rb = (int)((n + 15) / 16);
-  hipLaunchKernelGGL(bwd_finish_kernel, dim3(rb), dim3(kBlock), 0, s, ws + L.n1, ws + L.n2, ws + L.inv1,
-                     ws + L.inv2, ws + L.w, ws + L.g1p, ws + L.g2p, L.cs_b, idx, n, d, tau, gloss, gz1, gz2);
-  MMSSL_LAUNCH_CHECK();
-  return 0;
+  float* gz1s[1] = {gz1};
+  return infonce_bwd_impl(idx, 1, n, d, tau, gloss, gz1s, gz2, workspace, workspace_bytes, stream);
+}
+
+extern "C" int mmssl_infonce_multi_fwd_f32(const float* const* z1s, const float* z2, const int64_t* idx,
+                                           int n_problems, int64_t n, int d, float tau, float* losses,
+                                           void* workspace, size_t workspace_bytes, void* stream) {
+  return infonce_fwd_impl(z1s, z2, idx, n_problems, n, d, tau, losses, workspace, workspace_bytes, stream);
+}
+
+extern "C" int mmssl_infonce_multi_bwd_f32(const int64_t* idx, int n_problems, int64_t n, int d, float tau,
+                                           const float* gloss, float* const* gz1s, float* gz2, void* workspace,
+                                           size_t workspace_bytes, void* stream) {
+  return infonce_bwd_impl(idx, n_problems, n, d, tau, gloss, gz1s, gz2, workspace, workspace_bytes, stream);
 }

@@ -6,6 +6,8 @@ tensor or a missing library raises.
 
 Reference call sites are listed per op (paths relative to /root/reference/MMSSL/).
 """
+import ctypes as _ct
+
 import torch
 
 from . import _lib
@@ -359,8 +361,17 @@ class _BatchLosses(torch.autograd.Function):
         rc = _lib.lib().mmssl_bpr_fwd_f32(_ptr(ua), _ptr(ia), None, _ptr(users), _ptr(pos), _ptr(neg), B, d,
                                           float(decay), int(batch_size), _ptr(out), _ptr(wsb), nb, _lib.stream_ptr())
         _lib.check(rc, "mmssl_bpr_fwd_f32")
-        _, ws1, n, _ = _infonce_fwd_raw(img_uid, ua, users, tau, loss=out[3:4])     # written in place
-        _, ws2, n, _ = _infonce_fwd_raw(txt_uid, ua, users, tau, loss=out[4:5])
+        # both InfoNCE problems (image / text view vs the same user table) in ONE set of launches,
+        # losses written straight into out[3], out[4]
+        nbw = _lib.lib().mmssl_infonce_multi_workspace_bytes(2, B, d)
+        if nbw == 0:
+            raise _lib.MmsslError("infonce: unsupported shape n=%d d=%d" % (B, d))
+        ws1 = torch.empty(nbw // 4, dtype=torch.float32, device=ua.device)
+        ws2 = ws1
+        z1s = (_ct.c_void_p * 2)(img_uid.data_ptr(), txt_uid.data_ptr())
+        rc = _lib.lib().mmssl_infonce_multi_fwd_f32(z1s, _ptr(ua), _ptr(users), 2, B, d, float(tau), _ptr(out[3:5]),
+                                                    _ptr(ws1), nbw, _lib.stream_ptr())
+        _lib.check(rc, "mmssl_infonce_multi_fwd_f32")
         ctx.save_for_backward(ua, ia, users, pos, neg, ws1, ws2)
         ctx.cfg = (B, d, float(decay), int(batch_size), float(tau), img_uid.shape, txt_uid.shape)
         return out
@@ -378,8 +389,10 @@ class _BatchLosses(torch.autograd.Function):
         _lib.check(rc, "mmssl_bpr_bwd_f32")
         g_img = torch.zeros(s_img, dtype=torch.float32, device=ua.device) if ctx.needs_input_grad[2] else None
         g_txt = torch.zeros(s_txt, dtype=torch.float32, device=ua.device) if ctx.needs_input_grad[3] else None
-        _infonce_bwd_raw(users, B, d, tau, g[3:4], g_img, g_ua, ws1)
-        _infonce_bwd_raw(users, B, d, tau, g[4:5], g_txt, g_ua, ws2)
+        gz1s = (_ct.c_void_p * 2)(_ptr(g_img), _ptr(g_txt))
+        rc = _lib.lib().mmssl_infonce_multi_bwd_f32(_ptr(users), 2, B, d, tau, _ptr(g[3:5]), gz1s, _ptr(g_ua), _ptr(ws1),
+                                                    ws1.numel() * 4, _lib.stream_ptr())
+        _lib.check(rc, "mmssl_infonce_multi_bwd_f32")
         return g_ua, g_ia, g_img, g_txt, None, None, None, None, None, None
 
 
@@ -443,9 +456,6 @@ def zero_grad_anchor(x, w):
 # ---------------------------------------------------------------------------------------
 # GCN propagation + layer mean + modality fusion as ONE autograd node       Models.py:199-218
 # ---------------------------------------------------------------------------------------
-import ctypes as _ct
-
-
 def _combine_fwd(layers, inv, A, B, r, part):
     out = torch.empty_like(A)
     arr = (_ct.c_void_p * len(layers))(*[t.data_ptr() for t in layers])
@@ -502,14 +512,16 @@ class _PropagateFuse(torch.autograd.Function):
         _lib.check(rc, "mmssl_sum_partials_f32")
         ctx.save_for_backward(img_user, txt_user, img_item, txt_item, us[-1], its[-1])
         ctx.cfg = (ui, iu, n_layers, float(r), inv)
+        ctx.set_materialize_grads(False)     # unused outputs arrive as None, not as zero-filled tensors
         return u_g, i_g, ss, img_item, txt_item, img_user, txt_user
 
     @staticmethod
     def backward(ctx, Gu, Gi, g_ss, G_img_item, G_txt_item, G_img_user, G_txt_user):
         img_user, txt_user, img_item, txt_item, uG, iG = ctx.saved_tensors
         ui, iu, n_layers, r, inv = ctx.cfg
-        Gu, Gi = _chk(Gu, "Gu"), _chk(Gi, "Gi")
-        g_ss = g_ss.contiguous().to(torch.float32)
+        Gu = _chk(Gu, "Gu") if Gu is not None else torch.zeros_like(img_user)
+        Gi = _chk(Gi, "Gi") if Gi is not None else torch.zeros_like(img_item)
+        g_ss = g_ss.contiguous().to(torch.float32) if g_ss is not None else None
         # d(ss)/dx = 2x; normalize-backward and the regulariser term share one pass over A, B
         g_iu_, g_tu_, g_u0 = _combine_bwd(img_user, txt_user, Gu, r, inv, g_ss, 2.0, True)
         g_ii_, g_ti_, _ = _combine_bwd(img_item, txt_item, Gi, r, inv, g_ss, 2.0, False)

@@ -158,9 +158,6 @@ class MMSSL(nn.Module):
                 dev = self.image_trans.weight.device
                 km_img = torch.empty(shape, dtype=torch.uint8, device=dev).bernoulli_(1.0 - p)   # 1 = keep
                 km_txt = torch.empty(shape, dtype=torch.uint8, device=dev).bernoulli_(1.0 - p)
-        x_img = ops.linear(self.image_feats, self.image_trans.weight, self.image_trans.bias, km_img, scale)
-        x_txt = ops.linear(self.text_feats, self.text_trans.weight, self.text_trans.bias, km_txt, scale)
-
         E_u, E_i = self.user_id_embedding.weight, self.item_id_embedding.weight
         # the reference repeats this block args.layers times without feeding anything back
         # (Models.py:176-186): the result is that of one pass.
@@ -190,10 +187,13 @@ class MMSSL(nn.Module):
         self.embedding_dict["item"]["image"] = image_item_id
         self.embedding_dict["item"]["text"] = text_item_id
 
-        # modal SpMM chains, G-layer propagation, layer mean and "+ rate * normalize(modal feats)" as
-        # one fused node; its by-product `ss` is the feature regulariser's sum of squares (main.py:252-257)
-        (u_g, i_g, ss, image_item_feats, text_item_feats, image_user_feats, text_user_feats) = ops.propagate_fuse(
-            ui, iu, u, i, x_img, x_txt, self.n_ui_layers, args.model_cat_rate)
+        # projection, modal SpMM chains, G-layer propagation, layer mean and "+ rate * normalize(modal
+        # feats)" as one fused node on three forked streams; its by-product `ss` is the feature
+        # regulariser's sum of squares (main.py:252-257)
+        (u_g, i_g, ss, image_item_feats, text_item_feats, image_user_feats, text_user_feats) = ops.hot_forward(
+            self.image_feats, self.image_trans.weight, self.image_trans.bias, km_img,
+            self.text_feats, self.text_trans.weight, self.text_trans.bias, km_txt, scale,
+            u, i, ui, iu, self.n_ui_layers, args.model_cat_rate)
         self._feat_sumsq = (ss, (image_item_feats, text_item_feats, image_user_feats, text_user_feats))
         return (u_g, i_g, image_item_feats, text_item_feats, image_user_feats, text_user_feats, u_g, i_g,
                 image_user_id, text_user_id, image_item_id, text_item_id)

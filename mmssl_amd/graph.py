@@ -66,16 +66,22 @@ class GraphPlan:
                 "task_nnz", "sorted"]
         return {k: int(v) for k, v in zip(keys, buf) if k != "_"}
 
-    def workspace(self, transpose, d):
+    def workspace(self, transpose, d, lane=0):
         """Scratch for the partial sums of rows cut into several wave tasks; cached per
-        (direction, d) so pointers stay stable under hipGraph replay."""
-        key = (bool(transpose), int(d))
+        (direction, d, lane) so pointers stay stable under hipGraph replay. SpMMs that may run
+        CONCURRENTLY on different streams must use different lanes (see `twin`)."""
+        key = (bool(transpose), int(d), int(lane))
         ws = self._ws.get(key)
         if ws is None:
             nbytes = _lib.lib().mmssl_spmm_workspace_bytes(self.handle, int(bool(transpose)), int(d))
             ws = torch.empty(max(nbytes // 4, 4), dtype=torch.float32, device=self.device)
             self._ws[key] = ws
         return ws
+
+    def twin(self, lane=1):
+        """A view of this plan (same device CSR, read-only) with its own partial-sum workspace, for
+        launches that overlap with launches through the plan itself on another stream."""
+        return _PlanView(self, lane)
 
     def export_transpose(self):
         """(rowptr, col, val) numpy arrays of the device-resident transposed CSR (tests)."""
@@ -100,6 +106,22 @@ class GraphPlan:
             self.destroy()
         except Exception:
             pass
+
+
+class _PlanView:
+    def __init__(self, plan, lane):
+        self._plan, self._lane = plan, int(lane)
+        self.shape, self.nnz = plan.shape, plan.nnz
+
+    @property
+    def handle(self):
+        return self._plan.handle
+
+    def workspace(self, transpose, d, lane=None):
+        return self._plan.workspace(transpose, d, self._lane)
+
+    def twin(self, lane=1):
+        return _PlanView(self._plan, lane)
 
 
 def _coo_tensor_to_scipy(t):

@@ -77,7 +77,7 @@ class _Spmm(torch.autograd.Function):
 
 def spmm(plan, X, epilogue=EPI_NONE, transpose=False):
     """Y = A @ X (or A^T @ X), optionally with the row softmax fused into the store."""
-    if not isinstance(plan, GraphPlan):
+    if not hasattr(plan, "handle"):
         raise _lib.MmsslError("spmm expects a GraphPlan (see mmssl_amd.graph.as_plan)")
     return _Spmm.apply(X, plan, bool(transpose), int(epilogue))
 
@@ -190,29 +190,35 @@ class _Linear(torch.autograd.Function):
     def backward(ctx, gY):
         F_, W, keep = ctx.saved_tensors
         gY = _chk(gY, "gY")
-        M, K = F_.shape
-        N = W.shape[0]
-        gW = torch.empty_like(W)
-        gb = torch.empty(N, dtype=torch.float32, device=W.device)
-        nb = _lib.lib().mmssl_linear_wgrad_workspace_bytes(M, K, N)
-        ws = torch.empty(max(nb // 4, 4), dtype=torch.float32, device=W.device)
-        if keep is not None:        # dropout backward: one pass (the in-fetch variant of wgrad measured slower)
-            gYm = torch.empty_like(gY)
-            rc = _lib.lib().mmssl_mask_scale_f32(_ptr(gY), _ptr(keep), ctx.scale, gY.numel(), _ptr(gYm),
-                                                 _lib.stream_ptr())
-            _lib.check(rc, "mmssl_mask_scale_f32")
-            gY = gYm
-        rc = _lib.lib().mmssl_linear_wgrad_f32(_ptr(gY), None, 1.0, _ptr(F_), M, K, N, _ptr(gW), _ptr(gb), _ptr(ws),
-                                               nb, _lib.stream_ptr())
-        _lib.check(rc, "mmssl_linear_wgrad_f32")
+        gY, gW, gb = _linear_wgrad_raw(gY, keep, ctx.scale, F_, W)
         gF = None
         if ctx.needs_input_grad[0]:
             # gF = gY @ W  ([M,N] x [N,K]); used by the small modality-fusion product (K = d).
             # The raw feature matrices are constants in the reference (Models.py:46-47).
-            if K > 256:
+            if F_.shape[1] > 256:
                 raise _lib.MmsslError("linear: input gradient only supported for K <= 256")
-            gF = _linear_raw(gY, W.t().contiguous(), None, None, 1.0)      # gY already masked above
+            gF = _linear_raw(gY, W.t().contiguous(), None, None, 1.0)      # gY already masked
         return gF, gW, (gb if ctx.has_bias else None), None, None
+
+
+def _linear_wgrad_raw(gY, keep, scale, F_, W):
+    """(masked gY, gW, gb) for Y = dropout(F W^T + b): dropout backward, then the wgrad GEMM."""
+    M, K = F_.shape
+    N = W.shape[0]
+    if keep is not None:        # dropout backward: one pass (the in-fetch variant of wgrad measured slower)
+        gYm = torch.empty_like(gY)
+        rc = _lib.lib().mmssl_mask_scale_f32(_ptr(gY), _ptr(keep), float(scale), gY.numel(), _ptr(gYm),
+                                             _lib.stream_ptr())
+        _lib.check(rc, "mmssl_mask_scale_f32")
+        gY = gYm
+    gW = torch.empty_like(W)
+    gb = torch.empty(N, dtype=torch.float32, device=W.device)
+    nb = _lib.lib().mmssl_linear_wgrad_workspace_bytes(M, K, N)
+    ws = torch.empty(max(nb // 4, 4), dtype=torch.float32, device=W.device)
+    rc = _lib.lib().mmssl_linear_wgrad_f32(_ptr(gY), None, 1.0, _ptr(F_), M, K, N, _ptr(gW), _ptr(gb), _ptr(ws), nb,
+                                           _lib.stream_ptr())
+    _lib.check(rc, "mmssl_linear_wgrad_f32")
+    return gY, gW, gb
 
 
 def linear(F_, W, b=None, keep=None, scale=1.0):
@@ -552,3 +558,139 @@ def propagate_fuse(ui, iu, u0, i0, x_img, x_txt, n_layers, r):
     GraphPlans; x_img / x_txt are the projected (and dropped-out) modality features [n_items, d]."""
     out = _PropagateFuse.apply(u0, i0, x_img, x_txt, ui, iu, int(n_layers), float(r))
     return out
+
+
+# ---------------------------------------------------------------------------------------
+# projection + modal chains + GCN chain + fusion as ONE node, three forked streams
+# ---------------------------------------------------------------------------------------
+import os as _os
+
+_SIDE_STREAMS = {}
+
+
+def _side_streams(device, n=3):
+    key = (device.type, device.index)
+    st = _SIDE_STREAMS.get(key)
+    if st is None:
+        st = [torch.cuda.Stream(device=device) for _ in range(n)]
+        _SIDE_STREAMS[key] = st
+    return st
+
+
+def overlap_enabled():
+    return _os.environ.get("MMSSL_STREAMS", "1") != "0"
+
+
+class _HotForward(torch.autograd.Function):
+    """x_m = dropout(F_m W_m^T + b_m) -> modal SpMM chains -> G-layer GCN -> layer mean + modality
+    fusion (+ regulariser sum): the complete MMSSL.forward after the id-embedding fusion
+    (Models.py:173-174,177-178,182-183,199-218) as one autograd node.
+
+    Three chains are independent and bound by different resources — image projection + its modal chain
+    (fp32 MFMA, then gather), text projection + chain, and the GCN chain (gather, latency) — so the
+    node forks three HIP streams from the current one, runs one chain on each and joins before the
+    combine kernels; the backward mirrors that (GCN backward || image wgrad path || text wgrad path).
+    Every side-stream region starts with wait_stream(current) and ends joined into the current
+    stream, so the node looks single-stream from outside (autograd, caching allocator, hipGraph
+    capture all see ordinary fork/join edges)."""
+
+    @staticmethod
+    def forward(ctx, F_img, W_img, b_img, keep_img, F_txt, W_txt, b_txt, keep_txt, scale, u0, i0, ui, iu,
+                n_layers, r, overlap):
+        F_img, W_img, F_txt, W_txt = _chk(F_img, "F_img"), _chk(W_img, "W_img"), _chk(F_txt, "F_txt"), _chk(W_txt, "W_txt")
+        u0, i0 = _chk(u0, "u0"), _chk(i0, "i0")
+        dev = u0.device
+        main = torch.cuda.current_stream(dev)
+        sA, sB, sC = _side_streams(dev) if overlap else (main, main, main)
+        if overlap:
+            for st in (sA, sB, sC):
+                st.wait_stream(main)
+        with torch.cuda.stream(sA):
+            x_img = _linear_raw(F_img, W_img, b_img, keep_img, scale)
+            img_user = _spmm_raw(ui, False, x_img, EPI_NONE)
+            img_item = _spmm_raw(iu, False, img_user, EPI_NONE)
+        with torch.cuda.stream(sB):
+            x_txt = _linear_raw(F_txt, W_txt, b_txt, keep_txt, scale)
+            txt_user = _spmm_raw(ui.twin(), False, x_txt, EPI_NONE)
+            txt_item = _spmm_raw(iu.twin(), False, txt_user, EPI_NONE)
+        with torch.cuda.stream(sC):
+            us, its = [u0], [i0]
+            u, i = u0, i0
+            uic, iuc = ui.twin(2), iu.twin(2)
+            for l in range(n_layers):
+                epi = EPI_SOFTMAX if l == n_layers - 1 else EPI_NONE
+                u = _spmm_raw(uic, False, i, epi)
+                i = _spmm_raw(iuc, False, u, epi)
+                us.append(u)
+                its.append(i)
+        if overlap:
+            for st in (sA, sB, sC):
+                main.wait_stream(st)
+        inv = 1.0 / (n_layers + 1)
+        d = u0.shape[1]
+        nbu = _lib.lib().mmssl_layer_combine_blocks(u0.shape[0], d)
+        nbi = _lib.lib().mmssl_layer_combine_blocks(i0.shape[0], d)
+        part = torch.empty(nbu + nbi, dtype=torch.float32, device=dev)
+        u_g = _combine_fwd(us, inv, img_user, txt_user, r, part[:nbu])
+        i_g = _combine_fwd(its, inv, img_item, txt_item, r, part[nbu:])
+        ss = torch.empty((), dtype=torch.float32, device=dev)
+        rc = _lib.lib().mmssl_sum_partials_f32(_ptr(part), nbu + nbi, _ptr(ss), _lib.stream_ptr())
+        _lib.check(rc, "mmssl_sum_partials_f32")
+        ctx.save_for_backward(F_img, W_img, keep_img, F_txt, W_txt, keep_txt, img_user, txt_user, img_item, txt_item,
+                              us[-1], its[-1])
+        ctx.cfg = (ui, iu, n_layers, float(r), inv, float(scale), bool(overlap), b_img is not None, b_txt is not None)
+        ctx.set_materialize_grads(False)
+        return u_g, i_g, ss, img_item, txt_item, img_user, txt_user
+
+    @staticmethod
+    def backward(ctx, Gu, Gi, g_ss, G_img_item, G_txt_item, G_img_user, G_txt_user):
+        (F_img, W_img, keep_img, F_txt, W_txt, keep_txt, img_user, txt_user, img_item, txt_item, uG,
+         iG) = ctx.saved_tensors
+        ui, iu, n_layers, r, inv, scale, overlap, has_bi, has_bt = ctx.cfg
+        Gu = _chk(Gu, "Gu") if Gu is not None else torch.zeros_like(img_user)
+        Gi = _chk(Gi, "Gi") if Gi is not None else torch.zeros_like(img_item)
+        g_ss = g_ss.contiguous().to(torch.float32) if g_ss is not None else None
+        g_iu_, g_tu_, g_u0 = _combine_bwd(img_user, txt_user, Gu, r, inv, g_ss, 2.0, True)
+        g_ii_, g_ti_, _ = _combine_bwd(img_item, txt_item, Gi, r, inv, g_ss, 2.0, False)
+        if G_img_item is not None:
+            g_ii_ = g_ii_ + G_img_item
+        if G_txt_item is not None:
+            g_ti_ = g_ti_ + G_txt_item
+        if G_img_user is not None:
+            g_iu_ = g_iu_ + G_img_user
+        if G_txt_user is not None:
+            g_tu_ = g_tu_ + G_txt_user
+        dev = Gu.device
+        main = torch.cuda.current_stream(dev)
+        sA, sB, sC = _side_streams(dev) if overlap else (main, main, main)
+        if overlap:
+            for st in (sA, sB, sC):
+                st.wait_stream(main)
+        with torch.cuda.stream(sC):
+            uic, iuc = ui.twin(2), iu.twin(2)
+            gi = softmax_rows_bwd(iG, Gi, inv)
+            gu = _spmm_raw(iuc, True, gi, EPI_AXPY_SOFTMAX_BWD, Gu, inv, uG)
+            gi = _spmm_raw(uic, True, gu, EPI_AXPY, Gi, inv)
+            for _ in range(n_layers - 1):
+                gu = _spmm_raw(iuc, True, gi, EPI_AXPY, Gu, inv)
+                gi = _spmm_raw(uic, True, gu, EPI_AXPY, Gi, inv)
+        with torch.cuda.stream(sA):
+            g_x_img = _spmm_raw(ui, True, _spmm_raw(iu, True, g_ii_, EPI_AXPY, g_iu_, 1.0), EPI_NONE)
+            _, gW_img, gb_img = _linear_wgrad_raw(g_x_img, keep_img, scale, F_img, W_img)
+        with torch.cuda.stream(sB):
+            g_x_txt = _spmm_raw(ui.twin(), True, _spmm_raw(iu.twin(), True, g_ti_, EPI_AXPY, g_tu_, 1.0), EPI_NONE)
+            _, gW_txt, gb_txt = _linear_wgrad_raw(g_x_txt, keep_txt, scale, F_txt, W_txt)
+        if overlap:
+            for st in (sA, sB, sC):
+                main.wait_stream(st)
+        return (None, gW_img, gb_img if has_bi else None, None, None, gW_txt, gb_txt if has_bt else None, None, None,
+                g_u0, gi, None, None, None, None, None)
+
+
+def hot_forward(F_img, W_img, b_img, keep_img, F_txt, W_txt, b_txt, keep_txt, scale, u0, i0, ui, iu, n_layers, r,
+                overlap=None):
+    """(u_g, i_g, ss, img_item, txt_item, img_user, txt_user): see _HotForward."""
+    if overlap is None:
+        overlap = overlap_enabled()
+    return _HotForward.apply(F_img, W_img, b_img, keep_img, F_txt, W_txt, b_txt, keep_txt, float(scale), u0, i0,
+                             ui, iu, int(n_layers), float(r), bool(overlap))

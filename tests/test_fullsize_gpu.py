@@ -1,0 +1,103 @@
+"""Parity at BASELINE.json's full sizes: the Tiktok shape directly against the oracle (seconds on CPU),
+the Amazon-Baby shape through size-independent properties (adjointness of the backward SpMM,
+linearity, softmax rows, determinism, loss invariants)."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import torch
+
+import helpers as H
+import mmssl_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _setup(shape, G=3):
+    from mmssl_amd import config, synth
+    from mmssl_amd.graph import GraphPlan
+    U, I, E, dv, dt = synth.SHAPES[shape]
+    config.configure([], drop_rate=0.0, batch_size=1024, weight_size=str([64] * G), debug=True)
+    raw = synth.interaction_matrix(U, I, E, seed=1)
+    ui, iu = synth.normalised_pair(raw)
+    return U, I, dv, dt, raw, ui, iu, GraphPlan(ui), GraphPlan(iu)
+
+
+def test_tiktok_full_size_forward_and_losses_match_oracle():
+    """configs[1]: Tiktok (9319 x 6710, 59.5K edges, V128/T768), d=64, 3-layer GCN + V/T InfoNCE."""
+    from mmssl_amd import ops
+    from mmssl_amd.Models import MMSSL
+    U, I, dv, dt, raw, ui, iu, P_ui, P_iu = _setup("tiktok")
+    g = torch.Generator().manual_seed(0)
+    img, txt = torch.randn(I, dv, generator=g), torch.randn(I, dt, generator=g)
+    torch.manual_seed(4)
+    model = MMSSL(U, I, 64, [64] * 3, [0.1] * 3, img.numpy(), txt.numpy())
+    P = {k: v.detach().clone().requires_grad_(v.dtype.is_floating_point) for k, v in model.state_dict().items()}
+    model = model.to(DEV).train()
+    rng = np.random.default_rng(1)
+    # one sparse modal graph pair so that the InfoNCE first operand is not all-zero
+    us = rng.choice(U, 1024, replace=False)
+    modal = sp.csr_matrix((np.ones(1024, np.float32), (us, rng.integers(0, I, 1024))), shape=(U, I))
+    from mmssl_amd.graph import GraphPlan
+    m_ui, m_iu = O.csr_norm(modal, True).tocsr(), O.csr_norm(modal.T, True).tocsr()
+    graphs_g = (P_ui, P_iu, GraphPlan(m_ui), GraphPlan(m_iu), GraphPlan(m_ui), GraphPlan(m_iu))
+    A = [O.to_torch_sparse(x) for x in (ui, iu, m_ui, m_iu, m_ui, m_iu)]
+    users = torch.from_numpy(us)
+    pos = torch.from_numpy(rng.integers(0, I, 1024))
+    neg = torch.from_numpy(rng.integers(0, I, 1024))
+    cfg = O.Cfg(drop_rate=0.0, n_ui_layers=3, batch_size=1024)
+    o = O.forward(P, img, txt, A, cfg, training=False)
+    mf, emb, _ = O.bpr(o[0][users], o[1][pos], o[1][neg], 1e-5, 1024)
+    ref = mf + emb + O.feat_reg(o[2], o[3], o[4], o[5], I, 1e-5) + 0.03 * (
+        O.infonce(o[8][users], o[6][users], 0.5) + O.infonce(o[9][users], o[6][users], 0.5))
+    ref.backward()
+    og = model(*graphs_g)
+    for k in (0, 1, 2, 4, 8, 10):
+        assert H.rel_err(og[k].detach().cpu(), o[k].detach()) < 1e-4, k
+    t = ops.batch_losses_vec(og[0], og[1], og[8], og[9], users.to(DEV), pos.to(DEV), neg.to(DEV), 1e-5, 1024, 0.5)
+    w = torch.tensor([1.0, 1.0, 1.0, 0.03, 0.03], device=DEV)
+    got = ops.loss_assemble(t, w, model.feat_sumsq(og[2], og[3], og[4], og[5]), 1e-5 * 0.5 / I)
+    assert abs(float(got) - float(ref)) <= 1e-4 * abs(float(ref)), (float(got), float(ref))     # north_star bar
+    got.backward()
+    named = dict(model.named_parameters())
+    for k in ("image_trans.weight", "text_trans.weight", "user_id_embedding.weight", "item_id_embedding.weight",
+              "weight_dict.w_self_attention_cat"):
+        assert H.rel_err(named[k].grad.cpu(), P[k].grad) < 5e-4, (k, H.rel_err(named[k].grad.cpu(), P[k].grad))
+
+
+def test_baby_full_size_properties():
+    """configs[2]: Amazon-Baby shape (35598 x 18357, 256308 edges), d=64."""
+    from mmssl_amd import ops
+    U, I, dv, dt, raw, ui, iu, P_ui, P_iu = _setup("baby")
+    g = torch.Generator().manual_seed(0)
+    X = torch.randn(I, 64, generator=g).to(DEV)
+    X2 = torch.randn(I, 64, generator=g).to(DEV)
+    Yv = torch.randn(U, 64, generator=g).to(DEV)
+    Y = ops.spmm(P_ui, X)
+    # adjointness: <A x, y> == <x, A^T y>  (the backward SpMM really is the transpose)
+    lhs = float((Y.double() * Yv.double()).sum())
+    rhs = float((X.double() * ops.spmm(P_ui, Yv, transpose=True).double()).sum())
+    assert abs(lhs - rhs) <= 1e-5 * abs(lhs)
+    # linearity
+    Z = ops.spmm(P_ui, 2.0 * X - 3.0 * X2)
+    assert H.rel_err(Z.cpu(), (2.0 * Y - 3.0 * ops.spmm(P_ui, X2)).cpu()) < 1e-5
+    # row sums of A_ui with 1/sqrt(deg) values: A.1 = sqrt(deg) (empty rows 0)
+    ones = torch.ones(I, 64, device=DEV)
+    deg = np.diff(raw.indptr).astype(np.float64)
+    np.testing.assert_allclose(ops.spmm(P_ui, ones)[:, 0].cpu().numpy(), np.sqrt(deg), rtol=2e-6, atol=1e-6)
+    # fused softmax rows sum to one; bitwise determinism
+    S = ops.spmm(P_iu, Yv, epilogue=ops.EPI_SOFTMAX)
+    assert float((S.sum(1) - 1).abs().max()) < 1e-5 and float(S.min()) >= 0.0
+    assert torch.equal(S, ops.spmm(P_iu, Yv, epilogue=ops.EPI_SOFTMAX))
+    # against the oracle on a 2000-row sample of the full product
+    ref = O.spmm(O.to_torch_sparse(ui), X.cpu())
+    rows = torch.randperm(U, generator=g)[:2000]
+    assert H.rel_err(Y.cpu()[rows], ref[rows]) < 3e-6
+    # InfoNCE invariants at B=1024: symmetric inputs scale-invariant (cosine), zero z1 -> closed form
+    z = torch.randn(1024, 64, generator=g).to(DEV)
+    z2 = torch.randn(1024, 64, generator=g).to(DEV)
+    a = float(ops.infonce(z, z2, 0.5))
+    b = float(ops.infonce(7.5 * z, 0.01 * z2, 0.5))
+    assert abs(a - b) <= 2e-6 * abs(a)
+    zero = float(ops.infonce(torch.zeros_like(z), z2, 0.5))
+    assert abs(zero + np.log(1.0 / (2 * 1024 - 1) + 1e-8)) < 1e-5

@@ -271,6 +271,89 @@ __global__ __launch_bounds__(kBlock) void gemm_w64_kernel(const float* __restric
     }
 }
 
+// ======================================================================================
+// v3 forward kernel: barrier-free, LDS-free. Every WAVE streams its own 32 x N output tile over a K range:
+// both MFMA operands (v_mfma_f32_16x16x4_f32) are loaded straight from global memory in fragment order —
+// lane (i = l&15, q = l>>4) reads the float4 F[row i][k + 4q .. +3]; element j of that float4 is the
+// k-slot-q operand of MFMA step j, and W is read with the same (q, j) -> k map, so the sum over the 4
+// slots and the 4 steps covers 16 consecutive k exactly once. Two register sets are ping-ponged (next
+// 16 k in flight while the current 16 are multiplied); waves never synchronise, so load latency of one
+// wave hides behind the MFMAs of the others. The 4 waves of a block take 4 consecutive row tiles of the
+// SAME K range, so their W fragments hit in the CU's L1. Rows past M are clamped (valid reads, results
+// discarded); requires K % 32 == 0 and N in {64, 128}; partials go through splitk_reduce_kernel.
+// ======================================================================================
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+template <int NT>
+__global__ __launch_bounds__(kBlock) void gemm_fwd_direct_kernel(const float* __restrict__ F,
+                                                                 const float* __restrict__ W, int64_t M, int K,
+                                                                 int k_chunk, float* __restrict__ P) {
+  constexpr int N = NT * 16;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & 15, lq = lane >> 4;
+  const int64_t m0 = ((int64_t)blockIdx.x * 4 + wave) * 32;
+  if (m0 >= M) return;                                   // no barriers in this kernel
+  const int k_beg = blockIdx.y * k_chunk;
+  const int k_end = min(K, k_beg + k_chunk);
+  const float* ap[2];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) {
+    int64_t r = m0 + mt * 16 + li;
+    r = r < M ? r : M - 1;
+    ap[mt] = F + r * K + 4 * lq;
+  }
+  const float* bp = W + (int64_t)li * K + 4 * lq;        // n-tile nt adds nt*16*K
+  floatx4 acc[2][NT];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[mt][nt][r] = 0.f;
+  float4 a0[2], b0[NT], a1[2], b1[NT];
+  auto load = [&](float4 (&a)[2], float4 (&b)[NT], int k) {
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) a[mt] = *reinterpret_cast<const float4*>(ap[mt] + k);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) b[nt] = *reinterpret_cast<const float4*>(bp + (int64_t)nt * 16 * K + k);
+  };
+  auto mul = [&](const float4 (&a)[2], const float4 (&b)[NT]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          const float av = j == 0 ? a[mt].x : j == 1 ? a[mt].y : j == 2 ? a[mt].z : a[mt].w;
+          const float bv = j == 0 ? b[nt].x : j == 1 ? b[nt].y : j == 2 ? b[nt].z : b[nt].w;
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[mt][nt], 0, 0, 0);
+        }
+  };
+  load(a0, b0, k_beg);
+  int k = k_beg;
+  for (; k + 32 < k_end; k += 32) {      // steady state: no conditional loads, so the counted vmcnt waits
+    load(a1, b1, k + 16);                //  only ever wait for the set that is about to be multiplied
+    mul(a0, b0);
+    load(a0, b0, k + 32);
+    mul(a1, b1);
+  }
+  load(a1, b1, k + 16);                  // peeled last 32
+  mul(a0, b0);
+  mul(a1, b1);
+  // C/D layout of the 16x16 MFMA: col = lane & 15, row = (lane >> 4) * 4 + reg
+  float* Pp = P + (int64_t)blockIdx.y * M * N;
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int64_t row = m0 + mt * 16 + lq * 4 + r;
+      if (row < M) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) Pp[row * N + nt * 16 + li] = acc[mt][nt][r];
+      }
+    }
+}
+
 // out[e] = epilogue(sum_s P[s][e]);  e = row*J + col.  Split loads are issued four at a time
 // (independent) so the loop is bandwidth- not latency-bound; the add order is fixed.
 __global__ __launch_bounds__(kBlock) void splitk_reduce_kernel(const float* __restrict__ P, int splits,
@@ -380,6 +463,22 @@ inline int choose_splits_v2(int64_t tiles, int64_t KK) {
   return (int)s;
 }
 
+// v3: one wave per 32-row tile and K range; aim for ~4-5 waves per SIMD (4096+ waves), K ranges
+// multiples of 32 and at least 128 deep
+inline int direct_splits(int64_t M, int K) {
+  if (const char* e = getenv("MMSSL_GEMM_SPLITS")) {
+    const int f = atoi(e);
+    if (f >= 1) return f > K / 32 ? K / 32 : f;
+  }
+  const int64_t tiles = (M + 31) / 32;
+  int64_t s = (4608 + tiles - 1) / tiles;
+  const int64_t max_s = K / 128 > 0 ? K / 128 : 1;
+  if (s > max_s) s = max_s;
+  if (s < 1) s = 1;
+  return (int)s;
+}
+inline int direct_chunk(int K, int splits) { return (((K / 32) + splits - 1) / splits) * 32; }
+
 // split count: aim for >= ~4 blocks per CU, every split at least 4 slices deep
 inline int choose_splits(int64_t tiles, int64_t KK) {
   const int64_t slices = (KK + BK - 1) / BK;
@@ -404,7 +503,12 @@ extern "C" size_t mmssl_linear_workspace_bytes(int64_t M, int K, int N) {
   if (M <= 0 || K <= 0 || N <= 0) return 16;
   const bool v2 = gemm_version() == 2;
   const int64_t tiles = v2 ? ((M + 255) / 256) * ((N + 63) / 64) : ((M + BT - 1) / BT) * ((N + BT - 1) / BT);
-  const int splits = v2 ? choose_splits_v2(tiles, K) : choose_splits(tiles, K);
+  int splits = v2 ? choose_splits_v2(tiles, K) : choose_splits(tiles, K);
+  if (gemm_version() == 3 && (K % 32) == 0 && (N == 64 || N == 128)) {
+    const int s3 = direct_splits(M, K);
+    splits = s3 > splits ? s3 : splits;
+    if (splits < 2) splits = 2;            // v3 always goes through the partial buffer
+  }
   return splits > 1 ? (size_t)splits * (size_t)M * (size_t)N * sizeof(float) : 16;
 }
 
@@ -416,6 +520,26 @@ extern "C" int mmssl_linear_f32(const float* F, const float* W, const float* b, 
   if (M == 0) return 0;
   if (((uintptr_t)F | (uintptr_t)W | (uintptr_t)Y) & 15) return MMSSL_E_BADARG;
   hipStream_t s = as_stream(stream);
+  if (gemm_version() == 3 && (K % 32) == 0 && (N == 64 || N == 128)) {
+    const int sp = direct_splits(M, K);
+    const int kc = direct_chunk(K, sp);
+    const size_t need3 = (size_t)sp * (size_t)M * (size_t)N * sizeof(float);
+    if (!workspace || workspace_bytes < need3) return MMSSL_E_WORKSPACE;
+    float* P3 = reinterpret_cast<float*>(workspace);
+    const dim3 grid3((unsigned)((M + 127) / 128), (unsigned)sp);
+    if (N == 64)
+      hipLaunchKernelGGL((gemm_fwd_direct_kernel<4>), grid3, dim3(kBlock), 0, s, F, W, M, K, kc, P3);
+    else
+      hipLaunchKernelGGL((gemm_fwd_direct_kernel<8>), grid3, dim3(kBlock), 0, s, F, W, M, K, kc, P3);
+    MMSSL_LAUNCH_CHECK();
+    const int64_t total3 = M * N;
+    int64_t nb3 = (total3 / 4 + kBlock - 1) / kBlock;
+    nb3 = nb3 > 4096 ? 4096 : (nb3 < 1 ? 1 : nb3);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)nb3), dim3(kBlock), 0, s, P3, sp, total3, (int64_t)N, b,
+                       keep, scale, Y);
+    MMSSL_LAUNCH_CHECK();
+    return 0;
+  }
   if (gemm_version() == 2) {
     const int64_t tm2 = (M + 255) / 256, tn2 = (N + 63) / 64;
     const int sp = choose_splits_v2(tm2 * tn2, K);

@@ -288,7 +288,10 @@ def build_bench_step(a, rank, world, dev):
     from . import synth
     from .config import configure, HotCfg
     U, I, E, dv, dt = synth.SHAPES[a.workload]
-    U, I, E = U * world, I * world, E * world
+    if a.workload == "synth":          # the 100M-edge stress shape is defined for the WHOLE job, d=128
+        U, I, E, dv, dt = U // 8 * world, I // 8 * world, E // 8 * world, 128, 128
+    else:
+        U, I, E = U * world, I * world, E * world
     configure([], embed_size=a.d, weight_size=str([a.d] * a.gcn_layers), batch_size=a.batch, drop_rate=0.2)
     raw = synth.interaction_matrix(U, I, E, seed=1)
     ui, iu = synth.normalised_pair(raw)

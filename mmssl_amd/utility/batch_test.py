@@ -4,9 +4,9 @@ score = U_b . I^T in fp32 on the device, drop each user's training items, take t
 by score with ties broken towards the LOWER item id (heapq.nlargest over an ascending-id dict is
 a stable sort), then precision / recall / ndcg / hit_ratio @ Ks averaged over the tested users.
 
-The reference ranks with a multiprocessing.Pool + heapq per user on the host; here ranking is a
-vectorised stable argsort per user batch (same order, no process pool). Device top-K is the
-SURVEY.md section 8f "next #2" item.
+The reference ranks with a multiprocessing.Pool + heapq per user on the host (SURVEY.md section 8f
+"next #2"); here scoring, masking and a stable descending sort run on the device of the embeddings
+(same order, no process pool, no [users, items] device-to-host copy).
 """
 import numpy as np
 import torch
@@ -26,10 +26,6 @@ def init_data(path=None, batch_size=None):
     return data_generator
 
 
-def _hit_list(order, pos_mask_row, k_max):
-    return pos_mask_row[order[:k_max]].astype(np.int64).tolist()
-
-
 def get_performance(user_pos_test, r, auc, Ks):
     precision, recall, ndcg, hit_ratio = [], [], [], []
     for K in Ks:
@@ -41,8 +37,26 @@ def get_performance(user_pos_test, r, auc, Ks):
             "hit_ratio": np.array(hit_ratio), "auc": auc}
 
 
+def _batch_masks(data, user_batch, pos_of, device):
+    """(train_rows, train_cols, pos_rows, pos_cols) index tensors for one user batch."""
+    tr_r, tr_c, po_r, po_c = [], [], [], []
+    for k, u in enumerate(user_batch):
+        seen = data.train_items.get(u, [])
+        tr_r += [k] * len(seen)
+        tr_c += seen
+        pos = pos_of[u]
+        po_r += [k] * len(pos)
+        po_c += pos
+    mk = lambda x: torch.as_tensor(x, dtype=torch.int64, device=device)     # noqa: E731
+    return mk(tr_r), mk(tr_c), mk(po_r), mk(po_c)
+
+
 def test_torch(ua_embeddings, ia_embeddings, users_to_test, is_val, drop_flag=False, batch_test_flag=False,
                data=None):
+    """Scores, masking and ranking run on the embeddings' device: score = U_b . I^T (fp32), training
+    items set to -inf (never candidates), then a STABLE descending sort — equal scores keep ascending
+    item id, which is exactly the order heapq.nlargest gives the reference (batch_test.py:21-36).
+    Only the [users, max(Ks)] hit matrix travels to the host for the metric formulas."""
     data = data or data_generator
     if data is None:
         raise RuntimeError("batch_test.init_data() must be called (or pass data=...)")
@@ -54,22 +68,22 @@ def test_torch(ua_embeddings, ia_embeddings, users_to_test, is_val, drop_flag=Fa
     u_batch = config.args.batch_size * 2
     n_test_users = len(users_to_test)
     pos_of = data.val_set if is_val else data.test_set
+    dev = ua_embeddings.device
     count = 0
     for start in range(0, max(n_test_users, 1), u_batch):
         user_batch = users_to_test[start:start + u_batch]
         if not len(user_batch):
             continue
-        idx = torch.as_tensor(user_batch, dtype=torch.int64, device=ua_embeddings.device)
-        rate = torch.matmul(ua_embeddings[idx], ia_embeddings.t()).detach().cpu().numpy()
-        for row, u in zip(rate, user_batch):
-            row = row.copy()
-            seen = data.train_items.get(u, [])
-            row[np.asarray(seen, dtype=np.int64)] = -np.inf      # never candidates (batch_test.py:98-100)
-            order = np.argsort(-row, kind="stable")[:k_max]      # ties -> lower item id first
-            pos = pos_of[u]
-            posset = set(pos)
-            r = [1 if int(i) in posset else 0 for i in order]
-            re = get_performance(pos, r, 0.0, Ks)
+        idx = torch.as_tensor(user_batch, dtype=torch.int64, device=dev)
+        rate = torch.matmul(ua_embeddings[idx], ia_embeddings.t()).detach()
+        tr_r, tr_c, po_r, po_c = _batch_masks(data, user_batch, pos_of, dev)
+        rate[tr_r, tr_c] = float("-inf")                              # batch_test.py:98-100
+        order = torch.sort(rate, dim=1, descending=True, stable=True).indices[:, :k_max]
+        is_pos = torch.zeros((len(user_batch), n_items), dtype=torch.bool, device=dev)
+        is_pos[po_r, po_c] = True
+        hits = torch.gather(is_pos, 1, order).to(torch.int64).cpu().numpy()
+        for r, u in zip(hits, user_batch):
+            re = get_performance(pos_of[u], r.tolist(), 0.0, Ks)
             for key in ("precision", "recall", "ndcg", "hit_ratio"):
                 result[key] += re[key] / n_test_users
             result["auc"] += re["auc"] / n_test_users

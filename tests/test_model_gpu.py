@@ -244,3 +244,20 @@ def test_hotpath_graph_replay_with_stream_overlap_matches_eager_sequential():
     for a, b in zip(ov_l, ref_l):
         assert abs(a - b) <= 1e-5 * abs(b), (ov_l, ref_l)
     assert H.rel_err(ov_e, ref_e) < 1e-4 and H.rel_err(ov_w, ref_w) < 1e-4
+
+
+def test_eval_on_device_matches_reference_recall(tmp_path):
+    """G7 through the device path of test_torch (GPU scores + stable sort): Recall/NDCG/precision/hit@K
+    identical to the reference, including the exact-tie items."""
+    from mmssl_amd import config
+    from mmssl_amd.utility import batch_test
+    root = H.write_dataset_dir(str(tmp_path))
+    config.configure([], data_path=root, dataset="tiny", batch_size=48)
+    data = batch_test.init_data()
+    g = H.load("g7_eval.npz")
+    ua, ia = torch.from_numpy(g["ua"]).to(DEV), torch.from_numpy(g["ia"]).to(DEV)
+    for nm, is_val in (("val", True), ("test", False)):
+        users = [int(u) for u in g[nm + ".users"]]
+        res = batch_test.test_torch(ua, ia, users, is_val, data=data)
+        for k in ("precision", "recall", "ndcg", "hit_ratio"):
+            np.testing.assert_allclose(res[k], g["%s.%s" % (nm, k)], rtol=1e-12, atol=1e-15, err_msg=k)

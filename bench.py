@@ -224,6 +224,8 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph-probe", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--dist-graph", action="store_true",
+                    help="N>1: capture the sharded step (RCCL collectives included) into a hipGraph")
     ap.add_argument("--force-dist", action="store_true",
                     help="use the row-sharded code path even with one rank (exercises RCCL + dist.py on 1 GPU)")
     a = ap.parse_args()
@@ -261,7 +263,9 @@ def main():
     else:
         from mmssl_amd import dist as mdist
         step, raw, mats, plans, stats = mdist.build_bench_step(a, rank, world, dev)
-        captured = False
+        # hipGraph capture with RCCL collectives inside is opt-in (it cannot be probed in a child process
+        # under the multi-rank launcher, and a runtime abort would lose the whole measurement)
+        captured = bool(a.dist_graph) and step.capture()
         edge_layers_total = stats["edge_layers_global"]
         parallelism = "row-shard x%d (RCCL all-gather / reduce-scatter)" % world
 

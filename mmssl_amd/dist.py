@@ -41,6 +41,24 @@ class HipBackend:
         self.EPI_NONE, self.EPI_SOFTMAX = ops.EPI_NONE, ops.EPI_SOFTMAX
         for name in ("spmm", "l2norm_rows", "linear", "bpr", "infonce", "sumsq"):
             setattr(self, name, getattr(ops, name))
+        # non-autograd kernels for the fused sharded node (same helpers ops._HotForward uses)
+        self.spmm_raw = ops._spmm_raw
+        self.linear_raw = ops._linear_raw
+        self.linear_wgrad_raw = ops._linear_wgrad_raw
+        self.combine_bwd = ops._combine_bwd
+        self.softmax_rows_bwd = ops.softmax_rows_bwd
+
+    def combine_fwd(self, layers, inv, A, B, r):
+        """(out, ss) with ss = |A|^2 + |B|^2 over the local rows (0-dim tensor)."""
+        import torch as _t
+        from . import _lib
+        nb = _lib.lib().mmssl_layer_combine_blocks(A.shape[0], A.shape[1])
+        part = _t.empty(nb, dtype=_t.float32, device=A.device)
+        out = self.ops._combine_fwd(layers, inv, A, B, r, part)
+        ss = _t.empty((), dtype=_t.float32, device=A.device)
+        _lib.check(_lib.lib().mmssl_sum_partials_f32(part.data_ptr(), nb, ss.data_ptr(), _lib.stream_ptr()),
+                   "mmssl_sum_partials_f32")
+        return out, ss
 
 
 # ---------------------------------------------------------------------------------------------
@@ -128,6 +146,41 @@ class GatherBatchRows(torch.autograd.Function):
         return out, None, None, None
 
 
+class GatherBatchRowsMulti(torch.autograd.Function):
+    """Several (table, idx) row gathers with ONE all-reduce: the [B_k, d] pieces are packed into one
+    buffer (each row still has exactly one non-zero contributor, so the sum is exact)."""
+
+    @staticmethod
+    def forward(ctx, group, n, *args):
+        tables, idxs, los = args[:n], args[n:2 * n], args[2 * n:3 * n]
+        pieces, meta = [], []
+        for t, idx, lo in zip(tables, idxs, los):
+            per = t.shape[0]
+            mine = (idx >= lo) & (idx < lo + per)
+            local = (idx - lo).clamp(0, per - 1)
+            pieces.append(t[local] * mine.unsqueeze(1).to(t.dtype))
+            meta.append((local, mine, per))
+        packed = torch.cat(pieces, 0)
+        dist.all_reduce(packed, group=group)
+        ctx.meta = meta
+        sizes = [p.shape[0] for p in pieces]
+        ctx.sizes = sizes
+        return tuple(packed.split(sizes, 0))
+
+    @staticmethod
+    def backward(ctx, *gs):
+        outs = []
+        for g, (local, mine, per) in zip(gs, ctx.meta):
+            if g is None:
+                outs.append(None)
+                continue
+            o = torch.zeros((per, g.shape[1]), dtype=g.dtype, device=g.device)
+            o.index_add_(0, local, g * mine.unsqueeze(1).to(g.dtype))
+            outs.append(o)
+        n = len(ctx.meta)
+        return (None, None) + tuple(outs) + (None,) * (2 * n)
+
+
 # ---------------------------------------------------------------------------------------------
 # sharded model + step
 # ---------------------------------------------------------------------------------------------
@@ -149,6 +202,34 @@ class ShardedMMSSL(nn.Module):
         self.register_buffer("image_feats", ish.slice_rows(torch.as_tensor(image_feats)), persistent=False)
         self.register_buffer("text_feats", ish.slice_rows(torch.as_tensor(text_feats)), persistent=False)
 
+    def _forward_fused(self, graphs, keep_masks, modal_empty):
+        bk, c = self.bk, self.cfg
+        ui, iu, img_ui, img_iu, txt_ui, txt_iu = graphs
+        scale, km_i, km_t = 1.0, None, None
+        if self.training and c.drop_rate > 0:
+            scale = 1.0 / (1.0 - c.drop_rate)
+            if keep_masks is not None:
+                km_i, km_t = keep_masks
+            else:
+                shape = (self.ish.per, c.embed_size)
+                km_i = torch.empty(shape, dtype=torch.uint8, device=self.E_i.device).bernoulli_(1.0 - c.drop_rate)
+                km_t = torch.empty(shape, dtype=torch.uint8, device=self.E_i.device).bernoulli_(1.0 - c.drop_rate)
+        if modal_empty:
+            img_uid = txt_uid = torch.zeros_like(self.E_u)
+            img_iid = txt_iid = torch.zeros_like(self.E_i)
+            u, i = self.E_u + 0 * self.w_cat.sum(), self.E_i      # zero (not missing) gradient for w_cat
+        else:
+            Ei_full, Eu_full = self._gather(self.E_i), self._gather(self.E_u)
+            img_uid, img_iid = bk.spmm(img_ui, Ei_full), bk.spmm(img_iu, Eu_full)
+            txt_uid, txt_iid = bk.spmm(txt_ui, Ei_full), bk.spmm(txt_iu, Eu_full)
+            u = bk.l2norm_rows(self._fusion(img_uid, txt_uid), self.E_u, c.id_cat_rate)
+            i = bk.l2norm_rows(self._fusion(img_iid, txt_iid), self.E_i, c.id_cat_rate)
+        (u_g, i_g, ss, img_item, txt_item, img_user, txt_user) = _ShardedHotForward.apply(
+            self.image_feats, self.img_w, self.img_b, km_i, self.text_feats, self.txt_w, self.txt_b, km_t, scale,
+            u, i, ui, iu, c.n_ui_layers, c.model_cat_rate, bk, self.group)
+        self._feat_ss_local = ss
+        return (u_g, i_g, img_item, txt_item, img_user, txt_user, u_g, i_g, img_uid, txt_uid, img_iid, txt_iid)
+
     def replicated_parameters(self):
         return [self.img_w, self.img_b, self.txt_w, self.txt_b, self.w_cat]
 
@@ -160,9 +241,13 @@ class ShardedMMSSL(nn.Module):
         fold = self.w_cat.view(c.head_num, c.embed_size, c.embed_size).sum(0)
         return self.bk.linear(a + b, (0.5 * fold).t().contiguous())
 
-    def forward(self, graphs, keep_masks=None, modal_empty=False):
+    def forward(self, graphs, keep_masks=None, modal_empty=False, fused=True):
         """graphs = local (ui, iu, img_ui, img_iu, txt_ui, txt_iu). Returns the local rows of the
-        reference's 12 outputs (0/6 and 1/7 identical)."""
+        reference's 12 outputs (0/6 and 1/7 identical). `fused` selects the single-node
+        implementation (_ShardedHotForward); fused=False composes differentiable backend ops and
+        AllGatherRows (the same math, kept as the cross-check)."""
+        if fused:
+            return self._forward_fused(graphs, keep_masks, modal_empty)
         bk, c = self.bk, self.cfg
         ui, iu, img_ui, img_iu, txt_ui, txt_iu = graphs
         scale = 1.0
@@ -213,38 +298,138 @@ class ShardedMMSSL(nn.Module):
         return (u_g, i_g, img_item, txt_item, img_user, txt_user, u_g, i_g, img_uid, txt_uid, img_iid, txt_iid)
 
 
+
+def _all_gather_raw(x, group):
+    world = dist.get_world_size(group)
+    out = torch.empty((world * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+    dist.all_gather_into_tensor(out, x.contiguous(), group=group)
+    return out
+
+
+class _ShardedHotForward(torch.autograd.Function):
+    """Row-sharded counterpart of ops._HotForward: projection of the local item rows, modal SpMM
+    chains, G-layer GCN chain and the layer-mean / modality fusion, with an all-gather of the row
+    shards before every A_r . X and — in the hand-written backward — a reduce-scatter of every
+    A_r^T . gY_r. One autograd node, ~45 kernels + 2(4+2G) collectives per step instead of a few
+    hundred autograd-composed launches."""
+
+    @staticmethod
+    def forward(ctx, F_img, W_img, b_img, keep_img, F_txt, W_txt, b_txt, keep_txt, scale, u0, i0, ui, iu,
+                n_layers, r, bk, group):
+        g = group
+        x_img = bk.linear_raw(F_img, W_img, b_img, keep_img, scale)
+        x_txt = bk.linear_raw(F_txt, W_txt, b_txt, keep_txt, scale)
+        img_user = bk.spmm_raw(ui, False, _all_gather_raw(x_img, g), bk.EPI_NONE)
+        txt_user = bk.spmm_raw(ui, False, _all_gather_raw(x_txt, g), bk.EPI_NONE)
+        img_item = bk.spmm_raw(iu, False, _all_gather_raw(img_user, g), bk.EPI_NONE)
+        txt_item = bk.spmm_raw(iu, False, _all_gather_raw(txt_user, g), bk.EPI_NONE)
+        us, its = [u0], [i0]
+        u, i = u0, i0
+        for l in range(n_layers):
+            epi = bk.EPI_SOFTMAX if l == n_layers - 1 else bk.EPI_NONE
+            u = bk.spmm_raw(ui, False, _all_gather_raw(i, g), epi)
+            i = bk.spmm_raw(iu, False, _all_gather_raw(u, g), epi)
+            us.append(u)
+            its.append(i)
+        inv = 1.0 / (n_layers + 1)
+        u_g, ss_u = bk.combine_fwd(us, inv, img_user, txt_user, r)
+        i_g, ss_i = bk.combine_fwd(its, inv, img_item, txt_item, r)
+        ctx.save_for_backward(F_img, W_img, keep_img, F_txt, W_txt, keep_txt, img_user, txt_user, img_item, txt_item,
+                              us[-1], its[-1])
+        ctx.cfg = (ui, iu, n_layers, float(r), inv, float(scale), bk, g, b_img is not None, b_txt is not None)
+        ctx.set_materialize_grads(False)
+        return u_g, i_g, ss_u + ss_i, img_item, txt_item, img_user, txt_user
+
+    @staticmethod
+    def backward(ctx, Gu, Gi, g_ss, G_img_item, G_txt_item, G_img_user, G_txt_user):
+        (F_img, W_img, keep_img, F_txt, W_txt, keep_txt, img_user, txt_user, img_item, txt_item, uG,
+         iG) = ctx.saved_tensors
+        ui, iu, n_layers, r, inv, scale, bk, g, has_bi, has_bt = ctx.cfg
+        per_u, per_i = img_user.shape[0], img_item.shape[0]
+        Gu = Gu.contiguous() if Gu is not None else torch.zeros_like(img_user)
+        Gi = Gi.contiguous() if Gi is not None else torch.zeros_like(img_item)
+        g_ss = g_ss.contiguous().to(torch.float32) if g_ss is not None else None
+        g_iu_, g_tu_, g_u0 = bk.combine_bwd(img_user, txt_user, Gu, r, inv, g_ss, 2.0, True)
+        g_ii_, g_ti_, _ = bk.combine_bwd(img_item, txt_item, Gi, r, inv, g_ss, 2.0, False)
+        if G_img_item is not None:
+            g_ii_ = g_ii_ + G_img_item
+        if G_txt_item is not None:
+            g_ti_ = g_ti_ + G_txt_item
+        if G_img_user is not None:
+            g_iu_ = g_iu_ + G_img_user
+        if G_txt_user is not None:
+            g_tu_ = g_tu_ + G_txt_user
+
+        def t_users(g_items):      # A_iu_r^T . g (full user range) -> my user rows
+            return _reduce_scatter_sum(bk.spmm_raw(iu, True, g_items, bk.EPI_NONE), per_u, g)
+
+        def t_items(g_users):      # A_ui_r^T . g (full item range) -> my item rows
+            return _reduce_scatter_sum(bk.spmm_raw(ui, True, g_users, bk.EPI_NONE), per_i, g)
+        g_x_img = t_items(t_users(g_ii_) + g_iu_)
+        g_x_txt = t_items(t_users(g_ti_) + g_tu_)
+        _, gW_img, gb_img = bk.linear_wgrad_raw(g_x_img, keep_img, scale, F_img, W_img)
+        _, gW_txt, gb_txt = bk.linear_wgrad_raw(g_x_txt, keep_txt, scale, F_txt, W_txt)
+        gi = bk.softmax_rows_bwd(iG, Gi, inv)
+        gu = bk.softmax_rows_bwd(uG, t_users(gi) + inv * Gu, 1.0)
+        gi = t_items(gu) + inv * Gi
+        for _ in range(n_layers - 1):
+            gu = t_users(gi) + inv * Gu
+            gi = t_items(gu) + inv * Gi
+        return (None, gW_img, gb_img if has_bi else None, None, None, gW_txt, gb_txt if has_bt else None, None, None,
+                g_u0, gi, None, None, None, None, None, None)
+
+
 class ShardedHotPathStep:
     """forward -> BPR + 2x InfoNCE + feat-reg -> backward -> bucketed all-reduce of the replicated
     gradients -> AdamW, over row shards (the N-rank counterpart of hotpath.HotPathStep)."""
 
     def __init__(self, model, graphs, batch_size, n_items, group=None, lr=5.5e-4, modal_empty=False,
-                 optimizer=True):
+                 optimizer=True, fused=True):
+        self.fused = fused
         self.model, self.graphs, self.group = model, tuple(graphs), group
         self.batch_size, self.n_items, self.modal_empty = int(batch_size), int(n_items), modal_empty
         dev = model.E_u.device
         self.users = torch.zeros(batch_size, dtype=torch.int64, device=dev)
         self.pos = torch.zeros(batch_size, dtype=torch.int64, device=dev)
         self.neg = torch.zeros(batch_size, dtype=torch.int64, device=dev)
-        self.optimizer = torch.optim.AdamW(model.parameters(), lr=lr) if optimizer else None
+        on_gpu = dev.type == "cuda"
+        self.optimizer = (torch.optim.AdamW(model.parameters(), lr=lr, capturable=on_gpu, fused=on_gpu)
+                          if optimizer else None)
         self.loss = torch.zeros((), device=dev)
+        self._graph = None
+        self.stream = torch.cuda.Stream(device=dev) if on_gpu else None
+        if on_gpu:
+            self.stream.wait_stream(torch.cuda.current_stream(dev))
+
+    def _ctx(self):
+        import contextlib
+        return torch.cuda.stream(self.stream) if self.stream is not None else contextlib.nullcontext()
 
     def set_batch(self, users, pos, neg):
-        self.users.copy_(users)
-        self.pos.copy_(pos)
-        self.neg.copy_(neg)
+        with self._ctx():
+            self.users.copy_(users)
+            self.pos.copy_(pos)
+            self.neg.copy_(neg)
 
     def losses(self, keep_masks=None):
         m, bk, c, g = self.model, self.model.bk, self.model.cfg, self.group
-        o = m(self.graphs, keep_masks=keep_masks, modal_empty=self.modal_empty)
-        rows = lambda t, idx, sh: GatherBatchRows.apply(t, idx, sh.lo, g)     # noqa: E731
-        u = rows(o[0], self.users, m.ush)
-        p = rows(o[1], self.pos, m.ish)
-        n = rows(o[1], self.neg, m.ish)
+        o = m(self.graphs, keep_masks=keep_masks, modal_empty=self.modal_empty, fused=self.fused)
+        if self.modal_empty:       # the id views are exact zeros: nothing to gather for them
+            u, p, n = GatherBatchRowsMulti.apply(g, 3, o[0], o[1], o[1], self.users, self.pos, self.neg,
+                                                 m.ush.lo, m.ish.lo, m.ish.lo)
+            z_img = z_txt = torch.zeros_like(u)
+        else:
+            u, p, n, z_img, z_txt = GatherBatchRowsMulti.apply(
+                g, 5, o[0], o[1], o[1], o[8], o[9], self.users, self.pos, self.neg, self.users, self.users,
+                m.ush.lo, m.ish.lo, m.ish.lo, m.ush.lo, m.ush.lo)
         mf, emb = bk.bpr(u, p, n, c.decay, self.batch_size)
-        feat_local = c.feat_reg_decay * ((0.5 * bk.sumsq(o[2]) + 0.5 * bk.sumsq(o[3]) + 0.5 * bk.sumsq(o[4])
-                                          + 0.5 * bk.sumsq(o[5])) / self.n_items)
-        cl1 = bk.infonce(rows(o[8], self.users, m.ush), u, c.tau)
-        cl2 = bk.infonce(rows(o[9], self.users, m.ush), u, c.tau)
+        if self.fused:
+            feat_local = (c.feat_reg_decay * 0.5 / self.n_items) * m._feat_ss_local
+        else:
+            feat_local = c.feat_reg_decay * ((0.5 * bk.sumsq(o[2]) + 0.5 * bk.sumsq(o[3]) + 0.5 * bk.sumsq(o[4])
+                                              + 0.5 * bk.sumsq(o[5])) / self.n_items)
+        cl1 = bk.infonce(z_img, u, c.tau)
+        cl2 = bk.infonce(z_txt, u, c.tau)
         replicated = mf + emb + c.cl_rate * (cl1 + cl2)
         return replicated, feat_local
 
@@ -269,14 +454,41 @@ class ShardedHotPathStep:
         self.loss.copy_(total)
         return total
 
-    def step(self):
+    def _step(self):
         total = self.backward()
         if self.optimizer is not None:
             self.optimizer.step()
         return total
 
+    def step(self):
+        with self._ctx():
+            return self._step()
+
+    def capture(self, warmup=3):
+        """OPT-IN: capture the whole sharded step, RCCL collectives included, into a hipGraph (all on
+        this object's stream). Returns False and stays eager if the runtime refuses."""
+        try:
+            with torch.cuda.stream(self.stream):
+                for _ in range(warmup):
+                    self._step()
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=self.stream):
+                self._step()
+            torch.cuda.synchronize()
+            self._graph = g
+            return True
+        except Exception as e:       # pragma: no cover
+            self._graph, self.capture_error = None, repr(e)
+            torch.cuda.synchronize()
+            return False
+
     def run(self):
-        self.step()
+        with self._ctx():
+            if self._graph is not None:
+                self._graph.replay()
+            else:
+                self._step()
 
 
 # ---------------------------------------------------------------------------------------------
@@ -339,6 +551,8 @@ def build_bench_step(a, rank, world, dev):
     ops.STATS["enabled"] = False
     stats = dict(ops.STATS)
     t = torch.tensor([stats["edge_layers"]], dtype=torch.int64, device=dev)
-    dist.all_reduce(t)
+    with torch.cuda.stream(step.stream):
+        dist.all_reduce(t)
+    torch.cuda.synchronize()
     stats["edge_layers_global"] = int(t.item())
     return step, raw, (ui_l, iu_l), plans, stats

@@ -47,3 +47,52 @@ class OracleBackend:
     @staticmethod
     def sumsq(x):
         return (x ** 2).sum()
+
+    # ---- non-autograd ("raw") ops used by the fused sharded node ------------------------------------
+    @staticmethod
+    def spmm_raw(plan, transpose, X, epilogue, Z=None, alpha=0.0, S=None):
+        with torch.no_grad():
+            Y = O.spmm(plan.AT if transpose else plan.A, X)
+            if epilogue == 1:
+                Y = torch.softmax(Y, -1)
+            elif epilogue in (2, 3):
+                Y = Y + alpha * Z
+                if epilogue == 3:
+                    Y = S * (Y - (Y * S).sum(1, keepdim=True))
+            return Y
+
+    @staticmethod
+    def linear_raw(F_, W, b, keep, scale):
+        with torch.no_grad():
+            return OracleBackend.linear(F_, W, b, keep, scale)
+
+    @staticmethod
+    def linear_wgrad_raw(gY, keep, scale, F_, W):
+        with torch.no_grad():
+            if keep is not None:
+                gY = gY * keep.to(gY.dtype) * scale
+            return gY, gY.t() @ F_, gY.sum(0)
+
+    @staticmethod
+    def combine_fwd(layers, inv, A, B, r):
+        with torch.no_grad():
+            out = inv * torch.stack(list(layers)).sum(0) + r * F.normalize(A) + r * F.normalize(B)
+            return out, (A ** 2).sum() + (B ** 2).sum()
+
+    @staticmethod
+    def combine_bwd(A, B, G, r, inv, c_dev, c_scale, want_gL):
+        outs = []
+        for X in (A, B):
+            with torch.enable_grad():          # we are inside a custom Function's backward
+                x = X.detach().clone().requires_grad_(True)
+                y = r * F.normalize(x)
+                (gx,) = torch.autograd.grad(y, x, G)
+            if c_dev is not None:
+                gx = gx + (c_scale * float(c_dev)) * X
+            outs.append(gx)
+        return outs[0], outs[1], (inv * G if want_gL else None)
+
+    @staticmethod
+    def softmax_rows_bwd(Y, gY, scale=1.0):
+        with torch.no_grad():
+            return scale * Y * (gY - (gY * Y).sum(1, keepdim=True))

@@ -37,7 +37,7 @@ def _global_problem(modal):
     return fx, d, raw, U, I, state, users, pos, neg, img_raw, txt_raw
 
 
-def _worker(rank, world, port, modal, out_dir):
+def _worker(rank, world, port, modal, out_dir, fused=True):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -58,7 +58,7 @@ def _worker(rank, world, port, modal, out_dir):
     c, e = local_pair(txt_raw)
     model = md.ShardedMMSSL(bk, cfg, ush, ish, state, d["image_feat"], d["text_feat"]).train()
     step = md.ShardedHotPathStep(model, (ui, iu, a, b, c, e), 48, I, modal_empty=(modal == "empty_shortcut"),
-                                 optimizer=False)
+                                 optimizer=False, fused=fused)
     step.set_batch(users, pos, neg)
     total = step.backward()
     torch.save({"loss": float(total), "ush": (ush.lo, ush.hi, ush.n), "ish": (ish.lo, ish.hi, ish.n),
@@ -86,10 +86,11 @@ def _reference(modal):
     return float(loss), P
 
 
-@pytest.mark.parametrize("world,modal", [(2, "full"), (3, "full"), (2, "empty"), (2, "empty_shortcut")])
-def test_sharded_step_equals_single_process(tmp_path, world, modal):
+@pytest.mark.parametrize("world,modal,fused", [(2, "full", True), (3, "full", True), (2, "empty", True),
+                                               (2, "empty_shortcut", True), (2, "full", False), (3, "full", False)])
+def test_sharded_step_equals_single_process(tmp_path, world, modal, fused):
     port = _free_port()
-    mp.spawn(_worker, args=(world, port, modal, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, modal, str(tmp_path), fused), nprocs=world, join=True)
     ref_loss, P = _reference(modal)
     outs = [torch.load(os.path.join(str(tmp_path), "r%d.pt" % r)) for r in range(world)]
     for o in outs:

@@ -92,15 +92,15 @@ def count_edge_layers(step):
     return dict(ops.STATS)
 
 
-def spmm_roofline(plans, mats, d, iters=200):
+def spmm_roofline(plans, mats, d, iters=200, traffic=True):
     """Average duration of the dominant kernel (the CSR SpMM, all four launch flavours of the
     step: A_ui, A_iu and their transposes) from HIP events on the launch stream, against the
     algorithmic bytes per launch (nnz*(8+4d) + rows*4d + (rows+1)*4)."""
     from mmssl_amd import ops, synth
     dev = "cuda"
     ui, iu = mats
-    X = {ui.shape[1]: torch.randn(ui.shape[1], d, device=dev), ui.shape[0]: torch.randn(ui.shape[0], d, device=dev)}
     launches = [(plans[0], False, ui), (plans[1], False, iu), (plans[0], True, ui.T.tocsr()), (plans[1], True, iu.T.tocsr())]
+    X = {r: torch.randn(r, d, device=dev) for r in {m.shape[1] for _, _, m in launches}}
     nbytes = [synth.spmm_bytes(m, d) for _, _, m in launches]
     with torch.no_grad():
         def one_round():
@@ -131,7 +131,7 @@ def spmm_roofline(plans, mats, d, iters=200):
     return {"bound": "hbm", "kernel": "spmm_kernel<16> (CSR SpMM d=%d)" % d, "achieved": round(achieved, 1),
             "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
             "avg_launch_us": round(avg_us, 2), "algorithmic_bytes_per_launch": int(avg_bytes),
-            "traffic": load_traffic()}
+            "traffic": load_traffic() if traffic else None}
 
 
 def load_traffic():
@@ -224,8 +224,10 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph-probe", action="store_true", help=argparse.SUPPRESS)
-    ap.add_argument("--dist-graph", action="store_true",
-                    help="N>1: capture the sharded step (RCCL collectives included) into a hipGraph")
+    ap.add_argument("--dist-graph", choices=["auto", "on", "off"], default="auto", nargs="?", const="on",
+                    help="sharded path: capture the step (RCCL collectives included) into a hipGraph. auto = "
+                         "only if a small-shape capture+replay succeeds on every rank in child processes")
+    ap.add_argument("--dist-graph-probe", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--force-dist", action="store_true",
                     help="use the row-sharded code path even with one rank (exercises RCCL + dist.py on 1 GPU)")
     a = ap.parse_args()
@@ -244,6 +246,8 @@ def main():
         if world == 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29533")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
             dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
         else:
             dist.init_process_group("nccl", device_id=dev)
@@ -262,10 +266,30 @@ def main():
         parallelism = "single"
     else:
         from mmssl_amd import dist as mdist
+        if a.dist_graph_probe:       # child of one rank: sharded capture + replay on a small shape
+            step, _, _, _, _ = mdist.build_bench_step(a, rank, world, dev)
+            ok = step.capture()
+            if ok:
+                for _ in range(3):
+                    step.run()
+                torch.cuda.synchronize()
+                ok = bool(torch.isfinite(step.loss).item())
+            dist.barrier()
+            dist.destroy_process_group()
+            sys.exit(0 if ok else 3)
+        want = a.dist_graph != "off" and not a.no_graph
+        if want and a.dist_graph == "auto":
+            # A failed capture with RCCL inside can abort or hang the process: try it first in one child
+            # per rank (own rendezvous on MASTER_PORT+1), then agree on the outcome across ranks.
+            cmd = [sys.executable, os.path.abspath(__file__), "--dist-graph-probe", "--gpus", str(a.gpus),
+                   "--workload", "tiktok", "--d", str(a.d), "--gcn-layers", str(a.gcn_layers), "--batch", str(a.batch)]
+            if a.force_dist:
+                cmd.append("--force-dist")
+            flag = torch.tensor([1 if mdist.spawn_rank_probe(cmd) else 0], device=dev, dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            want = bool(flag.item())
         step, raw, mats, plans, stats = mdist.build_bench_step(a, rank, world, dev)
-        # hipGraph capture with RCCL collectives inside is opt-in (it cannot be probed in a child process
-        # under the multi-rank launcher, and a runtime abort would lose the whole measurement)
-        captured = bool(a.dist_graph) and step.capture()
+        captured = want and step.capture()
         edge_layers_total = stats["edge_layers_global"]
         parallelism = "row-shard x%d (RCCL all-gather / reduce-scatter)" % world
 
@@ -314,6 +338,8 @@ def main():
             out["roofline"] = spmm_roofline(plans, mats, a.d)
             if not a.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline(a, raw, mats)
+        else:
+            out["roofline"] = spmm_roofline(plans, mats, a.d, traffic=False)   # rank 0's shard
         print(json.dumps(out))
     if sharded:
         dist.barrier()

@@ -23,6 +23,8 @@ The compute kernels are reached through a small backend object so that the shard
 be exercised on CPU with `gloo` (tests/test_dist_cpu.py plugs the oracle in); the product
 backend is `HipBackend` (libmmssl_hip.so) and there is no CPU fallback in this package.
 """
+import os
+
 import numpy as np
 import scipy.sparse as sp
 import torch
@@ -494,6 +496,25 @@ class ShardedHotPathStep:
 # ---------------------------------------------------------------------------------------------
 # bench.py helper (N > 1)
 # ---------------------------------------------------------------------------------------------
+def spawn_rank_probe(argv, port_offset=1, timeout=180):
+    """Run `argv` as a child of THIS rank with the launcher's RANK/LOCAL_RANK/WORLD_SIZE but a private
+    rendezvous (MASTER_PORT + port_offset, hosted by the rank-0 child instead of the launcher's agent
+    store), so that all ranks' children form their own process group. Used to try something that can
+    abort or hang a process (hipGraph capture with RCCL collectives inside) without losing the parent.
+    Returns True iff this rank's child exited 0 within `timeout` seconds; callers must still agree on
+    the answer across ranks (all-reduce MIN)."""
+    import subprocess
+    env = dict(os.environ)
+    env["MASTER_PORT"] = str(int(env.get("MASTER_PORT", "29500")) + port_offset)
+    env.setdefault("MASTER_ADDR", "127.0.0.1")
+    env.pop("TORCHELASTIC_USE_AGENT_STORE", None)
+    try:
+        r = subprocess.run(argv, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout)
+        return r.returncode == 0
+    except Exception:
+        return False
+
+
 def build_bench_step(a, rank, world, dev):
     """Weak-scaled bench workload: the `a.workload` shape x world, seeded identically on every
     rank; each rank keeps its row blocks only. Returns (step, raw_global, mats_local, plans, stats)."""

@@ -132,3 +132,21 @@ def test_row_shard_and_graph_slicing():
     assert np.array_equal(full[:10, :7], m.toarray()) and not full[10:].any() and not full[:, 7:].any()
     t = torch.arange(20.).view(10, 2)
     assert torch.equal(md.RowShard(10, 3, 2).slice_rows(t), torch.cat([t[8:], torch.zeros(2, 2)]))
+
+
+@pytest.mark.parametrize("mode", ["ok", "fail"])
+def test_spawn_rank_probe(mode):
+    """bench.py decides on hipGraph capture for N>1 from per-rank child processes that form their own
+    process group (dist.spawn_rank_probe). Checked here under the real launcher with gloo."""
+    import subprocess
+    import sys
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port),
+                        os.path.join(here, "_probe_parent.py"), "parent", mode],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]

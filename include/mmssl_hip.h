@@ -160,6 +160,25 @@ int mmssl_linear_wgrad_f32(const float* gY, const uint8_t* keep, float scale, co
 /* out = g * keep * scale over n (multiple of 4) elements: the dropout backward as one pass. */
 int mmssl_mask_scale_f32(const float* g, const uint8_t* keep, float scale, int64_t n, float* out,
                          void* stream);
+/* Dropout keep-mask (nn.Dropout(p), Models.py:54): keep[i] = 1 with probability 1-p, from
+ * Philox4x32-10 keyed by rng_state[0] (seed) and counted by (i/4, rng_state[1]); the launch advances
+ * rng_state[1] itself, so hipGraph replays draw fresh masks. rng_state: 3 x uint64 in device memory
+ * {seed, launch counter, 0}; n multiple of 4. The stream of masks is this library's own (the
+ * reference's depends on torch's CUDA generator and is not reproducible across devices either). */
+int mmssl_dropout_mask_u8(uint64_t* rng_state, float p, int64_t n, uint8_t* keep, void* stream);
+
+/* AdamW update of up to MMSSL_ADAMW_MAX_TENSORS fp32 tensors in ONE launch — torch.optim.AdamW as
+ * built at main.py:76-80 (amsgrad=False, maximize=False):
+ *   p *= 1 - lr*wd; m += (g-m)(1-b1); v = v*b2 + (1-b2) g*g;
+ *   p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps),   t = state[0] + 1
+ * params/grads/exp_avg/exp_avg_sq/numel are HOST arrays of `count` device pointers / sizes (16-B
+ * aligned); state = 2 floats in device memory {completed steps, 0}: the launch increments
+ * state[0] itself (graph-replay safe). */
+#define MMSSL_ADAMW_MAX_TENSORS 24
+int mmssl_adamw_f32(float* const* params, const float* const* grads, float* const* exp_avg,
+                    float* const* exp_avg_sq, const int64_t* numel, int count, float* state, float lr,
+                    float beta1, float beta2, float eps, float weight_decay, void* stream);
+
 /* total[0] = sum_k w[k] * terms[k] (k < n <= 16) + c * extra[0]: the scalar loss assembly of
  * main.py:420 in one launch (terms / w / extra are device arrays; extra may be NULL). */
 int mmssl_loss_assemble_f32(const float* terms, const float* w, int n, const float* extra, float c,

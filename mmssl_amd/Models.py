@@ -10,6 +10,8 @@ A reference `state_dict` loads unchanged (same keys incl. the aliased encoder.* 
 entries and the unused image_embedding / text_embedding / batch_norm parameters). Graph
 arguments may be the reference's torch sparse COO tensors or `GraphPlan`s.
 """
+import os as _os
+
 import torch
 import torch.nn as nn
 
@@ -141,8 +143,8 @@ class MMSSL(nn.Module):
     def forward(self, ui_graph, iu_graph, image_ui_graph, image_iu_graph, text_ui_graph, text_iu_graph,
                 keep_masks=None):
         """Returns the 12-tuple of Models.py:220. `keep_masks=(img, txt)` injects uint8 dropout
-        keep-masks [n_items, d] (parity runs); by default masks are drawn with torch's RNG in
-        training mode, like nn.Dropout."""
+        keep-masks [n_items, d] (parity runs); by default both masks are drawn by one Philox launch
+        (ops.dropout_masks; seed with ops.seed_dropout / main.set_seed) in training mode."""
         ui, iu = _plan_of(ui_graph), _plan_of(iu_graph)
         img_ui, img_iu = _plan_of(image_ui_graph), _plan_of(image_iu_graph)
         txt_ui, txt_iu = _plan_of(text_ui_graph), _plan_of(text_iu_graph)
@@ -154,10 +156,14 @@ class MMSSL(nn.Module):
             if keep_masks is not None:
                 km_img, km_txt = keep_masks
             else:
-                shape = (self.n_items, args.embed_size)
-                dev = self.image_trans.weight.device
-                km_img = torch.empty(shape, dtype=torch.uint8, device=dev).bernoulli_(1.0 - p)   # 1 = keep
-                km_txt = torch.empty(shape, dtype=torch.uint8, device=dev).bernoulli_(1.0 - p)
+                if _os.environ.get("MMSSL_TORCH_MASKS") == "1":      # A/B switch for profiling only
+                    shape = (self.n_items, args.embed_size)
+                    dev = self.image_trans.weight.device
+                    km_img = torch.empty(shape, dtype=torch.uint8, device=dev).bernoulli_(1.0 - p)
+                    km_txt = torch.empty(shape, dtype=torch.uint8, device=dev).bernoulli_(1.0 - p)
+                else:
+                    km_img, km_txt = ops.dropout_masks(2, self.n_items, args.embed_size, p,
+                                                       self.image_trans.weight.device)          # 1 = keep
         E_u, E_i = self.user_id_embedding.weight, self.item_id_embedding.weight
         # the reference repeats this block args.layers times without feeding anything back
         # (Models.py:176-186): the result is that of one pass.

@@ -49,6 +49,7 @@ class HipBackend:
         self.linear_wgrad_raw = ops._linear_wgrad_raw
         self.combine_bwd = ops._combine_bwd
         self.softmax_rows_bwd = ops.softmax_rows_bwd
+        self.dropout_masks = ops.dropout_masks
 
     def combine_fwd(self, layers, inv, A, B, r):
         """(out, ss) with ss = |A|^2 + |B|^2 over the local rows (0-dim tensor)."""
@@ -213,9 +214,7 @@ class ShardedMMSSL(nn.Module):
             if keep_masks is not None:
                 km_i, km_t = keep_masks
             else:
-                shape = (self.ish.per, c.embed_size)
-                km_i = torch.empty(shape, dtype=torch.uint8, device=self.E_i.device).bernoulli_(1.0 - c.drop_rate)
-                km_t = torch.empty(shape, dtype=torch.uint8, device=self.E_i.device).bernoulli_(1.0 - c.drop_rate)
+                km_i, km_t = bk.dropout_masks(2, self.ish.per, c.embed_size, c.drop_rate, self.E_i.device)
         if modal_empty:
             img_uid = txt_uid = torch.zeros_like(self.E_u)
             img_iid = txt_iid = torch.zeros_like(self.E_i)
@@ -395,8 +394,13 @@ class ShardedHotPathStep:
         self.pos = torch.zeros(batch_size, dtype=torch.int64, device=dev)
         self.neg = torch.zeros(batch_size, dtype=torch.int64, device=dev)
         on_gpu = dev.type == "cuda"
-        self.optimizer = (torch.optim.AdamW(model.parameters(), lr=lr, capturable=on_gpu, fused=on_gpu)
-                          if optimizer else None)
+        if not optimizer:
+            self.optimizer = None
+        elif on_gpu:
+            from .optim import FusedAdamW
+            self.optimizer = FusedAdamW(model.parameters(), lr=lr)
+        else:
+            self.optimizer = torch.optim.AdamW(model.parameters(), lr=lr)
         self.loss = torch.zeros((), device=dev)
         self._graph = None
         self.stream = torch.cuda.Stream(device=dev) if on_gpu else None
@@ -536,6 +540,8 @@ def build_bench_step(a, rank, world, dev):
         e_ui = bk.make_graph(sp.csr_matrix((ush.per, ish.n_pad), dtype=np.float32))
         e_iu = bk.make_graph(sp.csr_matrix((ish.per, ush.n_pad), dtype=np.float32))
     cfg = HotCfg()
+    from . import ops as _ops
+    _ops.seed_dropout(2022 + rank, dev)            # independent masks per row shard
     g = torch.Generator().manual_seed(2022)
 
     def xavier(rows, cols):

@@ -10,6 +10,7 @@ the host launch gaps that dominate at these problem sizes (a Baby-shape SpMM is 
 import torch
 
 from . import ops
+from .optim import FusedAdamW
 from .config import args
 
 
@@ -24,11 +25,15 @@ class HotPathStep:
         self.users, self.pos, self.neg = self.batch[0], self.batch[1], self.batch[2]
         # loss assembly weights for [mf, emb, reg, cl_img, cl_txt] (main.py:420 without the GAN term)
         self.loss_w = torch.tensor([1.0, 1.0, 1.0, args.cl_rate, args.cl_rate], dtype=torch.float32, device=dev)
-        # same update rule as the reference's optim.AdamW (main.py:76-80); `fused` = one kernel
-        # for all parameters instead of ~16 foreach launches, `capturable` keeps the step counter
-        # on the device so the step can live inside a hipGraph.
-        self.optimizer = torch.optim.AdamW([{"params": model.parameters()}], lr=lr or args.lr,
-                                           capturable=capturable, fused=True)
+        # same update rule as the reference's optim.AdamW (main.py:76-80) as ONE launch over all tensors
+        # with a gradient; the step counter lives on the device so the step can be replayed in a hipGraph.
+        # (`capturable` is kept for signature compatibility: the kernel always is.)
+        import os
+        if os.environ.get("MMSSL_TORCH_ADAMW") == "1":         # A/B switch for profiling only
+            self.optimizer = torch.optim.AdamW([{"params": model.parameters()}], lr=lr or args.lr,
+                                               capturable=True, fused=True)
+        else:
+            self.optimizer = FusedAdamW([{"params": model.parameters()}], lr=lr or args.lr)
         self.loss = torch.zeros((), device=dev)
         self.parts = {}
         self._graph = None

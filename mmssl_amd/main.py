@@ -43,6 +43,7 @@ def set_seed(seed):
     random.seed(seed)
     torch.manual_seed(seed)
     torch.cuda.manual_seed_all(seed)
+    ops.seed_dropout(seed)                 # the dropout keep-mask generator of libmmssl_hip (Models.py:54)
 
 
 class Trainer(object):

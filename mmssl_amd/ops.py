@@ -167,6 +167,45 @@ def _linear_raw(F_, W, b, keep, scale):
     return Y
 
 
+# Dropout keep-masks: one Philox launch for any number of equally shaped masks (nn.Dropout, Models.py:54).
+_RNG_STATE = {}
+
+
+def _rng_state(device):
+    key = (device.type, device.index)
+    st = _RNG_STATE.get(key)
+    if st is None:
+        st = torch.tensor([torch.initial_seed() & 0x7FFFFFFFFFFFFFFF, 0, 0], dtype=torch.int64, device=device)
+        _RNG_STATE[key] = st
+    return st
+
+
+def seed_dropout(seed, device=None):
+    """Reset the mask generator (all devices seen so far, or `device`): masks are a pure function of
+    (seed, number of launches since the reset). Unseeded, the state starts from torch.initial_seed()."""
+    val = torch.tensor([int(seed) & 0x7FFFFFFFFFFFFFFF, 0, 0], dtype=torch.int64)
+    if device is not None:
+        device = torch.device(device)
+        _RNG_STATE[(device.type, device.index)] = val.to(device)
+        return
+    for key in list(_RNG_STATE):
+        _RNG_STATE[key].copy_(val)
+
+
+def dropout_masks(count, rows, cols, p, device):
+    """uint8 [count, rows, cols], 1 = keep with probability 1-p; the generator state lives on the device and
+    advances by itself, so a captured step draws fresh masks on every replay."""
+    device = torch.device(device)
+    if device.type != "cuda":
+        raise _lib.MmsslError("dropout_masks: needs a CUDA (HIP) device")
+    n = count * rows * cols
+    pad = (-n) % 4
+    buf = torch.empty(n + pad, dtype=torch.uint8, device=device)
+    rc = _lib.lib().mmssl_dropout_mask_u8(_ptr(_rng_state(device)), float(p), n + pad, _ptr(buf), _lib.stream_ptr())
+    _lib.check(rc, "mmssl_dropout_mask_u8")
+    return buf[:n].view(count, rows, cols)
+
+
 class _Linear(torch.autograd.Function):
     @staticmethod
     def forward(ctx, F_, W, b, keep, scale):
@@ -572,9 +611,17 @@ def _side_streams(device, n=3):
     key = (device.type, device.index)
     st = _SIDE_STREAMS.get(key)
     if st is None:
-        st = [torch.cuda.Stream(device=device) for _ in range(n)]
+        prio = [int(x) for x in _os.environ.get("MMSSL_STREAM_PRIO", "0,0,0").split(",")]
+        st = [torch.cuda.Stream(device=device, priority=prio[k % len(prio)]) for k in range(n)]
         _SIDE_STREAMS[key] = st
     return st
+
+
+def _branch_order(var, default):
+    """Enqueue order of the three chains (A image, B text, C GCN): the order in which a captured graph's
+    branches were recorded influences how the hipGraph executor interleaves them."""
+    o = _os.environ.get(var, default).upper()
+    return o if sorted(o) == ["A", "B", "C"] else default
 
 
 def overlap_enabled():
@@ -605,24 +652,38 @@ class _HotForward(torch.autograd.Function):
         if overlap:
             for st in (sA, sB, sC):
                 st.wait_stream(main)
-        with torch.cuda.stream(sA):
-            x_img = _linear_raw(F_img, W_img, b_img, keep_img, scale)
-            img_user = _spmm_raw(ui, False, x_img, EPI_NONE)
-            img_item = _spmm_raw(iu, False, img_user, EPI_NONE)
-        with torch.cuda.stream(sB):
-            x_txt = _linear_raw(F_txt, W_txt, b_txt, keep_txt, scale)
-            txt_user = _spmm_raw(ui.twin(), False, x_txt, EPI_NONE)
-            txt_item = _spmm_raw(iu.twin(), False, txt_user, EPI_NONE)
-        with torch.cuda.stream(sC):
-            us, its = [u0], [i0]
-            u, i = u0, i0
-            uic, iuc = ui.twin(2), iu.twin(2)
-            for l in range(n_layers):
-                epi = EPI_SOFTMAX if l == n_layers - 1 else EPI_NONE
-                u = _spmm_raw(uic, False, i, epi)
-                i = _spmm_raw(iuc, False, u, epi)
-                us.append(u)
-                its.append(i)
+        out = {}
+
+        def chain_a():
+            with torch.cuda.stream(sA):
+                x_img = _linear_raw(F_img, W_img, b_img, keep_img, scale)
+                out["img_user"] = _spmm_raw(ui, False, x_img, EPI_NONE)
+                out["img_item"] = _spmm_raw(iu, False, out["img_user"], EPI_NONE)
+
+        def chain_b():
+            with torch.cuda.stream(sB):
+                x_txt = _linear_raw(F_txt, W_txt, b_txt, keep_txt, scale)
+                out["txt_user"] = _spmm_raw(ui.twin(), False, x_txt, EPI_NONE)
+                out["txt_item"] = _spmm_raw(iu.twin(), False, out["txt_user"], EPI_NONE)
+
+        def chain_c():
+            with torch.cuda.stream(sC):
+                us, its = [u0], [i0]
+                u, i = u0, i0
+                uic, iuc = ui.twin(2), iu.twin(2)
+                for l in range(n_layers):
+                    epi = EPI_SOFTMAX if l == n_layers - 1 else EPI_NONE
+                    u = _spmm_raw(uic, False, i, epi)
+                    i = _spmm_raw(iuc, False, u, epi)
+                    us.append(u)
+                    its.append(i)
+                out["us"], out["its"] = us, its
+
+        chains = {"A": chain_a, "B": chain_b, "C": chain_c}
+        for c in _branch_order("MMSSL_FWD_ORDER", "ABC"):
+            chains[c]()
+        img_user, img_item, txt_user, txt_item = out["img_user"], out["img_item"], out["txt_user"], out["txt_item"]
+        us, its = out["us"], out["its"]
         if overlap:
             for st in (sA, sB, sC):
                 main.wait_stream(st)
@@ -666,20 +727,33 @@ class _HotForward(torch.autograd.Function):
         if overlap:
             for st in (sA, sB, sC):
                 st.wait_stream(main)
-        with torch.cuda.stream(sC):
-            uic, iuc = ui.twin(2), iu.twin(2)
-            gi = softmax_rows_bwd(iG, Gi, inv)
-            gu = _spmm_raw(iuc, True, gi, EPI_AXPY_SOFTMAX_BWD, Gu, inv, uG)
-            gi = _spmm_raw(uic, True, gu, EPI_AXPY, Gi, inv)
-            for _ in range(n_layers - 1):
-                gu = _spmm_raw(iuc, True, gi, EPI_AXPY, Gu, inv)
+        out = {}
+
+        def chain_c():
+            with torch.cuda.stream(sC):
+                uic, iuc = ui.twin(2), iu.twin(2)
+                gi = softmax_rows_bwd(iG, Gi, inv)
+                gu = _spmm_raw(iuc, True, gi, EPI_AXPY_SOFTMAX_BWD, Gu, inv, uG)
                 gi = _spmm_raw(uic, True, gu, EPI_AXPY, Gi, inv)
-        with torch.cuda.stream(sA):
-            g_x_img = _spmm_raw(ui, True, _spmm_raw(iu, True, g_ii_, EPI_AXPY, g_iu_, 1.0), EPI_NONE)
-            _, gW_img, gb_img = _linear_wgrad_raw(g_x_img, keep_img, scale, F_img, W_img)
-        with torch.cuda.stream(sB):
-            g_x_txt = _spmm_raw(ui.twin(), True, _spmm_raw(iu.twin(), True, g_ti_, EPI_AXPY, g_tu_, 1.0), EPI_NONE)
-            _, gW_txt, gb_txt = _linear_wgrad_raw(g_x_txt, keep_txt, scale, F_txt, W_txt)
+                for _ in range(n_layers - 1):
+                    gu = _spmm_raw(iuc, True, gi, EPI_AXPY, Gu, inv)
+                    gi = _spmm_raw(uic, True, gu, EPI_AXPY, Gi, inv)
+                out["gi"] = gi
+
+        def chain_a():
+            with torch.cuda.stream(sA):
+                g_x_img = _spmm_raw(ui, True, _spmm_raw(iu, True, g_ii_, EPI_AXPY, g_iu_, 1.0), EPI_NONE)
+                _, out["gW_img"], out["gb_img"] = _linear_wgrad_raw(g_x_img, keep_img, scale, F_img, W_img)
+
+        def chain_b():
+            with torch.cuda.stream(sB):
+                g_x_txt = _spmm_raw(ui.twin(), True, _spmm_raw(iu.twin(), True, g_ti_, EPI_AXPY, g_tu_, 1.0), EPI_NONE)
+                _, out["gW_txt"], out["gb_txt"] = _linear_wgrad_raw(g_x_txt, keep_txt, scale, F_txt, W_txt)
+
+        chains = {"A": chain_a, "B": chain_b, "C": chain_c}
+        for c in _branch_order("MMSSL_BWD_ORDER", "CAB"):
+            chains[c]()
+        gi, gW_img, gb_img, gW_txt, gb_txt = out["gi"], out["gW_img"], out["gb_img"], out["gW_txt"], out["gb_txt"]
         if overlap:
             for st in (sA, sB, sC):
                 main.wait_stream(st)

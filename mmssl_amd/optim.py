@@ -1,0 +1,92 @@
+"""AdamW with the reference's update rule (torch.optim.AdamW as built at
+/root/reference/MMSSL/main.py:76-80) as ONE kernel launch over all tensors that have a gradient
+(`mmssl_adamw_f32`), with the step counter in device memory so the update can be replayed inside a
+hipGraph. Drop-in for the subset of the torch optimizer API the trainer uses (`zero_grad`, `step`,
+`param_groups`, `state_dict`/`load_state_dict` in torch's AdamW layout)."""
+import ctypes as _ct
+
+import torch
+
+from . import _lib
+
+_MAX = 24        # MMSSL_ADAMW_MAX_TENSORS
+
+
+class FusedAdamW(torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
+        if lr < 0 or eps < 0 or not (0 <= betas[0] < 1 and 0 <= betas[1] < 1) or weight_decay < 0:
+            raise ValueError("FusedAdamW: invalid hyper-parameter")
+        super().__init__(params, dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay))
+        self._steps = {}        # per param group: device float[2] {completed steps, block counter}
+
+    def _group_state(self, gi, device):
+        st = self._steps.get(gi)
+        if st is None:
+            st = torch.zeros(2, dtype=torch.float32, device=device)
+            self._steps[gi] = st
+        return st
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        for gi, group in enumerate(self.param_groups):
+            todo = []
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                if not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous()):
+                    raise _lib.MmsslError("FusedAdamW: parameters must be contiguous fp32 HIP tensors")
+                g = p.grad
+                if g.is_sparse:
+                    raise _lib.MmsslError("FusedAdamW: sparse gradients are not supported")
+                if not g.is_contiguous():
+                    g = g.contiguous()
+                st = self.state[p]
+                if not st:
+                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                todo.append((p, g, st["exp_avg"], st["exp_avg_sq"]))
+            if not todo:
+                continue
+            state = self._group_state(gi, todo[0][0].device)
+            b1, b2 = group["betas"]
+            # one launch per _MAX tensors; only the LAST launch of a group may advance the step counter,
+            # so larger groups are not supported (the hot path has 7 tensors with gradients)
+            if len(todo) > _MAX:
+                raise _lib.MmsslError("FusedAdamW: more than %d tensors with gradients in one group" % _MAX)
+            n = len(todo)
+            arr = lambda k: (_ct.c_void_p * n)(*[t[k].data_ptr() for t in todo])       # noqa: E731
+            numel = (_ct.c_int64 * n)(*[t[0].numel() for t in todo])
+            rc = _lib.lib().mmssl_adamw_f32(arr(0), arr(1), arr(2), arr(3), numel, n, state.data_ptr(),
+                                            float(group["lr"]), float(b1), float(b2), float(group["eps"]),
+                                            float(group["weight_decay"]), _lib.stream_ptr())
+            _lib.check(rc, "mmssl_adamw_f32")
+        return loss
+
+    # torch.optim.AdamW-compatible checkpoint layout: per-parameter "step" tensors
+    def state_dict(self):
+        sd = super().state_dict()
+        for gi, group in enumerate(sd["param_groups"]):
+            st = self._steps.get(gi)
+            for pid in group["params"]:
+                if pid in sd["state"]:
+                    sd["state"][pid]["step"] = (st[0:1].clone().reshape(()) if st is not None
+                                                else torch.tensor(0.0))
+        return sd
+
+    def load_state_dict(self, state_dict):
+        steps = {}
+        for gi, group in enumerate(state_dict["param_groups"]):
+            for pid in group["params"]:
+                st = state_dict["state"].get(pid)
+                if st is not None and "step" in st:
+                    steps[gi] = float(st["step"])
+        super().load_state_dict(state_dict)
+        for p_state in self.state.values():
+            p_state.pop("step", None)
+        for gi, val in steps.items():
+            dev = self.param_groups[gi]["params"][0].device
+            self._group_state(gi, dev)[0] = val

@@ -21,6 +21,10 @@ class OracleBackend:
     make_graph = _Graph
 
     @staticmethod
+    def dropout_masks(count, rows, cols, p, device):
+        return torch.empty((count, rows, cols), dtype=torch.uint8, device=device).bernoulli_(1.0 - p)
+
+    @staticmethod
     def spmm(plan, X, epilogue=0, transpose=False):
         Y = O.spmm(plan.AT if transpose else plan.A, X)
         return torch.softmax(Y, -1) if epilogue else Y

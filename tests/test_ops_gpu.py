@@ -349,3 +349,97 @@ def test_spmm_inkernel_combine_stress(d):
         if k in first:
             assert torch.equal(Yc, first[k]), (it, k)
         first[k] = Yc
+
+
+def test_fused_adamw_matches_torch_adamw():
+    """mmssl_adamw_f32 == torch.optim.AdamW (the reference's optimiser, main.py:76-80) step for step;
+    tensors without a gradient are skipped; ragged sizes exercise the scalar tail."""
+    from mmssl_amd.optim import FusedAdamW
+    torch.manual_seed(5)
+    shapes = [(1000, 64), (17, 64), (64,), (4099,), (256, 64), (3,)]
+    ref_p = [torch.nn.Parameter(torch.randn(s, device=DEV)) for s in shapes]
+    got_p = [torch.nn.Parameter(p.detach().clone()) for p in ref_p]
+    frozen = got_p[4].detach().clone()
+    ref = torch.optim.AdamW(ref_p, lr=5.5e-4)
+    got = FusedAdamW(got_p, lr=5.5e-4)
+    for step in range(6):
+        for k, (a, b) in enumerate(zip(ref_p, got_p)):
+            if k == 4:                       # never receives a gradient (like the reference's unused tensors)
+                continue
+            g = torch.randn_like(a) * (10.0 ** (step - 3))
+            a.grad, b.grad = g.clone(), g.clone()
+        ref.step()
+        got.step()
+    for k, (a, b) in enumerate(zip(ref_p, got_p)):
+        assert torch.allclose(a, b, rtol=2e-6, atol=1e-7), (k, float((a - b).abs().max()))
+    assert torch.equal(got_p[4], frozen)
+    sd = got.state_dict()
+    assert float(sd["state"][0]["step"]) == 6.0
+    assert 4 not in sd["state"]
+    assert torch.allclose(sd["state"][0]["exp_avg"], ref.state_dict()["state"][0]["exp_avg"], rtol=1e-5, atol=1e-7)
+    # round trip through the torch-layout checkpoint
+    again = FusedAdamW([torch.nn.Parameter(p.detach().clone()) for p in got_p], lr=5.5e-4)
+    again.load_state_dict(sd)
+    assert float(again.state_dict()["state"][0]["step"]) == 6.0
+
+
+def test_fused_adamw_in_hipgraph_advances_step():
+    from mmssl_amd.optim import FusedAdamW
+    p = torch.nn.Parameter(torch.ones(4099, device=DEV))
+    q = torch.nn.Parameter(torch.ones(4099, device=DEV))
+    p.grad = torch.full_like(p, 0.5)
+    q.grad = torch.full_like(q, 0.5)
+    a, b = FusedAdamW([p], lr=1e-2), torch.optim.AdamW([q], lr=1e-2)
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        a.step()                              # eager step 1
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=s):   # capture only records
+            a.step()
+        for _ in range(3):                    # steps 2..4
+            g.replay()
+    torch.cuda.synchronize()
+    for _ in range(4):
+        b.step()
+    assert float(a.state_dict()["state"][0]["step"]) == 4.0
+    assert torch.allclose(p, q, rtol=2e-6, atol=1e-7), float((p - q).abs().max())
+
+
+def test_dropout_masks_statistics_and_determinism():
+    from mmssl_amd import ops
+    ops.seed_dropout(123, DEV)
+    a = ops.dropout_masks(2, 18357, 64, 0.2, DEV)
+    b = ops.dropout_masks(2, 18357, 64, 0.2, DEV)
+    ops.seed_dropout(123, DEV)
+    a2 = ops.dropout_masks(2, 18357, 64, 0.2, DEV)
+    torch.cuda.synchronize()
+    assert a.dtype == torch.uint8 and tuple(a.shape) == (2, 18357, 64)
+    assert set(torch.unique(a).tolist()) == {0, 1}
+    assert torch.equal(a, a2) and not torch.equal(a, b)
+    n = a.numel()
+    for m in (a, b):
+        keep = float(m.float().mean())
+        assert abs(keep - 0.8) < 5 * (0.8 * 0.2 / n) ** 0.5 + 1e-4, keep
+    assert abs(float((a[0] == a[1]).float().mean()) - (0.8 * 0.8 + 0.2 * 0.2)) < 2e-3      # masks independent
+    assert abs(float((a == b).float().mean()) - 0.68) < 2e-3                                 # launches independent
+    # per-column / per-row keep rates are flat (no lattice structure along either axis)
+    assert float((a[0].float().mean(0) - 0.8).abs().max()) < 0.02
+    z = ops.dropout_masks(1, 5, 3, 0.5, DEV)                      # n not a multiple of 4
+    assert tuple(z.shape) == (1, 5, 3)
+    # graph replays draw fresh masks
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        ops.dropout_masks(1, 64, 64, 0.2, DEV)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=s):
+            m = ops.dropout_masks(1, 64, 64, 0.2, DEV)
+        g.replay()
+        torch.cuda.synchronize()
+        first = m.clone()
+        g.replay()
+        torch.cuda.synchronize()
+    assert not torch.equal(first, m)

@@ -183,6 +183,9 @@ int mmssl_adamw_f32(float* const* params, const float* const* grads, float* cons
  * main.py:420 in one launch (terms / w / extra are device arrays; extra may be NULL). */
 int mmssl_loss_assemble_f32(const float* terms, const float* w, int n, const float* extra, float c,
                             float* total, void* stream);
+/* Backward of the above: gterms[k] = g[0] * w[k], gextra[0] = g[0] * c (gextra may be NULL). */
+int mmssl_loss_assemble_bwd_f32(const float* g, const float* w, int n, float c, float* gterms,
+                                float* gextra, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * InfoNCE  — Trainer.batched_contrastive_loss + Trainer.sim (main.py:211-249)
@@ -215,6 +218,13 @@ int mmssl_infonce_multi_fwd_f32(const float* const* z1s, const float* z2, const 
 int mmssl_infonce_multi_bwd_f32(const int64_t* idx, int n_problems, int64_t n, int d, float tau,
                                 const float* gloss, float* const* gz1s, float* gz2, void* workspace,
                                 size_t workspace_bytes, void* stream);
+/* The same in two separately launchable phases so that independent work (the BPR backward, which
+ * scatters into the same table gradient and must stay ordered before phase 2) can overlap phase 1:
+ * phases bit 0 = pair tiles (workspace only), bit 1 = finish (diagonal terms, normalise-backward,
+ * scatter-add into gz1s / gz2). phases == 3 is mmssl_infonce_multi_bwd_f32. */
+int mmssl_infonce_multi_bwd_phase_f32(const int64_t* idx, int n_problems, int64_t n, int d, float tau,
+                                      const float* gloss, float* const* gz1s, float* gz2,
+                                      void* workspace, size_t workspace_bytes, int phases, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * BPR  — gathers (main.py:368-370) + Trainer.bpr_loss (main.py:499-511)

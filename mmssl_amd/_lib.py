@@ -62,6 +62,7 @@ SIGNATURES = {
     "mmssl_dropout_mask_u8": (c_int, [c_void_p, c_float, c_int64, c_void_p, c_void_p]),
     "mmssl_adamw_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_float, c_float,
                                 c_float, c_float, c_float, c_void_p]),
+    "mmssl_loss_assemble_bwd_f32": (c_int, [c_void_p, c_void_p, c_int, c_float, c_void_p, c_void_p, c_void_p]),
     "mmssl_loss_assemble_f32": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_float, c_void_p, c_void_p]),
     "mmssl_infonce_workspace_bytes": (c_size_t, [c_int64, c_int]),
     "mmssl_infonce_fwd_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_float, c_void_p, c_void_p,
@@ -73,6 +74,8 @@ SIGNATURES = {
                                             c_void_p, c_size_t, c_void_p]),
     "mmssl_infonce_multi_bwd_f32": (c_int, [c_void_p, c_int, c_int64, c_int, c_float, c_void_p, c_void_p, c_void_p,
                                             c_void_p, c_size_t, c_void_p]),
+    "mmssl_infonce_multi_bwd_phase_f32": (c_int, [c_void_p, c_int, c_int64, c_int, c_float, c_void_p, c_void_p,
+                                                  c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
     "mmssl_bpr_workspace_bytes": (c_size_t, [c_int64]),
     "mmssl_bpr_fwd_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
                                   c_int, c_float, c_int64, c_void_p, c_void_p, c_size_t, c_void_p]),

@@ -476,8 +476,9 @@ int infonce_fwd_impl(const float* const* z1s, const float* z2, const int64_t* id
 }
 
 int infonce_bwd_impl(const int64_t* idx, int P, int64_t n, int d, float tau, const float* gloss,
-                     float* const* gz1s, float* gz2, void* workspace, size_t workspace_bytes, void* stream) {
-  if (P < 1 || P > kMaxProblems || n <= 0 || !gloss || !(tau > 0.f)) return MMSSL_E_BADARG;
+                     float* const* gz1s, float* gz2, void* workspace, size_t workspace_bytes, void* stream,
+                     int phases = 3) {
+  if (P < 1 || P > kMaxProblems || n <= 0 || !gloss || !(tau > 0.f) || phases < 1 || phases > 3) return MMSSL_E_BADARG;
   if (!infonce_d_ok(d)) return MMSSL_E_UNSUPP;
   const Layout L = make_layout(n, d);
   if (!workspace || workspace_bytes < (size_t)P * L.total * sizeof(float)) return MMSSL_E_WORKSPACE;
@@ -495,13 +496,16 @@ int infonce_bwd_impl(const int64_t* idx, int P, int64_t n, int d, float tau, con
   hipStream_t s = as_stream(stream);
   const int nt = n_tiles(n);
   const dim3 grid(nt * L.cs_b, P);
-  switch (d) {
-    case 32: hipLaunchKernelGGL((bwd_tiles_kernel<32>), grid, dim3(kBlock), 0, s, ws, L.total, L, n, tau, L.cs_b); break;
-    case 64: hipLaunchKernelGGL((bwd_tiles_kernel<64>), grid, dim3(kBlock), 0, s, ws, L.total, L, n, tau, L.cs_b); break;
-    case 128: hipLaunchKernelGGL((bwd_tiles_kernel<128>), grid, dim3(kBlock), 0, s, ws, L.total, L, n, tau, L.cs_b); break;
-    case 256: hipLaunchKernelGGL((bwd_tiles_kernel<256>), grid, dim3(kBlock), 0, s, ws, L.total, L, n, tau, L.cs_b); break;
+  if (phases & 1) {
+    switch (d) {
+      case 32: hipLaunchKernelGGL((bwd_tiles_kernel<32>), grid, dim3(kBlock), 0, s, ws, L.total, L, n, tau, L.cs_b); break;
+      case 64: hipLaunchKernelGGL((bwd_tiles_kernel<64>), grid, dim3(kBlock), 0, s, ws, L.total, L, n, tau, L.cs_b); break;
+      case 128: hipLaunchKernelGGL((bwd_tiles_kernel<128>), grid, dim3(kBlock), 0, s, ws, L.total, L, n, tau, L.cs_b); break;
+      case 256: hipLaunchKernelGGL((bwd_tiles_kernel<256>), grid, dim3(kBlock), 0, s, ws, L.total, L, n, tau, L.cs_b); break;
+    }
+    MMSSL_LAUNCH_CHECK();
   }
-  MMSSL_LAUNCH_CHECK();
+  if (!(phases & 2)) return 0;
   const int rb = (int)((n + 15) / 16);
   hipLaunchKernelGGL(bwd_finish_kernel, dim3(rb), dim3(kBlock), 0, s, ws, L.total, L, P, L.cs_b, idx, n, d, tau, gloss,
                      Z, gz2);
@@ -545,4 +549,10 @@ extern "C" int mmssl_infonce_multi_bwd_f32(const int64_t* idx, int n_problems, i
                                            const float* gloss, float* const* gz1s, float* gz2, void* workspace,
                                            size_t workspace_bytes, void* stream) {
   return infonce_bwd_impl(idx, n_problems, n, d, tau, gloss, gz1s, gz2, workspace, workspace_bytes, stream);
+}
+
+extern "C" int mmssl_infonce_multi_bwd_phase_f32(const int64_t* idx, int n_problems, int64_t n, int d, float tau,
+                                                 const float* gloss, float* const* gz1s, float* gz2,
+                                                 void* workspace, size_t workspace_bytes, int phases, void* stream) {
+  return infonce_bwd_impl(idx, n_problems, n, d, tau, gloss, gz1s, gz2, workspace, workspace_bytes, stream, phases);
 }

@@ -323,6 +323,23 @@ __global__ void loss_assemble_kernel(const float* __restrict__ terms, const floa
 }
 }  // namespace
 
+namespace {
+__global__ void loss_assemble_bwd_kernel(const float* __restrict__ g, const float* __restrict__ w, int n, float c,
+                                         float* __restrict__ gterms, float* __restrict__ gextra) {
+  const float gv = g[0];
+  if ((int)threadIdx.x < n) gterms[threadIdx.x] = gv * w[threadIdx.x];
+  if (threadIdx.x == 0 && gextra) gextra[0] = gv * c;
+}
+}  // namespace
+
+extern "C" int mmssl_loss_assemble_bwd_f32(const float* g, const float* w, int n, float c, float* gterms,
+                                           float* gextra, void* stream) {
+  if (!g || !w || !gterms || n < 0 || n > 16) return MMSSL_E_BADARG;
+  hipLaunchKernelGGL(loss_assemble_bwd_kernel, dim3(1), dim3(64), 0, as_stream(stream), g, w, n, c, gterms, gextra);
+  MMSSL_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int mmssl_loss_assemble_f32(const float* terms, const float* w, int n, const float* extra, float c,
                                        float* total, void* stream) {
   if (!terms || !w || !total || n < 0 || n > 16) return MMSSL_E_BADARG;

@@ -35,6 +35,7 @@ class HotPathStep:
         else:
             self.optimizer = FusedAdamW([{"params": model.parameters()}], lr=lr or args.lr)
         self.loss = torch.zeros((), device=dev)
+        self._one = torch.ones((), device=dev)
         self.parts = {}
         self._graph = None
         # ONE stream for everything this object launches (eager steps, capture, replays): autograd
@@ -59,7 +60,8 @@ class HotPathStep:
         terms = ops.batch_losses_vec(ua, ia, img_uid, txt_uid, self.users, self.pos, self.neg, self.decay,
                                      self.batch_size, args.tau)                 # [mf, emb, 0, cl_img, cl_txt]
         ss = m.feat_sumsq(img_item, txt_item, img_user, txt_user)
-        total = ops.loss_assemble(terms, self.loss_w, ss, args.feat_reg_decay * 0.5 / m.n_items)
+        # the step's loss lands in the persistent buffer self.loss (read back by callers after a replay)
+        total = ops.loss_assemble(terms, self.loss_w, ss, args.feat_reg_decay * 0.5 / m.n_items, out=self.loss)
         return total, dict(terms=terms, ss=ss)
 
     def step(self):
@@ -70,10 +72,9 @@ class HotPathStep:
     def _step(self):
         self.optimizer.zero_grad(set_to_none=True)
         total, parts = self.losses()
-        total.backward()
+        total.backward(gradient=self._one)           # persistent root gradient: no ones_like fill per step
         self.optimizer.step()
-        self.loss.copy_(total.detach())
-        return total.detach()
+        return self.loss
 
     # ---- hipGraph capture ---------------------------------------------------------------------
     def capture(self, warmup=3):

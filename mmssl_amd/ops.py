@@ -400,44 +400,78 @@ class _BatchLosses(torch.autograd.Function):
         ua, ia = _chk(ua, "ua"), _chk(ia, "ia")
         img_uid, txt_uid = _chk(img_uid, "img_uid"), _chk(txt_uid, "txt_uid")
         B, d = users.shape[0], ua.shape[1]
-        out = torch.empty(5, dtype=torch.float32, device=ua.device)     # mf, emb, reg(=0), cl_img, cl_txt
+        dev = ua.device
+        out = torch.empty(5, dtype=torch.float32, device=dev)     # mf, emb, reg(=0), cl_img, cl_txt
         nb = _lib.lib().mmssl_bpr_workspace_bytes(B)
-        wsb = torch.empty(nb // 4, dtype=torch.float32, device=ua.device)
-        rc = _lib.lib().mmssl_bpr_fwd_f32(_ptr(ua), _ptr(ia), None, _ptr(users), _ptr(pos), _ptr(neg), B, d,
-                                          float(decay), int(batch_size), _ptr(out), _ptr(wsb), nb, _lib.stream_ptr())
-        _lib.check(rc, "mmssl_bpr_fwd_f32")
+        wsb = torch.empty(nb // 4, dtype=torch.float32, device=dev)
+        need_grad = any(ctx.needs_input_grad[:4])
+        # the table gradients the backward scatter-adds into are allocated here and zero-filled on a side
+        # stream, next to the BPR forward, while the (longer) InfoNCE forward runs on the current stream
+        g_ua = torch.empty_like(ua) if need_grad else None
+        g_ia = torch.empty_like(ia) if need_grad else None
+        overlap = overlap_enabled()
+        main = torch.cuda.current_stream(dev)
+        side = _side_streams(dev)[0] if overlap else main
+        if overlap:
+            side.wait_stream(main)
+        with torch.cuda.stream(side):
+            rc = _lib.lib().mmssl_bpr_fwd_f32(_ptr(ua), _ptr(ia), None, _ptr(users), _ptr(pos), _ptr(neg), B, d,
+                                              float(decay), int(batch_size), _ptr(out), _ptr(wsb), nb,
+                                              _lib.stream_ptr())
+            _lib.check(rc, "mmssl_bpr_fwd_f32")
+            if need_grad:
+                g_ua.zero_()
+                g_ia.zero_()
         # both InfoNCE problems (image / text view vs the same user table) in ONE set of launches,
         # losses written straight into out[3], out[4]
         nbw = _lib.lib().mmssl_infonce_multi_workspace_bytes(2, B, d)
         if nbw == 0:
             raise _lib.MmsslError("infonce: unsupported shape n=%d d=%d" % (B, d))
-        ws1 = torch.empty(nbw // 4, dtype=torch.float32, device=ua.device)
-        ws2 = ws1
+        ws1 = torch.empty(nbw // 4, dtype=torch.float32, device=dev)
         z1s = (_ct.c_void_p * 2)(img_uid.data_ptr(), txt_uid.data_ptr())
         rc = _lib.lib().mmssl_infonce_multi_fwd_f32(z1s, _ptr(ua), _ptr(users), 2, B, d, float(tau), _ptr(out[3:5]),
                                                     _ptr(ws1), nbw, _lib.stream_ptr())
         _lib.check(rc, "mmssl_infonce_multi_fwd_f32")
-        ctx.save_for_backward(ua, ia, users, pos, neg, ws1, ws2)
-        ctx.cfg = (B, d, float(decay), int(batch_size), float(tau), img_uid.shape, txt_uid.shape)
+        if overlap:
+            main.wait_stream(side)
+        ctx.save_for_backward(ua, ia, users, pos, neg, ws1)
+        ctx.gbuf = (g_ua, g_ia)
+        ctx.cfg = (B, d, float(decay), int(batch_size), float(tau), img_uid.shape, txt_uid.shape, overlap)
         return out
 
     @staticmethod
     def backward(ctx, g):
-        ua, ia, users, pos, neg, ws1, ws2 = ctx.saved_tensors
-        B, d, decay, batch_size, tau, s_img, s_txt = ctx.cfg
+        ua, ia, users, pos, neg, ws1 = ctx.saved_tensors
+        B, d, decay, batch_size, tau, s_img, s_txt, overlap = ctx.cfg
         g = g.contiguous().to(torch.float32)
-        g_ua = torch.zeros_like(ua)
-        g_ia = torch.zeros_like(ia)
-        rc = _lib.lib().mmssl_bpr_bwd_f32(_ptr(ua), _ptr(ia), None, _ptr(users), _ptr(pos), _ptr(neg), B, d, decay,
-                                          batch_size, _ptr(g[0:1]), _ptr(g[1:2]), _ptr(g_ua), _ptr(g_ia), None,
-                                          _lib.stream_ptr())
-        _lib.check(rc, "mmssl_bpr_bwd_f32")
-        g_img = torch.zeros(s_img, dtype=torch.float32, device=ua.device) if ctx.needs_input_grad[2] else None
-        g_txt = torch.zeros(s_txt, dtype=torch.float32, device=ua.device) if ctx.needs_input_grad[3] else None
+        g_ua, g_ia = ctx.gbuf
+        ctx.gbuf = None
+        if g_ua is None:                     # second backward through a retained graph
+            g_ua, g_ia = torch.zeros_like(ua), torch.zeros_like(ia)
+        dev = ua.device
+        g_img = torch.zeros(s_img, dtype=torch.float32, device=dev) if ctx.needs_input_grad[2] else None
+        g_txt = torch.zeros(s_txt, dtype=torch.float32, device=dev) if ctx.needs_input_grad[3] else None
         gz1s = (_ct.c_void_p * 2)(_ptr(g_img), _ptr(g_txt))
-        rc = _lib.lib().mmssl_infonce_multi_bwd_f32(_ptr(users), 2, B, d, tau, _ptr(g[3:5]), gz1s, _ptr(g_ua), _ptr(ws1),
-                                                    ws1.numel() * 4, _lib.stream_ptr())
-        _lib.check(rc, "mmssl_infonce_multi_bwd_f32")
+        main = torch.cuda.current_stream(dev)
+        side = _side_streams(dev)[0] if overlap else main
+        if overlap:
+            side.wait_stream(main)
+        # BPR backward (scatter-add into g_ua / g_ia) next to the InfoNCE pair tiles (workspace only);
+        # the InfoNCE finish scatter-adds into g_ua AFTER the join: same accumulation order as serial
+        with torch.cuda.stream(side):
+            rc = _lib.lib().mmssl_bpr_bwd_f32(_ptr(ua), _ptr(ia), None, _ptr(users), _ptr(pos), _ptr(neg), B, d,
+                                              decay, batch_size, _ptr(g[0:1]), _ptr(g[1:2]), _ptr(g_ua), _ptr(g_ia),
+                                              None, _lib.stream_ptr())
+            _lib.check(rc, "mmssl_bpr_bwd_f32")
+        call = _lib.lib().mmssl_infonce_multi_bwd_phase_f32
+        rc = call(_ptr(users), 2, B, d, tau, _ptr(g[3:5]), gz1s, _ptr(g_ua), _ptr(ws1), ws1.numel() * 4, 1,
+                  _lib.stream_ptr())
+        _lib.check(rc, "mmssl_infonce_multi_bwd_phase_f32")
+        if overlap:
+            main.wait_stream(side)
+        rc = call(_ptr(users), 2, B, d, tau, _ptr(g[3:5]), gz1s, _ptr(g_ua), _ptr(ws1), ws1.numel() * 4, 2,
+                  _lib.stream_ptr())
+        _lib.check(rc, "mmssl_infonce_multi_bwd_phase_f32")
         return g_ua, g_ia, g_img, g_txt, None, None, None, None, None, None
 
 
@@ -455,12 +489,19 @@ def batch_losses(ua, ia, img_uid, txt_uid, users, pos, neg, decay, batch_size, t
 
 
 class _LossAssemble(torch.autograd.Function):
-    """total = sum_k w[k] * terms[k] + c * extra   (main.py:420) in one launch; the backward is two
-    tiny scalings instead of the ~20 scalar autograd kernels of the op-by-op expression."""
+    """total = sum_k w[k] * terms[k] + c * extra   (main.py:420) in one launch, written into `out` when
+    given (a persistent buffer: no copy of the step's loss afterwards); the backward is one launch too,
+    instead of the ~20 scalar autograd kernels of the op-by-op expression."""
 
     @staticmethod
-    def forward(ctx, terms, w, extra, c):
-        total = torch.empty((), dtype=torch.float32, device=terms.device)
+    def forward(ctx, terms, w, extra, c, out):
+        if out is not None:
+            # a fresh tensor object over `out`'s memory: the result carries the autograd history, the
+            # caller's buffer stays a plain leaf that can be passed again next step
+            total = torch.empty(0, dtype=torch.float32, device=out.device).set_(
+                out.untyped_storage(), out.storage_offset(), torch.Size(()), ())
+        else:
+            total = torch.empty((), dtype=torch.float32, device=terms.device)
         rc = _lib.lib().mmssl_loss_assemble_f32(_ptr(terms), _ptr(w), terms.numel(), _ptr(extra), float(c),
                                                 _ptr(total), _lib.stream_ptr())
         _lib.check(rc, "mmssl_loss_assemble_f32")
@@ -472,11 +513,19 @@ class _LossAssemble(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         (w,) = ctx.saved_tensors
-        return g * w, None, (g * ctx.c if ctx.has_extra else None), None
+        g = g.contiguous().to(torch.float32)
+        gt = torch.empty_like(w)
+        ge = torch.empty((), dtype=torch.float32, device=w.device) if ctx.has_extra else None
+        rc = _lib.lib().mmssl_loss_assemble_bwd_f32(_ptr(g), _ptr(w), w.numel(), ctx.c, _ptr(gt), _ptr(ge),
+                                                    _lib.stream_ptr())
+        _lib.check(rc, "mmssl_loss_assemble_bwd_f32")
+        return gt, None, ge, None, None
 
 
-def loss_assemble(terms, w, extra=None, c=0.0):
-    return _LossAssemble.apply(_chk(terms, "terms"), _chk(w, "w"), extra, c)
+def loss_assemble(terms, w, extra=None, c=0.0, out=None):
+    if out is not None and (out.dtype != torch.float32 or out.numel() != 1 or not out.is_cuda or out.requires_grad):
+        raise _lib.MmsslError("loss_assemble: `out` must be a one-element fp32 HIP tensor that needs no gradient")
+    return _LossAssemble.apply(_chk(terms, "terms"), _chk(w, "w"), extra, c, out)
 
 
 class _ZeroGradAnchor(torch.autograd.Function):

@@ -39,16 +39,27 @@ inline int splits_for(int64_t n, int col_tiles) {
   return cs;
 }
 
+// MFMA path: column tiles per block in the forward (4 waves x 2) / pair tiles per block in the backward (4 x 1)
+constexpr int kFwdTilesPerBlock = 8;
+constexpr int kBwdTilesPerBlock = 4;
+
 struct Layout {   // offsets in floats into the workspace
   size_t n1, n2, inv1, inv2, pos, w, c, rows_part, loss, g1p, g2p, total;
   int cs_f, cs_b;
 };
 
+inline bool use_mfma(int d);
+
 inline Layout make_layout(int64_t n, int d) {
   Layout L;
   const int nt = n_tiles(n);
-  L.cs_f = splits_for(n, 2 * nt);   // forward walks 2*nt column tiles (n1 then n2)
-  L.cs_b = splits_for(n, nt);
+  if (use_mfma(d)) {                // block-level splits: 8 column tiles / 4 pair tiles per block
+    L.cs_f = (2 * nt + kFwdTilesPerBlock - 1) / kFwdTilesPerBlock;
+    L.cs_b = (nt + kBwdTilesPerBlock - 1) / kBwdTilesPerBlock;
+  } else {
+    L.cs_f = splits_for(n, 2 * nt);   // forward walks 2*nt column tiles (n1 then n2)
+    L.cs_b = splits_for(n, nt);
+  }
   size_t o = 0;
   auto take = [&](size_t cnt) { size_t r = o; o += (cnt + 3) & ~(size_t)3; return r; };
   L.n1 = take((size_t)n * d);
@@ -434,6 +445,288 @@ __global__ __launch_bounds__(kBlock) void bwd_finish_kernel(const float* __restr
   }
 }
 
+
+// =================================================================================================
+// MFMA tile kernels (D in {32, 64}): the n x n similarity tiles and, in the backward, the
+// coefficient-tile x embedding products are fp32 matrix-core work (v_mfma_f32_32x32x2_f32).
+//
+// Both operands of a similarity tile S = X_t . Y_s^T are [rows, D] row-major with D contiguous, so
+// a wave loads them STRAIGHT from global (L2-resident, <= 256 KB per matrix) into MFMA fragment
+// layout: lane l owns row (l & 31) and the D/2 features [h*D/2, (h+1)*D/2), h = l >> 5, as D/8
+// float4 loads; MFMA step s then contracts features {s, D/2 + s} (any pairing of k indices is valid
+// as long as A and B agree). No LDS staging, no barriers in the tile loop.
+//
+// C/D layout of the 32x32 MFMA: lane l holds C[(r & 3) + 8 (r >> 2) + 4 h][l & 31], r = 0..15.
+// =================================================================================================
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+template <int D>
+__device__ __forceinline__ void load_frag(const float* __restrict__ src, int64_t row, int64_t n, int h,
+                                          float (&f)[D / 2]) {
+  if (row < n) {
+    const float4* p = reinterpret_cast<const float4*>(src + row * D + h * (D / 2));
+#pragma unroll
+    for (int q = 0; q < D / 8; ++q) {
+      const float4 v = p[q];
+      f[4 * q] = v.x; f[4 * q + 1] = v.y; f[4 * q + 2] = v.z; f[4 * q + 3] = v.w;
+    }
+  } else {
+#pragma unroll
+    for (int q = 0; q < D / 2; ++q) f[q] = 0.f;
+  }
+}
+
+// e^x for the similarity logits (|x| <= 1/tau: cosines): v_exp_f32 on x*log2(e), ~1 ulp; the full-range
+// expf costs as many VALU cycles per tile as the MFMAs that produced it.
+__device__ __forceinline__ float fast_exp(float x) { return __expf(x); }
+
+template <int D>
+__device__ __forceinline__ floatx16 sim_tile(const float (&a)[D / 2], const float (&b)[D / 2]) {
+  floatx16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+  for (int s = 0; s < D / 2; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b[s], acc, 0, 0, 0);
+  return acc;
+}
+
+
+// ---- forward: partial denominators per (row, block split); the 4 waves of a block share a row tile,
+// take column tiles round-robin and reduce their row sums through LDS in a fixed order.
+template <int D>
+__global__ __launch_bounds__(kBlock) void fwd_tiles_mfma_kernel(const float* __restrict__ ws, size_t ws_stride,
+                                                                Layout L, int64_t n, float tau, int cs) {
+  const float* __restrict__ wsp = ws + (size_t)blockIdx.y * ws_stride;
+  const float* __restrict__ n1 = wsp + L.n1;
+  const float* __restrict__ n2 = wsp + L.n2;
+  float* __restrict__ rows_part = const_cast<float*>(wsp) + L.rows_part;
+  __shared__ float red[4][T];
+  const int nt = n_tiles(n);
+  const int ti = blockIdx.x % nt;
+  const int split = blockIdx.x / nt;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int h = lane >> 5, lr = lane & 31;
+  const int64_t i0 = (int64_t)ti * T;
+  float a[D / 2];
+  load_frag<D>(n1, i0 + lr, n, h, a);
+  const int per = (2 * nt + cs - 1) / cs;
+  const int c_beg = split * per, c_end = min(2 * nt, c_beg + per);
+  const float inv_tau = 1.f / tau;
+  float rowacc[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) rowacc[r] = 0.f;
+  // two column tiles per trip: both B fragments are requested before the first MFMA so that the second
+  // load and the exponentials of the first tile hide behind matrix-core work
+  auto tile_src = [&](int ct, const float*& src, int64_t& j0, bool& refl) {
+    refl = ct < nt;
+    src = refl ? n1 : n2;
+    j0 = (int64_t)(refl ? ct : ct - nt) * T;
+  };
+  auto accumulate = [&](const floatx16& acc, int64_t j0, bool refl) {
+    const int64_t col = j0 + lr;
+    const bool vcol = col < n;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int64_t row = i0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      const float e = fast_exp(acc[r] * inv_tau);
+      rowacc[r] += (vcol && !(refl && col == row)) ? e : 0.f;
+    }
+  };
+  for (int ct = c_beg + wave; ct < c_end; ct += 8) {
+    const float* src0; const float* src1;
+    int64_t j0, j1;
+    bool refl0, refl1;
+    tile_src(ct, src0, j0, refl0);
+    const bool two = ct + 4 < c_end;
+    tile_src(two ? ct + 4 : ct, src1, j1, refl1);
+    float b0[D / 2], b1[D / 2];
+    load_frag<D>(src0, j0 + lr, n, h, b0);
+    load_frag<D>(src1, j1 + lr, n, h, b1);
+    const floatx16 acc0 = sim_tile<D>(a, b0);
+    const floatx16 acc1 = sim_tile<D>(a, b1);
+    accumulate(acc0, j0, refl0);
+    if (two) accumulate(acc1, j1, refl1);
+  }
+  // sum over the 32 lanes (columns) that share h; lane lr == 0 of each half then owns 16 rows
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    float v = rowacc[r];
+#pragma unroll
+    for (int m = 1; m < 32; m <<= 1) v += __shfl_xor(v, m, kWave);
+    rowacc[r] = v;
+  }
+  if (lr == 0) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[wave][(r & 3) + 8 * (r >> 2) + 4 * h] = rowacc[r];
+  }
+  __syncthreads();
+  if (threadIdx.x < T) {
+    const int64_t gi = i0 + threadIdx.x;
+    if (gi < n)
+      rows_part[(size_t)split * n + gi] =
+          ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
+  }
+}
+
+// ---- backward pair tiles. Per (t, s) tile pair and wave:
+//   S12 = n1_t.n2_s^T, S11 = n1_t.n1_s^T, S21 = n2_t.n1_s^T            (3 x D/2 MFMAs)
+//   C1 = -c_t e^{S12/tau}, C2 = -(c_t+c_s) e^{S11/tau} [t != s], C3 = -c_s e^{S21/tau}
+//   g1_t += C1 . n2_s + C2 . n1_s ;  g2_t += C3 . n1_s                 (3 x 16 x D/32 MFMAs)
+// The coefficient tiles go accumulator layout -> LDS ([32][33], private to the wave) -> A operand;
+// the embedding rows of tile s are read again from L2 in B-operand layout (row 2k + h, 32
+// consecutive features per half-wave: coalesced). The 4 waves of a block share t, take s tiles
+// round-robin and add their g1/g2 tiles in a fixed order through LDS before one store per block.
+template <int D, bool SINGLE>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2))) void bwd_tiles_mfma_kernel(float* __restrict__ ws, size_t ws_stride, Layout L,
+                                                                int64_t n, float tau, int cs) {
+  float* __restrict__ wsp = ws + (size_t)blockIdx.y * ws_stride;
+  const float* __restrict__ n1 = wsp + L.n1;
+  const float* __restrict__ n2 = wsp + L.n2;
+  const float* __restrict__ c = wsp + L.c;
+  float* __restrict__ g1p = wsp + L.g1p;
+  float* __restrict__ g2p = wsp + L.g2p;
+  constexpr int FT = D / 32;                 // 32-wide feature tiles of the gradient
+  constexpr int CS = T + 1;                  // coefficient tile row stride (conflict-free A-operand reads)
+  constexpr int CW = 3 * T * CS;             // floats of coefficient tiles per wave
+  __shared__ float lds[4 * CW];
+  static_assert(3 * 2 * T * D <= 4 * CW, "reduction buffers of waves 1..3 must fit the coefficient region");
+  const int nt = n_tiles(n);
+  const int tt = blockIdx.x % nt;
+  const int split = blockIdx.x / nt;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int h = lane >> 5, lr = lane & 31;
+  const int64_t t0 = (int64_t)tt * T;
+  float* __restrict__ C1 = lds + wave * CW;
+  float* __restrict__ C2 = C1 + T * CS;
+  float* __restrict__ C3 = C2 + T * CS;
+  float a1[D / 2], a2[D / 2];
+  load_frag<D>(n1, t0 + lr, n, h, a1);
+  load_frag<D>(n2, t0 + lr, n, h, a2);
+  float ct[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int64_t gt = t0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+    ct[r] = gt < n ? c[gt] : 0.f;
+  }
+  floatx16 g1[FT], g2[FT];
+#pragma unroll
+  for (int f = 0; f < FT; ++f)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) g1[f][r] = g2[f][r] = 0.f;
+  const float inv_tau = 1.f / tau;
+  const int per = (nt + cs - 1) / cs;
+  const int s_beg = split * per, s_end = min(nt, s_beg + per);
+  auto pair = [&](int st) {
+    const int64_t s0 = (int64_t)st * T;
+    const int64_t gs = s0 + lr;
+    const bool vs = gs < n;
+    const float cs_ = vs ? c[gs] : 0.f;
+    // every global load of the pair's first half is requested before the first MFMA
+    float b2[D / 2], b1[D / 2];
+    load_frag<D>(n2, gs, n, h, b2);
+    load_frag<D>(n1, gs, n, h, b1);
+    const floatx16 s12 = sim_tile<D>(a1, b2);
+    const floatx16 s11 = sim_tile<D>(a1, b1);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+      const bool v = vs && (t0 + row) < n;
+      C1[row * CS + lr] = v ? -ct[r] * fast_exp(s12[r] * inv_tau) : 0.f;
+    }
+    const floatx16 s21 = sim_tile<D>(a2, b1);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+      const bool v = vs && (t0 + row) < n;
+      C2[row * CS + lr] = (v && (t0 + row) != gs) ? -(ct[r] + cs_) * fast_exp(s11[r] * inv_tau) : 0.f;
+    }
+    // second-stage B operands (k = s index: step ks contracts rows {2 ks, 2 ks + 1} of tile s)
+    float q2[T / 2][FT], q1[T / 2][FT];
+#pragma unroll
+    for (int ks = 0; ks < T / 2; ++ks) {
+      const int64_t row = s0 + 2 * ks + h;
+#pragma unroll
+      for (int f = 0; f < FT; ++f) q2[ks][f] = row < n ? n2[row * D + 32 * f + lr] : 0.f;
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+      const bool v = vs && (t0 + row) < n;
+      C3[row * CS + lr] = v ? -cs_ * fast_exp(s21[r] * inv_tau) : 0.f;
+    }
+#pragma unroll
+    for (int ks = 0; ks < T / 2; ++ks) {
+      const int64_t row = s0 + 2 * ks + h;
+#pragma unroll
+      for (int f = 0; f < FT; ++f) q1[ks][f] = row < n ? n1[row * D + 32 * f + lr] : 0.f;
+    }
+    // the coefficient tiles were written by this wave and are read by this wave only
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int ks = 0; ks < T / 2; ++ks) {
+      const float x = C1[lr * CS + 2 * ks + h];
+#pragma unroll
+      for (int f = 0; f < FT; ++f) g1[f] = __builtin_amdgcn_mfma_f32_32x32x2f32(x, q2[ks][f], g1[f], 0, 0, 0);
+    }
+#pragma unroll
+    for (int ks = 0; ks < T / 2; ++ks) {
+      const float x = C2[lr * CS + 2 * ks + h];
+      const float y = C3[lr * CS + 2 * ks + h];
+#pragma unroll
+      for (int f = 0; f < FT; ++f) {
+        g1[f] = __builtin_amdgcn_mfma_f32_32x32x2f32(x, q1[ks][f], g1[f], 0, 0, 0);
+        g2[f] = __builtin_amdgcn_mfma_f32_32x32x2f32(y, q1[ks][f], g2[f], 0, 0, 0);
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();      // all lanes done reading before a next pair overwrites C*
+  };
+  if (SINGLE) {          // at most one pair per wave: a1/a2/ct die after the first half of the pair
+    if (s_beg + wave < s_end) pair(s_beg + wave);
+  } else {
+    for (int st = s_beg + wave; st < s_end; st += 4) pair(st);
+  }
+  // block reduction: waves 1..3 park their tiles in LDS, wave 0 adds them in the order 1, 2, 3
+  __syncthreads();
+  constexpr int GW = 2 * T * D;           // floats per wave: g1 then g2, [row][feature]
+  if (wave > 0) {
+    float* dst = lds + (wave - 1) * GW;
+#pragma unroll
+    for (int f = 0; f < FT; ++f)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+        dst[row * D + 32 * f + lr] = g1[f][r];
+        dst[T * D + row * D + 32 * f + lr] = g2[f][r];
+      }
+  }
+  __syncthreads();
+  if (wave == 0) {
+    const size_t base = (size_t)split * n * D;
+#pragma unroll
+    for (int f = 0; f < FT; ++f)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+        const int o = row * D + 32 * f + lr;
+        const float v1 = ((g1[f][r] + lds[o]) + lds[GW + o]) + lds[2 * GW + o];
+        const float v2 = ((g2[f][r] + lds[T * D + o]) + lds[GW + T * D + o]) + lds[2 * GW + T * D + o];
+        const int64_t gt = t0 + row;
+        if (gt < n) {
+          g1p[base + gt * D + 32 * f + lr] = v1;
+          g2p[base + gt * D + 32 * f + lr] = v2;
+        }
+      }
+  }
+}
+
+inline bool use_mfma(int d) {
+  static const int off = getenv("MMSSL_INFONCE_VALU") ? atoi(getenv("MMSSL_INFONCE_VALU")) : 0;
+  return !off && (d == 32 || d == 64);
+}
+
 inline bool infonce_d_ok(int d) { return d == 32 || d == 64 || d == 128 || d == 256; }
 
 }  // namespace
@@ -460,7 +753,10 @@ int infonce_fwd_impl(const float* const* z1s, const float* z2, const int64_t* id
   hipLaunchKernelGGL(prep_kernel, dim3(rb, P), dim3(kBlock), 0, s, Z, z2, idx, n, d, ws, L.total, L);
   MMSSL_LAUNCH_CHECK();
   const dim3 grid(nt * L.cs_f, P);
-  switch (d) {
+  if (use_mfma(d)) {
+    if (d == 32) hipLaunchKernelGGL((fwd_tiles_mfma_kernel<32>), grid, dim3(kBlock), 0, s, ws, L.total, L, n, tau, L.cs_f);
+    else hipLaunchKernelGGL((fwd_tiles_mfma_kernel<64>), grid, dim3(kBlock), 0, s, ws, L.total, L, n, tau, L.cs_f);
+  } else switch (d) {
     case 32: hipLaunchKernelGGL((fwd_tiles_kernel<32>), grid, dim3(kBlock), 0, s, ws, L.total, L, n, tau, L.cs_f); break;
     case 64: hipLaunchKernelGGL((fwd_tiles_kernel<64>), grid, dim3(kBlock), 0, s, ws, L.total, L, n, tau, L.cs_f); break;
     case 128: hipLaunchKernelGGL((fwd_tiles_kernel<128>), grid, dim3(kBlock), 0, s, ws, L.total, L, n, tau, L.cs_f); break;
@@ -496,7 +792,14 @@ int infonce_bwd_impl(const int64_t* idx, int P, int64_t n, int d, float tau, con
   hipStream_t s = as_stream(stream);
   const int nt = n_tiles(n);
   const dim3 grid(nt * L.cs_b, P);
-  if (phases & 1) {
+  if ((phases & 1) && use_mfma(d)) {
+    const bool single = (nt + L.cs_b - 1) / L.cs_b <= 4;      // pair tiles per block <= waves per block
+    if (d == 32 && single) hipLaunchKernelGGL((bwd_tiles_mfma_kernel<32, true>), grid, dim3(kBlock), 0, s, ws, L.total, L, n, tau, L.cs_b);
+    else if (d == 32) hipLaunchKernelGGL((bwd_tiles_mfma_kernel<32, false>), grid, dim3(kBlock), 0, s, ws, L.total, L, n, tau, L.cs_b);
+    else if (single) hipLaunchKernelGGL((bwd_tiles_mfma_kernel<64, true>), grid, dim3(kBlock), 0, s, ws, L.total, L, n, tau, L.cs_b);
+    else hipLaunchKernelGGL((bwd_tiles_mfma_kernel<64, false>), grid, dim3(kBlock), 0, s, ws, L.total, L, n, tau, L.cs_b);
+    MMSSL_LAUNCH_CHECK();
+  } else if (phases & 1) {
     switch (d) {
       case 32: hipLaunchKernelGGL((bwd_tiles_kernel<32>), grid, dim3(kBlock), 0, s, ws, L.total, L, n, tau, L.cs_b); break;
       case 64: hipLaunchKernelGGL((bwd_tiles_kernel<64>), grid, dim3(kBlock), 0, s, ws, L.total, L, n, tau, L.cs_b); break;

@@ -6,14 +6,18 @@
 //   forward : Y[M,N]  = dropout(F[M,K] . W[N,K]^T + b)          (F streamed once from HBM)
 //   wgrad   : gW[N,K] = gY[M,N]^T . F[M,K],  gb[N] = colsum(gY)
 //
-// One kernel body: a 256-thread block (2x2 waves, one 32x32 MFMA accumulator each) owns a
-// 64x64 output tile and walks its reduction range in 32-deep slices. Operand slices are
-// fetched global->registers one slice ahead (full 128-B row segments), written to a
-// double-buffered k-major LDS image (row stride 65 floats: conflict-free ds_write_b32 of the
-// transposed slice and conflict-free ds_read_b32 of the MFMA fragments), one barrier per
-// slice. The reduction dimension is split over blockIdx.z so that >= ~4 blocks per CU exist
-// even for M = 18K; split partials are summed in a fixed order by a small epilogue kernel
-// that also applies bias + dropout (deterministic, no float atomics).
+// Tiling (both kernels): a 256-thread block (2x2 waves, one 32x32 MFMA accumulator each) owns a
+// 64x64 output tile and walks its reduction range in 32-deep slices; the reduction dimension is
+// split over blockIdx.z so that >= ~4 blocks per CU exist even for M = 18K; split partials are
+// summed in a fixed order by a small epilogue kernel that also applies bias + dropout
+// (deterministic, no float atomics).
+//   gemm64_kernel<DIRECT>  register-staged: slices fetched global->registers one slice ahead,
+//       written to a double-buffered k-major LDS image (row stride 65: conflict-free transposed
+//       ds_write_b32 and fragment ds_read_b32), one barrier per slice. Used for wgrad (both
+//       operand layouts, ragged reduction length, dropout mask applied while fetching gY) and as the
+//       forward fallback for K ranges that are not whole slices.
+//   gemm_fwd_dma_kernel    forward default: slices go global->LDS by LDS-DMA into a 4-stage ring
+//       (XOR-swizzled through the source addresses), fragments come back as ds_read_b128.
 #include <cstdlib>
 
 #include "common.hpp"
@@ -146,213 +150,121 @@ __global__ __launch_bounds__(kBlock) void gemm64_kernel(const float* __restrict_
   }
 }
 
+
 // ======================================================================================
-// v2 kernel: each wave owns a 64x64 output patch (2x2 MFMA tiles, four INDEPENDENT 32x32 accumulators),
-// so one A and one B fragment feed two MFMAs each (MFMA : ds_read = 1 : 1 instead of 1 : 2) and a
-// 32-deep slice carries 64 MFMAs (4096 pipe cycles) per wave between barriers instead of 16.
-// The 4 waves of a block are stacked along the LONG output dimension: 256x64 (forward: rows of F)
-// or 64x256 (wgrad: columns of gW). One LDS image per operand (~41 KB per block -> 3 blocks per CU),
-// next slice prefetched global->registers during the MFMA phase, two barriers per slice.
+// v5 forward kernel: same 64x64 block tile / 32x32-per-wave MFMA tiling, but the operand slices go
+// global -> LDS by LDS-DMA (global_load_lds_dwordx4: no VGPR round trip, no ds_write pass) into a
+// 4-stage ring (3 slices = 24 KB of F in flight per block), and the fragments come back with
+// ds_read_b128. Decomposition runs of v4 (MMSSL_GEMM_MODE) showed the forward is bound by what returns
+// INTO the VGPRs: VMEM load returns and LDS fragment reads add up (stream-only 55 us, MFMA+LDS-only
+// 70 us, both 110 us, unchanged without LDS stores or without barriers). LDS-DMA removes the first term.
+//
+// LDS image of one operand slice: 64 rows x 8 chunks of 16 B, chunk c of row i at slot
+// i*8 + (c ^ ((i >> 1) & 7)). LDS-DMA writes lane-linearly (M0 base + lane*16), so the XOR swizzle is
+// applied to each lane's SOURCE address; the same involution is applied when reading. With it the 16-lane
+// groups of ds_read_b128 ({0-3,12-15,20-27}, ...) cover all 64 banks exactly once.
+// A lane's float4 (4 consecutive k) feeds 4 MFMA steps; step 4q+e contracts k = {8q+e, 8q+4+e}
+// (the pairing of k indices is free as long as A and B agree).
+// Preconditions (host-checked): chunk % 32 == 0, KK % chunk == 0, chunk >= 96, row-major [i][kk] operands.
 // ======================================================================================
-template <bool DIRECT, int BT>
-__device__ __forceinline__ void fetch_tile(const float* __restrict__ P, int64_t ld, int64_t i0, int64_t I,
-                                           int64_t kk0, int64_t kk_end, float4 (&r)[BT / 32]) {
-  constexpr int NF = BT / 32;        // float4 per thread: BT * BK / (256 * 4)
-  const int tid = threadIdx.x;
-#pragma unroll
-  for (int p = 0; p < NF; ++p) {
-    r[p] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (!DIRECT) {
-      const int64_t i = i0 + (tid >> 3) + 32 * p;
-      const int64_t kk = kk0 + 4 * (tid & 7);
-      if (i < I && kk < kk_end) r[p] = *reinterpret_cast<const float4*>(P + i * ld + kk);
-    } else {
-      constexpr int LPRW = BT / 4;            // lanes per slice row
-      const int64_t kk = kk0 + tid / LPRW + (kBlock / LPRW) * p;
-      const int64_t i = i0 + 4 * (tid % LPRW);
-      if (kk < kk_end && i < I) r[p] = *reinterpret_cast<const float4*>(P + kk * ld + i);
-    }
-  }
+constexpr int kDmaStages = 4;
+constexpr int kDmaStageFloats = 2 * BT * BK;        // A slice then B slice: 8 KB + 8 KB
+
+__device__ __forceinline__ void glds16(const float* gsrc, unsigned lds_dst) {
+  unsigned keep_m0;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep_m0)
+      : "v"(gsrc), "s"(lds_dst)
+      : "memory");
+}
+template <int N>
+__device__ __forceinline__ void vm_wait_n() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+__device__ __forceinline__ void bare_barrier() {
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
 }
 
-template <bool DIRECT, int BT>
-__device__ __forceinline__ void store_tile(float* __restrict__ S, const float4 (&r)[BT / 32]) {
-  constexpr int NF = BT / 32;
-  constexpr int LD = BT + (DIRECT ? 4 : 1);
-  const int tid = threadIdx.x;
-#pragma unroll
-  for (int p = 0; p < NF; ++p) {
-    if (!DIRECT) {
-      const int i = (tid >> 3) + 32 * p, k = 4 * (tid & 7);
-      S[(k + 0) * LD + i] = r[p].x;
-      S[(k + 1) * LD + i] = r[p].y;
-      S[(k + 2) * LD + i] = r[p].z;
-      S[(k + 3) * LD + i] = r[p].w;
-    } else {
-      constexpr int LPRW = BT / 4;
-      const int k = tid / LPRW + (kBlock / LPRW) * p, i = 4 * (tid % LPRW);
-      *reinterpret_cast<float4*>(S + k * LD + i) = r[p];
-    }
-  }
-}
-
-template <bool DIRECT, int WM, int WN>
-__global__ __launch_bounds__(kBlock) void gemm_w64_kernel(const float* __restrict__ A, int64_t lda,
-                                                          const float* __restrict__ B, int64_t ldb, int64_t I,
-                                                          int64_t J, int64_t KK, int64_t kk_chunk,
-                                                          float* __restrict__ C, int64_t ldc, int64_t split_stride,
-                                                          const float* __restrict__ bias,
-                                                          const uint8_t* __restrict__ keep, float scale) {
-  static_assert(WM * WN == 4, "four waves per block");
-  constexpr int BTI = WM * 64, BTJ = WN * 64;
-  constexpr int LDI = BTI + (DIRECT ? 4 : 1), LDJ = BTJ + (DIRECT ? 4 : 1);
-  __shared__ __attribute__((aligned(16))) float As[BK * LDI];
-  __shared__ __attribute__((aligned(16))) float Bs[BK * LDJ];
+__global__ __launch_bounds__(kBlock) void gemm_fwd_dma_kernel(const float* __restrict__ A, int64_t lda,
+                                                              const float* __restrict__ B, int64_t ldb, int64_t I,
+                                                              int64_t J, int64_t kk_chunk, float* __restrict__ C,
+                                                              int64_t ldc, int64_t split_stride,
+                                                              const float* __restrict__ bias,
+                                                              const uint8_t* __restrict__ keep, float scale) {
+  __shared__ __attribute__((aligned(16))) float ring[kDmaStages * kDmaStageFloats];     // 64 KB
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave / WN, wn = wave % WN;
-  const int64_t i0 = (int64_t)blockIdx.x * BTI, j0 = (int64_t)blockIdx.y * BTJ;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int64_t i0 = (int64_t)blockIdx.x * BT, j0 = (int64_t)blockIdx.y * BT;
   const int64_t kk_beg = (int64_t)blockIdx.z * kk_chunk;
-  const int64_t kk_end = min(KK, kk_beg + kk_chunk);
-  const int nk = (int)((kk_end - kk_beg + BK - 1) / BK);
-  floatx16 acc[2][2];
+  const int nk = (int)(kk_chunk / BK);
+  floatx16 acc;
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  // DMA pieces: wave w moves rows [16w, 16w+16) of each operand slice as 2 x (8 rows x 128 B)
+  const float* pa[2];
+  const float* pb[2];
 #pragma unroll
-    for (int b = 0; b < 2; ++b)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-  float4 ra[BTI / 32], rb[BTJ / 32];
-  if (nk > 0) {
-    fetch_tile<DIRECT, BTI>(A, lda, i0, I, kk_beg, kk_end, ra);
-    fetch_tile<DIRECT, BTJ>(B, ldb, j0, J, kk_beg, kk_end, rb);
-    store_tile<DIRECT, BTI>(As, ra);
-    store_tile<DIRECT, BTJ>(Bs, rb);
+  for (int j = 0; j < 2; ++j) {
+    const int r = 16 * wave + 8 * j + (lane >> 3);
+    const int c = (lane & 7) ^ ((r >> 1) & 7);                  // source-side swizzle
+    pa[j] = A + min(i0 + r, I - 1) * lda + kk_beg + 4 * c;
+    pb[j] = B + min(j0 + r, J - 1) * ldb + kk_beg + 4 * c;
   }
-  __syncthreads();
-  const float* as = As + (lane >> 5) * LDI + wm * 64 + (lane & 31);
-  const float* bs = Bs + (lane >> 5) * LDJ + wn * 64 + (lane & 31);
+  const unsigned ring_lds = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)ring);
+  const unsigned piece = __builtin_amdgcn_readfirstlane((unsigned)(16 * wave * BK * 4));
+  auto issue = [&](int kt) {
+    const unsigned st = ring_lds + (unsigned)(kt & (kDmaStages - 1)) * (kDmaStageFloats * 4) + piece;
+    glds16(pa[0] + (int64_t)kt * BK, st);
+    glds16(pa[1] + (int64_t)kt * BK, st + 8 * BK * 4);
+    glds16(pb[0] + (int64_t)kt * BK, st + BT * BK * 4);
+    glds16(pb[1] + (int64_t)kt * BK, st + BT * BK * 4 + 8 * BK * 4);
+  };
+  issue(0);
+  issue(1);
+  issue(2);
+  const int h = lane >> 5, lr = lane & 31;
+  const int sw = (lr >> 1) & 7;
+  const int ia = (wm * 32 + lr) * BK, jb = BT * BK + (wn * 32 + lr) * BK;
   for (int kt = 0; kt < nk; ++kt) {
-    if (kt + 1 < nk) {   // next slice: global -> registers while this slice is multiplied
-      fetch_tile<DIRECT, BTI>(A, lda, i0, I, kk_beg + (int64_t)(kt + 1) * BK, kk_end, ra);
-      fetch_tile<DIRECT, BTJ>(B, ldb, j0, J, kk_beg + (int64_t)(kt + 1) * BK, kk_end, rb);
+    // this wave's pieces of slice kt have landed when at most the pieces of the slices issued after it remain
+    if (kt + 2 < nk) vm_wait_n<8>();
+    else if (kt + 1 < nk) vm_wait_n<4>();
+    else vm_wait_n<0>();
+    bare_barrier();          // everyone's pieces of slice kt are in LDS; stage (kt-1)&3 is no longer read
+    if (kt + 3 < nk) issue(kt + 3);
+    const float* st = ring + (kt & (kDmaStages - 1)) * kDmaStageFloats;
+    float4 fa[4], fb[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int pos = ((2 * q + h) ^ sw) * 4;
+      fa[q] = *reinterpret_cast<const float4*>(st + ia + pos);
+      fb[q] = *reinterpret_cast<const float4*>(st + jb + pos);
     }
 #pragma unroll
-    for (int s = 0; s < BK / 2; ++s) {
-      const float a0 = as[2 * s * LDI], a1 = as[2 * s * LDI + 32];
-      const float b0 = bs[2 * s * LDJ], b1 = bs[2 * s * LDJ + 32];
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+    for (int q = 0; q < 4; ++q) {
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[q].x, fb[q].x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[q].y, fb[q].y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[q].z, fb[q].z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[q].w, fb[q].w, acc, 0, 0, 0);
     }
-    __syncthreads();                       // every wave is done reading this slice
-    if (kt + 1 < nk) {
-      store_tile<DIRECT, BTI>(As, ra);
-      store_tile<DIRECT, BTJ>(Bs, rb);
-    }
-    __syncthreads();
   }
+  const int64_t col = j0 + wn * 32 + (lane & 31);
   float* Cp = C + (int64_t)blockIdx.z * split_stride;
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int b = 0; b < 2; ++b) {
-      const int64_t col = j0 + wn * 64 + b * 32 + (lane & 31);
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int64_t row = i0 + wm * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (row < I && col < J) {
-          float v = acc[a][b][r];
-          if (bias) v += bias[col];
-          if (keep) v = keep[row * J + col] ? v * scale : 0.f;
-          Cp[row * ldc + col] = v;
-        }
-      }
+  for (int r = 0; r < 16; ++r) {
+    const int64_t row = i0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+    if (row < I && col < J) {
+      float v = acc[r];
+      if (bias) v += bias[col];
+      if (keep) v = keep[row * J + col] ? v * scale : 0.f;
+      Cp[row * ldc + col] = v;
     }
+  }
 }
 
-// ======================================================================================
-// v3 forward kernel: barrier-free, LDS-free. Every WAVE streams its own 32 x N output tile over a K range:
-// both MFMA operands (v_mfma_f32_16x16x4_f32) are loaded straight from global memory in fragment order —
-// lane (i = l&15, q = l>>4) reads the float4 F[row i][k + 4q .. +3]; element j of that float4 is the
-// k-slot-q operand of MFMA step j, and W is read with the same (q, j) -> k map, so the sum over the 4
-// slots and the 4 steps covers 16 consecutive k exactly once. Two register sets are ping-ponged (next
-// 16 k in flight while the current 16 are multiplied); waves never synchronise, so load latency of one
-// wave hides behind the MFMAs of the others. The 4 waves of a block take 4 consecutive row tiles of the
-// SAME K range, so their W fragments hit in the CU's L1. Rows past M are clamped (valid reads, results
-// discarded); requires K % 32 == 0 and N in {64, 128}; partials go through splitk_reduce_kernel.
-// ======================================================================================
-typedef float floatx4 __attribute__((ext_vector_type(4)));
-
-template <int NT>
-__global__ __launch_bounds__(kBlock) void gemm_fwd_direct_kernel(const float* __restrict__ F,
-                                                                 const float* __restrict__ W, int64_t M, int K,
-                                                                 int k_chunk, float* __restrict__ P) {
-  constexpr int N = NT * 16;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int li = lane & 15, lq = lane >> 4;
-  const int64_t m0 = ((int64_t)blockIdx.x * 4 + wave) * 32;
-  if (m0 >= M) return;                                   // no barriers in this kernel
-  const int k_beg = blockIdx.y * k_chunk;
-  const int k_end = min(K, k_beg + k_chunk);
-  const float* ap[2];
-#pragma unroll
-  for (int mt = 0; mt < 2; ++mt) {
-    int64_t r = m0 + mt * 16 + li;
-    r = r < M ? r : M - 1;
-    ap[mt] = F + r * K + 4 * lq;
-  }
-  const float* bp = W + (int64_t)li * K + 4 * lq;        // n-tile nt adds nt*16*K
-  floatx4 acc[2][NT];
-#pragma unroll
-  for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) acc[mt][nt][r] = 0.f;
-  float4 a0[2], b0[NT], a1[2], b1[NT];
-  auto load = [&](float4 (&a)[2], float4 (&b)[NT], int k) {
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt) a[mt] = *reinterpret_cast<const float4*>(ap[mt] + k);
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) b[nt] = *reinterpret_cast<const float4*>(bp + (int64_t)nt * 16 * K + k);
-  };
-  auto mul = [&](const float4 (&a)[2], const float4 (&b)[NT]) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-          const float av = j == 0 ? a[mt].x : j == 1 ? a[mt].y : j == 2 ? a[mt].z : a[mt].w;
-          const float bv = j == 0 ? b[nt].x : j == 1 ? b[nt].y : j == 2 ? b[nt].z : b[nt].w;
-          acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[mt][nt], 0, 0, 0);
-        }
-  };
-  load(a0, b0, k_beg);
-  int k = k_beg;
-  for (; k + 32 < k_end; k += 32) {      // steady state: no conditional loads, so the counted vmcnt waits
-    load(a1, b1, k + 16);                //  only ever wait for the set that is about to be multiplied
-    mul(a0, b0);
-    load(a0, b0, k + 32);
-    mul(a1, b1);
-  }
-  load(a1, b1, k + 16);                  // peeled last 32
-  mul(a0, b0);
-  mul(a1, b1);
-  // C/D layout of the 16x16 MFMA: col = lane & 15, row = (lane >> 4) * 4 + reg
-  float* Pp = P + (int64_t)blockIdx.y * M * N;
-#pragma unroll
-  for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int64_t row = m0 + mt * 16 + lq * 4 + r;
-      if (row < M) {
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) Pp[row * N + nt * 16 + li] = acc[mt][nt][r];
-      }
-    }
-}
 
 // out[e] = epilogue(sum_s P[s][e]);  e = row*J + col.  Split loads are issued four at a time
 // (independent) so the loop is bandwidth- not latency-bound; the add order is fixed.
@@ -440,44 +352,15 @@ __global__ __launch_bounds__(kBlock) void colsum_stage2(const float* __restrict_
   colsum_body(part, 0, kBlock / N, nparts, N, out);
 }
 
-// 1 (default): 64x64 block tile, 32x32 per wave.  2: 64x64 per wave (gemm_w64_kernel).
-// Measured on MI355X (Baby image projection, K=4096): v1 132 / 127 us (fwd / wgrad), v2 139 / 126 us:
-// both sit at ~75 TF because the limiter is the bulk-synchronous load -> wait -> MFMA cadence
-// (tools/overlap_probe.py), not the LDS:MFMA ratio.
-inline int gemm_version() {
-  static int v = getenv("MMSSL_GEMM_V") ? atoi(getenv("MMSSL_GEMM_V")) : 1;
-  return v;
+// Forward kernel choice. Default: the LDS-DMA kernel whenever the K range splits into whole 32-deep slices
+// (every Tiktok / Baby / stress shape); MMSSL_GEMM_V=1 forces the register-staged kernel everywhere.
+// Measured on MI355X, Baby image projection [18357,4096]x[4096,64], kernel + split reduce under a hipGraph:
+// register-staged 137-141 us (70 TF), LDS-DMA 130-132 us (73-74 TF); DESIGN.md section 4 has the
+// decomposition runs that explain why both sit near 75 TF.
+inline bool dma_enabled() {
+  static const int v = getenv("MMSSL_GEMM_V") ? atoi(getenv("MMSSL_GEMM_V")) : 5;
+  return v != 1;
 }
-// v2: ~3 blocks of 41 KB LDS per CU
-inline int choose_splits_v2(int64_t tiles, int64_t KK) {
-  const int64_t slices = (KK + BK - 1) / BK;
-  if (const char* e = getenv("MMSSL_GEMM_SPLITS")) {
-    const int64_t f = atoi(e);
-    if (f >= 1) return (int)(f > slices ? slices : f);
-  }
-  static const int target = getenv("MMSSL_GEMM_TARGET_BLOCKS") ? atoi(getenv("MMSSL_GEMM_TARGET_BLOCKS")) : 768;
-  int64_t s = (target + tiles - 1) / tiles;
-  const int64_t max_s = slices / 4 > 0 ? slices / 4 : 1;
-  if (s > max_s) s = max_s;
-  if (s < 1) s = 1;
-  return (int)s;
-}
-
-// v3: one wave per 32-row tile and K range; aim for ~4-5 waves per SIMD (4096+ waves), K ranges
-// multiples of 32 and at least 128 deep
-inline int direct_splits(int64_t M, int K) {
-  if (const char* e = getenv("MMSSL_GEMM_SPLITS")) {
-    const int f = atoi(e);
-    if (f >= 1) return f > K / 32 ? K / 32 : f;
-  }
-  const int64_t tiles = (M + 31) / 32;
-  int64_t s = (4608 + tiles - 1) / tiles;
-  const int64_t max_s = K / 128 > 0 ? K / 128 : 1;
-  if (s > max_s) s = max_s;
-  if (s < 1) s = 1;
-  return (int)s;
-}
-inline int direct_chunk(int K, int splits) { return (((K / 32) + splits - 1) / splits) * 32; }
 
 // split count: aim for >= ~4 blocks per CU, every split at least 4 slices deep
 inline int choose_splits(int64_t tiles, int64_t KK) {
@@ -501,14 +384,8 @@ inline int64_t chunk_for(int64_t KK, int splits) {
 
 extern "C" size_t mmssl_linear_workspace_bytes(int64_t M, int K, int N) {
   if (M <= 0 || K <= 0 || N <= 0) return 16;
-  const bool v2 = gemm_version() == 2;
-  const int64_t tiles = v2 ? ((M + 255) / 256) * ((N + 63) / 64) : ((M + BT - 1) / BT) * ((N + BT - 1) / BT);
-  int splits = v2 ? choose_splits_v2(tiles, K) : choose_splits(tiles, K);
-  if (gemm_version() == 3 && (K % 32) == 0 && (N == 64 || N == 128)) {
-    const int s3 = direct_splits(M, K);
-    splits = s3 > splits ? s3 : splits;
-    if (splits < 2) splits = 2;            // v3 always goes through the partial buffer
-  }
+  const int64_t tiles = ((M + BT - 1) / BT) * ((N + BT - 1) / BT);
+  const int splits = choose_splits(tiles, K);
   return splits > 1 ? (size_t)splits * (size_t)M * (size_t)N * sizeof(float) : 16;
 }
 
@@ -520,84 +397,43 @@ extern "C" int mmssl_linear_f32(const float* F, const float* W, const float* b, 
   if (M == 0) return 0;
   if (((uintptr_t)F | (uintptr_t)W | (uintptr_t)Y) & 15) return MMSSL_E_BADARG;
   hipStream_t s = as_stream(stream);
-  if (gemm_version() == 3 && (K % 32) == 0 && (N == 64 || N == 128)) {
-    const int sp = direct_splits(M, K);
-    const int kc = direct_chunk(K, sp);
-    const size_t need3 = (size_t)sp * (size_t)M * (size_t)N * sizeof(float);
-    if (!workspace || workspace_bytes < need3) return MMSSL_E_WORKSPACE;
-    float* P3 = reinterpret_cast<float*>(workspace);
-    const dim3 grid3((unsigned)((M + 127) / 128), (unsigned)sp);
-    if (N == 64)
-      hipLaunchKernelGGL((gemm_fwd_direct_kernel<4>), grid3, dim3(kBlock), 0, s, F, W, M, K, kc, P3);
-    else
-      hipLaunchKernelGGL((gemm_fwd_direct_kernel<8>), grid3, dim3(kBlock), 0, s, F, W, M, K, kc, P3);
-    MMSSL_LAUNCH_CHECK();
-    const int64_t total3 = M * N;
-    int64_t nb3 = (total3 / 4 + kBlock - 1) / kBlock;
-    nb3 = nb3 > 4096 ? 4096 : (nb3 < 1 ? 1 : nb3);
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)nb3), dim3(kBlock), 0, s, P3, sp, total3, (int64_t)N, b,
-                       keep, scale, Y);
-    MMSSL_LAUNCH_CHECK();
-    return 0;
-  }
-  if (gemm_version() == 2) {
-    const int64_t tm2 = (M + 255) / 256, tn2 = (N + 63) / 64;
-    const int sp = choose_splits_v2(tm2 * tn2, K);
-    const int64_t ch = chunk_for(K, sp);
-    if (sp == 1) {
-      hipLaunchKernelGGL((gemm_w64_kernel<false, 4, 1>), dim3((unsigned)tm2, (unsigned)tn2, 1), dim3(kBlock), 0, s, F,
-                         (int64_t)K, W, (int64_t)K, M, (int64_t)N, (int64_t)K, ch, Y, (int64_t)N, (int64_t)0, b, keep,
-                         scale);
-      MMSSL_LAUNCH_CHECK();
-      return 0;
-    }
-    const size_t need2 = (size_t)sp * (size_t)M * (size_t)N * sizeof(float);
-    if (!workspace || workspace_bytes < need2) return MMSSL_E_WORKSPACE;
-    float* P2 = reinterpret_cast<float*>(workspace);
-    hipLaunchKernelGGL((gemm_w64_kernel<false, 4, 1>), dim3((unsigned)tm2, (unsigned)tn2, (unsigned)sp), dim3(kBlock),
-                       0, s, F, (int64_t)K, W, (int64_t)K, M, (int64_t)N, (int64_t)K, ch, P2, (int64_t)N,
-                       (int64_t)M * N, (const float*)nullptr, (const uint8_t*)nullptr, 1.f);
-    MMSSL_LAUNCH_CHECK();
-    const int64_t total2 = M * N;
-    int64_t nb2 = (total2 / 4 + kBlock - 1) / kBlock;
-    nb2 = nb2 > 4096 ? 4096 : (nb2 < 1 ? 1 : nb2);
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)nb2), dim3(kBlock), 0, s, P2, sp, total2, (int64_t)N, b,
-                       keep, scale, Y);
-    MMSSL_LAUNCH_CHECK();
-    return 0;
-  }
   const int64_t tm = (M + BT - 1) / BT, tn = (N + BT - 1) / BT;
   const int splits = choose_splits(tm * tn, K);
   const int64_t chunk = chunk_for(K, splits);
-  if (splits == 1) {
-    hipLaunchKernelGGL((gemm64_kernel<false>), dim3((unsigned)tm, (unsigned)tn, 1), dim3(kBlock), 0, s, F,
-                       (int64_t)K, W, (int64_t)K, M, (int64_t)N, (int64_t)K, chunk, Y, (int64_t)N, (int64_t)0, b,
-                       keep, scale, (const uint8_t*)nullptr, 1.f);
-    MMSSL_LAUNCH_CHECK();
-    return 0;
+  // LDS-DMA kernel: whole slices only, at least the 3 slices its prologue puts in flight
+  const bool dma = dma_enabled() && (chunk % BK) == 0 && chunk >= 3 * BK && (int64_t)splits * chunk == K;
+  float* out = Y;
+  if (splits > 1) {
+    const size_t need = (size_t)splits * (size_t)M * (size_t)N * sizeof(float);
+    if (!workspace || workspace_bytes < need) return MMSSL_E_WORKSPACE;
+    out = reinterpret_cast<float*>(workspace);
   }
-  const size_t need = (size_t)splits * (size_t)M * (size_t)N * sizeof(float);
-  if (!workspace || workspace_bytes < need) return MMSSL_E_WORKSPACE;
-  float* P = reinterpret_cast<float*>(workspace);
-  hipLaunchKernelGGL((gemm64_kernel<false>), dim3((unsigned)tm, (unsigned)tn, (unsigned)splits), dim3(kBlock), 0,
-                     s, F, (int64_t)K, W, (int64_t)K, M, (int64_t)N, (int64_t)K, chunk, P, (int64_t)N,
-                     (int64_t)M * N, (const float*)nullptr, (const uint8_t*)nullptr, 1.f, (const uint8_t*)nullptr, 1.f);
+  // single split: bias + dropout in the kernel's own epilogue; otherwise in the fixed-order split reduce
+  const float* kb = splits > 1 ? (const float*)nullptr : b;
+  const uint8_t* kk = splits > 1 ? (const uint8_t*)nullptr : keep;
+  const int64_t sstride = splits > 1 ? (int64_t)M * N : (int64_t)0;
+  const dim3 grid((unsigned)tm, (unsigned)tn, (unsigned)splits);
+  if (dma)
+    hipLaunchKernelGGL(gemm_fwd_dma_kernel, grid, dim3(kBlock), 0, s, F, (int64_t)K, W, (int64_t)K, M, (int64_t)N, chunk,
+                       out, (int64_t)N, sstride, kb, kk, scale);
+  else
+    hipLaunchKernelGGL((gemm64_kernel<false>), grid, dim3(kBlock), 0, s, F, (int64_t)K, W, (int64_t)K, M, (int64_t)N,
+                       (int64_t)K, chunk, out, (int64_t)N, sstride, kb, kk, scale, (const uint8_t*)nullptr, 1.f);
   MMSSL_LAUNCH_CHECK();
-  const int64_t total = M * N;
-  int64_t nb = (total / 4 + kBlock - 1) / kBlock;
-  nb = nb > 4096 ? 4096 : (nb < 1 ? 1 : nb);
-  hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)nb), dim3(kBlock), 0, s, P, splits, total, (int64_t)N,
-                     b, keep, scale, Y);
-  MMSSL_LAUNCH_CHECK();
+  if (splits > 1) {
+    const int64_t total = M * N;
+    int64_t nb = (total / 4 + kBlock - 1) / kBlock;
+    nb = nb > 4096 ? 4096 : (nb < 1 ? 1 : nb);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)nb), dim3(kBlock), 0, s, out, splits, total, (int64_t)N, b,
+                       keep, scale, Y);
+    MMSSL_LAUNCH_CHECK();
+  }
   return 0;
 }
 
 extern "C" size_t mmssl_linear_wgrad_workspace_bytes(int64_t M, int K, int N) {
   if (M <= 0 || K <= 0 || N <= 0) return 16;
-  // large enough for either kernel version (the masked-fetch form always uses v1)
-  const int s1 = choose_splits(((N + BT - 1) / BT) * ((K + BT - 1) / BT), M);
-  const int s2 = choose_splits_v2(((N + 63) / 64) * ((K + 255) / 256), M);
-  const int splits = s1 > s2 ? s1 : s2;
+  const int splits = choose_splits(((N + BT - 1) / BT) * ((K + BT - 1) / BT), M);
   const size_t part = splits > 1 ? (size_t)splits * (size_t)N * (size_t)K * sizeof(float) : 0;
   return part + (size_t)kColsumBlocks * (size_t)N * sizeof(float) + 16;
 }
@@ -609,39 +445,19 @@ extern "C" int mmssl_linear_wgrad_f32(const float* gY, const uint8_t* keep, floa
   if ((K & 3) || (N & 3) || N > 256) return MMSSL_E_UNSUPP;
   if (!workspace || workspace_bytes < mmssl_linear_wgrad_workspace_bytes(M, K, N)) return MMSSL_E_WORKSPACE;
   hipStream_t s = as_stream(stream);
-  const bool v2 = gemm_version() == 2 && keep == nullptr;
-  const int64_t tn = v2 ? (N + 63) / 64 : (N + BT - 1) / BT, tk = v2 ? (K + 255) / 256 : (K + BT - 1) / BT;
-  const int splits = v2 ? choose_splits_v2(tn * tk, M) : choose_splits(tn * tk, M);
+  const int64_t tn = (N + BT - 1) / BT, tk = (K + BT - 1) / BT;
+  const int splits = choose_splits(tn * tk, M);
   const int64_t chunk = chunk_for(M, splits);
   float* ws = reinterpret_cast<float*>(workspace);
   float* colpart = ws;                                   // [kColsumBlocks][N]
   float* P = ws + (size_t)kColsumBlocks * N;             // [splits][N][K]
-  if (v2) {
-    float* dst = splits == 1 ? gW : P;
-    hipLaunchKernelGGL((gemm_w64_kernel<true, 1, 4>), dim3((unsigned)tn, (unsigned)tk, (unsigned)splits), dim3(kBlock),
-                       0, s, gY, (int64_t)N, F, (int64_t)K, (int64_t)N, (int64_t)K, M, chunk, dst, (int64_t)K,
-                       splits == 1 ? (int64_t)0 : (int64_t)N * K, (const float*)nullptr, (const uint8_t*)nullptr, 1.f);
-    MMSSL_LAUNCH_CHECK();
-    if (splits > 1) {
-      const int64_t total = (int64_t)N * K;
-      int64_t nb = (total / 4 + kBlock - 1) / kBlock;
-      nb = nb > 4096 ? 4096 : (nb < 1 ? 1 : nb);
-      hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)nb), dim3(kBlock), 0, s, P, splits, total, (int64_t)K,
-                         (const float*)nullptr, (const uint8_t*)nullptr, 1.f, gW);
-      MMSSL_LAUNCH_CHECK();
-    }
-  } else
   // gW[n][k] = sum_m gY[m][n] * F[m][k]: A = gY as [kk=m][i=n], B = F as [kk=m][j=k]
-  if (splits == 1) {
-    hipLaunchKernelGGL((gemm64_kernel<true>), dim3((unsigned)tn, (unsigned)tk, 1), dim3(kBlock), 0, s, gY,
-                       (int64_t)N, F, (int64_t)K, (int64_t)N, (int64_t)K, M, chunk, gW, (int64_t)K, (int64_t)0,
-                       (const float*)nullptr, (const uint8_t*)nullptr, 1.f, keep, scale);
-    MMSSL_LAUNCH_CHECK();
-  } else {
-    hipLaunchKernelGGL((gemm64_kernel<true>), dim3((unsigned)tn, (unsigned)tk, (unsigned)splits), dim3(kBlock),
-                       0, s, gY, (int64_t)N, F, (int64_t)K, (int64_t)N, (int64_t)K, M, chunk, P, (int64_t)K,
-                       (int64_t)N * K, (const float*)nullptr, (const uint8_t*)nullptr, 1.f, keep, scale);
-    MMSSL_LAUNCH_CHECK();
+  hipLaunchKernelGGL((gemm64_kernel<true>), dim3((unsigned)tn, (unsigned)tk, (unsigned)splits), dim3(kBlock), 0, s, gY,
+                     (int64_t)N, F, (int64_t)K, (int64_t)N, (int64_t)K, M, chunk, splits == 1 ? gW : P, (int64_t)K,
+                     splits == 1 ? (int64_t)0 : (int64_t)N * K, (const float*)nullptr, (const uint8_t*)nullptr, 1.f,
+                     keep, scale);
+  MMSSL_LAUNCH_CHECK();
+  if (splits > 1) {
     const int64_t total = (int64_t)N * K;
     int64_t nb = (total / 4 + kBlock - 1) / kBlock;
     nb = nb > 4096 ? 4096 : (nb < 1 ? 1 : nb);

@@ -93,7 +93,25 @@ int mmssl_plan_fill_host(const int32_t* rowptr, int32_t rows, int32_t* group_ite
 /* extended (mmssl_spmm_ex_f32 only): the two epilogues that let the whole backward of the GCN
  * chain (Models.py:199-214: layer mean + last-layer softmax) consist of SpMM launches alone */
 #define MMSSL_EPI_AXPY             2  /* Y = A.X + alpha * Z[row]                               */
-#define MMSSL_EPI_AXPY_SOFTMAX_BWD 3  /* t = A.X + alpha * Z[row]; Y = S[row]*(t - <t,S[row]>)  */
+#define MMSSL_EPI_AXPY_SOFTMAX_BWD 3  /* ---- batch rows of the interaction pattern (SURVEY.md 8f "next #1") --------------------------------
+ * The reference builds `torch.tensor(self.ui_graph_raw[users].todense()).cuda()` — a dense
+ * [B, n_items] host matrix + upload — in every Trainer.u_sim_calculation call and for the
+ * discriminator's real-data rows (main.py:281-298, 349). These read the same pattern from the plan's
+ * device CSR (row u of g = the items of user u). rows: int64 device array of n row ids of g;
+ * width must equal the number of columns of g; P/S/gS/gP/out are [n, width] fp32, contiguous.
+ *   mask_normalize      in place: P[b, seen] = 0; P[b,:] /= max(|P[b,:]|, eps); inv_norm[b] = the factor
+ *                       (u_sim = F.normalize(sim * (1 - R[users])), main.py:293-297)
+ *   mask_normalize_bwd  gP = (1-R) * inv * (gS - S (S.gS))   (gS/eps for clamped rows)
+ *   rows_dense          out[b,:] = value * R[rows[b],:] */
+int mmssl_graph_rows_mask_normalize_f32(const mmssl_graph* g, const int64_t* rows, int64_t n, float* P,
+                                        int64_t width, float eps, float* inv_norm, void* stream);
+int mmssl_graph_rows_mask_normalize_bwd_f32(const mmssl_graph* g, const int64_t* rows, int64_t n,
+                                            const float* S, const float* gS, const float* inv_norm,
+                                            int64_t width, float eps, float* gP, void* stream);
+int mmssl_graph_rows_dense_f32(const mmssl_graph* g, const int64_t* rows, int64_t n, float value,
+                               float* out, int64_t width, void* stream);
+
+/* t = A.X + alpha * Z[row]; Y = S[row]*(t - <t,S[row]>)  */
 
 size_t mmssl_spmm_workspace_bytes(const mmssl_graph* g, int transpose, int d);
 int mmssl_spmm_f32(const mmssl_graph* g, int transpose, const float* X, int d, float* Y,

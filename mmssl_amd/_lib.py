@@ -34,6 +34,11 @@ SIGNATURES = {
                                          c_void_p, c_void_p, c_void_p]),
     "mmssl_plan_count_host": (c_int, [c_void_p, c_int32, _i64p]),
     "mmssl_plan_fill_host": (c_int, [c_void_p, c_int32, c_void_p, c_void_p, c_void_p]),
+    "mmssl_graph_rows_mask_normalize_f32": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_float, c_void_p,
+                                                    c_void_p]),
+    "mmssl_graph_rows_mask_normalize_bwd_f32": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p,
+                                                        c_int64, c_float, c_void_p, c_void_p]),
+    "mmssl_graph_rows_dense_f32": (c_int, [c_void_p, c_void_p, c_int64, c_float, c_void_p, c_int64, c_void_p]),
     "mmssl_spmm_workspace_bytes": (c_size_t, [c_void_p, c_int, c_int]),
     "mmssl_spmm_f32": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_size_t,
                                c_void_p]),

@@ -552,3 +552,127 @@ extern "C" int mmssl_spmm_f32(const mmssl_graph* g, int transpose, const float* 
   return mmssl_spmm_ex_f32(g, transpose, X, d, Y, epilogue, nullptr, 0.f, nullptr, workspace, workspace_bytes,
                            stream);
 }
+
+// =================================================================================================
+// Batch rows of the interaction PATTERN (which items a user has in the train matrix), read from the
+// plan's device CSR instead of the dense `ui_graph_raw[users].todense()` the reference uploads for
+// every u_sim_calculation call and for the real-data rows of the discriminator
+// (/root/reference/MMSSL/main.py:281-298, 349).
+//
+//   mask+normalise : S[b,:] = normalize(P[b,:] * (1 - R[rows[b],:]))        (main.py:293-297)
+//   its backward   : gP = (1 - R) * (gS - S (S.gS)) / |masked P|             (F.normalize backward; g/eps
+//                                                                            branch for clamped rows)
+//   dense rows     : out[b,:] = value * R[rows[b],:]                          (main.py:349 before the Gumbel noise)
+// One block per batch row; each row is [width] floats (width = number of items, rows need not be
+// 16-B aligned, so accesses are coalesced scalar loads). Deterministic (fixed-order block sums).
+// =================================================================================================
+namespace {
+
+__device__ __forceinline__ float block_sum_bcast(float v, float* red) {
+  v = group_sum<64>(v);
+  const int w = threadIdx.x >> 6;
+  __syncthreads();                       // `red` may still be read from a previous call
+  if ((threadIdx.x & 63) == 0) red[w] = v;
+  __syncthreads();
+  return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(kBlock) void rows_mask_normalize_kernel(const int32_t* __restrict__ rowptr,
+                                                                     const Edge* __restrict__ edges,
+                                                                     const int64_t* __restrict__ rows,
+                                                                     float* __restrict__ P, int64_t width, float eps,
+                                                                     float* __restrict__ inv_out) {
+  __shared__ float red[4];
+  const int64_t b = blockIdx.x;
+  const int64_t u = rows[b];
+  float* __restrict__ row = P + b * width;
+  for (int e = rowptr[u] + threadIdx.x; e < rowptr[u + 1]; e += kBlock) row[edges[e].col] = 0.f;
+  __syncthreads();
+  float s = 0.f;
+  for (int64_t j = threadIdx.x; j < width; j += kBlock) {
+    const float v = row[j];
+    s = fmaf(v, v, s);
+  }
+  const float tot = block_sum_bcast(s, red);
+  const float inv = 1.f / fmaxf(sqrtf(tot), eps);
+  for (int64_t j = threadIdx.x; j < width; j += kBlock) row[j] *= inv;
+  if (threadIdx.x == 0) inv_out[b] = inv;
+}
+
+__global__ __launch_bounds__(kBlock) void rows_mask_normalize_bwd_kernel(const int32_t* __restrict__ rowptr,
+                                                                         const Edge* __restrict__ edges,
+                                                                         const int64_t* __restrict__ rows,
+                                                                         const float* __restrict__ S,
+                                                                         const float* __restrict__ gS,
+                                                                         const float* __restrict__ inv_in,
+                                                                         int64_t width, float eps,
+                                                                         float* __restrict__ gP) {
+  __shared__ float red[4];
+  const int64_t b = blockIdx.x;
+  const int64_t u = rows[b];
+  const float* __restrict__ s_row = S + b * width;
+  const float* __restrict__ g_row = gS + b * width;
+  float* __restrict__ o_row = gP + b * width;
+  const float inv = inv_in[b];
+  float dot = 0.f;
+  for (int64_t j = threadIdx.x; j < width; j += kBlock) dot = fmaf(s_row[j], g_row[j], dot);
+  // inv == 1/eps exactly when the norm was clamped: F.normalize then is x/eps, gradient g/eps
+  const float proj = (inv >= 1.f / eps) ? 0.f : block_sum_bcast(dot, red);
+  for (int64_t j = threadIdx.x; j < width; j += kBlock) o_row[j] = inv * (g_row[j] - s_row[j] * proj);
+  __syncthreads();
+  for (int e = rowptr[u] + threadIdx.x; e < rowptr[u + 1]; e += kBlock) o_row[edges[e].col] = 0.f;
+}
+
+__global__ __launch_bounds__(kBlock) void rows_dense_kernel(const int32_t* __restrict__ rowptr,
+                                                            const Edge* __restrict__ edges,
+                                                            const int64_t* __restrict__ rows, float value,
+                                                            float* __restrict__ out, int64_t width) {
+  const int64_t b = blockIdx.x;
+  const int64_t u = rows[b];
+  float* __restrict__ row = out + b * width;
+  for (int64_t j = threadIdx.x; j < width; j += kBlock) row[j] = 0.f;
+  __syncthreads();
+  for (int e = rowptr[u] + threadIdx.x; e < rowptr[u + 1]; e += kBlock) row[edges[e].col] = value;
+}
+
+int rows_args_ok(const mmssl_graph* g, const int64_t* rows, int64_t n, int64_t width) {
+  if (!g || n < 0 || (n > 0 && !rows)) return MMSSL_E_BADARG;
+  if (width != g->fwd.cols || n > 0x7fffffff) return MMSSL_E_BADARG;
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int mmssl_graph_rows_mask_normalize_f32(const mmssl_graph* g, const int64_t* rows, int64_t n, float* P,
+                                                   int64_t width, float eps, float* inv_norm, void* stream) {
+  if (int rc = rows_args_ok(g, rows, n, width)) return rc;
+  if (n == 0) return 0;
+  if (!P || !inv_norm || !(eps > 0.f)) return MMSSL_E_BADARG;
+  hipLaunchKernelGGL(rows_mask_normalize_kernel, dim3((unsigned)n), dim3(kBlock), 0, as_stream(stream), g->fwd.rowptr,
+                     g->fwd.edges, rows, P, width, eps, inv_norm);
+  MMSSL_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int mmssl_graph_rows_mask_normalize_bwd_f32(const mmssl_graph* g, const int64_t* rows, int64_t n,
+                                                       const float* S, const float* gS, const float* inv_norm,
+                                                       int64_t width, float eps, float* gP, void* stream) {
+  if (int rc = rows_args_ok(g, rows, n, width)) return rc;
+  if (n == 0) return 0;
+  if (!S || !gS || !inv_norm || !gP || !(eps > 0.f)) return MMSSL_E_BADARG;
+  hipLaunchKernelGGL(rows_mask_normalize_bwd_kernel, dim3((unsigned)n), dim3(kBlock), 0, as_stream(stream),
+                     g->fwd.rowptr, g->fwd.edges, rows, S, gS, inv_norm, width, eps, gP);
+  MMSSL_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int mmssl_graph_rows_dense_f32(const mmssl_graph* g, const int64_t* rows, int64_t n, float value,
+                                          float* out, int64_t width, void* stream) {
+  if (int rc = rows_args_ok(g, rows, n, width)) return rc;
+  if (n == 0) return 0;
+  if (!out) return MMSSL_E_BADARG;
+  hipLaunchKernelGGL(rows_dense_kernel, dim3((unsigned)n), dim3(kBlock), 0, as_stream(stream), g->fwd.rowptr,
+                     g->fwd.edges, rows, value, out, width);
+  MMSSL_LAUNCH_CHECK();
+  return 0;
+}

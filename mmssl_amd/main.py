@@ -86,7 +86,7 @@ class Trainer(object):
         self.optim_D = optim.Adam(self.D.parameters(), lr=args.D_lr, betas=(0.5, 0.9))
         self.optimizer_D = optim.AdamW([{"params": self.model.parameters()}], lr=self.lr)
         self.scheduler_D = self.set_lr_scheduler()
-        self._seen_cache = (None, None)
+        self._idx_cache = (None, None)
         if batch_test.data_generator is None:
             batch_test.init_data()
         self.data_generator = batch_test.data_generator
@@ -146,20 +146,23 @@ class Trainer(object):
         mf_loss, emb_loss = ops.bpr(users, pos_items, neg_items, self.decay, self.batch_size)
         return mf_loss, emb_loss, 0.0
 
-    def _seen_rows(self, users):
-        """Dense 0/1 rows of the train matrix for this batch (the reference rebuilds and uploads
-        them in every u_sim_calculation call and once more for the Gumbel step)."""
-        key, val = self._seen_cache
+    def _users_idx(self, users):
+        """int64 device tensor of the batch's user ids (cached per batch object)."""
+        key, val = self._idx_cache
         if key is not users:
-            dense = np.asarray(self.ui_graph_raw[np.asarray(users)].todense(), dtype=np.float32)
-            val = torch.from_numpy(dense).to(self.device)
-            self._seen_cache = (users, val)
+            val = torch.as_tensor(np.asarray(users), dtype=torch.int64, device=self.device)
+            self._idx_cache = (users, val)
         return val
 
+    def _seen_rows(self, users):
+        """Dense 0/1 rows of the train matrix for this batch, built ON THE DEVICE from the CSR pattern of
+        the user-item plan (the reference calls ui_graph_raw[users].todense() and uploads [B, n_items]
+        floats in every u_sim_calculation call and once more for the Gumbel step, main.py:283,349)."""
+        return ops.graph_rows_dense(self.ui_graph, self._users_idx(users), 1.0)
+
     def u_sim_calculation(self, users, user_final, item_final):
-        idx = torch.as_tensor(np.asarray(users), dtype=torch.int64, device=self.device)
-        sim = torch.mm(user_final[idx], item_final.t())
-        return F.normalize(sim * (1 - self._seen_rows(users)), p=2, dim=1)
+        """main.py:281-298: library GEMM + fused mask/normalise over the plan's CSR rows (ops.usim)."""
+        return ops.usim(self._users_idx(users), user_final, item_final, self.ui_graph)
 
     def _graphs(self):
         return (self.ui_graph, self.iu_graph, self.image_ui_graph, self.image_iu_graph, self.text_ui_graph,

@@ -387,6 +387,72 @@ def bpr(u, p, n, decay, batch_size):
 
 
 # ---------------------------------------------------------------------------------------
+# u_sim + real-data rows              Trainer.u_sim_calculation main.py:281-298, :349
+# ---------------------------------------------------------------------------------------
+class _USim(torch.autograd.Function):
+    """normalize((U[users] . I^T) * (1 - R[users]), dim=1). The [B, d] x [d, n_items] products are plain
+    library GEMMs (rocBLAS via torch.mm); masking by the users' train items — read from the plan's device
+    CSR, not from a dense uploaded R[users] — and the row normalisation are one fused in-place kernel."""
+
+    @staticmethod
+    def forward(ctx, user_final, item_final, users, plan):
+        user_final, item_final = _chk(user_final, "user_final"), _chk(item_final, "item_final")
+        if plan.shape != (user_final.shape[0], item_final.shape[0]):
+            raise _lib.MmsslError("usim: plan is %s, tables are [%d, d] / [%d, d]" % (
+                plan.shape, user_final.shape[0], item_final.shape[0]))
+        Ub = user_final.index_select(0, users)
+        S = torch.mm(Ub, item_final.t())
+        B, width = S.shape
+        inv = torch.empty(B, dtype=torch.float32, device=S.device)
+        rc = _lib.lib().mmssl_graph_rows_mask_normalize_f32(plan.handle, _ptr(users), B, _ptr(S), width, _NORM_EPS,
+                                                            _ptr(inv), _lib.stream_ptr())
+        _lib.check(rc, "mmssl_graph_rows_mask_normalize_f32")
+        ctx.save_for_backward(Ub, item_final, users, S, inv)
+        ctx.plan, ctx.n_users = plan, user_final.shape[0]
+        return S
+
+    @staticmethod
+    def backward(ctx, gS):
+        Ub, item_final, users, S, inv = ctx.saved_tensors
+        gS = _chk(gS, "gS")
+        gP = torch.empty_like(S)
+        B, width = S.shape
+        rc = _lib.lib().mmssl_graph_rows_mask_normalize_bwd_f32(ctx.plan.handle, _ptr(users), B, _ptr(S), _ptr(gS),
+                                                                _ptr(inv), width, _NORM_EPS, _ptr(gP),
+                                                                _lib.stream_ptr())
+        _lib.check(rc, "mmssl_graph_rows_mask_normalize_bwd_f32")
+        gU = gI = None
+        if ctx.needs_input_grad[0]:
+            gU = torch.zeros((ctx.n_users, Ub.shape[1]), dtype=torch.float32, device=S.device)
+            gU.index_add_(0, users, torch.mm(gP, item_final))
+        if ctx.needs_input_grad[1]:
+            gI = torch.mm(gP.t(), Ub)
+        return gU, gI, None, None
+
+
+def usim(users, user_final, item_final, plan):
+    """Trainer.u_sim_calculation: [B, n_items] masked, row-normalised scores of the batch users.
+    `plan` is the GraphPlan of the user-item train graph (its sparsity pattern is the mask)."""
+    if not hasattr(plan, "handle"):
+        raise _lib.MmsslError("usim expects a GraphPlan")
+    return _USim.apply(user_final, item_final, _idx(users, "users", user_final.device), plan)
+
+
+def graph_rows_dense(plan, rows, value=1.0):
+    """[len(rows), n_cols] dense rows of the plan's pattern (value where an edge exists, else 0): the
+    reference's `torch.tensor(ui_graph_raw[users].todense()).cuda()` built on the device."""
+    if not hasattr(plan, "handle"):
+        raise _lib.MmsslError("graph_rows_dense expects a GraphPlan")
+    dev = plan.device if hasattr(plan, "device") else torch.device("cuda")
+    rows = _idx(rows, "rows", dev)
+    out = torch.empty((rows.shape[0], plan.shape[1]), dtype=torch.float32, device=rows.device)
+    rc = _lib.lib().mmssl_graph_rows_dense_f32(plan.handle, _ptr(rows), rows.shape[0], float(value), _ptr(out),
+                                               plan.shape[1], _lib.stream_ptr())
+    _lib.check(rc, "mmssl_graph_rows_dense_f32")
+    return out
+
+
+# ---------------------------------------------------------------------------------------
 # all batch losses in one autograd node          main.py:368-371, 411-412, 499-511
 # ---------------------------------------------------------------------------------------
 class _BatchLosses(torch.autograd.Function):

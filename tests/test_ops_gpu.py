@@ -443,3 +443,37 @@ def test_dropout_masks_statistics_and_determinism():
         g.replay()
         torch.cuda.synchronize()
     assert not torch.equal(first, m)
+
+
+@pytest.mark.parametrize("U,I,d,B", [(300, 517, 64, 64), (50, 33, 32, 50)])
+def test_usim_matches_oracle_and_dense_rows(U, I, d, B):
+    """ops.usim == Trainer.u_sim_calculation (oracle restatement of main.py:281-298) forward and backward,
+    with the mask read from the plan's CSR rows; graph_rows_dense == ui_graph_raw[users].todense()."""
+    from mmssl_amd import ops
+    from mmssl_amd.graph import GraphPlan
+    rng = np.random.RandomState(U)
+    raw = sp.random(U, I, density=0.05, random_state=rng, format="csr", dtype=np.float32)
+    raw.data[:] = 1.0
+    raw[3] = 0                                   # a user without train items
+    raw.eliminate_zeros()
+    plan = GraphPlan(O.csr_norm(raw, mean_flag=True))
+    users = rng.choice(U, size=B, replace=B > U).tolist()
+    users[0] = 3
+    gen = torch.Generator().manual_seed(I)
+    uf = torch.randn(U, d, generator=gen)
+    itf = torch.randn(I, d, generator=gen)
+    uf[users[1]] = 0.0                           # an all-zero user row: clamped norm branch
+    w = torch.randn(B, I, generator=gen)
+    ur, ir = uf.clone().requires_grad_(True), itf.clone().requires_grad_(True)
+    ref = O.u_sim(users, ur, ir, raw, 128)
+    (ref * w).sum().backward()
+    ug, ig = uf.clone().to(DEV).requires_grad_(True), itf.clone().to(DEV).requires_grad_(True)
+    got = ops.usim(users, ug, ig, plan)
+    (got * w.to(DEV)).sum().backward()
+    assert H.rel_err(got.detach().cpu(), ref.detach()) < 2e-6
+    dense = np.asarray(raw[np.asarray(users)].todense())
+    assert float(got.detach().cpu()[torch.from_numpy(dense > 0)].abs().max()) == 0.0      # seen items masked exactly
+    assert H.rel_err(ug.grad.cpu(), ur.grad) < 2e-5
+    assert H.rel_err(ig.grad.cpu(), ir.grad) < 2e-5
+    rows = ops.graph_rows_dense(plan, users, 1.0)
+    assert torch.equal(rows.cpu(), torch.from_numpy(dense.astype(np.float32)))

@@ -1,0 +1,76 @@
+"""Whole-loop timing of mmssl_amd.main.Trainer (the reference's training loop: sampler -> D step ->
+G step per batch, evaluation per epoch) on a synthetic dataset of a named shape written in the
+reference's on-disk format. Prints a per-phase breakdown (ms per batch, CUDA-synchronised).
+
+    python tools/trainer_bench.py [--workload baby|tiktok] [--batches 12]
+"""
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--workload", default="baby")
+    ap.add_argument("--batches", type=int, default=12)
+    ap.add_argument("--eval-users", type=int, default=4096)
+    a = ap.parse_args()
+    import synth_data
+    from mmssl_amd import synth
+    from mmssl_amd.config import configure
+    from mmssl_amd.utility import batch_test
+    from mmssl_amd import main as M
+    U, I, E, dv, dt = synth.SHAPES[a.workload]
+    root = tempfile.mkdtemp(prefix="mmssl_bench_")
+    t0 = time.time()
+    synth_data.write_dataset(root, a.workload, U, I, E, dv, dt, seed=1)
+    t_data = time.time() - t0
+    configure(["--data_path", root + "/", "--dataset", a.workload, "--weight_size", "[64,64,64]", "--verbose", "0"])
+    M.set_seed(2022)
+    dg = batch_test.init_data()
+    tr = M.Trainer({"n_users": dg.n_users, "n_items": dg.n_items})
+    sync = torch.cuda.synchronize
+    acc = {"sample": 0.0, "d_step": 0.0, "g_step": 0.0}
+    n = 0
+    for idx in range(a.batches):
+        tr.model.train()
+        t = time.perf_counter()
+        users, pos, neg = dg.sample()
+        t1 = time.perf_counter()
+        tr._discriminator_step(users)
+        sync()
+        t2 = time.perf_counter()
+        tr._generator_step(idx, users, pos, neg)
+        sync()
+        t3 = time.perf_counter()
+        if idx >= 2:                     # first two batches build caches / modal graphs
+            acc["sample"] += t1 - t
+            acc["d_step"] += t2 - t1
+            acc["g_step"] += t3 - t2
+            n += 1
+    out = {k: round(v / n * 1e3, 2) for k, v in acc.items()}
+    out["batch_total_ms"] = round(sum(acc.values()) / n * 1e3, 2)
+    users = list(dg.val_set.keys())[:a.eval_users]
+    sync()
+    t = time.perf_counter()
+    ret = tr.test(users, is_val=True)
+    sync()
+    out["eval_ms_per_1k_users"] = round((time.perf_counter() - t) * 1e3 / max(len(users), 1) * 1000, 2)
+    out["recall@20"] = float(ret["recall"][1])
+    out["workload"] = a.workload
+    out["dataset_write_s"] = round(t_data, 1)
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -33,6 +33,7 @@ from torch import autograd
 from . import ops
 from .config import args, configure
 from .graph import GraphPlan
+from .optim import FusedAdamW
 from .Models import MMSSL, Discriminator
 from .utility import batch_test
 from .utility.logging import Logger
@@ -84,7 +85,8 @@ class Trainer(object):
         self.D = Discriminator(self.n_items).cuda()
         self.D.apply(self.weights_init)
         self.optim_D = optim.Adam(self.D.parameters(), lr=args.D_lr, betas=(0.5, 0.9))
-        self.optimizer_D = optim.AdamW([{"params": self.model.parameters()}], lr=self.lr)
+        # the generator's AdamW (named optimizer_D in the reference, main.py:76-80): one-launch fused kernel
+        self.optimizer_D = FusedAdamW([{"params": self.model.parameters()}], lr=self.lr)
         self.scheduler_D = self.set_lr_scheduler()
         self._idx_cache = (None, None)
         if batch_test.data_generator is None:
@@ -222,19 +224,20 @@ class Trainer(object):
         (G_ua, G_ia, G_img_item, G_txt_item, G_img_user, G_txt_user, G_user_emb, _, G_img_uid, G_txt_uid, _, _) = \
             self.model(*self._graphs(), keep_masks=keep_masks)
         dev = self.device
-        u_idx = torch.as_tensor(np.asarray(users), dtype=torch.int64, device=dev)
+        u_idx = self._users_idx(users)
         p_idx = torch.as_tensor(np.asarray(pos_items), dtype=torch.int64, device=dev)
         n_idx = torch.as_tensor(np.asarray(neg_items), dtype=torch.int64, device=dev)
-        mf_loss, emb_loss = ops.bpr_gather(G_ua, G_ia, u_idx, p_idx, n_idx, self.decay, self.batch_size)
+        # gathers + bpr_loss (main.py:368-371) and both batched_contrastive_loss calls (:411-412) as ONE
+        # autograd node on the full tables (G_user_emb is G_ua: outputs 0 and 6 of the model are one tensor)
+        assert G_user_emb is G_ua
+        mf_loss, emb_loss, cl1, cl2 = ops.batch_losses(G_ua, G_ia, G_img_uid, G_txt_uid, u_idx, p_idx, n_idx,
+                                                       self.decay, self.batch_size, args.tau)
         reg_loss = 0.0
         G_img_sim = self.u_sim_calculation(users, G_img_user, G_img_item)
         G_txt_sim = self.u_sim_calculation(users, G_txt_user, G_txt_item)
         if maintain_graphs:
             self._maintain_modal_graphs(idx, users, G_img_sim.detach(), G_txt_sim.detach())
         feat_emb_loss = self.feat_reg_loss_calculation(G_img_item, G_txt_item, G_img_user, G_txt_user)
-        uemb = G_user_emb[u_idx]
-        cl1 = self.batched_contrastive_loss(G_img_uid[u_idx], uemb)
-        cl2 = self.batched_contrastive_loss(G_txt_uid[u_idx], uemb)
         G_lossf = -(self.D(torch.cat((G_img_sim, G_txt_sim), dim=0)).mean())
         batch_loss = mf_loss + emb_loss + reg_loss + feat_emb_loss + args.cl_rate * (cl1 + cl2) \
             + args.G_rate * G_lossf

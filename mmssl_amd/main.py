@@ -89,6 +89,7 @@ class Trainer(object):
         self.optimizer_D = FusedAdamW([{"params": self.model.parameters()}], lr=self.lr)
         self.scheduler_D = self.set_lr_scheduler()
         self._idx_cache = (None, None)
+        self._empty_plans = None
         if batch_test.data_generator is None:
             batch_test.init_data()
         self.data_generator = batch_test.data_generator
@@ -205,6 +206,15 @@ class Trainer(object):
         if idx % args.T == 0 and idx != 0:
             shape = (self.n_users, self.n_items)
             for name, store in (("image", self.image_ui_index), ("text", self.text_ui_index)):
+                if not store["x"]:
+                    # nothing collected (the reference's steady state from the third batch on):
+                    # the rebuilt graphs are empty; reuse one empty plan pair instead of 4 scipy + plan builds
+                    if self._empty_plans is None:
+                        e = sp.csr_matrix(shape, dtype=np.float32)
+                        self._empty_plans = (self.matrix_to_tensor(e), self.matrix_to_tensor(e.T.tocsr()))
+                    setattr(self, name + "_ui_graph", self._empty_plans[0])
+                    setattr(self, name + "_iu_graph", self._empty_plans[1])
+                    continue
                 tmp = sp.csr_matrix((np.ones(len(store["x"]), np.float32), (store["x"], store["y"])), shape=shape)
                 setattr(self, name + "_ui_graph", self.matrix_to_tensor(self.csr_norm(tmp, mean_flag=True)))
                 setattr(self, name + "_iu_graph", self.matrix_to_tensor(self.csr_norm(tmp.T, mean_flag=True)))

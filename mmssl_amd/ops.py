@@ -807,8 +807,15 @@ class _HotForward(torch.autograd.Function):
         nbu = _lib.lib().mmssl_layer_combine_blocks(u0.shape[0], d)
         nbi = _lib.lib().mmssl_layer_combine_blocks(i0.shape[0], d)
         part = torch.empty(nbu + nbi, dtype=torch.float32, device=dev)
-        u_g = _combine_fwd(us, inv, img_user, txt_user, r, part[:nbu])
-        i_g = _combine_fwd(its, inv, img_item, txt_item, r, part[nbu:])
+        if overlap:                       # the two combines are independent: item side next to the user side
+            sA.wait_stream(main)
+            with torch.cuda.stream(sA):
+                i_g = _combine_fwd(its, inv, img_item, txt_item, r, part[nbu:])
+            u_g = _combine_fwd(us, inv, img_user, txt_user, r, part[:nbu])
+            main.wait_stream(sA)
+        else:
+            u_g = _combine_fwd(us, inv, img_user, txt_user, r, part[:nbu])
+            i_g = _combine_fwd(its, inv, img_item, txt_item, r, part[nbu:])
         ss = torch.empty((), dtype=torch.float32, device=dev)
         rc = _lib.lib().mmssl_sum_partials_f32(_ptr(part), nbu + nbi, _ptr(ss), _lib.stream_ptr())
         _lib.check(rc, "mmssl_sum_partials_f32")
@@ -826,22 +833,43 @@ class _HotForward(torch.autograd.Function):
         Gu = _chk(Gu, "Gu") if Gu is not None else torch.zeros_like(img_user)
         Gi = _chk(Gi, "Gi") if Gi is not None else torch.zeros_like(img_item)
         g_ss = g_ss.contiguous().to(torch.float32) if g_ss is not None else None
-        g_iu_, g_tu_, g_u0 = _combine_bwd(img_user, txt_user, Gu, r, inv, g_ss, 2.0, True)
-        g_ii_, g_ti_, _ = _combine_bwd(img_item, txt_item, Gi, r, inv, g_ss, 2.0, False)
-        if G_img_item is not None:
-            g_ii_ = g_ii_ + G_img_item
-        if G_txt_item is not None:
-            g_ti_ = g_ti_ + G_txt_item
-        if G_img_user is not None:
-            g_iu_ = g_iu_ + G_img_user
-        if G_txt_user is not None:
-            g_tu_ = g_tu_ + G_txt_user
         dev = Gu.device
         main = torch.cuda.current_stream(dev)
         sA, sB, sC = _side_streams(dev) if overlap else (main, main, main)
+        extra = (G_img_item, G_txt_item, G_img_user, G_txt_user)
+        # normalise-backward + regulariser gradient of the user side on sA and of the item side on sB, next to
+        # each other and next to the GCN chain (which only needs Gu / Gi); each modal chain then needs one
+        # tensor from the other stream
+        split = overlap and all(t is None for t in extra)
         if overlap:
             for st in (sA, sB, sC):
                 st.wait_stream(main)
+        if split:
+            with torch.cuda.stream(sA):
+                g_iu_, g_tu_, g_u0 = _combine_bwd(img_user, txt_user, Gu, r, inv, g_ss, 2.0, True)
+            with torch.cuda.stream(sB):
+                g_ii_, g_ti_, _ = _combine_bwd(img_item, txt_item, Gi, r, inv, g_ss, 2.0, False)
+            # each modal chain needs one tensor of the other side: exchange through the current stream
+            # (a direct sA <-> sB event pair crashes hipGraph capture in this ROCm build)
+            main.wait_stream(sA)
+            main.wait_stream(sB)
+            sA.wait_stream(main)
+            sB.wait_stream(main)
+        else:
+            with torch.cuda.stream(sA):
+                g_iu_, g_tu_, g_u0 = _combine_bwd(img_user, txt_user, Gu, r, inv, g_ss, 2.0, True)
+                g_ii_, g_ti_, _ = _combine_bwd(img_item, txt_item, Gi, r, inv, g_ss, 2.0, False)
+                # gradients that arrive on the modal outputs themselves (only if a caller used them elsewhere)
+                if G_img_item is not None:
+                    g_ii_ = g_ii_ + G_img_item
+                if G_txt_item is not None:
+                    g_ti_ = g_ti_ + G_txt_item
+                if G_img_user is not None:
+                    g_iu_ = g_iu_ + G_img_user
+                if G_txt_user is not None:
+                    g_tu_ = g_tu_ + G_txt_user
+            if overlap:
+                sB.wait_stream(sA)
         out = {}
 
         def chain_c():

@@ -10,8 +10,6 @@ A reference `state_dict` loads unchanged (same keys incl. the aliased encoder.* 
 entries and the unused image_embedding / text_embedding / batch_norm parameters). Graph
 arguments may be the reference's torch sparse COO tensors or `GraphPlan`s.
 """
-import os as _os
-
 import torch
 import torch.nn as nn
 
@@ -156,14 +154,8 @@ class MMSSL(nn.Module):
             if keep_masks is not None:
                 km_img, km_txt = keep_masks
             else:
-                if _os.environ.get("MMSSL_TORCH_MASKS") == "1":      # A/B switch for profiling only
-                    shape = (self.n_items, args.embed_size)
-                    dev = self.image_trans.weight.device
-                    km_img = torch.empty(shape, dtype=torch.uint8, device=dev).bernoulli_(1.0 - p)
-                    km_txt = torch.empty(shape, dtype=torch.uint8, device=dev).bernoulli_(1.0 - p)
-                else:
-                    km_img, km_txt = ops.dropout_masks(2, self.n_items, args.embed_size, p,
-                                                       self.image_trans.weight.device)          # 1 = keep
+                km_img, km_txt = ops.dropout_masks(2, self.n_items, args.embed_size, p,
+                                                   self.image_trans.weight.device)              # 1 = keep
         E_u, E_i = self.user_id_embedding.weight, self.item_id_embedding.weight
         # the reference repeats this block args.layers times without feeding anything back
         # (Models.py:176-186): the result is that of one pass.

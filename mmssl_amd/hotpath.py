@@ -28,12 +28,12 @@ class HotPathStep:
         # same update rule as the reference's optim.AdamW (main.py:76-80) as ONE launch over all tensors
         # with a gradient; the step counter lives on the device so the step can be replayed in a hipGraph.
         # (`capturable` is kept for signature compatibility: the kernel always is.)
-        import os
-        if os.environ.get("MMSSL_TORCH_ADAMW") == "1":         # A/B switch for profiling only
-            self.optimizer = torch.optim.AdamW([{"params": model.parameters()}], lr=lr or args.lr,
-                                               capturable=True, fused=True)
-        else:
-            self.optimizer = FusedAdamW([{"params": model.parameters()}], lr=lr or args.lr)
+        # Two groups with the same hyper-parameters: the embedding tables (their gradients are complete when the
+        # GCN backward chain is) are updated while the projection wgrad GEMMs are still running.
+        tables = [model.user_id_embedding.weight, model.item_id_embedding.weight]
+        tid = {id(p) for p in tables}
+        rest = [p for p in model.parameters() if id(p) not in tid]
+        self.optimizer = FusedAdamW([{"params": tables}, {"params": rest}], lr=lr or args.lr)
         self.loss = torch.zeros((), device=dev)
         self._one = torch.ones((), device=dev)
         self.parts = {}
@@ -72,8 +72,14 @@ class HotPathStep:
     def _step(self):
         self.optimizer.zero_grad(set_to_none=True)
         total, parts = self.losses()
-        total.backward(gradient=self._one)           # persistent root gradient: no ones_like fill per step
-        self.optimizer.step()
+        prev = ops.defer_wgrad_join(True)
+        try:
+            total.backward(gradient=self._one)       # persistent root gradient: no ones_like fill per step
+        finally:
+            ops.defer_wgrad_join(prev)
+        self.optimizer.step(groups=(0,))             # embedding tables, next to the wgrad GEMMs
+        ops.join_side_streams(self.loss.device)
+        self.optimizer.step(groups=(1,))
         return self.loss
 
     # ---- hipGraph capture ---------------------------------------------------------------------

@@ -743,6 +743,28 @@ def overlap_enabled():
     return _os.environ.get("MMSSL_STREAMS", "1") != "0"
 
 
+# Deferred join of the weight-gradient chains. By default _HotForward.backward returns with every side
+# stream joined. A caller that owns the whole step (hotpath.HotPathStep) may set this flag: backward then
+# returns as soon as the embedding-table gradients are complete, the projection wgrad GEMMs still running on
+# their side streams, and the caller must call join_side_streams() before anything reads image_trans /
+# text_trans gradients (it updates the embedding tables in between).
+_DEFER = {"on": False}
+
+
+def defer_wgrad_join(flag):
+    prev = _DEFER["on"]
+    _DEFER["on"] = bool(flag)
+    return prev
+
+
+def join_side_streams(device):
+    """Make the current stream wait for everything queued on this package's side streams."""
+    device = torch.device(device)
+    main = torch.cuda.current_stream(device)
+    for st in _SIDE_STREAMS.get((device.type, device.index), ()):
+        main.wait_stream(st)
+
+
 class _HotForward(torch.autograd.Function):
     """x_m = dropout(F_m W_m^T + b_m) -> modal SpMM chains -> G-layer GCN -> layer mean + modality
     fusion (+ regulariser sum): the complete MMSSL.forward after the id-embedding fusion
@@ -898,7 +920,9 @@ class _HotForward(torch.autograd.Function):
             chains[c]()
         gi, gW_img, gb_img, gW_txt, gb_txt = out["gi"], out["gW_img"], out["gb_img"], out["gW_txt"], out["gb_txt"]
         if overlap:
-            for st in (sA, sB, sC):
+            # g_u0 (sA, before the exchange) and gi (sC) are what the embedding tables need; in deferred mode the
+            # wgrad chains on sA / sB are left running (see defer_wgrad_join)
+            for st in ((sC,) if (split and _DEFER["on"]) else (sA, sB, sC)):
                 main.wait_stream(st)
         return (None, gW_img, gb_img if has_bi else None, None, None, gW_txt, gb_txt if has_bt else None, None, None,
                 g_u0, gi, None, None, None, None, None)

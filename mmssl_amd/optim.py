@@ -27,12 +27,16 @@ class FusedAdamW(torch.optim.Optimizer):
         return st
 
     @torch.no_grad()
-    def step(self, closure=None):
+    def step(self, closure=None, groups=None):
+        """`groups`: optional iterable of param-group indices to update (each group has its own device step
+        counter, so groups may be stepped at different points of one iteration)."""
         loss = None
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
         for gi, group in enumerate(self.param_groups):
+            if groups is not None and gi not in groups:
+                continue
             todo = []
             for p in group["params"]:
                 if p.grad is None:

@@ -37,18 +37,67 @@ def get_performance(user_pos_test, r, auc, Ks):
             "hit_ratio": np.array(hit_ratio), "auc": auc}
 
 
+def _set_csr(data, name, mapping):
+    """CSR (indptr, indices) over user ids of a {user: [items]} mapping, cached on the Data object."""
+    cache = data.__dict__.setdefault("_eval_csr", {})
+    hit = cache.get(name)
+    if hit is None or hit[0] is not mapping:
+        n_users = data.n_users
+        counts = np.zeros(n_users + 1, dtype=np.int64)
+        for u, items in mapping.items():
+            counts[int(u) + 1] = len(items)
+        indptr = np.cumsum(counts)
+        indices = np.empty(int(indptr[-1]), dtype=np.int64)
+        for u, items in mapping.items():
+            u = int(u)
+            indices[indptr[u]:indptr[u + 1]] = items
+        hit = (mapping, indptr, indices)
+        cache[name] = hit
+    return hit[1], hit[2]
+
+
+def _rows_of(indptr, indices, users):
+    """(row-in-batch, item) pairs of the given users, vectorised."""
+    users = np.asarray(users, dtype=np.int64)
+    beg, end = indptr[users], indptr[users + 1]
+    cnt = end - beg
+    rows = np.repeat(np.arange(len(users), dtype=np.int64), cnt)
+    # offsets inside each user's slice
+    start_of = np.repeat(beg - np.concatenate(([0], np.cumsum(cnt)[:-1])), cnt)
+    cols = indices[np.arange(int(cnt.sum()), dtype=np.int64) + start_of]
+    return rows, cols, cnt
+
+
 def _batch_masks(data, user_batch, pos_of, device):
-    """(train_rows, train_cols, pos_rows, pos_cols) index tensors for one user batch."""
-    tr_r, tr_c, po_r, po_c = [], [], [], []
-    for k, u in enumerate(user_batch):
-        seen = data.train_items.get(u, [])
-        tr_r += [k] * len(seen)
-        tr_c += seen
-        pos = pos_of[u]
-        po_r += [k] * len(pos)
-        po_c += pos
+    """(train_rows, train_cols, pos_rows, pos_cols, n_pos) for one user batch."""
+    tr_ptr, tr_idx = _set_csr(data, "train", data.train_items)
+    po_ptr, po_idx = _set_csr(data, "val" if pos_of is data.val_set else "test", pos_of)
+    tr_r, tr_c, _ = _rows_of(tr_ptr, tr_idx, user_batch)
+    po_r, po_c, n_pos = _rows_of(po_ptr, po_idx, user_batch)
     mk = lambda x: torch.as_tensor(x, dtype=torch.int64, device=device)     # noqa: E731
-    return mk(tr_r), mk(tr_c), mk(po_r), mk(po_c)
+    return mk(tr_r), mk(tr_c), mk(po_r), mk(po_c), n_pos
+
+
+def _metric_sums(hits, n_pos, Ks):
+    """Sums over users of precision / recall / ndcg / hit_ratio @ Ks from the binary hit matrix
+    [users, max(Ks)] (float64, the formulas of utility/metrics.py applied to all rows at once).
+    ndcg's ideal DCG comes from the row's own hit count, like metrics.ndcg_at_k (sorted(r))."""
+    hits = np.asarray(hits, dtype=np.float64)
+    n_pos = np.asarray(n_pos, dtype=np.float64)
+    disc = 1.0 / np.log2(np.arange(2, hits.shape[1] + 2, dtype=np.float64))
+    cum_disc = np.concatenate(([0.0], np.cumsum(disc)))
+    tot = hits.sum(1).astype(np.int64)                       # hits within max(Ks): the "ideal" list's ones
+    out = {k: np.zeros(len(Ks)) for k in ("precision", "recall", "ndcg", "hit_ratio")}
+    for j, K in enumerate(Ks):
+        h = hits[:, :K]
+        s = h.sum(1)
+        out["precision"][j] = (s / K).sum()
+        out["recall"][j] = np.where(n_pos > 0, s / np.maximum(n_pos, 1.0), 0.0).sum()
+        dcg = (h * disc[:K]).sum(1)
+        best = cum_disc[np.minimum(tot, K)]
+        out["ndcg"][j] = np.where(best > 0, dcg / np.where(best > 0, best, 1.0), 0.0).sum()
+        out["hit_ratio"][j] = (s > 0).sum()
+    return out
 
 
 def test_torch(ua_embeddings, ia_embeddings, users_to_test, is_val, drop_flag=False, batch_test_flag=False,
@@ -76,17 +125,15 @@ def test_torch(ua_embeddings, ia_embeddings, users_to_test, is_val, drop_flag=Fa
             continue
         idx = torch.as_tensor(user_batch, dtype=torch.int64, device=dev)
         rate = torch.matmul(ua_embeddings[idx], ia_embeddings.t()).detach()
-        tr_r, tr_c, po_r, po_c = _batch_masks(data, user_batch, pos_of, dev)
+        tr_r, tr_c, po_r, po_c, n_pos = _batch_masks(data, user_batch, pos_of, dev)
         rate[tr_r, tr_c] = float("-inf")                              # batch_test.py:98-100
         order = torch.sort(rate, dim=1, descending=True, stable=True).indices[:, :k_max]
         is_pos = torch.zeros((len(user_batch), n_items), dtype=torch.bool, device=dev)
         is_pos[po_r, po_c] = True
-        hits = torch.gather(is_pos, 1, order).to(torch.int64).cpu().numpy()
-        for r, u in zip(hits, user_batch):
-            re = get_performance(pos_of[u], r.tolist(), 0.0, Ks)
-            for key in ("precision", "recall", "ndcg", "hit_ratio"):
-                result[key] += re[key] / n_test_users
-            result["auc"] += re["auc"] / n_test_users
-            count += 1
+        hits = torch.gather(is_pos, 1, order).cpu().numpy()
+        sums = _metric_sums(hits, n_pos, Ks)
+        for key in ("precision", "recall", "ndcg", "hit_ratio"):
+            result[key] += sums[key] / n_test_users
+        count += len(user_batch)
     assert count == n_test_users
     return result

@@ -149,13 +149,24 @@ class Trainer(object):
         mf_loss, emb_loss = ops.bpr(users, pos_items, neg_items, self.decay, self.batch_size)
         return mf_loss, emb_loss, 0.0
 
-    def _users_idx(self, users):
-        """int64 device tensor of the batch's user ids (cached per batch object)."""
+    def _batch_idx(self, users, pos_items=None, neg_items=None):
+        """int64 device tensors of one sampled batch, uploaded ONCE per batch object through pinned memory
+        (non-blocking: the host does not wait for the kernels queued before the copy). Returns (u, p, n);
+        p / n are None until a call supplies the item lists."""
         key, val = self._idx_cache
         if key is not users:
-            val = torch.as_tensor(np.asarray(users), dtype=torch.int64, device=self.device)
+            val = [self._upload(users), None, None]
             self._idx_cache = (users, val)
+        if pos_items is not None and val[1] is None:
+            val[1], val[2] = self._upload(pos_items), self._upload(neg_items)
         return val
+
+    def _upload(self, ids):
+        host = torch.from_numpy(np.asarray(ids, dtype=np.int64)).pin_memory()
+        return host.to(self.device, non_blocking=True)
+
+    def _users_idx(self, users):
+        return self._batch_idx(users)[0]
 
     def _seen_rows(self, users):
         """Dense 0/1 rows of the train matrix for this batch, built ON THE DEVICE from the CSR pattern of
@@ -234,9 +245,7 @@ class Trainer(object):
         (G_ua, G_ia, G_img_item, G_txt_item, G_img_user, G_txt_user, G_user_emb, _, G_img_uid, G_txt_uid, _, _) = \
             self.model(*self._graphs(), keep_masks=keep_masks)
         dev = self.device
-        u_idx = self._users_idx(users)
-        p_idx = torch.as_tensor(np.asarray(pos_items), dtype=torch.int64, device=dev)
-        n_idx = torch.as_tensor(np.asarray(neg_items), dtype=torch.int64, device=dev)
+        u_idx, p_idx, n_idx = self._batch_idx(users, pos_items, neg_items)
         # gathers + bpr_loss (main.py:368-371) and both batched_contrastive_loss calls (:411-412) as ONE
         # autograd node on the full tables (G_user_emb is G_ua: outputs 0 and 6 of the model are one tensor)
         assert G_user_emb is G_ua
@@ -267,15 +276,20 @@ class Trainer(object):
         dg = self.data_generator
         stopping_step, best_recall, test_ret = 0, 0, None
         Ks = eval(args.Ks)
+        nxt = dg.sample()
         for epoch in range(args.epoch):
             t1 = time()
             loss = mf_loss = emb_loss = reg_loss = 0.0
             n_batch = dg.n_train // args.batch_size + 1
             for idx in range(n_batch):
                 self.model.train()
-                users, pos_items, neg_items = dg.sample()
+                users, pos_items, neg_items = nxt
+                self._batch_idx(users, pos_items, neg_items)       # uploads before any kernel of the batch
                 self._discriminator_step(users)
                 bl, mf, emb, reg, _, _ = self._generator_step(idx, users, pos_items, neg_items)
+                # the next batch is sampled while the device works on this one: Data.sample() consumes the host
+                # RNG streams in exactly the reference's order (one call per batch, nothing else draws from them)
+                nxt = dg.sample()
                 loss += float(bl)
                 mf_loss += float(mf)
                 emb_loss += float(emb)

@@ -245,7 +245,11 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if world == 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            os.environ.setdefault("MASTER_PORT", "29533")
+            if "MASTER_PORT" not in os.environ:          # a free port: back-to-back runs must not collide
+                import socket
+                with socket.socket() as so:
+                    so.bind(("127.0.0.1", 0))
+                    os.environ["MASTER_PORT"] = str(so.getsockname()[1])
             os.environ.setdefault("RANK", "0")
             os.environ.setdefault("WORLD_SIZE", "1")
             dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)

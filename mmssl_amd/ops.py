@@ -462,7 +462,7 @@ class _BatchLosses(torch.autograd.Function):
     summed by autograd)."""
 
     @staticmethod
-    def forward(ctx, ua, ia, img_uid, txt_uid, users, pos, neg, decay, batch_size, tau):
+    def forward(ctx, ua, ia, img_uid, txt_uid, users, pos, neg, decay, batch_size, tau, overlap=None):
         ua, ia = _chk(ua, "ua"), _chk(ia, "ia")
         img_uid, txt_uid = _chk(img_uid, "img_uid"), _chk(txt_uid, "txt_uid")
         B, d = users.shape[0], ua.shape[1]
@@ -475,7 +475,7 @@ class _BatchLosses(torch.autograd.Function):
         # stream, next to the BPR forward, while the (longer) InfoNCE forward runs on the current stream
         g_ua = torch.empty_like(ua) if need_grad else None
         g_ia = torch.empty_like(ia) if need_grad else None
-        overlap = overlap_enabled()
+        overlap = overlap_enabled() if overlap is None else bool(overlap)
         main = torch.cuda.current_stream(dev)
         side = _side_streams(dev)[0] if overlap else main
         if overlap:
@@ -538,14 +538,15 @@ class _BatchLosses(torch.autograd.Function):
         rc = call(_ptr(users), 2, B, d, tau, _ptr(g[3:5]), gz1s, _ptr(g_ua), _ptr(ws1), ws1.numel() * 4, 2,
                   _lib.stream_ptr())
         _lib.check(rc, "mmssl_infonce_multi_bwd_phase_f32")
-        return g_ua, g_ia, g_img, g_txt, None, None, None, None, None, None
+        return g_ua, g_ia, g_img, g_txt, None, None, None, None, None, None, None
 
 
-def batch_losses_vec(ua, ia, img_uid, txt_uid, users, pos, neg, decay, batch_size, tau):
-    """[mf_loss, emb_loss, 0, cl_img, cl_txt] as ONE tensor (see _BatchLosses / loss_assemble)."""
+def batch_losses_vec(ua, ia, img_uid, txt_uid, users, pos, neg, decay, batch_size, tau, overlap=None):
+    """[mf_loss, emb_loss, 0, cl_img, cl_txt] as ONE tensor (see _BatchLosses / loss_assemble).
+    overlap=False keeps every launch on the current stream (None: the MMSSL_STREAMS default)."""
     dev = ua.device
     return _BatchLosses.apply(ua, ia, img_uid, txt_uid, _idx(users, "users", dev), _idx(pos, "pos", dev),
-                              _idx(neg, "neg", dev), decay, batch_size, tau)
+                              _idx(neg, "neg", dev), decay, batch_size, tau, overlap)
 
 
 def batch_losses(ua, ia, img_uid, txt_uid, users, pos, neg, decay, batch_size, tau):

@@ -52,6 +52,17 @@ class OracleBackend:
     def sumsq(x):
         return (x ** 2).sum()
 
+    @staticmethod
+    def batch_losses_rows(u, p, n, z_img, z_txt, decay, batch_size, tau):
+        mf, emb, _ = O.bpr(u, p, n, decay, batch_size)
+        zero = torch.zeros((), dtype=u.dtype)
+        return torch.stack([mf, emb, zero, O.infonce(z_img, u, tau), O.infonce(z_txt, u, tau)])
+
+    @staticmethod
+    def loss_assemble(terms, w, extra=None, c=0.0):
+        total = (terms * w).sum()
+        return total if extra is None else total + c * extra
+
     # ---- non-autograd ("raw") ops used by the fused sharded node ------------------------------------
     @staticmethod
     def spmm_raw(plan, transpose, X, epilogue, Z=None, alpha=0.0, S=None):

@@ -257,7 +257,18 @@ class Trainer(object):
         if maintain_graphs:
             self._maintain_modal_graphs(idx, users, G_img_sim.detach(), G_txt_sim.detach())
         feat_emb_loss = self.feat_reg_loss_calculation(G_img_item, G_txt_item, G_img_user, G_txt_user)
-        G_lossf = -(self.D(torch.cat((G_img_sim, G_txt_sim), dim=0)).mean())
+        # The generator loss needs d(D)/d(input) only. The reference also accumulates this step's gradients
+        # into D's own parameters, which nothing reads (optim_D.zero_grad() clears them before D's next
+        # backward, main.py:357-359): with D's parameters frozen while the graph is built, autograd skips
+        # those [2B, n_items] x [n_items, n_items/4] weight-gradient GEMMs.
+        d_params = [p for p in self.D.parameters() if p.requires_grad]
+        for p in d_params:
+            p.requires_grad_(False)
+        try:
+            G_lossf = -(self.D(torch.cat((G_img_sim, G_txt_sim), dim=0)).mean())
+        finally:
+            for p in d_params:
+                p.requires_grad_(True)
         batch_loss = mf_loss + emb_loss + reg_loss + feat_emb_loss + args.cl_rate * (cl1 + cl2) \
             + args.G_rate * G_lossf
         return dict(batch_loss=batch_loss, mf=mf_loss, emb=emb_loss, reg=reg_loss, feat=feat_emb_loss, cl1=cl1,

@@ -30,7 +30,12 @@ typedef float floatx16 __attribute__((ext_vector_type(16)));
 
 constexpr int BT = 64;    // output tile edge
 constexpr int BK = 32;    // reduction slice
-constexpr int LD = 65;    // LDS row stride (floats)
+// LDS row stride (floats) of gemm64_kernel's k-major operand image: 65 when the slice is TRANSPOSED into it
+// (conflict-free ds_write_b32 and fragment ds_read_b32); 68 when it is copied as is (wgrad): rows stay 16-B
+// aligned, so a thread's float4 is ONE conflict-free ds_write_b128 instead of four 2-way-conflicting
+// ds_write_b32 (PMC: 25 % of the wgrad kernel's LDS cycles were bank conflicts with stride 65).
+template <bool DIRECT>
+constexpr int ld_of() { return DIRECT ? 68 : 65; }
 
 // DIRECT = false: operands are row-major [i][kk] (forward: F[M,K], W[N,K]) -> transposed into LDS
 // DIRECT = true : operands are row-major [kk][i] (wgrad: gY[M,N], F[M,K])  -> copied as is
@@ -67,6 +72,7 @@ __device__ __forceinline__ void fetch_slice(const float* __restrict__ P, int64_t
 
 template <bool DIRECT>
 __device__ __forceinline__ void store_slice(float* __restrict__ S, const float4 (&r)[2]) {
+  constexpr int LD = ld_of<DIRECT>();
   const int tid = threadIdx.x;
 #pragma unroll
   for (int p = 0; p < 2; ++p) {
@@ -78,10 +84,7 @@ __device__ __forceinline__ void store_slice(float* __restrict__ S, const float4 
       S[(k + 3) * LD + i] = r[p].w;
     } else {
       const int k = (tid >> 4) + 16 * p, i = 4 * (tid & 15);
-      S[k * LD + i + 0] = r[p].x;
-      S[k * LD + i + 1] = r[p].y;
-      S[k * LD + i + 2] = r[p].z;
-      S[k * LD + i + 3] = r[p].w;
+      *reinterpret_cast<float4*>(S + k * LD + i) = r[p];
     }
   }
 }
@@ -95,8 +98,9 @@ __global__ __launch_bounds__(kBlock) void gemm64_kernel(const float* __restrict_
                                                         int64_t split_stride, const float* __restrict__ bias,
                                                         const uint8_t* __restrict__ keep, float scale,
                                                         const uint8_t* __restrict__ maskA, float scaleA) {
-  __shared__ float As[2][BK * LD];
-  __shared__ float Bs[2][BK * LD];
+  constexpr int LD = ld_of<DIRECT>();
+  __shared__ __attribute__((aligned(16))) float As[2][BK * LD];
+  __shared__ __attribute__((aligned(16))) float Bs[2][BK * LD];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int64_t i0 = (int64_t)blockIdx.x * BT, j0 = (int64_t)blockIdx.y * BT;

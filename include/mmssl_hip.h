@@ -50,7 +50,8 @@ const char* mmssl_strerror(int code);
  * The plan holds, on the device of the current HIP context: the CSR (edges packed as
  * {col,val} pairs), its transpose (for backward: torch autograd's A^T . gradY), and a
  * degree-balanced work list (short rows -> one 16-lane group each, long rows split into
- * <=128-nnz wave tasks with a deterministic second-stage sum).
+ * <=128-nnz wave slices, four slices of a row per block summed through LDS, rows beyond 512
+ * edges combined across blocks in a fixed order).
  * nnz == 0 is legal (the reference's "empty modal graph" state).
  * ---------------------------------------------------------------------------------- */
 typedef struct mmssl_graph mmssl_graph;
@@ -73,10 +74,17 @@ int mmssl_csr_validate_host(const int32_t* rowptr, const int32_t* col, int32_t r
 int mmssl_csr_transpose_host(const int32_t* rowptr, const int32_t* col, const float* val,
                              int32_t rows, int32_t cols, int64_t nnz, int32_t* t_rowptr,
                              int32_t* t_col, float* t_val);
-/* counts[0..3] = group_items, wave_items, multi_rows, partial_slots */
+/* counts[0..3] = group_items, wave_items (incl. padding), multi_rows, partial_slots */
 int mmssl_plan_count_host(const int32_t* rowptr, int32_t rows, int64_t counts[4]);
-/* items are int32 quadruples {row, edge_begin, edge_end, slot(-1 = direct)};
- * multi are quadruples {row, first_slot, n_slots, 0}. */
+/* items are int32 quadruples {row, edge_begin, edge_end, code}:
+ *   group items : rows with <= 32 edges (one lane group each), longest first, code -1;
+ *   wave items  : <= 128-edge slices, [heavy section | light section]:
+ *       light, code -1 : a whole row of 33..128 edges;
+ *       heavy : rows with > 128 edges, heaviest first, each row padded with no-work items
+ *               {-1,0,0,code} to a multiple of 4 so that one 4-wave block holds slices of ONE row
+ *               (summed through LDS): code -2 = the row fits the block (<= 512 edges);
+ *               code s >= 0 = the row spans several blocks and this block owns partial slot s;
+ *   multi are quadruples {row, first_slot, n_slots, 0} for the rows that span several blocks. */
 int mmssl_plan_fill_host(const int32_t* rowptr, int32_t rows, int32_t* group_items,
                          int32_t* wave_items, int32_t* multi);
 

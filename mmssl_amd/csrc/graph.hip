@@ -33,11 +33,12 @@ int env_int(const char* name, int dflt) {
 int short_max() { static int v = std::max(1, env_int("MMSSL_PLAN_SHORT_MAX", 32)); return v; }
 int task_nnz() { static int v = std::max(short_max(), env_int("MMSSL_PLAN_TASK_NNZ", 128)); return v; }
 int plan_sort() { static int v = env_int("MMSSL_PLAN_SORT", 1); return v; }
-// 1 (default) = rows cut into several wave items are combined by a small second kernel;
-// 0 = by the last-arriving wave inside the SpMM kernel (write-through partials + arrival ticket).
-// Measured on MI355X (Baby shape): two-stage 11.2 us per SpMM vs 12.1 us in-kernel (the serial
-// tail of the last arrivers costs more than the ~1.5 us launch boundary), fence-based 17.8 us.
-int two_stage() { static int v = env_int("MMSSL_SPMM_TWO_STAGE", 1); return v; }
+// 0 (default) = rows that span several heavy blocks are combined by the last-arriving block inside the
+// SpMM kernel (write-through partials + arrival ticket); 1 = by a small second kernel.
+// Measured on MI355X (Baby shape) with the block-grouped plan (only rows > 512 nnz span blocks: 2 + 30 rows):
+// in-kernel 75.2 us vs two-stage 76.7 us for the 6-SpMM forward chain, 12.8 vs 16.3 us for one eager launch.
+// (With one slot per 128-nnz slice — 183 multi rows on the item side — the in-kernel form was the slower one.)
+int two_stage() { static int v = env_int("MMSSL_SPMM_TWO_STAGE", 0); return v; }
 
 struct DirPlan {
   int32_t rows = 0, cols = 0;
@@ -139,6 +140,29 @@ extern "C" int mmssl_csr_transpose_host(const int32_t* rowptr, const int32_t* co
   return 0;
 }
 
+// Work-list layout (see include/mmssl_hip.h):
+//   group items : rows with deg <= short_max, one lane group each, longest first.
+//   wave items  : <= task_nnz-edge slices {row, beg, end, code}; the list is [heavy section | light section].
+//     light  (code -1): a whole row of short_max < deg <= task_nnz; four unrelated rows share a block.
+//     heavy  : rows with deg > task_nnz, heaviest first; a row's slices are padded with no-work items
+//              {-1, 0, 0, code} to a multiple of 4, so every BLOCK of the heavy section holds slices of ONE row.
+//              Its four waves add their partial sums through LDS;
+//              code -2 : the row fits this block (deg <= 4 task_nnz) -> epilogue + store, no partial slot;
+//              code s>=0: the row spans several blocks; this block owns partial slot s (one per block, not
+//                         one per slice: 4x fewer slots and 4x fewer rows that need a cross-block combine).
+//   multi       : rows spanning several blocks {row, first_slot, n_slots, 0}.
+namespace {
+struct HeavyRow { int32_t row; int32_t deg; };
+inline void heavy_rows_sorted(const int32_t* rowptr, int32_t rows, int tn, std::vector<HeavyRow>& out) {
+  for (int32_t r = 0; r < rows; ++r) {
+    const int32_t deg = rowptr[r + 1] - rowptr[r];
+    if (deg > tn) out.push_back({r, deg});
+  }
+  if (plan_sort())
+    std::stable_sort(out.begin(), out.end(), [](const HeavyRow& a, const HeavyRow& b) { return a.deg > b.deg; });
+}
+}  // namespace
+
 extern "C" int mmssl_plan_count_host(const int32_t* rowptr, int32_t rows, int64_t counts[4]) {
   if (!rowptr || !counts || rows < 0) return MMSSL_E_BADARG;
   const int smax = short_max(), tn = task_nnz();
@@ -147,10 +171,13 @@ extern "C" int mmssl_plan_count_host(const int32_t* rowptr, int32_t rows, int64_
     const int64_t deg = rowptr[r + 1] - rowptr[r];
     if (deg <= smax) {
       ++g;
+    } else if (deg <= tn) {
+      ++w;                                   // light wave item
     } else {
-      const int64_t t = (deg + tn - 1) / tn;
-      w += t;
-      if (t > 1) { ++m; s += t; }
+      const int64_t t = (deg + tn - 1) / tn;   // slices
+      const int64_t nb = (t + 3) / 4;          // blocks
+      w += nb * 4;                             // padded
+      if (nb > 1) { ++m; s += nb; }
     }
   }
   counts[0] = g; counts[1] = w; counts[2] = m; counts[3] = s;
@@ -171,6 +198,32 @@ extern "C" int mmssl_plan_fill_host(const int32_t* rowptr, int32_t rows, int32_t
     for (int k = 0; k <= smax; ++k) start[k + 1] += start[k];
   }
   int64_t gseq = 0, w = 0, m = 0, slot = 0;
+  // heavy section first
+  std::vector<HeavyRow> heavy;
+  heavy_rows_sorted(rowptr, rows, tn, heavy);
+  for (const HeavyRow& hr : heavy) {
+    const int32_t beg = rowptr[hr.row], end = rowptr[hr.row + 1];
+    const int32_t t = (hr.deg + tn - 1) / tn, nb = (t + 3) / 4;
+    if (nb > 1) {
+      int32_t* mm = mi + m * 4;
+      mm[0] = hr.row; mm[1] = (int32_t)slot; mm[2] = nb; mm[3] = 0;
+      ++m;
+    }
+    for (int32_t k = 0; k < nb * 4; ++k) {
+      int32_t* it = wi + w * 4;
+      const int32_t code = nb > 1 ? (int32_t)(slot + k / 4) : -2;
+      if (k < t) {
+        it[0] = hr.row;
+        it[1] = beg + k * tn;
+        it[2] = std::min(end, beg + (k + 1) * tn);
+      } else {
+        it[0] = -1; it[1] = 0; it[2] = 0;
+      }
+      it[3] = code;
+      ++w;
+    }
+    if (nb > 1) slot += nb;
+  }
   for (int32_t r = 0; r < rows; ++r) {
     const int32_t beg = rowptr[r], end = rowptr[r + 1];
     const int deg = end - beg;
@@ -178,21 +231,10 @@ extern "C" int mmssl_plan_fill_host(const int32_t* rowptr, int32_t rows, int32_t
       const int64_t pos = plan_sort() ? start[smax - deg]++ : gseq++;
       int32_t* it = gi + pos * 4;
       it[0] = r; it[1] = beg; it[2] = end; it[3] = -1;
-    } else {
-      const int32_t t = (deg + tn - 1) / tn;
-      if (t > 1) {
-        int32_t* mm = mi + m * 4;
-        mm[0] = r; mm[1] = (int32_t)slot; mm[2] = t; mm[3] = 0;
-        ++m;
-      }
-      for (int32_t k = 0; k < t; ++k) {
-        int32_t* it = wi + w * 4;
-        it[0] = r;
-        it[1] = beg + k * tn;
-        it[2] = std::min(end, beg + (k + 1) * tn);
-        it[3] = (t > 1) ? (int32_t)slot++ : -1;
-        ++w;
-      }
+    } else if (deg <= tn) {
+      int32_t* it = wi + w * 4;
+      it[0] = r; it[1] = beg; it[2] = end; it[3] = -1;
+      ++w;
     }
   }
   return 0;
@@ -373,40 +415,72 @@ __global__ __launch_bounds__(kBlock) void spmm_kernel(const int4* __restrict__ g
     acc = apply_epilogue<LPR, EPI>(acc, it.x, lig, epi);
     Y[(size_t)it.x * LPR + lig] = acc;
   } else {
-    const int wi = (int)blockIdx.x * 4 + ((int)threadIdx.x >> 6);
-    if (wi >= n_w) return;
-    const int4 it = witems[wi];
-    float4 acc = gather_rows<LPR>(edges, X, it.y, it.z, lane / LPR, GPW, lig);
-    acc.x = cross_group_sum<LPR>(acc.x);
-    acc.y = cross_group_sum<LPR>(acc.y);
-    acc.z = cross_group_sum<LPR>(acc.z);
-    acc.w = cross_group_sum<LPR>(acc.w);
-    if (it.w < 0) {
+    const int wave = (int)threadIdx.x >> 6;
+    const int wi = (int)blockIdx.x * 4 + wave;
+    const int code0 = witems[(int)blockIdx.x * 4].w;       // block-uniform: light (-1) or heavy block
+    if (code0 == -1) {                                      // four unrelated whole rows
+      if (wi >= n_w) return;
+      const int4 it = witems[wi];
+      float4 acc = gather_rows<LPR>(edges, X, it.y, it.z, lane / LPR, GPW, lig);
+      acc.x = cross_group_sum<LPR>(acc.x);
+      acc.y = cross_group_sum<LPR>(acc.y);
+      acc.z = cross_group_sum<LPR>(acc.z);
+      acc.w = cross_group_sum<LPR>(acc.w);
       acc = apply_epilogue<LPR, EPI>(acc, it.x, lig, epi);
       if (lane < LPR) Y[(size_t)it.x * LPR + lig] = acc;
-    } else {
+      return;
+    }
+    // ---- heavy block: up to four slices of ONE row (the heavy section is padded to whole blocks) ----
+    __shared__ float4 red[4][LPR];
+    const int4 it = witems[wi];
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (it.x >= 0) {
+      acc = gather_rows<LPR>(edges, X, it.y, it.z, lane / LPR, GPW, lig);
+      acc.x = cross_group_sum<LPR>(acc.x);
+      acc.y = cross_group_sum<LPR>(acc.y);
+      acc.z = cross_group_sum<LPR>(acc.z);
+      acc.w = cross_group_sum<LPR>(acc.w);
+    }
+    if (lane < LPR) red[wave][lig] = acc;
+    __syncthreads();
+    if (wave != 0) return;
+    const int row = witems[(int)blockIdx.x * 4].x;          // the first slice of a block is never padding
+    if (lane < LPR) {
+      const float4 b1 = red[1][lig], b2 = red[2][lig], b3 = red[3][lig];
+      acc.x = ((acc.x + b1.x) + b2.x) + b3.x;
+      acc.y = ((acc.y + b1.y) + b2.y) + b3.y;
+      acc.z = ((acc.z + b1.z) + b2.z) + b3.z;
+      acc.w = ((acc.w + b1.w) + b2.w) + b3.w;
+    }
+    if (code0 == -2) {                                      // the whole row lives in this block
+      acc = apply_epilogue<LPR, EPI>(acc, row, lig, epi);
+      if (lane < LPR) Y[(size_t)row * LPR + lig] = acc;
+      return;
+    }
+    {
+      const int slot = code0;
       if (arrivals == nullptr) {           // two-stage mode: spmm_multi_kernel combines
-        if (lane < LPR) partials[(size_t)it.w * LPR + lig] = acc;
+        if (lane < LPR) partials[(size_t)slot * LPR + lig] = acc;
         return;
       }
-      // ---- in-kernel combine by the LAST-arriving wave of this row (split-K arrival pattern) ----
+      // ---- in-kernel combine by the LAST-arriving block of this row (split-K arrival pattern) ----
       // The 16*LPR-byte partial is stored WRITE-THROUGH (agent-scope relaxed atomic stores lower to
       // `global_store ... sc1`), drained, then one lane takes a ticket: no release fence, so the
       // other rows' dirty output lines stay in this XCD's L2. The last arriver re-reads every
       // slot with sc1 loads (bypass the non-coherent L1) in a FIXED order, so the result does not
-      // depend on which wave happens to be last.
+      // depend on which block happens to be last.
       typedef unsigned long long u64;
       u64* pw = reinterpret_cast<u64*>(partials);
       if (lane < LPR) {
         u64 lo, hi;
         __builtin_memcpy(&lo, &acc.x, 8);
         __builtin_memcpy(&hi, &acc.z, 8);
-        const size_t o = ((size_t)it.w * LPR + lig) * 2;
+        const size_t o = ((size_t)slot * LPR + lig) * 2;
         __hip_atomic_store(pw + o, lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(pw + o + 1, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      const int m = slot2multi[it.w];
+      const int m = slot2multi[slot];
       const int4 mr = multi[m];            // {row, first_slot, n_slots, 0}
       int last = 0;
       if (lane == 0) {
@@ -439,7 +513,7 @@ __global__ __launch_bounds__(kBlock) void spmm_kernel(const int4* __restrict__ g
   }
 }
 
-// second stage for rows cut into several wave items: one block per such row. Lane group g
+// second stage for rows that span several heavy blocks: one block per such row. Lane group g
 // adds slots g, g+GPB, ... (independent loads), the GPB group sums are combined through LDS in a
 // fixed order -> bitwise reproducible, and the serial depth is slots/GPB instead of slots.
 template <int LPR, int EPI>

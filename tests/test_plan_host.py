@@ -72,22 +72,43 @@ def test_plan_covers_every_edge_once():
     gdeg = g[:, 2] - g[:, 1]
     assert np.all(np.diff(gdeg) <= 0)
     assert 3 in g[:, 0] and gdeg[-1] == 0
-    # wave items tile the long rows
+    # wave items tile the long rows; the list is [heavy section (whole blocks of 4 per row) | light section]
     covered = np.zeros(m.nnz, np.int32)
-    for row, beg, end, slot in w:
+    for row, beg, end, code in w:
+        if row < 0:                                  # padding of a heavy row's last block: no work
+            assert beg == 0 and end == 0 and code != -1
+            continue
         assert deg[row] > short_max and 0 < end - beg <= task
         covered[beg:end] += 1
     for row, beg, end, slot in g:
         covered[beg:end] += 1
     assert np.all(covered == 1)
-    # multi rows own consecutive slots
-    assert slots == int(sum(-(-int(deg[r]) // task) for r in np.nonzero(deg > task)[0]))
+    heavy = w[w[:, 3] != -1]
+    light = w[w[:, 3] == -1]
+    assert len(heavy) % 4 == 0 and np.array_equal(w[:len(heavy)], heavy)        # heavy section first
+    assert all(short_max < deg[r] <= task for r in light[:, 0])
+    assert sorted(light[:, 0].tolist()) == np.nonzero((deg > short_max) & (deg <= task))[0].tolist()
+    # every block of the heavy section holds slices of ONE row, real slices first, one code per block
+    hdeg = []
+    for b0 in range(0, len(heavy), 4):
+        blk = heavy[b0:b0 + 4]
+        assert blk[0, 0] >= 0 and len(set(blk[:, 3].tolist())) == 1
+        real = blk[blk[:, 0] >= 0]
+        assert len(set(real[:, 0].tolist())) == 1 and np.all(blk[:len(real), 0] >= 0)
+        assert deg[blk[0, 0]] > task
+        hdeg.append(int(deg[blk[0, 0]]))
+    assert all(a >= b for a, b in zip(hdeg, hdeg[1:]))                           # heaviest rows first
+    blocks_of = lambda d: -(-(-(-int(d) // task)) // 4)                          # noqa: E731  ceil(ceil(d/task)/4)
+    # rows that fit one block (deg <= 4*task) need no partial slot; the others own one slot per block
+    assert slots == int(sum(blocks_of(deg[r]) for r in np.nonzero(deg > 4 * task)[0]))
     seen = []
     for row, first, n, _ in multi:
-        assert n == -(-int(deg[row]) // task) and n > 1
-        mine = w[w[:, 0] == row]
-        assert mine[:, 3].tolist() == list(range(first, first + n))
+        assert deg[row] > 4 * task and n == blocks_of(deg[row]) and n > 1
+        mine = heavy[heavy[:, 0] == row]
+        assert len(mine) == -(-int(deg[row]) // task)
+        assert mine[:, 3].tolist() == [first + k // 4 for k in range(len(mine))]
         seen += list(range(first, first + n))
     assert sorted(seen) == list(range(slots))
-    single = w[w[:, 3] < 0]
-    assert all(deg[r] <= task for r in single[:, 0])
+    fit = [r for r in np.nonzero((deg > task) & (deg <= 4 * task))[0]]
+    for r in fit:
+        assert set(heavy[heavy[:, 0] == r][:, 3].tolist()) == {-2}

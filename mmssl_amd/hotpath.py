@@ -36,6 +36,7 @@ class HotPathStep:
         self.optimizer = FusedAdamW([{"params": tables}, {"params": rest}], lr=lr or args.lr)
         self.loss = torch.zeros((), device=dev)
         self._one = torch.ones((), device=dev)
+        self._feat_c, self._feat_c_val = None, None
         self.parts = {}
         self._graph = None
         # ONE stream for everything this object launches (eager steps, capture, replays): autograd
@@ -61,7 +62,11 @@ class HotPathStep:
                                      self.batch_size, args.tau)                 # [mf, emb, 0, cl_img, cl_txt]
         ss = m.feat_sumsq(img_item, txt_item, img_user, txt_user)
         # the step's loss lands in the persistent buffer self.loss (read back by callers after a replay)
-        total = ops.loss_assemble(terms, self.loss_w, ss, args.feat_reg_decay * 0.5 / m.n_items, out=self.loss)
+        c = args.feat_reg_decay * 0.5 / m.n_items
+        if self._feat_c is None or self._feat_c_val != c:
+            self._feat_c, self._feat_c_val = torch.full((), c, dtype=torch.float32, device=self.loss.device), c
+        # _step() backpropagates the persistent ones tensor: the assembly's gradients are the constants
+        total = ops.loss_assemble(terms, self.loss_w, ss, c, out=self.loss, unit_grad_c=self._feat_c)
         return total, dict(terms=terms, ss=ss)
 
     def step(self):

@@ -558,10 +558,12 @@ def batch_losses(ua, ia, img_uid, txt_uid, users, pos, neg, decay, batch_size, t
 class _LossAssemble(torch.autograd.Function):
     """total = sum_k w[k] * terms[k] + c * extra   (main.py:420) in one launch, written into `out` when
     given (a persistent buffer: no copy of the step's loss afterwards); the backward is one launch too,
-    instead of the ~20 scalar autograd kernels of the op-by-op expression."""
+    instead of the ~20 scalar autograd kernels of the op-by-op expression. With `unit_grad` the caller
+    PROMISES to backpropagate a gradient of exactly 1 (HotPathStep passes its persistent ones tensor): the
+    gradients are then the constants w and c themselves and the backward launches nothing."""
 
     @staticmethod
-    def forward(ctx, terms, w, extra, c, out):
+    def forward(ctx, terms, w, extra, c, out, unit_grad):
         if out is not None:
             # a fresh tensor object over `out`'s memory: the result carries the autograd history, the
             # caller's buffer stays a plain leaf that can be passed again next step
@@ -575,24 +577,29 @@ class _LossAssemble(torch.autograd.Function):
         ctx.save_for_backward(w)
         ctx.c = float(c)
         ctx.has_extra = extra is not None
+        ctx.unit = unit_grad if (unit_grad is None or isinstance(unit_grad, torch.Tensor)) else None
         return total
 
     @staticmethod
     def backward(ctx, g):
         (w,) = ctx.saved_tensors
+        if ctx.unit is not None:             # promised d(total) == 1: gradients are the constants themselves
+            return w, None, (ctx.unit if ctx.has_extra else None), None, None, None
         g = g.contiguous().to(torch.float32)
         gt = torch.empty_like(w)
         ge = torch.empty((), dtype=torch.float32, device=w.device) if ctx.has_extra else None
         rc = _lib.lib().mmssl_loss_assemble_bwd_f32(_ptr(g), _ptr(w), w.numel(), ctx.c, _ptr(gt), _ptr(ge),
                                                     _lib.stream_ptr())
         _lib.check(rc, "mmssl_loss_assemble_bwd_f32")
-        return gt, None, ge, None, None
+        return gt, None, ge, None, None, None
 
 
-def loss_assemble(terms, w, extra=None, c=0.0, out=None):
+def loss_assemble(terms, w, extra=None, c=0.0, out=None, unit_grad_c=None):
+    """`unit_grad_c`: a persistent 0-dim tensor holding the value `c`; passing it is the promise that the
+    result is backpropagated with a gradient of exactly 1 (see _LossAssemble)."""
     if out is not None and (out.dtype != torch.float32 or out.numel() != 1 or not out.is_cuda or out.requires_grad):
         raise _lib.MmsslError("loss_assemble: `out` must be a one-element fp32 HIP tensor that needs no gradient")
-    return _LossAssemble.apply(_chk(terms, "terms"), _chk(w, "w"), extra, c, out)
+    return _LossAssemble.apply(_chk(terms, "terms"), _chk(w, "w"), extra, c, out, unit_grad_c)
 
 
 class _ZeroGradAnchor(torch.autograd.Function):

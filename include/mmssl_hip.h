@@ -121,6 +121,9 @@ int mmssl_graph_rows_dense_f32(const mmssl_graph* g, const int64_t* rows, int64_
 
 /* t = A.X + alpha * Z[row]; Y = S[row]*(t - <t,S[row]>)  */
 
+/* Workspace of one launch = partial sums of the rows that span several blocks + their arrival counters.
+ * It must be ZERO-FILLED ONCE by the caller before its first use (every launch leaves the counters zero
+ * again). Launches that may overlap on different streams need different workspaces. */
 size_t mmssl_spmm_workspace_bytes(const mmssl_graph* g, int transpose, int d);
 int mmssl_spmm_f32(const mmssl_graph* g, int transpose, const float* X, int d, float* Y,
                    int epilogue, void* workspace, size_t workspace_bytes, void* stream);

@@ -49,7 +49,6 @@ struct DirPlan {
   int4* witems = nullptr;     // wave items   {row, beg, end, slot|-1}
   int4* multi = nullptr;      // multi rows   {row, first_slot, n_slots, 0}
   int32_t* slot2multi = nullptr;  // [n_slots] -> index into `multi`
-  int32_t* arrivals = nullptr;    // [n_multi] arrival counters of the in-kernel combine (zero between launches)
   int64_t n_g = 0, n_w = 0, n_multi = 0, n_slots = 0;
 };
 
@@ -60,7 +59,6 @@ void free_dir(DirPlan& p) {
   if (p.witems) (void)hipFree(p.witems);
   if (p.multi) (void)hipFree(p.multi);
   if (p.slot2multi) (void)hipFree(p.slot2multi);
-  if (p.arrivals) (void)hipFree(p.arrivals);
   p = DirPlan();
 }
 
@@ -91,11 +89,10 @@ int build_dir(DirPlan& p, const int32_t* rowptr, const int32_t* col, const float
   if ((rc = upload(&p.gitems, reinterpret_cast<const int4*>(g.data()), (size_t)p.n_g))) return rc;
   if ((rc = upload(&p.witems, reinterpret_cast<const int4*>(w.data()), (size_t)p.n_w))) return rc;
   if ((rc = upload(&p.multi, reinterpret_cast<const int4*>(m.data()), (size_t)p.n_multi))) return rc;
-  std::vector<int32_t> s2m((size_t)p.n_slots), zeros((size_t)p.n_multi, 0);
+  std::vector<int32_t> s2m((size_t)p.n_slots);
   for (int64_t k = 0; k < p.n_multi; ++k)
     for (int32_t j = 0; j < m[k * 4 + 2]; ++j) s2m[(size_t)m[k * 4 + 1] + j] = (int32_t)k;
   if ((rc = upload(&p.slot2multi, s2m.data(), (size_t)p.n_slots))) return rc;
-  if ((rc = upload(&p.arrivals, zeros.data(), (size_t)p.n_multi))) return rc;
   return 0;
 }
 
@@ -549,9 +546,19 @@ __global__ __launch_bounds__(kBlock) void spmm_multi_kernel(const int4* __restri
   }
 }
 
+// Workspace of one SpMM launch: [partial slots: n_slots * d floats | arrival counters: n_multi int32].
+// The counters belong to the WORKSPACE, not to the plan: launches that overlap on different streams use
+// different workspaces (GraphPlan.twin), and each must count its own arrivals. They must be zero before the
+// first launch; every launch leaves them zero again (the last arriver re-arms its counter).
+inline size_t ws_partials_bytes(const DirPlan& p, int d) { return (((size_t)p.n_slots * (size_t)d * sizeof(float)) + 15) & ~(size_t)15; }
+inline size_t ws_total_bytes(const DirPlan& p, int d) {
+  return ws_partials_bytes(p, d) + ((((size_t)p.n_multi * sizeof(int32_t)) + 15) & ~(size_t)15);
+}
+
 template <int LPR, int EPI>
 int launch_spmm(const DirPlan& p, const float* X, float* Y, float* partials, const EpiArgs& epi,
                 hipStream_t s) {
+  int32_t* arrivals = reinterpret_cast<int32_t*>(reinterpret_cast<char*>(partials) + ws_partials_bytes(p, LPR * 4));
   constexpr int GPB = kBlock / LPR;
   const int n_wblocks = (int)((p.n_w + 3) / 4);
   const int n_gblocks = (int)((p.n_g + GPB - 1) / GPB);
@@ -560,7 +567,7 @@ int launch_spmm(const DirPlan& p, const float* X, float* Y, float* partials, con
                        p.gitems, (int)p.n_g, p.witems, (int)p.n_w, n_wblocks, p.edges,
                        reinterpret_cast<const float4*>(X), reinterpret_cast<float4*>(Y),
                        reinterpret_cast<float4*>(partials), epi, p.multi, p.slot2multi,
-                       two_stage() ? (int32_t*)nullptr : p.arrivals);
+                       two_stage() ? (int32_t*)nullptr : arrivals);
     MMSSL_LAUNCH_CHECK();
   }
   if (p.n_multi > 0 && two_stage()) {
@@ -589,7 +596,7 @@ int dispatch_epi(const DirPlan& p, const float* X, float* Y, float* partials, in
 extern "C" size_t mmssl_spmm_workspace_bytes(const mmssl_graph* g, int transpose, int d) {
   if (!g || d <= 0) return 0;
   const DirPlan& p = transpose ? g->bwd : g->fwd;
-  return (size_t)p.n_slots * (size_t)d * sizeof(float);
+  return p.n_slots > 0 ? ws_total_bytes(p, d) : 0;
 }
 
 extern "C" int mmssl_spmm_ex_f32(const mmssl_graph* g, int transpose, const float* X, int d, float* Y,
@@ -603,7 +610,7 @@ extern "C" int mmssl_spmm_ex_f32(const mmssl_graph* g, int transpose, const floa
   if ((epilogue == MMSSL_EPI_AXPY || epilogue == MMSSL_EPI_AXPY_SOFTMAX_BWD) && !Z) return MMSSL_E_BADARG;
   if (epilogue == MMSSL_EPI_AXPY_SOFTMAX_BWD && !S) return MMSSL_E_BADARG;
   if (((uintptr_t)X | (uintptr_t)Y | (uintptr_t)workspace | (uintptr_t)Z | (uintptr_t)S) & 15) return MMSSL_E_BADARG;
-  const size_t need = (size_t)p.n_slots * (size_t)d * sizeof(float);
+  const size_t need = p.n_slots > 0 ? ws_total_bytes(p, d) : 0;
   if (need > 0 && (!workspace || workspace_bytes < need)) return MMSSL_E_WORKSPACE;
   hipStream_t s = as_stream(stream);
   float* ws = reinterpret_cast<float*>(workspace);

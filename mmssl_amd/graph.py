@@ -67,14 +67,15 @@ class GraphPlan:
         return {k: int(v) for k, v in zip(keys, buf) if k != "_"}
 
     def workspace(self, transpose, d, lane=0):
-        """Scratch for the partial sums of rows cut into several wave tasks; cached per
-        (direction, d, lane) so pointers stay stable under hipGraph replay. SpMMs that may run
-        CONCURRENTLY on different streams must use different lanes (see `twin`)."""
+        """Scratch of one SpMM launch (partial sums of the rows that span several blocks + their arrival
+        counters, which must start at zero); cached per (direction, d, lane) so pointers stay stable under
+        hipGraph replay. SpMMs that may run CONCURRENTLY on different streams must use different lanes
+        (see `twin`): they would otherwise share partial slots AND arrival counters."""
         key = (bool(transpose), int(d), int(lane))
         ws = self._ws.get(key)
         if ws is None:
             nbytes = _lib.lib().mmssl_spmm_workspace_bytes(self.handle, int(bool(transpose)), int(d))
-            ws = torch.empty(max(nbytes // 4, 4), dtype=torch.float32, device=self.device)
+            ws = torch.zeros(max(nbytes // 4, 4), dtype=torch.float32, device=self.device)
             self._ws[key] = ws
         return ws
 

@@ -481,3 +481,37 @@ def test_usim_matches_oracle_and_dense_rows(U, I, d, B):
     assert H.rel_err(ig.grad.cpu(), ir.grad) < 2e-5
     rows = ops.graph_rows_dense(plan, users, 1.0)
     assert torch.equal(rows.cpu(), torch.from_numpy(dense.astype(np.float32)))
+
+
+def test_spmm_concurrent_launches_on_one_plan_do_not_share_state():
+    """The three chains of the fused forward/backward run SpMMs on the SAME plan at the same time on different
+    streams (GraphPlan.twin = own workspace). Rows that span several blocks are combined through partial
+    slots and arrival counters in that workspace: overlapping launches must not see each other's (regression:
+    the counters once lived in the plan and concurrent launches corrupted the heavy rows)."""
+    from mmssl_amd import ops, synth
+    from mmssl_amd.graph import GraphPlan
+    U, I, E, _, _ = synth.SHAPES["baby"]
+    raw = synth.interaction_matrix(U, I, E, seed=1)
+    ui, iu = synth.normalised_pair(raw)
+    plan = GraphPlan(iu)                                   # item rows: 30 rows beyond 512 nnz
+    assert plan.info()["multi_rows"] >= 10
+    d = 64
+    gen = torch.Generator().manual_seed(3)
+    Xs = [torch.randn(U, d, generator=gen).to(DEV) for _ in range(3)]
+    with torch.no_grad():
+        refs = [ops._spmm_raw(plan, False, X, ops.EPI_NONE).clone() for X in Xs]      # sequential, one stream
+        torch.cuda.synchronize()
+        streams = [torch.cuda.Stream() for _ in range(3)]
+        views = [plan, plan.twin(1), plan.twin(2)]
+        for rnd in range(30):
+            outs = []
+            # a spin kernel first: all three launches are queued behind it and then start TOGETHER
+            # (launched one by one from Python they would never overlap on the device)
+            torch.cuda._sleep(3_000_000)
+            for k, st in enumerate(streams):
+                st.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(st):
+                    outs.append(ops._spmm_raw(views[k], False, Xs[(k + rnd) % 3], ops.EPI_NONE))
+            torch.cuda.synchronize()
+            for k in range(3):
+                assert torch.equal(outs[k], refs[(k + rnd) % 3]), (rnd, k)

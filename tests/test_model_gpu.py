@@ -209,6 +209,7 @@ def test_hotpath_graph_replay_with_stream_overlap_matches_eager_sequential():
                 torch.randint(0, I, (B,), generator=g)) for _ in range(4)]
 
     def run(overlap, capture):
+        """One warm-up step on batch 0 (eager; inside capture() for the captured run), then the 4 batches."""
         os.environ["MMSSL_STREAMS"] = "1" if overlap else "0"
         torch.manual_seed(11)
         model = MMSSL(U, I, 64, [64] * 3, [0.1] * 3, img, txt).to(DEV).train()
@@ -216,7 +217,9 @@ def test_hotpath_graph_replay_with_stream_overlap_matches_eager_sequential():
         step = HotPathStep(model, (GraphPlan(ui), GraphPlan(iu), e1, e2, e1, e2), B)
         step.set_batch(*[t.to(DEV) for t in batches[0]])
         if capture:
-            assert step.capture(warmup=0), getattr(step, "capture_error", "")
+            assert step.capture(warmup=1), getattr(step, "capture_error", "")
+        else:
+            step.step()
         losses = []
         for b in batches:
             step.set_batch(*[t.to(DEV) for t in b])
@@ -226,24 +229,20 @@ def test_hotpath_graph_replay_with_stream_overlap_matches_eager_sequential():
         return losses, model.item_id_embedding.weight.detach().cpu().clone(), model.image_trans.weight.detach().cpu().clone()
 
     try:
-        ref_l, ref_e, ref_w = run(overlap=False, capture=False)
-        got_l, got_e, got_w = run(overlap=True, capture=True)
+        ref_l, ref_e, ref_w = run(overlap=False, capture=False)          # one stream, eager
+        got_l, got_e, got_w = run(overlap=True, capture=True)            # forked streams inside a hipGraph
+        ov_l, ov_e, ov_w = run(overlap=True, capture=False)              # forked streams, eager
     finally:
         os.environ.pop("MMSSL_STREAMS", None)
-    # the captured run executed one extra (capture) step on batch 0 before the loop: compare from there
-    ref2_l, _, _ = ref_l, ref_e, ref_w
     assert all(np.isfinite(got_l)) and all(np.isfinite(ref_l))
-    # same first-step loss (identical init, identical batch)
-    assert abs(got_l[0] - ref_l[0]) <= 5e-3 * abs(ref_l[0])      # captured run is one AdamW step ahead
-    # exact trajectory check: eager+overlap (no capture) vs eager sequential
-    os.environ["MMSSL_STREAMS"] = "1"
-    try:
-        ov_l, ov_e, ov_w = run(overlap=True, capture=False)
-    finally:
-        os.environ.pop("MMSSL_STREAMS", None)
-    for a, b in zip(ov_l, ref_l):
-        assert abs(a - b) <= 1e-5 * abs(b), (ov_l, ref_l)
-    assert H.rel_err(ov_e, ref_e) < 1e-4 and H.rel_err(ov_w, ref_w) < 1e-4
+    # Streams and graph replay change WHEN kernels run, never what they compute (every reduction has a fixed
+    # order): the three trajectories agree to rounding. In a replayed graph the chains really overlap on the
+    # device (SpMMs on one plan at the same time), so this is also the race check for shared kernel state.
+    for name, (l, e, w) in (("graph+streams", (got_l, got_e, got_w)), ("streams", (ov_l, ov_e, ov_w))):
+        for a, b in zip(l, ref_l):
+            assert abs(a - b) <= 1e-5 * abs(b), (name, l, ref_l)
+        assert H.rel_err(e, ref_e) < 1e-5, name
+        assert H.rel_err(w, ref_w) < 1e-5, name
 
 
 def test_eval_on_device_matches_reference_recall(tmp_path):

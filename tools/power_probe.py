@@ -73,3 +73,8 @@ run("gemm wgrad img", lambda: _lib.lib().mmssl_linear_wgrad_f32(gY.data_ptr(), N
                                                              gb.data_ptr(), ws.data_ptr(), nb, _lib.stream_ptr()))
 x = torch.randn(8192, 8192, device="cuda")
 run("rocBLAS sgemm 8192^3", lambda: torch.mm(x, x))
+xb = x.to(torch.bfloat16)
+run("rocBLAS/hipBLASLt bf16 gemm 8192^3", lambda: torch.mm(xb, xb))
+small = torch.randn(4 * 1024 * 1024, device="cuda")        # 16 MB: stays in L2 / Infinity Cache
+small2 = torch.empty_like(small)
+run("cache-resident copy 16 MB", lambda: small2.copy_(small))

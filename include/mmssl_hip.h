@@ -182,6 +182,26 @@ size_t mmssl_linear_workspace_bytes(int64_t M, int K, int N);   /* split-K parti
 int mmssl_linear_f32(const float* F, const float* W, const float* b, const uint8_t* keep,
                      float scale, int64_t M, int K, int N, float* Y, void* workspace,
                      size_t workspace_bytes, void* stream);
+/* OPT-IN split-precision product (not used unless the caller asks for it): Y[M,N] = A . B^T (+ bias, dropout
+ * as in mmssl_linear_f32) with A [M,K] and B [N,K] each given as TWO bf16 matrices (hi = bf16(x),
+ * lo = bf16(x - hi)); the result is hi*hi + hi*lo + lo*hi accumulated in fp32 on the bf16 matrix cores
+ * (relative error of a product ~2^-16). K % 32 == 0. Motivation and numbers: DESIGN.md section 4. */
+size_t mmssl_linear_split_workspace_bytes(int64_t M, int K, int N);
+/* N may exceed 256 when b and keep are NULL: the weight gradient gW [N_out, K_in] is this product with
+ * A = gY^T pair [N_out, Mp], B = F^T pair [K_in, Mp] (reduction over the padded M). */
+int mmssl_linear_split_f32(const uint16_t* A_hi, const uint16_t* A_lo, const uint16_t* B_hi,
+                           const uint16_t* B_lo, const float* b, const uint8_t* keep, float scale,
+                           int64_t M, int K, int N, float* Y, void* workspace, size_t workspace_bytes,
+                           void* stream);
+/* Operand preparation for the above: X (n fp32 values, n % 4 == 0) -> hi = bf16(X), lo = bf16(X - hi). */
+int mmssl_split_bf16_f32(const float* X, int64_t n, uint16_t* hi, uint16_t* lo, void* stream);
+/* G [M, N] fp32 (optionally dropout-masked: keep/scale) -> T_hi, T_lo [N, Mp] bf16 = the transposed pair, zero
+ * in columns M..Mp-1 (Mp % 64 == 0: the reduction of the wgrad product runs over Mp); colsum (may be NULL)
+ * receives the column sums of the masked G, i.e. the bias gradient. */
+size_t mmssl_split_transpose_workspace_bytes(int64_t Mp, int N);
+int mmssl_split_transpose_bf16_f32(const float* G, const uint8_t* keep, float scale, int64_t M, int N,
+                                   int64_t Mp, uint16_t* T_hi, uint16_t* T_lo, float* colsum,
+                                   void* workspace, size_t workspace_bytes, void* stream);
 size_t mmssl_linear_wgrad_workspace_bytes(int64_t M, int K, int N);
 int mmssl_linear_wgrad_f32(const float* gY, const uint8_t* keep, float scale, const float* F,
                            int64_t M, int K, int N, float* gW, float* gb, void* workspace,

@@ -156,6 +156,9 @@ class MMSSL(nn.Module):
             else:
                 km_img, km_txt = ops.dropout_masks(2, self.n_items, args.embed_size, p,
                                                    self.image_trans.weight.device)              # 1 = keep
+        if ops.split_projection_enabled():       # opt-in split-precision projection (MMSSL_GEMM_SPLIT=1)
+            ops.register_split_features(self.image_feats)
+            ops.register_split_features(self.text_feats)
         E_u, E_i = self.user_id_embedding.weight, self.item_id_embedding.weight
         # the reference repeats this block args.layers times without feeding anything back
         # (Models.py:176-186): the result is that of one pass.

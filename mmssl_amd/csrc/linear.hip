@@ -270,6 +270,92 @@ __global__ __launch_bounds__(kBlock) void gemm_fwd_dma_kernel(const float* __res
 }
 
 
+// ======================================================================================
+// OPT-IN split-precision product (MMSSL_GEMM_SPLIT=1 on the Python side; NOT the default path):
+//   C[i][j] = sum_k A[i][k] * B[j][k]   with A, B given as bf16 (hi, lo) pairs, x ~= hi + lo (16 mantissa bits),
+//   accumulated in fp32 as  hi*hi + hi*lo + lo*hi  on the bf16 matrix cores (v_mfma_f32_32x32x16_bf16).
+// Why it exists: the fp32 projection is ENERGY-bound at the board's power cap (profiles/r01_power_probe.txt:
+// 5.9 pJ per fp32 matrix flop vs 0.79 pJ per bf16 matrix flop), so three bf16 products cost ~0.4x the matrix energy;
+// the operand pairs occupy the same bytes as fp32. Relative error of a product ~2^-16 (tests bound the result).
+// Same structure as gemm_fwd_dma_kernel: 64x64 block tile, 2x2 waves, 32-deep slices, 4-stage LDS-DMA ring.
+// One stage = four 4 KB tiles (A_hi, A_lo, B_hi, B_lo), each 64 rows x 32 bf16 = 4 chunks of 16 B per row;
+// chunk c of row r sits at slot 4r + (c ^ ((r >> 2) & 3)) (swizzle applied to the DMA source address), which makes
+// the 16-lane groups of ds_read_b128 conflict-free with the 64-B row pitch.
+// ======================================================================================
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+constexpr int kSplitTileBytes = BT * BK * 2;                 // 4 KB
+constexpr int kSplitStageBytes = 4 * kSplitTileBytes;        // 16 KB
+
+__global__ __launch_bounds__(kBlock) void gemm_split_kernel(const uint16_t* __restrict__ Ahi,
+                                                            const uint16_t* __restrict__ Alo, int64_t lda,
+                                                            const uint16_t* __restrict__ Bhi,
+                                                            const uint16_t* __restrict__ Blo, int64_t ldb, int64_t I,
+                                                            int64_t J, int64_t kk_chunk, float* __restrict__ C,
+                                                            int64_t ldc, int64_t split_stride,
+                                                            const float* __restrict__ bias,
+                                                            const uint8_t* __restrict__ keep, float scale) {
+  __shared__ __attribute__((aligned(16))) unsigned char ring[kDmaStages * kSplitStageBytes];   // 64 KB
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int64_t i0 = (int64_t)blockIdx.x * BT, j0 = (int64_t)blockIdx.y * BT;
+  const int64_t kk_beg = (int64_t)blockIdx.z * kk_chunk;
+  const int nk = (int)(kk_chunk / BK);
+  floatx16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  // DMA pieces: wave w moves rows [16w, 16w+16) of each of the four tiles (16 rows x 64 B = 1 KiB per piece)
+  const int pr = 16 * wave + (lane >> 2);
+  const int pc = (lane & 3) ^ ((pr >> 2) & 3);                 // source-side swizzle
+  const int64_t ra = min(i0 + pr, I - 1) * lda + kk_beg + 8 * pc;
+  const int64_t rb = min(j0 + pr, J - 1) * ldb + kk_beg + 8 * pc;
+  const uint16_t* src[4] = {Ahi + ra, Alo + ra, Bhi + rb, Blo + rb};
+  const unsigned ring_lds = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)ring);
+  const unsigned piece = __builtin_amdgcn_readfirstlane((unsigned)(16 * wave * BK * 2));
+  auto issue = [&](int kt) {
+    const unsigned st = ring_lds + (unsigned)(kt & (kDmaStages - 1)) * kSplitStageBytes + piece;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+      glds16(reinterpret_cast<const float*>(src[t] + (int64_t)kt * BK), st + t * kSplitTileBytes);
+  };
+  issue(0);
+  issue(1);
+  issue(2);
+  const int h = lane >> 5, lr = lane & 31;
+  const int ia = (wm * 32 + lr) * (BK * 2), jb = (wn * 32 + lr) * (BK * 2);      // byte offsets of the lane's rows
+  const int swa = ((wm * 32 + lr) >> 2) & 3, swb = ((wn * 32 + lr) >> 2) & 3;
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 2 < nk) vm_wait_n<8>();
+    else if (kt + 1 < nk) vm_wait_n<4>();
+    else vm_wait_n<0>();
+    bare_barrier();
+    if (kt + 3 < nk) issue(kt + 3);
+    const unsigned char* st = ring + (kt & (kDmaStages - 1)) * kSplitStageBytes;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {                // two 16-deep MFMA steps per slice; lane half h owns k = 16t + 8h .. +7
+      const int ca = ((2 * t + h) ^ swa) * 16, cb = ((2 * t + h) ^ swb) * 16;
+      const bf16x8 ah = *reinterpret_cast<const bf16x8*>(st + ia + ca);
+      const bf16x8 al = *reinterpret_cast<const bf16x8*>(st + kSplitTileBytes + ia + ca);
+      const bf16x8 bh = *reinterpret_cast<const bf16x8*>(st + 2 * kSplitTileBytes + jb + cb);
+      const bf16x8 bl = *reinterpret_cast<const bf16x8*>(st + 3 * kSplitTileBytes + jb + cb);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);      // small terms first
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
+    }
+  }
+  const int64_t col = j0 + wn * 32 + (lane & 31);
+  float* Cp = C + (int64_t)blockIdx.z * split_stride;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int64_t row = i0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+    if (row < I && col < J) {
+      float v = acc[r];
+      if (bias) v += bias[col];
+      if (keep) v = keep[row * J + col] ? v * scale : 0.f;
+      Cp[row * ldc + col] = v;
+    }
+  }
+}
+
 // out[e] = epilogue(sum_s P[s][e]);  e = row*J + col.  Split loads are issued four at a time
 // (independent) so the loop is bandwidth- not latency-bound; the add order is fixed.
 __global__ __launch_bounds__(kBlock) void splitk_reduce_kernel(const float* __restrict__ P, int splits,
@@ -356,6 +442,72 @@ __global__ __launch_bounds__(kBlock) void colsum_stage2(const float* __restrict_
   colsum_body(part, 0, kBlock / N, nparts, N, out);
 }
 
+// ---- operand preparation for the opt-in split-precision product -------------------------------------------
+__device__ __forceinline__ uint16_t bf16_rne(float x) {        // round-to-nearest-even, finite inputs
+  unsigned b = __float_as_uint(x);
+  b += 0x7fffu + ((b >> 16) & 1u);
+  return (uint16_t)(b >> 16);
+}
+__device__ __forceinline__ void bf16_pair(float x, uint16_t& hi, uint16_t& lo) {
+  hi = bf16_rne(x);
+  lo = bf16_rne(x - __uint_as_float((unsigned)hi << 16));
+}
+
+__global__ __launch_bounds__(kBlock) void split_pair_kernel(const float4* __restrict__ X, int64_t n4,
+                                                            ushort4* __restrict__ hi, ushort4* __restrict__ lo) {
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n4; i += (int64_t)gridDim.x * kBlock) {
+    const float4 v = X[i];
+    ushort4 h, l;
+    bf16_pair(v.x, h.x, l.x);
+    bf16_pair(v.y, h.y, l.y);
+    bf16_pair(v.z, h.z, l.z);
+    bf16_pair(v.w, h.w, l.w);
+    hi[i] = h;
+    lo[i] = l;
+  }
+}
+
+// G [M, N] (optionally dropout-masked) -> T_hi, T_lo [N, Mp] bf16, transposed, zero past row M, plus per-block
+// column sums of the masked G (-> bias gradient). One block = 64 rows x 64 columns through a padded LDS tile.
+__global__ __launch_bounds__(kBlock) void split_transpose_kernel(const float* __restrict__ G,
+                                                                 const uint8_t* __restrict__ keep, float scale,
+                                                                 int64_t M, int N, int64_t Mp,
+                                                                 uint16_t* __restrict__ Thi,
+                                                                 uint16_t* __restrict__ Tlo,
+                                                                 float* __restrict__ colpart) {
+  __shared__ float tile[64][65];
+  __shared__ float red[4][64];
+  const int c = threadIdx.x & 63, q = threadIdx.x >> 6;
+  const int64_t m0 = (int64_t)blockIdx.x * 64;
+  const int n0 = (int)blockIdx.y * 64;
+  float sum = 0.f;
+#pragma unroll 4
+  for (int i = 0; i < 16; ++i) {
+    const int r = q + 4 * i;
+    const int64_t m = m0 + r;
+    float v = 0.f;
+    if (m < M && n0 + c < N) {
+      v = G[m * N + n0 + c];
+      if (keep) v = keep[m * N + n0 + c] ? v * scale : 0.f;
+    }
+    tile[r][c] = v;
+    sum += v;
+  }
+  red[q][c] = sum;
+  __syncthreads();
+  if (q == 0 && n0 + c < N) colpart[(int64_t)blockIdx.x * N + n0 + c] = ((red[0][c] + red[1][c]) + red[2][c]) + red[3][c];
+#pragma unroll 4
+  for (int i = 0; i < 16; ++i) {
+    const int n = q + 4 * i;
+    if (n0 + n < N) {
+      uint16_t h, l;
+      bf16_pair(tile[c][n], h, l);
+      Thi[(int64_t)(n0 + n) * Mp + m0 + c] = h;
+      Tlo[(int64_t)(n0 + n) * Mp + m0 + c] = l;
+    }
+  }
+}
+
 // Forward kernel choice. Default: the LDS-DMA kernel whenever the K range splits into whole 32-deep slices
 // (every Tiktok / Baby / stress shape); MMSSL_GEMM_V=1 forces the register-staged kernel everywhere.
 // Measured on MI355X, Baby image projection [18357,4096]x[4096,64], kernel + split reduce under a hipGraph:
@@ -423,6 +575,88 @@ extern "C" int mmssl_linear_f32(const float* F, const float* W, const float* b, 
   else
     hipLaunchKernelGGL((gemm64_kernel<false>), grid, dim3(kBlock), 0, s, F, (int64_t)K, W, (int64_t)K, M, (int64_t)N,
                        (int64_t)K, chunk, out, (int64_t)N, sstride, kb, kk, scale, (const uint8_t*)nullptr, 1.f);
+  MMSSL_LAUNCH_CHECK();
+  if (splits > 1) {
+    const int64_t total = M * N;
+    int64_t nb = (total / 4 + kBlock - 1) / kBlock;
+    nb = nb > 4096 ? 4096 : (nb < 1 ? 1 : nb);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)nb), dim3(kBlock), 0, s, out, splits, total, (int64_t)N, b,
+                       keep, scale, Y);
+    MMSSL_LAUNCH_CHECK();
+  }
+  return 0;
+}
+
+extern "C" size_t mmssl_linear_split_workspace_bytes(int64_t M, int K, int N) {
+  if (M <= 0 || K <= 0 || N <= 0) return 16;
+  const int splits = choose_splits(((M + BT - 1) / BT) * ((N + BT - 1) / BT), K);
+  return splits > 1 ? (size_t)splits * (size_t)M * (size_t)N * sizeof(float) : 16;
+}
+
+extern "C" int mmssl_split_bf16_f32(const float* X, int64_t n, uint16_t* hi, uint16_t* lo, void* stream) {
+  if (n < 0 || (n & 3) || (n > 0 && (!X || !hi || !lo))) return MMSSL_E_BADARG;
+  if (((uintptr_t)X & 15) || (((uintptr_t)hi | (uintptr_t)lo) & 7)) return MMSSL_E_BADARG;
+  if (n == 0) return 0;
+  int64_t nb = (n / 4 + kBlock - 1) / kBlock;
+  nb = nb > 4096 ? 4096 : nb;
+  hipLaunchKernelGGL(split_pair_kernel, dim3((unsigned)nb), dim3(kBlock), 0, as_stream(stream),
+                     reinterpret_cast<const float4*>(X), n / 4, reinterpret_cast<ushort4*>(hi),
+                     reinterpret_cast<ushort4*>(lo));
+  MMSSL_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" size_t mmssl_split_transpose_workspace_bytes(int64_t M, int N) {
+  if (M <= 0 || N <= 0) return 16;
+  return (size_t)((M + 63) / 64) * (size_t)N * sizeof(float) + 16;
+}
+
+extern "C" int mmssl_split_transpose_bf16_f32(const float* G, const uint8_t* keep, float scale, int64_t M, int N,
+                                              int64_t Mp, uint16_t* T_hi, uint16_t* T_lo, float* colsum,
+                                              void* workspace, size_t workspace_bytes, void* stream) {
+  if (M <= 0 || N <= 0 || !G || !T_hi || !T_lo || Mp < M || (Mp & 63)) return MMSSL_E_BADARG;
+  if ((N & 3) || N > 256) return MMSSL_E_UNSUPP;
+  if (!workspace || workspace_bytes < mmssl_split_transpose_workspace_bytes(Mp, N)) return MMSSL_E_WORKSPACE;
+  hipStream_t s = as_stream(stream);
+  float* colpart = reinterpret_cast<float*>(workspace);
+  const unsigned nbm = (unsigned)(Mp / 64);
+  hipLaunchKernelGGL(split_transpose_kernel, dim3(nbm, (unsigned)((N + 63) / 64)), dim3(kBlock), 0, s, G, keep, scale,
+                     M, N, Mp, T_hi, T_lo, colpart);
+  MMSSL_LAUNCH_CHECK();
+  if (colsum) {
+    hipLaunchKernelGGL(colsum_stage2, dim3(1), dim3(kBlock), 0, s, colpart, (int)nbm, N, colsum);
+    MMSSL_LAUNCH_CHECK();
+  }
+  return 0;
+}
+
+extern "C" int mmssl_linear_split_f32(const uint16_t* A_hi, const uint16_t* A_lo, const uint16_t* B_hi,
+                                      const uint16_t* B_lo, const float* b, const uint8_t* keep, float scale,
+                                      int64_t M, int K, int N, float* Y, void* workspace, size_t workspace_bytes,
+                                      void* stream) {
+  if (M <= 0 || K <= 0 || N <= 0 || !A_hi || !A_lo || !B_hi || !B_lo || !Y) return MMSSL_E_BADARG;
+  if ((K % BK) || (N & 3)) return MMSSL_E_UNSUPP;
+  if ((b || keep) && N > 256) return MMSSL_E_UNSUPP;
+  if (((uintptr_t)A_hi | (uintptr_t)A_lo | (uintptr_t)B_hi | (uintptr_t)B_lo | (uintptr_t)Y) & 15) return MMSSL_E_BADARG;
+  hipStream_t s = as_stream(stream);
+  const int64_t tm = (M + BT - 1) / BT, tn = (N + BT - 1) / BT;
+  int splits = choose_splits(tm * tn, K);
+  int64_t chunk = chunk_for(K, splits);
+  while (splits > 1 && ((int64_t)splits * chunk != K || chunk < 3 * BK)) {     // whole slices, >= 3 per split
+    --splits;
+    chunk = chunk_for(K, splits);
+  }
+  if ((int64_t)splits * chunk != K || chunk < 3 * BK) return MMSSL_E_UNSUPP;
+  float* out = Y;
+  if (splits > 1) {
+    const size_t need = (size_t)splits * (size_t)M * (size_t)N * sizeof(float);
+    if (!workspace || workspace_bytes < need) return MMSSL_E_WORKSPACE;
+    out = reinterpret_cast<float*>(workspace);
+  }
+  hipLaunchKernelGGL(gemm_split_kernel, dim3((unsigned)tm, (unsigned)tn, (unsigned)splits), dim3(kBlock), 0, s, A_hi,
+                     A_lo, (int64_t)K, B_hi, B_lo, (int64_t)K, M, (int64_t)N, chunk, out, (int64_t)N,
+                     splits > 1 ? (int64_t)M * N : (int64_t)0, splits > 1 ? (const float*)nullptr : b,
+                     splits > 1 ? (const uint8_t*)nullptr : keep, scale);
   MMSSL_LAUNCH_CHECK();
   if (splits > 1) {
     const int64_t total = M * N;

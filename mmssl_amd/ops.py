@@ -155,9 +155,72 @@ def sumsq(X):
 # ---------------------------------------------------------------------------------------
 # modality projection          nn.Linear + nn.Dropout, Models.py:28-29,54,173-174
 # ---------------------------------------------------------------------------------------
+# OPT-IN split-precision projection (MMSSL_GEMM_SPLIT=1; default OFF = exact fp32 MFMA arithmetic).
+# The constant feature matrix is split ONCE into bf16 (hi, lo) pairs (same bytes as fp32), forward and
+# transposed-for-wgrad; W and gY are split per call. See csrc/linear.hip (gemm_split_kernel) and DESIGN.md.
+_SPLIT = {}
+
+
+def split_projection_enabled():
+    return _os.environ.get("MMSSL_GEMM_SPLIT", "0") == "1"
+
+
+def _bf16_pair(x):
+    hi = x.to(torch.bfloat16)
+    lo = (x - hi.float()).to(torch.bfloat16)
+    return hi.contiguous(), lo.contiguous()
+
+
+def register_split_features(F_):
+    """Declare `F_` a CONSTANT feature matrix and build its split copies once: (F_hi, F_lo [M, K]) and the
+    transposed pair padded along M to a multiple of 128 (the wgrad reduction runs over M). Only registered
+    tensors take the split path (anything else - activations, test inputs - stays on the exact fp32 kernels)."""
+    key = (F_.data_ptr(), tuple(F_.shape))
+    if key not in _SPLIT:
+        M, K = F_.shape
+        Mp = (M + 127) // 128 * 128
+        FT = torch.zeros((K, Mp), dtype=torch.float32, device=F_.device)
+        FT[:, :M] = F_.t()
+        _SPLIT[key] = (_bf16_pair(F_), _bf16_pair(FT), Mp, F_)          # keeps F_ alive: the key stays valid
+        del FT
+    return _SPLIT[key]
+
+
+def _split_features(F_):
+    return _SPLIT.get((F_.data_ptr(), tuple(F_.shape)))
+
+
+def _use_split(F_):
+    K = F_.shape[1]
+    return split_projection_enabled() and K % 32 == 0 and K >= 96 and _split_features(F_) is not None
+
+
+def _split_call(Ah, Al, Bh, Bl, b, keep, scale, M, K, N):
+    Y = torch.empty((M, N), dtype=torch.float32, device=Ah.device)
+    nb = _lib.lib().mmssl_linear_split_workspace_bytes(M, K, N)
+    ws = torch.empty(max(nb // 4, 4), dtype=torch.float32, device=Ah.device)
+    rc = _lib.lib().mmssl_linear_split_f32(_ptr(Ah), _ptr(Al), _ptr(Bh), _ptr(Bl), _ptr(b), _ptr(keep), float(scale), M, K,
+                                           N, _ptr(Y), _ptr(ws), ws.numel() * 4, _lib.stream_ptr())
+    _lib.check(rc, "mmssl_linear_split_f32")
+    return Y
+
+
+def _split_pair_dev(x):
+    """(hi, lo) bf16 pair of a contiguous fp32 tensor in one launch."""
+    hi = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+    lo = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+    rc = _lib.lib().mmssl_split_bf16_f32(_ptr(x), x.numel(), _ptr(hi), _ptr(lo), _lib.stream_ptr())
+    _lib.check(rc, "mmssl_split_bf16_f32")
+    return hi, lo
+
+
 def _linear_raw(F_, W, b, keep, scale):
     M, K = F_.shape
     N = W.shape[0]
+    if _use_split(F_):
+        (Fh, Fl) = _split_features(F_)[0]
+        Wh, Wl = _split_pair_dev(W)
+        return _split_call(Fh, Fl, Wh, Wl, b, keep, scale, M, K, N)
     Y = torch.empty((M, N), dtype=torch.float32, device=F_.device)
     nb = _lib.lib().mmssl_linear_workspace_bytes(M, K, N)
     ws = torch.empty(max(nb // 4, 4), dtype=torch.float32, device=F_.device)
@@ -240,10 +303,33 @@ class _Linear(torch.autograd.Function):
         return gF, gW, (gb if ctx.has_bias else None), None, None
 
 
+def _linear_wgrad_split(gY0, keep, scale, F_, W):
+    M, K = F_.shape
+    N = W.shape[0]
+    # gW [N, K] = gY^T [N, Mp] . F^T [K, Mp]^T through the same split kernel (reduction over the padded M);
+    # one preparation launch transposes, masks and splits gY and sums its columns (bias gradient)
+    _, (FTh, FTl), Mp, _keep_alive = _split_features(F_)
+    dev = gY0.device
+    gTh = torch.empty((N, Mp), dtype=torch.bfloat16, device=dev)
+    gTl = torch.empty((N, Mp), dtype=torch.bfloat16, device=dev)
+    gb = torch.empty(N, dtype=torch.float32, device=dev)
+    nbt = _lib.lib().mmssl_split_transpose_workspace_bytes(Mp, N)
+    wst = torch.empty(max(nbt // 4, 4), dtype=torch.float32, device=dev)
+    rc = _lib.lib().mmssl_split_transpose_bf16_f32(_ptr(gY0), _ptr(keep), float(scale), M, N, Mp, _ptr(gTh),
+                                                   _ptr(gTl), _ptr(gb), _ptr(wst), wst.numel() * 4,
+                                                   _lib.stream_ptr())
+    _lib.check(rc, "mmssl_split_transpose_bf16_f32")
+    gW = _split_call(gTh, gTl, FTh, FTl, None, None, 1.0, N, Mp, K)
+    return None, gW, gb
+
+
 def _linear_wgrad_raw(gY, keep, scale, F_, W):
     """(masked gY, gW, gb) for Y = dropout(F W^T + b): dropout backward, then the wgrad GEMM."""
     M, K = F_.shape
     N = W.shape[0]
+    gY0 = gY
+    if _use_split(F_):
+        return _linear_wgrad_split(gY0, keep, scale, F_, W)
     if keep is not None:        # dropout backward: one pass (the in-fetch variant of wgrad measured slower)
         gYm = torch.empty_like(gY)
         rc = _lib.lib().mmssl_mask_scale_f32(_ptr(gY), _ptr(keep), float(scale), gY.numel(), _ptr(gYm),

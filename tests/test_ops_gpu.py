@@ -515,3 +515,47 @@ def test_spmm_concurrent_launches_on_one_plan_do_not_share_state():
             torch.cuda.synchronize()
             for k in range(3):
                 assert torch.equal(outs[k], refs[(k + rnd) % 3]), (rnd, k)
+
+
+def test_split_precision_projection_kernels():
+    """OPT-IN split-precision product (mmssl_linear_split_f32 and its two preparation kernels; the default path
+    does not use them): hi + lo reproduces x to 2^-16, the transposing preparation equals its definition, and the
+    three-product result is within 2e-5 (max-norm relative) of an fp64 reference, forward and wgrad form."""
+    from mmssl_amd import ops, _lib
+    L = _lib.lib()
+    torch.manual_seed(9)
+    M, K, N = 1000, 512, 64
+    F_ = torch.randn(M, K, device=DEV)
+    W = torch.randn(N, K, device=DEV) * 0.05
+    b = torch.randn(N, device=DEV)
+    hi, lo = ops._split_pair_dev(F_)
+    assert hi.dtype == torch.bfloat16 and torch.equal(hi, F_.to(torch.bfloat16))            # round-to-nearest-even
+    rec = hi.float() + lo.float()
+    assert float(((rec - F_).abs() / F_.abs().clamp_min(1e-30)).max()) < 2.0 ** -15
+    Wh, Wl = ops._split_pair_dev(W)
+    keep = (torch.rand(M, N, device=DEV) > 0.2).to(torch.uint8)
+    Y = ops._split_call(hi, lo, Wh, Wl, b, keep, 1.25, M, K, N)
+    ref = ((F_.double() @ W.double().t()) + b.double()) * keep.double() * 1.25
+    assert float((Y.double() - ref).abs().max() / ref.abs().max()) < 2e-5
+    # wgrad form: gW [N, K] = gY^T . F with the reduction padded to Mp, operands prepared by the fused kernel
+    gY = torch.randn(M, N, device=DEV)
+    Mp = (M + 127) // 128 * 128
+    FT = torch.zeros(K, Mp, device=DEV)
+    FT[:, :M] = F_.t()
+    FTh, FTl = ops._bf16_pair(FT)
+    gTh = torch.empty(N, Mp, dtype=torch.bfloat16, device=DEV)
+    gTl = torch.empty_like(gTh)
+    gb = torch.empty(N, device=DEV)
+    nb = L.mmssl_split_transpose_workspace_bytes(Mp, N)
+    ws = torch.empty(nb // 4 + 4, device=DEV)
+    rc = L.mmssl_split_transpose_bf16_f32(gY.data_ptr(), keep.data_ptr(), 1.25, M, N, Mp, gTh.data_ptr(), gTl.data_ptr(),
+                                          gb.data_ptr(), ws.data_ptr(), ws.numel() * 4, _lib.stream_ptr())
+    assert rc == 0
+    gYm = gY * keep.float() * 1.25
+    exp_hi, exp_lo = ops._bf16_pair(gYm.t().contiguous())
+    assert torch.equal(gTh[:, :M], exp_hi) and torch.equal(gTl[:, :M], exp_lo)
+    assert float(gTh[:, M:].float().abs().max()) == 0.0 and float(gTl[:, M:].float().abs().max()) == 0.0
+    assert torch.allclose(gb, gYm.sum(0), rtol=1e-5, atol=1e-5)
+    gW = ops._split_call(gTh, gTl, FTh, FTl, None, None, 1.0, N, Mp, K)
+    refw = gYm.double().t() @ F_.double()
+    assert float((gW.double() - refw).abs().max() / refw.abs().max()) < 2e-5

@@ -13,6 +13,7 @@ Each fixture cites the reference call that produced it:
   G6  Data.sample()                                     utility/load_data.py:153-191
   G7  test_torch (Recall/NDCG/precision/hit @ Ks)       utility/batch_test.py:112-169
   G8  G-step loss assembly                              main.py:363-420
+  G9  modal-graph maintenance inside Trainer.train()    main.py:378-405 (k = int(n_items*m_topk_rate) in {1, 2}, T in {1, 2})
 """
 import os
 import shutil
@@ -284,9 +285,76 @@ def main():
             cl1=np.float32(cl1.item()), cl2=np.float32(cl2.item()), G_lossf=np.float32(G_lossf.item()),
             batch_loss=np.float32(batch_loss.item()), cl_rate=args.cl_rate, G_rate=args.G_rate, **grads)
 
+    gen_g9(ref, dg)
     for f in sorted(os.listdir(OUT)):
         print("%9d  %s" % (os.path.getsize(os.path.join(OUT, f)), f))
 
 
+class _StopTraining(Exception):
+    pass
+
+
+def gen_g9(ref, dg, n_batches=5):
+    """G9: run the reference's own Trainer.train() (main.py:320-430) for `n_batches` batches with k >= 1 and
+    record, per batch, what its modal-graph maintenance consumed and produced: the batch users, the two
+    [B, n_items] similarity matrices that feed torch.topk (4th and 5th u_sim_calculation call of a batch,
+    main.py:372-373) and the four modal graphs the model receives at the START of every batch (i.e. the state
+    left by the previous batch's rebuild-or-collect branch). Nothing of the loop is restated here: the loop is
+    the reference's, observed through wrappers around model.forward / u_sim_calculation."""
+    args = ref.args
+    old = (args.m_topk_rate, args.T, args.epoch)
+    for tag, rate, T in (("k1_T1", 0.011, 1), ("k2_T1", 0.021, 1), ("k2_T2", 0.021, 2)):
+        args.m_topk_rate, args.T, args.epoch = rate, T, 1
+        k = int(I * rate)
+        ref.set_seed(2022)
+        tr = ref.Trainer(data_config={"n_users": dg.n_users, "n_items": dg.n_items})
+        rec = {"k": k, "T": T, "m_topk_rate": rate, "n_batches": n_batches}
+        state = {"fwd_calls": 0, "sim_calls": 0}
+        orig_fwd, orig_sim = tr.model.forward, tr.u_sim_calculation
+
+        def fwd(*graphs, _o=orig_fwd):
+            c = state["fwd_calls"]
+            state["fwd_calls"] += 1
+            if c % 2 == 0:                       # first forward of batch c // 2
+                b = c // 2
+                if b >= n_batches:
+                    raise _StopTraining()
+                for nm, g in zip(("img_ui", "img_iu", "txt_ui", "txt_iu"), graphs[2:6]):
+                    g = g.coalesce()
+                    idx = g.indices().numpy()
+                    rec["b%d.%s_row" % (b, nm)] = idx[0].astype(np.int64)
+                    rec["b%d.%s_col" % (b, nm)] = idx[1].astype(np.int64)
+                    rec["b%d.%s_val" % (b, nm)] = g.values().numpy().astype(np.float32)
+            return _o(*graphs)
+
+        def sim(users, ue, ie, _o=orig_sim):
+            c = state["sim_calls"]
+            state["sim_calls"] += 1
+            out = _o(users, ue, ie)
+            b, j = divmod(c, 5)
+            if j == 3:
+                rec["b%d.users" % b] = np.array(users, np.int64)
+                rec["b%d.img_sim" % b] = npy(out)
+            elif j == 4:
+                rec["b%d.txt_sim" % b] = npy(out)
+            return out
+
+        tr.model.forward = fwd
+        tr.u_sim_calculation = sim
+        try:
+            tr.train()
+        except _StopTraining:
+            pass
+        np.savez_compressed(os.path.join(OUT, "g9_modal_rebuild_%s.npz" % tag), **rec)
+    args.m_topk_rate, args.T, args.epoch = old
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "g9":      # only (re)generate G9; same data set, same seeds
+        if os.path.isdir(TMP):
+            shutil.rmtree(TMP)
+        synth_data.write_dataset(TMP, "tiny", U, I, E, DV, DT, seed=1)
+        _ref = ref_shim.load(TMP, "tiny", ["--batch_size", str(B), "--drop_rate", "0.0"])
+        gen_g9(_ref, _ref.data_generator)
+    else:
+        main()

@@ -119,3 +119,82 @@ def test_same_seed_same_initial_weights_as_reference():
     for k in fx.files:
         if k.startswith("p."):
             assert np.array_equal(sd[k[2:]].numpy(), fx[k]), k
+
+
+# ---------------------------------------------------------------------------------------------------
+# a-3: modal-graph maintenance (main.py:378-405) against G9, recorded from the reference's own train() loop
+# ---------------------------------------------------------------------------------------------------
+def _g9_expected(g, b, nm, shape):
+    import scipy.sparse as sp
+    r, c, v = g["b%d.%s_row" % (b, nm)], g["b%d.%s_col" % (b, nm)], g["b%d.%s_val" % (b, nm)]
+    return sp.csr_matrix((v, (r, c)), shape=shape)
+
+
+def _same_sparse(a, b, tol=1e-6):
+    a, b = a.tocsr().copy(), b.tocsr().copy()
+    for m in (a, b):
+        m.sum_duplicates()
+        m.eliminate_zeros()
+        m.sort_indices()
+    return (a.shape == b.shape and np.array_equal(a.indptr, b.indptr) and np.array_equal(a.indices, b.indices)
+            and np.allclose(a.data, b.data, rtol=tol, atol=tol))
+
+
+def run_g9_host(tag):
+    """Drive Trainer._maintain_modal_graphs with the recorded (users, sims) of `tag` and compare the graphs it
+    leaves for the NEXT batch with what the reference's model received there (k >= 1 branch, T in {1, 2})."""
+    import scipy.sparse as sp
+    from mmssl_amd import config
+    from mmssl_amd.main import Trainer
+    g = H.load("g9_modal_rebuild_%s.npz" % tag)
+    d, raw, U, I = H.dataset()
+    config.configure([], m_topk_rate=float(g["m_topk_rate"]), T=int(g["T"]))
+    assert int(I * config.args.m_topk_rate) == int(g["k"]) >= 1
+    tr = object.__new__(Trainer)                      # host logic only: no model, no device
+    tr.n_users, tr.n_items = U, I
+    tr.image_ui_index = {"x": [], "y": []}
+    tr.text_ui_index = {"x": [], "y": []}
+    tr._empty_plans = None
+    tr.matrix_to_tensor = lambda m: sp.csr_matrix(m)  # keep the scipy matrix instead of a device plan
+    init_ui = tr.csr_norm(raw, mean_flag=True)
+    init_iu = tr.csr_norm(raw.T, mean_flag=True)
+    tr.image_ui_graph = tr.text_ui_graph = init_ui
+    tr.image_iu_graph = tr.text_iu_graph = init_iu
+    nb = int(g["n_batches"])
+    for b in range(nb):
+        for nm, cur in (("img_ui", tr.image_ui_graph), ("img_iu", tr.image_iu_graph), ("txt_ui", tr.text_ui_graph),
+                        ("txt_iu", tr.text_iu_graph)):
+            shape = (U, I) if nm.endswith("ui") else (I, U)
+            assert _same_sparse(sp.csr_matrix(cur), _g9_expected(g, b, nm, shape)), (tag, b, nm)
+        tr._maintain_modal_graphs(b, [int(u) for u in g["b%d.users" % b]], torch.from_numpy(g["b%d.img_sim" % b]),
+                                  torch.from_numpy(g["b%d.txt_sim" % b]))
+    config.configure([])
+
+
+def test_modal_graph_rebuild_matches_reference_loop_k1():
+    run_g9_host("k1_T1")
+
+
+def test_modal_graph_rebuild_matches_reference_loop_k2():
+    run_g9_host("k2_T1")
+
+
+def test_modal_graph_rebuild_matches_reference_loop_k2_T2():
+    run_g9_host("k2_T2")
+
+
+def test_trainer_csr_norm_matches_reference_g1():
+    """The PRODUCT's Trainer.csr_norm (not the oracle's) raw -> normalised, both branches, incl. zero-degree rows."""
+    import scipy.sparse as sp
+    from mmssl_amd.main import Trainer
+    g = H.load("g1_csr_norm.npz")
+    tr = object.__new__(Trainer)
+
+    def mat(nm):
+        return sp.csr_matrix((g[nm + "_val"], (g[nm + "_row"], g[nm + "_col"])), shape=tuple(g[nm + "_shape"]))
+    raw, cm = mat("raw"), mat("cm")
+    assert _same_sparse(tr.csr_norm(raw, mean_flag=True), mat("ui"), 1e-7)
+    assert _same_sparse(tr.csr_norm(raw.T, mean_flag=True), mat("iu"), 1e-7)
+    assert (np.diff(cm.indptr) == 0).any()                      # the fixture has zero-degree rows
+    assert _same_sparse(tr.csr_norm(cm, mean_flag=True), mat("cm_norm"), 1e-7)
+    assert _same_sparse(tr.csr_norm(cm, mean_flag=False), mat("cm_sym"), 1e-7)

@@ -10,12 +10,17 @@ projection, modal + 3-layer GCN SpMM propagation, fusion) -> BPR + 2x InfoNCE + 
 regulariser -> backward -> AdamW — the reference's generator step (main.py:363-429) without the
 adjacent GAN pieces. Inputs (graph, features, parameters, batch indices) are resident in HBM
 before the timed region. Workload at N=1: the Amazon-Baby shape BASELINE.json quotes the metric on
-(35598 x 18357, 256308 edges, V4096/T1024, d=64, B=1024), seeded synthetic data. At N>1 the graph is the
-same shape scaled N x (weak scaling) and row-sharded with RCCL all-gather before every
-propagation layer.
+(35598 x 18357, 256308 edges, V4096/T1024, d=64, B=1024), seeded synthetic data. At N>1 the tables and CSR rows
+are row-sharded with an RCCL all-gather before every propagation layer (reduce-scatter in the backward):
+`--scaling weak` (default) = the shape x N, every rank generating only its own users' interactions;
+`--scaling strong` = the Baby graph itself cut N ways (BASELINE configs[3]); `--workload synth` = the 100M-edge
+d=128 stress shape of configs[4] (2M x 1M over 8 ranks: 250K users x 125K items x 12.5M edges per rank).
 
 metric = edge.layers/s: nonzeros summed over EVERY SpMM launch of the step (forward and
-backward) / step time, whole job. One JSON line is printed by rank 0.
+backward) / step time, whole job. One JSON line is printed by rank 0. Besides the contract fields it carries
+`roofline` (the CSR SpMM, isolated, HIP events), `gcn_forward` (the 6-SpMM 3-layer propagation alone under hipGraph:
+the quantity north_star's ">= 60 % of the HBM roofline" target is stated on), `loss_check` (the first step's loss
+with injected dropout masks against the CPU oracle), `cpu_baseline`, and at N>1 `comm`.
 """
 import argparse
 import json
@@ -62,8 +67,6 @@ def build_single_gpu(a, dev):
     from mmssl_amd.Models import MMSSL
     import scipy.sparse as sp
     U, I, E, dv, dt = synth.SHAPES[a.workload]
-    if a.workload == "synth":
-        raise SystemExit("the 'synth' stress shape is an 8-GPU configuration (use --gpus 8)")
     config.configure([], embed_size=a.d, weight_size=str([a.d] * a.gcn_layers), batch_size=a.batch,
                      drop_rate=0.2, layers=1)
     raw = synth.interaction_matrix(U, I, E, seed=1)
@@ -134,6 +137,72 @@ def spmm_roofline(plans, mats, d, iters=200, traffic=True):
             "traffic": load_traffic() if traffic else None}
 
 
+def gcn_forward_record(plans, mats, d, n_layers, iters=200):
+    """The G-layer GCN propagation alone (Models.py:201-211: u = A_ui.i, i = A_iu.u, G times = 2G dependent
+    SpMMs, softmax epilogue on the last layer) captured in one hipGraph and replayed back to back."""
+    from mmssl_amd import ops, synth
+    ui, iu = mats
+    dev = "cuda"
+    u0, i0 = torch.randn(ui.shape[0], d, device=dev), torch.randn(iu.shape[0], d, device=dev)
+
+    def chain():
+        u, i = u0, i0
+        for l in range(n_layers):
+            epi = ops.EPI_SOFTMAX if l == n_layers - 1 else ops.EPI_NONE
+            u = ops.spmm(plans[0], i, epilogue=epi)
+            i = ops.spmm(plans[1], u, epilogue=epi)
+        return i
+    with torch.no_grad():
+        for _ in range(5):
+            chain()
+        g = torch.cuda.CUDAGraph()
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            torch.cuda.synchronize()
+            with torch.cuda.graph(g, stream=s):
+                chain()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        with torch.cuda.stream(s):
+            g.replay()
+            e0.record()
+            for _ in range(iters):
+                g.replay()
+            e1.record()
+        torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / iters
+    nbytes = n_layers * (synth.spmm_bytes(ui, d) + synth.spmm_bytes(iu, d))
+    el = n_layers * (ui.nnz + iu.nnz)
+    gbps = nbytes / us * 1e-3
+    return {"what": "%d-layer GCN forward = %d dependent SpMM, one hipGraph, replayed back to back" % (n_layers, 2 * n_layers),
+            "us": round(us, 2), "edge_layers": int(el), "edge_layers_per_s": round(el / us * 1e6, 1),
+            "algorithmic_bytes": int(nbytes), "achieved_GBps": round(gbps, 1), "frac_hbm": round(gbps / HBM_PEAK_GBPS, 4),
+            "target_frac": 0.6}
+
+
+def first_step_loss(a, step, raw, batch):
+    """HIP side of the loss check: the loss of ONE hot-path forward on the bench model's initial parameters with
+    injected dropout masks. Returns (loss, snapshot of the inputs) — cpu_baseline() evaluates the CPU oracle on the
+    snapshot (north_star: fp32 loss within 1e-4 relative)."""
+    m = step.model
+    I = raw.shape[1]
+    gen = torch.Generator().manual_seed(123)
+    km = [(torch.rand(I, a.d, generator=gen) >= 0.2) for _ in range(2)]
+    users, pos, neg = (torch.from_numpy(x) for x in batch)
+    step.keep_masks = tuple(k.to(torch.uint8).cuda() for k in km)
+    step.set_batch(users.cuda(), pos.cuda(), neg.cuda())
+    with torch.no_grad(), torch.cuda.stream(step.stream):
+        total, _ = step.losses()
+    torch.cuda.synchronize()
+    hip = float(total)
+    step.keep_masks = None
+    P = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()
+         if not k.startswith(("image_embedding", "text_embedding", "batch_norm", "encoder.", "align."))}
+    return hip, {"P": P, "img": m.image_feats.cpu(), "txt": m.text_feats.cpu(), "keep": [k.float() for k in km],
+                 "batch": (users, pos, neg)}
+
+
 def load_traffic():
     """HBM bytes per SpMM launch from the committed rocprofv3 PMC pass (profiles/*_pmc.json), if any."""
     p = os.path.join(ROOT, "profiles", "spmm_pmc.json")
@@ -145,10 +214,11 @@ def load_traffic():
     return None
 
 
-def cpu_baseline(a, raw, mats, budget_s=20.0):
+def cpu_baseline(a, raw, mats, budget_s=20.0, first=None):
     """The CPU oracle (torch-CPU restatement of the reference path, 'port') on this box's host cores:
     the same step (forward + losses + backward; torch COO sparse.mm like the reference), a bounded
-    number of iterations."""
+    number of iterations. With `first` = first_step_loss()'s result the oracle also evaluates that very step
+    (same parameters, masks, batch) and the two losses are reported side by side (`loss_check`)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import mmssl_oracle as O
     from mmssl_amd import synth
@@ -172,6 +242,18 @@ def cpu_baseline(a, raw, mats, budget_s=20.0):
     for v in P.values():
         v.requires_grad_(True)
     cfg = O.Cfg(embed_size=d, n_ui_layers=a.gcn_layers, layers=1, drop_rate=0.2, batch_size=a.batch)
+    check = None
+    if first is not None:
+        hip, snap = first
+        u_, p_, n_ = snap["batch"]
+        with torch.no_grad():
+            o = O.forward(snap["P"], snap["img"], snap["txt"], graphs, cfg, training=True, keep_masks=snap["keep"])
+            mf, emb, _ = O.bpr(o[0][u_], o[1][p_], o[1][n_], 1e-5, a.batch)
+            ref = float(mf + emb + O.feat_reg(o[2], o[3], o[4], o[5], I, 1e-5) + 0.03 * (
+                O.infonce(o[8][u_], o[6][u_], 0.5) + O.infonce(o[9][u_], o[6][u_], 0.5)))
+        check = {"hip": round(hip, 7), "oracle": round(ref, 7), "rel_err": float("%.3g" % (abs(hip - ref) / abs(ref))),
+                 "tolerance": 1e-4, "what": "loss of the first step (initial parameters, injected dropout masks)"}
+        del o, snap
     users, pos, neg = (torch.from_numpy(x) for x in make_batches(raw, 1, a.batch, 3)[0])
     keep = [(torch.rand(I, d) >= 0.2).float() for _ in range(2)]
     n_spmm = 2 * (4 + 2 * a.gcn_layers)     # nonzero-graph launches, forward + backward
@@ -193,7 +275,24 @@ def cpu_baseline(a, raw, mats, budget_s=20.0):
         step()
         n += 1
     dt_s = (time.time() - t0) / n
+    # the propagation alone, on torch's CSR kernels (the CPU's best case; the reference itself uses COO)
+    gcn = {}
+    with torch.no_grad():
+        Eu, Ei = torch.randn(U, d), torch.randn(I, d)
+        for fmt, (Au, Ai) in (("coo", (A_ui, A_iu)), ("csr", (A_ui.to_sparse_csr(), A_iu.to_sparse_csr()))):
+            for threads in sorted({min(32, os.cpu_count() or 1), os.cpu_count() or 1}):
+                torch.set_num_threads(threads)
+                t0, k = time.time(), 0
+                while k < 2 or (time.time() - t0 < 1.5 and k < 50):
+                    u, i = Eu, Ei
+                    for _ in range(a.gcn_layers):
+                        u = torch.sparse.mm(Au, i)
+                        i = torch.sparse.mm(Ai, u)
+                    k += 1
+                gcn["%s_%dthr" % (fmt, threads)] = round(2 * a.gcn_layers * raw.nnz / ((time.time() - t0) / k), 1)
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
     return {"value": round(n_spmm * raw.nnz / dt_s, 1), "unit": "edge.layers/s", "cores": torch.get_num_threads(),
+            "host_cores": os.cpu_count(), "gcn_forward_edge_layers_per_s": gcn, "loss_check": check,
             "kind": "port", "ms_per_step": round(dt_s * 1e3, 1),
             "sample": "%d steps of the same %s-shape step (fwd+losses+bwd, no optimiser) by oracle/mmssl_oracle.py "
                       "on torch-CPU COO sparse.mm" % (n, a.workload)}
@@ -223,6 +322,10 @@ def main():
     ap.add_argument("--batch", type=int, default=1024)
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="N>1: weak = shape x N (per-rank work fixed); strong = the shape itself cut N ways")
+    ap.add_argument("--only", choices=["all", "steps", "roofline"], default="all",
+                    help="profiling aid: run only the timed steps, or only the isolated SpMM roofline loop")
     ap.add_argument("--graph-probe", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--dist-graph", choices=["auto", "on", "off"], default="auto", nargs="?", const="on",
                     help="sharded path: capture the step (RCCL collectives included) into a hipGraph. auto = "
@@ -231,6 +334,8 @@ def main():
     ap.add_argument("--force-dist", action="store_true",
                     help="use the row-sharded code path even with one rank (exercises RCCL + dist.py on 1 GPU)")
     a = ap.parse_args()
+    if a.workload == "synth" and a.d == 64:
+        a.d = 128                      # configs[4] is defined at d=128
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -240,7 +345,7 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
-    sharded = world > 1 or a.force_dist
+    sharded = world > 1 or a.force_dist or a.workload == "synth"
     if sharded:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if world == 1:
@@ -256,6 +361,8 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=dev)
 
+    n_users = n_items = n_edges = None
+    comm = None
     if not sharded:
         step, raw, mats, plans = build_single_gpu(a, dev)
         stats = count_edge_layers(step)
@@ -265,13 +372,21 @@ def main():
                 step.run()
                 torch.cuda.synchronize()
             sys.exit(0 if ok else 3)
+        first = None
+        if rank == 0 and a.only == "all" and not a.no_cpu_baseline:
+            first = first_step_loss(a, step, raw, make_batches(raw, 1, a.batch, seed=5)[0])
         captured = (not a.no_graph) and graph_capture_works(a) and step.capture()
         edge_layers_total = stats["edge_layers"]
         parallelism = "single"
+        n_users, n_items, n_edges = int(raw.shape[0]), int(raw.shape[1]), int(raw.nnz)
+        scaling = "weak"
+        batches = [(torch.stack([torch.from_numpy(x).to(dev) for x in b]),)      # packed [3, B]: one copy per step
+                   for b in make_batches(raw, 8, a.batch, seed=2022)]
     else:
         from mmssl_amd import dist as mdist
+        scaling = "weak" if a.workload == "synth" else a.scaling
         if a.dist_graph_probe:       # child of one rank: sharded capture + replay on a small shape
-            step, _, _, _, _ = mdist.build_bench_step(a, rank, world, dev)
+            step, _, _, _ = mdist.build_bench_step(a, rank, world, dev, scaling)
             ok = step.capture()
             if ok:
                 for _ in range(3):
@@ -286,27 +401,41 @@ def main():
             # A failed capture with RCCL inside can abort or hang the process: try it first in one child
             # per rank (own rendezvous on MASTER_PORT+1), then agree on the outcome across ranks.
             cmd = [sys.executable, os.path.abspath(__file__), "--dist-graph-probe", "--gpus", str(a.gpus),
-                   "--workload", "tiktok", "--d", str(a.d), "--gcn-layers", str(a.gcn_layers), "--batch", str(a.batch)]
+                   "--workload", "tiktok", "--d", str(a.d), "--gcn-layers", str(a.gcn_layers), "--batch", str(a.batch),
+                   "--scaling", "strong"]
             if a.force_dist:
                 cmd.append("--force-dist")
             flag = torch.tensor([1 if mdist.spawn_rank_probe(cmd) else 0], device=dev, dtype=torch.int32)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             want = bool(flag.item())
-        step, raw, mats, plans, stats = mdist.build_bench_step(a, rank, world, dev)
+        step, mats, plans, stats = mdist.build_bench_step(a, rank, world, dev, scaling)
         captured = want and step.capture()
         edge_layers_total = stats["edge_layers_global"]
-        parallelism = "row-shard x%d (RCCL all-gather / reduce-scatter)" % world
-
-    batches = [tuple(torch.from_numpy(x).to(dev) for x in b)
-               for b in make_batches(raw, 8, a.batch, seed=2022)]
-    if not sharded:
-        batches = [(torch.stack(b),) for b in batches]          # packed [3, B]: one copy per step
+        parallelism = "row-shard x%d (RCCL all-gather / reduce-scatter, 3 interleaved chains)" % world
+        n_users, n_items, n_edges = stats["n_users"], stats["n_items"], stats["n_edges"]
+        # communication of one step: what was issued, and how long those collectives take on their own
+        log = stats["comm_log"]
+        comm = {"collectives_per_step": len(log),
+                "bytes_per_step": int(sum(b for _, _, b in log)),
+                "by_kind": {k: [sum(1 for x in log if x[0] == k), int(sum(x[2] for x in log if x[0] == k))]
+                            for k in ("all_gather", "reduce_scatter", "all_reduce")},
+                "note": "bytes = size of the full (gathered / to-be-scattered / reduced) fp32 buffer of every collective "
+                        "of one step on one rank; comm_only_ms = the same collectives replayed alone, back to back"}
+        with torch.cuda.stream(step.stream):
+            comm["comm_only_ms"] = round(mdist.comm_replay_ms(log, None, dev), 4)
+        rngb = np.random.default_rng(2022)          # identical batches on every rank (global ids)
+        batches = [tuple(torch.from_numpy(x).to(dev) for x in (
+            rngb.choice(n_users, a.batch, replace=a.batch > n_users).astype(np.int64),
+            rngb.integers(0, n_items, a.batch).astype(np.int64), rngb.integers(0, n_items, a.batch).astype(np.int64)))
+            for _ in range(8)]
 
     def run_steps(n):
         for i in range(n):
             step.set_batch(*batches[i % len(batches)])
             step.run()
 
+    if a.only == "roofline":
+        a.warmup, a.steps = 1, 1
     run_steps(a.warmup)
     if sharded:
         dist.barrier()
@@ -324,26 +453,36 @@ def main():
         elapsed = float(t.item())
     loss = float(step.loss)
     ms = elapsed * 1e3 / a.steps
+    shape_note = "" if world == 1 else (" x%d (weak: per-rank share fixed)" % world if scaling == "weak"
+                                        else " cut %d ways (strong)" % world)
     out = {
         "metric": "edge.layers/s (nonzeros of every SpMM launch per hot-path step / step time)",
         "value": round(edge_layers_total / (ms * 1e-3), 1), "unit": "edge.layers/s", "n_gpus": world,
         "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 4), "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "scaling": scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "%s-shaped graph%s, d=%d, %d-layer GCN + V/T projection + InfoNCE x2 + BPR + "
-                               "feat-reg, fwd+bwd+AdamW, B=%d" % (
-                                   a.workload, "" if world == 1 else " x%d (weak)" % world, a.d, a.gcn_layers, a.batch),
-                   "n_users": int(raw.shape[0]), "n_items": int(raw.shape[1]), "n_edges": int(raw.nnz),
+                               "feat-reg, fwd+bwd+AdamW, B=%d" % (a.workload, shape_note, a.d, a.gcn_layers, a.batch),
+                   "n_users": n_users, "n_items": n_items, "n_edges": n_edges,
                    "edge_layers_per_step": int(edge_layers_total), "spmm_launches_per_step": int(stats["spmm_launches"]),
                    "launch": "hipGraph replay" if captured else "eager", "parallelism": parallelism,
                    "final_loss": round(loss, 6)},
     }
     if rank == 0:
         if not sharded:
-            out["roofline"] = spmm_roofline(plans, mats, a.d)
-            if not a.no_cpu_baseline:
-                out["cpu_baseline"] = cpu_baseline(a, raw, mats)
+            if a.only != "steps":
+                rf = spmm_roofline(plans, mats, a.d)
+                # the same byte model over the WHOLE step: every SpMM launch's algorithmic bytes / step time. The
+                # step is not SpMM-bound (projection GEMMs and the loss section share it), so this is far lower.
+                rf["step_spmm_GBps"] = round(stats["spmm_bytes"] / (ms * 1e-3) * 1e-9, 1)
+                rf["step_frac"] = round(rf["step_spmm_GBps"] / HBM_PEAK_GBPS, 4)
+                out["roofline"] = rf
+                out["gcn_forward"] = gcn_forward_record(plans, mats, a.d, a.gcn_layers)
+            if not a.no_cpu_baseline and a.only == "all":
+                out["cpu_baseline"] = cpu_baseline(a, raw, mats, first=first)
+                out["loss_check"] = out["cpu_baseline"].pop("loss_check")
         else:
             out["roofline"] = spmm_roofline(plans, mats, a.d, traffic=False)   # rank 0's shard
+            out["comm"] = comm
         print(json.dumps(out))
     if sharded:
         dist.barrier()

@@ -20,7 +20,7 @@ from .graph import GraphPlan
 
 def _plan_of(g):
     """GraphPlan for a graph argument; torch sparse tensors get a plan cached on the tensor."""
-    if isinstance(g, GraphPlan):
+    if isinstance(g, GraphPlan) or hasattr(g, "twin"):      # a plan or a plan view (GraphPlan.twin)
         return g
     plan = getattr(g, "_mmssl_plan", None)
     if plan is None:
@@ -146,6 +146,11 @@ class MMSSL(nn.Module):
         ui, iu = _plan_of(ui_graph), _plan_of(iu_graph)
         img_ui, img_iu = _plan_of(image_ui_graph), _plan_of(image_iu_graph)
         txt_ui, txt_iu = _plan_of(text_ui_graph), _plan_of(text_iu_graph)
+        # The modal-id SpMMs (and their autograd backward) run on the caller's stream while ops.hot_forward's
+        # chains may still be running on its side streams (deferred wgrad join, hotpath.HotPathStep). A caller
+        # may pass the SAME plan as ui_graph and image_ui_graph (Trainer's initial state, main.py:69-72): give
+        # the modal launches their own partial-sum workspace + arrival counters (lanes 0-2 belong to hot_forward).
+        img_ui, img_iu, txt_ui, txt_iu = img_ui.twin(3), img_iu.twin(3), txt_ui.twin(3), txt_iu.twin(3)
         p = float(args.drop_rate)
         km_img = km_txt = None
         scale = 1.0

@@ -53,6 +53,12 @@ class HipBackend:
         self.loss_assemble = ops.loss_assemble
         self._ar = {}
 
+    def side_streams(self, device):
+        """Three side streams for the sharded node's chains (the same objects ops._HotForward forks)."""
+        if os.environ.get("MMSSL_DIST_STREAMS", "1") == "0":
+            return None
+        return self.ops._side_streams(device)
+
     def batch_losses_rows(self, u, p, n, z_img, z_txt, decay, batch_size, tau):
         """[mf, emb, 0, cl_img, cl_txt] from already gathered [B, d] rows: ONE fused node (BPR + both InfoNCE
         problems, see ops._BatchLosses) fed with identity indices."""
@@ -181,6 +187,7 @@ class GatherBatchRowsMulti(torch.autograd.Function):
             meta.append((local, mine, per))
         packed = torch.cat(pieces, 0)
         dist.all_reduce(packed, group=group)
+        _log_comm("all_reduce", packed)
         ctx.meta = meta
         sizes = [p.shape[0] for p in pieces]
         ctx.sizes = sizes
@@ -316,38 +323,112 @@ class ShardedMMSSL(nn.Module):
 
 
 
+# launch accounting for bench.py: every collective of a counted step {kind, bytes of the full (gathered /
+# to-be-scattered / reduced) buffer}; COMM["log"] is None when not recording
+COMM = {"log": None}
+
+
+def _log_comm(kind, t):
+    if COMM["log"] is not None:
+        COMM["log"].append((kind, tuple(t.shape), t.numel() * t.element_size()))
+
+
 def _all_gather_raw(x, group):
     world = dist.get_world_size(group)
     out = torch.empty((world * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
     dist.all_gather_into_tensor(out, x.contiguous(), group=group)
+    _log_comm("all_gather", out)
     return out
+
+
+def _run_interleaved(chains):
+    """Drive generator `chains` round-robin: each chain does its compute (on its own stream) and YIELDS right
+    before every collective it is about to issue. One process group executes collectives in issue order, so
+    issuing them depth by depth (C1 B1 A1 C2 B2 A2 ...) instead of chain by chain lets one chain's kernels run
+    under another chain's collective, and the order is the same on every rank by construction."""
+    live = list(chains)
+    while live:
+        nxt = []
+        for c in live:
+            try:
+                next(c)
+                nxt.append(c)
+            except StopIteration:
+                pass
+        live = nxt
+
+
+class _Streams:
+    """Fork/join helper around three side streams (None on CPU: everything runs inline)."""
+
+    def __init__(self, bk, ref):
+        self.side = bk.side_streams(ref.device) if (hasattr(bk, "side_streams") and ref.is_cuda) else None
+        self.side = self.side or None
+        self.main = torch.cuda.current_stream(ref.device) if self.side else None
+
+    def fork(self):
+        if self.side:
+            for st in self.side:
+                st.wait_stream(self.main)
+
+    def join(self):
+        if self.side:
+            for st in self.side:
+                self.main.wait_stream(st)
+
+    def on(self, k):
+        import contextlib
+        return torch.cuda.stream(self.side[k]) if self.side else contextlib.nullcontext()
 
 
 class _ShardedHotForward(torch.autograd.Function):
     """Row-sharded counterpart of ops._HotForward: projection of the local item rows, modal SpMM
     chains, G-layer GCN chain and the layer-mean / modality fusion, with an all-gather of the row
     shards before every A_r . X and — in the hand-written backward — a reduce-scatter of every
-    A_r^T . gY_r. One autograd node, ~45 kernels + 2(4+2G) collectives per step instead of a few
-    hundred autograd-composed launches."""
+    A_r^T . gY_r. One autograd node. The three independent chains (image, text, GCN) run on three forked
+    streams and their collectives are issued interleaved (see _run_interleaved), so a gather of one chain is
+    hidden behind the kernels of the other two."""
 
     @staticmethod
     def forward(ctx, F_img, W_img, b_img, keep_img, F_txt, W_txt, b_txt, keep_txt, scale, u0, i0, ui, iu,
                 n_layers, r, bk, group):
         g = group
-        x_img = bk.linear_raw(F_img, W_img, b_img, keep_img, scale)
-        x_txt = bk.linear_raw(F_txt, W_txt, b_txt, keep_txt, scale)
-        img_user = bk.spmm_raw(ui, False, _all_gather_raw(x_img, g), bk.EPI_NONE)
-        txt_user = bk.spmm_raw(ui, False, _all_gather_raw(x_txt, g), bk.EPI_NONE)
-        img_item = bk.spmm_raw(iu, False, _all_gather_raw(img_user, g), bk.EPI_NONE)
-        txt_item = bk.spmm_raw(iu, False, _all_gather_raw(txt_user, g), bk.EPI_NONE)
-        us, its = [u0], [i0]
-        u, i = u0, i0
-        for l in range(n_layers):
-            epi = bk.EPI_SOFTMAX if l == n_layers - 1 else bk.EPI_NONE
-            u = bk.spmm_raw(ui, False, _all_gather_raw(i, g), epi)
-            i = bk.spmm_raw(iu, False, _all_gather_raw(u, g), epi)
-            us.append(u)
-            its.append(i)
+        st = _Streams(bk, u0)
+        twin = (lambda p, k: p.twin(k)) if hasattr(ui, "twin") else (lambda p, k: p)
+        out = {}
+
+        def modal_chain(k, F_, W, b, keep, key):
+            with st.on(k):
+                x = bk.linear_raw(F_, W, b, keep, scale)
+            yield
+            with st.on(k):
+                user = bk.spmm_raw(twin(ui, k), False, _all_gather_raw(x, g), bk.EPI_NONE)
+            yield
+            with st.on(k):
+                item = bk.spmm_raw(twin(iu, k), False, _all_gather_raw(user, g), bk.EPI_NONE)
+            out[key] = (user, item)
+
+        def gcn_chain():
+            us, its = [u0], [i0]
+            u, i = u0, i0
+            for l in range(n_layers):
+                epi = bk.EPI_SOFTMAX if l == n_layers - 1 else bk.EPI_NONE
+                yield
+                with st.on(2):
+                    u = bk.spmm_raw(twin(ui, 2), False, _all_gather_raw(i, g), epi)
+                yield
+                with st.on(2):
+                    i = bk.spmm_raw(twin(iu, 2), False, _all_gather_raw(u, g), epi)
+                us.append(u)
+                its.append(i)
+            out["gcn"] = (us, its)
+
+        st.fork()
+        # issue order per depth: GCN first (ready at once), then text (short GEMM), then image (long GEMM)
+        _run_interleaved([gcn_chain(), modal_chain(1, F_txt, W_txt, b_txt, keep_txt, "txt"),
+                          modal_chain(0, F_img, W_img, b_img, keep_img, "img")])
+        st.join()
+        (img_user, img_item), (txt_user, txt_item), (us, its) = out["img"], out["txt"], out["gcn"]
         inv = 1.0 / (n_layers + 1)
         u_g, ss_u = bk.combine_fwd(us, inv, img_user, txt_user, r)
         i_g, ss_i = bk.combine_fwd(its, inv, img_item, txt_item, r)
@@ -376,22 +457,62 @@ class _ShardedHotForward(torch.autograd.Function):
             g_iu_ = g_iu_ + G_img_user
         if G_txt_user is not None:
             g_tu_ = g_tu_ + G_txt_user
+        st = _Streams(bk, Gu)
+        twin = (lambda p, k: p.twin(k)) if hasattr(ui, "twin") else (lambda p, k: p)
+        if st.side:                      # main-pool tensors read on the side streams
+            for t in (keep_img, keep_txt, img_user, txt_user, img_item, txt_item, uG, iG, Gu, Gi, g_iu_, g_tu_,
+                      g_ii_, g_ti_):
+                if t is not None:
+                    for s_ in st.side:
+                        t.record_stream(s_)
+        out = {}
 
-        def t_users(g_items):      # A_iu_r^T . g (full user range) -> my user rows
-            return _reduce_scatter_sum(bk.spmm_raw(iu, True, g_items, bk.EPI_NONE), per_u, g)
+        def rs(full, per, k):            # reduce-scatter of a full-height partial to the row owners
+            _log_comm("reduce_scatter", full)
+            return _reduce_scatter_sum(full, per, g)
 
-        def t_items(g_users):      # A_ui_r^T . g (full item range) -> my item rows
-            return _reduce_scatter_sum(bk.spmm_raw(ui, True, g_users, bk.EPI_NONE), per_i, g)
-        g_x_img = t_items(t_users(g_ii_) + g_iu_)
-        g_x_txt = t_items(t_users(g_ti_) + g_tu_)
-        _, gW_img, gb_img = bk.linear_wgrad_raw(g_x_img, keep_img, scale, F_img, W_img)
-        _, gW_txt, gb_txt = bk.linear_wgrad_raw(g_x_txt, keep_txt, scale, F_txt, W_txt)
-        gi = bk.softmax_rows_bwd(iG, Gi, inv)
-        gu = bk.softmax_rows_bwd(uG, t_users(gi) + inv * Gu, 1.0)
-        gi = t_items(gu) + inv * Gi
-        for _ in range(n_layers - 1):
-            gu = t_users(gi) + inv * Gu
-            gi = t_items(gu) + inv * Gi
+        def modal_chain(k, g_item, g_user, keep, F_, W, key):
+            # g(x) = A_ui_r^T . (A_iu_r^T . g(item feats) + g(user feats)), each A_r^T product reduce-scattered
+            with st.on(k):
+                part = bk.spmm_raw(twin(iu, k), True, g_item, bk.EPI_NONE)
+            yield
+            with st.on(k):
+                gu_ = rs(part, per_u, k) + g_user
+                part = bk.spmm_raw(twin(ui, k), True, gu_, bk.EPI_NONE)
+            yield
+            with st.on(k):
+                gx = rs(part, per_i, k)
+                _, gW, gb = bk.linear_wgrad_raw(gx, keep, scale, F_, W)
+            out[key] = (gW, gb)
+
+        def gcn_chain():
+            with st.on(2):
+                gi = bk.softmax_rows_bwd(iG, Gi, inv)
+                part = bk.spmm_raw(twin(iu, 2), True, gi, bk.EPI_NONE)
+            yield
+            with st.on(2):
+                gu = bk.softmax_rows_bwd(uG, rs(part, per_u, 2) + inv * Gu, 1.0)
+                part = bk.spmm_raw(twin(ui, 2), True, gu, bk.EPI_NONE)
+            yield
+            with st.on(2):
+                gi = rs(part, per_i, 2) + inv * Gi
+            for _ in range(n_layers - 1):
+                with st.on(2):
+                    part = bk.spmm_raw(twin(iu, 2), True, gi, bk.EPI_NONE)
+                yield
+                with st.on(2):
+                    gu = rs(part, per_u, 2) + inv * Gu
+                    part = bk.spmm_raw(twin(ui, 2), True, gu, bk.EPI_NONE)
+                yield
+                with st.on(2):
+                    gi = rs(part, per_i, 2) + inv * Gi
+            out["gi"] = gi
+
+        st.fork()
+        _run_interleaved([gcn_chain(), modal_chain(0, g_ii_, g_iu_, keep_img, F_img, W_img, "img"),
+                          modal_chain(1, g_ti_, g_tu_, keep_txt, F_txt, W_txt, "txt")])
+        st.join()
+        (gW_img, gb_img), (gW_txt, gb_txt), gi = out["img"], out["txt"], out["gi"]
         return (None, gW_img, gb_img if has_bi else None, None, None, gW_txt, gb_txt if has_bt else None, None, None,
                 g_u0, gi, None, None, None, None, None, None)
 
@@ -478,6 +599,7 @@ class ShardedHotPathStep:
         if params:
             flat = torch.cat([p.grad.reshape(-1) for p in params])
             dist.all_reduce(flat, group=self.group)
+            _log_comm("all_reduce", flat)
             k = 0
             for p in params:
                 n = p.grad.numel()
@@ -485,6 +607,7 @@ class ShardedHotPathStep:
                 k += n
         feat = feat_local.detach().clone()
         dist.all_reduce(feat, group=self.group)
+        _log_comm("all_reduce", feat)
         total = local_total.detach() - feat_local.detach() + feat      # replicated part + GLOBAL regulariser
         self.loss.copy_(total)
         return total
@@ -548,22 +671,98 @@ def spawn_rank_probe(argv, port_offset=1, timeout=180):
         return False
 
 
-def build_bench_step(a, rank, world, dev):
-    """Weak-scaled bench workload: the `a.workload` shape x world, seeded identically on every
-    rank; each rank keeps its row blocks only. Returns (step, raw_global, mats_local, plans, stats)."""
+def comm_replay_ms(log, group, dev, iters=10):
+    """Time the collectives of one step ALONE (same kinds and sizes, dummy buffers, back to back on one stream):
+    the per-step communication time if nothing overlapped. HIP events on the issuing stream."""
+    world = dist.get_world_size(group)
+    bufs = []
+    for kind, shape, _ in log:
+        full = torch.zeros(shape, dtype=torch.float32, device=dev)
+        per = (shape[0] // world,) + tuple(shape[1:]) if kind != "all_reduce" else shape
+        bufs.append((kind, full, torch.zeros(per, dtype=torch.float32, device=dev)))
+
+    def once():
+        for kind, full, part in bufs:
+            if kind == "all_gather":
+                dist.all_gather_into_tensor(full, part, group=group)
+            elif kind == "reduce_scatter":
+                dist.reduce_scatter_tensor(part, full, group=group)
+            else:
+                dist.all_reduce(full, group=group)
+    once()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        once()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def _exchange_edges_to_item_owners(users_g, items, ish, world, rank, dev):
+    """Every rank holds the edges of ITS users (global ids); the owner of item block I_r needs all edges whose
+    item falls into I_r. One variable-size all-to-all of (user, item) pairs over the job's process group."""
+    owner = items // ish.per
+    order = np.argsort(owner, kind="stable")
+    send = torch.from_numpy(np.stack((users_g[order], items[order]), 1).astype(np.int64)).to(dev)
+    counts = torch.from_numpy(np.bincount(owner, minlength=world).astype(np.int64)).to(dev)
+    recv_counts = torch.empty_like(counts)
+    dist.all_to_all_single(recv_counts, counts)
+    rc = recv_counts.cpu().tolist()
+    recv = torch.empty((int(sum(rc)), 2), dtype=torch.int64, device=dev)
+    dist.all_to_all_single(recv, send, output_split_sizes=rc, input_split_sizes=counts.cpu().tolist())
+    recv = recv.cpu().numpy()
+    return recv[:, 0], recv[:, 1]
+
+
+def build_sharded_graph(a, rank, world, dev, scaling):
+    """The job's graph as this rank's two CSR row blocks (A_ui[U_r, :], A_iu[I_r, :], global columns).
+
+    strong : the `a.workload` shape itself (configs[3]: Amazon-Baby sharded N-way). The global graph is small
+             (0.2 s to generate), so every rank generates it from the same seed and keeps its rows.
+    weak   : the shape x world. Each rank generates ONLY the interactions of its own user block (per-rank seed)
+             and the (user, item) pairs are routed to the item owners by one all-to-all: no rank ever holds the
+             global edge list. `synth` (configs[4]) is defined for the whole 8-GPU job, so its per-rank share is
+             2M/8 users x 1M/8 items x 100M/8 edges whatever N is.
+    Returns (ui_local, iu_local, ush, ish, U, I, E_global, dv, dt)."""
+    from . import synth
+    U, I, E, dv, dt = synth.SHAPES[a.workload]
+    if a.workload == "synth":
+        U, I, E, dv, dt = U // 8, I // 8, E // 8, 128, 128
+        scaling = "weak"
+    if scaling == "strong":
+        raw = synth.interaction_matrix(U, I, E, seed=1)
+        ui, iu = synth.normalised_pair(raw)
+        ush, ish = RowShard(U, world, rank), RowShard(I, world, rank)
+        return shard_graph(ui, ush, ish), shard_graph(iu, ish, ush), ush, ish, U, I, int(raw.nnz), dv, dt
+    Ug, Ig = U * world, I * world
+    ush, ish = RowShard(Ug, world, rank), RowShard(Ig, world, rank)
+    # my users' interactions with ALL items (item popularity shared by all ranks through the seed of `p`)
+    raw_u = synth.interaction_matrix(U, Ig, E, seed=1000 + rank, item_seed=77)
+    ui_l = synth.normalised_rows(raw_u)                               # [U, Ig] rows of A_ui
+    ui_l.resize((ush.per, ish.n_pad))
+    coo = raw_u.tocoo()
+    if world > 1:
+        ug, it = _exchange_edges_to_item_owners(coo.row.astype(np.int64) + ush.lo, coo.col.astype(np.int64), ish,
+                                                world, rank, dev)
+    else:
+        ug, it = coo.row.astype(np.int64), coo.col.astype(np.int64)
+    raw_i = sp.csr_matrix((np.ones(ug.shape[0], np.float32), (it - ish.lo, ug)), shape=(ish.per, ush.n_pad))
+    iu_l = synth.normalised_rows(raw_i)                               # [I_per, Ug] rows of A_iu
+    t = torch.tensor([raw_u.nnz], dtype=torch.int64, device=dev)
+    if world > 1:
+        dist.all_reduce(t)
+    return ui_l, iu_l, ush, ish, Ug, Ig, int(t.item()), dv, dt
+
+
+def build_bench_step(a, rank, world, dev, scaling="weak"):
+    """bench.py workload for the sharded path. Returns (step, local_mats, plans, stats)."""
     from . import synth
     from .config import configure, HotCfg
-    U, I, E, dv, dt = synth.SHAPES[a.workload]
-    if a.workload == "synth":          # the 100M-edge stress shape is defined for the WHOLE job, d=128
-        U, I, E, dv, dt = U // 8 * world, I // 8 * world, E // 8 * world, 128, 128
-    else:
-        U, I, E = U * world, I * world, E * world
     configure([], embed_size=a.d, weight_size=str([a.d] * a.gcn_layers), batch_size=a.batch, drop_rate=0.2)
-    raw = synth.interaction_matrix(U, I, E, seed=1)
-    ui, iu = synth.normalised_pair(raw)
-    ush, ish = RowShard(U, world, rank), RowShard(I, world, rank)
+    ui_l, iu_l, ush, ish, U, I, E_global, dv, dt = build_sharded_graph(a, rank, world, dev, scaling)
     bk = HipBackend()
-    ui_l, iu_l = shard_graph(ui, ush, ish), shard_graph(iu, ish, ush)
     with torch.cuda.device(dev):
         plans = [bk.make_graph(ui_l), bk.make_graph(iu_l)]
         e_ui = bk.make_graph(sp.csr_matrix((ush.per, ish.n_pad), dtype=np.float32))
@@ -576,25 +775,20 @@ def build_bench_step(a, rank, world, dev):
     def xavier(rows, cols):
         bound = (6.0 / (rows + cols)) ** 0.5
         return (torch.rand(rows, cols, generator=g) * 2 - 1) * bound
-    # features / embeddings are generated per shard from a rank-independent stream position
+    # features / embeddings are generated per shard (rank-dependent seeds); replicated weights from a shared seed
     gi = torch.Generator().manual_seed(7 + 1000 * rank)
     img_l = torch.randn(ish.per, dv, generator=gi)
     txt_l = torch.randn(ish.per, dt, generator=gi)
-    state = {"image_trans.weight": xavier(a.d, dv), "image_trans.bias": torch.zeros(a.d),
-             "text_trans.weight": xavier(a.d, dt), "text_trans.bias": torch.zeros(a.d),
-             "weight_dict.w_self_attention_cat": xavier(4 * a.d, a.d)}
     ge = torch.Generator().manual_seed(99 + rank)
-    bound = (6.0 / (U + a.d)) ** 0.5
-    state["user_id_embedding.weight"] = None
     model = ShardedMMSSL.__new__(ShardedMMSSL)
     nn.Module.__init__(model)
     model.bk, model.cfg, model.ush, model.ish, model.group = bk, cfg, ush, ish, None
-    model.img_w = nn.Parameter(state["image_trans.weight"])
-    model.img_b = nn.Parameter(state["image_trans.bias"])
-    model.txt_w = nn.Parameter(state["text_trans.weight"])
-    model.txt_b = nn.Parameter(state["text_trans.bias"])
-    model.w_cat = nn.Parameter(state["weight_dict.w_self_attention_cat"])
-    model.E_u = nn.Parameter((torch.rand(ush.per, a.d, generator=ge) * 2 - 1) * bound)
+    model.img_w = nn.Parameter(xavier(a.d, dv))
+    model.img_b = nn.Parameter(torch.zeros(a.d))
+    model.txt_w = nn.Parameter(xavier(a.d, dt))
+    model.txt_b = nn.Parameter(torch.zeros(a.d))
+    model.w_cat = nn.Parameter(xavier(4 * a.d, a.d))
+    model.E_u = nn.Parameter((torch.rand(ush.per, a.d, generator=ge) * 2 - 1) * (6.0 / (U + a.d)) ** 0.5)
     model.E_i = nn.Parameter((torch.rand(ish.per, a.d, generator=ge) * 2 - 1) * (6.0 / (I + a.d)) ** 0.5)
     model.register_buffer("image_feats", img_l, persistent=False)
     model.register_buffer("text_feats", txt_l, persistent=False)
@@ -602,13 +796,17 @@ def build_bench_step(a, rank, world, dev):
     step = ShardedHotPathStep(model, (plans[0], plans[1], e_ui, e_iu, e_ui, e_iu), a.batch, I, modal_empty=True)
     from . import ops
     ops.STATS.update(enabled=True, spmm_launches=0, edge_layers=0, spmm_bytes=0)
+    COMM["log"] = []
     step.step()
     torch.cuda.synchronize()
     ops.STATS["enabled"] = False
     stats = dict(ops.STATS)
+    stats["comm_log"], COMM["log"] = COMM["log"], None
     t = torch.tensor([stats["edge_layers"]], dtype=torch.int64, device=dev)
     with torch.cuda.stream(step.stream):
         dist.all_reduce(t)
     torch.cuda.synchronize()
     stats["edge_layers_global"] = int(t.item())
-    return step, raw, (ui_l, iu_l), plans, stats
+    stats.update(n_users=U, n_items=I, n_edges=E_global, local_users=ush.per, local_items=ish.per,
+                 local_edges=int(ui_l.nnz))
+    return step, (ui_l, iu_l), plans, stats

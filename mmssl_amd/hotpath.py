@@ -39,6 +39,9 @@ class HotPathStep:
         self._feat_c, self._feat_c_val = None, None
         self.parts = {}
         self._graph = None
+        # parity runs inject fixed uint8 dropout keep-masks (img, txt), each [n_items, d]; None = one Philox launch
+        # per step (fresh masks on every replay)
+        self.keep_masks = None
         # ONE stream for everything this object launches (eager steps, capture, replays): autograd
         # binds each parameter's AccumulateGrad node to the stream of its first backward, and a
         # later capture on a different stream would have to synchronise across streams.
@@ -57,7 +60,7 @@ class HotPathStep:
 
     def losses(self):
         m = self.model
-        (ua, ia, img_item, txt_item, img_user, txt_user, uemb, _, img_uid, txt_uid, _, _) = m(*self.graphs)
+        (ua, ia, img_item, txt_item, img_user, txt_user, uemb, _, img_uid, txt_uid, _, _) = m(*self.graphs, keep_masks=self.keep_masks)
         terms = ops.batch_losses_vec(ua, ia, img_uid, txt_uid, self.users, self.pos, self.neg, self.decay,
                                      self.batch_size, args.tau)                 # [mf, emb, 0, cl_img, cl_txt]
         ss = m.feat_sumsq(img_item, txt_item, img_user, txt_user)

@@ -960,6 +960,13 @@ class _HotForward(torch.autograd.Function):
         if overlap:
             for st in (sA, sB, sC):
                 st.wait_stream(main)
+            # saved tensors from the main stream's pool that the side streams read, possibly AFTER this
+            # backward has returned (deferred join): the caching allocator must not hand their blocks to a
+            # main-stream allocation before the side stream is done with them
+            for t, st in ((keep_img, sA), (keep_txt, sB), (img_user, sA), (txt_user, sA), (img_item, sB),
+                          (txt_item, sB), (uG, sC), (iG, sC)):
+                if t is not None:
+                    t.record_stream(st)
         if split:
             with torch.cuda.stream(sA):
                 g_iu_, g_tu_, g_u0 = _combine_bwd(img_user, txt_user, Gu, r, inv, g_ss, 2.0, True)

@@ -29,7 +29,30 @@ def test_bench_json_contract():
     for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert key in rf, key
     assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
+    assert "step_frac" in rf and 0 < rf["step_frac"] < rf["frac"] * 1.5
+    gf = d["gcn_forward"]
+    assert gf["edge_layers"] == 3 * 2 * d["config"]["n_edges"] and gf["us"] > 0
+    assert abs(gf["edge_layers_per_s"] - gf["edge_layers"] / gf["us"] * 1e6) <= 1e-3 * gf["edge_layers_per_s"]
+    lc = d["loss_check"]
+    assert lc["rel_err"] <= lc["tolerance"] == 1e-4, lc          # north_star: fp32 loss within 1e-4 relative
     cb = d["cpu_baseline"]
     for key in ("value", "unit", "cores", "kind", "sample"):
         assert key in cb, key
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0
+
+
+def test_bench_sharded_path_one_rank_reports_comm():
+    """The row-sharded code path (RCCL collectives, interleaved chains, captured step) on ONE rank: the JSON line
+    keeps the contract and carries the communication record."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "5", "--warmup", "2",
+                        "--workload", "tiktok", "--force-dist", "--scaling", "strong"], capture_output=True, text=True,
+                       timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["scaling"] == "strong" and d["value"] > 0
+    c = d["comm"]
+    # 3-layer GCN + two modal chains: 2*(3*2 + 2*2) gathers / reduce-scatters + 3 all-reduces (batch rows, dense grads, regulariser)
+    assert c["by_kind"]["all_gather"][0] == 10 and c["by_kind"]["reduce_scatter"][0] == 10 and c["by_kind"]["all_reduce"][0] == 3
+    assert c["comm_only_ms"] > 0 and c["bytes_per_step"] > 0

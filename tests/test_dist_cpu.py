@@ -150,3 +150,39 @@ def test_spawn_rank_probe(mode):
                         os.path.join(here, "_probe_parent.py"), "parent", mode],
                        capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
+
+
+def _graph_worker(rank, world, port, scaling, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import types
+    from mmssl_amd import dist as md
+    a = types.SimpleNamespace(workload="tiny")
+    ui_l, iu_l, ush, ish, U, I, E, dv, dt = md.build_sharded_graph(a, rank, world, torch.device("cpu"), scaling)
+    torch.save({"ui": ui_l, "iu": iu_l, "U": U, "I": I, "E": E, "per": (ush.per, ish.per)},
+               os.path.join(out_dir, "g%d.pt" % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,scaling", [(2, "weak"), (3, "weak"), (2, "strong")])
+def test_sharded_graph_generation_is_one_consistent_global_graph(tmp_path, world, scaling):
+    """bench.py's N>1 workloads: in weak mode every rank generates only its users' interactions and the edges
+    reach the item owners through an all-to-all; the row blocks must assemble to ONE graph whose A_iu is the
+    row-normalised transpose of the same interactions as A_ui (main.py:65-67), with nothing lost or duplicated."""
+    import scipy.sparse as sp
+    port = _free_port()
+    mp.spawn(_graph_worker, args=(world, port, scaling, str(tmp_path)), nprocs=world, join=True)
+    outs = [torch.load(os.path.join(str(tmp_path), "g%d.pt" % r), weights_only=False) for r in range(world)]
+    U, I, E = outs[0]["U"], outs[0]["I"], outs[0]["E"]
+    A_ui = sp.vstack([o["ui"] for o in outs]).tocsr()[:U, :I]
+    A_iu = sp.vstack([o["iu"] for o in outs]).tocsr()[:I, :U]
+    assert A_ui.nnz == E == A_iu.nnz
+    pat = (A_ui != 0).astype(np.float32)
+    assert ((A_iu != 0).astype(np.float32) != pat.T).nnz == 0            # same interactions, transposed
+    from mmssl_amd import synth
+    ref_ui, ref_iu = synth.normalised_pair(pat.tocsr())
+    assert abs(A_ui - ref_ui).max() < 1e-6 and abs(A_iu - ref_iu).max() < 1e-6
+    if scaling == "weak":
+        assert (U, I) == (600 * world, 400 * world)

@@ -101,3 +101,109 @@ def test_baby_full_size_properties():
     assert abs(a - b) <= 2e-6 * abs(a)
     zero = float(ops.infonce(torch.zeros_like(z), z2, 0.5))
     assert abs(zero + np.log(1.0 / (2 * 1024 - 1) + 1e-8)) < 1e-5
+
+
+# ---------------------------------------------------------------------------------------------------
+# configs[2] end to end: the FULL Amazon-Baby hot-path step (18357 x 4096 projection, fused propagate node,
+# batch losses, backward; eager AND as the captured hipGraph bench.py times) against the oracle.
+# ---------------------------------------------------------------------------------------------------
+_BABY = {}
+
+
+def _baby_case(modal):
+    """(model factory, graphs, batch, masks, oracle loss, oracle grads) for the Baby shape; `modal` = 'empty'
+    (the reference's steady state, what bench.py times) or 'full' (its first two batches: modal graphs ARE the
+    interaction graph — the same GraphPlan objects passed twice, like Trainer's initial state)."""
+    if modal in _BABY:
+        return _BABY[modal]
+    from mmssl_amd.graph import GraphPlan
+    from mmssl_amd.Models import MMSSL
+    U, I, dv, dt, raw, ui, iu, P_ui, P_iu = _setup("baby")
+    from mmssl_amd import config
+    config.configure([], drop_rate=0.2, batch_size=1024, weight_size=str([64] * 3), debug=True)
+    g = torch.Generator().manual_seed(0)
+    img, txt = torch.randn(I, dv, generator=g), torch.randn(I, dt, generator=g)
+    torch.manual_seed(4)
+    cpu_model = MMSSL(U, I, 64, [64] * 3, [0.1] * 3, img.numpy(), txt.numpy())
+    state0 = {k: v.detach().clone() for k, v in cpu_model.state_dict().items()}
+    del cpu_model
+    km = [(torch.rand(I, 64, generator=g) >= 0.2) for _ in range(2)]
+    rng = np.random.default_rng(1)
+    users = torch.from_numpy(rng.choice(U, 1024, replace=False))
+    pos = torch.from_numpy(rng.integers(0, I, 1024))
+    neg = torch.from_numpy(rng.integers(0, I, 1024))
+    if modal == "empty":
+        e_ui, e_iu = sp.csr_matrix((U, I), dtype=np.float32), sp.csr_matrix((I, U), dtype=np.float32)
+        graphs_g = (P_ui, P_iu, GraphPlan(e_ui), GraphPlan(e_iu), GraphPlan(e_ui), GraphPlan(e_iu))
+        mats = (ui, iu, e_ui, e_iu, e_ui, e_iu)
+    else:
+        graphs_g = (P_ui, P_iu, P_ui, P_iu, P_ui, P_iu)
+        mats = (ui, iu, ui, iu, ui, iu)
+    A = [O.to_torch_sparse(x) for x in mats]
+    P = {k: v.clone().requires_grad_(v.dtype.is_floating_point) for k, v in state0.items()
+         if not k.startswith(("image_embedding", "text_embedding", "batch_norm", "encoder.", "align."))}
+    cfg = O.Cfg(drop_rate=0.2, n_ui_layers=3, batch_size=1024)
+    o = O.forward(P, img, txt, A, cfg, training=True, keep_masks=[k.float() for k in km])
+    mf, emb, _ = O.bpr(o[0][users], o[1][pos], o[1][neg], 1e-5, 1024)
+    ref = mf + emb + O.feat_reg(o[2], o[3], o[4], o[5], I, 1e-5) + 0.03 * (
+        O.infonce(o[8][users], o[6][users], 0.5) + O.infonce(o[9][users], o[6][users], 0.5))
+    ref.backward()
+    grads = {k: P[k].grad.clone() for k in ("image_trans.weight", "image_trans.bias", "text_trans.weight",
+                                            "text_trans.bias", "user_id_embedding.weight", "item_id_embedding.weight")}
+    if modal == "full":
+        grads["weight_dict.w_self_attention_cat"] = P["weight_dict.w_self_attention_cat"].grad.clone()
+
+    def make_step():
+        from mmssl_amd.hotpath import HotPathStep
+        model = MMSSL(U, I, 64, [64] * 3, [0.1] * 3, img.numpy(), txt.numpy())
+        model.load_state_dict(state0)
+        model = model.to(DEV).train()
+        step = HotPathStep(model, graphs_g, 1024, decay=1e-5)
+        step.keep_masks = tuple(k.to(torch.uint8).to(DEV) for k in km)
+        step.set_batch(users.to(DEV), pos.to(DEV), neg.to(DEV))
+        return model, step
+    _BABY[modal] = (make_step, state0, float(ref), grads)
+    return _BABY[modal]
+
+
+def _check_baby(model, step, ref, grads, tag):
+    got = float(step.loss)
+    assert abs(got - ref) <= 1e-4 * abs(ref), (tag, got, ref)                       # north_star bar
+    named = dict(model.named_parameters())
+    for k, gref in grads.items():
+        e = H.rel_err(named[k].grad.cpu(), gref)
+        assert e < 5e-4, (tag, k, e)
+
+
+@pytest.mark.parametrize("modal", ["empty", "full"])
+def test_baby_full_step_eager_matches_oracle(modal):
+    make_step, state0, ref, grads = _baby_case(modal)
+    model, step = make_step()
+    step.step()
+    torch.cuda.synchronize()
+    _check_baby(model, step, ref, grads, "eager/" + modal)
+
+
+def test_baby_full_step_captured_graph_matches_oracle():
+    """The unit bench.py times: one whole step (3 forked streams, deferred wgrad join, fused AdamW) replayed from
+    a hipGraph. Parameters are restored after the warm-up / capture steps, so the replay starts from the same
+    state as the oracle's step; its loss and every parameter gradient must match."""
+    make_step, state0, ref, grads = _baby_case("empty")
+    model, step = make_step()
+    assert step.capture(warmup=2), getattr(step, "capture_error", "")
+    with torch.no_grad():
+        for k, p in model.named_parameters():
+            p.copy_(state0[k])
+    torch.cuda.synchronize()
+    step.run()
+    torch.cuda.synchronize()
+    _check_baby(model, step, ref, grads, "captured")
+    # and a second replay from the same parameters reproduces the first bit for bit (fixed-order reductions)
+    first = float(step.loss)
+    g1 = model.image_trans.weight.grad.clone()
+    with torch.no_grad():
+        for k, p in model.named_parameters():
+            p.copy_(state0[k])
+    step.run()
+    torch.cuda.synchronize()
+    assert float(step.loss) == first and torch.equal(g1, model.image_trans.weight.grad)

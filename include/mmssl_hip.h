@@ -173,7 +173,8 @@ int mmssl_sumsq_f32(const float* X, int64_t n, float* out, void* workspace,
  *   nn.Linear image_trans / text_trans + nn.Dropout (Models.py:28-29, 54, 173-174).
  *   keep: optional uint8 [M,N] keep-mask (1 = keep); kept entries are scaled by `scale`
  *   (= 1/(1-p)); keep == NULL means no dropout (eval mode). fp32 MFMA
- *   (v_mfma_f32_32x32x2_f32), exact fp32. N % 4 == 0, N <= 256, K % 4 == 0.
+ *   (v_mfma_f32_32x32x2_f32), exact fp32. N % 4 == 0, K % 4 == 0; N <= 256 unless b == keep == NULL and
+ *   K % 32 == 0.
  *   mmssl_linear_wgrad: gW[N,K] = gYm[M,N]^T . F[M,K], gb[N] = column sums of gYm, where
  *   gYm = gY * keep * scale is the dropout backward, applied while gY is fetched (keep == NULL:
  *   gYm = gY). Autograd of the same call site.
@@ -202,6 +203,15 @@ size_t mmssl_split_transpose_workspace_bytes(int64_t Mp, int N);
 int mmssl_split_transpose_bf16_f32(const float* G, const uint8_t* keep, float scale, int64_t M, int N,
                                    int64_t Mp, uint16_t* T_hi, uint16_t* T_lo, float* colsum,
                                    void* workspace, size_t workspace_bytes, void* stream);
+/* G [M, N] fp32 (optionally dropout-masked: keep/scale) -> T [N, Mp] fp32 = G^T, zero in columns M..Mp-1
+ * (Mp % 4 == 0); colsum (may be NULL) receives the column sums of the masked G, i.e. the bias gradient.
+ * With it the weight gradient of the projection (autograd of Models.py:173-174) is the FORWARD product
+ *   gW [N, K] = mmssl_linear_f32(F = T [N, Mp], W = F^T [K, Mp], b = NULL, keep = NULL, M = N, K = Mp, N = K)
+ * against a transposed copy of the constant feature matrix (mmssl_linear_f32 accepts N > 256 for that plain
+ * product when K % 32 == 0). */
+size_t mmssl_transpose_mask_workspace_bytes(int64_t Mp, int N);
+int mmssl_transpose_mask_f32(const float* G, const uint8_t* keep, float scale, int64_t M, int N, int64_t Mp,
+                             float* T, float* colsum, void* workspace, size_t workspace_bytes, void* stream);
 size_t mmssl_linear_wgrad_workspace_bytes(int64_t M, int K, int N);
 int mmssl_linear_wgrad_f32(const float* gY, const uint8_t* keep, float scale, const float* F,
                            int64_t M, int K, int N, float* gW, float* gb, void* workspace,

@@ -67,6 +67,9 @@ SIGNATURES = {
     "mmssl_split_transpose_workspace_bytes": (c_size_t, [c_int64, c_int]),
     "mmssl_split_transpose_bf16_f32": (c_int, [c_void_p, c_void_p, c_float, c_int64, c_int, c_int64, c_void_p, c_void_p,
                                                c_void_p, c_void_p, c_size_t, c_void_p]),
+    "mmssl_transpose_mask_workspace_bytes": (c_size_t, [c_int64, c_int]),
+    "mmssl_transpose_mask_f32": (c_int, [c_void_p, c_void_p, c_float, c_int64, c_int, c_int64, c_void_p, c_void_p,
+                                         c_void_p, c_size_t, c_void_p]),
     "mmssl_linear_wgrad_workspace_bytes": (c_size_t, [c_int64, c_int, c_int]),
     "mmssl_linear_wgrad_f32": (c_int, [c_void_p, c_void_p, c_float, c_void_p, c_int64, c_int, c_int, c_void_p,
                                        c_void_p, c_void_p, c_size_t, c_void_p]),

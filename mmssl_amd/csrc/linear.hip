@@ -271,6 +271,253 @@ __global__ __launch_bounds__(kBlock) void gemm_fwd_dma_kernel(const float* __res
 
 
 // ======================================================================================
+// v6 "stream-K" forward kernel (default since round 2). Same 64x64 block tile, 2x2 waves, 32-deep slices and
+// swizzled 4-stage LDS-DMA ring as gemm_fwd_dma_kernel, with two changes that the round-1 profile asked for:
+//
+//  * WORK DECOMPOSITION. The split-K grid of v5 launches tiles x splits blocks of equal size; for the Baby image
+//    projection that is 287 x 4 = 1148 blocks on 512 block slots (2 per CU): 2.24 rounds, i.e. the last round
+//    runs on a quarter of the chip. Here the (tile, slice) units are laid out on one axis and cut into as many
+//    EQUAL contiguous ranges as there are block slots (287 x 128 = 36736 units / 512 = 71.75): every block does
+//    the same number of slices, whatever the tile count. A range that covers a whole tile stores the result
+//    directly (bias + dropout in the epilogue); partial ranges store the raw accumulator to one of the block's two
+//    slots (head / tail) and sk_reduce_kernel adds a tile's slots in block order (fixed order: deterministic).
+//    Partial traffic: <= 2 x 16 KB per block (13 MB for the Baby image shape, vs 19 MB of split partials in v5).
+//  * FRAGMENT DOUBLE BUFFERING. v5 read the 8 ds_read_b128 fragments of a slice right after the barrier and only
+//    then started the slice's 16 dependent MFMAs, so every slice paid barrier + LDS latency in front of its MFMA
+//    chain (PMC: SQ_WAIT_INST_ANY 66 % of wave cycles, MFMA pipe 59 % busy). Now the fragments of slice kt+1 are
+//    fetched into a second register set BEFORE the MFMAs of slice kt are issued.
+// Preconditions (host-checked): KK % 32 == 0, row-major [i][kk] operands, 16-B aligned rows.
+// ======================================================================================
+constexpr int kSkTileFloats = BT * BT;      // one partial slot: the block's 64x64 accumulator image (16 KB)
+
+// lgkmcnt(0) as the BUILTIN (simm16: vmcnt = 63, expcnt = 7, lgkmcnt = 0): the compiler's wait-count pass sees it,
+// so it does not put redundant s_waitcnt instructions between the dependent MFMAs that follow (any instruction
+// between two MFMAs on one accumulator breaks their back-to-back issue).
+__device__ __forceinline__ void lgkm_wait0() {
+  __builtin_amdgcn_s_waitcnt(0xC07F);
+  asm volatile("" ::: "memory");
+}
+
+struct Frag {
+  float4 a[4], b[4];
+};
+
+__global__ __launch_bounds__(kBlock) void gemm_sk_kernel(const float* __restrict__ A, int64_t lda,
+                                                         const float* __restrict__ B, int64_t ldb, int64_t I,
+                                                         int64_t J, int tiles_j, int S, int64_t total_units, int upb,
+                                                         float* __restrict__ C, int64_t ldc,
+                                                         const float* __restrict__ bias,
+                                                         const uint8_t* __restrict__ keep, float scale,
+                                                         float* __restrict__ partials) {
+  __shared__ __attribute__((aligned(16))) float ring[kDmaStages * kDmaStageFloats];     // 64 KB
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int h = lane >> 5, lr = lane & 31;
+  const int sw = (lr >> 1) & 7;
+  const int ia = (wm * 32 + lr) * BK, jb = BT * BK + (wn * 32 + lr) * BK;
+  const unsigned ring_lds = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)ring);
+  const unsigned piece = __builtin_amdgcn_readfirstlane((unsigned)(16 * wave * BK * 4));
+  const int64_t u_begin = (int64_t)blockIdx.x * upb;
+  const int64_t u_end = min(total_units, u_begin + upb);
+  int64_t u = u_begin;
+  while (u < u_end) {
+    const int64_t tile = u / S;
+    const int s0 = (int)(u - tile * S);
+    const int s1 = (int)min((int64_t)S, s0 + (u_end - u));
+    const int nk = s1 - s0;
+    const int64_t i0 = (tile / tiles_j) * BT, j0 = (tile % tiles_j) * BT;
+    // DMA pieces: wave w moves rows [16w, 16w+16) of each operand slice as 2 x (8 rows x 128 B)
+    const float* pa[2];
+    const float* pb[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int r = 16 * wave + 8 * j + (lane >> 3);
+      const int c = (lane & 7) ^ ((r >> 1) & 7);                  // source-side swizzle
+      pa[j] = A + min(i0 + r, I - 1) * lda + (int64_t)s0 * BK + 4 * c;
+      pb[j] = B + min(j0 + r, J - 1) * ldb + (int64_t)s0 * BK + 4 * c;
+    }
+    auto issue = [&](int kt) {
+      const unsigned st = ring_lds + (unsigned)(kt & (kDmaStages - 1)) * (kDmaStageFloats * 4) + piece;
+      glds16(pa[0] + (int64_t)kt * BK, st);
+      glds16(pa[1] + (int64_t)kt * BK, st + 8 * BK * 4);
+      glds16(pb[0] + (int64_t)kt * BK, st + BT * BK * 4);
+      glds16(pb[1] + (int64_t)kt * BK, st + BT * BK * 4 + 8 * BK * 4);
+    };
+    auto read_frags = [&](int kt, Frag& f) {
+      const float* st = ring + (kt & (kDmaStages - 1)) * kDmaStageFloats;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int pos = ((2 * q + h) ^ sw) * 4;
+        f.a[q] = *reinterpret_cast<const float4*>(st + ia + pos);
+        f.b[q] = *reinterpret_cast<const float4*>(st + jb + pos);
+      }
+    };
+    floatx16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    auto mfma16 = [&](const Frag& f) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[q].x, f.b[q].x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[q].y, f.b[q].y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[q].z, f.b[q].z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[q].w, f.b[q].w, acc, 0, 0, 0);
+      }
+    };
+    // one pipeline step: make slice kt+1 resident, fetch its fragments into `nxt`, then run slice kt from `cur`
+    auto step = [&](int kt, const Frag& cur, Frag& nxt) {
+      if (kt + 1 < nk) {
+        const int after = min(nk - 1, kt + 3) - (kt + 1);     // DMA groups issued after slice kt+1
+        if (after >= 2) vm_wait_n<8>();
+        else if (after == 1) vm_wait_n<4>();
+        else vm_wait_n<0>();
+        lgkm_wait0();        // my fragment reads of slice kt are done: its stage may be refilled after the barrier
+        bare_barrier();      // everyone's pieces of slice kt+1 have landed; nobody reads stage kt & 3 any more
+        if (kt + 4 < nk) issue(kt + 4);
+        read_frags(kt + 1, nxt);
+      }
+      mfma16(cur);
+    };
+    // the previous segment's epilogue stores and fragment reads must be done before the ring is refilled
+    vm_wait_n<0>();
+    lgkm_wait0();
+    bare_barrier();
+    issue(0);
+    if (nk > 1) issue(1);
+    if (nk > 2) issue(2);
+    if (nk > 2) vm_wait_n<8>();
+    else if (nk > 1) vm_wait_n<4>();
+    else vm_wait_n<0>();
+    bare_barrier();
+    if (nk > 3) issue(3);
+    // steady state (slices kt+1 .. kt+4 exist): branch-free, so the accumulator stays in its AGPRs and the
+    // compiler's own LDS wait in front of the MFMAs only covers the OLDER fragment set
+    // (sched_barrier: the compiler otherwise sinks this step's MFMAs below the NEXT step's barrier and LDS wait,
+    //  which puts the fragment-read latency back in front of them)
+    auto step_steady = [&](int kt, const Frag& cur, Frag& nxt) {
+      vm_wait_n<8>();
+      lgkm_wait0();
+      bare_barrier();
+      issue(kt + 4);
+      read_frags(kt + 1, nxt);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma16(cur);
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    Frag f0, f1;
+    read_frags(0, f0);
+    int kt = 0;
+    for (; kt + 5 < nk; kt += 2) {
+      step_steady(kt, f0, f1);
+      step_steady(kt + 1, f1, f0);
+    }
+    for (; kt < nk; kt += 2) {                 // drain: at most 6 slices
+      step(kt, f0, f1);
+      if (kt + 1 < nk) step(kt + 1, f1, f0);
+    }
+    if (s0 == 0 && s1 == S) {                  // whole tile: finished result
+      const int64_t col = j0 + wn * 32 + (lane & 31);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t row = i0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (row < I && col < J) {
+          float v = acc[r];
+          if (bias) v += bias[col];
+          if (keep) v = keep[row * J + col] ? v * scale : 0.f;
+          C[row * ldc + col] = v;
+        }
+      }
+    } else {                                    // partial range: raw accumulator image, thread-major float4s
+      const int seg = (u == u_begin) ? 0 : 1;
+      float4* P = reinterpret_cast<float4*>(partials + ((size_t)blockIdx.x * 2 + seg) * kSkTileFloats);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) P[q * kBlock + tid] = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+    }
+    u += nk;
+  }
+}
+
+// one block per output tile: adds the tile's partial slots in block order, applies bias + dropout, stores.
+__global__ __launch_bounds__(kBlock) void sk_reduce_kernel(const float* __restrict__ partials, int tiles_j, int S,
+                                                           int64_t total_units, int upb, int64_t I, int64_t J,
+                                                           float* __restrict__ C, int64_t ldc,
+                                                           const float* __restrict__ bias,
+                                                           const uint8_t* __restrict__ keep, float scale) {
+  const int64_t tile = blockIdx.x;
+  const int64_t u_lo = tile * S, u_hi = u_lo + S;
+  const int64_t b_first = u_lo / upb, b_last = (u_hi - 1) / upb;
+  if (b_first == b_last) return;               // one block covered the whole tile and stored it itself
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float4 v[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) v[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int64_t b = b_first; b <= b_last; ++b) {
+    const int seg = (b * upb < u_lo) ? 1 : 0;
+    const float4* P = reinterpret_cast<const float4*>(partials + ((size_t)b * 2 + seg) * kSkTileFloats);
+    float4 p[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) p[q] = P[q * kBlock + tid];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      v[q].x += p[q].x; v[q].y += p[q].y; v[q].z += p[q].z; v[q].w += p[q].w;
+    }
+  }
+  const int wm = wave >> 1, wn = wave & 1;
+  const int64_t i0 = (tile / tiles_j) * BT, j0 = (tile % tiles_j) * BT;
+  const int64_t col = j0 + wn * 32 + (lane & 31);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const float e[4] = {v[q].x, v[q].y, v[q].z, v[q].w};
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int r = 4 * q + c;
+      const int64_t row = i0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      if (row < I && col < J) {
+        float x = e[c];
+        if (bias) x += bias[col];
+        if (keep) x = keep[row * J + col] ? x * scale : 0.f;
+        C[row * ldc + col] = x;
+      }
+    }
+  }
+}
+
+// G [M, N] (optionally dropout-masked) -> T [N, Mp] fp32 transposed, zero in columns M..Mp-1, plus per-block column
+// sums of the masked G (-> bias gradient): the A operand of the weight-gradient product gW = gY^T . F when that
+// product runs through the forward kernel against a transposed copy of the constant feature matrix.
+__global__ __launch_bounds__(kBlock) void transpose_mask_kernel(const float* __restrict__ G,
+                                                                const uint8_t* __restrict__ keep, float scale,
+                                                                int64_t M, int N, int64_t Mp, float* __restrict__ T,
+                                                                float* __restrict__ colpart) {
+  __shared__ float tile[64][65];
+  __shared__ float red[4][64];
+  const int c = threadIdx.x & 63, q = threadIdx.x >> 6;
+  const int64_t m0 = (int64_t)blockIdx.x * 64;
+  const int n0 = (int)blockIdx.y * 64;
+  float sum = 0.f;
+#pragma unroll 4
+  for (int i = 0; i < 16; ++i) {
+    const int r = q + 4 * i;
+    const int64_t m = m0 + r;
+    float v = 0.f;
+    if (m < M && n0 + c < N) {
+      v = G[m * N + n0 + c];
+      if (keep) v = keep[m * N + n0 + c] ? v * scale : 0.f;
+    }
+    tile[r][c] = v;
+    sum += v;
+  }
+  red[q][c] = sum;
+  __syncthreads();
+  if (q == 0 && n0 + c < N) colpart[(int64_t)blockIdx.x * N + n0 + c] = ((red[0][c] + red[1][c]) + red[2][c]) + red[3][c];
+#pragma unroll 4
+  for (int i = 0; i < 16; ++i) {
+    const int n = q + 4 * i;
+    if (n0 + n < N && m0 + c < Mp) T[(int64_t)(n0 + n) * Mp + m0 + c] = tile[c][n];
+  }
+}
+
+// ======================================================================================
 // OPT-IN split-precision product (MMSSL_GEMM_SPLIT=1 on the Python side; NOT the default path):
 //   C[i][j] = sum_k A[i][k] * B[j][k]   with A, B given as bf16 (hi, lo) pairs, x ~= hi + lo (16 mantissa bits),
 //   accumulated in fp32 as  hi*hi + hi*lo + lo*hi  on the bf16 matrix cores (v_mfma_f32_32x32x16_bf16).
@@ -513,10 +760,35 @@ __global__ __launch_bounds__(kBlock) void split_transpose_kernel(const float* __
 // Measured on MI355X, Baby image projection [18357,4096]x[4096,64], kernel + split reduce under a hipGraph:
 // register-staged 137-141 us (70 TF), LDS-DMA 130-132 us (73-74 TF); DESIGN.md section 4 has the
 // decomposition runs that explain why both sit near 75 TF.
-inline bool dma_enabled() {
-  static const int v = getenv("MMSSL_GEMM_V") ? atoi(getenv("MMSSL_GEMM_V")) : 5;
-  return v != 1;
+inline int gemm_version() {
+  static const int v = getenv("MMSSL_GEMM_V") ? atoi(getenv("MMSSL_GEMM_V")) : 6;
+  return v;
 }
+inline bool dma_enabled() { return gemm_version() != 1; }
+
+// stream-K decomposition (gemm_sk_kernel): `slots` equal unit ranges, at least min(S, 8) slices each
+struct SkPlan {
+  int64_t tiles_i, tiles_j, total;
+  int S, upb, blocks;
+};
+inline int sk_slots() {
+  static const int v = getenv("MMSSL_GEMM_SK_BLOCKS") ? atoi(getenv("MMSSL_GEMM_SK_BLOCKS")) : 512;   // 2 per CU
+  return v > 0 ? v : 512;
+}
+inline SkPlan sk_plan(int64_t I, int64_t J, int64_t KK) {
+  SkPlan p;
+  p.tiles_i = (I + BT - 1) / BT;
+  p.tiles_j = (J + BT - 1) / BT;
+  p.S = (int)(KK / BK);
+  p.total = p.tiles_i * p.tiles_j * p.S;
+  int64_t upb = (p.total + sk_slots() - 1) / sk_slots();
+  const int64_t floor_ = p.S < 8 ? p.S : 8;
+  if (upb < floor_) upb = floor_;
+  p.upb = (int)upb;
+  p.blocks = (int)((p.total + upb - 1) / upb);
+  return p;
+}
+inline bool sk_usable(int64_t KK) { return gemm_version() == 6 && KK % BK == 0 && KK >= BK; }
 
 // split count: aim for >= ~4 blocks per CU, every split at least 4 slices deep
 inline int choose_splits(int64_t tiles, int64_t KK) {
@@ -540,6 +812,7 @@ inline int64_t chunk_for(int64_t KK, int splits) {
 
 extern "C" size_t mmssl_linear_workspace_bytes(int64_t M, int K, int N) {
   if (M <= 0 || K <= 0 || N <= 0) return 16;
+  if (sk_usable(K)) return (size_t)sk_plan(M, N, K).blocks * 2 * kSkTileFloats * sizeof(float) + 16;
   const int64_t tiles = ((M + BT - 1) / BT) * ((N + BT - 1) / BT);
   const int splits = choose_splits(tiles, K);
   return splits > 1 ? (size_t)splits * (size_t)M * (size_t)N * sizeof(float) : 16;
@@ -549,10 +822,25 @@ extern "C" int mmssl_linear_f32(const float* F, const float* W, const float* b, 
                                 int64_t M, int K, int N, float* Y, void* workspace, size_t workspace_bytes,
                                 void* stream) {
   if (M < 0 || K <= 0 || N <= 0 || (M > 0 && (!F || !W || !Y))) return MMSSL_E_BADARG;
-  if ((K & 3) || (N & 3) || N > 256) return MMSSL_E_UNSUPP;
+  if ((K & 3) || (N & 3)) return MMSSL_E_UNSUPP;
+  if (N > 256 && (b || keep || !sk_usable(K))) return MMSSL_E_UNSUPP;   // wide outputs: plain product only (wgrad)
   if (M == 0) return 0;
   if (((uintptr_t)F | (uintptr_t)W | (uintptr_t)Y) & 15) return MMSSL_E_BADARG;
   hipStream_t s = as_stream(stream);
+  if (sk_usable(K)) {
+    const SkPlan p = sk_plan(M, N, K);
+    if (!workspace || workspace_bytes < (size_t)p.blocks * 2 * kSkTileFloats * sizeof(float)) return MMSSL_E_WORKSPACE;
+    float* part = reinterpret_cast<float*>(workspace);
+    hipLaunchKernelGGL(gemm_sk_kernel, dim3((unsigned)p.blocks), dim3(kBlock), 0, s, F, (int64_t)K, W, (int64_t)K, M,
+                       (int64_t)N, (int)p.tiles_j, p.S, p.total, p.upb, Y, (int64_t)N, b, keep, scale, part);
+    MMSSL_LAUNCH_CHECK();
+    if (p.upb % p.S != 0) {        // some range ends inside a tile: partial slots exist
+      hipLaunchKernelGGL(sk_reduce_kernel, dim3((unsigned)(p.tiles_i * p.tiles_j)), dim3(kBlock), 0, s, part,
+                         (int)p.tiles_j, p.S, p.total, p.upb, M, (int64_t)N, Y, (int64_t)N, b, keep, scale);
+      MMSSL_LAUNCH_CHECK();
+    }
+    return 0;
+  }
   const int64_t tm = (M + BT - 1) / BT, tn = (N + BT - 1) / BT;
   const int splits = choose_splits(tm * tn, K);
   const int64_t chunk = chunk_for(K, splits);
@@ -664,6 +952,30 @@ extern "C" int mmssl_linear_split_f32(const uint16_t* A_hi, const uint16_t* A_lo
     nb = nb > 4096 ? 4096 : (nb < 1 ? 1 : nb);
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)nb), dim3(kBlock), 0, s, out, splits, total, (int64_t)N, b,
                        keep, scale, Y);
+    MMSSL_LAUNCH_CHECK();
+  }
+  return 0;
+}
+
+extern "C" size_t mmssl_transpose_mask_workspace_bytes(int64_t Mp, int N) {
+  if (Mp <= 0 || N <= 0) return 16;
+  return (size_t)((Mp + 63) / 64) * (size_t)N * sizeof(float) + 16;
+}
+
+extern "C" int mmssl_transpose_mask_f32(const float* G, const uint8_t* keep, float scale, int64_t M, int N, int64_t Mp,
+                                        float* T, float* colsum, void* workspace, size_t workspace_bytes,
+                                        void* stream) {
+  if (M <= 0 || N <= 0 || !G || !T || Mp < M || (Mp & 3)) return MMSSL_E_BADARG;
+  if ((N & 3) || N > 256) return MMSSL_E_UNSUPP;
+  if (!workspace || workspace_bytes < mmssl_transpose_mask_workspace_bytes(Mp, N)) return MMSSL_E_WORKSPACE;
+  hipStream_t s = as_stream(stream);
+  float* colpart = reinterpret_cast<float*>(workspace);
+  const unsigned nbm = (unsigned)((Mp + 63) / 64);
+  hipLaunchKernelGGL(transpose_mask_kernel, dim3(nbm, (unsigned)((N + 63) / 64)), dim3(kBlock), 0, s, G, keep, scale, M,
+                     N, Mp, T, colpart);
+  MMSSL_LAUNCH_CHECK();
+  if (colsum) {
+    hipLaunchKernelGGL(colsum_stage2, dim3(1), dim3(kBlock), 0, s, colpart, (int)nbm, N, colsum);
     MMSSL_LAUNCH_CHECK();
   }
   return 0;

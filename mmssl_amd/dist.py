@@ -121,7 +121,21 @@ def shard_graph(mat, row_shard, col_shard):
 # ---------------------------------------------------------------------------------------------
 # collectives with autograd
 # ---------------------------------------------------------------------------------------------
+def _solo(group):
+    """world == 1: every collective is the identity; no RCCL launch (MMSSL_DIST_FORCE_COLLECTIVES=1 keeps the
+    launches, e.g. to exercise RCCL-in-hipGraph capture on one GPU)."""
+    return dist.get_world_size(group) == 1 and os.environ.get("MMSSL_DIST_FORCE_COLLECTIVES", "0") != "1"
+
+
+def _all_reduce(t, group):
+    if not _solo(group):
+        dist.all_reduce(t, group=group)
+    return t
+
+
 def _reduce_scatter_sum(full, per, group):
+    if _solo(group):
+        return full
     if dist.get_backend(group) == "gloo":      # gloo has no reduce_scatter: all-reduce + slice
         full = full.contiguous()
         dist.all_reduce(full, group=group)
@@ -186,7 +200,7 @@ class GatherBatchRowsMulti(torch.autograd.Function):
             pieces.append(t[local] * mine.unsqueeze(1).to(t.dtype))
             meta.append((local, mine, per))
         packed = torch.cat(pieces, 0)
-        dist.all_reduce(packed, group=group)
+        _all_reduce(packed, group)
         _log_comm("all_reduce", packed)
         ctx.meta = meta
         sizes = [p.shape[0] for p in pieces]
@@ -238,6 +252,9 @@ class ShardedMMSSL(nn.Module):
                 km_i, km_t = keep_masks
             else:
                 km_i, km_t = bk.dropout_masks(2, self.ish.per, c.embed_size, c.drop_rate, self.E_i.device)
+        if self.training and hasattr(bk, "ops") and bk.ops.wgrad_ft_enabled() and self.image_feats.is_cuda:
+            bk.ops.register_transposed_features(self.image_feats)
+            bk.ops.register_transposed_features(self.text_feats)
         if modal_empty:
             img_uid = txt_uid = torch.zeros_like(self.E_u)
             img_iid = txt_iid = torch.zeros_like(self.E_i)
@@ -335,6 +352,9 @@ def _log_comm(kind, t):
 
 def _all_gather_raw(x, group):
     world = dist.get_world_size(group)
+    if _solo(group):
+        _log_comm("all_gather", x)
+        return x
     out = torch.empty((world * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
     dist.all_gather_into_tensor(out, x.contiguous(), group=group)
     _log_comm("all_gather", out)
@@ -598,7 +618,7 @@ class ShardedHotPathStep:
         params = [p for p in self.model.replicated_parameters() if p.grad is not None]
         if params:
             flat = torch.cat([p.grad.reshape(-1) for p in params])
-            dist.all_reduce(flat, group=self.group)
+            _all_reduce(flat, self.group)
             _log_comm("all_reduce", flat)
             k = 0
             for p in params:
@@ -606,7 +626,7 @@ class ShardedHotPathStep:
                 p.grad.copy_(flat[k:k + n].view_as(p.grad))
                 k += n
         feat = feat_local.detach().clone()
-        dist.all_reduce(feat, group=self.group)
+        _all_reduce(feat, self.group)
         _log_comm("all_reduce", feat)
         total = local_total.detach() - feat_local.detach() + feat      # replicated part + GLOBAL regulariser
         self.loss.copy_(total)
@@ -631,7 +651,10 @@ class ShardedHotPathStep:
                     self._step()
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, stream=self.stream):
+            # thread_local: the process group's watchdog thread keeps querying the events of earlier collectives
+            # while this thread captures; in the default (global) mode that query is an illegal call during capture
+            # and aborts the process ("operation not permitted when stream is capturing")
+            with torch.cuda.graph(g, stream=self.stream, capture_error_mode="thread_local"):
                 self._step()
             torch.cuda.synchronize()
             self._graph = g

@@ -292,9 +292,17 @@ class _Linear(torch.autograd.Function):
     def backward(ctx, gY):
         F_, W, keep = ctx.saved_tensors
         gY = _chk(gY, "gY")
+        gY_in = gY
         gY, gW, gb = _linear_wgrad_raw(gY, keep, ctx.scale, F_, W)
         gF = None
         if ctx.needs_input_grad[0]:
+            if gY is None:                 # the transposed-feature path does not return the masked gradient
+                gY = gY_in
+                if keep is not None:
+                    gY = torch.empty_like(gY_in)
+                    rc = _lib.lib().mmssl_mask_scale_f32(_ptr(gY_in), _ptr(keep), ctx.scale, gY_in.numel(), _ptr(gY),
+                                                         _lib.stream_ptr())
+                    _lib.check(rc, "mmssl_mask_scale_f32")
             # gF = gY @ W  ([M,N] x [N,K]); used by the small modality-fusion product (K = d).
             # The raw feature matrices are constants in the reference (Models.py:46-47).
             if F_.shape[1] > 256:
@@ -323,13 +331,56 @@ def _linear_wgrad_split(gY0, keep, scale, F_, W):
     return None, gW, gb
 
 
+# Weight gradient through the FORWARD kernel: gW [N, K] = gYm^T [N, Mp] . (F^T [K, Mp])^T. The feature matrices are
+# constants (Models.py:46-47), so F^T is built once (register_transposed_features, + M*K*4 bytes of HBM); per call one
+# kernel transposes + dropout-masks gY and sums its columns (the bias gradient). Both projection GEMMs then run on
+# the same stream-K LDS-DMA kernel (csrc/linear.hip, gemm_sk_kernel). MMSSL_WGRAD_FT=0 keeps the register-staged
+# wgrad kernel (mmssl_linear_wgrad_f32), which is also what unregistered inputs use.
+_FT = {}
+
+
+def wgrad_ft_enabled():
+    return _os.environ.get("MMSSL_WGRAD_FT", "1") != "0"
+
+
+def register_transposed_features(F_):
+    key = (F_.data_ptr(), tuple(F_.shape))
+    hit = _FT.get(key)
+    if hit is None:
+        M, K = F_.shape
+        Mp = (M + 31) // 32 * 32
+        FT = torch.zeros((K, Mp), dtype=torch.float32, device=F_.device)
+        FT[:, :M] = F_.t()
+        hit = (FT, Mp, F_)                      # keeps F_ alive: the key stays valid
+        _FT[key] = hit
+    return hit
+
+
+def _linear_wgrad_ft(gY, keep, scale, F_, W, FT, Mp):
+    M, K = F_.shape
+    N = W.shape[0]
+    dev = gY.device
+    gT = torch.empty((N, Mp), dtype=torch.float32, device=dev)
+    gb = torch.empty(N, dtype=torch.float32, device=dev)
+    nbt = _lib.lib().mmssl_transpose_mask_workspace_bytes(Mp, N)
+    wst = torch.empty(max(nbt // 4, 4), dtype=torch.float32, device=dev)
+    rc = _lib.lib().mmssl_transpose_mask_f32(_ptr(gY), _ptr(keep), float(scale), M, N, Mp, _ptr(gT), _ptr(gb),
+                                             _ptr(wst), wst.numel() * 4, _lib.stream_ptr())
+    _lib.check(rc, "mmssl_transpose_mask_f32")
+    gW = _linear_raw(gT, FT, None, None, 1.0)          # [N, Mp] x [K, Mp]^T -> [N, K]
+    return None, gW, gb
+
+
 def _linear_wgrad_raw(gY, keep, scale, F_, W):
-    """(masked gY, gW, gb) for Y = dropout(F W^T + b): dropout backward, then the wgrad GEMM."""
+    """(masked gY or None, gW, gb) for Y = dropout(F W^T + b): dropout backward, then the wgrad GEMM."""
     M, K = F_.shape
     N = W.shape[0]
     gY0 = gY
     if _use_split(F_):
         return _linear_wgrad_split(gY0, keep, scale, F_, W)
+    ft = _FT.get((F_.data_ptr(), tuple(F_.shape))) if wgrad_ft_enabled() else None
+    if ft is not None and N % 4 == 0 and N <= 256:
+        return _linear_wgrad_ft(gY0, keep, scale, F_, W, ft[0], ft[1])
     if keep is not None:        # dropout backward: one pass (the in-fetch variant of wgrad measured slower)
         gYm = torch.empty_like(gY)
         rc = _lib.lib().mmssl_mask_scale_f32(_ptr(gY), _ptr(keep), float(scale), gY.numel(), _ptr(gYm),

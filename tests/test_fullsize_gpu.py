@@ -198,7 +198,9 @@ def test_baby_full_step_captured_graph_matches_oracle():
     step.run()
     torch.cuda.synchronize()
     _check_baby(model, step, ref, grads, "captured")
-    # and a second replay from the same parameters reproduces the first bit for bit (fixed-order reductions)
+    # a second replay from the same parameters: the forward (fixed-order reductions everywhere) reproduces the loss
+    # bit for bit; gradients agree to rounding (the BPR backward scatter-adds duplicate batch items with hardware
+    # fp32 atomics, whose order is not fixed)
     first = float(step.loss)
     g1 = model.image_trans.weight.grad.clone()
     with torch.no_grad():
@@ -206,4 +208,5 @@ def test_baby_full_step_captured_graph_matches_oracle():
             p.copy_(state0[k])
     step.run()
     torch.cuda.synchronize()
-    assert float(step.loss) == first and torch.equal(g1, model.image_trans.weight.grad)
+    assert float(step.loss) == first
+    assert H.rel_err(model.image_trans.weight.grad.cpu(), g1.cpu()) < 1e-5

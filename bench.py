@@ -116,7 +116,7 @@ def spmm_roofline(plans, mats, d, iters=200, traffic=True):
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
             torch.cuda.synchronize()
-            with torch.cuda.graph(g, stream=s):
+            with torch.cuda.graph(g, stream=s, capture_error_mode="thread_local"):
                 for _ in range(10):
                     one_round()
         torch.cuda.synchronize()
@@ -160,7 +160,7 @@ def gcn_forward_record(plans, mats, d, n_layers, iters=200):
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
             torch.cuda.synchronize()
-            with torch.cuda.graph(g, stream=s):
+            with torch.cuda.graph(g, stream=s, capture_error_mode="thread_local"):
                 chain()
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

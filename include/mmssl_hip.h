@@ -242,6 +242,19 @@ int mmssl_adamw_f32(float* const* params, const float* const* grads, float* cons
  * main.py:420 in one launch (terms / w / extra are device arrays; extra may be NULL). */
 int mmssl_loss_assemble_f32(const float* terms, const float* w, int n, const float* extra, float c,
                             float* total, void* stream);
+/* The same launch also advances up to 4 float and 4 uint64 device counters by one (the AdamW step counters and
+ * the dropout launch counter of a whole captured step: see the *_ex entry points, external_tick = 1). */
+int mmssl_loss_assemble_tick_f32(const float* terms, const float* w, int n, const float* extra, float c,
+                                 float* total, float* const* f32_ticks, int n_f32,
+                                 uint64_t* const* u64_ticks, int n_u64, void* stream);
+/* external_tick = 1: the launch does NOT advance its counter; a stream-ordered launch between the dropout and the
+ * optimiser does (mmssl_loss_assemble_tick_f32). For AdamW the counter then already holds the number of THIS step
+ * when the update runs; for the dropout mask it is advanced after use, as before. */
+int mmssl_adamw_ex_f32(float* const* params, const float* const* grads, float* const* exp_avg,
+                       float* const* exp_avg_sq, const int64_t* numel, int count, float* state, float lr,
+                       float beta1, float beta2, float eps, float weight_decay, int external_tick, void* stream);
+int mmssl_dropout_mask_ex_u8(uint64_t* rng_state, float p, int64_t n, uint8_t* keep, int external_tick,
+                             void* stream);
 /* Backward of the above: gterms[k] = g[0] * w[k], gextra[0] = g[0] * c (gextra may be NULL). */
 int mmssl_loss_assemble_bwd_f32(const float* g, const float* w, int n, float c, float* gterms,
                                 float* gextra, void* stream);

@@ -77,6 +77,11 @@ SIGNATURES = {
     "mmssl_dropout_mask_u8": (c_int, [c_void_p, c_float, c_int64, c_void_p, c_void_p]),
     "mmssl_adamw_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_float, c_float,
                                 c_float, c_float, c_float, c_void_p]),
+    "mmssl_loss_assemble_tick_f32": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_float, c_void_p, c_void_p, c_int,
+                                             c_void_p, c_int, c_void_p]),
+    "mmssl_adamw_ex_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_float, c_float,
+                                   c_float, c_float, c_float, c_int, c_void_p]),
+    "mmssl_dropout_mask_ex_u8": (c_int, [c_void_p, c_float, c_int64, c_void_p, c_int, c_void_p]),
     "mmssl_loss_assemble_bwd_f32": (c_int, [c_void_p, c_void_p, c_int, c_float, c_void_p, c_void_p, c_void_p]),
     "mmssl_loss_assemble_f32": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_float, c_void_p, c_void_p]),
     "mmssl_infonce_workspace_bytes": (c_size_t, [c_int64, c_int]),

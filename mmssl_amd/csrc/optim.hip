@@ -30,8 +30,10 @@ constexpr int kAdamPerBlock = kBlock * kAdamPerThread * 4;   // 4096 elements pe
 __global__ void tick_f32_kernel(float* __restrict__ counter) { counter[0] += 1.0f; }
 __global__ void tick_u64_kernel(uint64_t* __restrict__ counter) { counter[0] += 1; }
 
+// `pre_ticked`: state[0] already is the number of THIS step (a stream-ordered launch before this one advanced it:
+// mmssl_step_tick / mmssl_loss_assemble_tick_f32); otherwise state[0] counts completed steps.
 __global__ __launch_bounds__(kBlock) void adamw_kernel(AdamTensors T, const float* __restrict__ state, float lr,
-                                                       float beta1, float beta2, float eps, float wd) {
+                                                       float beta1, float beta2, float eps, float wd, int pre_ticked) {
   int t = 0;
   while (t + 1 < T.count && (int)blockIdx.x >= T.first_block[t + 1]) ++t;
   const int64_t base = (int64_t)(blockIdx.x - T.first_block[t]) * kAdamPerBlock;
@@ -44,7 +46,7 @@ __global__ __launch_bounds__(kBlock) void adamw_kernel(AdamTensors T, const floa
   // same operation order as torch's _single_tensor_adamw / fused kernel in fp32
   __shared__ float sh[2];
   if (threadIdx.x == 0) {
-    const float step = state[0] + 1.0f;
+    const float step = pre_ticked ? state[0] : state[0] + 1.0f;
     sh[0] = lr / (1.0f - powf(beta1, step));
     sh[1] = sqrtf(1.0f - powf(beta2, step));
   }
@@ -133,9 +135,10 @@ __global__ __launch_bounds__(kBlock) void dropout_mask_kernel(const uint64_t* __
 
 using namespace mmssl;
 
-extern "C" int mmssl_adamw_f32(float* const* params, const float* const* grads, float* const* exp_avg,
-                               float* const* exp_avg_sq, const int64_t* numel, int count, float* state, float lr,
-                               float beta1, float beta2, float eps, float weight_decay, void* stream) {
+extern "C" int mmssl_adamw_ex_f32(float* const* params, const float* const* grads, float* const* exp_avg,
+                                  float* const* exp_avg_sq, const int64_t* numel, int count, float* state, float lr,
+                                  float beta1, float beta2, float eps, float weight_decay, int external_tick,
+                                  void* stream) {
   if (count < 0 || count > MMSSL_ADAMW_MAX_TENSORS || !state) return MMSSL_E_BADARG;
   if (count == 0) return 0;
   if (!params || !grads || !exp_avg || !exp_avg_sq || !numel) return MMSSL_E_BADARG;
@@ -159,14 +162,24 @@ extern "C" int mmssl_adamw_f32(float* const* params, const float* const* grads, 
   T.first_block[count] = blocks;
   T.count = count;
   hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, T,
-                     (const float*)state, lr, beta1, beta2, eps, weight_decay);
+                     (const float*)state, lr, beta1, beta2, eps, weight_decay, external_tick ? 1 : 0);
   MMSSL_LAUNCH_CHECK();
-  hipLaunchKernelGGL(tick_f32_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, state);
-  MMSSL_LAUNCH_CHECK();
+  if (!external_tick) {
+    hipLaunchKernelGGL(tick_f32_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, state);
+    MMSSL_LAUNCH_CHECK();
+  }
   return 0;
 }
 
-extern "C" int mmssl_dropout_mask_u8(uint64_t* rng_state, float p, int64_t n, uint8_t* keep, void* stream) {
+extern "C" int mmssl_adamw_f32(float* const* params, const float* const* grads, float* const* exp_avg,
+                               float* const* exp_avg_sq, const int64_t* numel, int count, float* state, float lr,
+                               float beta1, float beta2, float eps, float weight_decay, void* stream) {
+  return mmssl_adamw_ex_f32(params, grads, exp_avg, exp_avg_sq, numel, count, state, lr, beta1, beta2, eps,
+                            weight_decay, 0, stream);
+}
+
+extern "C" int mmssl_dropout_mask_ex_u8(uint64_t* rng_state, float p, int64_t n, uint8_t* keep, int external_tick,
+                                        void* stream) {
   if (!rng_state || !keep || n < 0 || (n & 3) || !(p >= 0.f && p < 1.f)) return MMSSL_E_BADARG;
   if ((reinterpret_cast<uintptr_t>(keep) & 3) || (reinterpret_cast<uintptr_t>(rng_state) & 7)) return MMSSL_E_BADARG;
   if (n == 0) return 0;
@@ -175,7 +188,13 @@ extern "C" int mmssl_dropout_mask_u8(uint64_t* rng_state, float p, int64_t n, ui
   hipLaunchKernelGGL(dropout_mask_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream,
                      (const uint64_t*)rng_state, p, n4, keep);
   MMSSL_LAUNCH_CHECK();
-  hipLaunchKernelGGL(tick_u64_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, rng_state + 1);
-  MMSSL_LAUNCH_CHECK();
+  if (!external_tick) {
+    hipLaunchKernelGGL(tick_u64_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, rng_state + 1);
+    MMSSL_LAUNCH_CHECK();
+  }
   return 0;
+}
+
+extern "C" int mmssl_dropout_mask_u8(uint64_t* rng_state, float p, int64_t n, uint8_t* keep, void* stream) {
+  return mmssl_dropout_mask_ex_u8(rng_state, p, n, keep, 0, stream);
 }

@@ -324,6 +324,47 @@ __global__ void loss_assemble_kernel(const float* __restrict__ terms, const floa
 }  // namespace
 
 namespace {
+// loss assembly + the step's counter ticks in ONE launch: this kernel sits between the forward (whose dropout
+// launch read the RNG launch counter) and the optimiser (whose bias correction reads the step counters), so it can
+// advance all of them without a launch of their own (3 one-thread kernels per step otherwise).
+struct TickPtrs {
+  float* f32[4];
+  unsigned long long* u64[4];
+  int n_f32, n_u64;
+};
+__global__ void loss_assemble_tick_kernel(const float* __restrict__ terms, const float* __restrict__ w, int n,
+                                          const float* __restrict__ extra, float c, float* __restrict__ total,
+                                          TickPtrs T) {
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+    for (int k = 0; k < n; ++k) t += w[k] * terms[k];
+    if (extra) t += c * extra[0];
+    total[0] = t;
+    for (int k = 0; k < T.n_f32; ++k) T.f32[k][0] += 1.0f;
+    for (int k = 0; k < T.n_u64; ++k) T.u64[k][0] += 1ull;
+  }
+}
+}  // namespace
+
+extern "C" int mmssl_loss_assemble_tick_f32(const float* terms, const float* w, int n, const float* extra, float c,
+                                            float* total, float* const* f32_ticks, int n_f32,
+                                            uint64_t* const* u64_ticks, int n_u64, void* stream) {
+  if (!terms || !w || !total || n < 0 || n > 16 || n_f32 < 0 || n_f32 > 4 || n_u64 < 0 || n_u64 > 4) return MMSSL_E_BADARG;
+  if ((n_f32 > 0 && !f32_ticks) || (n_u64 > 0 && !u64_ticks)) return MMSSL_E_BADARG;
+  TickPtrs T;
+  T.n_f32 = n_f32;
+  T.n_u64 = n_u64;
+  for (int k = 0; k < 4; ++k) {
+    T.f32[k] = k < n_f32 ? f32_ticks[k] : nullptr;
+    T.u64[k] = k < n_u64 ? reinterpret_cast<unsigned long long*>(u64_ticks[k]) : nullptr;
+    if ((k < n_f32 && !T.f32[k]) || (k < n_u64 && !T.u64[k])) return MMSSL_E_BADARG;
+  }
+  hipLaunchKernelGGL(loss_assemble_tick_kernel, dim3(1), dim3(64), 0, as_stream(stream), terms, w, n, extra, c, total, T);
+  MMSSL_LAUNCH_CHECK();
+  return 0;
+}
+
+namespace {
 __global__ void loss_assemble_bwd_kernel(const float* __restrict__ g, const float* __restrict__ w, int n, float c,
                                          float* __restrict__ gterms, float* __restrict__ gextra) {
   const float gv = g[0];

@@ -69,7 +69,8 @@ class HotPathStep:
         if self._feat_c is None or self._feat_c_val != c:
             self._feat_c, self._feat_c_val = torch.full((), c, dtype=torch.float32, device=self.loss.device), c
         # _step() backpropagates the persistent ones tensor: the assembly's gradients are the constants
-        total = ops.loss_assemble(terms, self.loss_w, ss, c, out=self.loss, unit_grad_c=self._feat_c)
+        total = ops.loss_assemble(terms, self.loss_w, ss, c, out=self.loss, unit_grad_c=self._feat_c,
+                                  ticks=self._ticks if ops.EXTERNAL["on"] else None)
         return total, dict(terms=terms, ss=ss)
 
     def step(self):
@@ -79,15 +80,24 @@ class HotPathStep:
 
     def _step(self):
         self.optimizer.zero_grad(set_to_none=True)
-        total, parts = self.losses()
+        # the step owns its counters: the dropout launch and both AdamW launches run without their one-thread tick
+        # kernels, the loss-assembly launch (between them in stream order) advances the RNG launch counter and
+        # both AdamW step counters
+        dev = self.loss.device
+        self._ticks = ([self.optimizer.step_counter(0, dev).data_ptr(), self.optimizer.step_counter(1, dev).data_ptr()],
+                       [ops._rng_state(dev).data_ptr() + 8])
+        prev_t = ops.external_ticks(True)
         prev = ops.defer_wgrad_join(True)
         try:
+            total, parts = self.losses()
             total.backward(gradient=self._one)       # persistent root gradient: no ones_like fill per step
+            ops.defer_wgrad_join(prev)
+            self.optimizer.step(groups=(0,))         # embedding tables, next to the wgrad GEMMs
+            ops.join_side_streams(dev)
+            self.optimizer.step(groups=(1,))
         finally:
             ops.defer_wgrad_join(prev)
-        self.optimizer.step(groups=(0,))             # embedding tables, next to the wgrad GEMMs
-        ops.join_side_streams(self.loss.device)
-        self.optimizer.step(groups=(1,))
+            ops.external_ticks(prev_t)
         return self.loss
 
     # ---- hipGraph capture ---------------------------------------------------------------------
@@ -104,7 +114,7 @@ class HotPathStep:
                     self._step()
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, stream=s):
+            with torch.cuda.graph(g, stream=s, capture_error_mode="thread_local"):
                 self._step()
             torch.cuda.synchronize()
             self._graph = g

@@ -255,6 +255,18 @@ def seed_dropout(seed, device=None):
         _RNG_STATE[key].copy_(val)
 
 
+# Step-owned counter ticks (hotpath.HotPathStep): with EXTERNAL["on"] the dropout launch and the fused AdamW do not
+# launch their own one-thread counter kernels; the step's loss-assembly launch advances all counters instead
+# (loss_assemble(..., ticks=...)). Off by default: every other caller keeps self-advancing launches.
+EXTERNAL = {"on": False}
+
+
+def external_ticks(flag):
+    prev = EXTERNAL["on"]
+    EXTERNAL["on"] = bool(flag)
+    return prev
+
+
 def dropout_masks(count, rows, cols, p, device):
     """uint8 [count, rows, cols], 1 = keep with probability 1-p; the generator state lives on the device and
     advances by itself, so a captured step draws fresh masks on every replay."""
@@ -264,8 +276,9 @@ def dropout_masks(count, rows, cols, p, device):
     n = count * rows * cols
     pad = (-n) % 4
     buf = torch.empty(n + pad, dtype=torch.uint8, device=device)
-    rc = _lib.lib().mmssl_dropout_mask_u8(_ptr(_rng_state(device)), float(p), n + pad, _ptr(buf), _lib.stream_ptr())
-    _lib.check(rc, "mmssl_dropout_mask_u8")
+    rc = _lib.lib().mmssl_dropout_mask_ex_u8(_ptr(_rng_state(device)), float(p), n + pad, _ptr(buf),
+                                             1 if EXTERNAL["on"] else 0, _lib.stream_ptr())
+    _lib.check(rc, "mmssl_dropout_mask_ex_u8")
     return buf[:n].view(count, rows, cols)
 
 
@@ -700,7 +713,7 @@ class _LossAssemble(torch.autograd.Function):
     gradients are then the constants w and c themselves and the backward launches nothing."""
 
     @staticmethod
-    def forward(ctx, terms, w, extra, c, out, unit_grad):
+    def forward(ctx, terms, w, extra, c, out, unit_grad, ticks=None):
         if out is not None:
             # a fresh tensor object over `out`'s memory: the result carries the autograd history, the
             # caller's buffer stays a plain leaf that can be passed again next step
@@ -708,9 +721,17 @@ class _LossAssemble(torch.autograd.Function):
                 out.untyped_storage(), out.storage_offset(), torch.Size(()), ())
         else:
             total = torch.empty((), dtype=torch.float32, device=terms.device)
-        rc = _lib.lib().mmssl_loss_assemble_f32(_ptr(terms), _ptr(w), terms.numel(), _ptr(extra), float(c),
-                                                _ptr(total), _lib.stream_ptr())
-        _lib.check(rc, "mmssl_loss_assemble_f32")
+        if ticks:
+            f32s, u64s = ticks
+            fa = (_ct.c_void_p * max(len(f32s), 1))(*[int(x) for x in f32s])
+            ua = (_ct.c_void_p * max(len(u64s), 1))(*[int(x) for x in u64s])
+            rc = _lib.lib().mmssl_loss_assemble_tick_f32(_ptr(terms), _ptr(w), terms.numel(), _ptr(extra), float(c),
+                                                         _ptr(total), fa, len(f32s), ua, len(u64s), _lib.stream_ptr())
+            _lib.check(rc, "mmssl_loss_assemble_tick_f32")
+        else:
+            rc = _lib.lib().mmssl_loss_assemble_f32(_ptr(terms), _ptr(w), terms.numel(), _ptr(extra), float(c),
+                                                    _ptr(total), _lib.stream_ptr())
+            _lib.check(rc, "mmssl_loss_assemble_f32")
         ctx.save_for_backward(w)
         ctx.c = float(c)
         ctx.has_extra = extra is not None
@@ -721,22 +742,23 @@ class _LossAssemble(torch.autograd.Function):
     def backward(ctx, g):
         (w,) = ctx.saved_tensors
         if ctx.unit is not None:             # promised d(total) == 1: gradients are the constants themselves
-            return w, None, (ctx.unit if ctx.has_extra else None), None, None, None
+            return w, None, (ctx.unit if ctx.has_extra else None), None, None, None, None
         g = g.contiguous().to(torch.float32)
         gt = torch.empty_like(w)
         ge = torch.empty((), dtype=torch.float32, device=w.device) if ctx.has_extra else None
         rc = _lib.lib().mmssl_loss_assemble_bwd_f32(_ptr(g), _ptr(w), w.numel(), ctx.c, _ptr(gt), _ptr(ge),
                                                     _lib.stream_ptr())
         _lib.check(rc, "mmssl_loss_assemble_bwd_f32")
-        return gt, None, ge, None, None, None
+        return gt, None, ge, None, None, None, None
 
 
-def loss_assemble(terms, w, extra=None, c=0.0, out=None, unit_grad_c=None):
+def loss_assemble(terms, w, extra=None, c=0.0, out=None, unit_grad_c=None, ticks=None):
     """`unit_grad_c`: a persistent 0-dim tensor holding the value `c`; passing it is the promise that the
-    result is backpropagated with a gradient of exactly 1 (see _LossAssemble)."""
+    result is backpropagated with a gradient of exactly 1 (see _LossAssemble). `ticks` = (float counter
+    addresses, uint64 counter addresses) advanced by one in the same launch (see external_ticks)."""
     if out is not None and (out.dtype != torch.float32 or out.numel() != 1 or not out.is_cuda or out.requires_grad):
         raise _lib.MmsslError("loss_assemble: `out` must be a one-element fp32 HIP tensor that needs no gradient")
-    return _LossAssemble.apply(_chk(terms, "terms"), _chk(w, "w"), extra, c, out, unit_grad_c)
+    return _LossAssemble.apply(_chk(terms, "terms"), _chk(w, "w"), extra, c, out, unit_grad_c, ticks)
 
 
 class _ZeroGradAnchor(torch.autograd.Function):

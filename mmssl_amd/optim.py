@@ -2,7 +2,12 @@
 /root/reference/MMSSL/main.py:76-80) as ONE kernel launch over all tensors that have a gradient
 (`mmssl_adamw_f32`), with the step counter in device memory so the update can be replayed inside a
 hipGraph. Drop-in for the subset of the torch optimizer API the trainer uses (`zero_grad`, `step`,
-`param_groups`, `state_dict`/`load_state_dict` in torch's AdamW layout)."""
+`param_groups`, `state_dict`/`load_state_dict` in torch's AdamW layout).
+
+Restrictions against torch.optim.AdamW (documented, enforced where they can be): one step counter per param GROUP
+(every parameter of a group must receive a gradient from the first step on, as all hot-path parameters do);
+bias corrections are evaluated in fp32 on the device (torch's default path: host double) - the difference is
+<= 1 ulp of the step size."""
 import ctypes as _ct
 
 import torch
@@ -64,10 +69,12 @@ class FusedAdamW(torch.optim.Optimizer):
             n = len(todo)
             arr = lambda k: (_ct.c_void_p * n)(*[t[k].data_ptr() for t in todo])       # noqa: E731
             numel = (_ct.c_int64 * n)(*[t[0].numel() for t in todo])
-            rc = _lib.lib().mmssl_adamw_f32(arr(0), arr(1), arr(2), arr(3), numel, n, state.data_ptr(),
-                                            float(group["lr"]), float(b1), float(b2), float(group["eps"]),
-                                            float(group["weight_decay"]), _lib.stream_ptr())
-            _lib.check(rc, "mmssl_adamw_f32")
+            from . import ops as _ops
+            rc = _lib.lib().mmssl_adamw_ex_f32(arr(0), arr(1), arr(2), arr(3), numel, n, state.data_ptr(),
+                                               float(group["lr"]), float(b1), float(b2), float(group["eps"]),
+                                               float(group["weight_decay"]), 1 if _ops.EXTERNAL["on"] else 0,
+                                               _lib.stream_ptr())
+            _lib.check(rc, "mmssl_adamw_ex_f32")
         return loss
 
     # torch.optim.AdamW-compatible checkpoint layout: per-parameter "step" tensors
@@ -81,12 +88,22 @@ class FusedAdamW(torch.optim.Optimizer):
                                                 else torch.tensor(0.0))
         return sd
 
+    def step_counter(self, gi, device):
+        """Device float[2] {completed steps, -} of param group `gi` (created on first use)."""
+        return self._group_state(gi, device)
+
     def load_state_dict(self, state_dict):
+        """ONE step counter per param group (torch.optim.AdamW keeps one per parameter): a checkpoint whose
+        parameters of one group disagree on `step` cannot be represented and is rejected."""
         steps = {}
         for gi, group in enumerate(state_dict["param_groups"]):
             for pid in group["params"]:
                 st = state_dict["state"].get(pid)
                 if st is not None and "step" in st:
+                    if gi in steps and steps[gi] != float(st["step"]):
+                        raise _lib.MmsslError("FusedAdamW: parameters of group %d have different step counts "
+                                              "(%g vs %g); this optimiser keeps one counter per group" % (
+                                                  gi, steps[gi], float(st["step"])))
                     steps[gi] = float(st["step"])
         super().load_state_dict(state_dict)
         for p_state in self.state.values():

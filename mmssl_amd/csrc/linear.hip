@@ -518,6 +518,293 @@ __global__ __launch_bounds__(kBlock) void transpose_mask_kernel(const float* __r
 }
 
 // ======================================================================================
+// v7 "ping-pong" kernel: the stream-K decomposition of v6 on a 128x64 tile with EIGHT waves per block that
+// alternate roles. v5/v6 counters (profiles/r02_gemm_pmc_*.txt): MFMA pipe 59 % busy, waves 66 % of their time
+// inside a dependent MFMA chain — with two unsynchronised waves per SIMD the chains of both collide on the one
+// matrix pipe while at other times both are in their DMA / LDS / barrier part and the pipe idles. Here the two
+// waves of a SIMD belong to ONE block and are anti-synchronised by its barrier: during phase p group p%2 runs the
+// 32 MFMAs of slice p from registers while the other group issues the LDS-DMA of slice p+4, reads the fragments of
+// slice p+1 into registers and waits for slice p+2 to land; then the roles swap. A wave covers 32 rows x 64
+// columns with two independent accumulators (the A fragment is used twice: 12 instead of 16 ds_read_b128 per
+// 32 MFMAs, and W is fetched once per 128 rows of F instead of once per 64). The two groups' accumulators (even /
+// odd slices) are added through LDS at the end of a range. 6-stage ring of 24 KB (16 KB A + 8 KB B) = 144 KB,
+// one block per CU, ranges of equal length (stream-K) over 256 blocks.
+// ======================================================================================
+constexpr int PT_I = 128;                    // tile rows
+constexpr int kPpThreads = 512;
+constexpr int kPpTileFloats = PT_I * BT;     // one partial slot (32 KB)
+
+template <int N>
+__device__ __forceinline__ void vm_wait_groups(int cnt) {     // s_waitcnt vmcnt(N * cnt), cnt in 0..4
+  switch (cnt) {
+    case 0: vm_wait_n<0>(); break;
+    case 1: vm_wait_n<N>(); break;
+    case 2: vm_wait_n<2 * N>(); break;
+    case 3: vm_wait_n<3 * N>(); break;
+    default: vm_wait_n<4 * N>(); break;
+  }
+}
+
+// PBK = slice depth (16 or 32 floats), NS = ring stages, D = issue distance (even, D + 2 <= NS): slice p + D is
+// issued in phase p and must have landed by the end of phase p + D - 2. The decomposition runs
+// (profiles/r02_gemm_modes.txt) showed the first version (PBK 32, 6 x 24 KB, D = 4: two phases = 1.8 us of lead)
+// LATENCY-bound - the DMA-only run needs 54 us at ~3 us of loaded HBM latency - so the default is PBK 16 with
+// 12 x 12 KB stages and D = 10: the same LDS, eight phases (~3.8 us) of lead.
+template <int PBK, int NS, int D>
+__global__ __launch_bounds__(kPpThreads) void gemm_pp_kernel(const float* __restrict__ A, int64_t lda,
+                                                             const float* __restrict__ B, int64_t ldb, int64_t I,
+                                                             int64_t J, int tiles_j, int S, int64_t total_units,
+                                                             int upb, float* __restrict__ C, int64_t ldc,
+                                                             int transpose_out, const float* __restrict__ bias,
+                                                             const uint8_t* __restrict__ keep, float scale,
+                                                             float* __restrict__ partials, int dbg) {
+  // dbg (tools/gemm_mode_probe.py only; 0 in production): bit 0 = no LDS-DMA, bit 1 = no MFMA, bit 2 = no fragment reads
+  constexpr int CPR = PBK / 4;                       // 16-B chunks per row
+  constexpr int RPP = 256 / PBK;                     // rows per 1-KB DMA piece
+  constexpr int PA = PT_I / RPP / 4, PB = BT / RPP / 4;       // pieces per wave of the loading group
+  constexpr int OPS = PA + PB;                       // DMA instructions per wave per slice
+  constexpr int NQ = PBK / 8;                        // float4 fragments per operand per slice
+  constexpr int STAGE = (PT_I + BT) * PBK;           // floats
+  static_assert(D % 2 == 0 && D + 2 <= NS && (D - 2) / 2 <= 4, "ring geometry");
+  extern __shared__ __attribute__((aligned(16))) float ring[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = wave >> 2, w = wave & 3;                 // role group, wave within the group
+  const int h = lane >> 5, lr = lane & 31;
+  auto swz = [](int r) { return PBK == 32 ? ((r >> 1) & 7) : ((r >> 2) & 3); };
+  const int sw = swz(lr);                                // rows w*32 + lr and lr (+32) share lr's swizzle
+  const int ia = (w * 32 + lr) * PBK;
+  const int jb0 = PT_I * PBK + lr * PBK, jb1 = jb0 + 32 * PBK;
+  const unsigned ring_lds = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)ring);
+  const int64_t u_begin = (int64_t)blockIdx.x * upb;
+  const int64_t u_end = min(total_units, u_begin + upb);
+  int64_t u = u_begin;
+  while (u < u_end) {
+    const int64_t tile = u / S;
+    const int s0 = (int)(u - tile * S);
+    const int s1 = (int)min((int64_t)S, s0 + (u_end - u));
+    const int nk = s1 - s0;
+    const int64_t i0 = (tile / tiles_j) * PT_I, j0 = (tile % tiles_j) * BT;
+    // DMA pieces of one stage, issued by the 4 waves of the loading group: A rows [32w, 32w+32), B rows [16w, 16w+16)
+    const float* pa[PA];
+    const float* pb[PB];
+#pragma unroll
+    for (int j = 0; j < PA; ++j) {
+      const int r = 32 * w + RPP * j + lane / CPR;
+      const int c = (lane % CPR) ^ swz(r);
+      pa[j] = A + min(i0 + r, I - 1) * lda + (int64_t)s0 * PBK + 4 * c;
+    }
+#pragma unroll
+    for (int j = 0; j < PB; ++j) {
+      const int r = 16 * w + RPP * j + lane / CPR;
+      const int c = (lane % CPR) ^ swz(r);
+      pb[j] = B + min(j0 + r, J - 1) * ldb + (int64_t)s0 * PBK + 4 * c;
+    }
+    const unsigned dst_a = __builtin_amdgcn_readfirstlane((unsigned)(32 * w * PBK * 4));
+    const unsigned dst_b = __builtin_amdgcn_readfirstlane((unsigned)((PT_I * PBK + 16 * w * PBK) * 4));
+    auto issue = [&](int kt) {
+      if (dbg & 1) return;
+      const unsigned st = ring_lds + (unsigned)(kt % NS) * (STAGE * 4);
+#pragma unroll
+      for (int j = 0; j < PA; ++j) glds16(pa[j] + (int64_t)kt * PBK, st + dst_a + j * 1024);
+#pragma unroll
+      for (int j = 0; j < PB; ++j) glds16(pb[j] + (int64_t)kt * PBK, st + dst_b + j * 1024);
+    };
+    float4 fa[NQ], fb0[NQ], fb1[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) fa[q] = fb0[q] = fb1[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto read_frags = [&](int kt) {
+      if (dbg & 4) return;
+      const float* st = ring + (kt % NS) * STAGE;
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        const int pos = ((2 * q + h) ^ sw) * 4;
+        fa[q] = *reinterpret_cast<const float4*>(st + ia + pos);
+        fb0[q] = *reinterpret_cast<const float4*>(st + jb0 + pos);
+        fb1[q] = *reinterpret_cast<const float4*>(st + jb1 + pos);
+      }
+    };
+    floatx16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+    auto compute = [&]() {
+      if (dbg & 2) return;
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[q].x, fb0[q].x, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[q].x, fb1[q].x, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[q].y, fb0[q].y, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[q].y, fb1[q].y, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[q].z, fb0[q].z, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[q].z, fb1[q].z, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[q].w, fb0[q].w, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[q].w, fb1[q].w, acc1, 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    // loading role of phase p (p may be -1): fragments of slice p+1, slice p+2 must have landed, slice p+D is issued
+    auto load_steady = [&](int p) {            // requires p + D < nk
+      issue(p + D);
+      read_frags(p + 1);
+      vm_wait_n<OPS*(D - 2) / 2>();
+      lgkm_wait0();
+    };
+    auto load_any = [&](int p) {
+      if (p + D < nk) issue(p + D);
+      if (p + 1 < nk) read_frags(p + 1);
+      if (p + 2 < nk) {
+        int cnt = 0;                           // my groups issued after slice p+2: p+4, p+6, ..., p+D (those < nk)
+#pragma unroll
+        for (int t = 4; t <= D; t += 2) cnt += (p + t < nk) ? 1 : 0;
+        vm_wait_groups<OPS>(cnt);
+      }
+      lgkm_wait0();
+    };
+    // ring hand-over from the previous range (its epilogue reads the ring, its stores use vmcnt)
+    vm_wait_n<0>();
+    lgkm_wait0();
+    bare_barrier();
+    {                                           // slices 0 .. D-2 in flight: even ones from group 1, odd from group 0
+      int mine = 0;
+#pragma unroll
+      for (int t = 0; t <= D - 2; ++t)
+        if ((t & 1) != g && t < nk) { issue(t); ++mine; }
+      if (g == 1) vm_wait_groups<OPS>(mine > 0 ? mine - 1 : 0);      // slice 0 has landed (mine)
+    }
+    bare_barrier();
+    if (g == 0) {
+      load_any(-1);
+      bare_barrier();
+      int p = 0;
+      for (; p + D + 2 < nk; p += 2) {
+        compute();                              // slice p
+        bare_barrier();
+        load_steady(p + 1);
+        bare_barrier();
+      }
+      for (; p < nk; p += 2) {
+        compute();
+        bare_barrier();
+        if (p + 1 < nk) {
+          load_any(p + 1);
+          bare_barrier();
+        }
+      }
+    } else {
+      bare_barrier();                           // phase -1: nothing to do
+      int p = 0;
+      for (; p + D + 2 < nk; p += 2) {
+        load_steady(p);
+        bare_barrier();
+        compute();                              // slice p + 1
+        bare_barrier();
+      }
+      for (; p < nk; p += 2) {
+        load_any(p);
+        bare_barrier();
+        if (p + 1 < nk) {
+          compute();
+          bare_barrier();
+        }
+      }
+    }
+    // add the two groups' accumulators (even + odd slices) through LDS; group 0 owns the result
+    vm_wait_n<0>();
+    float4* X = reinterpret_cast<float4*>(ring);
+    const int t = tid & 255;
+    if (g == 1) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        X[q * 256 + t] = make_float4(acc0[4 * q], acc0[4 * q + 1], acc0[4 * q + 2], acc0[4 * q + 3]);
+        X[(4 + q) * 256 + t] = make_float4(acc1[4 * q], acc1[4 * q + 1], acc1[4 * q + 2], acc1[4 * q + 3]);
+      }
+    }
+    __syncthreads();
+    if (g == 0) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 x0 = X[q * 256 + t], x1 = X[(4 + q) * 256 + t];
+        acc0[4 * q] += x0.x; acc0[4 * q + 1] += x0.y; acc0[4 * q + 2] += x0.z; acc0[4 * q + 3] += x0.w;
+        acc1[4 * q] += x1.x; acc1[4 * q + 1] += x1.y; acc1[4 * q + 2] += x1.z; acc1[4 * q + 3] += x1.w;
+      }
+      if (s0 == 0 && s1 == S) {                 // whole tile: finished result
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+          const int64_t col = j0 + 32 * a + lr;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int64_t row = i0 + w * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (row < I && col < J) {
+              float v = a ? acc1[r] : acc0[r];
+              if (bias) v += bias[col];
+              if (keep) v = keep[row * J + col] ? v * scale : 0.f;
+              if (transpose_out) C[col * ldc + row] = v;
+              else C[row * ldc + col] = v;
+            }
+          }
+        }
+      } else {
+        const int seg = (u == u_begin) ? 0 : 1;
+        float4* P = reinterpret_cast<float4*>(partials + ((size_t)blockIdx.x * 2 + seg) * kPpTileFloats);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          P[q * 256 + t] = make_float4(acc0[4 * q], acc0[4 * q + 1], acc0[4 * q + 2], acc0[4 * q + 3]);
+          P[(4 + q) * 256 + t] = make_float4(acc1[4 * q], acc1[4 * q + 1], acc1[4 * q + 2], acc1[4 * q + 3]);
+        }
+      }
+    }
+    u += nk;
+  }
+}
+
+// one block (256 threads) per 128x64 output tile: adds the tile's partial slots in block order
+__global__ __launch_bounds__(kBlock) void pp_reduce_kernel(const float* __restrict__ partials, int tiles_j, int S,
+                                                           int64_t total_units, int upb, int64_t I, int64_t J,
+                                                           float* __restrict__ C, int64_t ldc, int transpose_out,
+                                                           const float* __restrict__ bias,
+                                                           const uint8_t* __restrict__ keep, float scale) {
+  const int64_t tile = blockIdx.x;
+  const int64_t u_lo = tile * S, u_hi = u_lo + S;
+  const int64_t b_first = u_lo / upb, b_last = (u_hi - 1) / upb;
+  if (b_first == b_last) return;
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const int h = lane >> 5, lr = lane & 31;
+  float4 v[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) v[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int64_t b = b_first; b <= b_last; ++b) {
+    const int seg = (b * upb < u_lo) ? 1 : 0;
+    const float4* P = reinterpret_cast<const float4*>(partials + ((size_t)b * 2 + seg) * kPpTileFloats);
+    float4 p[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) p[q] = P[q * 256 + t];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      v[q].x += p[q].x; v[q].y += p[q].y; v[q].z += p[q].z; v[q].w += p[q].w;
+    }
+  }
+  const int64_t i0 = (tile / tiles_j) * PT_I, j0 = (tile % tiles_j) * BT;
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const int a = q >> 2;
+    const int64_t col = j0 + 32 * a + lr;
+    const float e[4] = {v[q].x, v[q].y, v[q].z, v[q].w};
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int r = 4 * (q & 3) + c;
+      const int64_t row = i0 + w * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      if (row < I && col < J) {
+        float x = e[c];
+        if (bias) x += bias[col];
+        if (keep) x = keep[row * J + col] ? x * scale : 0.f;
+        if (transpose_out) C[col * ldc + row] = x;
+        else C[row * ldc + col] = x;
+      }
+    }
+  }
+}
+
+// ======================================================================================
 // OPT-IN split-precision product (MMSSL_GEMM_SPLIT=1 on the Python side; NOT the default path):
 //   C[i][j] = sum_k A[i][k] * B[j][k]   with A, B given as bf16 (hi, lo) pairs, x ~= hi + lo (16 mantissa bits),
 //   accumulated in fp32 as  hi*hi + hi*lo + lo*hi  on the bf16 matrix cores (v_mfma_f32_32x32x16_bf16).
@@ -788,7 +1075,65 @@ inline SkPlan sk_plan(int64_t I, int64_t J, int64_t KK) {
   p.blocks = (int)((p.total + upb - 1) / upb);
   return p;
 }
-inline bool sk_usable(int64_t KK) { return gemm_version() == 6 && KK % BK == 0 && KK >= BK; }
+inline bool sk_usable(int64_t KK) { return gemm_version() >= 6 && KK % BK == 0 && KK >= BK; }
+
+// v7 decomposition: 128x64 tiles, one 8-wave block per CU
+inline int pp_slots() {
+  static const int v = getenv("MMSSL_GEMM_PP_BLOCKS") ? atoi(getenv("MMSSL_GEMM_PP_BLOCKS")) : 256;
+  return v > 0 ? v : 256;
+}
+inline int pp_bk() {
+  static const int v = getenv("MMSSL_GEMM_PP_BK") ? atoi(getenv("MMSSL_GEMM_PP_BK")) : 16;
+  return v == 32 ? 32 : 16;
+}
+inline SkPlan pp_plan(int64_t I, int64_t J, int64_t KK) {
+  SkPlan p;
+  p.tiles_i = (I + PT_I - 1) / PT_I;
+  p.tiles_j = (J + BT - 1) / BT;
+  p.S = (int)(KK / pp_bk());
+  p.total = p.tiles_i * p.tiles_j * p.S;
+  int64_t upb = (p.total + pp_slots() - 1) / pp_slots();
+  const int64_t floor_ = p.S < 16 ? p.S : 16;
+  if (upb < floor_) upb = floor_;
+  p.upb = (int)upb;
+  p.blocks = (int)((p.total + upb - 1) / upb);
+  return p;
+}
+inline bool pp_usable(int64_t KK) { return gemm_version() == 7 && KK % BK == 0 && KK >= BK; }
+constexpr int kPpLdsBytes = 144 * 1024;                  // 12 x 12 KB (PBK 16) or 6 x 24 KB (PBK 32)
+inline int pp_lds_ready() {       // 144 KB of dynamic LDS needs the opt-in attribute once per instantiation
+  static const int rc = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_pp_kernel<16, 12, 10>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, kPpLdsBytes) |
+                        (int)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_pp_kernel<32, 6, 4>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, kPpLdsBytes);
+  return rc;
+}
+// C[I,J] (or its transpose) = A[I,KK] . B[J,KK]^T (+ bias, dropout) on the ping-pong kernel
+inline int launch_pp(const float* A, const float* B, int64_t I, int64_t J, int64_t KK, float* C, int64_t ldc,
+                     int transpose_out, const float* b, const uint8_t* keep, float scale, float* part, hipStream_t s) {
+  if (pp_lds_ready() != 0) return MMSSL_E_UNSUPP;
+  const SkPlan p = pp_plan(I, J, KK);
+  const char* dm = getenv("MMSSL_GEMM_PP_MODE");        // debugging aid (tools/gemm_mode_probe.py)
+  const int dbg = dm ? atoi(dm) : 0;
+  if (pp_bk() == 16)
+    hipLaunchKernelGGL((gemm_pp_kernel<16, 12, 10>), dim3((unsigned)p.blocks), dim3(kPpThreads), kPpLdsBytes, s, A, KK, B,
+                       KK, I, J, (int)p.tiles_j, p.S, p.total, p.upb, C, ldc, transpose_out, b, keep, scale, part, dbg);
+  else
+    hipLaunchKernelGGL((gemm_pp_kernel<32, 6, 4>), dim3((unsigned)p.blocks), dim3(kPpThreads), kPpLdsBytes, s, A, KK, B,
+                       KK, I, J, (int)p.tiles_j, p.S, p.total, p.upb, C, ldc, transpose_out, b, keep, scale, part, dbg);
+  MMSSL_LAUNCH_CHECK();
+  if (p.upb % p.S != 0) {
+    hipLaunchKernelGGL(pp_reduce_kernel, dim3((unsigned)(p.tiles_i * p.tiles_j)), dim3(kBlock), 0, s, part,
+                       (int)p.tiles_j, p.S, p.total, p.upb, I, J, C, ldc, transpose_out, b, keep, scale);
+    MMSSL_LAUNCH_CHECK();
+  }
+  return 0;
+}
+inline size_t pp_ws_bytes(int64_t I, int64_t J, int64_t KK) {
+  return (size_t)pp_plan(I, J, KK).blocks * 2 * kPpTileFloats * sizeof(float) + 16;
+}
+// the ping-pong tile is 128 (A rows) x 64 (B rows): put the LONG operand on the A side, transposing the store
+inline bool pp_swap(int64_t M, int64_t N) { return N > M; }
 
 // split count: aim for >= ~4 blocks per CU, every split at least 4 slices deep
 inline int choose_splits(int64_t tiles, int64_t KK) {
@@ -812,6 +1157,7 @@ inline int64_t chunk_for(int64_t KK, int splits) {
 
 extern "C" size_t mmssl_linear_workspace_bytes(int64_t M, int K, int N) {
   if (M <= 0 || K <= 0 || N <= 0) return 16;
+  if (pp_usable(K)) return pp_swap(M, N) ? pp_ws_bytes(N, M, K) : pp_ws_bytes(M, N, K);
   if (sk_usable(K)) return (size_t)sk_plan(M, N, K).blocks * 2 * kSkTileFloats * sizeof(float) + 16;
   const int64_t tiles = ((M + BT - 1) / BT) * ((N + BT - 1) / BT);
   const int splits = choose_splits(tiles, K);
@@ -827,6 +1173,14 @@ extern "C" int mmssl_linear_f32(const float* F, const float* W, const float* b, 
   if (M == 0) return 0;
   if (((uintptr_t)F | (uintptr_t)W | (uintptr_t)Y) & 15) return MMSSL_E_BADARG;
   hipStream_t s = as_stream(stream);
+  if (pp_usable(K)) {
+    if (!workspace || workspace_bytes < mmssl_linear_workspace_bytes(M, K, N)) return MMSSL_E_WORKSPACE;
+    float* part = reinterpret_cast<float*>(workspace);
+    // Y[M,N] = F[M,K] . W[N,K]^T. Wide outputs (the weight gradient: M = 64, N = 4096) run as the transposed product
+    // W . F^T with a transposed store, so that the 128-row side of the tile is the long one.
+    if (pp_swap(M, N)) return launch_pp(W, F, N, M, K, Y, (int64_t)N, 1, nullptr, nullptr, 1.f, part, s);
+    return launch_pp(F, W, M, N, K, Y, (int64_t)N, 0, b, keep, scale, part, s);
+  }
   if (sk_usable(K)) {
     const SkPlan p = sk_plan(M, N, K);
     if (!workspace || workspace_bytes < (size_t)p.blocks * 2 * kSkTileFloats * sizeof(float)) return MMSSL_E_WORKSPACE;

@@ -131,3 +131,118 @@ class HotPathStep:
                 self._graph.replay()
             else:
                 self._step()
+
+
+class SplitHotPath:
+    """The hot path as TWO replayable segments for callers that do other work between the forward and the backward
+    of one step — the reference loop does: `u_sim_calculation` and the discriminator consume the forward's modal
+    outputs and their loss term sends gradients back into them (main.py:372-420).
+
+        F  model forward -> BPR + 2x InfoNCE + feature regulariser -> hot part of main.py:420        (one hipGraph)
+           ... caller: anything eager on the static outputs; writes d(extra loss)/d(modal outputs) into .extra_grads
+        B  backward of hot loss (+ the extra output gradients) -> AdamW                               (one hipGraph)
+
+    Both graphs are captured once (autograd runs at capture time only, like torch.cuda.make_graphed_callables); the
+    parameters, optimiser state, step counters and the dropout generator are snapshotted around warm-up + capture,
+    so capturing does not advance training. Valid as long as the six graph handles stay the same objects."""
+
+    def __init__(self, model, graphs, optimizer, batch_size, decay, loss_w, feat_c):
+        self.model, self.graphs, self.optimizer = model, tuple(graphs), optimizer
+        self.batch_size, self.decay, self.feat_c = int(batch_size), float(decay), float(feat_c)
+        dev = model.user_id_embedding.weight.device
+        self.device = dev
+        self.batch = torch.zeros((3, batch_size), dtype=torch.int64, device=dev)
+        self.loss_w = torch.tensor(list(loss_w), dtype=torch.float32, device=dev)
+        self.loss = torch.zeros((), device=dev)
+        self._one = torch.ones((), device=dev)
+        self._c = torch.full((), self.feat_c, dtype=torch.float32, device=dev)
+        self.stream = torch.cuda.Stream(device=dev)
+        self.outs = None            # the model's 12-tuple (static tensors of graph F)
+        self.terms = None           # [mf, emb, 0, cl_img, cl_txt]
+        self.extra_grads = None     # gradients w.r.t. outs[2..5] from the caller's loss terms
+        self._gF = self._gB = None
+
+    def _forward(self):
+        m = self.model
+        outs = m(*self.graphs)
+        u, p, n = self.batch[0], self.batch[1], self.batch[2]
+        terms = ops.batch_losses_vec(outs[0], outs[1], outs[8], outs[9], u, p, n, self.decay, self.batch_size, args.tau)
+        ss = m.feat_sumsq(outs[2], outs[3], outs[4], outs[5])
+        total = ops.loss_assemble(terms, self.loss_w, ss, self.feat_c, out=self.loss, unit_grad_c=self._c)
+        return outs, terms, total
+
+    def _backward(self, outs, total):
+        self.optimizer.zero_grad(set_to_none=True)
+        torch.autograd.backward([total] + [outs[k] for k in (2, 3, 4, 5)], [self._one] + list(self.extra_grads))
+        self.optimizer.step()
+
+    def _snapshot(self):
+        st = {"p": [p.detach().clone() for p in self.model.parameters()],
+              "rng": ops._rng_state(self.device).clone(),
+              "opt": {id(p): {k: v.clone() for k, v in s.items() if torch.is_tensor(v)}
+                      for p, s in self.optimizer.state.items()},
+              "steps": {gi: t.clone() for gi, t in self.optimizer._steps.items()}}
+        return st
+
+    def _restore(self, st):
+        with torch.no_grad():
+            for p, q in zip(self.model.parameters(), st["p"]):
+                p.copy_(q)
+            ops._rng_state(self.device).copy_(st["rng"])
+            for p, s in self.optimizer.state.items():
+                old = st["opt"].get(id(p))
+                for k, v in s.items():
+                    if torch.is_tensor(v):
+                        v.copy_(old[k]) if old is not None and k in old else v.zero_()
+            for gi, t in self.optimizer._steps.items():
+                t.copy_(st["steps"][gi]) if gi in st["steps"] else t.zero_()
+
+    def capture(self, warmup=2):
+        self.model.train()
+        s = self.stream
+        s.wait_stream(torch.cuda.current_stream(self.device))
+        snap = self._snapshot()
+        try:
+            with torch.cuda.stream(s):
+                for _ in range(warmup):
+                    outs, terms, total = self._forward()
+                    if self.extra_grads is None:
+                        self.extra_grads = [torch.zeros_like(outs[k]) for k in (2, 3, 4, 5)]
+                    self._backward(outs, total)
+            torch.cuda.synchronize()
+            gF, gB = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gF, stream=s, capture_error_mode="thread_local"):
+                outs, terms, total = self._forward()
+            with torch.cuda.graph(gB, stream=s, pool=gF.pool(), capture_error_mode="thread_local"):
+                self._backward(outs, total)
+            torch.cuda.synchronize()
+            self.outs, self.terms, self._gF, self._gB = outs, terms, gF, gB
+            ok = True
+        except Exception as e:       # pragma: no cover - depends on the runtime
+            self.capture_error, ok = repr(e), False
+            self._gF = self._gB = None
+            torch.cuda.synchronize()
+        self._restore(snap)
+        torch.cuda.current_stream(self.device).wait_stream(s)
+        return ok
+
+    def forward(self, batch3):
+        """Replay F on the packed [3, B] int64 batch; returns the model's output tuple (static tensors: valid until
+        the next replay). The caller's stream is ordered after the replay."""
+        cur = torch.cuda.current_stream(self.device)
+        self.stream.wait_stream(cur)
+        with torch.cuda.stream(self.stream):
+            self.batch.copy_(batch3, non_blocking=True)
+            self._gF.replay()
+        cur.wait_stream(self.stream)
+        return self.outs
+
+    def backward(self, extra=None):
+        """Replay B. `extra`: four tensors d(caller loss)/d(outs[2..5]) or None (zeros)."""
+        cur = torch.cuda.current_stream(self.device)
+        self.stream.wait_stream(cur)
+        with torch.cuda.stream(self.stream):
+            for dst, src in zip(self.extra_grads, extra or (None,) * 4):
+                dst.zero_() if src is None else dst.copy_(src, non_blocking=True)
+            self._gB.replay()
+        cur.wait_stream(self.stream)

@@ -625,7 +625,7 @@ class _BatchLosses(torch.autograd.Function):
         # stream, next to the BPR forward, while the (longer) InfoNCE forward runs on the current stream
         g_ua = torch.empty_like(ua) if need_grad else None
         g_ia = torch.empty_like(ia) if need_grad else None
-        overlap = overlap_enabled() if overlap is None else bool(overlap)
+        overlap = loss_overlap_enabled() if overlap is None else bool(overlap)
         main = torch.cuda.current_stream(dev)
         side = _side_streams(dev)[0] if overlap else main
         if overlap:
@@ -910,6 +910,13 @@ def overlap_enabled():
     return _os.environ.get("MMSSL_STREAMS", "1") != "0"
 
 
+def loss_overlap_enabled():
+    """BPR next to InfoNCE on a forked stream inside the loss node. Off by default since round 2: in a replayed
+    hipGraph every cross-stream edge costs ~6-10 us (profiles/r02_step_timeline.txt), more than the 6 + 5 + 6 us of
+    BPR kernels it hides. MMSSL_LOSS_OVERLAP=1 restores it."""
+    return overlap_enabled() and _os.environ.get("MMSSL_LOSS_OVERLAP", "0") == "1"
+
+
 # Deferred join of the weight-gradient chains. By default _HotForward.backward returns with every side
 # stream joined. A caller that owns the whole step (hotpath.HotPathStep) may set this flag: backward then
 # returns as soon as the embedding-table gradients are complete, the projection wgrad GEMMs still running on
@@ -996,7 +1003,9 @@ class _HotForward(torch.autograd.Function):
         nbu = _lib.lib().mmssl_layer_combine_blocks(u0.shape[0], d)
         nbi = _lib.lib().mmssl_layer_combine_blocks(i0.shape[0], d)
         part = torch.empty(nbu + nbi, dtype=torch.float32, device=dev)
-        if overlap:                       # the two combines are independent: item side next to the user side
+        # (a cross-stream edge inside a replayed hipGraph costs ~6-10 us, more than running the second 12 us combine
+        #  kernel behind the first: profiles/r02_step_timeline.txt; MMSSL_COMBINE_FORK=1 restores the forked form)
+        if overlap and _os.environ.get("MMSSL_COMBINE_FORK", "0") == "1":
             sA.wait_stream(main)
             with torch.cuda.stream(sA):
                 i_g = _combine_fwd(its, inv, img_item, txt_item, r, part[nbu:])
@@ -1026,46 +1035,32 @@ class _HotForward(torch.autograd.Function):
         main = torch.cuda.current_stream(dev)
         sA, sB, sC = _side_streams(dev) if overlap else (main, main, main)
         extra = (G_img_item, G_txt_item, G_img_user, G_txt_user)
-        # normalise-backward + regulariser gradient of the user side on sA and of the item side on sB, next to
-        # each other and next to the GCN chain (which only needs Gu / Gi); each modal chain then needs one
-        # tensor from the other stream
-        split = overlap and all(t is None for t in extra)
+        # normalise-backward + regulariser gradient of both sides on the CURRENT stream, then ONE fork into the three
+        # chains (GCN backward || image wgrad path || text wgrad path). Round 1 ran the two combine kernels side by
+        # side on sA / sB and exchanged their results through the current stream: two extra cross-stream hops of a
+        # replayed hipGraph (~6-10 us each) to save one 5 us kernel.
+        g_iu_, g_tu_, g_u0 = _combine_bwd(img_user, txt_user, Gu, r, inv, g_ss, 2.0, True)
+        g_ii_, g_ti_, _ = _combine_bwd(img_item, txt_item, Gi, r, inv, g_ss, 2.0, False)
+        # gradients that arrive on the modal outputs themselves (a caller used them elsewhere, e.g. u_sim -> D)
+        if G_img_item is not None:
+            g_ii_ = g_ii_ + G_img_item
+        if G_txt_item is not None:
+            g_ti_ = g_ti_ + G_txt_item
+        if G_img_user is not None:
+            g_iu_ = g_iu_ + G_img_user
+        if G_txt_user is not None:
+            g_tu_ = g_tu_ + G_txt_user
+        split = overlap
         if overlap:
             for st in (sA, sB, sC):
                 st.wait_stream(main)
-            # saved tensors from the main stream's pool that the side streams read, possibly AFTER this
-            # backward has returned (deferred join): the caching allocator must not hand their blocks to a
-            # main-stream allocation before the side stream is done with them
-            for t, st in ((keep_img, sA), (keep_txt, sB), (img_user, sA), (txt_user, sA), (img_item, sB),
-                          (txt_item, sB), (uG, sC), (iG, sC)):
+            # tensors from the main stream's pool that the side streams read, possibly AFTER this backward has
+            # returned (deferred join): the caching allocator must not hand their blocks to a main-stream allocation
+            # before the side stream is done with them
+            for t, st in ((keep_img, sA), (keep_txt, sB), (g_ii_, sA), (g_iu_, sA), (g_ti_, sB), (g_tu_, sB), (uG, sC),
+                          (iG, sC), (Gu, sC), (Gi, sC)):
                 if t is not None:
                     t.record_stream(st)
-        if split:
-            with torch.cuda.stream(sA):
-                g_iu_, g_tu_, g_u0 = _combine_bwd(img_user, txt_user, Gu, r, inv, g_ss, 2.0, True)
-            with torch.cuda.stream(sB):
-                g_ii_, g_ti_, _ = _combine_bwd(img_item, txt_item, Gi, r, inv, g_ss, 2.0, False)
-            # each modal chain needs one tensor of the other side: exchange through the current stream
-            # (a direct sA <-> sB event pair crashes hipGraph capture in this ROCm build)
-            main.wait_stream(sA)
-            main.wait_stream(sB)
-            sA.wait_stream(main)
-            sB.wait_stream(main)
-        else:
-            with torch.cuda.stream(sA):
-                g_iu_, g_tu_, g_u0 = _combine_bwd(img_user, txt_user, Gu, r, inv, g_ss, 2.0, True)
-                g_ii_, g_ti_, _ = _combine_bwd(img_item, txt_item, Gi, r, inv, g_ss, 2.0, False)
-                # gradients that arrive on the modal outputs themselves (only if a caller used them elsewhere)
-                if G_img_item is not None:
-                    g_ii_ = g_ii_ + G_img_item
-                if G_txt_item is not None:
-                    g_ti_ = g_ti_ + G_txt_item
-                if G_img_user is not None:
-                    g_iu_ = g_iu_ + G_img_user
-                if G_txt_user is not None:
-                    g_tu_ = g_tu_ + G_txt_user
-            if overlap:
-                sB.wait_stream(sA)
         out = {}
 
         def chain_c():
@@ -1094,8 +1089,8 @@ class _HotForward(torch.autograd.Function):
             chains[c]()
         gi, gW_img, gb_img, gW_txt, gb_txt = out["gi"], out["gW_img"], out["gb_img"], out["gW_txt"], out["gb_txt"]
         if overlap:
-            # g_u0 (sA, before the exchange) and gi (sC) are what the embedding tables need; in deferred mode the
-            # wgrad chains on sA / sB are left running (see defer_wgrad_join)
+            # g_u0 (current stream) and gi (sC) are what the embedding tables need; in deferred mode the wgrad
+            # chains on sA / sB are left running (see defer_wgrad_join)
             for st in ((sC,) if (split and _DEFER["on"]) else (sA, sB, sC)):
                 main.wait_stream(st)
         return (None, gW_img, gb_img if has_bi else None, None, None, gW_txt, gb_txt if has_bt else None, None, None,

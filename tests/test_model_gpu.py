@@ -260,3 +260,38 @@ def test_eval_on_device_matches_reference_recall(tmp_path):
         res = batch_test.test_torch(ua, ia, users, is_val, data=data)
         for k in ("precision", "recall", "ndcg", "hit_ratio"):
             np.testing.assert_allclose(res[k], g["%s.%s" % (nm, k)], rtol=1e-12, atol=1e-15, err_msg=k)
+
+
+def test_trainer_captured_hot_path_matches_eager_trainer(tmp_path):
+    """Trainer.train_batch switches to the two captured segments (hotpath.SplitHotPath) once the modal graphs are
+    the cached empty plans (batch 2 on under the defaults). The whole trajectory — every batch loss and the final
+    parameters — must equal the op-by-op Trainer's from the same seed: capturing (warm-up included) must not advance
+    training, and the GAN gradient must reach the captured backward."""
+    import os
+
+    def run(flag, sub):
+        os.environ["MMSSL_TRAINER_GRAPH"] = flag
+        try:
+            tr = _trainer(tmp_path / sub, drop_rate=0.2)
+            dg = tr.data_generator
+            losses, used = [], []
+            for idx in range(7):
+                tr.model.train()
+                users, pos, neg = dg.sample()
+                out = tr.train_batch(idx, users, pos, neg)
+                losses.append([float(out[0]), float(out[1]), float(out[2]), float(out[4]), float(out[5])])
+                used.append(getattr(tr, "_split", None) not in (None, False))
+            torch.cuda.synchronize()
+            P = {k: v.detach().cpu().clone() for k, v in tr.model.named_parameters()
+                 if k.split(".")[0] in ("image_trans", "text_trans", "user_id_embedding", "item_id_embedding")}
+            return np.array(losses), used, P
+        finally:
+            os.environ.pop("MMSSL_TRAINER_GRAPH", None)
+    (tmp_path / "a").mkdir()
+    (tmp_path / "b").mkdir()
+    ref_l, ref_used, ref_P = run("0", "a")
+    got_l, got_used, got_P = run("1", "b")
+    assert not any(ref_used) and got_used[-1] and got_used.count(True) >= 4, (ref_used, got_used)
+    np.testing.assert_allclose(got_l, ref_l, rtol=2e-5, atol=1e-7)
+    for k in ref_P:
+        assert H.rel_err(got_P[k], ref_P[k]) < 2e-5, k

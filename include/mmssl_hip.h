@@ -119,6 +119,39 @@ int mmssl_graph_rows_mask_normalize_bwd_f32(const mmssl_graph* g, const int64_t*
 int mmssl_graph_rows_dense_f32(const mmssl_graph* g, const int64_t* rows, int64_t n, float value,
                                float* out, int64_t width, void* stream);
 
+/* ------------------------------------------------------------------------------------
+ * Batch similarity rows and per-row top-K (csrc/simtopk.hip)
+ *   Trainer.u_sim_calculation     main.py:283-298   (scores . (1 - R[users]), then F.normalize(dim=1))
+ *   evaluation scoring + ranking  utility/batch_test.py:21-36, 91-100, 150-152
+ * mmssl_sim_rows_f32: out[b, j] = < Q[qidx[b], :], T[j, :] > (qidx NULL: row b itself), fp32 MFMA tiles, d in
+ *   {32, 64, 128}; entries (b, c) with c in the CSR row qidx[b] of (mask_rowptr, mask_cols: int32, sorted per row;
+ *   both NULL = no mask) become mask_value (0 for u_sim, -inf for the evaluation). out has row pitch ldo >= n_items.
+ *   sumsq_part (may be NULL): [B, mmssl_sim_rows_parts(n_items)] partial sums of squares of the unmasked scores;
+ *   mmssl_rows_scale_parts_f32 turns them into the row factors 1/max(norm, eps), applies them in place and
+ *   returns them (inv_out may be NULL). mmssl_graph_sim_rows_f32: the same with a graph plan's CSR as the mask.
+ * mmssl_topk_rows_f32: idx_out[b, 0..K) = columns of the K largest entries of row b in DESCENDING value, ties by
+ *   ASCENDING column (heapq.nlargest over an ascending-id dict); K <= 64, n_cols <= 36864; rows shorter than K are
+ *   padded with -1. val_out (may be NULL) receives the values.
+ * mmssl_rows_membership_u8: out[b, k] = 1 iff cand[b, k] is a column of CSR row rows[b] (sorted columns): the
+ *   hit matrix of the evaluation without a dense [users, items] positives matrix.
+ * ---------------------------------------------------------------------------------- */
+int mmssl_sim_rows_parts(int64_t n_items);
+int mmssl_sim_rows_f32(const float* Q, const int64_t* qidx, int64_t B, const float* T, int64_t n_items, int d,
+                       const int32_t* mask_rowptr, const int32_t* mask_cols, float mask_value, float* out,
+                       int64_t ldo, float* sumsq_part, void* stream);
+int mmssl_graph_sim_rows_f32(const mmssl_graph* g, const float* Q, const int64_t* rows, int64_t n, const float* T,
+                             int d, float mask_value, float* out, int64_t ldo, float* sumsq_part, void* stream);
+int mmssl_rows_scale_parts_f32(float* X, int64_t B, int64_t n_items, int64_t ldo, const float* sumsq_part,
+                               int nparts, float eps, float* inv_out, void* stream);
+/* mmssl_graph_rows_mask_normalize_bwd_f32 with separate row pitches for S, gS and gP */
+int mmssl_graph_rows_mask_normalize_bwd_ld_f32(const mmssl_graph* g, const int64_t* rows, int64_t n, const float* S,
+                                               int64_t ld_s, const float* gS, int64_t ld_g, const float* inv_norm,
+                                               int64_t width, float eps, float* gP, int64_t ld_p, void* stream);
+int mmssl_topk_rows_f32(const float* X, int64_t B, int64_t n_cols, int64_t ldx, int K, int64_t* idx_out,
+                        float* val_out, void* stream);
+int mmssl_rows_membership_u8(const int32_t* rowptr, const int32_t* cols, const int64_t* rows, int64_t B, int K,
+                             const int64_t* cand, uint8_t* out, void* stream);
+
 /* t = A.X + alpha * Z[row]; Y = S[row]*(t - <t,S[row]>)  */
 
 /* Workspace of one launch = partial sums of the rows that span several blocks + their arrival counters.

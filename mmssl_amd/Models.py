@@ -33,7 +33,13 @@ def _plan_of(g):
 
 
 class MMSSL(nn.Module):
-    def __init__(self, n_users, n_items, embedding_dim, weight_size, dropout_list, image_feats, text_feats):
+    def __init__(self, n_users, n_items, embedding_dim, weight_size, dropout_list, image_feats, text_feats,
+                 extra_feats=None):
+        """`extra_feats` (not in the reference): ordered {name: ndarray [n_items, d_name]} of further item modalities
+        (BASELINE configs[1] names an acoustic one). Each gets `<name>_trans` / `<name>_embedding` modules created
+        AFTER all reference modules (so a seed still reproduces the reference's initial weights) and is handled by
+        `forward(..., extra_graphs=...)`. Parity of anything beyond image/text is UNPINNED: the reference loads
+        image_feat.npy and text_feat.npy only (main.py:54-55)."""
         super().__init__()
         self.n_users = n_users
         self.n_items = n_items
@@ -71,12 +77,25 @@ class MMSSL(nn.Module):
             "w_self_attention_cat": nn.Parameter(init(torch.empty([args.head_num * d, d]))),
         })
         self.embedding_dict = {"user": {}, "item": {}}
+        self.extra_names = []
+        self.extra_feats = {}
+        for name, feats in (extra_feats or {}).items():
+            if name in ("image", "text") or not name.isidentifier():
+                raise ValueError("extra modality name %r" % (name,))
+            lin = nn.Linear(feats.shape[1], d)
+            nn.init.xavier_uniform_(lin.weight)
+            setattr(self, name + "_trans", lin)
+            self.encoder[name + "_encoder"] = lin
+            setattr(self, name + "_embedding", nn.Embedding.from_pretrained(torch.Tensor(feats), freeze=False))
+            self.extra_feats[name] = torch.as_tensor(feats).float()
+            self.extra_names.append(name)
 
     # the feature matrices follow the module across devices (the reference hard-codes .cuda())
     def _apply(self, fn, *a, **k):
         super()._apply(fn, *a, **k)
         self.image_feats = fn(self.image_feats)
         self.text_feats = fn(self.text_feats)
+        self.extra_feats = {k_: fn(v) for k_, v in self.extra_feats.items()}
         return self
 
     # ---- helpers with the reference's names --------------------------------------------------
@@ -137,13 +156,72 @@ class MMSSL(nn.Module):
             self._zero_cache[key] = z
         return z
 
+    # ---- M-modality forward (extra modalities present) ------------------------------------------
+    def _forward_multi(self, ui, iu, modal_plans, keep_masks):
+        """The forward for a LIST of modalities [image, text, *extra] out of differentiable HIP ops (ops.linear,
+        ops.spmm, ops.l2norm_rows): the same computation as the fused two-modality path, one more projection /
+        feature chain / id view / `+ r * normalize(.)` term per extra modality (oracle: forward_multi)."""
+        names = ["image", "text"] + self.extra_names
+        feats = [self.image_feats, self.text_feats] + [self.extra_feats[n] for n in self.extra_names]
+        p = float(args.drop_rate)
+        scale, masks = 1.0, [None] * len(names)
+        if self.training and p > 0.0:
+            scale = 1.0 / (1.0 - p)
+            masks = keep_masks if keep_masks is not None else list(ops.dropout_masks(
+                len(names), self.n_items, args.embed_size, p, self.image_trans.weight.device))
+        E_u, E_i = self.user_id_embedding.weight, self.item_id_embedding.weight
+        user_f, item_f, user_id, item_id = [], [], [], []
+        for k, nm in enumerate(names):
+            lin = getattr(self, nm + "_trans")
+            x = ops.linear(feats[k], lin.weight, lin.bias, masks[k], scale)
+            uf = ops.spmm(ui, x)
+            user_f.append(uf)
+            item_f.append(ops.spmm(iu, uf))
+            m_ui, m_iu = modal_plans[k]
+            user_id.append(ops.spmm(m_ui, E_i))
+            item_id.append(ops.spmm(m_iu, E_u))
+        d = args.embed_size
+        fold = self.weight_dict["w_self_attention_cat"].view(args.head_num, d, d).sum(0)
+        w = ((1.0 / len(names)) * fold).t().contiguous()          # mean over the M views of V_b . fold
+        u = ops.l2norm_rows(ops.linear(sum(user_id[1:], user_id[0]), w), E_u, args.id_cat_rate)
+        i = ops.l2norm_rows(ops.linear(sum(item_id[1:], item_id[0]), w), E_i, args.id_cat_rate)
+        us, its = u, i
+        for l in range(self.n_ui_layers):
+            epi = ops.EPI_SOFTMAX if l == self.n_ui_layers - 1 else ops.EPI_NONE
+            u = ops.spmm(ui, i, epi)
+            i = ops.spmm(iu, u, epi)
+            us, its = us + u, its + i
+        inv = 1.0 / (self.n_ui_layers + 1)
+        u_g, i_g = us * inv, its * inv
+        for uf, itf in zip(user_f, item_f):
+            u_g = ops.l2norm_rows(uf, u_g, args.model_cat_rate)
+            i_g = ops.l2norm_rows(itf, i_g, args.model_cat_rate)
+        self._feat_sumsq = None
+        for k, nm in enumerate(names):
+            self.embedding_dict["user"][nm], self.embedding_dict["item"][nm] = user_id[k], item_id[k]
+        out = [u_g, i_g, item_f[0], item_f[1], user_f[0], user_f[1], u_g, i_g, user_id[0], user_id[1], item_id[0],
+               item_id[1]]
+        for k in range(2, len(names)):
+            out += [item_f[k], user_f[k], user_id[k], item_id[k]]
+        return tuple(out)
+
     # ---- forward -----------------------------------------------------------------------------
     def forward(self, ui_graph, iu_graph, image_ui_graph, image_iu_graph, text_ui_graph, text_iu_graph,
-                keep_masks=None):
+                keep_masks=None, extra_graphs=None):
         """Returns the 12-tuple of Models.py:220. `keep_masks=(img, txt)` injects uint8 dropout
         keep-masks [n_items, d] (parity runs); by default both masks are drawn by one Philox launch
-        (ops.dropout_masks; seed with ops.seed_dropout / main.set_seed) in training mode."""
+        (ops.dropout_masks; seed with ops.seed_dropout / main.set_seed) in training mode.
+        With extra modalities (ctor `extra_feats`) the tuple is followed by (item_feats, user_feats, user_id,
+        item_id) of each extra modality; `extra_graphs` = {name: (ui_graph, iu_graph)} are their modal graphs
+        (default: the interaction graphs, like the reference's initial image / text graphs, main.py:69-72)."""
         ui, iu = _plan_of(ui_graph), _plan_of(iu_graph)
+        if self.extra_names:
+            modal = [(_plan_of(image_ui_graph).twin(3), _plan_of(image_iu_graph).twin(3)),
+                     (_plan_of(text_ui_graph).twin(3), _plan_of(text_iu_graph).twin(3))]
+            for nm in self.extra_names:
+                g = (extra_graphs or {}).get(nm, (ui_graph, iu_graph))
+                modal.append((_plan_of(g[0]).twin(3), _plan_of(g[1]).twin(3)))
+            return self._forward_multi(ui, iu, modal, keep_masks)
         img_ui, img_iu = _plan_of(image_ui_graph), _plan_of(image_iu_graph)
         txt_ui, txt_iu = _plan_of(text_ui_graph), _plan_of(text_iu_graph)
         # The modal-id SpMMs (and their autograd backward) run on the caller's stream while ops.hot_forward's

@@ -39,6 +39,18 @@ SIGNATURES = {
     "mmssl_graph_rows_mask_normalize_bwd_f32": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p,
                                                         c_int64, c_float, c_void_p, c_void_p]),
     "mmssl_graph_rows_dense_f32": (c_int, [c_void_p, c_void_p, c_int64, c_float, c_void_p, c_int64, c_void_p]),
+    "mmssl_sim_rows_parts": (c_int, [c_int64]),
+    "mmssl_sim_rows_f32": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_float,
+                                   c_void_p, c_int64, c_void_p, c_void_p]),
+    "mmssl_graph_sim_rows_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int, c_float, c_void_p,
+                                         c_int64, c_void_p, c_void_p]),
+    "mmssl_rows_scale_parts_f32": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int, c_float, c_void_p,
+                                           c_void_p]),
+    "mmssl_graph_rows_mask_normalize_bwd_ld_f32": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p,
+                                                           c_int64, c_void_p, c_int64, c_float, c_void_p, c_int64,
+                                                           c_void_p]),
+    "mmssl_topk_rows_f32": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int, c_void_p, c_void_p, c_void_p]),
+    "mmssl_rows_membership_u8": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p]),
     "mmssl_spmm_workspace_bytes": (c_size_t, [c_void_p, c_int, c_int]),
     "mmssl_spmm_f32": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_size_t,
                                c_void_p]),

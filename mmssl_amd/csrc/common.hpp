@@ -77,4 +77,10 @@ inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s);
 
 inline bool supported_d(int d) { return d == 32 || d == 64 || d == 128 || d == 256; }
 
+// csrc/simtopk.hip: batch similarity rows with a CSR mask given as (rowptr, column array with `m_stride` bytes
+// between consecutive columns)
+int sim_launch(const float* Q, const int64_t* qidx, int64_t B, const float* T, int64_t I, int d, const int32_t* m_rowptr,
+               const void* m_cols, int m_stride, float mask_value, float* out, int64_t ldo, float* sumsq_part,
+               hipStream_t s);
+
 }  // namespace mmssl

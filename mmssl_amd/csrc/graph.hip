@@ -683,17 +683,17 @@ __global__ __launch_bounds__(kBlock) void rows_mask_normalize_kernel(const int32
 __global__ __launch_bounds__(kBlock) void rows_mask_normalize_bwd_kernel(const int32_t* __restrict__ rowptr,
                                                                          const Edge* __restrict__ edges,
                                                                          const int64_t* __restrict__ rows,
-                                                                         const float* __restrict__ S,
-                                                                         const float* __restrict__ gS,
+                                                                         const float* __restrict__ S, int64_t lds_,
+                                                                         const float* __restrict__ gS, int64_t ldg,
                                                                          const float* __restrict__ inv_in,
                                                                          int64_t width, float eps,
-                                                                         float* __restrict__ gP) {
+                                                                         float* __restrict__ gP, int64_t ldp) {
   __shared__ float red[4];
   const int64_t b = blockIdx.x;
   const int64_t u = rows[b];
-  const float* __restrict__ s_row = S + b * width;
-  const float* __restrict__ g_row = gS + b * width;
-  float* __restrict__ o_row = gP + b * width;
+  const float* __restrict__ s_row = S + b * lds_;
+  const float* __restrict__ g_row = gS + b * ldg;
+  float* __restrict__ o_row = gP + b * ldp;
   const float inv = inv_in[b];
   float dot = 0.f;
   for (int64_t j = threadIdx.x; j < width; j += kBlock) dot = fmaf(s_row[j], g_row[j], dot);
@@ -735,16 +735,35 @@ extern "C" int mmssl_graph_rows_mask_normalize_f32(const mmssl_graph* g, const i
   return 0;
 }
 
+extern "C" int mmssl_graph_rows_mask_normalize_bwd_ld_f32(const mmssl_graph* g, const int64_t* rows, int64_t n,
+                                                          const float* S, int64_t ld_s, const float* gS, int64_t ld_g,
+                                                          const float* inv_norm, int64_t width, float eps, float* gP,
+                                                          int64_t ld_p, void* stream) {
+  if (int rc = rows_args_ok(g, rows, n, width)) return rc;
+  if (n == 0) return 0;
+  if (!S || !gS || !inv_norm || !gP || !(eps > 0.f) || ld_s < width || ld_g < width || ld_p < width) return MMSSL_E_BADARG;
+  hipLaunchKernelGGL(rows_mask_normalize_bwd_kernel, dim3((unsigned)n), dim3(kBlock), 0, as_stream(stream),
+                     g->fwd.rowptr, g->fwd.edges, rows, S, ld_s, gS, ld_g, inv_norm, width, eps, gP, ld_p);
+  MMSSL_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int mmssl_graph_rows_mask_normalize_bwd_f32(const mmssl_graph* g, const int64_t* rows, int64_t n,
                                                        const float* S, const float* gS, const float* inv_norm,
                                                        int64_t width, float eps, float* gP, void* stream) {
-  if (int rc = rows_args_ok(g, rows, n, width)) return rc;
-  if (n == 0) return 0;
-  if (!S || !gS || !inv_norm || !gP || !(eps > 0.f)) return MMSSL_E_BADARG;
-  hipLaunchKernelGGL(rows_mask_normalize_bwd_kernel, dim3((unsigned)n), dim3(kBlock), 0, as_stream(stream),
-                     g->fwd.rowptr, g->fwd.edges, rows, S, gS, inv_norm, width, eps, gP);
-  MMSSL_LAUNCH_CHECK();
-  return 0;
+  return mmssl_graph_rows_mask_normalize_bwd_ld_f32(g, rows, n, S, width, gS, width, inv_norm, width, eps, gP, width,
+                                                    stream);
+}
+
+// S[b, :] = < Q[rows[b], :], T[j, :] > with the plan's entries of row rows[b] replaced by mask_value (csrc/simtopk.hip)
+extern "C" int mmssl_graph_sim_rows_f32(const mmssl_graph* g, const float* Q, const int64_t* rows, int64_t n,
+                                        const float* T, int d, float mask_value, float* out, int64_t ldo,
+                                        float* sumsq_part, void* stream) {
+  if (!g || n < 0 || (n > 0 && (!rows || !Q || !T || !out)) || ldo < g->fwd.cols) return MMSSL_E_BADARG;
+  if (n == 0 || g->fwd.cols == 0) return 0;
+  if (((uintptr_t)Q | (uintptr_t)T) & 15) return MMSSL_E_BADARG;
+  return sim_launch(Q, rows, n, T, g->fwd.cols, d, g->fwd.rowptr, g->fwd.edges, (int)sizeof(Edge), mask_value, out, ldo,
+                    sumsq_part, as_stream(stream));
 }
 
 extern "C" int mmssl_graph_rows_dense_f32(const mmssl_graph* g, const int64_t* rows, int64_t n, float value,

@@ -347,13 +347,16 @@ def _linear_wgrad_split(gY0, keep, scale, F_, W):
 # Weight gradient through the FORWARD kernel: gW [N, K] = gYm^T [N, Mp] . (F^T [K, Mp])^T. The feature matrices are
 # constants (Models.py:46-47), so F^T is built once (register_transposed_features, + M*K*4 bytes of HBM); per call one
 # kernel transposes + dropout-masks gY and sums its columns (the bias gradient). Both projection GEMMs then run on
-# the same stream-K LDS-DMA kernel (csrc/linear.hip, gemm_sk_kernel). MMSSL_WGRAD_FT=0 keeps the register-staged
-# wgrad kernel (mmssl_linear_wgrad_f32), which is also what unregistered inputs use.
+# the same stream-K LDS-DMA kernel (csrc/linear.hip, gemm_sk_kernel). Opt-in (see wgrad_ft_enabled); the default is
+# the register-staged wgrad kernel (mmssl_linear_wgrad_f32), which is also what unregistered inputs use.
 _FT = {}
 
 
 def wgrad_ft_enabled():
-    return _os.environ.get("MMSSL_WGRAD_FT", "1") != "0"
+    """OPT-IN (MMSSL_WGRAD_FT=1). Measured on MI355X (tools/gemm_v6_probe.py, hipGraph replay): Baby image wgrad
+    130-135 us vs 138-141 us for the register-staged kernel, Baby text 59 vs 52 us, and no difference in the whole
+    step (0.623 vs 0.620 ms) for +376 MB of HBM, so the default stays the register-staged kernel."""
+    return _os.environ.get("MMSSL_WGRAD_FT", "0") == "1"
 
 
 def register_transposed_features(F_):
@@ -539,10 +542,77 @@ def bpr(u, p, n, decay, batch_size):
 # ---------------------------------------------------------------------------------------
 # u_sim + real-data rows              Trainer.u_sim_calculation main.py:281-298, :349
 # ---------------------------------------------------------------------------------------
+def _pitch(n, mult=32):
+    return (n + mult - 1) // mult * mult
+
+
+def sim_rows(Q, T, qidx=None, mask=None, mask_value=0.0, normalize=False, eps=_NORM_EPS, pitch_mult=1):
+    """S[b, j] = <Q[qidx[b]], T[j]> for every row j of T, on the fp32 matrix cores, with the entries of a CSR mask row
+    replaced by `mask_value` and (optionally) the rows L2-normalised: the score product of
+    Trainer.u_sim_calculation (main.py:283-298) / of the evaluation (utility/batch_test.py:150-152, 91-100) as ONE tile
+    kernel + one scale pass (csrc/simtopk.hip) instead of a library GEMM followed by masking / norm passes.
+    `mask`: None, a GraphPlan (its CSR pattern, rows indexed by qidx) or a pair of int32 device tensors
+    (rowptr, sorted cols). Returns (S [B, n] view of a [B, pitch] buffer, inv_norm [B] or None)."""
+    Q, T = _chk(Q, "Q"), _chk(T, "T")
+    if Q.dim() != 2 or T.dim() != 2 or Q.shape[1] != T.shape[1]:
+        raise _lib.MmsslError("sim_rows: Q [*, d] and T [n, d] expected")
+    dev = Q.device
+    qidx = _idx(qidx, "qidx", dev)
+    B = Q.shape[0] if qidx is None else qidx.shape[0]
+    n, d = T.shape
+    ld = _pitch(n, pitch_mult)
+    out = (torch.zeros if ld != n else torch.empty)((B, ld), dtype=torch.float32, device=dev)
+    nparts = _lib.lib().mmssl_sim_rows_parts(n)
+    part = torch.empty((B, max(nparts, 1)), dtype=torch.float32, device=dev) if normalize else None
+    if mask is not None and hasattr(mask, "handle"):
+        if qidx is None:
+            raise _lib.MmsslError("sim_rows: a plan mask needs qidx (the plan rows of the batch)")
+        rc = _lib.lib().mmssl_graph_sim_rows_f32(mask.handle, _ptr(Q), _ptr(qidx), B, _ptr(T), d, float(mask_value),
+                                                 _ptr(out), ld, _ptr(part), _lib.stream_ptr())
+        _lib.check(rc, "mmssl_graph_sim_rows_f32")
+    else:
+        rp, cols = (None, None) if mask is None else mask
+        rc = _lib.lib().mmssl_sim_rows_f32(_ptr(Q), _ptr(qidx), B, _ptr(T), n, d, _ptr(rp), _ptr(cols), float(mask_value),
+                                           _ptr(out), ld, _ptr(part), _lib.stream_ptr())
+        _lib.check(rc, "mmssl_sim_rows_f32")
+    inv = None
+    if normalize:
+        inv = torch.empty(B, dtype=torch.float32, device=dev)
+        rc = _lib.lib().mmssl_rows_scale_parts_f32(_ptr(out), B, n, ld, _ptr(part), nparts, float(eps), _ptr(inv),
+                                                   _lib.stream_ptr())
+        _lib.check(rc, "mmssl_rows_scale_parts_f32")
+    return (out if ld == n else out[:, :n]), inv
+
+
+def topk_rows(X, k, values=False):
+    """Columns of the k largest entries of every row, descending value, ties by ascending column (the order
+    heapq.nlargest gives the reference's evaluation, batch_test.py:21-36). X may be a row-pitched view."""
+    if not (X.is_cuda and X.dtype == torch.float32 and X.dim() == 2 and X.stride(1) == 1):
+        raise _lib.MmsslError("topk_rows: fp32 [B, n] HIP tensor with unit column stride expected")
+    B, n = X.shape
+    idx = torch.empty((B, k), dtype=torch.int64, device=X.device)
+    val = torch.empty((B, k), dtype=torch.float32, device=X.device) if values else None
+    rc = _lib.lib().mmssl_topk_rows_f32(_ptr(X), B, n, X.stride(0), int(k), _ptr(idx), _ptr(val), _lib.stream_ptr())
+    _lib.check(rc, "mmssl_topk_rows_f32")
+    return (idx, val) if values else idx
+
+
+def rows_membership(rowptr, cols, rows, cand):
+    """uint8 [B, K]: cand[b, k] in CSR row rows[b] (int32 rowptr / sorted cols on the device)."""
+    B, K = cand.shape
+    out = torch.empty((B, K), dtype=torch.uint8, device=cand.device)
+    rc = _lib.lib().mmssl_rows_membership_u8(_ptr(rowptr), _ptr(cols), _ptr(rows), B, K, _ptr(cand.contiguous()), _ptr(out),
+                                             _lib.stream_ptr())
+    _lib.check(rc, "mmssl_rows_membership_u8")
+    return out
+
+
 class _USim(torch.autograd.Function):
-    """normalize((U[users] . I^T) * (1 - R[users]), dim=1). The [B, d] x [d, n_items] products are plain
-    library GEMMs (rocBLAS via torch.mm); masking by the users' train items — read from the plan's device
-    CSR, not from a dense uploaded R[users] — and the row normalisation are one fused in-place kernel."""
+    """normalize((U[users] . I^T) * (1 - R[users]), dim=1) (main.py:283-298). Forward: the fused tile kernel of
+    sim_rows (fp32 MFMA, gather of the batch rows, mask from the plan's device CSR, row norms from in-kernel
+    partials). Backward: one kernel for the normalise/mask backward, then both products on this library's
+    projection kernels: gU_b = gP . I (mmssl_linear_f32 against I^T) and gI = gP^T . U_b (mmssl_linear_wgrad_f32);
+    S and gP use a 32-float row pitch so that the reduction dimension meets those kernels' alignment."""
 
     @staticmethod
     def forward(ctx, user_final, item_final, users, plan):
@@ -550,33 +620,46 @@ class _USim(torch.autograd.Function):
         if plan.shape != (user_final.shape[0], item_final.shape[0]):
             raise _lib.MmsslError("usim: plan is %s, tables are [%d, d] / [%d, d]" % (
                 plan.shape, user_final.shape[0], item_final.shape[0]))
-        Ub = user_final.index_select(0, users)
-        S = torch.mm(Ub, item_final.t())
-        B, width = S.shape
-        inv = torch.empty(B, dtype=torch.float32, device=S.device)
-        rc = _lib.lib().mmssl_graph_rows_mask_normalize_f32(plan.handle, _ptr(users), B, _ptr(S), width, _NORM_EPS,
-                                                            _ptr(inv), _lib.stream_ptr())
-        _lib.check(rc, "mmssl_graph_rows_mask_normalize_f32")
-        ctx.save_for_backward(Ub, item_final, users, S, inv)
-        ctx.plan, ctx.n_users = plan, user_final.shape[0]
+        S, inv = sim_rows(user_final, item_final, qidx=users, mask=plan, mask_value=0.0, normalize=True, pitch_mult=32)
+        ctx.save_for_backward(user_final, item_final, users, S, inv)
+        ctx.plan = plan
         return S
 
     @staticmethod
     def backward(ctx, gS):
-        Ub, item_final, users, S, inv = ctx.saved_tensors
+        user_final, item_final, users, S, inv = ctx.saved_tensors
         gS = _chk(gS, "gS")
-        gP = torch.empty_like(S)
         B, width = S.shape
-        rc = _lib.lib().mmssl_graph_rows_mask_normalize_bwd_f32(ctx.plan.handle, _ptr(users), B, _ptr(S), _ptr(gS),
-                                                                _ptr(inv), width, _NORM_EPS, _ptr(gP),
-                                                                _lib.stream_ptr())
-        _lib.check(rc, "mmssl_graph_rows_mask_normalize_bwd_f32")
+        ld = S.stride(0)
+        d = item_final.shape[1]
+        dev = S.device
+        gP = torch.zeros((B, ld), dtype=torch.float32, device=dev) if ld != width else torch.empty_like(S)
+        rc = _lib.lib().mmssl_graph_rows_mask_normalize_bwd_ld_f32(ctx.plan.handle, _ptr(users), B, _ptr(S), ld, _ptr(gS),
+                                                                   gS.stride(0), _ptr(inv), width, _NORM_EPS, _ptr(gP),
+                                                                   ld, _lib.stream_ptr())
+        _lib.check(rc, "mmssl_graph_rows_mask_normalize_bwd_ld_f32")
         gU = gI = None
         if ctx.needs_input_grad[0]:
-            gU = torch.zeros((ctx.n_users, Ub.shape[1]), dtype=torch.float32, device=S.device)
-            gU.index_add_(0, users, torch.mm(gP, item_final))
+            # I^T with the padded pitch [d, ld] (zero columns past n_items), then gU_b [B, d] = gP [B, ld] . (I^T)^T
+            ItT = torch.empty((d, ld), dtype=torch.float32, device=dev)
+            nbt = _lib.lib().mmssl_transpose_mask_workspace_bytes(ld, d)
+            wst = torch.empty(max(nbt // 4, 4), dtype=torch.float32, device=dev)
+            rc = _lib.lib().mmssl_transpose_mask_f32(_ptr(item_final), None, 1.0, width, d, ld, _ptr(ItT), None, _ptr(wst),
+                                                     wst.numel() * 4, _lib.stream_ptr())
+            _lib.check(rc, "mmssl_transpose_mask_f32")
+            gUb = _linear_raw(gP, ItT, None, None, 1.0)
+            gU = torch.zeros((user_final.shape[0], d), dtype=torch.float32, device=dev)
+            gU.index_add_(0, users, gUb)
         if ctx.needs_input_grad[1]:
-            gI = torch.mm(gP.t(), Ub)
+            # gI^T [d, ld] = U_b^T [d, B] . gP [B, ld]: the weight-gradient form (reduction over the batch)
+            Ub = user_final.index_select(0, users)
+            gIt = torch.empty((d, ld), dtype=torch.float32, device=dev)
+            nb = _lib.lib().mmssl_linear_wgrad_workspace_bytes(B, ld, d)
+            ws = torch.empty(max(nb // 4, 4), dtype=torch.float32, device=dev)
+            rc = _lib.lib().mmssl_linear_wgrad_f32(_ptr(Ub), None, 1.0, _ptr(gP), B, ld, d, _ptr(gIt), None, _ptr(ws), nb,
+                                                   _lib.stream_ptr())
+            _lib.check(rc, "mmssl_linear_wgrad_f32")
+            gI = gIt[:, :width].t().contiguous()
         return gU, gI, None, None
 
 
@@ -911,10 +994,9 @@ def overlap_enabled():
 
 
 def loss_overlap_enabled():
-    """BPR next to InfoNCE on a forked stream inside the loss node. Off by default since round 2: in a replayed
-    hipGraph every cross-stream edge costs ~6-10 us (profiles/r02_step_timeline.txt), more than the 6 + 5 + 6 us of
-    BPR kernels it hides. MMSSL_LOSS_OVERLAP=1 restores it."""
-    return overlap_enabled() and _os.environ.get("MMSSL_LOSS_OVERLAP", "0") == "1"
+    """BPR next to InfoNCE on a forked stream inside the loss node (MMSSL_LOSS_OVERLAP=0: one stream). Measured on the
+    Baby step under hipGraph replay: forked 0.636 ms, one stream 0.654 ms."""
+    return overlap_enabled() and _os.environ.get("MMSSL_LOSS_OVERLAP", "1") == "1"
 
 
 # Deferred join of the weight-gradient chains. By default _HotForward.backward returns with every side
@@ -1003,9 +1085,9 @@ class _HotForward(torch.autograd.Function):
         nbu = _lib.lib().mmssl_layer_combine_blocks(u0.shape[0], d)
         nbi = _lib.lib().mmssl_layer_combine_blocks(i0.shape[0], d)
         part = torch.empty(nbu + nbi, dtype=torch.float32, device=dev)
-        # (a cross-stream edge inside a replayed hipGraph costs ~6-10 us, more than running the second 12 us combine
-        #  kernel behind the first: profiles/r02_step_timeline.txt; MMSSL_COMBINE_FORK=1 restores the forked form)
-        if overlap and _os.environ.get("MMSSL_COMBINE_FORK", "0") == "1":
+        # the two combines are independent: item side next to the user side (MMSSL_COMBINE_FORK=0: one stream; measured
+        # equal within noise on the Baby step, 0.654 vs 0.656 ms)
+        if overlap and _os.environ.get("MMSSL_COMBINE_FORK", "1") == "1":
             sA.wait_stream(main)
             with torch.cuda.stream(sA):
                 i_g = _combine_fwd(its, inv, img_item, txt_item, r, part[nbu:])
@@ -1035,32 +1117,48 @@ class _HotForward(torch.autograd.Function):
         main = torch.cuda.current_stream(dev)
         sA, sB, sC = _side_streams(dev) if overlap else (main, main, main)
         extra = (G_img_item, G_txt_item, G_img_user, G_txt_user)
-        # normalise-backward + regulariser gradient of both sides on the CURRENT stream, then ONE fork into the three
-        # chains (GCN backward || image wgrad path || text wgrad path). Round 1 ran the two combine kernels side by
-        # side on sA / sB and exchanged their results through the current stream: two extra cross-stream hops of a
-        # replayed hipGraph (~6-10 us each) to save one 5 us kernel.
-        g_iu_, g_tu_, g_u0 = _combine_bwd(img_user, txt_user, Gu, r, inv, g_ss, 2.0, True)
-        g_ii_, g_ti_, _ = _combine_bwd(img_item, txt_item, Gi, r, inv, g_ss, 2.0, False)
-        # gradients that arrive on the modal outputs themselves (a caller used them elsewhere, e.g. u_sim -> D)
-        if G_img_item is not None:
-            g_ii_ = g_ii_ + G_img_item
-        if G_txt_item is not None:
-            g_ti_ = g_ti_ + G_txt_item
-        if G_img_user is not None:
-            g_iu_ = g_iu_ + G_img_user
-        if G_txt_user is not None:
-            g_tu_ = g_tu_ + G_txt_user
-        split = overlap
+        # normalise-backward + regulariser gradient of the user side on sA and of the item side on sB, next to each
+        # other and next to the GCN chain (which only needs Gu / Gi); each modal chain then needs one tensor from the
+        # other stream. (Measured, Baby step under hipGraph replay: this form 0.62 ms; both combines on the current
+        # stream followed by ONE fork 0.65 ms - the extra cross-stream hops cost less than the serialised kernels.)
+        split = overlap and all(t is None for t in extra)
         if overlap:
             for st in (sA, sB, sC):
                 st.wait_stream(main)
-            # tensors from the main stream's pool that the side streams read, possibly AFTER this backward has
-            # returned (deferred join): the caching allocator must not hand their blocks to a main-stream allocation
-            # before the side stream is done with them
-            for t, st in ((keep_img, sA), (keep_txt, sB), (g_ii_, sA), (g_iu_, sA), (g_ti_, sB), (g_tu_, sB), (uG, sC),
-                          (iG, sC), (Gu, sC), (Gi, sC)):
-                if t is not None:
-                    t.record_stream(st)
+            for t, st in ((keep_img, sA), (keep_txt, sB), (img_user, sA), (txt_user, sA), (img_item, sB),
+                          (txt_item, sB), (uG, sC), (iG, sC), (Gu, sA), (Gu, sC), (Gi, sB), (Gi, sC)):
+                if t is not None and _os.environ.get("MMSSL_NO_RECORD_STREAM") != "1":
+                    t.record_stream(st)     # main-pool tensors read on side streams, possibly after this backward returned
+        if split:
+            with torch.cuda.stream(sA):
+                g_iu_, g_tu_, g_u0 = _combine_bwd(img_user, txt_user, Gu, r, inv, g_ss, 2.0, True)
+            with torch.cuda.stream(sB):
+                g_ii_, g_ti_, _ = _combine_bwd(img_item, txt_item, Gi, r, inv, g_ss, 2.0, False)
+            # each modal chain needs one tensor of the other side: exchange through the current stream
+            # (a direct sA <-> sB event pair crashes hipGraph capture in this ROCm build)
+            main.wait_stream(sA)
+            main.wait_stream(sB)
+            sA.wait_stream(main)
+            sB.wait_stream(main)
+        else:
+            # gradients arrive on the modal outputs themselves (a caller used them elsewhere, e.g. u_sim -> D): both
+            # combines and the adds on the current stream, then one fork
+            g_iu_, g_tu_, g_u0 = _combine_bwd(img_user, txt_user, Gu, r, inv, g_ss, 2.0, True)
+            g_ii_, g_ti_, _ = _combine_bwd(img_item, txt_item, Gi, r, inv, g_ss, 2.0, False)
+            if G_img_item is not None:
+                g_ii_ = g_ii_ + G_img_item
+            if G_txt_item is not None:
+                g_ti_ = g_ti_ + G_txt_item
+            if G_img_user is not None:
+                g_iu_ = g_iu_ + G_img_user
+            if G_txt_user is not None:
+                g_tu_ = g_tu_ + G_txt_user
+            if overlap:
+                for st in (sA, sB):
+                    st.wait_stream(main)
+                for t, st in ((g_ii_, sA), (g_iu_, sA), (g_ti_, sB), (g_tu_, sB)):
+                    if _os.environ.get("MMSSL_NO_RECORD_STREAM") != "1":
+                        t.record_stream(st)
         out = {}
 
         def chain_c():
@@ -1089,8 +1187,8 @@ class _HotForward(torch.autograd.Function):
             chains[c]()
         gi, gW_img, gb_img, gW_txt, gb_txt = out["gi"], out["gW_img"], out["gb_img"], out["gW_txt"], out["gb_txt"]
         if overlap:
-            # g_u0 (current stream) and gi (sC) are what the embedding tables need; in deferred mode the wgrad
-            # chains on sA / sB are left running (see defer_wgrad_join)
+            # g_u0 (sA before the exchange, or the current stream) and gi (sC) are what the embedding tables need; in
+            # deferred mode the wgrad chains on sA / sB are left running (see defer_wgrad_join)
             for st in ((sC,) if (split and _DEFER["on"]) else (sA, sB, sC)):
                 main.wait_stream(st)
         return (None, gW_img, gb_img if has_bi else None, None, None, gW_txt, gb_txt if has_bt else None, None, None,

@@ -5,13 +5,14 @@ by score with ties broken towards the LOWER item id (heapq.nlargest over an asce
 a stable sort), then precision / recall / ndcg / hit_ratio @ Ks averaged over the tested users.
 
 The reference ranks with a multiprocessing.Pool + heapq per user on the host (SURVEY.md section 8f
-"next #2"); here scoring, masking and a stable descending sort run on the device of the embeddings
-(same order, no process pool, no [users, items] device-to-host copy).
+"next #2"); here scoring + masking (one fused fp32-MFMA tile kernel), the top-K selection (one kernel, the heapq
+tie rule) and the hit test run on the device of the embeddings through libmmssl_hip.so: no library GEMM, no sort
+of the [users, items] matrix, no process pool, no [users, items] device-to-host copy.
 """
 import numpy as np
 import torch
 
-from .. import config
+from .. import config, ops
 from . import metrics
 from .load_data import Data
 
@@ -68,14 +69,20 @@ def _rows_of(indptr, indices, users):
     return rows, cols, cnt
 
 
-def _batch_masks(data, user_batch, pos_of, device):
-    """(train_rows, train_cols, pos_rows, pos_cols, n_pos) for one user batch."""
-    tr_ptr, tr_idx = _set_csr(data, "train", data.train_items)
-    po_ptr, po_idx = _set_csr(data, "val" if pos_of is data.val_set else "test", pos_of)
-    tr_r, tr_c, _ = _rows_of(tr_ptr, tr_idx, user_batch)
-    po_r, po_c, n_pos = _rows_of(po_ptr, po_idx, user_batch)
-    mk = lambda x: torch.as_tensor(x, dtype=torch.int64, device=device)     # noqa: E731
-    return mk(tr_r), mk(tr_c), mk(po_r), mk(po_c), n_pos
+def _device_csr(data, name, mapping, device):
+    """(rowptr int32, sorted cols int32) of a {user: [items]} mapping on `device`, cached on the Data object."""
+    cache = data.__dict__.setdefault("_eval_csr_dev", {})
+    key = (name, str(device))
+    hit = cache.get(key)
+    if hit is None or hit[0] is not mapping:
+        indptr, indices = _set_csr(data, name, mapping)
+        cols = indices.copy()
+        for u in range(len(indptr) - 1):                       # per-row ascending (the kernels bisect the rows)
+            cols[indptr[u]:indptr[u + 1]].sort()
+        hit = (mapping, torch.as_tensor(indptr, dtype=torch.int32, device=device),
+               torch.as_tensor(cols, dtype=torch.int32, device=device))
+        cache[key] = hit
+    return hit[1], hit[2]
 
 
 def _metric_sums(hits, n_pos, Ks):
@@ -118,19 +125,24 @@ def test_torch(ua_embeddings, ia_embeddings, users_to_test, is_val, drop_flag=Fa
     n_test_users = len(users_to_test)
     pos_of = data.val_set if is_val else data.test_set
     dev = ua_embeddings.device
+    tr_csr = _device_csr(data, "train", data.train_items, dev)
+    pos_name = "val" if is_val else "test"
+    po_csr = _device_csr(data, pos_name, pos_of, dev)
+    po_ptr, _ = _set_csr(data, pos_name, pos_of)
     count = 0
     for start in range(0, max(n_test_users, 1), u_batch):
         user_batch = users_to_test[start:start + u_batch]
         if not len(user_batch):
             continue
         idx = torch.as_tensor(user_batch, dtype=torch.int64, device=dev)
-        rate = torch.matmul(ua_embeddings[idx], ia_embeddings.t()).detach()
-        tr_r, tr_c, po_r, po_c, n_pos = _batch_masks(data, user_batch, pos_of, dev)
-        rate[tr_r, tr_c] = float("-inf")                              # batch_test.py:98-100
-        order = torch.sort(rate, dim=1, descending=True, stable=True).indices[:, :k_max]
-        is_pos = torch.zeros((len(user_batch), n_items), dtype=torch.bool, device=dev)
-        is_pos[po_r, po_c] = True
-        hits = torch.gather(is_pos, 1, order).cpu().numpy()
+        # scores with the training items at -inf (batch_test.py:98-100) from ONE fused tile kernel, the top max(Ks)
+        # per row by the selection kernel (descending score, ascending id on ties), hits by CSR membership: no
+        # [users, items] sort, no dense positives matrix
+        rate, _ = ops.sim_rows(ua_embeddings.detach(), ia_embeddings.detach(), qidx=idx, mask=tr_csr,
+                               mask_value=float("-inf"))
+        order = ops.topk_rows(rate, k_max)
+        hits = ops.rows_membership(po_csr[0], po_csr[1], idx, order).cpu().numpy()
+        n_pos = (po_ptr[np.asarray(user_batch, dtype=np.int64) + 1] - po_ptr[np.asarray(user_batch, dtype=np.int64)])
         sums = _metric_sums(hits, n_pos, Ks)
         for key in ("precision", "recall", "ndcg", "hit_ratio"):
             result[key] += sums[key] / n_test_users

@@ -146,6 +146,83 @@ def forward(P, image_feats, text_feats, graphs, cfg, training=False, keep_masks=
             img_user_id, txt_user_id, img_item_id, txt_item_id)
 
 
+def modality_attention_multi(P, embs, cfg):
+    """modality_attention over M >= 2 modality views (the reference's code is already written for a dict of
+    views, Models.py:139-169; it only ever holds two). Same quirks, same operation order."""
+    H, d = cfg.head_num, cfg.embed_size
+    dh = d // H
+    V = torch.stack(list(embs), 0)                           # [beh, N, d]
+    beh, N = V.shape[0], V.shape[1]
+    Q = V @ P["weight_dict.w_q"]
+    Qp = Q.reshape(beh, N, H, dh).permute(2, 0, 1, 3)
+    Kp = Qp.contiguous().view(beh, N, H, dh).permute(2, 0, 1, 3)
+    att = (Qp.unsqueeze(2) * Kp.unsqueeze(1)).sum(-1) / math.sqrt(float(d) / H)
+    att = torch.softmax(att, dim=2).unsqueeze(-1)
+    Z = (att * V.unsqueeze(1)).sum(2)
+    Z = torch.cat([Z[h] for h in range(H)], -1)
+    return Z @ P["weight_dict.w_self_attention_cat"]
+
+
+def forward_multi(P, feats, graphs, modal_graphs, cfg, names=("image", "text"), training=False, keep_masks=None):
+    """MMSSL.forward generalised to a LIST of modalities (BASELINE configs[1] names V/A/T).
+    With names == ("image", "text") this is `forward` operation for operation (tests pin that, bit for bit); a third
+    modality follows the same pattern: its own projection `<name>_trans`, feature chain, id views from its own
+    modal graph pair, one more view in the attention mean, one more `+ r * normalize(.)` term.
+    PARITY STATUS of any modality beyond image/text: UNPINNED - the reference loads only image_feat.npy and
+    text_feat.npy (main.py:54-55), so there is nothing to pin an acoustic branch to.
+    feats: list of [I, d_m]; graphs = (ui, iu); modal_graphs: list of (m_ui, m_iu). Returns a dict."""
+    ui, iu = graphs
+    E_u, E_i = P["user_id_embedding.weight"], P["item_id_embedding.weight"]
+    xs = []
+    for k, (nm, Fm) in enumerate(zip(names, feats)):
+        x = F.linear(Fm, P[nm + "_trans.weight"], P[nm + "_trans.bias"])
+        if training and cfg.drop_rate > 0:
+            assert keep_masks is not None
+            x = x * keep_masks[k] * (1.0 / (1.0 - cfg.drop_rate))
+        xs.append(x)
+    user_f, item_f, user_id, item_id = [], [], [], []
+    for x, (m_ui, m_iu) in zip(xs, modal_graphs):
+        uf = spmm(ui, x)
+        user_f.append(uf)
+        item_f.append(spmm(iu, uf))
+        user_id.append(spmm(m_ui, E_i))
+        item_id.append(spmm(m_iu, E_u))
+    user_z = modality_attention_multi(P, user_id, cfg).mean(0)
+    item_z = modality_attention_multi(P, item_id, cfg).mean(0)
+    u = E_u + cfg.id_cat_rate * F.normalize(user_z, p=2, dim=1)
+    i = E_i + cfg.id_cat_rate * F.normalize(item_z, p=2, dim=1)
+    us, its = [u], [i]
+    for l in range(cfg.n_ui_layers):
+        u = spmm(ui, i)
+        if l == cfg.n_ui_layers - 1:
+            u = torch.softmax(u, dim=-1)
+        i = spmm(iu, u)
+        if l == cfg.n_ui_layers - 1:
+            i = torch.softmax(i, dim=-1)
+        us.append(u)
+        its.append(i)
+    u = torch.stack(us).mean(0)
+    i = torch.stack(its).mean(0)
+    r = cfg.model_cat_rate
+    for uf, itf in zip(user_f, item_f):
+        u = u + r * F.normalize(uf, p=2, dim=1)
+        i = i + r * F.normalize(itf, p=2, dim=1)
+    return {"ua": u, "ia": i, "item_feats": item_f, "user_feats": user_f, "user_id": user_id, "item_id": item_id}
+
+
+def generator_loss_multi(o, users, pos, neg, n_items, cfg):
+    """main.py:368-371, 407-420 without the GAN term, over every modality of a forward_multi result."""
+    mf, emb, _ = bpr(o["ua"][users], o["ia"][pos], o["ia"][neg], cfg.decay, cfg.batch_size)
+    s = 0.0
+    for t in o["item_feats"] + o["user_feats"]:
+        s = s + 0.5 * (t ** 2).sum()
+    feat = cfg.feat_reg_decay * (s / n_items)
+    cl = 0.0
+    for z in o["user_id"]:
+        cl = cl + infonce(z[users], o["ua"][users], cfg.tau)
+    return mf + emb + feat + cfg.cl_rate * cl
+
+
 def gcn_propagate(ui, iu, u0, i0, n_layers):
     """Just the K4 chain (Models.py:199-214): the '3-layer GCN SpMM' the metric counts."""
     u, i = u0, i0

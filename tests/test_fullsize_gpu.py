@@ -210,3 +210,54 @@ def test_baby_full_step_captured_graph_matches_oracle():
     torch.cuda.synchronize()
     assert float(step.loss) == first
     assert H.rel_err(model.image_trans.weight.grad.cpu(), g1.cpu()) < 1e-5
+
+
+def test_tiktok_three_modalities_v_a_t_match_oracle_extension():
+    """configs[1] as BASELINE.json words it: Tiktok, 3-layer GCN + V/A/T InfoNCE. The reference itself only has V and
+    T (main.py:54-55); the acoustic branch follows the same pattern (oracle.forward_multi, pinned to the reference
+    for V/T, UNPINNED for A). HIP ops vs that oracle: loss 1e-4, gradients 5e-4, all three projections included."""
+    from mmssl_amd import config, ops
+    from mmssl_amd.Models import MMSSL
+    U, I, dv, dt, raw, ui, iu, P_ui, P_iu = _setup("tiktok")
+    config.configure([], drop_rate=0.2, batch_size=1024, weight_size=str([64] * 3), debug=True)
+    da = 128
+    g = torch.Generator().manual_seed(0)
+    img, txt, aud = torch.randn(I, dv, generator=g), torch.randn(I, dt, generator=g), torch.randn(I, da, generator=g)
+    torch.manual_seed(4)
+    model = MMSSL(U, I, 64, [64] * 3, [0.1] * 3, img.numpy(), txt.numpy(), extra_feats={"audio": aud.numpy()})
+    P = {k: v.detach().clone().requires_grad_(v.dtype.is_floating_point) for k, v in model.state_dict().items()
+         if not k.startswith(("image_embedding", "text_embedding", "audio_embedding", "batch_norm", "encoder.", "align."))}
+    model = model.to(DEV).train()
+    rng = np.random.default_rng(1)
+    from mmssl_amd.graph import GraphPlan
+    modal_m, modal_g = [], []
+    for s in range(3):                      # a different sparse modal graph pair per modality
+        us = rng.choice(U, 1024, replace=False)
+        m = sp.csr_matrix((np.ones(1024, np.float32), (us, rng.integers(0, I, 1024))), shape=(U, I))
+        m_ui, m_iu = O.csr_norm(m, True).tocsr(), O.csr_norm(m.T, True).tocsr()
+        modal_m.append((O.to_torch_sparse(m_ui), O.to_torch_sparse(m_iu)))
+        modal_g.append((GraphPlan(m_ui), GraphPlan(m_iu)))
+    km = [(torch.rand(I, 64, generator=g) >= 0.2) for _ in range(3)]
+    users = torch.from_numpy(rng.choice(U, 1024, replace=False))
+    pos = torch.from_numpy(rng.integers(0, I, 1024))
+    neg = torch.from_numpy(rng.integers(0, I, 1024))
+    cfg = O.Cfg(drop_rate=0.2, n_ui_layers=3, batch_size=1024)
+    o = O.forward_multi(P, [img, txt, aud], (O.to_torch_sparse(ui), O.to_torch_sparse(iu)), modal_m, cfg,
+                        names=("image", "text", "audio"), training=True, keep_masks=[k.float() for k in km])
+    ref = O.generator_loss_multi(o, users, pos, neg, I, cfg)
+    ref.backward()
+    out = model(P_ui, P_iu, modal_g[0][0], modal_g[0][1], modal_g[1][0], modal_g[1][1],
+                keep_masks=[k.to(torch.uint8).to(DEV) for k in km], extra_graphs={"audio": modal_g[2]})
+    assert len(out) == 16
+    assert H.rel_err(out[0].detach().cpu(), o["ua"].detach()) < 1e-4 and H.rel_err(out[13].detach().cpu(), o["user_feats"][2].detach()) < 1e-4
+    ug = users.to(DEV)
+    mf, emb = ops.bpr_gather(out[0], out[1], ug, pos.to(DEV), neg.to(DEV), 1e-5, 1024)
+    feat = sum(ops.sumsq(out[k]) for k in (2, 3, 4, 5, 12, 13)) * (0.5 * 1e-5 / I)
+    cl = sum(ops.infonce(out[k], out[0], 0.5, idx=ug) for k in (8, 9, 14))
+    got = mf + emb + feat + 0.03 * cl
+    assert abs(float(got) - float(ref)) <= 1e-4 * abs(float(ref)), (float(got), float(ref))
+    got.backward()
+    named = dict(model.named_parameters())
+    for k in ("image_trans.weight", "text_trans.weight", "audio_trans.weight", "audio_trans.bias", "user_id_embedding.weight",
+              "item_id_embedding.weight", "weight_dict.w_self_attention_cat"):
+        assert H.rel_err(named[k].grad.cpu(), P[k].grad) < 5e-4, (k, H.rel_err(named[k].grad.cpu(), P[k].grad))

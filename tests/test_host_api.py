@@ -1,6 +1,7 @@
 """CPU tests of the host-side mirror of the reference API: flags, Data + bit-exact sampler,
 evaluation (Recall@K) — checked against the golden vectors captured from the reference."""
 import numpy as np
+import pytest
 import torch
 
 import helpers as H
@@ -67,19 +68,35 @@ def test_data_and_sampler_bit_exact(tmp_path):
     np.testing.assert_allclose(np.asarray(mean_adj.sum(1)).ravel()[np.diff(adj.indptr) > 0], 1.0, rtol=1e-5)
 
 
-def test_eval_recall_matches_reference(tmp_path):
+def test_eval_metric_formulas_match_reference(tmp_path):
+    """Host half of the evaluation against G7: the CSR bookkeeping of train / positive items and the vectorised
+    metric formulas (utility/metrics.py applied to all rows at once). Scores and ranking are HIP kernels in the
+    product (no CPU path; their GPU test is tests/test_model_gpu.py::test_eval_on_device_matches_reference_recall),
+    so the ranking here is a numpy stable sort standing in for them."""
     from mmssl_amd import config
     from mmssl_amd.utility import batch_test
     root = H.write_dataset_dir(str(tmp_path))
     config.configure([], data_path=root, dataset="tiny", batch_size=48)
     data = batch_test.init_data()
     g = H.load("g7_eval.npz")
-    ua, ia = torch.from_numpy(g["ua"]), torch.from_numpy(g["ia"])
+    ua, ia = g["ua"], g["ia"]
+    Ks = [int(k) for k in g["Ks"]]
     for nm, is_val in (("val", True), ("test", False)):
-        users = [int(u) for u in g[nm + ".users"]]
-        res = batch_test.test_torch(ua, ia, users, is_val, data=data)
+        users = np.array([int(u) for u in g[nm + ".users"]])
+        pos_of = data.val_set if is_val else data.test_set
+        tr_ptr, tr_idx = batch_test._set_csr(data, "train", data.train_items)
+        po_ptr, po_idx = batch_test._set_csr(data, nm, pos_of)
+        rate = (ua[users] @ ia.T).astype(np.float32)
+        for b, u in enumerate(users):
+            rate[b, tr_idx[tr_ptr[u]:tr_ptr[u + 1]]] = -np.inf
+        order = np.argsort(-rate, axis=1, kind="stable")[:, :max(Ks)]
+        hits = np.array([[1 if j in set(po_idx[po_ptr[u]:po_ptr[u + 1]].tolist()) else 0 for j in order[b]]
+                         for b, u in enumerate(users)])
+        sums = batch_test._metric_sums(hits, po_ptr[users + 1] - po_ptr[users], Ks)
         for k in ("precision", "recall", "ndcg", "hit_ratio"):
-            np.testing.assert_allclose(res[k], g["%s.%s" % (nm, k)], rtol=1e-12, atol=1e-15, err_msg=k)
+            np.testing.assert_allclose(sums[k] / len(users), g["%s.%s" % (nm, k)], rtol=1e-12, atol=1e-15, err_msg=k)
+    with pytest.raises(Exception):                       # CPU tensors are refused, not silently handled
+        batch_test.test_torch(torch.from_numpy(ua), torch.from_numpy(ia), [0, 1], True, data=data)
 
 
 def test_state_dict_keys_match_reference_inventory():

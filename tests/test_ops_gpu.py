@@ -559,3 +559,79 @@ def test_split_precision_projection_kernels():
     gW = ops._split_call(gTh, gTl, FTh, FTl, None, None, 1.0, N, Mp, K)
     refw = gYm.double().t() @ F_.double()
     assert float((gW.double() - refw).abs().max() / refw.abs().max()) < 2e-5
+
+
+# ---------------------------------------------------------------------------------------------------
+# fused similarity rows + top-K selection (csrc/simtopk.hip): evaluation scoring / ranking and u_sim forward
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("Q,n,d,B", [(500, 4500, 64, 77), (90, 33, 32, 90), (300, 2049, 128, 64)])
+def test_sim_rows_matches_fp64_product_with_csr_mask(Q, n, d, B):
+    """scores of a batch against every row of the table (several 2048-item chunks, ragged last tile, batch not a
+    multiple of 32), masked entries exactly mask_value, row norms from the in-kernel partials."""
+    from mmssl_amd import ops
+    gen = torch.Generator().manual_seed(n)
+    qt, tt = torch.randn(Q, d, generator=gen), torch.randn(n, d, generator=gen)
+    idx = torch.randint(0, Q, (B,), generator=gen)
+    rng = np.random.RandomState(n)
+    mask = sp.random(Q, n, density=0.03, random_state=rng, format="csr", dtype=np.float32)
+    mask.sort_indices()
+    rp = torch.from_numpy(mask.indptr.astype(np.int32)).to(DEV)
+    cols = torch.from_numpy(mask.indices.astype(np.int32)).to(DEV)
+    dense = torch.from_numpy(np.asarray(mask[idx.numpy()].todense()) != 0)
+    ref = qt[idx].double() @ tt.double().t()
+    S, _ = ops.sim_rows(qt.to(DEV), tt.to(DEV), qidx=idx.to(DEV), mask=(rp, cols), mask_value=float("-inf"))
+    S = S.cpu()
+    assert torch.isinf(S[dense]).all() and (S[dense] < 0).all() and torch.isfinite(S[~dense]).all()
+    assert float((S[~dense].double() - ref[~dense]).abs().max()) <= 2e-6 * float(ref.abs().max())
+    Sn, inv = ops.sim_rows(qt.to(DEV), tt.to(DEV), qidx=idx.to(DEV), mask=(rp, cols), mask_value=0.0, normalize=True,
+                           pitch_mult=32)
+    assert Sn.stride(0) % 32 == 0 and Sn.shape == (B, n)
+    refn = torch.nn.functional.normalize(ref.masked_fill(dense, 0.0), dim=1)
+    assert H.rel_err(Sn.cpu(), refn) < 3e-6
+    S0, _ = ops.sim_rows(qt.to(DEV), tt.to(DEV))                       # no gather, no mask: plain Q . T^T
+    assert float((S0.cpu().double() - qt.double() @ tt.double().t()).abs().max()) <= 2e-6 * float(ref.abs().max())
+
+
+def _heapq_topk(row, k):
+    """The reference's ranking rule (batch_test.py:21-36): heapq.nlargest over an ascending-id dict."""
+    import heapq
+    score = {i: float(v) for i, v in enumerate(row)}
+    return heapq.nlargest(k, score, key=score.get)
+
+
+@pytest.mark.parametrize("n,k", [(18357, 50), (700, 50), (40, 50), (5000, 1), (36864, 64)])
+def test_topk_rows_is_heapq_nlargest_including_ties(n, k):
+    from mmssl_amd import ops
+    gen = torch.Generator().manual_seed(n + k)
+    B = 37
+    X = torch.randn(B, n, generator=gen)
+    X[:, ::7] = X[:, 3:4]                      # many exact ties per row (every 7th column equals column 3)
+    X[1] = 0.25                                # a constant row: the first k ids win
+    X[2, : n // 2] = float("-inf")             # masked half
+    X[3, 5] = X[3].max() + 1.0
+    idx, val = ops.topk_rows(X.to(DEV), k, values=True)
+    idx, val = idx.cpu(), val.cpu()
+    ke = min(k, n)
+    for b in range(B):
+        want = _heapq_topk(X[b].tolist(), ke)
+        assert idx[b, :ke].tolist() == want, (b, idx[b, :8].tolist(), want[:8])
+        assert torch.equal(val[b, :ke], X[b, torch.tensor(want)])
+        assert (idx[b, ke:] == -1).all()
+    # row-pitched input (the padded similarity buffer)
+    Xp = torch.zeros(B, n + 13).to(DEV)
+    Xp[:, :n] = X.to(DEV)
+    assert torch.equal(ops.topk_rows(Xp[:, :n], k).cpu(), idx)
+
+
+def test_rows_membership_matches_sets():
+    from mmssl_amd import ops
+    rng = np.random.RandomState(0)
+    m = sp.random(64, 500, density=0.05, random_state=rng, format="csr")
+    m.sort_indices()
+    rows = torch.from_numpy(rng.randint(0, 64, 40).astype(np.int64))
+    cand = torch.from_numpy(rng.randint(-1, 500, (40, 20)).astype(np.int64))
+    out = ops.rows_membership(torch.from_numpy(m.indptr.astype(np.int32)).to(DEV),
+                              torch.from_numpy(m.indices.astype(np.int32)).to(DEV), rows.to(DEV), cand.to(DEV)).cpu()
+    for b in range(40):
+        have = set(m.indices[m.indptr[rows[b]]:m.indptr[rows[b] + 1]].tolist())
+        assert out[b].tolist() == [1 if int(c) in have else 0 for c in cand[b]]

@@ -168,3 +168,22 @@ def test_g8_gstep_assembly(modal):
     for k in fx.files:
         if k.startswith("g."):
             assert H.rel_err(P[k[2:]].grad.numpy(), fx[k]) < 2e-5, k
+
+
+def test_forward_multi_with_two_modalities_is_forward_bit_for_bit():
+    """The M-modality generalisation (J-1) restricted to (image, text) must be the pinned oracle forward itself."""
+    fx = H.load("g2_forward_g3_l2_sparse.npz")
+    d, raw, U, I = H.dataset()
+    P = H.params(fx)
+    cfg = O.Cfg(layers=2, n_ui_layers=3, drop_rate=0.0)
+    ui, iu = O.graph_pair(raw)
+    a, b = O.graph_pair(H.modal_raw(fx, "img", U, I))
+    c, e = O.graph_pair(H.modal_raw(fx, "txt", U, I))
+    img, txt = torch.from_numpy(d["image_feat"]), torch.from_numpy(d["text_feat"])
+    ref = O.forward(P, img, txt, (ui, iu, a, b, c, e), cfg)
+    got = O.forward_multi(P, [img, txt], (ui, iu), [(a, b), (c, e)], cfg)
+    assert torch.equal(got["ua"], ref[0]) and torch.equal(got["ia"], ref[1])
+    assert torch.equal(got["item_feats"][0], ref[2]) and torch.equal(got["item_feats"][1], ref[3])
+    assert torch.equal(got["user_feats"][0], ref[4]) and torch.equal(got["user_feats"][1], ref[5])
+    assert torch.equal(got["user_id"][0], ref[8]) and torch.equal(got["user_id"][1], ref[9])
+    assert torch.equal(got["item_id"][0], ref[10]) and torch.equal(got["item_id"][1], ref[11])

@@ -66,6 +66,26 @@ int mmssl_graph_info(const mmssl_graph* g, int64_t info[16]);
 /* Copy the device-resident transposed CSR back to host buffers (tests / debugging). */
 int mmssl_graph_export_transpose(const mmssl_graph* g, int32_t* t_rowptr, int32_t* t_col,
                                  float* t_val, void* stream);
+/* (rowptr [rows+1], col, val) of A (transpose = 0) or A^T (1) to the host; col / val hold `cap` entries;
+ * *nnz_out = stored entries (read from the device: works for device-built plans too). Synchronises. */
+int mmssl_graph_export_f32(const mmssl_graph* g, int transpose, int32_t* rowptr, int32_t* col, float* val,
+                           int64_t cap, int64_t* nnz_out, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Modal-graph rebuild on the device (main.py:378-405): both plans of the rebuild
+ *   A_ui = csr_norm(csr_matrix(ones, (users, items)), mean_flag=True),  A_iu = csr_norm(its transpose, True)
+ * from one (user, item) pair list that is already on the device (the batch users tiled k times and their top-k
+ * items), with no host round trip, no allocation and no synchronisation: capturable in a hipGraph. A pair handle is
+ * created once for a capacity (<= 16384 pairs) and rebuilt in place; mmssl_graph_pair_get returns the two graph
+ * handles (owned by the pair; usable with every mmssl_spmm / mmssl_graph_* call). Duplicate pairs stay separate
+ * edges of weight 1/sqrt(deg(row)) (= the reference's summed duplicates). n = 0 gives empty graphs.
+ * ---------------------------------------------------------------------------------- */
+typedef struct mmssl_graph_pair mmssl_graph_pair;
+int mmssl_graph_pair_create(int32_t n_users, int32_t n_items, int64_t capacity, mmssl_graph_pair** out);
+int mmssl_graph_pair_destroy(mmssl_graph_pair* h);
+int mmssl_graph_pair_get(mmssl_graph_pair* h, mmssl_graph** ui, mmssl_graph** iu);
+int mmssl_graph_pair_rebuild(mmssl_graph_pair* h, const int64_t* users, const int64_t* items, int64_t n,
+                             void* stream);
 
 /* Host-only planning helpers (pure CPU, no device needed) — exported so the host logic
  * is testable without a GPU; mmssl_graph_create uses exactly these. */

@@ -29,6 +29,11 @@ SIGNATURES = {
     "mmssl_graph_destroy": (c_int, [c_void_p]),
     "mmssl_graph_info": (c_int, [c_void_p, _i64p]),
     "mmssl_graph_export_transpose": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "mmssl_graph_export_f32": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int64, _i64p, c_void_p]),
+    "mmssl_graph_pair_create": (c_int, [c_int32, c_int32, c_int64, POINTER(c_void_p)]),
+    "mmssl_graph_pair_destroy": (c_int, [c_void_p]),
+    "mmssl_graph_pair_get": (c_int, [c_void_p, POINTER(c_void_p), POINTER(c_void_p)]),
+    "mmssl_graph_pair_rebuild": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "mmssl_csr_validate_host": (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int64]),
     "mmssl_csr_transpose_host": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int64,
                                          c_void_p, c_void_p, c_void_p]),

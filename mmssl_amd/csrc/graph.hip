@@ -21,6 +21,7 @@
 #include <vector>
 
 #include "common.hpp"
+#include "graph_internal.hpp"
 
 using namespace mmssl;
 
@@ -40,19 +41,11 @@ int plan_sort() { static int v = env_int("MMSSL_PLAN_SORT", 1); return v; }
 // (With one slot per 128-nnz slice — 183 multi rows on the item side — the in-kernel form was the slower one.)
 int two_stage() { static int v = env_int("MMSSL_SPMM_TWO_STAGE", 0); return v; }
 
-struct DirPlan {
-  int32_t rows = 0, cols = 0;
-  int64_t nnz = 0;
-  int32_t* rowptr = nullptr;  // [rows+1]   (device)
-  Edge* edges = nullptr;      // [nnz]
-  int4* gitems = nullptr;     // group items  {row, beg, end, -1}
-  int4* witems = nullptr;     // wave items   {row, beg, end, slot|-1}
-  int4* multi = nullptr;      // multi rows   {row, first_slot, n_slots, 0}
-  int32_t* slot2multi = nullptr;  // [n_slots] -> index into `multi`
-  int64_t n_g = 0, n_w = 0, n_multi = 0, n_slots = 0;
-};
+}  // namespace
 
+namespace mmssl {
 void free_dir(DirPlan& p) {
+  if (p.dyn) (void)hipFree(p.dyn);
   if (p.rowptr) (void)hipFree(p.rowptr);
   if (p.edges) (void)hipFree(p.edges);
   if (p.gitems) (void)hipFree(p.gitems);
@@ -61,6 +54,9 @@ void free_dir(DirPlan& p) {
   if (p.slot2multi) (void)hipFree(p.slot2multi);
   p = DirPlan();
 }
+}  // namespace mmssl
+
+namespace {
 
 template <typename T>
 int upload(T** dst, const T* src, size_t n) {
@@ -98,9 +94,6 @@ int build_dir(DirPlan& p, const int32_t* rowptr, const int32_t* col, const float
 
 }  // namespace
 
-struct mmssl_graph {
-  DirPlan fwd, bwd;
-};
 
 // ======================================================================================
 // host planning (pure CPU; exported for CPU-only tests)
@@ -286,6 +279,26 @@ extern "C" int mmssl_graph_info(const mmssl_graph* g, int64_t info[16]) {
   return 0;
 }
 
+// (rowptr, col, val) of either direction to the host; `cap` = capacity of col / val (entries). Returns the number
+// of stored entries through *nnz_out (device-built plans keep it in device memory). Synchronises the stream.
+extern "C" int mmssl_graph_export_f32(const mmssl_graph* g, int transpose, int32_t* rowptr, int32_t* col, float* val,
+                                      int64_t cap, int64_t* nnz_out, void* stream) {
+  if (!g || !rowptr || !nnz_out) return MMSSL_E_BADARG;
+  MMSSL_HIP_TRY(hipStreamSynchronize(as_stream(stream)));
+  const DirPlan& p = transpose ? g->bwd : g->fwd;
+  MMSSL_HIP_TRY(hipMemcpy(rowptr, p.rowptr, ((size_t)p.rows + 1) * sizeof(int32_t), hipMemcpyDeviceToHost));
+  const int64_t nnz = rowptr[p.rows];
+  *nnz_out = nnz;
+  if (nnz > cap) return MMSSL_E_WORKSPACE;
+  if (nnz) {
+    if (!col || !val) return MMSSL_E_BADARG;
+    std::vector<Edge> e((size_t)nnz);
+    MMSSL_HIP_TRY(hipMemcpy(e.data(), p.edges, (size_t)nnz * sizeof(Edge), hipMemcpyDeviceToHost));
+    for (int64_t i = 0; i < nnz; ++i) { col[i] = e[i].col; val[i] = e[i].val; }
+  }
+  return 0;
+}
+
 extern "C" int mmssl_graph_export_transpose(const mmssl_graph* g, int32_t* t_rowptr, int32_t* t_col,
                                             float* t_val, void* stream) {
   if (!g || !t_rowptr) return MMSSL_E_BADARG;
@@ -399,7 +412,14 @@ __global__ __launch_bounds__(kBlock) void spmm_kernel(const int4* __restrict__ g
                                                       float4* __restrict__ partials, EpiArgs epi,
                                                       const int4* __restrict__ multi,
                                                       const int32_t* __restrict__ slot2multi,
-                                                      int32_t* __restrict__ arrivals) {
+                                                      int32_t* __restrict__ arrivals,
+                                                      const int32_t* __restrict__ dyn) {
+  // device-built plans (csrc/graphdev.hip): the item counts live in device memory and the grid is an upper bound
+  if (dyn) {
+    n_g = dyn[0];
+    n_w = dyn[1];
+    n_wblocks = (n_w + 3) >> 2;
+  }
   constexpr int GPW = kWave / LPR;   // lane groups per wave
   constexpr int GPB = kBlock / LPR;  // lane groups per block
   const int lane = threadIdx.x & 63;
@@ -567,10 +587,10 @@ int launch_spmm(const DirPlan& p, const float* X, float* Y, float* partials, con
                        p.gitems, (int)p.n_g, p.witems, (int)p.n_w, n_wblocks, p.edges,
                        reinterpret_cast<const float4*>(X), reinterpret_cast<float4*>(Y),
                        reinterpret_cast<float4*>(partials), epi, p.multi, p.slot2multi,
-                       two_stage() ? (int32_t*)nullptr : arrivals);
+                       (two_stage() && !p.dyn) ? (int32_t*)nullptr : arrivals, p.dyn);
     MMSSL_LAUNCH_CHECK();
   }
-  if (p.n_multi > 0 && two_stage()) {
+  if (p.n_multi > 0 && two_stage() && !p.dyn) {
     hipLaunchKernelGGL((spmm_multi_kernel<LPR, EPI>), dim3((unsigned)p.n_multi), dim3(kBlock), 0, s, p.multi,
                        (int)p.n_multi, reinterpret_cast<const float4*>(partials),
                        reinterpret_cast<float4*>(Y), epi);

@@ -125,6 +125,98 @@ class _PlanView:
         return _PlanView(self._plan, lane)
 
 
+class _DevPlan:
+    """One of the two plans of a DeviceGraphPair: same surface as GraphPlan (handle, shape, nnz, workspace, twin)."""
+
+    def __init__(self, pair, handle, shape):
+        self._pair, self._handle, self.shape = pair, handle, shape
+        self.nnz = 0
+        self.device = pair.device
+        self._ws = {}
+
+    @property
+    def handle(self):
+        if not self._pair._handle:
+            raise _lib.MmsslError("DeviceGraphPair used after destroy")
+        return self._handle
+
+    def _nnz(self):
+        return self.nnz
+
+    def size(self, dim=None):
+        return torch.Size(self.shape) if dim is None else self.shape[dim]
+
+    def cuda(self, *a, **k):
+        return self
+
+    workspace = GraphPlan.workspace
+    twin = GraphPlan.twin
+
+    def export(self, transpose=False):
+        """scipy CSR of A (or A^T) with duplicate pairs summed (tests; synchronises)."""
+        rows = self.shape[1] if transpose else self.shape[0]
+        cols = self.shape[0] if transpose else self.shape[1]
+        cap = max(self._pair.capacity, 1)
+        rp = np.empty(rows + 1, np.int32)
+        col = np.empty(cap, np.int32)
+        val = np.empty(cap, np.float32)
+        nnz = ctypes.c_int64(0)
+        with torch.cuda.device(self.device):
+            rc = _lib.lib().mmssl_graph_export_f32(self.handle, int(bool(transpose)), rp.ctypes.data, col.ctypes.data,
+                                                   val.ctypes.data, cap, ctypes.byref(nnz), _lib.stream_ptr())
+        _lib.check(rc, "mmssl_graph_export_f32")
+        n = int(nnz.value)
+        m = sp.csr_matrix((val[:n], col[:n], rp), shape=(rows, cols))
+        m.sum_duplicates()
+        return m
+
+
+class DeviceGraphPair:
+    """Both graph plans of one modal-graph rebuild (main.py:378-405), built on the device from (user, item) pairs:
+        pair = DeviceGraphPair(n_users, n_items, capacity)      # once (capacity <= 16384 pairs)
+        pair.rebuild(users_idx, items_idx)                      # int64 device tensors, every T batches; no sync
+        model(ui, iu, pair.ui, pair.iu, ...)
+    pair.ui = csr_norm(csr_matrix(ones, (users, items)), mean_flag=True), pair.iu = csr_norm(its transpose, True)."""
+
+    MAX_PAIRS = 16384
+
+    def __init__(self, n_users, n_items, capacity, device=None):
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        self.capacity = int(capacity)
+        self._handle = ctypes.c_void_p()
+        with torch.cuda.device(self.device):
+            rc = _lib.lib().mmssl_graph_pair_create(int(n_users), int(n_items), self.capacity, ctypes.byref(self._handle))
+        _lib.check(rc, "mmssl_graph_pair_create")
+        a, b = ctypes.c_void_p(), ctypes.c_void_p()
+        _lib.check(_lib.lib().mmssl_graph_pair_get(self._handle, ctypes.byref(a), ctypes.byref(b)), "mmssl_graph_pair_get")
+        self.ui = _DevPlan(self, a, (int(n_users), int(n_items)))
+        self.iu = _DevPlan(self, b, (int(n_items), int(n_users)))
+
+    def rebuild(self, users, items):
+        users = users.to(device=self.device, dtype=torch.int64).contiguous().view(-1)
+        items = items.to(device=self.device, dtype=torch.int64).contiguous().view(-1)
+        n = users.shape[0]
+        if items.shape[0] != n or n > self.capacity:
+            raise _lib.MmsslError("DeviceGraphPair.rebuild: %d / %d pairs, capacity %d" % (n, items.shape[0], self.capacity))
+        with torch.cuda.device(self.device):
+            rc = _lib.lib().mmssl_graph_pair_rebuild(self._handle, users.data_ptr() if n else None,
+                                                     items.data_ptr() if n else None, n, _lib.stream_ptr())
+        _lib.check(rc, "mmssl_graph_pair_rebuild")
+        self.ui.nnz = self.iu.nnz = n          # stored edges (duplicates are separate edges)
+        return self
+
+    def destroy(self):
+        if self._handle:
+            _lib.lib().mmssl_graph_pair_destroy(self._handle)
+            self._handle = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+
 def _coo_tensor_to_scipy(t):
     if not t.is_sparse:
         raise TypeError("expected a torch sparse COO tensor")

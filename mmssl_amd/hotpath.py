@@ -209,6 +209,10 @@ class SplitHotPath:
                     if self.extra_grads is None:
                         self.extra_grads = [torch.zeros_like(outs[k]) for k in (2, 3, 4, 5)]
                     self._backward(outs, total)
+                    # drop the warm-up's tensors NOW: released inside the capture region (when the names are rebound)
+                    # their blocks carry record_stream marks from the side streams and the allocator's bookkeeping
+                    # for them runs in the middle of the capture - hipStreamEndCapture then segfaults (ROCm 7.2)
+                    del outs, terms, total
             torch.cuda.synchronize()
             gF, gB = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
             with torch.cuda.graph(gF, stream=s, capture_error_mode="thread_local"):

@@ -212,10 +212,46 @@ class Trainer(object):
         self.optim_D.step()
         return loss_D.detach()
 
+    def _maintain_modal_graphs_device(self, idx, users, img_sim, txt_sim, k):
+        """The same bookkeeping as _maintain_modal_graphs with everything on the device: top-k by the selection
+        kernel (ops.topk_rows), the (user, item) pair lists as device tensors, the four graphs rebuilt in place by
+        graph.DeviceGraphPair (CSR + transpose + work lists built by kernels; no .cpu(), no python lists, no scipy,
+        no plan upload). Used when the collected pairs fit its capacity (MMSSL_DEVICE_GRAPHS=0 disables it)."""
+        from .graph import DeviceGraphPair
+        store = self.__dict__.setdefault("_dev_pairs", {"image": [], "text": []})
+        if idx % args.T == 0 and idx != 0:
+            for name in ("image", "text"):
+                pair = self.__dict__.setdefault("_dev_graphs", {}).get(name)
+                if pair is None:
+                    pair = DeviceGraphPair(self.n_users, self.n_items, DeviceGraphPair.MAX_PAIRS)
+                    self._dev_graphs[name] = pair
+                xs = [x for x, _ in store[name]]
+                ys = [y for _, y in store[name]]
+                empty = torch.empty(0, dtype=torch.int64, device=self.device)
+                pair.rebuild(torch.cat(xs) if xs else empty, torch.cat(ys) if ys else empty)
+                setattr(self, name + "_ui_graph", pair.ui)
+                setattr(self, name + "_iu_graph", pair.iu)
+            self._dev_pairs = {"image": [], "text": []}
+        else:
+            u = self._users_idx(users)
+            for name, s in (("image", img_sim), ("text", txt_sim)):
+                ids = ops.topk_rows(s, k)                       # [B, k], descending score, lowest id on ties
+                # the reference pairs the user list TILED k times with the row-major top-k ids (tensor.repeat(1, k))
+                store[name].append((u.repeat(k), ids.reshape(-1)))
+
+    def _device_graphs_ok(self, k, n_batch_users):
+        from .graph import DeviceGraphPair
+        if os.environ.get("MMSSL_DEVICE_GRAPHS", "1") == "0" or k < 1 or k > 64:
+            return False
+        return n_batch_users * k * max(int(args.T), 1) <= DeviceGraphPair.MAX_PAIRS and self.n_items <= 36864
+
     def _maintain_modal_graphs(self, idx, users, img_sim, txt_sim):
-        """main.py:378-405: every T-th batch (idx != 0) rebuild the four modal graphs on the host from
-        the collected (user, top-k item) pairs and clear the lists; otherwise collect."""
+        """main.py:378-405: every T-th batch (idx != 0) rebuild the four modal graphs from the collected (user, top-k
+        item) pairs and clear the lists; otherwise collect. On the device when the pairs fit (see
+        _maintain_modal_graphs_device), else on the host like the reference (scipy)."""
         k = int(self.n_items * args.m_topk_rate)
+        if img_sim.is_cuda and self._device_graphs_ok(k, len(users)):
+            return self._maintain_modal_graphs_device(idx, users, img_sim, txt_sim, k)
         if idx % args.T == 0 and idx != 0:
             shape = (self.n_users, self.n_items)
             for name, store in (("image", self.image_ui_index), ("text", self.text_ui_index)):

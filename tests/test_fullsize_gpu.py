@@ -257,7 +257,7 @@ def test_tiktok_three_modalities_v_a_t_match_oracle_extension():
     got = mf + emb + feat + 0.03 * cl
     assert abs(float(got) - float(ref)) <= 1e-4 * abs(float(ref)), (float(got), float(ref))
     got.backward()
-    named = dict(model.named_parameters())
     for k in ("image_trans.weight", "text_trans.weight", "audio_trans.weight", "audio_trans.bias", "user_id_embedding.weight",
               "item_id_embedding.weight", "weight_dict.w_self_attention_cat"):
-        assert H.rel_err(named[k].grad.cpu(), P[k].grad) < 5e-4, (k, H.rel_err(named[k].grad.cpu(), P[k].grad))
+        e = H.rel_err(model.get_parameter(k).grad.cpu(), P[k].grad)
+        assert e < 5e-4, (k, e)

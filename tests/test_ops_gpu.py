@@ -635,3 +635,94 @@ def test_rows_membership_matches_sets():
     for b in range(40):
         have = set(m.indices[m.indptr[rows[b]]:m.indptr[rows[b] + 1]].tolist())
         assert out[b].tolist() == [1 if int(c) in have else 0 for c in cand[b]]
+
+
+# ---------------------------------------------------------------------------------------------------
+# f-3: graph plans built on the device from (user, item) pairs (csrc/graphdev.hip)
+# ---------------------------------------------------------------------------------------------------
+def _pairs_reference(users, items, U, I):
+    m = sp.csr_matrix((np.ones(len(users), np.float32), (users, items)), shape=(U, I))      # duplicates summed
+    return O.csr_norm(m, True).tocsr(), O.csr_norm(m.T.tocsr(), True).tocsr()
+
+
+@pytest.mark.parametrize("U,I,n,hot", [(700, 500, 1024, 0), (3000, 900, 9000, 4000), (50, 40, 0, 0), (400, 300, 16384, 700)])
+def test_device_graph_pair_equals_scipy_rebuild_and_its_spmm(U, I, n, hot):
+    """A_ui / A_iu of one rebuild (main.py:378-405) from a pair list with duplicates and (hot > 0) one item chosen by
+    `hot` users — rows far beyond the 128- and 512-edge thresholds of the plan, i.e. multi-block rows combined in the
+    kernel — against scipy's csr_matrix + csr_norm; then SpMM in all four directions, the softmax epilogue, autograd."""
+    from mmssl_amd import ops
+    from mmssl_amd.graph import DeviceGraphPair
+    rng = np.random.default_rng(n + hot)
+    users = rng.integers(0, U, n)
+    items = rng.integers(0, I, n)
+    items[:hot] = 7
+    if n:
+        users[-5:] = users[0]
+        items[-5:] = items[0]                       # duplicates of one pair
+    pair = DeviceGraphPair(U, I, max(n, 1))
+    pair.rebuild(torch.from_numpy(users).to(DEV), torch.from_numpy(items).to(DEV))
+    ref_ui, ref_iu = _pairs_reference(users, items, U, I)
+    for plan, ref in ((pair.ui, ref_ui), (pair.iu, ref_iu)):
+        got = plan.export()
+        assert abs(got - ref).max() <= 2e-6 if ref.nnz else got.nnz == 0
+        got_t = plan.export(transpose=True)
+        assert abs(got_t - ref.T.tocsr()).max() <= 2e-6 if ref.nnz else got_t.nnz == 0
+    g = torch.Generator().manual_seed(1)
+    Xi, Xu = torch.randn(I, 64, generator=g), torch.randn(U, 64, generator=g)
+    for plan, ref, X in ((pair.ui, ref_ui, Xi), (pair.iu, ref_iu, Xu)):
+        Y = ops.spmm(plan, X.to(DEV)).cpu()
+        want = torch.from_numpy(ref @ X.numpy())
+        assert H.rel_err(Y, want) < 3e-6 if ref.nnz else float(Y.abs().max()) == 0.0
+        Xo = Xu if X is Xi else Xi
+        Yt = ops.spmm(plan, Xo.to(DEV), transpose=True).cpu()
+        want_t = torch.from_numpy(ref.T.tocsr() @ Xo.numpy())
+        assert H.rel_err(Yt, want_t) < 3e-6 if ref.nnz else float(Yt.abs().max()) == 0.0
+        assert torch.equal(ops.spmm(plan, X.to(DEV)).cpu(), Y)                 # bitwise reproducible
+    if n:
+        S = ops.spmm(pair.ui, Xi.to(DEV), epilogue=ops.EPI_SOFTMAX).cpu()
+        assert H.rel_err(S, torch.softmax(torch.from_numpy(ref_ui @ Xi.numpy()), -1)) < 3e-6
+        xg = Xi.clone().to(DEV).requires_grad_(True)
+        w = torch.randn(U, 64, generator=g)
+        (ops.spmm(pair.ui, xg) * w.to(DEV)).sum().backward()
+        assert H.rel_err(xg.grad.cpu(), torch.from_numpy(ref_ui.T.tocsr() @ w.numpy())) < 3e-6
+    # rebuild in place with other pairs: same buffers, new graph
+    users2, items2 = rng.integers(0, U, max(n // 2, 1)), rng.integers(0, I, max(n // 2, 1))
+    pair.rebuild(torch.from_numpy(users2).to(DEV), torch.from_numpy(items2).to(DEV))
+    r2_ui, _ = _pairs_reference(users2, items2, U, I)
+    assert abs(pair.ui.export() - r2_ui).max() <= 2e-6
+    assert H.rel_err(ops.spmm(pair.ui, Xi.to(DEV)).cpu(), torch.from_numpy(r2_ui @ Xi.numpy())) < 3e-6
+
+
+@pytest.mark.parametrize("tag", ["k1_T1", "k2_T1", "k2_T2"])
+def test_device_modal_graph_rebuild_matches_reference_loop(tag):
+    """G9 (recorded from the reference's own Trainer.train(): sims in, modal graphs out) through the DEVICE path of
+    Trainer._maintain_modal_graphs: top-k kernel -> pair tensors -> DeviceGraphPair.rebuild. The graphs it leaves for
+    the next batch must be the reference's (values to fp32 rounding; duplicates summed)."""
+    from mmssl_amd import config
+    from mmssl_amd.main import Trainer
+    from mmssl_amd.graph import GraphPlan
+    g = H.load("g9_modal_rebuild_%s.npz" % tag)
+    d, raw, U, I = H.dataset()
+    config.configure([], m_topk_rate=float(g["m_topk_rate"]), T=int(g["T"]))
+    tr = object.__new__(Trainer)
+    tr.n_users, tr.n_items, tr.device = U, I, torch.device(DEV)
+    tr._idx_cache, tr._empty_plans = (None, None), None
+    tr.image_ui_index, tr.text_ui_index = {"x": [], "y": []}, {"x": [], "y": []}
+    checked = 0
+    for b in range(int(g["n_batches"])):
+        for nm, attr in (("img_ui", "image_ui_graph"), ("img_iu", "image_iu_graph"), ("txt_ui", "text_ui_graph"),
+                         ("txt_iu", "text_iu_graph")):
+            cur = getattr(tr, attr, None)
+            if cur is None or isinstance(cur, GraphPlan):
+                continue                              # still the initial interaction graph (host plan)
+            shape = (U, I) if nm.endswith("ui") else (I, U)
+            want = sp.csr_matrix((g["b%d.%s_val" % (b, nm)], (g["b%d.%s_row" % (b, nm)], g["b%d.%s_col" % (b, nm)])), shape=shape)
+            got = cur.export()
+            assert got.shape == want.shape and (abs(got - want).max() <= 2e-6 if want.nnz else got.nnz == 0), (tag, b, nm)
+            assert cur.nnz == int(want.sum() > 0) * cur.nnz      # nnz (host view) is 0 exactly for empty rebuilds
+            checked += 1
+        users = [int(u) for u in g["b%d.users" % b]]
+        tr._maintain_modal_graphs(b, users, torch.from_numpy(g["b%d.img_sim" % b]).to(DEV),
+                                  torch.from_numpy(g["b%d.txt_sim" % b]).to(DEV))
+    assert checked >= 8
+    config.configure([])

@@ -329,6 +329,11 @@ size_t mmssl_infonce_workspace_bytes(int64_t n, int d);
 int mmssl_infonce_fwd_f32(const float* z1, const float* z2, const int64_t* idx, int64_t n, int d,
                           float tau, float* loss, void* workspace, size_t workspace_bytes,
                           void* stream);
+/* mmssl_infonce_fwd_f32 with a caller-chosen constant inside the logarithm (the trainer's variant uses 1e-8,
+ * main.py:244; Models.batched_contrastive_loss, Models.py:79-98, and the MICRO baseline use 0). Backward:
+ * mmssl_infonce_bwd_f32 on the same workspace. */
+int mmssl_infonce_fwd_eps_f32(const float* z1, const float* z2, const int64_t* idx, int64_t n, int d, float tau,
+                              float log_eps, float* loss, void* workspace, size_t workspace_bytes, void* stream);
 int mmssl_infonce_bwd_f32(const int64_t* idx, int64_t n, int d, float tau, const float* gloss,
                           float* gz1, float* gz2, void* workspace, size_t workspace_bytes,
                           void* stream);

@@ -104,6 +104,8 @@ SIGNATURES = {
     "mmssl_infonce_workspace_bytes": (c_size_t, [c_int64, c_int]),
     "mmssl_infonce_fwd_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_float, c_void_p, c_void_p,
                                       c_size_t, c_void_p]),
+    "mmssl_infonce_fwd_eps_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_float, c_float, c_void_p,
+                                          c_void_p, c_size_t, c_void_p]),
     "mmssl_infonce_bwd_f32": (c_int, [c_void_p, c_int64, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p,
                                       c_size_t, c_void_p]),
     "mmssl_infonce_multi_workspace_bytes": (c_size_t, [c_int, c_int64, c_int]),

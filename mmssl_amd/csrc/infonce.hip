@@ -213,7 +213,7 @@ __global__ __launch_bounds__(kBlock) void fwd_tiles_kernel(const float* __restri
 
 // ---- finalize: per-row backward coefficients (row-parallel) + loss (fixed-order two-stage sum) ----
 __global__ __launch_bounds__(kBlock) void finalize_rows_kernel(float* __restrict__ ws, size_t ws_stride, Layout L,
-                                                               int cs, int64_t n, float tau) {
+                                                               int cs, int64_t n, float tau, float log_eps) {
   float* __restrict__ wsp = ws + (size_t)blockIdx.y * ws_stride;
   const float* __restrict__ rows_part = wsp + L.rows_part;
   const float* __restrict__ pos = wsp + L.pos;
@@ -227,8 +227,8 @@ __global__ __launch_bounds__(kBlock) void finalize_rows_kernel(float* __restrict
     float Dn = 0.f;
     for (int s = 0; s < cs; ++s) Dn += rows_part[(size_t)s * n + i];
     const float q = expf(pos[i] / tau) / Dn;
-    li = -logf(q + 1e-8f);
-    const float wi = -(q / (q + 1e-8f)) / (float)n;
+    li = -logf(q + log_eps);
+    const float wi = -(q / (q + log_eps)) / (float)n;
     w[i] = wi;
     c[i] = wi / (Dn * tau);
   }
@@ -739,7 +739,8 @@ inline bool infonce_d_ok(int d) { return d == 32 || d == 64 || d == 128 || d == 
 namespace {
 
 int infonce_fwd_impl(const float* const* z1s, const float* z2, const int64_t* idx, int P, int64_t n, int d,
-                     float tau, float* losses, void* workspace, size_t workspace_bytes, void* stream) {
+                     float tau, float* losses, void* workspace, size_t workspace_bytes, void* stream,
+                     float log_eps = 1e-8f) {
   if (P < 1 || P > kMaxProblems || n <= 0 || !z1s || !z2 || !losses || !(tau > 0.f)) return MMSSL_E_BADARG;
   if (!infonce_d_ok(d)) return MMSSL_E_UNSUPP;
   const Layout L = make_layout(n, d);
@@ -769,7 +770,7 @@ int infonce_fwd_impl(const float* const* z1s, const float* z2, const int64_t* id
   }
   MMSSL_LAUNCH_CHECK();
   const int fb = (int)((n + kBlock - 1) / kBlock);
-  hipLaunchKernelGGL(finalize_rows_kernel, dim3(fb, P), dim3(kBlock), 0, s, ws, L.total, L, L.cs_f, n, tau);
+  hipLaunchKernelGGL(finalize_rows_kernel, dim3(fb, P), dim3(kBlock), 0, s, ws, L.total, L, L.cs_f, n, tau, log_eps);
   MMSSL_LAUNCH_CHECK();
   hipLaunchKernelGGL(finalize_loss_kernel, dim3(1, P), dim3(kBlock), 0, s, ws, L.total, L, fb, n, losses);
   MMSSL_LAUNCH_CHECK();
@@ -838,6 +839,18 @@ extern "C" int mmssl_infonce_fwd_f32(const float* z1, const float* z2, const int
                                      void* stream) {
   const float* z1s[1] = {z1};
   return infonce_fwd_impl(z1s, z2, idx, 1, n, d, tau, loss, workspace, workspace_bytes, stream);
+}
+
+// The same loss with a caller-chosen constant inside the logarithm: -log(b_ii / D_i + log_eps). The trainer's
+// variant (main.py:244) uses 1e-8; Models.batched_contrastive_loss of MMSSL (Models.py:79-98) and of the MICRO
+// baseline (MICRO/codes/Models.py:74-95) use none (log_eps = 0). The backward is mmssl_infonce_bwd_f32 (the
+// forward leaves the per-row coefficients, which already contain the constant, in the workspace).
+extern "C" int mmssl_infonce_fwd_eps_f32(const float* z1, const float* z2, const int64_t* idx, int64_t n, int d,
+                                         float tau, float log_eps, float* loss, void* workspace,
+                                         size_t workspace_bytes, void* stream) {
+  if (!(log_eps >= 0.f)) return MMSSL_E_BADARG;
+  const float* z1s[1] = {z1};
+  return infonce_fwd_impl(z1s, z2, idx, 1, n, d, tau, loss, workspace, workspace_bytes, stream, log_eps);
 }
 
 extern "C" int mmssl_infonce_bwd_f32(const int64_t* idx, int64_t n, int d, float tau, const float* gloss,

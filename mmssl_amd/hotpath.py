@@ -198,6 +198,16 @@ class SplitHotPath:
                 t.copy_(st["steps"][gi]) if gi in st["steps"] else t.zero_()
 
     def capture(self, warmup=2):
+        """Autograd binds a parameter's gradient accumulator to the stream on which the parameter first entered a
+        graph, for as long as any such graph is alive. Eager steps before this call ran on another stream, so their
+        graphs must be gone (callers keep detached losses only; gc below) or the captured backward would have to
+        synchronise with that stream inside the capture - hipStreamEndCapture segfaults on that (ROCm 7.2)."""
+        import gc
+        # the model caches tensors of its latest forward (feature-regulariser sum, id views): they carry that
+        # forward's graph - and through it the old accumulators, which every later forward would inherit
+        self.model._feat_sumsq = None
+        self.model.embedding_dict = {"user": {}, "item": {}}
+        gc.collect()
         self.model.train()
         s = self.stream
         s.wait_stream(torch.cuda.current_stream(self.device))
@@ -209,10 +219,7 @@ class SplitHotPath:
                     if self.extra_grads is None:
                         self.extra_grads = [torch.zeros_like(outs[k]) for k in (2, 3, 4, 5)]
                     self._backward(outs, total)
-                    # drop the warm-up's tensors NOW: released inside the capture region (when the names are rebound)
-                    # their blocks carry record_stream marks from the side streams and the allocator's bookkeeping
-                    # for them runs in the middle of the capture - hipStreamEndCapture then segfaults (ROCm 7.2)
-                    del outs, terms, total
+                    del outs, terms, total          # nothing of the warm-up is released inside the capture region
             torch.cuda.synchronize()
             gF, gB = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
             with torch.cuda.graph(gF, stream=s, capture_error_mode="thread_local"):

@@ -317,7 +317,10 @@ class Trainer(object):
         self.optimizer_D.zero_grad()
         L["batch_loss"].backward(retain_graph=False)
         self.optimizer_D.step()
-        return L["batch_loss"], L["mf"], L["emb"], L["reg"], L["cl1"] + L["cl2"], L["G_lossf"]
+        # detached: a returned loss that still carried its autograd graph would keep the parameters' gradient
+        # accumulators (bound to THIS stream) alive into a later hipGraph capture on another stream
+        det = lambda t: t.detach() if torch.is_tensor(t) else t      # noqa: E731
+        return (det(L["batch_loss"]), det(L["mf"]), det(L["emb"]), L["reg"], det(L["cl1"] + L["cl2"]), det(L["G_lossf"]))
 
     # ---- the same batch on the captured hot path ---------------------------------------------------
     def _steady_state(self):
@@ -335,6 +338,12 @@ class Trainer(object):
             return None
         cap = getattr(self, "_split", None)
         if cap is None:
+            # the first steady-state batch still runs op by op: everything a steady-state step allocates on first
+            # use (cached zero views of the empty modal graphs, workspaces of the empty plans) then exists before the
+            # capture
+            self._steady_seen = getattr(self, "_steady_seen", 0) + 1
+            if self._steady_seen < 2:
+                return None
             from .hotpath import SplitHotPath
             cap = SplitHotPath(self.model, self._graphs(), self.optimizer_D, self.batch_size, self.decay,
                                [1.0, 1.0, 1.0, args.cl_rate, args.cl_rate], args.feat_reg_decay * 0.5 / self.n_items)

@@ -318,8 +318,8 @@ class _Linear(torch.autograd.Function):
                     _lib.check(rc, "mmssl_mask_scale_f32")
             # gF = gY @ W  ([M,N] x [N,K]); used by the small modality-fusion product (K = d).
             # The raw feature matrices are constants in the reference (Models.py:46-47).
-            if F_.shape[1] > 256:
-                raise _lib.MmsslError("linear: input gradient only supported for K <= 256")
+            if F_.shape[1] > 256 and W.shape[0] % 32 != 0:
+                raise _lib.MmsslError("linear: the input gradient of a wide input (K > 256) needs N % 32 == 0")
             gF = _linear_raw(gY, W.t().contiguous(), None, None, 1.0)      # gY already masked
         return gF, gW, (gb if ctx.has_bias else None), None, None
 
@@ -421,7 +421,7 @@ def linear(F_, W, b=None, keep=None, scale=1.0):
 # ---------------------------------------------------------------------------------------
 # InfoNCE                       Trainer.sim + batched_contrastive_loss, main.py:211-249
 # ---------------------------------------------------------------------------------------
-def _infonce_fwd_raw(z1, z2, idx, tau, loss=None):
+def _infonce_fwd_raw(z1, z2, idx, tau, loss=None, log_eps=1e-8):
     n = z1.shape[0] if idx is None else idx.shape[0]
     d = z1.shape[1]
     nb = _lib.lib().mmssl_infonce_workspace_bytes(n, d)
@@ -430,9 +430,9 @@ def _infonce_fwd_raw(z1, z2, idx, tau, loss=None):
     ws = torch.empty(nb // 4, dtype=torch.float32, device=z1.device)
     if loss is None:
         loss = torch.empty((), dtype=torch.float32, device=z1.device)
-    rc = _lib.lib().mmssl_infonce_fwd_f32(_ptr(z1), _ptr(z2), _ptr(idx), n, d, float(tau), _ptr(loss), _ptr(ws), nb,
-                                          _lib.stream_ptr())
-    _lib.check(rc, "mmssl_infonce_fwd_f32")
+    rc = _lib.lib().mmssl_infonce_fwd_eps_f32(_ptr(z1), _ptr(z2), _ptr(idx), n, d, float(tau), float(log_eps), _ptr(loss),
+                                              _ptr(ws), nb, _lib.stream_ptr())
+    _lib.check(rc, "mmssl_infonce_fwd_eps_f32")
     return loss, ws, n, d
 
 
@@ -444,11 +444,11 @@ def _infonce_bwd_raw(idx, n, d, tau, g, gz1, gz2, ws):
 
 class _InfoNCE(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, z1, z2, idx, tau):
+    def forward(ctx, z1, z2, idx, tau, log_eps=1e-8):
         z1, z2 = _chk(z1, "z1"), _chk(z2, "z2")
         if z1.dim() != 2 or z2.dim() != 2 or z1.shape[1] != z2.shape[1] or (idx is None and z1.shape != z2.shape):
             raise _lib.MmsslError("infonce: z1/z2 must be [n, d] (or tables + idx)")
-        loss, ws, n, d = _infonce_fwd_raw(z1, z2, idx, tau)
+        loss, ws, n, d = _infonce_fwd_raw(z1, z2, idx, tau, log_eps=log_eps)
         ctx.save_for_backward(ws, idx)
         ctx.cfg = (n, d, float(tau), z1.shape, z2.shape)
         return loss
@@ -463,14 +463,15 @@ class _InfoNCE(torch.autograd.Function):
         gz2 = alloc(s2, dtype=torch.float32, device=ws.device) if ctx.needs_input_grad[1] else None
         if gz1 is not None or gz2 is not None:
             _infonce_bwd_raw(idx, n, d, tau, g, gz1, gz2, ws)
-        return gz1, gz2, None, None
+        return gz1, gz2, None, None, None
 
 
-def infonce(z1, z2, tau=0.5, idx=None):
+def infonce(z1, z2, tau=0.5, idx=None, log_eps=1e-8):
     """The reference's batched_contrastive_loss(z1, z2) (its 1024-row blocking is exactly the
     full-matrix formula). With `idx` (int64 [n]) z1/z2 are whole tables and the
-    gather table[idx] is fused into the kernels (main.py:411-412 gathers both by `users`)."""
-    return _InfoNCE.apply(z1, z2, None if idx is None else _idx(idx, "idx", z1.device), tau)
+    gather table[idx] is fused into the kernels (main.py:411-412 gathers both by `users`).
+    `log_eps`: the constant inside the log (1e-8 in the trainer, main.py:244; 0 in Models.py:79-98 and MICRO)."""
+    return _InfoNCE.apply(z1, z2, None if idx is None else _idx(idx, "idx", z1.device), tau, float(log_eps))
 
 
 # ---------------------------------------------------------------------------------------

@@ -4,6 +4,7 @@ import math
 
 import numpy as np
 import pytest
+import scipy.sparse as sp
 import torch
 
 import helpers as H
@@ -295,3 +296,59 @@ def test_trainer_captured_hot_path_matches_eager_trainer(tmp_path):
     np.testing.assert_allclose(got_l, ref_l, rtol=2e-5, atol=1e-7)
     for k in ref_P:
         assert H.rel_err(got_P[k], ref_P[k]) < 2e-5, k
+
+
+# ---------------------------------------------------------------------------------------------------
+# f-4: the LATTICE / MICRO baselines (mmssl_amd/baselines.py) against goldens recorded from the reference classes
+# ---------------------------------------------------------------------------------------------------
+def _baseline_case(name):
+    fx = H.load("g1%d_%s_lightgcn.npz" % (0 if name == "lattice" else 1, name))
+    U, I = int(fx["n_users"]), int(fx["n_items"])
+    A = sp.csr_matrix((fx["adj_val"], (fx["adj_row"], fx["adj_col"])), shape=(U + I, U + I))
+    from mmssl_amd.graph import GraphPlan
+    return fx, U, I, GraphPlan(A)
+
+
+def _cot(U, I, D=64):
+    i_ = np.arange(U + I, dtype=np.float64)[:, None]
+    j_ = np.arange(D, dtype=np.float64)[None, :]
+    return torch.from_numpy(np.sin(0.37 * i_ + 1.3 * j_).astype(np.float32)).to(DEV)
+
+
+@pytest.mark.parametrize("name", ["lattice", "micro"])
+def test_baselines_match_reference_classes(name):
+    """G10 / G11: forward(adj, build_item_graph=True) of the reference's LATTICE / MICRO (lightgcn) on a tiny problem:
+    every output, MICRO's contrastive loss, and the gradients that flow through the LEARNED item graph (projection
+    weights, modal weights / attention query, id embeddings)."""
+    from mmssl_amd import baselines
+    fx, U, I, plan = _baseline_case(name)
+    cls = baselines.LATTICE if name == "lattice" else baselines.MICRO
+    model = cls(U, I, 64, [64, 64], [0.1, 0.1], fx["image_feat"], fx["text_feat"], topk=int(fx["topk"]))
+    missing = model.load_state_dict({k[2:]: torch.from_numpy(fx[k]) for k in fx.files if k.startswith("p.")}, strict=True)
+    model = model.to(DEV).train()
+    outs = model(plan, build_item_graph=True)
+    names = ["ua", "ia"] if name == "lattice" else ["ua", "ia", "image_item", "text_item", "h"]
+    assert len(outs) == len(names)
+    for n, o in zip(names, outs):
+        assert H.rel_err(o.detach().cpu(), fx["o." + n]) < 2e-5, (n, H.rel_err(o.detach().cpu(), fx["o." + n]))
+    cot = _cot(U, I)
+    scalar = (outs[0] * cot[:U]).sum() + (outs[1] * cot[U:]).sum()
+    if name == "micro":
+        cl = model.batched_contrastive_loss(outs[2], outs[4]) + model.batched_contrastive_loss(outs[3], outs[4])
+        assert abs(float(cl) - float(fx["cl"])) <= 1e-4 * abs(float(fx["cl"]))
+        scalar = scalar + 0.03 * cl
+    assert abs(float(scalar) - float(fx["scalar"])) <= 1e-4 * abs(float(fx["scalar"]))
+    scalar.backward()
+    checked = 0
+    for k in fx.files:
+        if k.startswith("g."):
+            e = H.rel_err(model.get_parameter(k[2:]).grad.cpu(), fx[k])
+            assert e < 5e-4, (k, e)
+            checked += 1
+    assert checked >= 6
+    # a second forward without rebuilding keeps the (detached) graph: same values, no gradient into the projections
+    model.zero_grad()
+    outs2 = model(plan, build_item_graph=False)
+    assert H.rel_err(outs2[1].detach().cpu(), fx["o.ia"]) < 2e-5
+    outs2[1].sum().backward()
+    assert model.image_trs.weight.grad is None or float(model.image_trs.weight.grad.abs().max()) == 0.0

@@ -22,7 +22,7 @@ set_seed(2022)
 tr = Trainer(data_config={})
 dg = tr.data_generator
 os.environ["MMSSL_TRAINER_GRAPH"] = "0"
-for idx in range(3):
+for idx in range(int(os.environ.get("EAGER_BATCHES", "3"))):
     tr.model.train(); u, p, n = dg.sample(); tr.train_batch(idx, u, p, n)
 torch.cuda.synchronize()
 assert tr._steady_state()
@@ -92,7 +92,7 @@ torch.cuda.synchronize()
 g.replay(); torch.cuda.synchronize()
 print("OK", variant, flush=True)
 ''' % (ROOT, ROOT, ROOT)
-for env, variant in (({}, "bis-noopt"), ({}, "bis-optonly"), ({}, "bis-oneroot"), ({}, "bis-keepgrads"), ({}, "bis-full")):
+for env, variant in (({"EAGER_BATCHES": "3"}, "cap-2"), ({"EAGER_BATCHES": "2"}, "cap-2")):
     e = dict(os.environ); e.update(env)
     r = subprocess.run([sys.executable, "-c", CHILD, variant], env=e, capture_output=True, text=True, timeout=300)
     tail = [l for l in (r.stdout + r.stderr).splitlines() if l.strip() and "amdgpu.ids" not in l][-6:]

@@ -295,6 +295,13 @@ int mmssl_adamw_f32(float* const* params, const float* const* grads, float* cons
  * main.py:420 in one launch (terms / w / extra are device arrays; extra may be NULL). */
 int mmssl_loss_assemble_f32(const float* terms, const float* w, int n, const float* extra, float c,
                             float* total, void* stream);
+/* Batch rows of a row-sharded table (no reference counterpart: the reference is single-GPU):
+ * out[j, :] = table[idx[j] - lo, :] if lo <= idx[j] < lo + rows_local else 0 (d % 4 == 0), and its adjoint
+ * gtable[idx[j] - lo, :] += g[j, :] for the rows this rank owns (gtable pre-zeroed; fp32 atomics). */
+int mmssl_gather_owned_rows_f32(const float* table, int64_t rows_local, int d, const int64_t* idx, int64_t n,
+                                int64_t lo, float* out, void* stream);
+int mmssl_scatter_owned_rows_f32(const float* g, const int64_t* idx, int64_t n, int64_t lo, int64_t rows_local,
+                                 int d, float* gtable, void* stream);
 /* The same launch also advances up to 4 float and 4 uint64 device counters by one (the AdamW step counters and
  * the dropout launch counter of a whole captured step: see the *_ex entry points, external_tick = 1). */
 int mmssl_loss_assemble_tick_f32(const float* terms, const float* w, int n, const float* extra, float c,

@@ -94,6 +94,8 @@ SIGNATURES = {
     "mmssl_dropout_mask_u8": (c_int, [c_void_p, c_float, c_int64, c_void_p, c_void_p]),
     "mmssl_adamw_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_float, c_float,
                                 c_float, c_float, c_float, c_void_p]),
+    "mmssl_gather_owned_rows_f32": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_int64, c_int64, c_void_p, c_void_p]),
+    "mmssl_scatter_owned_rows_f32": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int, c_void_p, c_void_p]),
     "mmssl_loss_assemble_tick_f32": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_float, c_void_p, c_void_p, c_int,
                                              c_void_p, c_int, c_void_p]),
     "mmssl_adamw_ex_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_float, c_float,

@@ -31,7 +31,9 @@ TOPK, LAMBDA, N_LAYERS = 10, 0.9, 1          # the reference's parser defaults (
 
 
 def _cosine_rows(x):
-    return ops.l2norm_rows(x)
+    """Row-normalised copy: the row kernel for embedding widths (32 / 64 / 128 / 256), torch for the raw feature
+    widths of the one-time original graphs."""
+    return ops.l2norm_rows(x) if x.shape[1] in (32, 64, 128, 256) else F.normalize(x, p=2, dim=1)
 
 
 def knn_lists(context, topk):

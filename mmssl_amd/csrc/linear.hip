@@ -308,7 +308,7 @@ __global__ __launch_bounds__(kBlock) void gemm_sk_kernel(const float* __restrict
                                                          float* __restrict__ C, int64_t ldc,
                                                          const float* __restrict__ bias,
                                                          const uint8_t* __restrict__ keep, float scale,
-                                                         float* __restrict__ partials) {
+                                                         float* __restrict__ partials, int prio) {
   __shared__ __attribute__((aligned(16))) float ring[kDmaStages * kDmaStageFloats];     // 64 KB
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
@@ -401,7 +401,9 @@ __global__ __launch_bounds__(kBlock) void gemm_sk_kernel(const float* __restrict
       issue(kt + 4);
       read_frags(kt + 1, nxt);
       __builtin_amdgcn_sched_barrier(0);
+      if (prio) __builtin_amdgcn_s_setprio(3);     // MMSSL_GEMM_PRIO=1 (experiment): MFMA chain outranks the partner wave
       mfma16(cur);
+      if (prio) __builtin_amdgcn_s_setprio(0);
       __builtin_amdgcn_sched_barrier(0);
     };
     Frag f0, f1;
@@ -628,6 +630,7 @@ __global__ __launch_bounds__(kPpThreads) void gemm_pp_kernel(const float* __rest
     for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
     auto compute = [&]() {
       if (dbg & 2) return;
+      if (dbg & 8) __builtin_amdgcn_s_setprio(3);        // experiment: the computing wave outranks its SIMD partner
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int q = 0; q < NQ; ++q) {
@@ -641,6 +644,7 @@ __global__ __launch_bounds__(kPpThreads) void gemm_pp_kernel(const float* __rest
         acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[q].w, fb1[q].w, acc1, 0, 0, 0);
       }
       __builtin_amdgcn_sched_barrier(0);
+      if (dbg & 8) __builtin_amdgcn_s_setprio(0);
     };
     // loading role of phase p (p may be -1): fragments of slice p+1, slice p+2 must have landed, slice p+D is issued
     auto load_steady = [&](int p) {            // requires p + D < nk
@@ -1185,8 +1189,10 @@ extern "C" int mmssl_linear_f32(const float* F, const float* W, const float* b, 
     const SkPlan p = sk_plan(M, N, K);
     if (!workspace || workspace_bytes < (size_t)p.blocks * 2 * kSkTileFloats * sizeof(float)) return MMSSL_E_WORKSPACE;
     float* part = reinterpret_cast<float*>(workspace);
+    const char* pr = getenv("MMSSL_GEMM_PRIO");
     hipLaunchKernelGGL(gemm_sk_kernel, dim3((unsigned)p.blocks), dim3(kBlock), 0, s, F, (int64_t)K, W, (int64_t)K, M,
-                       (int64_t)N, (int)p.tiles_j, p.S, p.total, p.upb, Y, (int64_t)N, b, keep, scale, part);
+                       (int64_t)N, (int)p.tiles_j, p.S, p.total, p.upb, Y, (int64_t)N, b, keep, scale, part,
+                       pr ? atoi(pr) : 0);
     MMSSL_LAUNCH_CHECK();
     if (p.upb % p.S != 0) {        // some range ends inside a tile: partial slots exist
       hipLaunchKernelGGL(sk_reduce_kernel, dim3((unsigned)(p.tiles_i * p.tiles_j)), dim3(kBlock), 0, s, part,

@@ -415,3 +415,58 @@ extern "C" int mmssl_mask_scale_f32(const float* g, const uint8_t* keep, float s
   MMSSL_LAUNCH_CHECK();
   return 0;
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Rows of a ROW-SHARDED table for a batch of global indices (mmssl_amd/dist.py: the batch rows of BPR / InfoNCE
+// are assembled from the row owners by an all-reduce of zero-padded buffers): out[j] = table[idx[j] - lo] when this
+// rank owns row idx[j] (lo <= idx[j] < lo + rows_local), else zeros. The backward scatter-adds the gradient rows this
+// rank owns into its (pre-zeroed) table gradient with hardware fp32 atomics (a batch may name a row twice).
+// ---------------------------------------------------------------------------------------------------------------
+namespace {
+__global__ __launch_bounds__(kBlock) void gather_owned_rows_kernel(const float4* __restrict__ table, int64_t rows_local,
+                                                                   int d4, const int64_t* __restrict__ idx, int64_t n,
+                                                                   int64_t lo, float4* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n * d4) return;
+  const int64_t j = i / d4;
+  const int c = (int)(i - j * d4);
+  const int64_t r = idx[j] - lo;
+  out[i] = (r >= 0 && r < rows_local) ? table[r * d4 + c] : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+__global__ __launch_bounds__(kBlock) void scatter_owned_rows_kernel(const float* __restrict__ g, int d,
+                                                                    const int64_t* __restrict__ idx, int64_t n,
+                                                                    int64_t lo, int64_t rows_local,
+                                                                    float* __restrict__ gtable) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n * d) return;
+  const int64_t j = i / d;
+  const int c = (int)(i - j * d);
+  const int64_t r = idx[j] - lo;
+  if (r >= 0 && r < rows_local) atomicAdd(gtable + r * d + c, g[i]);
+}
+}  // namespace
+
+extern "C" int mmssl_gather_owned_rows_f32(const float* table, int64_t rows_local, int d, const int64_t* idx, int64_t n,
+                                           int64_t lo, float* out, void* stream) {
+  if (rows_local < 0 || n < 0 || d <= 0 || (d & 3)) return MMSSL_E_BADARG;
+  if (n == 0) return 0;
+  if (!table || !idx || !out || (((uintptr_t)table | (uintptr_t)out) & 15)) return MMSSL_E_BADARG;
+  const int64_t total = n * (d / 4);
+  hipLaunchKernelGGL(gather_owned_rows_kernel, dim3((unsigned)((total + kBlock - 1) / kBlock)), dim3(kBlock), 0,
+                     as_stream(stream), reinterpret_cast<const float4*>(table), rows_local, d / 4, idx, n, lo,
+                     reinterpret_cast<float4*>(out));
+  MMSSL_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int mmssl_scatter_owned_rows_f32(const float* g, const int64_t* idx, int64_t n, int64_t lo, int64_t rows_local,
+                                            int d, float* gtable, void* stream) {
+  if (rows_local < 0 || n < 0 || d <= 0) return MMSSL_E_BADARG;
+  if (n == 0) return 0;
+  if (!g || !idx || !gtable) return MMSSL_E_BADARG;
+  const int64_t total = n * d;
+  hipLaunchKernelGGL(scatter_owned_rows_kernel, dim3((unsigned)((total + kBlock - 1) / kBlock)), dim3(kBlock), 0,
+                     as_stream(stream), g, d, idx, n, lo, rows_local, gtable);
+  MMSSL_LAUNCH_CHECK();
+  return 0;
+}

@@ -53,6 +53,18 @@ class HipBackend:
         self.loss_assemble = ops.loss_assemble
         self._ar = {}
 
+    def gather_owned(self, table, idx, lo, out):
+        from . import _lib
+        rc = _lib.lib().mmssl_gather_owned_rows_f32(table.data_ptr(), table.shape[0], table.shape[1], idx.data_ptr(),
+                                                    idx.shape[0], int(lo), out.data_ptr(), _lib.stream_ptr())
+        _lib.check(rc, "mmssl_gather_owned_rows_f32")
+
+    def scatter_owned(self, g, idx, lo, gtable):
+        from . import _lib
+        rc = _lib.lib().mmssl_scatter_owned_rows_f32(g.data_ptr(), idx.data_ptr(), idx.shape[0], int(lo), gtable.shape[0],
+                                                     gtable.shape[1], gtable.data_ptr(), _lib.stream_ptr())
+        _lib.check(rc, "mmssl_scatter_owned_rows_f32")
+
     def side_streams(self, device):
         """Three side streams for the sharded node's chains (the same objects ops._HotForward forks)."""
         if os.environ.get("MMSSL_DIST_STREAMS", "1") == "0":
@@ -187,38 +199,56 @@ class GatherBatchRows(torch.autograd.Function):
 
 class GatherBatchRowsMulti(torch.autograd.Function):
     """Several (table, idx) row gathers with ONE all-reduce: the [B_k, d] pieces are packed into one
-    buffer (each row still has exactly one non-zero contributor, so the sum is exact)."""
+    buffer (each row has exactly one non-zero contributor, so the sum is exact). With a backend that has the
+    owned-row kernels (HipBackend) every piece is ONE launch forward and one backward; the generic form (CPU / gloo
+    tests) composes torch index ops."""
 
     @staticmethod
-    def forward(ctx, group, n, *args):
+    def forward(ctx, group, n, bk, *args):
         tables, idxs, los = args[:n], args[n:2 * n], args[2 * n:3 * n]
-        pieces, meta = [], []
-        for t, idx, lo in zip(tables, idxs, los):
-            per = t.shape[0]
-            mine = (idx >= lo) & (idx < lo + per)
-            local = (idx - lo).clamp(0, per - 1)
-            pieces.append(t[local] * mine.unsqueeze(1).to(t.dtype))
-            meta.append((local, mine, per))
-        packed = torch.cat(pieces, 0)
+        fast = bk is not None and hasattr(bk, "gather_owned") and tables[0].is_cuda
+        sizes = [int(i.shape[0]) for i in idxs]
+        if fast:
+            d = tables[0].shape[1]
+            packed = torch.empty((sum(sizes), d), dtype=tables[0].dtype, device=tables[0].device)
+            o = 0
+            for t, idx, lo, sz in zip(tables, idxs, los, sizes):
+                bk.gather_owned(t.detach().contiguous(), idx, lo, packed[o:o + sz])
+                o += sz
+            ctx.meta = [(idx, lo, t.shape[0]) for t, idx, lo in zip(tables, idxs, los)]
+        else:
+            pieces, meta = [], []
+            for t, idx, lo in zip(tables, idxs, los):
+                per = t.shape[0]
+                mine = (idx >= lo) & (idx < lo + per)
+                local = (idx - lo).clamp(0, per - 1)
+                pieces.append(t[local] * mine.unsqueeze(1).to(t.dtype))
+                meta.append((local, mine, per))
+            packed = torch.cat(pieces, 0)
+            ctx.meta = meta
         _all_reduce(packed, group)
         _log_comm("all_reduce", packed)
-        ctx.meta = meta
-        sizes = [p.shape[0] for p in pieces]
-        ctx.sizes = sizes
+        ctx.fast, ctx.bk = fast, bk
         return tuple(packed.split(sizes, 0))
 
     @staticmethod
     def backward(ctx, *gs):
         outs = []
-        for g, (local, mine, per) in zip(gs, ctx.meta):
+        for g, m in zip(gs, ctx.meta):
             if g is None:
                 outs.append(None)
                 continue
-            o = torch.zeros((per, g.shape[1]), dtype=g.dtype, device=g.device)
-            o.index_add_(0, local, g * mine.unsqueeze(1).to(g.dtype))
+            if ctx.fast:
+                idx, lo, per = m
+                o = torch.zeros((per, g.shape[1]), dtype=g.dtype, device=g.device)
+                ctx.bk.scatter_owned(g.contiguous(), idx, lo, o)
+            else:
+                local, mine, per = m
+                o = torch.zeros((per, g.shape[1]), dtype=g.dtype, device=g.device)
+                o.index_add_(0, local, g * mine.unsqueeze(1).to(g.dtype))
             outs.append(o)
         n = len(ctx.meta)
-        return (None, None) + tuple(outs) + (None,) * (2 * n)
+        return (None, None, None) + tuple(outs) + (None,) * (2 * n)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -256,9 +286,15 @@ class ShardedMMSSL(nn.Module):
             bk.ops.register_transposed_features(self.image_feats)
             bk.ops.register_transposed_features(self.text_feats)
         if modal_empty:
-            img_uid = txt_uid = torch.zeros_like(self.E_u)
-            img_iid = txt_iid = torch.zeros_like(self.E_i)
-            u, i = self.E_u + 0 * self.w_cat.sum(), self.E_i      # zero (not missing) gradient for w_cat
+            z = getattr(self, "_zero_views", None)
+            if z is None or z[0].device != self.E_u.device:
+                z = self._zero_views = (torch.zeros_like(self.E_u), torch.zeros_like(self.E_i))
+            img_uid = txt_uid = z[0]
+            img_iid = txt_iid = z[1]
+            if hasattr(bk, "ops"):       # zero (not missing) gradient for w_cat, without arithmetic on the tables
+                u, i = bk.ops.zero_grad_anchor(self.E_u, self.w_cat), self.E_i
+            else:
+                u, i = self.E_u + 0 * self.w_cat.sum(), self.E_i
         else:
             Ei_full, Eu_full = self._gather(self.E_i), self._gather(self.E_u)
             img_uid, img_iid = bk.spmm(img_ui, Ei_full), bk.spmm(img_iu, Eu_full)
@@ -487,45 +523,51 @@ class _ShardedHotForward(torch.autograd.Function):
                         t.record_stream(s_)
         out = {}
 
-        def rs(full, per, k):            # reduce-scatter of a full-height partial to the row owners
-            _log_comm("reduce_scatter", full)
-            return _reduce_scatter_sum(full, per, g)
+        solo = _solo(g) and hasattr(bk, "ops")
+        EPI_AXPY = 2                      # ops.EPI_AXPY: y = A^T.x + alpha * Z fused into the SpMM store
+
+        def t_add(plan, x, per, k, Z, alpha):
+            """reduce_scatter(A_r^T . x) + alpha * Z. One rank: the scatter is the identity and the add rides in the
+            SpMM's epilogue (as in the unsharded node); else SpMM -> reduce-scatter -> one fused add."""
+            if solo:
+                _log_comm("reduce_scatter", Z)
+                return bk.spmm_raw(plan, True, x, EPI_AXPY, Z, alpha)
+            part = bk.spmm_raw(plan, True, x, bk.EPI_NONE)
+            _log_comm("reduce_scatter", part)
+            return torch.add(_reduce_scatter_sum(part, per, g), Z, alpha=alpha)
+
+        def t_plain(plan, x, per, k):
+            part = bk.spmm_raw(plan, True, x, bk.EPI_NONE)
+            _log_comm("reduce_scatter", part)
+            return _reduce_scatter_sum(part, per, g)
 
         def modal_chain(k, g_item, g_user, keep, F_, W, key):
             # g(x) = A_ui_r^T . (A_iu_r^T . g(item feats) + g(user feats)), each A_r^T product reduce-scattered
-            with st.on(k):
-                part = bk.spmm_raw(twin(iu, k), True, g_item, bk.EPI_NONE)
             yield
             with st.on(k):
-                gu_ = rs(part, per_u, k) + g_user
-                part = bk.spmm_raw(twin(ui, k), True, gu_, bk.EPI_NONE)
+                gu_ = t_add(twin(iu, k), g_item, per_u, k, g_user, 1.0)
             yield
             with st.on(k):
-                gx = rs(part, per_i, k)
+                gx = t_plain(twin(ui, k), gu_, per_i, k)
                 _, gW, gb = bk.linear_wgrad_raw(gx, keep, scale, F_, W)
             out[key] = (gW, gb)
 
         def gcn_chain():
             with st.on(2):
                 gi = bk.softmax_rows_bwd(iG, Gi, inv)
-                part = bk.spmm_raw(twin(iu, 2), True, gi, bk.EPI_NONE)
             yield
             with st.on(2):
-                gu = bk.softmax_rows_bwd(uG, rs(part, per_u, 2) + inv * Gu, 1.0)
-                part = bk.spmm_raw(twin(ui, 2), True, gu, bk.EPI_NONE)
+                gu = bk.softmax_rows_bwd(uG, t_add(twin(iu, 2), gi, per_u, 2, Gu, inv), 1.0)
             yield
             with st.on(2):
-                gi = rs(part, per_i, 2) + inv * Gi
+                gi = t_add(twin(ui, 2), gu, per_i, 2, Gi, inv)
             for _ in range(n_layers - 1):
-                with st.on(2):
-                    part = bk.spmm_raw(twin(iu, 2), True, gi, bk.EPI_NONE)
                 yield
                 with st.on(2):
-                    gu = rs(part, per_u, 2) + inv * Gu
-                    part = bk.spmm_raw(twin(ui, 2), True, gu, bk.EPI_NONE)
+                    gu = t_add(twin(iu, 2), gi, per_u, 2, Gu, inv)
                 yield
                 with st.on(2):
-                    gi = rs(part, per_i, 2) + inv * Gi
+                    gi = t_add(twin(ui, 2), gu, per_i, 2, Gi, inv)
             out["gi"] = gi
 
         st.fork()
@@ -579,12 +621,15 @@ class ShardedHotPathStep:
         m, bk, c, g = self.model, self.model.bk, self.model.cfg, self.group
         o = m(self.graphs, keep_masks=keep_masks, modal_empty=self.modal_empty, fused=self.fused)
         if self.modal_empty:       # the id views are exact zeros: nothing to gather for them
-            u, p, n = GatherBatchRowsMulti.apply(g, 3, o[0], o[1], o[1], self.users, self.pos, self.neg,
+            u, p, n = GatherBatchRowsMulti.apply(g, 3, bk, o[0], o[1], o[1], self.users, self.pos, self.neg,
                                                  m.ush.lo, m.ish.lo, m.ish.lo)
-            z_img = z_txt = torch.zeros_like(u)
+            zc = getattr(self, "_zero_rows", None)
+            if zc is None or zc.shape != u.shape or zc.device != u.device:
+                zc = self._zero_rows = torch.zeros_like(u)
+            z_img = z_txt = zc
         else:
             u, p, n, z_img, z_txt = GatherBatchRowsMulti.apply(
-                g, 5, o[0], o[1], o[1], o[8], o[9], self.users, self.pos, self.neg, self.users, self.users,
+                g, 5, bk, o[0], o[1], o[1], o[8], o[9], self.users, self.pos, self.neg, self.users, self.users,
                 m.ush.lo, m.ish.lo, m.ish.lo, m.ush.lo, m.ush.lo)
         if self.fused:
             # one fused loss node + one-launch assembly; the regulariser enters with this rank's local sum
@@ -616,15 +661,25 @@ class ShardedHotPathStep:
         local_total.backward()
         # replicated dense parameters: partial (local-row) gradients -> one bucketed all-reduce
         params = [p for p in self.model.replicated_parameters() if p.grad is not None]
+        solo = _solo(self.group)
         if params:
-            flat = torch.cat([p.grad.reshape(-1) for p in params])
-            _all_reduce(flat, self.group)
-            _log_comm("all_reduce", flat)
-            k = 0
-            for p in params:
-                n = p.grad.numel()
-                p.grad.copy_(flat[k:k + n].view_as(p.grad))
-                k += n
+            if solo:                     # one rank: the local gradients ARE the global ones (only the accounting stays)
+                if COMM["log"] is not None:
+                    COMM["log"].append(("all_reduce", (sum(p.grad.numel() for p in params),),
+                                        4 * sum(p.grad.numel() for p in params)))
+            else:
+                flat = torch.cat([p.grad.reshape(-1) for p in params])
+                _all_reduce(flat, self.group)
+                _log_comm("all_reduce", flat)
+                k = 0
+                for p in params:
+                    n = p.grad.numel()
+                    p.grad.copy_(flat[k:k + n].view_as(p.grad))
+                    k += n
+        if solo:
+            _log_comm("all_reduce", feat_local)
+            self.loss.copy_(local_total.detach())
+            return self.loss
         feat = feat_local.detach().clone()
         _all_reduce(feat, self.group)
         _log_comm("all_reduce", feat)

@@ -221,6 +221,9 @@ class Trainer(object):
         store = self.__dict__.setdefault("_dev_pairs", {"image": [], "text": []})
         if idx % args.T == 0 and idx != 0:
             for name in ("image", "text"):
+                if not store[name]:             # nothing collected: the cached empty plans (no launches at all)
+                    self._set_empty_modal(name)
+                    continue
                 pair = self.__dict__.setdefault("_dev_graphs", {}).get(name)
                 if pair is None:
                     pair = DeviceGraphPair(self.n_users, self.n_items, DeviceGraphPair.MAX_PAIRS)
@@ -238,6 +241,13 @@ class Trainer(object):
                 ids = ops.topk_rows(s, k)                       # [B, k], descending score, lowest id on ties
                 # the reference pairs the user list TILED k times with the row-major top-k ids (tensor.repeat(1, k))
                 store[name].append((u.repeat(k), ids.reshape(-1)))
+
+    def _set_empty_modal(self, name):
+        if self._empty_plans is None:
+            e = sp.csr_matrix((self.n_users, self.n_items), dtype=np.float32)
+            self._empty_plans = (self.matrix_to_tensor(e), self.matrix_to_tensor(e.T.tocsr()))
+        setattr(self, name + "_ui_graph", self._empty_plans[0])
+        setattr(self, name + "_iu_graph", self._empty_plans[1])
 
     def _device_graphs_ok(self, k, n_batch_users):
         from .graph import DeviceGraphPair
@@ -258,11 +268,7 @@ class Trainer(object):
                 if not store["x"]:
                     # nothing collected (the reference's steady state from the third batch on):
                     # the rebuilt graphs are empty; reuse one empty plan pair instead of 4 scipy + plan builds
-                    if self._empty_plans is None:
-                        e = sp.csr_matrix(shape, dtype=np.float32)
-                        self._empty_plans = (self.matrix_to_tensor(e), self.matrix_to_tensor(e.T.tocsr()))
-                    setattr(self, name + "_ui_graph", self._empty_plans[0])
-                    setattr(self, name + "_iu_graph", self._empty_plans[1])
+                    self._set_empty_modal(name)
                     continue
                 tmp = sp.csr_matrix((np.ones(len(store["x"]), np.float32), (store["x"], store["y"])), shape=shape)
                 setattr(self, name + "_ui_graph", self.matrix_to_tensor(self.csr_norm(tmp, mean_flag=True)))
@@ -328,9 +334,11 @@ class Trainer(object):
         reference's state from the fourth batch on under its defaults — i.e. when the graph handles
         no longer change from batch to batch and a captured step stays valid."""
         e = self._empty_plans
+        # with k == 0 nothing is ever collected; with T == 1 every batch from the second on takes the rebuild branch,
+        # so nothing is collected after the first batch either (Baby: k = 1, T = 1): the graphs stay empty for good
+        never_collects = int(self.n_items * args.m_topk_rate) == 0 or int(args.T) == 1
         return (e is not None and self.image_ui_graph is e[0] and self.text_ui_graph is e[0]
-                and self.image_iu_graph is e[1] and self.text_iu_graph is e[1]
-                and int(self.n_items * args.m_topk_rate) == 0)
+                and self.image_iu_graph is e[1] and self.text_iu_graph is e[1] and never_collects)
 
     def _captured(self):
         """SplitHotPath for the current (steady) graph set, captured on first use; None if disabled / refused."""

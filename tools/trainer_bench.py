@@ -63,17 +63,28 @@ def main():
     out = {k: round(v / n * 1e3, 2) for k, v in acc.items()}
     out["phases_sum_ms"] = round(sum(acc.values()) / n * 1e3, 2)
     # ... and the loop exactly as Trainer.train() runs it (next batch sampled while the device works)
-    nxt = dg.sample()
-    sync()
-    t0 = time.perf_counter()
-    for idx in range(a.batches):
-        users, pos, neg = nxt
-        tr._batch_idx(users, pos, neg)
-        tr._discriminator_step(users)
-        bl = tr._generator_step(a.batches + idx, users, pos, neg)[0]
+    # (Trainer.train_batch: op by op with MMSSL_TRAINER_GRAPH=0, then on the two captured hot-path segments)
+    base = a.batches
+    for tag, flag in (("batch_total_ms_eager", "0"), ("batch_total_ms_captured", "1")):
+        os.environ["MMSSL_TRAINER_GRAPH"] = flag
         nxt = dg.sample()
-        float(bl)
-    out["batch_total_ms"] = round((time.perf_counter() - t0) / a.batches * 1e3, 2)
+        for idx in range(3):                              # reach / capture the steady state outside the timed loop
+            users, pos, neg = nxt
+            tr._batch_idx(users, pos, neg)
+            float(tr.train_batch(base + idx, users, pos, neg)[0])
+            nxt = dg.sample()
+        sync()
+        t0 = time.perf_counter()
+        for idx in range(a.batches):
+            users, pos, neg = nxt
+            tr._batch_idx(users, pos, neg)
+            bl = tr.train_batch(base + 3 + idx, users, pos, neg)[0]
+            nxt = dg.sample()
+            float(bl)
+        out[tag] = round((time.perf_counter() - t0) / a.batches * 1e3, 2)
+        base += a.batches + 3
+    out["captured_path_used"] = getattr(tr, "_split", None) not in (None, False)
+    os.environ.pop("MMSSL_TRAINER_GRAPH", None)
     users = list(dg.val_set.keys())[:a.eval_users]
     sync()
     t = time.perf_counter()

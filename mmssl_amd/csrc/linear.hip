@@ -19,6 +19,7 @@
 //   gemm_fwd_dma_kernel    forward default: slices go global->LDS by LDS-DMA into a 4-stage ring
 //       (XOR-swizzled through the source addresses), fragments come back as ds_read_b128.
 #include <cstdlib>
+#include <type_traits>
 
 #include "common.hpp"
 
@@ -809,6 +810,216 @@ __global__ __launch_bounds__(kBlock) void pp_reduce_kernel(const float* __restri
 }
 
 // ======================================================================================
+// v8 (MMSSL_GEMM_V=8, experiment): ONE wave per SIMD, 256x64 block tile, every wave a 64x64 tile with four
+// independent accumulators, the slice's LDS-DMA issue and the next slice's fragment reads interleaved between the
+// MFMAs of the current slice (one filler after every group of four MFMAs on four different accumulators).
+// Why: the v7 decomposition shows each side near its own limit alone and the MFMA wave slowed by whatever its SIMD
+// partner does; here there is no partner, and a 64x64 wave tile needs 1 fragment register per MFMA instead of 1.5 (v7)
+// or 2 (v5/v6). 3 stages of 40 KB (A 256x32 + B 64x32 floats); a wave DMAs its OWN 64 A rows and a quarter of B.
+// ======================================================================================
+constexpr int W8_I = 256;
+constexpr int kW8Stages = 3;
+constexpr int kW8StageFloats = (W8_I + BT) * BK;          // 10240 floats = 40 KB
+constexpr int kW8TileFloats = W8_I * BT;                  // partial slot: 64 KB
+constexpr int kW8LdsBytes = kW8Stages * kW8StageFloats * 4;
+
+struct Frag4 {
+  float4 a0[4], a1[4], b0[4], b1[4];
+};
+__device__ __forceinline__ float f4c(const float4& v, int e) { return e == 0 ? v.x : (e == 1 ? v.y : (e == 2 ? v.z : v.w)); }
+
+__global__ __launch_bounds__(kBlock, 1) void gemm_w8_kernel(const float* __restrict__ A, int64_t lda,
+                                                            const float* __restrict__ B, int64_t ldb, int64_t I, int64_t J,
+                                                            int tiles_j, int S, int64_t total_units, int upb,
+                                                            float* __restrict__ C, int64_t ldc, int transpose_out,
+                                                            const float* __restrict__ bias,
+                                                            const uint8_t* __restrict__ keep, float scale,
+                                                            float* __restrict__ partials) {
+  extern __shared__ __attribute__((aligned(16))) float ring[];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int h = lane >> 5, lr = lane & 31;
+  const int sw = (lr >> 1) & 7;
+  const int ia0 = (w * 64 + lr) * BK, ia1 = ia0 + 32 * BK;
+  const int jb0 = W8_I * BK + lr * BK, jb1 = jb0 + 32 * BK;
+  const unsigned ring_lds = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)ring);
+  const int64_t u_begin = (int64_t)blockIdx.x * upb;
+  const int64_t u_end = min(total_units, u_begin + upb);
+  int64_t u = u_begin;
+  while (u < u_end) {
+    const int64_t tile = u / S;
+    const int s0 = (int)(u - tile * S);
+    const int s1 = (int)min((int64_t)S, s0 + (u_end - u));
+    const int nk = s1 - s0;
+    const int64_t i0 = (tile / tiles_j) * W8_I, j0 = (tile % tiles_j) * BT;
+    const float* pa[8];
+    const float* pb[2];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int r = 64 * w + 8 * j + (lane >> 3);
+      const int c = (lane & 7) ^ ((r >> 1) & 7);
+      pa[j] = A + min(i0 + r, I - 1) * lda + (int64_t)s0 * BK + 4 * c;
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int r = 16 * w + 8 * j + (lane >> 3);
+      const int c = (lane & 7) ^ ((r >> 1) & 7);
+      pb[j] = B + min(j0 + r, J - 1) * ldb + (int64_t)s0 * BK + 4 * c;
+    }
+    const unsigned dst_a = __builtin_amdgcn_readfirstlane((unsigned)(64 * w * BK * 4));
+    const unsigned dst_b = __builtin_amdgcn_readfirstlane((unsigned)((W8_I * BK + 16 * w * BK) * 4));
+    // one of the 10 DMA instructions of slice kt (p < 8: my A rows, else my B rows)
+    auto issue_one = [&](int kt, int p) {
+      const unsigned st = ring_lds + (unsigned)(kt % kW8Stages) * (kW8StageFloats * 4);
+      if (p < 8) glds16(pa[p] + (int64_t)kt * BK, st + dst_a + p * 1024);
+      else glds16(pb[p - 8] + (int64_t)kt * BK, st + dst_b + (p - 8) * 1024);
+    };
+    // one of the 16 fragment float4s of slice kt
+    auto read_one = [&](int kt, int g, Frag4& f) {
+      const float* st = ring + (kt % kW8Stages) * kW8StageFloats;
+      const int q = g & 3;
+      const int pos = ((2 * q + h) ^ sw) * 4;
+      if (g < 4) f.a0[q] = *reinterpret_cast<const float4*>(st + ia0 + pos);
+      else if (g < 8) f.a1[q] = *reinterpret_cast<const float4*>(st + ia1 + pos);
+      else if (g < 12) f.b0[q] = *reinterpret_cast<const float4*>(st + jb0 + pos);
+      else f.b1[q] = *reinterpret_cast<const float4*>(st + jb1 + pos);
+    };
+    floatx16 c00, c01, c10, c11;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { c00[r] = 0.f; c01[r] = 0.f; c10[r] = 0.f; c11[r] = 0.f; }
+    // slice kt from `cur`; meanwhile DMA of slice kt+3 and the fragments of slice kt+1 into `nxt`.
+    // MORE: slice kt+1 exists, FAR: slice kt+3 exists (compile-time, so the steady-state body is branch-free and the
+    // accumulators stay in their AGPRs across iterations)
+    auto body = [&](int kt, const Frag4& cur, Frag4& nxt, auto more_c, auto far_c, auto two_c) {
+      constexpr bool MORE = decltype(more_c)::value, FAR = decltype(far_c)::value, TWO = decltype(two_c)::value;
+      if (MORE) {
+        if (TWO) vm_wait_n<10>();      // slice kt+2 is in flight behind slice kt+1
+        else vm_wait_n<0>();
+        lgkm_wait0();
+        bare_barrier();                // slice kt+1 has landed everywhere; nobody still reads stage kt % 3
+      }
+#pragma unroll
+      for (int g = 0; g < 16; ++g) {
+        const int q = g >> 2, e = g & 3;
+        const float a0 = f4c(cur.a0[q], e), a1 = f4c(cur.a1[q], e), b0 = f4c(cur.b0[q], e), b1 = f4c(cur.b1[q], e);
+        c00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, c00, 0, 0, 0);
+        c01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, c01, 0, 0, 0);
+        c10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, c10, 0, 0, 0);
+        c11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, c11, 0, 0, 0);
+        if (FAR && g < 10) issue_one(kt + 3, g);
+        if (MORE) read_one(kt + 1, g, nxt);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    };
+    const std::true_type T_;
+    const std::false_type F_;
+    vm_wait_n<0>();
+    lgkm_wait0();
+    bare_barrier();                    // ring hand-over from the previous range
+    for (int t = 0; t < 3 && t < nk; ++t)
+#pragma unroll
+      for (int p = 0; p < 10; ++p) issue_one(t, p);
+    if (nk > 2) vm_wait_n<20>();
+    else if (nk > 1) vm_wait_n<10>();
+    else vm_wait_n<0>();
+    bare_barrier();
+    Frag4 f0, f1;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) read_one(0, g, f0);
+    int kt = 0;
+    for (; kt + 4 < nk; kt += 2) {             // steady state: slices kt+3 and kt+4 exist
+      body(kt, f0, f1, T_, T_, T_);
+      body(kt + 1, f1, f0, T_, T_, T_);
+    }
+    for (; kt < nk; kt += 2) {                 // drain (<= 4 slices): the same body with its conditions resolved
+      const int left = nk - kt;                // slices kt .. nk-1
+      if (left >= 4) body(kt, f0, f1, T_, T_, T_);
+      else if (left == 3) body(kt, f0, f1, T_, F_, T_);
+      else if (left == 2) body(kt, f0, f1, T_, F_, F_);
+      else body(kt, f0, f1, F_, F_, F_);
+      if (left >= 2) {
+        if (left >= 5) body(kt + 1, f1, f0, T_, T_, T_);
+        else if (left == 4) body(kt + 1, f1, f0, T_, F_, T_);
+        else if (left == 3) body(kt + 1, f1, f0, T_, F_, F_);
+        else body(kt + 1, f1, f0, F_, F_, F_);
+      }
+    }
+    const bool whole = (s0 == 0 && s1 == S);
+    const int seg = (u == u_begin) ? 0 : 1;
+    float4* P = reinterpret_cast<float4*>(partials + ((size_t)blockIdx.x * 2 + seg) * kW8TileFloats);
+#pragma unroll
+    for (int ab = 0; ab < 4; ++ab) {
+      const floatx16& acc = ab == 0 ? c00 : (ab == 1 ? c01 : (ab == 2 ? c10 : c11));
+      const int a = ab >> 1, b = ab & 1;
+      if (whole) {
+        const int64_t col = j0 + 32 * b + lr;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int64_t row = i0 + w * 64 + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * h;
+          if (row < I && col < J) {
+            float v = acc[r];
+            if (bias) v += bias[col];
+            if (keep) v = keep[row * J + col] ? v * scale : 0.f;
+            if (transpose_out) C[col * ldc + row] = v;
+            else C[row * ldc + col] = v;
+          }
+        }
+      } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          P[(ab * 4 + q) * kBlock + tid] = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+      }
+    }
+    u += nk;
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void w8_reduce_kernel(const float* __restrict__ partials, int tiles_j, int S,
+                                                           int64_t total_units, int upb, int64_t I, int64_t J,
+                                                           float* __restrict__ C, int64_t ldc, int transpose_out,
+                                                           const float* __restrict__ bias,
+                                                           const uint8_t* __restrict__ keep, float scale) {
+  const int64_t tile = blockIdx.x;
+  const int64_t u_lo = tile * S, u_hi = u_lo + S;
+  const int64_t b_first = u_lo / upb, b_last = (u_hi - 1) / upb;
+  if (b_first == b_last) return;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int h = lane >> 5, lr = lane & 31;
+  const int64_t i0 = (tile / tiles_j) * W8_I, j0 = (tile % tiles_j) * BT;
+  for (int ab = 0; ab < 4; ++ab) {
+    float4 v[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int64_t b = b_first; b <= b_last; ++b) {
+      const int seg = (b * upb < u_lo) ? 1 : 0;
+      const float4* P = reinterpret_cast<const float4*>(partials + ((size_t)b * 2 + seg) * kW8TileFloats);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 p = P[(ab * 4 + q) * kBlock + tid];
+        v[q].x += p.x; v[q].y += p.y; v[q].z += p.z; v[q].w += p.w;
+      }
+    }
+    const int a = ab >> 1, bb = ab & 1;
+    const int64_t col = j0 + 32 * bb + lr;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float e[4] = {v[q].x, v[q].y, v[q].z, v[q].w};
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int r = 4 * q + c;
+        const int64_t row = i0 + w * 64 + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (row < I && col < J) {
+          float x = e[c];
+          if (bias) x += bias[col];
+          if (keep) x = keep[row * J + col] ? x * scale : 0.f;
+          if (transpose_out) C[col * ldc + row] = x;
+          else C[row * ldc + col] = x;
+        }
+      }
+    }
+  }
+}
+
+// ======================================================================================
 // OPT-IN split-precision product (MMSSL_GEMM_SPLIT=1 on the Python side; NOT the default path):
 //   C[i][j] = sum_k A[i][k] * B[j][k]   with A, B given as bf16 (hi, lo) pairs, x ~= hi + lo (16 mantissa bits),
 //   accumulated in fp32 as  hi*hi + hi*lo + lo*hi  on the bf16 matrix cores (v_mfma_f32_32x32x16_bf16).
@@ -1133,6 +1344,36 @@ inline int launch_pp(const float* A, const float* B, int64_t I, int64_t J, int64
   }
   return 0;
 }
+inline bool w8_usable(int64_t KK) { return gemm_version() == 8 && KK % BK == 0 && KK >= BK; }
+inline SkPlan w8_plan(int64_t I, int64_t J, int64_t KK) {
+  SkPlan p;
+  p.tiles_i = (I + W8_I - 1) / W8_I;
+  p.tiles_j = (J + BT - 1) / BT;
+  p.S = (int)(KK / BK);
+  p.total = p.tiles_i * p.tiles_j * p.S;
+  int64_t upb = (p.total + 255) / 256;
+  const int64_t floor_ = p.S < 8 ? p.S : 8;
+  if (upb < floor_) upb = floor_;
+  p.upb = (int)upb;
+  p.blocks = (int)((p.total + upb - 1) / upb);
+  return p;
+}
+inline int launch_w8(const float* A, const float* B, int64_t I, int64_t J, int64_t KK, float* C, int64_t ldc,
+                     int transpose_out, const float* b, const uint8_t* keep, float scale, float* part, hipStream_t s) {
+  static const int rc = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_w8_kernel),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, kW8LdsBytes);
+  if (rc != 0) return MMSSL_E_UNSUPP;
+  const SkPlan p = w8_plan(I, J, KK);
+  hipLaunchKernelGGL(gemm_w8_kernel, dim3((unsigned)p.blocks), dim3(kBlock), kW8LdsBytes, s, A, KK, B, KK, I, J,
+                     (int)p.tiles_j, p.S, p.total, p.upb, C, ldc, transpose_out, b, keep, scale, part);
+  MMSSL_LAUNCH_CHECK();
+  if (p.upb % p.S != 0) {
+    hipLaunchKernelGGL(w8_reduce_kernel, dim3((unsigned)(p.tiles_i * p.tiles_j)), dim3(kBlock), 0, s, part,
+                       (int)p.tiles_j, p.S, p.total, p.upb, I, J, C, ldc, transpose_out, b, keep, scale);
+    MMSSL_LAUNCH_CHECK();
+  }
+  return 0;
+}
 inline size_t pp_ws_bytes(int64_t I, int64_t J, int64_t KK) {
   return (size_t)pp_plan(I, J, KK).blocks * 2 * kPpTileFloats * sizeof(float) + 16;
 }
@@ -1161,6 +1402,10 @@ inline int64_t chunk_for(int64_t KK, int splits) {
 
 extern "C" size_t mmssl_linear_workspace_bytes(int64_t M, int K, int N) {
   if (M <= 0 || K <= 0 || N <= 0) return 16;
+  if (w8_usable(K)) {
+    const SkPlan p = pp_swap(M, N) ? w8_plan(N, M, K) : w8_plan(M, N, K);
+    return (size_t)p.blocks * 2 * kW8TileFloats * sizeof(float) + 16;
+  }
   if (pp_usable(K)) return pp_swap(M, N) ? pp_ws_bytes(N, M, K) : pp_ws_bytes(M, N, K);
   if (sk_usable(K)) return (size_t)sk_plan(M, N, K).blocks * 2 * kSkTileFloats * sizeof(float) + 16;
   const int64_t tiles = ((M + BT - 1) / BT) * ((N + BT - 1) / BT);
@@ -1177,6 +1422,12 @@ extern "C" int mmssl_linear_f32(const float* F, const float* W, const float* b, 
   if (M == 0) return 0;
   if (((uintptr_t)F | (uintptr_t)W | (uintptr_t)Y) & 15) return MMSSL_E_BADARG;
   hipStream_t s = as_stream(stream);
+  if (w8_usable(K)) {
+    if (!workspace || workspace_bytes < mmssl_linear_workspace_bytes(M, K, N)) return MMSSL_E_WORKSPACE;
+    float* part = reinterpret_cast<float*>(workspace);
+    if (pp_swap(M, N)) return launch_w8(W, F, N, M, K, Y, (int64_t)N, 1, nullptr, nullptr, 1.f, part, s);
+    return launch_w8(F, W, M, N, K, Y, (int64_t)N, 0, b, keep, scale, part, s);
+  }
   if (pp_usable(K)) {
     if (!workspace || workspace_bytes < mmssl_linear_workspace_bytes(M, K, N)) return MMSSL_E_WORKSPACE;
     float* part = reinterpret_cast<float*>(workspace);

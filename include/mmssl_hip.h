@@ -121,7 +121,9 @@ int mmssl_plan_fill_host(const int32_t* rowptr, int32_t rows, int32_t* group_ite
 /* extended (mmssl_spmm_ex_f32 only): the two epilogues that let the whole backward of the GCN
  * chain (Models.py:199-214: layer mean + last-layer softmax) consist of SpMM launches alone */
 #define MMSSL_EPI_AXPY             2  /* Y = A.X + alpha * Z[row]                               */
-#define MMSSL_EPI_AXPY_SOFTMAX_BWD 3  /* ---- batch rows of the interaction pattern (SURVEY.md 8f "next #1") --------------------------------
+#define MMSSL_EPI_AXPY_SOFTMAX_BWD 3  /* t = A.X + alpha * Z[row]; Y = S[row] * (t - <t, S[row]>)  (softmax bwd) */
+
+/* ---- batch rows of the interaction pattern (SURVEY.md 8f "next #1") --------------------------------
  * The reference builds `torch.tensor(self.ui_graph_raw[users].todense()).cuda()` — a dense
  * [B, n_items] host matrix + upload — in every Trainer.u_sim_calculation call and for the
  * discriminator's real-data rows (main.py:281-298, 349). These read the same pattern from the plan's

@@ -481,6 +481,12 @@ __global__ __launch_bounds__(kBlock) void spmm_kernel(const int4* __restrict__ g
         return;
       }
       // ---- in-kernel combine by the LAST-arriving block of this row (split-K arrival pattern) ----
+      // The protocol below (write-through sc1 stores drained with vmcnt, relaxed ticket, sc1 re-reads; no
+      // release/acquire fence) relies on gfx9 store accounting (stores retire through vmcnt) and on agent-scope
+      // relaxed atomics lowering to sc1 accesses. Other targets must use a fence pair or the two-stage mode.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__) && !defined(__gfx942__)
+#error "spmm_kernel's in-kernel combine is written for gfx942/gfx950 memory semantics"
+#endif
       // The 16*LPR-byte partial is stored WRITE-THROUGH (agent-scope relaxed atomic stores lower to
       // `global_store ... sc1`), drained, then one lane takes a ticket: no release fence, so the
       // other rows' dirty output lines stay in this XCD's L2. The last arriver re-reads every

@@ -199,7 +199,12 @@ class Trainer(object):
                             self.u_sim_calculation(users, txt_user, txt_item).detach()), dim=0)
         lossf = self.D(inputf).mean()
         u_ui = self._seen_rows(users)
-        noise = torch.empty_like(u_ui).uniform_(0, 1)
+        if os.environ.get("MMSSL_REF_NOISE", "0") == "1":
+            # the reference draws the Gumbel noise from the CPU generator and uploads it (main.py:350): with the same
+            # set_seed the discriminator then sees the reference's noise stream (costs a [B, n_items] host draw + copy)
+            noise = torch.empty(u_ui.shape, dtype=torch.float32).uniform_(0, 1).pin_memory().to(u_ui.device, non_blocking=True)
+        else:
+            noise = torch.empty_like(u_ui).uniform_(0, 1)
         u_ui = F.softmax(u_ui - args.log_log_scale * torch.log(-torch.log(noise + 1e-8) + 1e-8) / args.real_data_tau,
                          dim=1)
         u_ui = F.normalize(u_ui + ui_u_sim * args.ui_pre_scale, dim=1)
@@ -424,6 +429,9 @@ class Trainer(object):
                 self.logger.logging("ERROR: loss is nan.")
                 sys.exit()
             t2 = time()
+            if args.verbose and (epoch + 1) % args.verbose != 0:      # main.py:444-448 (evaluation still follows)
+                self.logger.logging("Epoch %d [%.1fs]: train==[%.5f=%.5f + %.5f + %.5f]" % (
+                    epoch, t2 - t1, loss, mf_loss, emb_loss, reg_loss))
             ret = self.test(list(dg.val_set.keys()), is_val=True)
             t3 = time()
             if args.verbose > 0:

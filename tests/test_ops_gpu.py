@@ -730,3 +730,49 @@ def test_device_modal_graph_rebuild_matches_reference_loop(tag):
                                   torch.from_numpy(g["b%d.txt_sim" % b]).to(DEV))
     assert checked >= 8
     config.configure([])
+
+
+@pytest.mark.parametrize("d", [32, 256])
+def test_spmm_inkernel_combine_under_graph_replay_with_five_concurrent_launches(d):
+    """The cross-block combine (write-through partials + arrival ticket, no fences) at the narrow and the wide feature
+    width, with FIVE launches on one plan overlapping inside a replayed hipGraph (five streams, five workspace lanes) and
+    heavy background traffic between replays: every replay must reproduce the eager single-launch result bit for bit."""
+    ops, graph = _ops()
+    rng = np.random.default_rng(100 + d)
+    heavy = [(int(r), int(k)) for r, k in zip(rng.choice(2000, 120, replace=False), rng.integers(600, 2400, 120))]
+    m = _rand_graph(2000, 2500, 4, seed=9, heavy=heavy)
+    plan = graph.GraphPlan(m)
+    assert plan.info()["multi_rows"] >= 100
+    gen = torch.Generator().manual_seed(1)
+    Xs = [torch.randn(2500, d, generator=gen).to(DEV) for _ in range(5)]
+    with torch.no_grad():
+        want = [ops._spmm_raw(plan, False, X, ops.EPI_NONE).clone() for X in Xs]
+        ref = O.spmm(O.to_torch_sparse(m), Xs[0].cpu())
+        assert H.rel_err(want[0].cpu(), ref) < 3e-6
+        streams = [torch.cuda.Stream() for _ in range(5)]
+        main = torch.cuda.Stream()
+        main.wait_stream(torch.cuda.current_stream())
+        outs = [None] * 5
+
+        def fanout():
+            for k, st in enumerate(streams):
+                st.wait_stream(main)
+                with torch.cuda.stream(st):
+                    outs[k] = ops._spmm_raw(plan.twin(k), False, Xs[k], ops.EPI_NONE)
+            for st in streams:
+                main.wait_stream(st)
+        with torch.cuda.stream(main):
+            fanout()
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=main, capture_error_mode="thread_local"):
+                fanout()
+        torch.cuda.synchronize()
+        big = torch.empty(64 << 20, device=DEV)
+        for it in range(12):
+            if it % 3 == 0:
+                big.normal_()
+            g.replay()
+            torch.cuda.synchronize()
+            for k in range(5):
+                assert torch.equal(outs[k], want[k]), (it, k)

@@ -268,6 +268,10 @@ size_t mmssl_transpose_mask_workspace_bytes(int64_t Mp, int N);
 int mmssl_transpose_mask_f32(const float* G, const uint8_t* keep, float scale, int64_t M, int N, int64_t Mp,
                              float* T, float* colsum, void* workspace, size_t workspace_bytes, void* stream);
 size_t mmssl_linear_wgrad_workspace_bytes(int64_t M, int K, int N);
+/* 1 when mmssl_linear_wgrad_f32 will run this shape on the register-direct kernel, which applies keep/scale and
+ * sums the bias gradient on the fragments it loads (pass `keep`; no separate dropout-backward pass is needed);
+ * 0 when it runs the register-staged kernel, for which a pre-masked gY (mmssl_mask_scale_f32) measured faster. */
+int mmssl_linear_wgrad_fuses_mask(int64_t M, int K, int N);
 int mmssl_linear_wgrad_f32(const float* gY, const uint8_t* keep, float scale, const float* F,
                            int64_t M, int K, int N, float* gW, float* gb, void* workspace,
                            size_t workspace_bytes, void* stream);

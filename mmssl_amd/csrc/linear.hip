@@ -175,6 +175,16 @@ __global__ __launch_bounds__(kBlock) void gemm64_kernel(const float* __restrict_
 constexpr int kDmaStages = 4;
 constexpr int kDmaStageFloats = 2 * BT * BK;        // A slice then B slice: 8 KB + 8 KB
 
+// same with the non-temporal hint: the streamed operand (the feature matrix, read once per product) should not push the
+// SpMM chains' tables out of L2 while both run side by side
+__device__ __forceinline__ void glds16_nt(const float* gsrc, unsigned lds_dst) {
+  unsigned keep_m0;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep_m0)
+      : "v"(gsrc), "s"(lds_dst)
+      : "memory");
+}
 __device__ __forceinline__ void glds16(const float* gsrc, unsigned lds_dst) {
   unsigned keep_m0;
   asm volatile(
@@ -339,8 +349,13 @@ __global__ __launch_bounds__(kBlock) void gemm_sk_kernel(const float* __restrict
     }
     auto issue = [&](int kt) {
       const unsigned st = ring_lds + (unsigned)(kt & (kDmaStages - 1)) * (kDmaStageFloats * 4) + piece;
-      glds16(pa[0] + (int64_t)kt * BK, st);
-      glds16(pa[1] + (int64_t)kt * BK, st + 8 * BK * 4);
+      if (prio & 2) {                       // MMSSL_GEMM_NT=1: stream the A operand past L2
+        glds16_nt(pa[0] + (int64_t)kt * BK, st);
+        glds16_nt(pa[1] + (int64_t)kt * BK, st + 8 * BK * 4);
+      } else {
+        glds16(pa[0] + (int64_t)kt * BK, st);
+        glds16(pa[1] + (int64_t)kt * BK, st + 8 * BK * 4);
+      }
       glds16(pb[0] + (int64_t)kt * BK, st + BT * BK * 4);
       glds16(pb[1] + (int64_t)kt * BK, st + BT * BK * 4 + 8 * BK * 4);
     };
@@ -402,9 +417,9 @@ __global__ __launch_bounds__(kBlock) void gemm_sk_kernel(const float* __restrict
       issue(kt + 4);
       read_frags(kt + 1, nxt);
       __builtin_amdgcn_sched_barrier(0);
-      if (prio) __builtin_amdgcn_s_setprio(3);     // MMSSL_GEMM_PRIO=1 (experiment): MFMA chain outranks the partner wave
+      if (prio & 1) __builtin_amdgcn_s_setprio(3);     // MMSSL_GEMM_PRIO=1 (experiment): MFMA chain outranks the partner wave
       mfma16(cur);
-      if (prio) __builtin_amdgcn_s_setprio(0);
+      if (prio & 1) __builtin_amdgcn_s_setprio(0);
       __builtin_amdgcn_sched_barrier(0);
     };
     Frag f0, f1;
@@ -1020,6 +1035,396 @@ __global__ __launch_bounds__(kBlock) void w8_reduce_kernel(const float* __restri
 }
 
 // ======================================================================================
+// v9 (MMSSL_GEMM_V=9): register-direct product. No LDS and no barrier in the main loop: every wave loads its MFMA
+// fragments straight from global memory with 16-byte loads and keeps two full fragment sets in registers.
+//
+// Why this is possible: v_mfma_f32_32x32x2_f32 wants lane l to hold A[row l%32][k-index l/32]; the sum over k does
+// not care WHICH two k-values form a pair as long as A and B agree. So lane l reads 64 contiguous bytes of its row,
+// k = kw + 16 (l/32) + 0..15, for both operands: MFMA step j multiplies the pair (kw + j, kw + 16 + j). A 32-row
+// block then costs 4 x global_load_dwordx4 per 32 k-values and lanes l / l+32 cover one whole 128-B line of the row.
+// Block = 4 waves on ONE 128 x 64 output tile; wave w takes k in [128 s + 32 w, +32) of every 128-deep unit s
+// (the block reads 512 contiguous bytes of each row per unit), holds 4 x 2 accumulators (128 registers) and two
+// fragment sets of 24 float4 (192 registers): 1 wave per SIMD, 0.75 loaded registers per MFMA (v6: 2, v7: 1.5, v8: 1),
+// one load instruction per 5.3 MFMAs, issued between groups of four MFMAs on four different accumulators.
+// The four waves' accumulators are added through LDS in wave order at the end of a unit range (fixed order);
+// ranges are cut stream-K style like v6 (head / tail partial slots + r9_reduce_kernel in block order).
+// Preconditions (host-checked): KK % 128 == 0, row-major [i][kk] operands, 16-B aligned rows.
+// ======================================================================================
+constexpr int R9_RB = 4;
+constexpr int R9_I = 32 * R9_RB;                          // 128 rows per tile
+constexpr int R9_KU = 128;                                // k-values per unit (4 waves x 32)
+constexpr int kR9TileFloats = R9_I * BT;                  // partial slot: 32 KB
+constexpr int kR9LdsBytes = 4 * kR9TileFloats * 4;        // the four waves' accumulator images: 128 KB
+
+struct R9Frag {
+  float4 a[R9_RB][4], b[2][4];
+};
+__device__ __forceinline__ float4 ldg16(const float* p) { return *reinterpret_cast<const float4*>(p); }
+
+template <int DBG>      // DBG (debugging aid, MMSSL_GEMM_R9_MODE): 1 = no loads in the loop, 2 = no MFMAs, 4 = no B loads in the loop
+__global__ __launch_bounds__(kBlock, 1) void gemm_r9_kernel(const float* __restrict__ A, int64_t lda,
+                                                            const float* __restrict__ B, int64_t ldb, int64_t I,
+                                                            int64_t J, int tiles_j, int S, int64_t total_units, int upb,
+                                                            float* __restrict__ C, int64_t ldc, int transpose_out,
+                                                            const float* __restrict__ bias,
+                                                            const uint8_t* __restrict__ keep, float scale,
+                                                            float* __restrict__ partials) {
+  extern __shared__ __attribute__((aligned(16))) float4 r9_red[];        // [4 waves][2048]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int h = lane >> 5, lr = lane & 31;
+  const int64_t u_begin = (int64_t)blockIdx.x * upb;
+  const int64_t u_end = min(total_units, u_begin + upb);
+  int64_t u = u_begin;
+  while (u < u_end) {
+    const int64_t tile = u / S;
+    const int s0 = (int)(u - tile * S);
+    const int s1 = (int)min((int64_t)S, s0 + (u_end - u));
+    const int nk = s1 - s0;
+    const int64_t i0 = (tile / tiles_j) * R9_I, j0 = (tile % tiles_j) * BT;
+    const float* pa[R9_RB];
+    const float* pb[2];
+    const int64_t k_first = (int64_t)s0 * R9_KU + 32 * wave + 16 * h;
+#pragma unroll
+    for (int rb = 0; rb < R9_RB; ++rb) pa[rb] = A + min(i0 + 32 * rb + lr, I - 1) * lda + k_first;
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) pb[cb] = B + min(j0 + 32 * cb + lr, J - 1) * ldb + k_first;
+    floatx16 acc[R9_RB][2];
+#pragma unroll
+    for (int rb = 0; rb < R9_RB; ++rb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        acc[rb][0][r] = 0.f;
+        acc[rb][1][r] = 0.f;
+      }
+    // one unit: 128 MFMAs from `cur`, the 24 loads of unit `kn` into `nxt` spread between them
+    auto step = [&](int kn, const R9Frag& cur, R9Frag& nxt) {
+      const int64_t off = (int64_t)kn * R9_KU;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {            // row blocks 0, 1; fetches a[0], b[0], b[1], a[1] of the next unit
+        const int q = i >> 2, c = i & 3;
+        const float x0 = f4c(cur.a[0][q], c), x1 = f4c(cur.a[1][q], c);
+        const float y0 = f4c(cur.b[0][q], c), y1 = f4c(cur.b[1][q], c);
+        if (DBG & 2) {
+          asm volatile("" ::"v"(x0), "v"(x1), "v"(y0), "v"(y1));
+        } else {
+          acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(x0, y0, acc[0][0], 0, 0, 0);
+          acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(x0, y1, acc[0][1], 0, 0, 0);
+          acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(x1, y0, acc[1][0], 0, 0, 0);
+          acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(x1, y1, acc[1][1], 0, 0, 0);
+        }
+        if (!(DBG & 1)) {
+          if (c == 0) nxt.a[0][q] = ldg16(pa[0] + off + 4 * q);
+          else if (c == 1 && !(DBG & 4)) nxt.b[0][q] = ldg16(pb[0] + off + 4 * q);
+          else if (c == 2 && !(DBG & 4)) nxt.b[1][q] = ldg16(pb[1] + off + 4 * q);
+          else if (c == 3) nxt.a[1][q] = ldg16(pa[1] + off + 4 * q);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {            // row blocks 2, 3; fetches a[2], a[3]
+        const int q = i >> 2, c = i & 3;
+        const float x0 = f4c(cur.a[2][q], c), x1 = f4c(cur.a[3][q], c);
+        const float y0 = f4c(cur.b[0][q], c), y1 = f4c(cur.b[1][q], c);
+        if (DBG & 2) {
+          asm volatile("" ::"v"(x0), "v"(x1), "v"(y0), "v"(y1));
+        } else {
+          acc[2][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(x0, y0, acc[2][0], 0, 0, 0);
+          acc[2][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(x0, y1, acc[2][1], 0, 0, 0);
+          acc[3][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(x1, y0, acc[3][0], 0, 0, 0);
+          acc[3][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(x1, y1, acc[3][1], 0, 0, 0);
+        }
+        if (!(DBG & 1)) {
+          if (c == 0) nxt.a[2][q] = ldg16(pa[2] + off + 4 * q);
+          else if (c == 2) nxt.a[3][q] = ldg16(pa[3] + off + 4 * q);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    };
+    R9Frag f0, f1;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      f0.a[0][q] = ldg16(pa[0] + 4 * q);
+      f0.b[0][q] = ldg16(pb[0] + 4 * q);
+      f0.b[1][q] = ldg16(pb[1] + 4 * q);
+      f0.a[1][q] = ldg16(pa[1] + 4 * q);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      f0.a[2][q] = ldg16(pa[2] + 4 * q);
+      f0.a[3][q] = ldg16(pa[3] + 4 * q);
+    }
+    if (DBG & 5) f1 = f0;
+    int kt = 0;
+    for (; kt + 1 < nk; kt += 2) {              // the prefetch of the last unit re-reads that unit (never used)
+      step(kt + 1, f0, f1);
+      step(min(kt + 2, nk - 1), f1, f0);
+    }
+    if (kt < nk) step(kt, f0, f1);
+    // add the four waves' accumulators in wave order: wave w finishes row block w
+    float4* mine = r9_red + wave * (kR9TileFloats / 4);
+#pragma unroll
+    for (int rb = 0; rb < R9_RB; ++rb)
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          mine[((rb * 2 + cb) * 4 + q) * 64 + lane] =
+              make_float4(acc[rb][cb][4 * q], acc[rb][cb][4 * q + 1], acc[rb][cb][4 * q + 2], acc[rb][cb][4 * q + 3]);
+    __syncthreads();
+    const bool whole = (s0 == 0 && s1 == S);
+    const int seg = (u == u_begin) ? 0 : 1;
+    float4* P = reinterpret_cast<float4*>(partials + ((size_t)blockIdx.x * 2 + seg) * kR9TileFloats);
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int idx = ((wave * 2 + cb) * 4 + q) * 64 + lane;
+        const float4 r0 = r9_red[idx], r1 = r9_red[2048 + idx], r2 = r9_red[4096 + idx], r3 = r9_red[6144 + idx];
+        float4 v;
+        v.x = ((r0.x + r1.x) + r2.x) + r3.x;
+        v.y = ((r0.y + r1.y) + r2.y) + r3.y;
+        v.z = ((r0.z + r1.z) + r2.z) + r3.z;
+        v.w = ((r0.w + r1.w) + r2.w) + r3.w;
+        if (!whole) {
+          P[idx] = v;
+        } else {
+          const int64_t col = j0 + 32 * cb + lr;
+          const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const int r = 4 * q + c;
+            const int64_t row = i0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (row < I && col < J) {
+              float x = e[c];
+              if (bias) x += bias[col];
+              if (keep) x = keep[row * J + col] ? x * scale : 0.f;
+              if (transpose_out) C[col * ldc + row] = x;
+              else C[row * ldc + col] = x;
+            }
+          }
+        }
+      }
+    __syncthreads();                            // the images are reused by the block's next range
+    u += nk;
+  }
+}
+
+// one block per 128x64 output tile: adds the tile's partial slots in block order
+__global__ __launch_bounds__(kBlock) void r9_reduce_kernel(const float* __restrict__ partials, int tiles_j, int S,
+                                                           int64_t total_units, int upb, int64_t I, int64_t J,
+                                                           float* __restrict__ C, int64_t ldc, int transpose_out,
+                                                           const float* __restrict__ bias,
+                                                           const uint8_t* __restrict__ keep, float scale) {
+  const int64_t tile = blockIdx.x;
+  const int64_t u_lo = tile * S, u_hi = u_lo + S;
+  const int64_t b_first = u_lo / upb, b_last = (u_hi - 1) / upb;
+  if (b_first == b_last) return;
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const int h = lane >> 5, lr = lane & 31;
+  float4 v[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) v[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int64_t b = b_first; b <= b_last; ++b) {
+    const int seg = (b * upb < u_lo) ? 1 : 0;
+    const float4* P = reinterpret_cast<const float4*>(partials + ((size_t)b * 2 + seg) * kR9TileFloats);
+    float4 p[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) p[q] = P[(w * 8 + q) * 64 + lane];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      v[q].x += p[q].x; v[q].y += p[q].y; v[q].z += p[q].z; v[q].w += p[q].w;
+    }
+  }
+  const int64_t i0 = (tile / tiles_j) * R9_I, j0 = (tile % tiles_j) * BT;
+#pragma unroll
+  for (int q8 = 0; q8 < 8; ++q8) {
+    const int cb = q8 >> 2, q = q8 & 3;
+    const int64_t col = j0 + 32 * cb + lr;
+    const float e[4] = {v[q8].x, v[q8].y, v[q8].z, v[q8].w};
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int r = 4 * q + c;
+      const int64_t row = i0 + w * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      if (row < I && col < J) {
+        float x = e[c];
+        if (bias) x += bias[col];
+        if (keep) x = keep[row * J + col] ? x * scale : 0.f;
+        if (transpose_out) C[col * ldc + row] = x;
+        else C[row * ldc + col] = x;
+      }
+    }
+  }
+}
+
+// ======================================================================================
+// v10 weight gradient (default): gW[n][k] = sum_m G[m][n] F[m][k] with G = dropout-backward(gY), register-direct.
+//
+// The reduction runs over ROWS of the row-major operands, so the MFMA fragments can be loaded from global memory
+// with fully coalesced 16-byte loads and no LDS: for v_mfma_f32_16x16x4_f32 lane l = (g = l / 16, j = l % 16) holds
+// A[i = j][k = g] and B[k = g][col = j]. Lane (g, j) loads F[m + g][c0 + 4j .. 4j+3] and gY[m + g][n0 + 4j .. 4j+3]:
+// one instruction covers 4 rows x 256 contiguous bytes, and component c of the two float4 is the operand of the
+// MFMAs of column block c / channel block c, where block c holds the columns (channels) {4j + c}: the permutation
+// of the OUTPUT index is undone for free when the tile is stored. Per step (4 rows per wave, 16 per block) a wave
+// issues 3 loads (F, gY, 4 mask bytes) and 16 MFMAs on 16 different accumulators; 8 steps of loads are in flight
+// in a register ring. Dropout backward and the bias gradient (column sums of G) happen on the loaded fragment:
+// no masked copy of gY, no column-sum kernels. Block = 64 channels x 64 columns x one row range (`sp` ranges);
+// the four waves' accumulators meet in LDS in wave order, row ranges in wg10_reduce_kernel in range order.
+// Preconditions (host-checked): K % 64 == 0, N % 64 == 0.
+// ======================================================================================
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+constexpr int WG_D = 8;
+
+template <bool KEEP, bool NT>
+__global__ __launch_bounds__(kBlock, 2) void wgrad10_kernel(const float* __restrict__ gY,
+                                                            const uint8_t* __restrict__ keep, float scale,
+                                                            const float* __restrict__ F, int64_t M, int K, int N,
+                                                            int64_t ms, float* __restrict__ out, int64_t split_stride,
+                                                            float* __restrict__ bpart) {
+  __shared__ __attribute__((aligned(16))) float4 red[4 * 1024];        // 4 waves x 16 blocks x 64 lanes: 64 KB
+  __shared__ float bred[4][64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 4, j = lane & 15;
+  const int c0 = (int)blockIdx.x * 64, n0 = (int)blockIdx.y * 64, split = (int)blockIdx.z;
+  const int64_t m_lo = (int64_t)split * ms, m_hi = min(M, m_lo + ms);
+  const int nsteps = m_hi > m_lo ? (int)((m_hi - m_lo + 15) / 16) : 0;
+  const float sc = KEEP ? scale : 1.f;
+  floatx4 acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = floatx4{0.f, 0.f, 0.f, 0.f};
+  float bs[4] = {0.f, 0.f, 0.f, 0.f};
+  // Register ring of WG_D steps. The loads are inline asm so that neither the IR passes nor the machine scheduler can
+  // sink them next to their use (both did, which serialised load latency and MFMAs); the matching waits therefore are
+  // explicit: when slot d is consumed, exactly WG_D - 1 younger steps of loads are outstanding.
+  floatx4 fv[WG_D], gv[WG_D];
+  uint32_t kv[WG_D];
+  const int64_t m_mine = m_lo + 4 * wave + g;
+  const int64_t m_base = min(m_mine, M - 1);
+  const int t_last = m_mine < M ? (int)((M - 1 - m_mine) / 16) : 0;             // later steps re-load this row
+  const int t_valid = m_mine < m_hi ? (int)((m_hi - 1 - m_mine) / 16) : -1;      // last step that contributes
+  // 32-bit byte offsets from uniform bases (host-checked: M * max(K, N) < 2^30), 24-bit multiplies
+  const uint32_t oF = (uint32_t)((m_base * K + c0 + 4 * j) * 4), oG = (uint32_t)((m_base * N + n0 + 4 * j) * 4);
+  const uint32_t oK = (uint32_t)(m_base * N + n0 + 4 * j);
+  const uint32_t sF = 64u * (uint32_t)K, sG = 64u * (uint32_t)N, sK = 16u * (uint32_t)N;
+  constexpr int kYounger = (KEEP ? 3 : 2) * (WG_D - 1);
+  auto load = [&](int slot, int t) {
+    const uint32_t tc = (uint32_t)min(t, t_last);
+    const uint32_t a = oF + __umul24(tc, sF), b = oG + __umul24(tc, sG);
+    if (NT) asm volatile("global_load_dwordx4 %0, %1, %2 nt" : "=v"(fv[slot]) : "v"(a), "s"(F) : "memory");
+    else asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(fv[slot]) : "v"(a), "s"(F) : "memory");
+    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(gv[slot]) : "v"(b), "s"(gY) : "memory");
+    if (KEEP) {
+      const uint32_t c = oK + __umul24(tc, sK);
+      asm volatile("global_load_dword %0, %1, %2" : "=v"(kv[slot]) : "v"(c), "s"(keep) : "memory");
+    }
+  };
+  auto consume = [&](int slot, int t) {
+    if (KEEP) asm volatile("s_waitcnt vmcnt(%3)" : "+v"(fv[slot]), "+v"(gv[slot]), "+v"(kv[slot]) : "n"(kYounger));
+    else asm volatile("s_waitcnt vmcnt(%2)" : "+v"(fv[slot]), "+v"(gv[slot]) : "n"(kYounger));
+    const float s1 = t <= t_valid ? sc : 0.f;
+    float a[4];
+    if (KEEP) {
+      a[0] = (kv[slot] & 0x000000ffu) ? gv[slot][0] * s1 : 0.f;
+      a[1] = (kv[slot] & 0x0000ff00u) ? gv[slot][1] * s1 : 0.f;
+      a[2] = (kv[slot] & 0x00ff0000u) ? gv[slot][2] * s1 : 0.f;
+      a[3] = (kv[slot] & 0xff000000u) ? gv[slot][3] * s1 : 0.f;
+    } else {
+      a[0] = gv[slot][0] * s1;
+      a[1] = gv[slot][1] * s1;
+      a[2] = gv[slot][2] * s1;
+      a[3] = gv[slot][3] * s1;
+    }
+    const float f[4] = {fv[slot][0], fv[slot][1], fv[slot][2], fv[slot][3]};
+#pragma unroll
+    for (int c = 0; c < 4; ++c) bs[c] += a[c];
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+      for (int cb = 0; cb < 4; ++cb) acc[rb][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rb], f[cb], acc[rb][cb], 0, 0, 0);
+    // pin: the MFMAs of this step are issued HERE (left alone, the DAG scheduler defers them past the next loads)
+#pragma unroll
+    for (int rb = 0; rb < 4; rb += 2)
+      asm volatile("" : "+v"(acc[rb][0]), "+v"(acc[rb][1]), "+v"(acc[rb][2]), "+v"(acc[rb][3]), "+v"(acc[rb + 1][0]),
+                        "+v"(acc[rb + 1][1]), "+v"(acc[rb + 1][2]), "+v"(acc[rb + 1][3]));
+  };
+#pragma unroll
+  for (int d = 0; d < WG_D; ++d) load(d, d);
+  for (int t0 = 0; t0 < nsteps; t0 += WG_D) {
+#pragma unroll
+    for (int d = 0; d < WG_D; ++d) {
+      consume(d, t0 + d);
+      __builtin_amdgcn_sched_barrier(0);
+      load(d, t0 + d + WG_D);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the ring's last prefetches still target live registers
+  float4* mine = red + wave * 1024;
+#pragma unroll
+  for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb)
+      mine[(rb * 4 + cb) * 64 + lane] = make_float4(acc[rb][cb][0], acc[rb][cb][1], acc[rb][cb][2], acc[rb][cb][3]);
+  if (bpart != nullptr && blockIdx.x == 0) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      bs[c] += __shfl_xor(bs[c], 16);
+      bs[c] += __shfl_xor(bs[c], 32);
+    }
+    if (g == 0) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) bred[wave][4 * j + c] = bs[c];
+    }
+  }
+  __syncthreads();
+  // wave w finishes channel block w: D[i = 4g + r][jj = j] of block (rb, cb) is gW[n0 + 4 i + rb][c0 + 4 jj + cb]
+  float4 v[4];
+#pragma unroll
+  for (int cb = 0; cb < 4; ++cb) {
+    const int idx = (wave * 4 + cb) * 64 + lane;
+    const float4 r0 = red[idx], r1 = red[1024 + idx], r2 = red[2048 + idx], r3 = red[3072 + idx];
+    v[cb].x = ((r0.x + r1.x) + r2.x) + r3.x;
+    v[cb].y = ((r0.y + r1.y) + r2.y) + r3.y;
+    v[cb].z = ((r0.z + r1.z) + r2.z) + r3.z;
+    v[cb].w = ((r0.w + r1.w) + r2.w) + r3.w;
+  }
+  float* o = out + (size_t)split * split_stride;
+  {
+    const int64_t nb = n0 + 16 * g + wave;
+    float* q = o + c0 + 4 * j;
+    *reinterpret_cast<float4*>(q + (nb + 0) * K) = make_float4(v[0].x, v[1].x, v[2].x, v[3].x);
+    *reinterpret_cast<float4*>(q + (nb + 4) * K) = make_float4(v[0].y, v[1].y, v[2].y, v[3].y);
+    *reinterpret_cast<float4*>(q + (nb + 8) * K) = make_float4(v[0].z, v[1].z, v[2].z, v[3].z);
+    *reinterpret_cast<float4*>(q + (nb + 12) * K) = make_float4(v[0].w, v[1].w, v[2].w, v[3].w);
+  }
+  if (bpart != nullptr && blockIdx.x == 0 && tid < 64)
+    bpart[(size_t)split * N + n0 + tid] = ((bred[0][tid] + bred[1][tid]) + bred[2][tid]) + bred[3][tid];
+}
+
+// adds the row ranges' partial gradients in range order (4 outputs per thread); the last block adds the bias partials
+__global__ __launch_bounds__(kBlock) void wg10_reduce_kernel(const float* __restrict__ P, int sp, int64_t total,
+                                                             float* __restrict__ gW, const float* __restrict__ bpart,
+                                                             int N, float* __restrict__ gb) {
+  const int64_t q = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (4 * q < total) {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int s = 0; s < sp; ++s) {
+      const float4 p = *reinterpret_cast<const float4*>(P + (size_t)s * total + 4 * q);
+      v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
+    }
+    *reinterpret_cast<float4*>(gW + 4 * q) = v;
+  }
+  if (gb != nullptr && blockIdx.x == gridDim.x - 1) {
+    for (int n = threadIdx.x; n < N; n += kBlock) {
+      float b = 0.f;
+      for (int s = 0; s < sp; ++s) b += bpart[(size_t)s * N + n];
+      gb[n] = b;
+    }
+  }
+}
+
+// ======================================================================================
 // OPT-IN split-precision product (MMSSL_GEMM_SPLIT=1 on the Python side; NOT the default path):
 //   C[i][j] = sum_k A[i][k] * B[j][k]   with A, B given as bf16 (hi, lo) pairs, x ~= hi + lo (16 mantissa bits),
 //   accumulated in fp32 as  hi*hi + hi*lo + lo*hi  on the bf16 matrix cores (v_mfma_f32_32x32x16_bf16).
@@ -1267,6 +1672,10 @@ inline int gemm_version() {
   return v;
 }
 inline bool dma_enabled() { return gemm_version() != 1; }
+inline bool gemm_nt() {
+  static const int v = getenv("MMSSL_GEMM_NT") ? atoi(getenv("MMSSL_GEMM_NT")) : 0;
+  return v != 0;
+}
 
 // stream-K decomposition (gemm_sk_kernel): `slots` equal unit ranges, at least min(S, 8) slices each
 struct SkPlan {
@@ -1374,6 +1783,51 @@ inline int launch_w8(const float* A, const float* B, int64_t I, int64_t J, int64
   }
   return 0;
 }
+inline bool r9_usable(int64_t KK) { return gemm_version() == 9 && KK % R9_KU == 0 && KK >= R9_KU; }
+inline int r9_slots() {
+  static const int v = getenv("MMSSL_GEMM_R9_BLOCKS") ? atoi(getenv("MMSSL_GEMM_R9_BLOCKS")) : 256;   // 1 per CU
+  return v > 0 ? v : 256;
+}
+inline SkPlan r9_plan(int64_t I, int64_t J, int64_t KK) {
+  SkPlan p;
+  p.tiles_i = (I + R9_I - 1) / R9_I;
+  p.tiles_j = (J + BT - 1) / BT;
+  p.S = (int)(KK / R9_KU);
+  p.total = p.tiles_i * p.tiles_j * p.S;
+  int64_t upb = (p.total + r9_slots() - 1) / r9_slots();
+  const int64_t floor_ = p.S < 2 ? p.S : 2;
+  if (upb < floor_) upb = floor_;
+  p.upb = (int)upb;
+  p.blocks = (int)((p.total + upb - 1) / upb);
+  return p;
+}
+inline int launch_r9(const float* A, const float* B, int64_t I, int64_t J, int64_t KK, float* C, int64_t ldc,
+                     int transpose_out, const float* b, const uint8_t* keep, float scale, float* part, hipStream_t s) {
+  static const int rc = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_r9_kernel<0>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, kR9LdsBytes) |
+                        (int)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_r9_kernel<1>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, kR9LdsBytes) |
+                        (int)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_r9_kernel<2>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, kR9LdsBytes) |
+                        (int)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_r9_kernel<4>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, kR9LdsBytes) |
+                        (int)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_r9_kernel<6>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, kR9LdsBytes);
+  if (rc != 0) return MMSSL_E_UNSUPP;
+  const SkPlan p = r9_plan(I, J, KK);
+  const char* dm = getenv("MMSSL_GEMM_R9_MODE");        // debugging aid: 1 = no loads in the loop, 2 = no MFMAs
+  const int dbg = dm ? atoi(dm) : 0;
+  auto* kern = dbg == 1 ? gemm_r9_kernel<1> : (dbg == 2 ? gemm_r9_kernel<2> : (dbg == 4 ? gemm_r9_kernel<4> : (dbg == 6 ? gemm_r9_kernel<6> : gemm_r9_kernel<0>)));
+  hipLaunchKernelGGL(kern, dim3((unsigned)p.blocks), dim3(kBlock), kR9LdsBytes, s, A, KK, B, KK, I, J,
+                     (int)p.tiles_j, p.S, p.total, p.upb, C, ldc, transpose_out, b, keep, scale, part);
+  MMSSL_LAUNCH_CHECK();
+  if (p.upb % p.S != 0) {
+    hipLaunchKernelGGL(r9_reduce_kernel, dim3((unsigned)(p.tiles_i * p.tiles_j)), dim3(kBlock), 0, s, part,
+                       (int)p.tiles_j, p.S, p.total, p.upb, I, J, C, ldc, transpose_out, b, keep, scale);
+    MMSSL_LAUNCH_CHECK();
+  }
+  return 0;
+}
 inline size_t pp_ws_bytes(int64_t I, int64_t J, int64_t KK) {
   return (size_t)pp_plan(I, J, KK).blocks * 2 * kPpTileFloats * sizeof(float) + 16;
 }
@@ -1402,6 +1856,10 @@ inline int64_t chunk_for(int64_t KK, int splits) {
 
 extern "C" size_t mmssl_linear_workspace_bytes(int64_t M, int K, int N) {
   if (M <= 0 || K <= 0 || N <= 0) return 16;
+  if (r9_usable(K)) {
+    const SkPlan p = pp_swap(M, N) ? r9_plan(N, M, K) : r9_plan(M, N, K);
+    return (size_t)p.blocks * 2 * kR9TileFloats * sizeof(float) + 16;
+  }
   if (w8_usable(K)) {
     const SkPlan p = pp_swap(M, N) ? w8_plan(N, M, K) : w8_plan(M, N, K);
     return (size_t)p.blocks * 2 * kW8TileFloats * sizeof(float) + 16;
@@ -1422,6 +1880,12 @@ extern "C" int mmssl_linear_f32(const float* F, const float* W, const float* b, 
   if (M == 0) return 0;
   if (((uintptr_t)F | (uintptr_t)W | (uintptr_t)Y) & 15) return MMSSL_E_BADARG;
   hipStream_t s = as_stream(stream);
+  if (r9_usable(K)) {
+    if (!workspace || workspace_bytes < mmssl_linear_workspace_bytes(M, K, N)) return MMSSL_E_WORKSPACE;
+    float* part = reinterpret_cast<float*>(workspace);
+    if (pp_swap(M, N)) return launch_r9(W, F, N, M, K, Y, (int64_t)N, 1, nullptr, nullptr, 1.f, part, s);
+    return launch_r9(F, W, M, N, K, Y, (int64_t)N, 0, b, keep, scale, part, s);
+  }
   if (w8_usable(K)) {
     if (!workspace || workspace_bytes < mmssl_linear_workspace_bytes(M, K, N)) return MMSSL_E_WORKSPACE;
     float* part = reinterpret_cast<float*>(workspace);
@@ -1443,7 +1907,7 @@ extern "C" int mmssl_linear_f32(const float* F, const float* W, const float* b, 
     const char* pr = getenv("MMSSL_GEMM_PRIO");
     hipLaunchKernelGGL(gemm_sk_kernel, dim3((unsigned)p.blocks), dim3(kBlock), 0, s, F, (int64_t)K, W, (int64_t)K, M,
                        (int64_t)N, (int)p.tiles_j, p.S, p.total, p.upb, Y, (int64_t)N, b, keep, scale, part,
-                       pr ? atoi(pr) : 0);
+                       ((pr ? atoi(pr) : 0) & 1) | (gemm_nt() ? 2 : 0));
     MMSSL_LAUNCH_CHECK();
     if (p.upb % p.S != 0) {        // some range ends inside a tile: partial slots exist
       hipLaunchKernelGGL(sk_reduce_kernel, dim3((unsigned)(p.tiles_i * p.tiles_j)), dim3(kBlock), 0, s, part,
@@ -1592,11 +2056,46 @@ extern "C" int mmssl_transpose_mask_f32(const float* G, const uint8_t* keep, flo
   return 0;
 }
 
+namespace {
+// v10 decomposition: 64x64 output tiles x `sp` row ranges, about one block per CU (measured: 256 blocks 93 / 34 us, 512 blocks 94 / 46 us for the Baby image / text shapes), ranges of at least 128 rows
+struct WgPlan {
+  int tk, tn, sp;
+  int64_t ms;
+};
+inline bool wg10_usable(int64_t M, int K, int N) {
+  static const int v = getenv("MMSSL_WGRAD_V") ? atoi(getenv("MMSSL_WGRAD_V")) : 10;
+  return v == 10 && K % 64 == 0 && N % 64 == 0 && M * (int64_t)(K > N ? K : N) < ((int64_t)1 << 30) &&
+         K < (1 << 18) && N < (1 << 18);
+}
+inline WgPlan wg10_plan(int64_t M, int K, int N) {
+  static const int target = getenv("MMSSL_WG10_BLOCKS") ? atoi(getenv("MMSSL_WG10_BLOCKS")) : 256;
+  WgPlan p;
+  p.tk = K / 64;
+  p.tn = N / 64;
+  const int64_t tiles = (int64_t)p.tk * p.tn;
+  int64_t sp = ((target > 0 ? target : 256) + tiles - 1) / tiles;
+  const int64_t cap = M / 128 > 0 ? M / 128 : 1;
+  if (sp > cap) sp = cap;
+  if (sp < 1) sp = 1;
+  p.ms = ((M + sp - 1) / sp + 15) / 16 * 16;
+  p.sp = (int)((M + p.ms - 1) / p.ms);
+  return p;
+}
+}  // namespace
+
 extern "C" size_t mmssl_linear_wgrad_workspace_bytes(int64_t M, int K, int N) {
   if (M <= 0 || K <= 0 || N <= 0) return 16;
+  if (wg10_usable(M, K, N)) {
+    const WgPlan p = wg10_plan(M, K, N);
+    return ((size_t)p.sp * (size_t)N * (size_t)K + (size_t)p.sp * (size_t)N) * sizeof(float) + 16;
+  }
   const int splits = choose_splits(((N + BT - 1) / BT) * ((K + BT - 1) / BT), M);
   const size_t part = splits > 1 ? (size_t)splits * (size_t)N * (size_t)K * sizeof(float) : 0;
   return part + (size_t)kColsumBlocks * (size_t)N * sizeof(float) + 16;
+}
+
+extern "C" int mmssl_linear_wgrad_fuses_mask(int64_t M, int K, int N) {
+  return (M > 0 && K > 0 && N > 0 && wg10_usable(M, K, N)) ? 1 : 0;
 }
 
 extern "C" int mmssl_linear_wgrad_f32(const float* gY, const uint8_t* keep, float scale, const float* F, int64_t M,
@@ -1606,6 +2105,26 @@ extern "C" int mmssl_linear_wgrad_f32(const float* gY, const uint8_t* keep, floa
   if ((K & 3) || (N & 3) || N > 256) return MMSSL_E_UNSUPP;
   if (!workspace || workspace_bytes < mmssl_linear_wgrad_workspace_bytes(M, K, N)) return MMSSL_E_WORKSPACE;
   hipStream_t s = as_stream(stream);
+  if (wg10_usable(M, K, N)) {
+    if (((uintptr_t)gY | (uintptr_t)F | (uintptr_t)gW | (uintptr_t)keep) & 3) return MMSSL_E_BADARG;
+    if (((uintptr_t)gY | (uintptr_t)F | (uintptr_t)gW) & 15) return MMSSL_E_BADARG;
+    const WgPlan p = wg10_plan(M, K, N);
+    float* P = reinterpret_cast<float*>(workspace);      // [sp][N][K]
+    float* bpart = P + (size_t)p.sp * N * K;             // [sp][N]
+    const bool direct = p.sp == 1;
+    auto* kern = keep ? (gemm_nt() ? wgrad10_kernel<true, true> : wgrad10_kernel<true, false>)
+                      : (gemm_nt() ? wgrad10_kernel<false, true> : wgrad10_kernel<false, false>);
+    hipLaunchKernelGGL(kern, dim3((unsigned)p.tk, (unsigned)p.tn, (unsigned)p.sp), dim3(kBlock), 0, s, gY, keep, scale, F,
+                       M, K, N, p.ms, direct ? gW : P, (int64_t)N * K, gb ? (direct ? gb : bpart) : (float*)nullptr);
+    MMSSL_LAUNCH_CHECK();
+    if (!direct) {
+      const int64_t total = (int64_t)N * K;
+      const int64_t nb = (total / 4 + kBlock - 1) / kBlock;
+      hipLaunchKernelGGL(wg10_reduce_kernel, dim3((unsigned)nb), dim3(kBlock), 0, s, P, p.sp, total, gW, bpart, N, gb);
+      MMSSL_LAUNCH_CHECK();
+    }
+    return 0;
+  }
   const int64_t tn = (N + BT - 1) / BT, tk = (K + BT - 1) / BT;
   const int splits = choose_splits(tn * tk, M);
   const int64_t chunk = chunk_for(M, splits);

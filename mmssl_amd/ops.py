@@ -397,7 +397,17 @@ def _linear_wgrad_raw(gY, keep, scale, F_, W):
     ft = _FT.get((F_.data_ptr(), tuple(F_.shape))) if wgrad_ft_enabled() else None
     if ft is not None and N % 4 == 0 and N <= 256:
         return _linear_wgrad_ft(gY0, keep, scale, F_, W, ft[0], ft[1])
-    if keep is not None:        # dropout backward: one pass (the in-fetch variant of wgrad measured slower)
+    fused = keep is not None and _lib.lib().mmssl_linear_wgrad_fuses_mask(M, K, N) == 1
+    if fused:                   # register-direct kernel: dropout backward + bias gradient on the loaded fragments
+        gW = torch.empty_like(W)
+        gb = torch.empty(N, dtype=torch.float32, device=W.device)
+        nb = _lib.lib().mmssl_linear_wgrad_workspace_bytes(M, K, N)
+        ws = torch.empty(max(nb // 4, 4), dtype=torch.float32, device=W.device)
+        rc = _lib.lib().mmssl_linear_wgrad_f32(_ptr(gY), _ptr(keep), float(scale), _ptr(F_), M, K, N, _ptr(gW), _ptr(gb),
+                                               _ptr(ws), nb, _lib.stream_ptr())
+        _lib.check(rc, "mmssl_linear_wgrad_f32")
+        return None, gW, gb
+    if keep is not None:        # register-staged kernel: one dropout-backward pass first (its in-fetch variant is slower)
         gYm = torch.empty_like(gY)
         rc = _lib.lib().mmssl_mask_scale_f32(_ptr(gY), _ptr(keep), float(scale), gY.numel(), _ptr(gYm),
                                              _lib.stream_ptr())
@@ -1130,6 +1140,25 @@ class _HotForward(torch.autograd.Function):
                           (txt_item, sB), (uG, sC), (iG, sC), (Gu, sA), (Gu, sC), (Gi, sB), (Gi, sC)):
                 if t is not None and _os.environ.get("MMSSL_NO_RECORD_STREAM") != "1":
                     t.record_stream(st)     # main-pool tensors read on side streams, possibly after this backward returned
+        out = {}
+
+        def chain_c():
+            with torch.cuda.stream(sC):
+                uic, iuc = ui.twin(2), iu.twin(2)
+                gi = softmax_rows_bwd(iG, Gi, inv)
+                gu = _spmm_raw(iuc, True, gi, EPI_AXPY_SOFTMAX_BWD, Gu, inv, uG)
+                gi = _spmm_raw(uic, True, gu, EPI_AXPY, Gi, inv)
+                for _ in range(n_layers - 1):
+                    gu = _spmm_raw(iuc, True, gi, EPI_AXPY, Gu, inv)
+                    gi = _spmm_raw(uic, True, gu, EPI_AXPY, Gi, inv)
+                out["gi"] = gi
+
+        c_first = overlap and _os.environ.get("MMSSL_BWD_C_FIRST", "0") == "1"
+        if c_first:
+            # experiment (MMSSL_BWD_C_FIRST=1): record the GCN chain before the combines. It then starts 70 us earlier,
+            # but runs next to the weight-gradient GEMMs for longer and both stretch (wgrad 122 -> 174 us, SpMM 16 ->
+            # 50-60 us): 0.640 vs 0.633 ms per Baby step, so the default keeps it after the exchange.
+            chain_c()
         if split:
             with torch.cuda.stream(sA):
                 g_iu_, g_tu_, g_u0 = _combine_bwd(img_user, txt_user, Gu, r, inv, g_ss, 2.0, True)
@@ -1160,19 +1189,6 @@ class _HotForward(torch.autograd.Function):
                 for t, st in ((g_ii_, sA), (g_iu_, sA), (g_ti_, sB), (g_tu_, sB)):
                     if _os.environ.get("MMSSL_NO_RECORD_STREAM") != "1":
                         t.record_stream(st)
-        out = {}
-
-        def chain_c():
-            with torch.cuda.stream(sC):
-                uic, iuc = ui.twin(2), iu.twin(2)
-                gi = softmax_rows_bwd(iG, Gi, inv)
-                gu = _spmm_raw(iuc, True, gi, EPI_AXPY_SOFTMAX_BWD, Gu, inv, uG)
-                gi = _spmm_raw(uic, True, gu, EPI_AXPY, Gi, inv)
-                for _ in range(n_layers - 1):
-                    gu = _spmm_raw(iuc, True, gi, EPI_AXPY, Gu, inv)
-                    gi = _spmm_raw(uic, True, gu, EPI_AXPY, Gi, inv)
-                out["gi"] = gi
-
         def chain_a():
             with torch.cuda.stream(sA):
                 g_x_img = _spmm_raw(ui, True, _spmm_raw(iu, True, g_ii_, EPI_AXPY, g_iu_, 1.0), EPI_NONE)
@@ -1185,7 +1201,8 @@ class _HotForward(torch.autograd.Function):
 
         chains = {"A": chain_a, "B": chain_b, "C": chain_c}
         for c in _branch_order("MMSSL_BWD_ORDER", "CAB"):
-            chains[c]()
+            if not (c == "C" and c_first):
+                chains[c]()
         gi, gW_img, gb_img, gW_txt, gb_txt = out["gi"], out["gW_img"], out["gb_img"], out["gW_txt"], out["gb_txt"]
         if overlap:
             # g_u0 (sA before the exchange, or the current stream) and gi (sC) are what the embedding tables need; in

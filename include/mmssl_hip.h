@@ -238,6 +238,16 @@ size_t mmssl_linear_workspace_bytes(int64_t M, int K, int N);   /* split-K parti
 int mmssl_linear_f32(const float* F, const float* W, const float* b, const uint8_t* keep,
                      float scale, int64_t M, int K, int N, float* Y, void* workspace,
                      size_t workspace_bytes, void* stream);
+/* The same product with the stream-K fix-up done inside the kernel: `tickets` = mmssl_linear_ticket_count(M, K, N)
+ * ints (one per output tile), ZERO before the first call and left zero by every call, private to calls that may run
+ * concurrently. The last block to deliver a partial of a tile adds the tile's partials in block order (bitwise the
+ * result of mmssl_linear_f32) and applies bias + dropout: no second launch between the product and its consumer.
+ * ticket_count == 0: this shape / kernel generation has no fix-up form, call mmssl_linear_f32. tickets == NULL is
+ * mmssl_linear_f32. */
+int64_t mmssl_linear_ticket_count(int64_t M, int K, int N);
+int mmssl_linear_tk_f32(const float* F, const float* W, const float* b, const uint8_t* keep,
+                        float scale, int64_t M, int K, int N, float* Y, void* workspace,
+                        size_t workspace_bytes, int* tickets, void* stream);
 /* OPT-IN split-precision product (not used unless the caller asks for it): Y[M,N] = A . B^T (+ bias, dropout
  * as in mmssl_linear_f32) with A [M,K] and B [N,K] each given as TWO bf16 matrices (hi = bf16(x),
  * lo = bf16(x - hi)); the result is hi*hi + hi*lo + lo*hi accumulated in fp32 on the bf16 matrix cores
@@ -358,6 +368,17 @@ size_t mmssl_infonce_multi_workspace_bytes(int n_problems, int64_t n, int d);
 int mmssl_infonce_multi_fwd_f32(const float* const* z1s, const float* z2, const int64_t* idx,
                                 int n_problems, int64_t n, int d, float tau, float* losses,
                                 void* workspace, size_t workspace_bytes, void* stream);
+/* The forward in two phases: bit 0 = row terms (prep, pair tiles, per-row log terms: everything the backward
+ * needs), bit 1 = the loss scalars from the row terms. A caller that already knows the upstream gradient of the
+ * losses can start the backward right after phase 1 and leave phase 2 off its critical path. */
+int mmssl_infonce_multi_fwd_phase_f32(const float* const* z1s, const float* z2, const int64_t* idx,
+                                      int n_problems, int64_t n, int d, float tau, float* losses,
+                                      void* workspace, size_t workspace_bytes, int phases, void* stream);
+/* The whole forward without the separate loss-reduction launch: the last row-term block of each problem to arrive
+ * reduces that problem's loss (same arithmetic, same value). tickets: n_problems ints, 0 on entry, left 0. */
+int mmssl_infonce_multi_fwd_ticket_f32(const float* const* z1s, const float* z2, const int64_t* idx,
+                                       int n_problems, int64_t n, int d, float tau, float* losses,
+                                       void* workspace, size_t workspace_bytes, int* tickets, void* stream);
 int mmssl_infonce_multi_bwd_f32(const int64_t* idx, int n_problems, int64_t n, int d, float tau,
                                 const float* gloss, float* const* gz1s, float* gz2, void* workspace,
                                 size_t workspace_bytes, void* stream);
@@ -389,6 +410,18 @@ int mmssl_bpr_bwd_f32(const float* Eu, const float* Ei, const float* Ei_neg, con
                       const int64_t* pos, const int64_t* neg, int64_t B, int d, float decay,
                       int64_t batch_size, const float* g_mf, const float* g_emb, float* gEu,
                       float* gEi, float* gEi_neg, void* stream);
+/* The hot step's loss tail as ONE launch (main.py:368-371, 420, 499-511 for a caller that knows the upstream
+ * gradients): BPR backward of the gathered rows for the device scalars g_mf / g_emb (scatter-add into gEu / gEi, which
+ * the caller zero-filled or already holds other gradients), the BPR loss values terms[0..2] = (mf, emb, 0) by a
+ * last-arriving-block reduction, total = sum_k w[k] * terms[k] + c * extra[0] (terms[3..n_terms-1] are read), and +1 on
+ * the given counters (see mmssl_loss_assemble_tick_f32). workspace: mmssl_bpr_workspace_bytes(B); ticket: one int,
+ * 0 on entry, left 0. */
+int mmssl_bpr_step_f32(const float* Eu, const float* Ei, const int64_t* users, const int64_t* pos,
+                       const int64_t* neg, int64_t B, int d, float decay, int64_t batch_size,
+                       const float* g_mf, const float* g_emb, float* gEu, float* gEi, float* terms,
+                       const float* w, int n_terms, const float* extra, float c, float* total,
+                       float* const* f32_ticks, int n_f32, uint64_t* const* u64_ticks, int n_u64,
+                       void* workspace, size_t workspace_bytes, int* ticket, void* stream);
 
 #ifdef __cplusplus
 }

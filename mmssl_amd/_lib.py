@@ -88,6 +88,9 @@ SIGNATURES = {
     "mmssl_transpose_mask_f32": (c_int, [c_void_p, c_void_p, c_float, c_int64, c_int, c_int64, c_void_p, c_void_p,
                                          c_void_p, c_size_t, c_void_p]),
     "mmssl_linear_wgrad_workspace_bytes": (c_size_t, [c_int64, c_int, c_int]),
+    "mmssl_linear_ticket_count": (c_int64, [c_int64, c_int, c_int]),
+    "mmssl_linear_tk_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int64, c_int, c_int, c_void_p,
+                                    c_void_p, c_size_t, c_void_p, c_void_p]),
     "mmssl_linear_wgrad_fuses_mask": (c_int, [c_int64, c_int, c_int]),
     "mmssl_linear_wgrad_f32": (c_int, [c_void_p, c_void_p, c_float, c_void_p, c_int64, c_int, c_int, c_void_p,
                                        c_void_p, c_void_p, c_size_t, c_void_p]),
@@ -116,6 +119,13 @@ SIGNATURES = {
                                             c_void_p, c_size_t, c_void_p]),
     "mmssl_infonce_multi_bwd_f32": (c_int, [c_void_p, c_int, c_int64, c_int, c_float, c_void_p, c_void_p, c_void_p,
                                             c_void_p, c_size_t, c_void_p]),
+    "mmssl_infonce_multi_fwd_phase_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int, c_float, c_void_p,
+                                                  c_void_p, c_size_t, c_int, c_void_p]),
+    "mmssl_infonce_multi_fwd_ticket_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int, c_float, c_void_p,
+                                                   c_void_p, c_size_t, c_void_p, c_void_p]),
+    "mmssl_bpr_step_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_float, c_int64,
+                                   c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_float,
+                                   c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_size_t, c_void_p, c_void_p]),
     "mmssl_infonce_multi_bwd_phase_f32": (c_int, [c_void_p, c_int, c_int64, c_int, c_float, c_void_p, c_void_p,
                                                   c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
     "mmssl_bpr_workspace_bytes": (c_size_t, [c_int64]),

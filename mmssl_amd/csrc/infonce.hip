@@ -212,8 +212,11 @@ __global__ __launch_bounds__(kBlock) void fwd_tiles_kernel(const float* __restri
 }
 
 // ---- finalize: per-row backward coefficients (row-parallel) + loss (fixed-order two-stage sum) ----
+// `tickets` (one int per problem, 0 on entry, left 0) != NULL: the last block of a problem to arrive also reduces the
+// row terms to the loss (the arithmetic of finalize_loss_kernel), which then is not launched.
 __global__ __launch_bounds__(kBlock) void finalize_rows_kernel(float* __restrict__ ws, size_t ws_stride, Layout L,
-                                                               int cs, int64_t n, float tau, float log_eps) {
+                                                               int cs, int64_t n, float tau, float log_eps,
+                                                               int* __restrict__ tickets, float* __restrict__ losses) {
   float* __restrict__ wsp = ws + (size_t)blockIdx.y * ws_stride;
   const float* __restrict__ rows_part = wsp + L.rows_part;
   const float* __restrict__ pos = wsp + L.pos;
@@ -233,7 +236,26 @@ __global__ __launch_bounds__(kBlock) void finalize_rows_kernel(float* __restrict
     c[i] = wi / (Dn * tau);
   }
   const float t = block_sum_256(li, red);
-  if (threadIdx.x == 0) loss_part[blockIdx.x] = t;
+  if (tickets == nullptr) {
+    if (threadIdx.x == 0) loss_part[blockIdx.x] = t;
+    return;
+  }
+  __shared__ int s_last;
+  if (threadIdx.x == 0) {
+    __hip_atomic_store(reinterpret_cast<unsigned*>(loss_part) + blockIdx.x, __float_as_uint(t), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __threadfence();
+    const int prev = __hip_atomic_fetch_add(tickets + blockIdx.y, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    s_last = (prev == (int)gridDim.x - 1);
+    if (s_last) __hip_atomic_store(tickets + blockIdx.y, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+  if (!s_last) return;
+  __threadfence();
+  float acc = 0.f;
+  for (int k = threadIdx.x; k < (int)gridDim.x; k += kBlock)
+    acc += __uint_as_float(__hip_atomic_load(reinterpret_cast<unsigned*>(loss_part) + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+  const float tt = block_sum_256(acc, red);
+  if (threadIdx.x == 0) losses[blockIdx.y] = tt / (float)n;
 }
 __global__ __launch_bounds__(kBlock) void finalize_loss_kernel(const float* __restrict__ ws, size_t ws_stride,
                                                                Layout L, int nparts, int64_t n,
@@ -740,7 +762,7 @@ namespace {
 
 int infonce_fwd_impl(const float* const* z1s, const float* z2, const int64_t* idx, int P, int64_t n, int d,
                      float tau, float* losses, void* workspace, size_t workspace_bytes, void* stream,
-                     float log_eps = 1e-8f) {
+                     float log_eps = 1e-8f, int phases = 3, int* tickets = nullptr) {
   if (P < 1 || P > kMaxProblems || n <= 0 || !z1s || !z2 || !losses || !(tau > 0.f)) return MMSSL_E_BADARG;
   if (!infonce_d_ok(d)) return MMSSL_E_UNSUPP;
   const Layout L = make_layout(n, d);
@@ -756,6 +778,12 @@ int infonce_fwd_impl(const float* const* z1s, const float* z2, const int64_t* id
   hipStream_t s = as_stream(stream);
   const int nt = n_tiles(n);
   const int rb = (int)((n + 15) / 16);
+  const int fb = (int)((n + kBlock - 1) / kBlock);
+  if (!(phases & 1)) {                      // phase 2 alone: only the loss scalars from the row terms
+    hipLaunchKernelGGL(finalize_loss_kernel, dim3(1, P), dim3(kBlock), 0, s, ws, L.total, L, fb, n, losses);
+    MMSSL_LAUNCH_CHECK();
+    return 0;
+  }
   hipLaunchKernelGGL(prep_kernel, dim3(rb, P), dim3(kBlock), 0, s, Z, z2, idx, n, d, ws, L.total, L);
   MMSSL_LAUNCH_CHECK();
   const dim3 grid(nt * L.cs_f, P);
@@ -769,9 +797,10 @@ int infonce_fwd_impl(const float* const* z1s, const float* z2, const int64_t* id
     case 256: hipLaunchKernelGGL((fwd_tiles_kernel<256>), grid, dim3(kBlock), 0, s, ws, L.total, L, n, tau, L.cs_f); break;
   }
   MMSSL_LAUNCH_CHECK();
-  const int fb = (int)((n + kBlock - 1) / kBlock);
-  hipLaunchKernelGGL(finalize_rows_kernel, dim3(fb, P), dim3(kBlock), 0, s, ws, L.total, L, L.cs_f, n, tau, log_eps);
+  hipLaunchKernelGGL(finalize_rows_kernel, dim3(fb, P), dim3(kBlock), 0, s, ws, L.total, L, L.cs_f, n, tau, log_eps,
+                     tickets, losses);
   MMSSL_LAUNCH_CHECK();
+  if (tickets || !(phases & 2)) return 0;
   hipLaunchKernelGGL(finalize_loss_kernel, dim3(1, P), dim3(kBlock), 0, s, ws, L.total, L, fb, n, losses);
   MMSSL_LAUNCH_CHECK();
   return 0;
@@ -864,6 +893,23 @@ extern "C" int mmssl_infonce_multi_fwd_f32(const float* const* z1s, const float*
                                            int n_problems, int64_t n, int d, float tau, float* losses,
                                            void* workspace, size_t workspace_bytes, void* stream) {
   return infonce_fwd_impl(z1s, z2, idx, n_problems, n, d, tau, losses, workspace, workspace_bytes, stream);
+}
+
+extern "C" int mmssl_infonce_multi_fwd_phase_f32(const float* const* z1s, const float* z2, const int64_t* idx,
+                                                 int n_problems, int64_t n, int d, float tau, float* losses,
+                                                 void* workspace, size_t workspace_bytes, int phases, void* stream) {
+  if (phases < 1 || phases > 3) return MMSSL_E_BADARG;
+  return infonce_fwd_impl(z1s, z2, idx, n_problems, n, d, tau, losses, workspace, workspace_bytes, stream, 1e-8f,
+                          phases);
+}
+
+extern "C" int mmssl_infonce_multi_fwd_ticket_f32(const float* const* z1s, const float* z2, const int64_t* idx,
+                                                  int n_problems, int64_t n, int d, float tau, float* losses,
+                                                  void* workspace, size_t workspace_bytes, int* tickets,
+                                                  void* stream) {
+  if (!tickets) return MMSSL_E_BADARG;
+  return infonce_fwd_impl(z1s, z2, idx, n_problems, n, d, tau, losses, workspace, workspace_bytes, stream, 1e-8f, 3,
+                          tickets);
 }
 
 extern "C" int mmssl_infonce_multi_bwd_f32(const int64_t* idx, int n_problems, int64_t n, int d, float tau,

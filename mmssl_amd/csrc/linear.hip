@@ -319,8 +319,10 @@ __global__ __launch_bounds__(kBlock) void gemm_sk_kernel(const float* __restrict
                                                          float* __restrict__ C, int64_t ldc,
                                                          const float* __restrict__ bias,
                                                          const uint8_t* __restrict__ keep, float scale,
-                                                         float* __restrict__ partials, int prio) {
+                                                         float* __restrict__ partials, int prio,
+                                                         int* __restrict__ tickets) {
   __shared__ __attribute__((aligned(16))) float ring[kDmaStages * kDmaStageFloats];     // 64 KB
+  __shared__ int s_last;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int h = lane >> 5, lr = lane & 31;
@@ -445,11 +447,67 @@ __global__ __launch_bounds__(kBlock) void gemm_sk_kernel(const float* __restrict
           C[row * ldc + col] = v;
         }
       }
-    } else {                                    // partial range: raw accumulator image, thread-major float4s
+    } else if (tickets == nullptr) {            // partial range: raw accumulator image, thread-major float4s
       const int seg = (u == u_begin) ? 0 : 1;
       float4* P = reinterpret_cast<float4*>(partials + ((size_t)blockIdx.x * 2 + seg) * kSkTileFloats);
 #pragma unroll
       for (int q = 0; q < 4; ++q) P[q * kBlock + tid] = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+    } else {
+      // In-kernel fix-up: the LAST block to deliver a tile's partial adds all of them in block order (the order
+      // sk_reduce_kernel uses: the result does not depend on who is last) and runs the epilogue; no second kernel
+      // stands between the product and its consumer. The images travel as write-through (sc1) stores and sc1 loads,
+      // like the SpMM's in-kernel combine (graph.hip): no release/acquire fence, other dirty lines stay in this L2.
+      typedef unsigned long long u64;
+      const int seg = (u == u_begin) ? 0 : 1;
+      u64* P = reinterpret_cast<u64*>(partials + ((size_t)blockIdx.x * 2 + seg) * kSkTileFloats);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        u64 v;
+        const float2 f2 = make_float2(acc[2 * q], acc[2 * q + 1]);
+        __builtin_memcpy(&v, &f2, 8);
+        __hip_atomic_store(P + q * kBlock + tid, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      const int64_t u_lo = tile * S;
+      const int64_t b_first = u_lo / upb, b_last = (u_lo + S - 1) / upb;
+      if (tid == 0) {
+        const int prev = __hip_atomic_fetch_add(tickets + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = prev == (int)(b_last - b_first);
+        if (last) __hip_atomic_store(tickets + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // re-arm
+        s_last = last;
+      }
+      __syncthreads();
+      if (s_last) {
+        float v[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = 0.f;
+        for (int64_t b = b_first; b <= b_last; ++b) {
+          const int sg = (b * upb < u_lo) ? 1 : 0;
+          const u64* Q = reinterpret_cast<const u64*>(partials + ((size_t)b * 2 + sg) * kSkTileFloats);
+          u64 w[8];
+#pragma unroll
+          for (int q = 0; q < 8; ++q) w[q] = __hip_atomic_load(Q + q * kBlock + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+          for (int q = 0; q < 8; ++q) {
+            float2 f2;
+            __builtin_memcpy(&f2, &w[q], 8);
+            v[2 * q] += f2.x;
+            v[2 * q + 1] += f2.y;
+          }
+        }
+        const int64_t col = j0 + wn * 32 + (lane & 31);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int64_t row = i0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          if (row < I && col < J) {
+            float x = v[r];
+            if (bias) x += bias[col];
+            if (keep) x = keep[row * J + col] ? x * scale : 0.f;
+            C[row * ldc + col] = x;
+          }
+        }
+      }
     }
     u += nk;
   }
@@ -1272,10 +1330,9 @@ __global__ __launch_bounds__(kBlock) void r9_reduce_kernel(const float* __restri
 // Preconditions (host-checked): K % 64 == 0, N % 64 == 0.
 // ======================================================================================
 typedef float floatx4 __attribute__((ext_vector_type(4)));
-constexpr int WG_D = 8;
 
-template <bool KEEP, bool NT>
-__global__ __launch_bounds__(kBlock, 2) void wgrad10_kernel(const float* __restrict__ gY,
+template <bool KEEP, bool NT, int WG_D>
+__global__ __launch_bounds__(kBlock, WG_D <= 8 ? 2 : 1) void wgrad10_kernel(const float* __restrict__ gY,
                                                             const uint8_t* __restrict__ keep, float scale,
                                                             const float* __restrict__ F, int64_t M, int K, int N,
                                                             int64_t ms, float* __restrict__ out, int64_t split_stride,
@@ -1871,9 +1928,30 @@ extern "C" size_t mmssl_linear_workspace_bytes(int64_t M, int K, int N) {
   return splits > 1 ? (size_t)splits * (size_t)M * (size_t)N * sizeof(float) : 16;
 }
 
+static int linear_impl(const float* F, const float* W, const float* b, const uint8_t* keep, float scale, int64_t M,
+                       int K, int N, float* Y, void* workspace, size_t workspace_bytes, int* tickets, void* stream);
+
 extern "C" int mmssl_linear_f32(const float* F, const float* W, const float* b, const uint8_t* keep, float scale,
                                 int64_t M, int K, int N, float* Y, void* workspace, size_t workspace_bytes,
                                 void* stream) {
+  return linear_impl(F, W, b, keep, scale, M, K, N, Y, workspace, workspace_bytes, nullptr, stream);
+}
+
+extern "C" int64_t mmssl_linear_ticket_count(int64_t M, int K, int N) {
+  if (M <= 0 || K <= 0 || N <= 0 || gemm_version() != 6 || !sk_usable(K)) return 0;
+  const SkPlan p = sk_plan(M, N, K);
+  return p.tiles_i * p.tiles_j;
+}
+
+extern "C" int mmssl_linear_tk_f32(const float* F, const float* W, const float* b, const uint8_t* keep, float scale,
+                                   int64_t M, int K, int N, float* Y, void* workspace, size_t workspace_bytes,
+                                   int* tickets, void* stream) {
+  if (tickets && (((uintptr_t)tickets & 3) || mmssl_linear_ticket_count(M, K, N) == 0)) return MMSSL_E_BADARG;
+  return linear_impl(F, W, b, keep, scale, M, K, N, Y, workspace, workspace_bytes, tickets, stream);
+}
+
+static int linear_impl(const float* F, const float* W, const float* b, const uint8_t* keep, float scale, int64_t M,
+                       int K, int N, float* Y, void* workspace, size_t workspace_bytes, int* tickets, void* stream) {
   if (M < 0 || K <= 0 || N <= 0 || (M > 0 && (!F || !W || !Y))) return MMSSL_E_BADARG;
   if ((K & 3) || (N & 3)) return MMSSL_E_UNSUPP;
   if (N > 256 && (b || keep || !sk_usable(K))) return MMSSL_E_UNSUPP;   // wide outputs: plain product only (wgrad)
@@ -1907,9 +1985,9 @@ extern "C" int mmssl_linear_f32(const float* F, const float* W, const float* b, 
     const char* pr = getenv("MMSSL_GEMM_PRIO");
     hipLaunchKernelGGL(gemm_sk_kernel, dim3((unsigned)p.blocks), dim3(kBlock), 0, s, F, (int64_t)K, W, (int64_t)K, M,
                        (int64_t)N, (int)p.tiles_j, p.S, p.total, p.upb, Y, (int64_t)N, b, keep, scale, part,
-                       ((pr ? atoi(pr) : 0) & 1) | (gemm_nt() ? 2 : 0));
+                       ((pr ? atoi(pr) : 0) & 1) | (gemm_nt() ? 2 : 0), tickets);
     MMSSL_LAUNCH_CHECK();
-    if (p.upb % p.S != 0) {        // some range ends inside a tile: partial slots exist
+    if (p.upb % p.S != 0 && !tickets) {        // some range ends inside a tile: partial slots exist
       hipLaunchKernelGGL(sk_reduce_kernel, dim3((unsigned)(p.tiles_i * p.tiles_j)), dim3(kBlock), 0, s, part,
                          (int)p.tiles_j, p.S, p.total, p.upb, M, (int64_t)N, Y, (int64_t)N, b, keep, scale);
       MMSSL_LAUNCH_CHECK();
@@ -2057,7 +2135,10 @@ extern "C" int mmssl_transpose_mask_f32(const float* G, const uint8_t* keep, flo
 }
 
 namespace {
-// v10 decomposition: 64x64 output tiles x `sp` row ranges, about one block per CU (measured: 256 blocks 93 / 34 us, 512 blocks 94 / 46 us for the Baby image / text shapes), ranges of at least 128 rows
+// v10 decomposition: 64x64 output tiles x `sp` row ranges of at least 128 rows, about two blocks per CU. Measured for the
+// Baby image / text shapes: alone, 256 blocks 93 / 34 us and 512 blocks 94 / 46 us; inside the hot-path step (next to the
+// SpMM chains) 512 blocks 0.610-0.620 ms per step, 256 blocks 0.625 ms - a second resident block covers the load latency
+// that grows when the SpMMs share the CU - so the default follows the step.
 struct WgPlan {
   int tk, tn, sp;
   int64_t ms;
@@ -2068,14 +2149,16 @@ inline bool wg10_usable(int64_t M, int K, int N) {
          K < (1 << 18) && N < (1 << 18);
 }
 inline WgPlan wg10_plan(int64_t M, int K, int N) {
-  static const int target = getenv("MMSSL_WG10_BLOCKS") ? atoi(getenv("MMSSL_WG10_BLOCKS")) : 256;
+  static const int target = getenv("MMSSL_WG10_BLOCKS") ? atoi(getenv("MMSSL_WG10_BLOCKS")) : 512;
   WgPlan p;
   p.tk = K / 64;
   p.tn = N / 64;
   const int64_t tiles = (int64_t)p.tk * p.tn;
-  int64_t sp = ((target > 0 ? target : 256) + tiles - 1) / tiles;
+  static const int max_sp = getenv("MMSSL_WG10_MAXSP") ? atoi(getenv("MMSSL_WG10_MAXSP")) : 64;
+  int64_t sp = ((target > 0 ? target : 512) + tiles - 1) / tiles;
   const int64_t cap = M / 128 > 0 ? M / 128 : 1;
   if (sp > cap) sp = cap;
+  if (sp > max_sp) sp = max_sp;
   if (sp < 1) sp = 1;
   p.ms = ((M + sp - 1) / sp + 15) / 16 * 16;
   p.sp = (int)((M + p.ms - 1) / p.ms);
@@ -2112,8 +2195,9 @@ extern "C" int mmssl_linear_wgrad_f32(const float* gY, const uint8_t* keep, floa
     float* P = reinterpret_cast<float*>(workspace);      // [sp][N][K]
     float* bpart = P + (size_t)p.sp * N * K;             // [sp][N]
     const bool direct = p.sp == 1;
-    auto* kern = keep ? (gemm_nt() ? wgrad10_kernel<true, true> : wgrad10_kernel<true, false>)
-                      : (gemm_nt() ? wgrad10_kernel<false, true> : wgrad10_kernel<false, false>);
+    // 8 steps of loads in flight (a ring of 12 measured 172 vs 93 us: the accumulators no longer fit next to it)
+    auto* kern = keep ? (gemm_nt() ? wgrad10_kernel<true, true, 8> : wgrad10_kernel<true, false, 8>)
+                      : (gemm_nt() ? wgrad10_kernel<false, true, 8> : wgrad10_kernel<false, false, 8>);
     hipLaunchKernelGGL(kern, dim3((unsigned)p.tk, (unsigned)p.tn, (unsigned)p.sp), dim3(kBlock), 0, s, gY, keep, scale, F,
                        M, K, N, p.ms, direct ? gW : P, (int64_t)N * K, gb ? (direct ? gb : bpart) : (float*)nullptr);
     MMSSL_LAUNCH_CHECK();

@@ -73,6 +73,22 @@ class HotPathStep:
                                   ticks=self._ticks if ops.EXTERNAL["on"] else None)
         return total, dict(terms=terms, ss=ss)
 
+    def _losses_eager(self):
+        """losses() for _step(): the terms' and the regulariser's gradients are known constants (loss_w, c), so the
+        backward is rooted at them directly; the loss value (self.loss) and the step's counter ticks come out of the
+        last launch of the loss section (ops._BatchLosses._forward_eager)."""
+        m = self.model
+        (ua, ia, img_item, txt_item, img_user, txt_user, uemb, _, img_uid, txt_uid, _, _) = m(*self.graphs, keep_masks=self.keep_masks)
+        ss = m.feat_sumsq(img_item, txt_item, img_user, txt_user)
+        c = args.feat_reg_decay * 0.5 / m.n_items
+        if self._feat_c is None or self._feat_c_val != c:
+            self._feat_c, self._feat_c_val = torch.full((), c, dtype=torch.float32, device=self.loss.device), c
+        terms = ops.batch_losses_vec(ua, ia, img_uid, txt_uid, self.users, self.pos, self.neg, self.decay,
+                                     self.batch_size, args.tau, eager_w=self.loss_w,
+                                     tail=(ss.detach(), c, self.loss, self._ticks if ops.EXTERNAL["on"] else None))
+        self.parts = dict(terms=terms, ss=ss)
+        return [terms, ss], [self.loss_w, self._feat_c]
+
     def step(self):
         """One eager step on this object's stream."""
         with torch.cuda.stream(self.stream):
@@ -89,8 +105,12 @@ class HotPathStep:
         prev_t = ops.external_ticks(True)
         prev = ops.defer_wgrad_join(True)
         try:
-            total, parts = self.losses()
-            total.backward(gradient=self._one)       # persistent root gradient: no ones_like fill per step
+            if ops.eager_loss_backward_enabled():
+                roots, grads = self._losses_eager()
+                torch.autograd.backward(roots, grads)
+            else:
+                total, parts = self.losses()
+                total.backward(gradient=self._one)       # persistent root gradient: no ones_like fill per step
             ops.defer_wgrad_join(prev)
             self.optimizer.step(groups=(0,))         # embedding tables, next to the wgrad GEMMs
             ops.join_side_streams(dev)

@@ -224,10 +224,45 @@ def _linear_raw(F_, W, b, keep, scale):
     Y = torch.empty((M, N), dtype=torch.float32, device=F_.device)
     nb = _lib.lib().mmssl_linear_workspace_bytes(M, K, N)
     ws = torch.empty(max(nb // 4, 4), dtype=torch.float32, device=F_.device)
+    tk = _linear_tickets(F_, M, K, N)
+    if tk is not None:
+        rc = _lib.lib().mmssl_linear_tk_f32(_ptr(F_), _ptr(W), _ptr(b), _ptr(keep), float(scale), M, K, N, _ptr(Y),
+                                            _ptr(ws), ws.numel() * 4, _ptr(tk), _lib.stream_ptr())
+        _lib.check(rc, "mmssl_linear_tk_f32")
+        return Y
     rc = _lib.lib().mmssl_linear_f32(_ptr(F_), _ptr(W), _ptr(b), _ptr(keep), float(scale), M, K, N, _ptr(Y),
                                      _ptr(ws), ws.numel() * 4, _lib.stream_ptr())
     _lib.check(rc, "mmssl_linear_f32")
     return Y
+
+
+# Arrival tickets of the in-kernel stream-K fix-up (mmssl_linear_tk_f32): zero-initialised once, left zero by every
+# call, one set per (shape, stream) so that products that run side by side never share one.
+_TICKETS = {}
+
+
+def linear_fixup_enabled():
+    """OPT-IN (MMSSL_GEMM_FIXUP=1): the stream-K fix-up inside the kernel instead of the separate reduce launch.
+    Measured: Baby image forward alone 102.3 vs 104.7 us, but the whole step 0.641 vs 0.625 ms, so the default stays
+    the two-launch form."""
+    return _os.environ.get("MMSSL_GEMM_FIXUP", "0") == "1"
+
+
+def _linear_tickets(F_, M, K, N):
+    if not linear_fixup_enabled():
+        return None
+    # launches on one stream are ordered, so one set per (shape, stream) is never in use twice at a time; the sets are
+    # kept for the life of the process (a captured graph holds their addresses)
+    key = (F_.device.index, M, K, N, torch.cuda.current_stream(F_.device).cuda_stream)
+    tk = _TICKETS.get(key)
+    if tk is None:
+        n = int(_lib.lib().mmssl_linear_ticket_count(M, K, N))
+        if n <= 0:
+            _TICKETS[key] = False
+            return None
+        tk = torch.zeros(n, dtype=torch.int32, device=F_.device)
+        _TICKETS[key] = tk
+    return tk if tk is not False else None
 
 
 # Dropout keep-masks: one Philox launch for any number of equally shaped masks (nn.Dropout, Models.py:54).
@@ -706,7 +741,8 @@ class _BatchLosses(torch.autograd.Function):
     summed by autograd)."""
 
     @staticmethod
-    def forward(ctx, ua, ia, img_uid, txt_uid, users, pos, neg, decay, batch_size, tau, overlap=None):
+    def forward(ctx, ua, ia, img_uid, txt_uid, users, pos, neg, decay, batch_size, tau, overlap=None, eager_w=None,
+                tail=None):
         ua, ia = _chk(ua, "ua"), _chk(ia, "ia")
         img_uid, txt_uid = _chk(img_uid, "img_uid"), _chk(txt_uid, "txt_uid")
         B, d = users.shape[0], ua.shape[1]
@@ -715,6 +751,10 @@ class _BatchLosses(torch.autograd.Function):
         nb = _lib.lib().mmssl_bpr_workspace_bytes(B)
         wsb = torch.empty(nb // 4, dtype=torch.float32, device=dev)
         need_grad = any(ctx.needs_input_grad[:4])
+        if eager_w is not None and tail is not None and need_grad:
+            return _BatchLosses._forward_eager(ctx, ua, ia, img_uid, txt_uid, users, pos, neg, decay, batch_size, tau,
+                                               eager_w, tail, out, wsb, nb)
+        ctx.eager = None
         # the table gradients the backward scatter-adds into are allocated here and zero-filled on a side
         # stream, next to the BPR forward, while the (longer) InfoNCE forward runs on the current stream
         g_ua = torch.empty_like(ua) if need_grad else None
@@ -750,7 +790,55 @@ class _BatchLosses(torch.autograd.Function):
         return out
 
     @staticmethod
+    def _forward_eager(ctx, ua, ia, img_uid, txt_uid, users, pos, neg, decay, batch_size, tau, w, tail, out, wsb, nb):
+        """The caller PROMISES that the result is backpropagated with exactly the gradient `w` (a persistent [5]
+        tensor: HotPathStep's loss weights, total = w . terms + c * extra backpropagated with 1). The gradients of
+        the loss terms are then known before the loss scalars are, and the whole loss section becomes ONE chain of
+        seven launches on the current stream, no fork / join (a cross-queue edge of a replayed hipGraph costs 10-15 us):
+          zero fill (all four gradients + the tickets), InfoNCE prep, pair tiles, row terms (the last block also reduces
+          the two losses), backward pair tiles, backward finish, BPR backward + BPR loss + loss assembly + counter ticks.
+        tail = (extra, c, total, ticks): see mmssl_bpr_step_f32. backward() returns the stored gradients."""
+        B, d = users.shape[0], ua.shape[1]
+        dev = ua.device
+        if w.dtype != torch.float32 or w.numel() != 5 or w.device != dev:
+            raise _lib.MmsslError("batch_losses: eager_w must be a [5] fp32 tensor on the tables' device")
+        extra, c, total, ticks = tail
+        n_ua, n_ia, n_im, n_tx = ua.numel(), ia.numel(), img_uid.numel(), txt_uid.numel()
+        gbuf = torch.zeros(n_ua + n_ia + n_im + n_tx + 4, dtype=torch.float32, device=dev)
+        g_ua = gbuf[:n_ua].view_as(ua)
+        g_ia = gbuf[n_ua:n_ua + n_ia].view_as(ia)
+        g_img = gbuf[n_ua + n_ia:n_ua + n_ia + n_im].view_as(img_uid)
+        g_txt = gbuf[n_ua + n_ia + n_im:n_ua + n_ia + n_im + n_tx].view_as(txt_uid)
+        tickets = gbuf[n_ua + n_ia + n_im + n_tx:]              # three zeroed ints (InfoNCE x2, BPR)
+        nbw = _lib.lib().mmssl_infonce_multi_workspace_bytes(2, B, d)
+        if nbw == 0:
+            raise _lib.MmsslError("infonce: unsupported shape n=%d d=%d" % (B, d))
+        ws1 = torch.empty(nbw // 4, dtype=torch.float32, device=dev)
+        z1s = (_ct.c_void_p * 2)(img_uid.data_ptr(), txt_uid.data_ptr())
+        rc = _lib.lib().mmssl_infonce_multi_fwd_ticket_f32(z1s, _ptr(ua), _ptr(users), 2, B, d, float(tau), _ptr(out[3:5]),
+                                                           _ptr(ws1), nbw, _ptr(tickets), _lib.stream_ptr())
+        _lib.check(rc, "mmssl_infonce_multi_fwd_ticket_f32")
+        gz1s = (_ct.c_void_p * 2)(_ptr(g_img), _ptr(g_txt))
+        rc = _lib.lib().mmssl_infonce_multi_bwd_phase_f32(_ptr(users), 2, B, d, float(tau), _ptr(w[3:5]), gz1s, _ptr(g_ua),
+                                                          _ptr(ws1), ws1.numel() * 4, 3, _lib.stream_ptr())
+        _lib.check(rc, "mmssl_infonce_multi_bwd_phase_f32")
+        f32s, u64s = ticks if ticks else ((), ())
+        fa = (_ct.c_void_p * max(len(f32s), 1))(*[int(x) for x in f32s])
+        ka = (_ct.c_void_p * max(len(u64s), 1))(*[int(x) for x in u64s])
+        rc = _lib.lib().mmssl_bpr_step_f32(_ptr(ua), _ptr(ia), _ptr(users), _ptr(pos), _ptr(neg), B, d, float(decay),
+                                           int(batch_size), _ptr(w[0:1]), _ptr(w[1:2]), _ptr(g_ua), _ptr(g_ia), _ptr(out),
+                                           _ptr(w), 5, _ptr(extra), float(c), _ptr(total), fa, len(f32s), ka, len(u64s),
+                                           _ptr(wsb), nb, _ptr(tickets[2:]), _lib.stream_ptr())
+        _lib.check(rc, "mmssl_bpr_step_f32")
+        ctx.eager = (g_ua, g_ia, g_img if ctx.needs_input_grad[2] else None, g_txt if ctx.needs_input_grad[3] else None)
+        return out
+
+    @staticmethod
     def backward(ctx, g):
+        if ctx.eager is not None:
+            g_ua, g_ia, g_img, g_txt = ctx.eager
+            ctx.eager = None
+            return g_ua, g_ia, g_img, g_txt, None, None, None, None, None, None, None, None, None
         ua, ia, users, pos, neg, ws1 = ctx.saved_tensors
         B, d, decay, batch_size, tau, s_img, s_txt, overlap = ctx.cfg
         g = g.contiguous().to(torch.float32)
@@ -782,15 +870,26 @@ class _BatchLosses(torch.autograd.Function):
         rc = call(_ptr(users), 2, B, d, tau, _ptr(g[3:5]), gz1s, _ptr(g_ua), _ptr(ws1), ws1.numel() * 4, 2,
                   _lib.stream_ptr())
         _lib.check(rc, "mmssl_infonce_multi_bwd_phase_f32")
-        return g_ua, g_ia, g_img, g_txt, None, None, None, None, None, None, None
+        return g_ua, g_ia, g_img, g_txt, None, None, None, None, None, None, None, None, None
 
 
-def batch_losses_vec(ua, ia, img_uid, txt_uid, users, pos, neg, decay, batch_size, tau, overlap=None):
+def eager_loss_backward_enabled():
+    """MMSSL_EAGER_LOSS_BWD=0: the loss backward waits for autograd (the round-1 structure)."""
+    return _os.environ.get("MMSSL_EAGER_LOSS_BWD", "1") == "1"
+
+
+def batch_losses_vec(ua, ia, img_uid, txt_uid, users, pos, neg, decay, batch_size, tau, overlap=None, eager_w=None,
+                     tail=None):
     """[mf_loss, emb_loss, 0, cl_img, cl_txt] as ONE tensor (see _BatchLosses / loss_assemble).
-    overlap=False keeps every launch on the current stream (None: the MMSSL_STREAMS default)."""
+    overlap=False keeps every launch on the current stream (None: the MMSSL_STREAMS default).
+    eager_w + tail=(extra, c, total, ticks): the caller's promise that the result is backpropagated with exactly the
+    [5] gradient eager_w, total = eager_w . terms + c * extra being written to `total` by the same launches
+    (see _BatchLosses._forward_eager)."""
     dev = ua.device
+    if eager_w is not None and (tail is None or not eager_loss_backward_enabled()):
+        eager_w = tail = None
     return _BatchLosses.apply(ua, ia, img_uid, txt_uid, _idx(users, "users", dev), _idx(pos, "pos", dev),
-                              _idx(neg, "neg", dev), decay, batch_size, tau, overlap)
+                              _idx(neg, "neg", dev), decay, batch_size, tau, overlap, eager_w, tail)
 
 
 def batch_losses(ua, ia, img_uid, txt_uid, users, pos, neg, decay, batch_size, tau):
@@ -988,9 +1087,16 @@ def _side_streams(device, n=3):
     st = _SIDE_STREAMS.get(key)
     if st is None:
         prio = [int(x) for x in _os.environ.get("MMSSL_STREAM_PRIO", "0,0,0").split(",")]
-        st = [torch.cuda.Stream(device=device, priority=prio[k % len(prio)]) for k in range(n)]
+        st = [torch.cuda.Stream(device=device, priority=prio[k % len(prio)]) for k in range(n + 1)]
         _SIDE_STREAMS[key] = st
-    return st
+    return st[:n]
+
+
+def scalar_stream(device):
+    """A fourth forked stream for launches nothing on the step's critical path waits for (loss scalars)."""
+    device = torch.device(device)
+    _side_streams(device)
+    return _SIDE_STREAMS[(device.type, device.index)][3]
 
 
 def _branch_order(var, default):
@@ -1189,20 +1295,57 @@ class _HotForward(torch.autograd.Function):
                 for t, st in ((g_ii_, sA), (g_iu_, sA), (g_ti_, sB), (g_tu_, sB)):
                     if _os.environ.get("MMSSL_NO_RECORD_STREAM") != "1":
                         t.record_stream(st)
-        def chain_a():
+        def chain_a1():
             with torch.cuda.stream(sA):
-                g_x_img = _spmm_raw(ui, True, _spmm_raw(iu, True, g_ii_, EPI_AXPY, g_iu_, 1.0), EPI_NONE)
-                _, out["gW_img"], out["gb_img"] = _linear_wgrad_raw(g_x_img, keep_img, scale, F_img, W_img)
+                out["g_x_img"] = _spmm_raw(ui, True, _spmm_raw(iu, True, g_ii_, EPI_AXPY, g_iu_, 1.0), EPI_NONE)
+
+        def chain_a2():
+            with torch.cuda.stream(sA):
+                _, out["gW_img"], out["gb_img"] = _linear_wgrad_raw(out["g_x_img"], keep_img, scale, F_img, W_img)
+
+        def chain_b1():
+            with torch.cuda.stream(sB):
+                out["g_x_txt"] = _spmm_raw(ui.twin(), True, _spmm_raw(iu.twin(), True, g_ti_, EPI_AXPY, g_tu_, 1.0), EPI_NONE)
+
+        def chain_b2():
+            with torch.cuda.stream(sB):
+                _, out["gW_txt"], out["gb_txt"] = _linear_wgrad_raw(out["g_x_txt"], keep_txt, scale, F_txt, W_txt)
+
+        def chain_a():
+            chain_a1()
+            chain_a2()
 
         def chain_b():
-            with torch.cuda.stream(sB):
-                g_x_txt = _spmm_raw(ui.twin(), True, _spmm_raw(iu.twin(), True, g_ti_, EPI_AXPY, g_tu_, 1.0), EPI_NONE)
-                _, out["gW_txt"], out["gb_txt"] = _linear_wgrad_raw(g_x_txt, keep_txt, scale, F_txt, W_txt)
+            chain_b1()
+            chain_b2()
 
-        chains = {"A": chain_a, "B": chain_b, "C": chain_c}
-        for c in _branch_order("MMSSL_BWD_ORDER", "CAB"):
-            if not (c == "C" and c_first):
-                chains[c]()
+        # MMSSL_BWD_SCHED (experiments; needs the split form): 1 = the GCN chain starts when both modal SpMM pairs are
+        # done, 2 = the weight-gradient GEMMs start when the GCN chain is done (the register-direct wgrad and the SpMMs
+        # stretch each other when they run side by side), 0 = only the data dependencies
+        sched = int(_os.environ.get("MMSSL_BWD_SCHED", "0")) if (split and not c_first) else 0
+        if sched == 1:
+            chain_a1()
+            chain_b1()
+            main.wait_stream(sA)
+            main.wait_stream(sB)
+            sC.wait_stream(main)
+            chain_c()
+            chain_a2()
+            chain_b2()
+        elif sched == 2:
+            chain_c()
+            chain_a1()
+            chain_b1()
+            main.wait_stream(sC)
+            sA.wait_stream(main)
+            sB.wait_stream(main)
+            chain_a2()
+            chain_b2()
+        else:
+            chains = {"A": chain_a, "B": chain_b, "C": chain_c}
+            for c in _branch_order("MMSSL_BWD_ORDER", "CAB"):
+                if not (c == "C" and c_first):
+                    chains[c]()
         gi, gW_img, gb_img, gW_txt, gb_txt = out["gi"], out["gW_img"], out["gb_img"], out["gW_txt"], out["gb_txt"]
         if overlap:
             # g_u0 (sA before the exchange, or the current stream) and gi (sC) are what the embedding tables need; in

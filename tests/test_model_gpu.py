@@ -209,9 +209,10 @@ def test_hotpath_graph_replay_with_stream_overlap_matches_eager_sequential():
     batches = [(torch.randperm(U, generator=g)[:B], torch.randint(0, I, (B,), generator=g),
                 torch.randint(0, I, (B,), generator=g)) for _ in range(4)]
 
-    def run(overlap, capture):
+    def run(overlap, capture, eager_loss=True):
         """One warm-up step on batch 0 (eager; inside capture() for the captured run), then the 4 batches."""
         os.environ["MMSSL_STREAMS"] = "1" if overlap else "0"
+        os.environ["MMSSL_EAGER_LOSS_BWD"] = "1" if eager_loss else "0"
         torch.manual_seed(11)
         model = MMSSL(U, I, 64, [64] * 3, [0.1] * 3, img, txt).to(DEV).train()
         e1, e2 = GraphPlan(sp.csr_matrix((U, I), dtype=np.float32)), GraphPlan(sp.csr_matrix((I, U), dtype=np.float32))
@@ -233,13 +234,18 @@ def test_hotpath_graph_replay_with_stream_overlap_matches_eager_sequential():
         ref_l, ref_e, ref_w = run(overlap=False, capture=False)          # one stream, eager
         got_l, got_e, got_w = run(overlap=True, capture=True)            # forked streams inside a hipGraph
         ov_l, ov_e, ov_w = run(overlap=True, capture=False)              # forked streams, eager
+        # the loss section as autograd launches it (separate loss kernels, backward after the loss assembly) instead of
+        # the single chain with the gradients launched in the forward (ops._BatchLosses._forward_eager)
+        ag_l, ag_e, ag_w = run(overlap=True, capture=True, eager_loss=False)
     finally:
         os.environ.pop("MMSSL_STREAMS", None)
+        os.environ.pop("MMSSL_EAGER_LOSS_BWD", None)
     assert all(np.isfinite(got_l)) and all(np.isfinite(ref_l))
     # Streams and graph replay change WHEN kernels run, never what they compute (every reduction has a fixed
     # order): the three trajectories agree to rounding. In a replayed graph the chains really overlap on the
     # device (SpMMs on one plan at the same time), so this is also the race check for shared kernel state.
-    for name, (l, e, w) in (("graph+streams", (got_l, got_e, got_w)), ("streams", (ov_l, ov_e, ov_w))):
+    for name, (l, e, w) in (("graph+streams", (got_l, got_e, got_w)), ("streams", (ov_l, ov_e, ov_w)),
+                            ("graph+streams, autograd loss section", (ag_l, ag_e, ag_w))):
         for a, b in zip(l, ref_l):
             assert abs(a - b) <= 1e-5 * abs(b), (name, l, ref_l)
         assert H.rel_err(e, ref_e) < 1e-5, name

@@ -286,6 +286,90 @@ def test_infonce_fused_gather_and_batch_losses():
     assert float(z1.grad[~torch.isin(torch.arange(U), users).to(DEV)].abs().max()) == 0.0
 
 
+def test_batch_losses_eager_chain_matches_oracle_and_autograd_form():
+    """The loss section as ONE chain (gradients for the promised upstream weights launched in the forward, losses by
+    last-arriving-block reductions, BPR backward + loss assembly + counter ticks in one launch: mmssl_bpr_step_f32,
+    mmssl_infonce_multi_fwd_ticket_f32) against the oracle and against the autograd form of the same node."""
+    ops, _ = _ops()
+    gen = torch.Generator().manual_seed(33)
+    U, I, B, d = 900, 310, 300, 64
+    ua = torch.randn(U, d, generator=gen) * 0.5
+    ia = torch.randn(I, d, generator=gen) * 0.5
+    t_img = torch.randn(U, d, generator=gen)
+    t_txt = torch.randn(U, d, generator=gen)
+    users = torch.randperm(U, generator=gen)[:B]
+    pos = torch.randint(0, I, (B,), generator=gen)          # repeated items: atomics in the scatter
+    neg = torch.randint(0, I, (B,), generator=gen)
+    w = torch.tensor([1.0, 1.0, 1.0, 0.03, 0.03])
+    extra, c = torch.tensor(123.5), 0.25
+    R = [x.clone().requires_grad_(True) for x in (ua, ia, t_img, t_txt)]
+    mf, emb, _ = O.bpr(R[0][users], R[1][pos], R[1][neg], 1e-5, 1024)
+    c1 = O.infonce(R[2][users], R[0][users], 0.5)
+    c2 = O.infonce(R[3][users], R[0][users], 0.5)
+    total_ref = w[0] * mf + w[1] * emb + w[3] * c1 + w[4] * c2 + c * extra
+    total_ref.backward()
+    wd = w.to(DEV)
+    total = torch.zeros((), device=DEV)
+    f32_tick = torch.tensor([4.0], device=DEV)
+    u64_tick = torch.tensor([7], dtype=torch.int64, device=DEV)
+    for rep in range(2):                                     # second round: the tickets re-armed themselves
+        G = [x.clone().to(DEV).requires_grad_(True) for x in (ua, ia, t_img, t_txt)]
+        terms = ops.batch_losses_vec(G[0], G[1], G[2], G[3], users.to(DEV), pos.to(DEV), neg.to(DEV), 1e-5, 1024, 0.5,
+                                     eager_w=wd, tail=(extra.to(DEV), c, total, ([f32_tick.data_ptr()], [u64_tick.data_ptr()])))
+        for k, ref in ((0, mf), (1, emb), (3, c1), (4, c2)):
+            assert abs(float(terms[k]) - float(ref)) <= 1e-5 * abs(float(ref)), (k, float(terms[k]), float(ref))
+        assert float(terms[2]) == 0.0
+        assert abs(float(total) - float(total_ref)) <= 1e-5 * abs(float(total_ref))
+        terms.backward(wd)
+        for a, b in zip(G, R):
+            assert H.rel_err(a.grad.cpu(), b.grad) < 2e-4
+        assert float(f32_tick) == 5.0 + rep and int(u64_tick) == 8 + rep
+    # the autograd form of the same node (backward launched by autograd, separate loss kernels): same losses bit for
+    # bit (same reduction arithmetic), same gradients up to the order of the scatter atomics
+    A = [x.clone().to(DEV).requires_grad_(True) for x in (ua, ia, t_img, t_txt)]
+    t2 = ops.batch_losses_vec(A[0], A[1], A[2], A[3], users.to(DEV), pos.to(DEV), neg.to(DEV), 1e-5, 1024, 0.5)
+    assert torch.equal(t2, terms.detach())
+    t2.backward(wd)
+    for a, b in zip(A, G):
+        assert H.rel_err(a.grad.cpu(), b.grad.cpu()) < 1e-5
+
+
+_OPTIN_SNIPPET = r"""
+import sys, torch
+sys.path.insert(0, %r)
+from mmssl_amd import ops
+g = torch.Generator().manual_seed(5)
+worst = 0.0
+for M, K, N in ((1000, 128, 64), (777, 4096, 64), (2049, 768, 128), (18357, 1024, 64)):
+    F_ = torch.randn(M, K, generator=g); W = torch.randn(N, K, generator=g) / K ** 0.5; b = torch.randn(N, generator=g)
+    keep = (torch.rand(M, N, generator=g) >= 0.2).to(torch.uint8); C = torch.randn(M, N, generator=g)
+    Wr = W.clone().requires_grad_(True); br = b.clone().requires_grad_(True)
+    yr = torch.nn.functional.linear(F_, Wr, br) * keep * 1.25
+    (yr * C).sum().backward()
+    Wg = W.clone().cuda().requires_grad_(True); bg = b.clone().cuda().requires_grad_(True)
+    yg = ops.linear(F_.cuda(), Wg, bg, keep.cuda(), 1.25)
+    (yg * C.cuda()).sum().backward()
+    rel = lambda a, r: float((a.cpu() - r).norm() / r.norm())
+    worst = max(worst, rel(yg.detach(), yr.detach()), rel(Wg.grad, Wr.grad) / 3, rel(bg.grad, br.grad) / 3)
+    tol = 3e-6 * max(1.0, (K / 128.0) ** 0.5)
+    assert worst < tol, (M, K, N, worst, tol)
+print("OK", worst)
+"""
+
+
+@pytest.mark.parametrize("env", [{"MMSSL_GEMM_V": "9"}, {"MMSSL_GEMM_FIXUP": "1"}, {"MMSSL_GEMM_NT": "1"},
+                                 {"MMSSL_WGRAD_V": "5"}, {"MMSSL_WG10_BLOCKS": "256"}])
+def test_linear_optin_kernel_generations(env):
+    """The projection's opt-in kernels (chosen by environment variables that the library reads once per process):
+    register-direct forward (v9), in-kernel stream-K fix-up, non-temporal streaming, the register-staged weight
+    gradient (v5) and the one-block-per-CU decomposition of the default one, each against torch in its own process."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = dict(os.environ); e.update(env)
+    r = subprocess.run([sys.executable, "-c", _OPTIN_SNIPPET % root], env=e, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "OK" in r.stdout, (env, r.stdout[-500:], r.stderr[-1500:])
+
+
 @pytest.mark.parametrize("G", [1, 2, 3])
 def test_propagate_fuse_matches_oracle(G):
     """The fused post-projection node (modal SpMM chains + 2G GCN SpMM + layer mean + modality fusion

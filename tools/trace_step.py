@@ -1,5 +1,6 @@
 """Per-step kernel breakdown from a rocprofv3 --kernel-trace CSV (one hot-path step = the kernels
-between two consecutive bpr_fwd_kernel launches).   python tools/trace_step.py <kernel_trace.csv> [step_index]"""
+between two consecutive launches of the marker kernel: the first kernel of the loss section, InfoNCE prep_kernel).
+python tools/trace_step.py <kernel_trace.csv> [step_index] [--timeline] [--marker=NAME]"""
 import collections
 import csv
 import re
@@ -13,7 +14,8 @@ def main(path, which=12):
             rows.append((r["Kernel_Name"], int(r["Start_Timestamp"]), int(r["End_Timestamp"]),
                          r.get("Queue_Id", r.get("Stream_Id", "?"))))
     rows.sort(key=lambda r: r[1])
-    idx = [i for i, r in enumerate(rows) if "bpr_fwd_kernel" in r[0]]
+    marker = ([a.split("=", 1)[1] for a in sys.argv if a.startswith("--marker=")] or ["prep_kernel"])[0]
+    idx = [i for i, r in enumerate(rows) if marker in r[0]]
     which = min(which, len(idx) - 2)
     step = rows[idx[which]:idx[which + 1]]
     tot = sum(e - s for _, s, e, _ in step) / 1e3

@@ -248,6 +248,14 @@ int64_t mmssl_linear_ticket_count(int64_t M, int K, int N);
 int mmssl_linear_tk_f32(const float* F, const float* W, const float* b, const uint8_t* keep,
                         float scale, int64_t M, int K, int N, float* Y, void* workspace,
                         size_t workspace_bytes, int* tickets, void* stream);
+/* OPT-IN: the same projection Y = dropout(F W^T + b) computed from a TRANSPOSED copy of the constant feature matrix,
+ * FT [K, Mp] (row k = column k of F, Mp >= M a multiple of 64, columns M..Mp-1 zero). The product then reduces over the
+ * ROWS of both operands (FT and W^T, which the call builds), the form the register-direct weight-gradient kernel
+ * streams with fully coalesced loads. N % 64 == 0; workspace_bytes() == 0 means the shape is not supported. */
+size_t mmssl_linear_ft_workspace_bytes(int64_t M, int K, int N, int64_t Mp);
+int mmssl_linear_ft_f32(const float* FT, int64_t Mp, const float* W, const float* b, const uint8_t* keep,
+                        float scale, int64_t M, int K, int N, float* Y, void* workspace,
+                        size_t workspace_bytes, void* stream);
 /* OPT-IN split-precision product (not used unless the caller asks for it): Y[M,N] = A . B^T (+ bias, dropout
  * as in mmssl_linear_f32) with A [M,K] and B [N,K] each given as TWO bf16 matrices (hi = bf16(x),
  * lo = bf16(x - hi)); the result is hi*hi + hi*lo + lo*hi accumulated in fp32 on the bf16 matrix cores

@@ -239,7 +239,7 @@ class MMSSL(nn.Module):
             else:
                 km_img, km_txt = ops.dropout_masks(2, self.n_items, args.embed_size, p,
                                                    self.image_trans.weight.device)              # 1 = keep
-        if self.training and ops.wgrad_ft_enabled() and torch.is_grad_enabled():
+        if self.training and (ops.wgrad_ft_enabled() or ops.fwd_ft_enabled()) and torch.is_grad_enabled():
             # weight gradients of the projections run on the forward kernel against F^T (built once)
             ops.register_transposed_features(self.image_feats)
             ops.register_transposed_features(self.text_feats)

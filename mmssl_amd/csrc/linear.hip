@@ -1482,12 +1482,89 @@ __global__ __launch_bounds__(kBlock) void wg10_reduce_kernel(const float* __rest
 }
 
 // ======================================================================================
+// v10 forward over a transposed copy of the feature matrix (opt-in, mmssl_linear_ft_f32):
+//   Y^T [N, Mp] = sum_k WT[k][n] * FT[k][m]  is the weight-gradient form (reduction over the rows of two row-major
+// operands), so the same register-direct kernel streams FT with fully coalesced 16-byte loads. W (64 x K, 1 MB) is
+// transposed per call by w_transpose_kernel; the row-range partials are added, transposed back through LDS and get bias
+// + dropout in ft_reduce_kernel.
+// ======================================================================================
+__global__ __launch_bounds__(kBlock) void w_transpose_kernel(const float* __restrict__ W, int N, int K,
+                                                             float* __restrict__ WT) {
+  __shared__ float tile[64][65];
+  const int c = threadIdx.x & 63, q = threadIdx.x >> 6;
+  const int k0 = (int)blockIdx.x * 64, n0 = (int)blockIdx.y * 64;
+#pragma unroll 4
+  for (int i = 0; i < 16; ++i) {
+    const int n = q + 4 * i;
+    tile[n][c] = (n0 + n < N && k0 + c < K) ? W[(int64_t)(n0 + n) * K + k0 + c] : 0.f;
+  }
+  __syncthreads();
+#pragma unroll 4
+  for (int i = 0; i < 16; ++i) {
+    const int k = q + 4 * i;
+    if (k0 + k < K && n0 + c < N) WT[(int64_t)(k0 + k) * N + n0 + c] = tile[c][k];
+  }
+}
+
+// one block per 64 output rows (m) x 64 columns (n): Y[m][n] = dropout(sum_s P[s][n][m] + bias[n])
+__global__ __launch_bounds__(kBlock) void ft_reduce_kernel(const float* __restrict__ P, int sp, int64_t split_stride,
+                                                           int64_t Mp, int64_t M, int N, float* __restrict__ Y,
+                                                           const float* __restrict__ bias,
+                                                           const uint8_t* __restrict__ keep, float scale) {
+  __shared__ float tile[64][65];
+  const int t = threadIdx.x;
+  const int64_t m0 = (int64_t)blockIdx.x * 64;
+  const int n0 = (int)blockIdx.y * 64;
+  {
+    const int n = t >> 2, mc = (t & 3) * 16;
+    float4 v[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int s = 0; s < sp; ++s) {
+      const float4* src = reinterpret_cast<const float4*>(P + (size_t)s * split_stride + (int64_t)(n0 + n) * Mp + m0 + mc);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 p = src[q];
+        v[q].x += p.x; v[q].y += p.y; v[q].z += p.z; v[q].w += p.w;
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      tile[n][mc + 4 * q + 0] = v[q].x;
+      tile[n][mc + 4 * q + 1] = v[q].y;
+      tile[n][mc + 4 * q + 2] = v[q].z;
+      tile[n][mc + 4 * q + 3] = v[q].w;
+    }
+  }
+  __syncthreads();
+  const int m = t >> 2, nc = (t & 3) * 16;
+  if (m0 + m >= M) return;
+  float o[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    float x = tile[nc + i][m];
+    if (bias) x += bias[n0 + nc + i];
+    o[i] = x;
+  }
+  if (keep) {
+    const uint4 kk = *reinterpret_cast<const uint4*>(keep + (m0 + m) * N + n0 + nc);
+    const unsigned kw[4] = {kk.x, kk.y, kk.z, kk.w};
+#pragma unroll
+    for (int i = 0; i < 16; ++i) o[i] = ((kw[i >> 2] >> (8 * (i & 3))) & 0xffu) ? o[i] * scale : 0.f;
+  }
+  float4* dst = reinterpret_cast<float4*>(Y + (m0 + m) * N + n0 + nc);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) dst[q] = make_float4(o[4 * q], o[4 * q + 1], o[4 * q + 2], o[4 * q + 3]);
+}
+
+// ======================================================================================
 // OPT-IN split-precision product (MMSSL_GEMM_SPLIT=1 on the Python side; NOT the default path):
 //   C[i][j] = sum_k A[i][k] * B[j][k]   with A, B given as bf16 (hi, lo) pairs, x ~= hi + lo (16 mantissa bits),
 //   accumulated in fp32 as  hi*hi + hi*lo + lo*hi  on the bf16 matrix cores (v_mfma_f32_32x32x16_bf16).
-// Why it exists: the fp32 projection is ENERGY-bound at the board's power cap (profiles/r01_power_probe.txt:
-// 5.9 pJ per fp32 matrix flop vs 0.79 pJ per bf16 matrix flop), so three bf16 products cost ~0.4x the matrix energy;
-// the operand pairs occupy the same bytes as fp32. Relative error of a product ~2^-16 (tests bound the result).
+// Why it exists: bf16 matrix instructions have 8x the fp32 rate (and cost ~0.13x the energy per flop,
+// profiles/r01_power_probe.txt), so three bf16 products are cheaper than one fp32 product; the operand pairs occupy the
+// same bytes as fp32. (Round 1 argued the fp32 kernel was held back by the power cap; round 2 measured that it is not -
+// DESIGN.md section 4 - so this path is an arithmetic trade, not a power workaround.)
 // Same structure as gemm_fwd_dma_kernel: 64x64 block tile, 2x2 waves, 32-deep slices, 4-stage LDS-DMA ring.
 // One stage = four 4 KB tiles (A_hi, A_lo, B_hi, B_lo), each 64 rows x 32 bf16 = 4 chunks of 16 B per row;
 // chunk c of row r sits at slot 4r + (c ^ ((r >> 2) & 3)) (swizzle applied to the DMA source address), which makes
@@ -2179,6 +2256,69 @@ extern "C" size_t mmssl_linear_wgrad_workspace_bytes(int64_t M, int K, int N) {
 
 extern "C" int mmssl_linear_wgrad_fuses_mask(int64_t M, int K, int N) {
   return (M > 0 && K > 0 && N > 0 && wg10_usable(M, K, N)) ? 1 : 0;
+}
+
+namespace {
+// row ranges of the transposed-feature forward: the count that minimises rounds x (work per block + epilogue) on two
+// block slots per CU, ranges of at least 128 reduction rows
+inline int ft_splits(int64_t tiles, int64_t K) {
+  int best = 1;
+  double best_cost = 1e30;
+  for (int sp = 1; sp <= 16; ++sp) {
+    const int64_t rows = ((K + sp - 1) / sp + 15) / 16 * 16;
+    if (sp > 1 && rows < 128) break;
+    const double rounds = (double)((tiles * sp + 511) / 512);
+    const double cost = rounds * ((double)rows / 16.0 * 1024.0 + 4000.0) + (double)sp * 1500.0;
+    if (cost < best_cost) {
+      best_cost = cost;
+      best = sp;
+    }
+  }
+  if (const char* e = getenv("MMSSL_FT_SPLITS")) {
+    const int f = atoi(e);
+    if (f >= 1 && f <= 64) best = f;
+  }
+  return best;
+}
+inline bool ft_usable(int64_t M, int K, int N, int64_t Mp) {
+  return N % 64 == 0 && K % 4 == 0 && Mp % 64 == 0 && Mp >= M && (int64_t)K * Mp < ((int64_t)1 << 30) && Mp < (1 << 18) &&
+         N < (1 << 18);
+}
+}  // namespace
+
+extern "C" size_t mmssl_linear_ft_workspace_bytes(int64_t M, int K, int N, int64_t Mp) {
+  if (M <= 0 || K <= 0 || N <= 0 || !ft_usable(M, K, N, Mp)) return 0;
+  const int sp = ft_splits((Mp / 64) * (N / 64), K);
+  return ((size_t)K * N + (size_t)sp * N * Mp) * sizeof(float) + 16;
+}
+
+extern "C" int mmssl_linear_ft_f32(const float* FT, int64_t Mp, const float* W, const float* b, const uint8_t* keep,
+                                   float scale, int64_t M, int K, int N, float* Y, void* workspace,
+                                   size_t workspace_bytes, void* stream) {
+  if (M <= 0 || K <= 0 || N <= 0 || !FT || !W || !Y) return MMSSL_E_BADARG;
+  if (!ft_usable(M, K, N, Mp)) return MMSSL_E_UNSUPP;
+  if (((uintptr_t)FT | (uintptr_t)W | (uintptr_t)Y | (uintptr_t)keep) & 15) return MMSSL_E_BADARG;
+  const size_t need = mmssl_linear_ft_workspace_bytes(M, K, N, Mp);
+  if (!workspace || workspace_bytes < need) return MMSSL_E_WORKSPACE;
+  hipStream_t s = as_stream(stream);
+  float* WT = reinterpret_cast<float*>(workspace);                 // [K][N]
+  float* P = WT + (size_t)K * N;                                    // [sp][N][Mp]
+  hipLaunchKernelGGL(w_transpose_kernel, dim3((unsigned)((K + 63) / 64), (unsigned)(N / 64)), dim3(kBlock), 0, s, W, N, K,
+                     WT);
+  MMSSL_LAUNCH_CHECK();
+  const int tk = (int)(Mp / 64), tn = N / 64;
+  const int sp0 = ft_splits((int64_t)tk * tn, K);
+  const int64_t ms = (((int64_t)K + sp0 - 1) / sp0 + 15) / 16 * 16;
+  const int sp = (int)((K + ms - 1) / ms);
+  // the weight-gradient kernel with (gY, F, M, K) := (WT, FT, K, Mp): out[n][m] = sum_k WT[k][n] FT[k][m]
+  auto* kern = gemm_nt() ? wgrad10_kernel<false, true, 8> : wgrad10_kernel<false, false, 8>;
+  hipLaunchKernelGGL(kern, dim3((unsigned)tk, (unsigned)tn, (unsigned)sp), dim3(kBlock), 0, s, WT, (const uint8_t*)nullptr,
+                     1.f, FT, (int64_t)K, (int)Mp, N, ms, P, (int64_t)N * Mp, (float*)nullptr);
+  MMSSL_LAUNCH_CHECK();
+  hipLaunchKernelGGL(ft_reduce_kernel, dim3((unsigned)tk, (unsigned)tn), dim3(kBlock), 0, s, P, sp, (int64_t)N * Mp, Mp, M,
+                     N, Y, b, keep, scale);
+  MMSSL_LAUNCH_CHECK();
+  return 0;
 }
 
 extern "C" int mmssl_linear_wgrad_f32(const float* gY, const uint8_t* keep, float scale, const float* F, int64_t M,

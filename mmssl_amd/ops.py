@@ -222,6 +222,15 @@ def _linear_raw(F_, W, b, keep, scale):
         Wh, Wl = _split_pair_dev(W)
         return _split_call(Fh, Fl, Wh, Wl, b, keep, scale, M, K, N)
     Y = torch.empty((M, N), dtype=torch.float32, device=F_.device)
+    ft = _FT.get((F_.data_ptr(), tuple(F_.shape))) if fwd_ft_enabled() else None
+    if ft is not None:
+        nbf = _lib.lib().mmssl_linear_ft_workspace_bytes(M, K, N, ft[1])
+        if nbf > 0:
+            wsf = torch.empty(nbf // 4, dtype=torch.float32, device=F_.device)
+            rc = _lib.lib().mmssl_linear_ft_f32(_ptr(ft[0]), ft[1], _ptr(W), _ptr(b), _ptr(keep), float(scale), M, K, N,
+                                                _ptr(Y), _ptr(wsf), nbf, _lib.stream_ptr())
+            _lib.check(rc, "mmssl_linear_ft_f32")
+            return Y
     nb = _lib.lib().mmssl_linear_workspace_bytes(M, K, N)
     ws = torch.empty(max(nb // 4, 4), dtype=torch.float32, device=F_.device)
     tk = _linear_tickets(F_, M, K, N)
@@ -394,12 +403,18 @@ def wgrad_ft_enabled():
     return _os.environ.get("MMSSL_WGRAD_FT", "0") == "1"
 
 
+def fwd_ft_enabled():
+    """OPT-IN (MMSSL_FWD_FT=1): the projection forward from the transposed feature copy (mmssl_linear_ft_f32) for
+    matrices registered with register_transposed_features."""
+    return _os.environ.get("MMSSL_FWD_FT", "0") == "1"
+
+
 def register_transposed_features(F_):
     key = (F_.data_ptr(), tuple(F_.shape))
     hit = _FT.get(key)
     if hit is None:
         M, K = F_.shape
-        Mp = (M + 31) // 32 * 32
+        Mp = (M + 63) // 64 * 64
         FT = torch.zeros((K, Mp), dtype=torch.float32, device=F_.device)
         FT[:, :M] = F_.t()
         hit = (FT, Mp, F_)                      # keeps F_ alive: the key stays valid

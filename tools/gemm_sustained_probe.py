@@ -34,6 +34,18 @@ def main():
             keep = (torch.rand(M, 64, device="cuda", generator=gen) >= 0.2).to(torch.uint8)
             gY = torch.randn(M, 64, device="cuda", generator=gen)
             fwd = run(lambda: ops._linear_raw(F_, W, b, keep, 1.25))
+            if os.environ.get("PROBE_FT_FWD") == "1":
+                os.environ["MMSSL_FWD_FT"] = "1"
+                ops.register_transposed_features(F_)
+                y1 = ops._linear_raw(F_, W, b, keep, 1.25)
+                os.environ["MMSSL_FWD_FT"] = "0"
+                y0 = ops._linear_raw(F_, W, b, keep, 1.25)
+                os.environ["MMSSL_FWD_FT"] = "1"
+                err = float((y1 - y0).norm() / y0.norm())
+                fwd_ft = run(lambda: ops._linear_raw(F_, W, b, keep, 1.25))
+                os.environ["MMSSL_FWD_FT"] = "0"
+                ops._FT.clear()
+                print("   %s fwd via F^T %.1f us (rel. diff to default %.2e)" % (name, fwd_ft, err), flush=True)
             os.environ["MMSSL_WGRAD_FT"] = "0"
             wg = run(lambda: ops._linear_wgrad_raw(gY, keep, 1.25, F_, W))
             wf = float("nan")

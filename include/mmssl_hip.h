@@ -423,13 +423,16 @@ int mmssl_bpr_bwd_f32(const float* Eu, const float* Ei, const float* Ei_neg, con
  * the caller zero-filled or already holds other gradients), the BPR loss values terms[0..2] = (mf, emb, 0) by a
  * last-arriving-block reduction, total = sum_k w[k] * terms[k] + c * extra[0] (terms[3..n_terms-1] are read), and +1 on
  * the given counters (see mmssl_loss_assemble_tick_f32). workspace: mmssl_bpr_workspace_bytes(B); ticket: one int,
- * 0 on entry, left 0. */
+ * 0 on entry, left 0. extra_parts != NULL: the extra term arrives as n_extra_parts partial sums (the forward's
+ * regulariser partials, mmssl_layer_combine_f32); they are reduced here (the arithmetic of mmssl_sum_partials_f32) and
+ * the sum is also STORED to extra[0], which then is an output. */
 int mmssl_bpr_step_f32(const float* Eu, const float* Ei, const int64_t* users, const int64_t* pos,
                        const int64_t* neg, int64_t B, int d, float decay, int64_t batch_size,
                        const float* g_mf, const float* g_emb, float* gEu, float* gEi, float* terms,
                        const float* w, int n_terms, const float* extra, float c, float* total,
                        float* const* f32_ticks, int n_f32, uint64_t* const* u64_ticks, int n_u64,
-                       void* workspace, size_t workspace_bytes, int* ticket, void* stream);
+                       void* workspace, size_t workspace_bytes, int* ticket, const float* extra_parts,
+                       int64_t n_extra_parts, void* stream);
 
 #ifdef __cplusplus
 }

@@ -161,7 +161,9 @@ __global__ __launch_bounds__(kBlock) void bpr_step_kernel(const float4* __restri
                                                           int* __restrict__ ticket, float* __restrict__ terms,
                                                           const float* __restrict__ w, int n_terms,
                                                           const float* __restrict__ extra, float cex,
-                                                          float* __restrict__ total, StepTicks T) {
+                                                          float* __restrict__ total, StepTicks T,
+                                                          const float* __restrict__ xparts, int64_t n_xparts,
+                                                          float* __restrict__ extra_out) {
   __shared__ float red[4];
   __shared__ int s_last;
   constexpr int GPB = kBlock / LPR;
@@ -213,6 +215,17 @@ __global__ __launch_bounds__(kBlock) void bpr_step_kernel(const float4* __restri
   }
   const float lsum = block_sum_256(a, red);
   const float qsum = block_sum_256(c, red);
+  // the extra term given as partial sums (the forward's regulariser partials): reduced here with the arithmetic of
+  // sum_partials_kernel instead of by a launch of its own in front of the loss chain
+  float xs = 0.f;
+  if (xparts) {
+    float e = 0.f;
+    for (int64_t i = threadIdx.x; i < n_xparts; i += kBlock) e += xparts[i];
+    xs = block_sum_256(e, red);
+    if (threadIdx.x == 0 && extra_out) extra_out[0] = xs;
+  } else if (extra) {
+    xs = extra[0];
+  }
   if (threadIdx.x == 0) {
     const float t_mf = -(lsum / (float)B), t_emb = decay * ((0.5f * qsum) / (float)batch_size);
     terms[0] = t_mf;
@@ -220,7 +233,7 @@ __global__ __launch_bounds__(kBlock) void bpr_step_kernel(const float4* __restri
     terms[2] = 0.f;
     float t = w[0] * t_mf + w[1] * t_emb + w[2] * 0.f;          // same order as loss_assemble_kernel
     for (int k = 3; k < n_terms; ++k) t += w[k] * terms[k];
-    if (extra) t += cex * extra[0];
+    if (extra || xparts) t += cex * xs;
     total[0] = t;
     for (int k = 0; k < T.n_f32; ++k) T.f32[k][0] += 1.0f;
     for (int k = 0; k < T.n_u64; ++k) T.u64[k][0] += 1ull;
@@ -295,10 +308,14 @@ extern "C" int mmssl_bpr_step_f32(const float* Eu, const float* Ei, const int64_
                                   const float* g_mf, const float* g_emb, float* gEu, float* gEi, float* terms,
                                   const float* w, int n_terms, const float* extra, float c, float* total,
                                   float* const* f32_ticks, int n_f32, uint64_t* const* u64_ticks, int n_u64,
-                                  void* workspace, size_t workspace_bytes, int* ticket, void* stream) {
+                                  void* workspace, size_t workspace_bytes, int* ticket, const float* extra_parts,
+                                  int64_t n_extra_parts, void* stream) {
   if (B <= 0 || batch_size <= 0 || !Eu || !Ei || !users || !pos || !neg || !g_mf || !g_emb || !gEu || !gEi)
     return MMSSL_E_BADARG;
   if (!terms || !w || !total || !ticket || n_terms < 3 || n_terms > 16) return MMSSL_E_BADARG;
+  if (extra_parts && (n_extra_parts <= 0 || !extra)) return MMSSL_E_BADARG;
+  float* extra_out = extra_parts ? const_cast<float*>(extra) : nullptr;       // the reduced value is stored there
+  const float* extra_in = extra_parts ? nullptr : extra;
   if (n_f32 < 0 || n_f32 > 4 || n_u64 < 0 || n_u64 > 4 || (n_f32 > 0 && !f32_ticks) || (n_u64 > 0 && !u64_ticks))
     return MMSSL_E_BADARG;
   if (!supported_d(d)) return MMSSL_E_UNSUPP;
@@ -316,10 +333,10 @@ extern "C" int mmssl_bpr_step_f32(const float* Eu, const float* Ei, const int64_
   const float4* a = reinterpret_cast<const float4*>(Eu);
   const float4* b = reinterpret_cast<const float4*>(Ei);
   switch (d) {
-    case 32: hipLaunchKernelGGL((bpr_step_kernel<8>), dim3(nb), dim3(kBlock), 0, s, a, b, users, pos, neg, B, decay, batch_size, g_mf, g_emb, gEu, gEi, part, ticket, terms, w, n_terms, extra, c, total, T); break;
-    case 64: hipLaunchKernelGGL((bpr_step_kernel<16>), dim3(nb), dim3(kBlock), 0, s, a, b, users, pos, neg, B, decay, batch_size, g_mf, g_emb, gEu, gEi, part, ticket, terms, w, n_terms, extra, c, total, T); break;
-    case 128: hipLaunchKernelGGL((bpr_step_kernel<32>), dim3(nb), dim3(kBlock), 0, s, a, b, users, pos, neg, B, decay, batch_size, g_mf, g_emb, gEu, gEi, part, ticket, terms, w, n_terms, extra, c, total, T); break;
-    case 256: hipLaunchKernelGGL((bpr_step_kernel<64>), dim3(nb), dim3(kBlock), 0, s, a, b, users, pos, neg, B, decay, batch_size, g_mf, g_emb, gEu, gEi, part, ticket, terms, w, n_terms, extra, c, total, T); break;
+    case 32: hipLaunchKernelGGL((bpr_step_kernel<8>), dim3(nb), dim3(kBlock), 0, s, a, b, users, pos, neg, B, decay, batch_size, g_mf, g_emb, gEu, gEi, part, ticket, terms, w, n_terms, extra_in, c, total, T, extra_parts, n_extra_parts, extra_out); break;
+    case 64: hipLaunchKernelGGL((bpr_step_kernel<16>), dim3(nb), dim3(kBlock), 0, s, a, b, users, pos, neg, B, decay, batch_size, g_mf, g_emb, gEu, gEi, part, ticket, terms, w, n_terms, extra_in, c, total, T, extra_parts, n_extra_parts, extra_out); break;
+    case 128: hipLaunchKernelGGL((bpr_step_kernel<32>), dim3(nb), dim3(kBlock), 0, s, a, b, users, pos, neg, B, decay, batch_size, g_mf, g_emb, gEu, gEi, part, ticket, terms, w, n_terms, extra_in, c, total, T, extra_parts, n_extra_parts, extra_out); break;
+    case 256: hipLaunchKernelGGL((bpr_step_kernel<64>), dim3(nb), dim3(kBlock), 0, s, a, b, users, pos, neg, B, decay, batch_size, g_mf, g_emb, gEu, gEi, part, ticket, terms, w, n_terms, extra_in, c, total, T, extra_parts, n_extra_parts, extra_out); break;
   }
   MMSSL_LAUNCH_CHECK();
   return 0;

@@ -457,6 +457,9 @@ __global__ __launch_bounds__(kBlock) void gemm_sk_kernel(const float* __restrict
       // sk_reduce_kernel uses: the result does not depend on who is last) and runs the epilogue; no second kernel
       // stands between the product and its consumer. The images travel as write-through (sc1) stores and sc1 loads,
       // like the SpMM's in-kernel combine (graph.hip): no release/acquire fence, other dirty lines stay in this L2.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__) && !defined(__gfx942__)
+#error "gemm_sk_kernel's in-kernel fix-up is written for gfx942/gfx950 memory semantics (stores retire through vmcnt)"
+#endif
       typedef unsigned long long u64;
       const int seg = (u == u_begin) ? 0 : 1;
       u64* P = reinterpret_cast<u64*>(partials + ((size_t)blockIdx.x * 2 + seg) * kSkTileFloats);

@@ -7,6 +7,8 @@ All launches (hand-written HIP kernels through the C ABI + a few torch elementwi
 kernels) go to one stream and can be captured once into a hipGraph and replayed, which removes
 the host launch gaps that dominate at these problem sizes (a Baby-shape SpMM is ~15 us).
 """
+import os
+
 import torch
 
 from . import ops
@@ -33,7 +35,14 @@ class HotPathStep:
         tables = [model.user_id_embedding.weight, model.item_id_embedding.weight]
         tid = {id(p) for p in tables}
         rest = [p for p in model.parameters() if id(p) not in tid]
-        self.optimizer = FusedAdamW([{"params": tables}, {"params": rest}], lr=lr or args.lr)
+        # One launch for everything after the join (default since the register-direct weight gradient ends about when
+        # the GCN backward chain does: 0.606 vs 0.613 ms per Baby step). MMSSL_ADAMW_GROUPS=2: the embedding tables in
+        # their own launch next to the wgrad GEMMs, the projection weights after the join.
+        self._one_group = os.environ.get("MMSSL_ADAMW_GROUPS", "1") == "1"
+        if self._one_group:
+            self.optimizer = FusedAdamW([{"params": tables + rest}], lr=lr or args.lr)
+        else:
+            self.optimizer = FusedAdamW([{"params": tables}, {"params": rest}], lr=lr or args.lr)
         self.loss = torch.zeros((), device=dev)
         self._one = torch.ones((), device=dev)
         self._feat_c, self._feat_c_val = None, None
@@ -78,7 +87,16 @@ class HotPathStep:
         backward is rooted at them directly; the loss value (self.loss) and the step's counter ticks come out of the
         last launch of the loss section (ops._BatchLosses._forward_eager)."""
         m = self.model
-        (ua, ia, img_item, txt_item, img_user, txt_user, uemb, _, img_uid, txt_uid, _, _) = m(*self.graphs, keep_masks=self.keep_masks)
+        # the forward leaves its regulariser sum unreduced; the loss tail reduces it (one launch less in front of the
+        # loss chain). Only valid because the very next consumer of `ss` IS that tail.
+        prev_ss = ops.defer_feat_sumsq(os.environ.get("MMSSL_DEFER_SS", "1") == "1")
+        prev_pf = ops.prefill_loss_buffer((lambda nu, ni, d: (3 * nu + ni) * d + 4)
+                                          if os.environ.get("MMSSL_PREFILL", "1") == "1" else None)
+        try:
+            (ua, ia, img_item, txt_item, img_user, txt_user, uemb, _, img_uid, txt_uid, _, _) = m(*self.graphs, keep_masks=self.keep_masks)
+        finally:
+            ops._DEFER_SS["on"] = prev_ss
+            ops._PREFILL["floats"] = prev_pf
         ss = m.feat_sumsq(img_item, txt_item, img_user, txt_user)
         c = args.feat_reg_decay * 0.5 / m.n_items
         if self._feat_c is None or self._feat_c_val != c:
@@ -100,10 +118,12 @@ class HotPathStep:
         # kernels, the loss-assembly launch (between them in stream order) advances the RNG launch counter and
         # both AdamW step counters
         dev = self.loss.device
-        self._ticks = ([self.optimizer.step_counter(0, dev).data_ptr(), self.optimizer.step_counter(1, dev).data_ptr()],
-                       [ops._rng_state(dev).data_ptr() + 8])
+        counters = [self.optimizer.step_counter(gi, dev).data_ptr() for gi in range(len(self.optimizer.param_groups))]
+        self._ticks = (counters, [ops._rng_state(dev).data_ptr() + 8])
         prev_t = ops.external_ticks(True)
         prev = ops.defer_wgrad_join(True)
+        # zero gradients of skipped branches: persistent tensors, no fill launch (MMSSL_LAZY_ANCHOR=0: a fill per step)
+        prev_a = ops.lazy_anchors(os.environ.get("MMSSL_LAZY_ANCHOR", "1") == "1")
         try:
             if ops.eager_loss_backward_enabled():
                 roots, grads = self._losses_eager()
@@ -112,12 +132,18 @@ class HotPathStep:
                 total, parts = self.losses()
                 total.backward(gradient=self._one)       # persistent root gradient: no ones_like fill per step
             ops.defer_wgrad_join(prev)
-            self.optimizer.step(groups=(0,))         # embedding tables, next to the wgrad GEMMs
-            ops.join_side_streams(dev)
-            self.optimizer.step(groups=(1,))
+            ops.assign_anchored_zero_grads()
+            if self._one_group:
+                ops.join_side_streams(dev)
+                self.optimizer.step()
+            else:
+                self.optimizer.step(groups=(0,))         # embedding tables, next to the wgrad GEMMs
+                ops.join_side_streams(dev)
+                self.optimizer.step(groups=(1,))
         finally:
             ops.defer_wgrad_join(prev)
             ops.external_ticks(prev_t)
+            ops.lazy_anchors(prev_a)
         return self.loss
 
     # ---- hipGraph capture ---------------------------------------------------------------------

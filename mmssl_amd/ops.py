@@ -819,7 +819,9 @@ class _BatchLosses(torch.autograd.Function):
             raise _lib.MmsslError("batch_losses: eager_w must be a [5] fp32 tensor on the tables' device")
         extra, c, total, ticks = tail
         n_ua, n_ia, n_im, n_tx = ua.numel(), ia.numel(), img_uid.numel(), txt_uid.numel()
-        gbuf = torch.zeros(n_ua + n_ia + n_im + n_tx + 4, dtype=torch.float32, device=dev)
+        gbuf, _PREFILL["buf"] = _PREFILL["buf"], None          # zero-filled by the forward (see _PREFILL), if enabled
+        if gbuf is None or gbuf.numel() != n_ua + n_ia + n_im + n_tx + 4 or gbuf.device != dev:
+            gbuf = torch.zeros(n_ua + n_ia + n_im + n_tx + 4, dtype=torch.float32, device=dev)
         g_ua = gbuf[:n_ua].view_as(ua)
         g_ia = gbuf[n_ua:n_ua + n_ia].view_as(ia)
         g_img = gbuf[n_ua + n_ia:n_ua + n_ia + n_im].view_as(img_uid)
@@ -840,10 +842,15 @@ class _BatchLosses(torch.autograd.Function):
         f32s, u64s = ticks if ticks else ((), ())
         fa = (_ct.c_void_p * max(len(f32s), 1))(*[int(x) for x in f32s])
         ka = (_ct.c_void_p * max(len(u64s), 1))(*[int(x) for x in u64s])
+        xparts, n_xparts = None, 0
+        last = _DEFER_SS["last"]
+        if last is not None and extra is not None and last[0].data_ptr() == extra.data_ptr():
+            xparts, n_xparts = last[1], last[1].numel()       # `extra` is a forward's unreduced regulariser sum
+            _DEFER_SS["last"] = None
         rc = _lib.lib().mmssl_bpr_step_f32(_ptr(ua), _ptr(ia), _ptr(users), _ptr(pos), _ptr(neg), B, d, float(decay),
                                            int(batch_size), _ptr(w[0:1]), _ptr(w[1:2]), _ptr(g_ua), _ptr(g_ia), _ptr(out),
                                            _ptr(w), 5, _ptr(extra), float(c), _ptr(total), fa, len(f32s), ka, len(u64s),
-                                           _ptr(wsb), nb, _ptr(tickets[2:]), _lib.stream_ptr())
+                                           _ptr(wsb), nb, _ptr(tickets[2:]), _ptr(xparts), n_xparts, _lib.stream_ptr())
         _lib.check(rc, "mmssl_bpr_step_f32")
         ctx.eager = (g_ua, g_ia, g_img if ctx.needs_input_grad[2] else None, g_txt if ctx.needs_input_grad[3] else None)
         return out
@@ -977,11 +984,40 @@ class _ZeroGradAnchor(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w):
         ctx.wshape, ctx.wdev = w.shape, w.device
+        ctx.lazy = _ANCHOR["lazy"]
+        if ctx.lazy:
+            _ANCHOR["params"].append(w)
         return x.view_as(x)
 
     @staticmethod
     def backward(ctx, g):
+        if ctx.lazy:          # the caller assigns the (persistent) zero gradient itself: no fill launch in the backward
+            return g, None
         return g, torch.zeros(ctx.wshape, dtype=torch.float32, device=ctx.wdev)
+
+
+# Lazy anchors (hotpath.HotPathStep): the anchor's backward launches nothing; after the backward the step points the
+# `.grad` of every anchored parameter that got no gradient at a persistent all-zero tensor (take_anchored_params).
+_ANCHOR = {"lazy": False, "params": [], "zeros": {}}
+
+
+def lazy_anchors(flag):
+    prev = _ANCHOR["lazy"]
+    _ANCHOR["lazy"] = bool(flag)
+    return prev
+
+
+def assign_anchored_zero_grads():
+    """Give every parameter anchored since the last call an exactly-zero gradient if autograd produced none."""
+    params, _ANCHOR["params"] = _ANCHOR["params"], []
+    for w in params:
+        if w.grad is None:
+            key = (w.data_ptr(), tuple(w.shape))
+            z = _ANCHOR["zeros"].get(key)
+            if z is None:
+                z = torch.zeros_like(w)
+                _ANCHOR["zeros"][key] = z
+            w.grad = z
 
 
 def zero_grad_anchor(x, w):
@@ -1138,6 +1174,32 @@ def loss_overlap_enabled():
 # text_trans gradients (it updates the embedding tables in between).
 _DEFER = {"on": False}
 
+# Deferred regulariser sum. A caller whose loss tail is mmssl_bpr_step_f32 (hotpath.HotPathStep) may set this flag:
+# _HotForward.forward then returns `ss` UNREDUCED (its partial sums are handed to the tail through _DEFER_SS["last"],
+# which reduces them and stores the value into the same tensor), and one launch leaves the front of the loss chain.
+_DEFER_SS = {"on": False, "last": None}
+
+
+# Pre-filled loss buffer: with _PREFILL["floats"] set (a function (n_users, n_items, d) -> float count), the forward
+# zero-fills a buffer of that size on the GCN chain's stream and leaves it in _PREFILL["buf"] for the loss tail.
+_PREFILL = {"floats": None, "buf": None}
+
+
+def prefill_loss_buffer(fn):
+    prev = _PREFILL["floats"]
+    _PREFILL["floats"] = fn
+    if fn is None:
+        _PREFILL["buf"] = None
+    return prev
+
+
+def defer_feat_sumsq(flag):
+    prev = _DEFER_SS["on"]
+    _DEFER_SS["on"] = bool(flag)
+    if not flag:
+        _DEFER_SS["last"] = None
+    return prev
+
 
 def defer_wgrad_join(flag):
     prev = _DEFER["on"]
@@ -1203,6 +1265,13 @@ class _HotForward(torch.autograd.Function):
                     us.append(u)
                     its.append(i)
                 out["us"], out["its"] = us, its
+                if overlap and _PREFILL["floats"] is not None:
+                    # the loss section's zero-filled gradient buffer: the GCN chain's stream is idle from here to the
+                    # join (the modal chains end later), so the fill costs nothing on the critical path
+                    buf = torch.zeros(_PREFILL["floats"](u0.shape[0], i0.shape[0], u0.shape[1]), dtype=torch.float32,
+                                      device=dev)
+                    buf.record_stream(main)
+                    _PREFILL["buf"] = buf
 
         chains = {"A": chain_a, "B": chain_b, "C": chain_c}
         for c in _branch_order("MMSSL_FWD_ORDER", "ABC"):
@@ -1229,8 +1298,12 @@ class _HotForward(torch.autograd.Function):
             u_g = _combine_fwd(us, inv, img_user, txt_user, r, part[:nbu])
             i_g = _combine_fwd(its, inv, img_item, txt_item, r, part[nbu:])
         ss = torch.empty((), dtype=torch.float32, device=dev)
-        rc = _lib.lib().mmssl_sum_partials_f32(_ptr(part), nbu + nbi, _ptr(ss), _lib.stream_ptr())
-        _lib.check(rc, "mmssl_sum_partials_f32")
+        if _DEFER_SS["on"]:
+            # the caller's loss tail (mmssl_bpr_step_f32) reduces the partials and stores the sum into `ss`
+            _DEFER_SS["last"] = (ss, part)
+        else:
+            rc = _lib.lib().mmssl_sum_partials_f32(_ptr(part), nbu + nbi, _ptr(ss), _lib.stream_ptr())
+            _lib.check(rc, "mmssl_sum_partials_f32")
         ctx.save_for_backward(F_img, W_img, keep_img, F_txt, W_txt, keep_txt, img_user, txt_user, img_item, txt_item,
                               us[-1], its[-1])
         ctx.cfg = (ui, iu, n_layers, float(r), inv, float(scale), bool(overlap), b_img is not None, b_txt is not None)

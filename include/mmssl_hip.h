@@ -243,7 +243,9 @@ int mmssl_linear_f32(const float* F, const float* W, const float* b, const uint8
  * concurrently. The last block to deliver a partial of a tile adds the tile's partials in block order (bitwise the
  * result of mmssl_linear_f32) and applies bias + dropout: no second launch between the product and its consumer.
  * ticket_count == 0: this shape / kernel generation has no fix-up form, call mmssl_linear_f32. tickets == NULL is
- * mmssl_linear_f32. */
+ * mmssl_linear_f32. With tickets the WORKSPACE must be private to this entry point as well (memory no other kernel
+ * has touched with ordinary cached accesses since it was allocated): the partial tiles travel as write-through stores
+ * and cache-bypassing loads, which are not ordered against stale cached copies of recycled memory. */
 int64_t mmssl_linear_ticket_count(int64_t M, int K, int N);
 int mmssl_linear_tk_f32(const float* F, const float* W, const float* b, const uint8_t* keep,
                         float scale, int64_t M, int K, int N, float* Y, void* workspace,

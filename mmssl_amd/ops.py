@@ -235,6 +235,7 @@ def _linear_raw(F_, W, b, keep, scale):
     ws = torch.empty(max(nb // 4, 4), dtype=torch.float32, device=F_.device)
     tk = _linear_tickets(F_, M, K, N)
     if tk is not None:
+        tk, ws = tk               # the fix-up form owns its partial slots (see _linear_tickets)
         rc = _lib.lib().mmssl_linear_tk_f32(_ptr(F_), _ptr(W), _ptr(b), _ptr(keep), float(scale), M, K, N, _ptr(Y),
                                             _ptr(ws), ws.numel() * 4, _ptr(tk), _lib.stream_ptr())
         _lib.check(rc, "mmssl_linear_tk_f32")
@@ -253,7 +254,7 @@ _TICKETS = {}
 def linear_fixup_enabled():
     """OPT-IN (MMSSL_GEMM_FIXUP=1): the stream-K fix-up inside the kernel instead of the separate reduce launch.
     Measured: Baby image forward alone 102.3 vs 104.7 us, but the whole step 0.641 vs 0.625 ms, so the default stays
-    the two-launch form."""
+    the two-launch form. (The same fix-up for the weight gradient measured 0.604 vs 0.592 ms and was dropped.)"""
     return _os.environ.get("MMSSL_GEMM_FIXUP", "0") == "1"
 
 
@@ -269,7 +270,12 @@ def _linear_tickets(F_, M, K, N):
         if n <= 0:
             _TICKETS[key] = False
             return None
-        tk = torch.zeros(n, dtype=torch.int32, device=F_.device)
+        # tickets AND partial slots are private to this key for the life of the process: the fix-up's write-through
+        # stores / cache-bypassing loads are not ordered against ordinary cached accesses other kernels may have made to
+        # recycled allocator memory (a transient workspace showed order-dependent wrong results in a long test run)
+        nb = _lib.lib().mmssl_linear_workspace_bytes(M, K, N)
+        tk = (torch.zeros(n, dtype=torch.int32, device=F_.device),
+              torch.zeros(max(nb // 4, 4), dtype=torch.float32, device=F_.device))
         _TICKETS[key] = tk
     return tk if tk is not False else None
 

@@ -292,6 +292,13 @@ size_t mmssl_linear_wgrad_workspace_bytes(int64_t M, int K, int N);
  * sums the bias gradient on the fragments it loads (pass `keep`; no separate dropout-backward pass is needed);
  * 0 when it runs the register-staged kernel, for which a pre-masked gY (mmssl_mask_scale_f32) measured faster. */
 int mmssl_linear_wgrad_fuses_mask(int64_t M, int K, int N);
+/* The weight gradient left as its row-range partials (register-direct kernel only: returns MMSSL_E_UNSUPP where
+ * mmssl_linear_wgrad_fuses_mask is 0): workspace (mmssl_linear_wgrad_workspace_bytes) receives gW partials
+ * [*n_parts][N][K] at its start and the bias-gradient partials [*n_parts][N] at float offset *bias_offset; no reduce is
+ * launched - the optimiser adds the slices (mmssl_adamw_sliced_f32). */
+int mmssl_linear_wgrad_parts_f32(const float* gY, const uint8_t* keep, float scale, const float* F,
+                                 int64_t M, int K, int N, void* workspace, size_t workspace_bytes,
+                                 int* n_parts, int64_t* bias_offset, void* stream);
 int mmssl_linear_wgrad_f32(const float* gY, const uint8_t* keep, float scale, const float* F,
                            int64_t M, int K, int N, float* gW, float* gb, void* workspace,
                            size_t workspace_bytes, void* stream);
@@ -339,6 +346,13 @@ int mmssl_loss_assemble_tick_f32(const float* terms, const float* w, int n, cons
 int mmssl_adamw_ex_f32(float* const* params, const float* const* grads, float* const* exp_avg,
                        float* const* exp_avg_sq, const int64_t* numel, int count, float* state, float lr,
                        float beta1, float beta2, float eps, float weight_decay, int external_tick, void* stream);
+/* The same update with SLICED gradients: tensor t's gradient is grads[t][i] + grads[t][gstride[t] + i] + ... over
+ * slices[t] slices, added in slice order - the row-range partials mmssl_linear_wgrad_parts_f32 leaves behind, consumed
+ * without a reduce launch (bitwise the result of reducing first). slices == gstride == NULL is mmssl_adamw_ex_f32. */
+int mmssl_adamw_sliced_f32(float* const* params, const float* const* grads, float* const* exp_avg,
+                           float* const* exp_avg_sq, const int64_t* numel, const int32_t* slices,
+                           const int64_t* gstride, int n_tensors, float* state, float lr, float beta1,
+                           float beta2, float eps, float weight_decay, int external_tick, void* stream);
 int mmssl_dropout_mask_ex_u8(uint64_t* rng_state, float p, int64_t n, uint8_t* keep, int external_tick,
                              void* stream);
 /* Backward of the above: gterms[k] = g[0] * w[k], gextra[0] = g[0] * c (gextra may be NULL). */

@@ -95,6 +95,10 @@ SIGNATURES = {
     "mmssl_linear_ft_f32": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_float, c_int64, c_int, c_int,
                                     c_void_p, c_void_p, c_size_t, c_void_p]),
     "mmssl_linear_wgrad_fuses_mask": (c_int, [c_int64, c_int, c_int]),
+    "mmssl_linear_wgrad_parts_f32": (c_int, [c_void_p, c_void_p, c_float, c_void_p, c_int64, c_int, c_int, c_void_p,
+                                             c_size_t, c_void_p, c_void_p, c_void_p]),
+    "mmssl_adamw_sliced_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                                       c_void_p, c_float, c_float, c_float, c_float, c_float, c_int, c_void_p]),
     "mmssl_linear_wgrad_f32": (c_int, [c_void_p, c_void_p, c_float, c_void_p, c_int64, c_int, c_int, c_void_p,
                                        c_void_p, c_void_p, c_size_t, c_void_p]),
     "mmssl_mask_scale_f32": (c_int, [c_void_p, c_void_p, c_float, c_int64, c_void_p, c_void_p]),

@@ -2234,7 +2234,7 @@ inline WgPlan wg10_plan(int64_t M, int K, int N) {
   p.tk = K / 64;
   p.tn = N / 64;
   const int64_t tiles = (int64_t)p.tk * p.tn;
-  static const int max_sp = getenv("MMSSL_WG10_MAXSP") ? atoi(getenv("MMSSL_WG10_MAXSP")) : 64;
+  static const int max_sp = getenv("MMSSL_WG10_MAXSP") ? atoi(getenv("MMSSL_WG10_MAXSP")) : 8;
   int64_t sp = ((target > 0 ? target : 512) + tiles - 1) / tiles;
   const int64_t cap = M / 128 > 0 ? M / 128 : 1;
   if (sp > cap) sp = cap;
@@ -2321,6 +2321,27 @@ extern "C" int mmssl_linear_ft_f32(const float* FT, int64_t Mp, const float* W, 
   hipLaunchKernelGGL(ft_reduce_kernel, dim3((unsigned)tk, (unsigned)tn), dim3(kBlock), 0, s, P, sp, (int64_t)N * Mp, Mp, M,
                      N, Y, b, keep, scale);
   MMSSL_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int mmssl_linear_wgrad_parts_f32(const float* gY, const uint8_t* keep, float scale, const float* F, int64_t M,
+                                            int K, int N, void* workspace, size_t workspace_bytes, int* n_parts,
+                                            int64_t* bias_offset, void* stream) {
+  if (M <= 0 || K <= 0 || N <= 0 || !gY || !F || !n_parts || !bias_offset) return MMSSL_E_BADARG;
+  if (!wg10_usable(M, K, N)) return MMSSL_E_UNSUPP;
+  if (!workspace || workspace_bytes < mmssl_linear_wgrad_workspace_bytes(M, K, N)) return MMSSL_E_WORKSPACE;
+  if (((uintptr_t)gY | (uintptr_t)F | (uintptr_t)workspace) & 15) return MMSSL_E_BADARG;
+  if ((uintptr_t)keep & 3) return MMSSL_E_BADARG;
+  const WgPlan p = wg10_plan(M, K, N);
+  float* P = reinterpret_cast<float*>(workspace);
+  float* bpart = P + (size_t)p.sp * N * K;
+  auto* kern = keep ? (gemm_nt() ? wgrad10_kernel<true, true, 8> : wgrad10_kernel<true, false, 8>)
+                    : (gemm_nt() ? wgrad10_kernel<false, true, 8> : wgrad10_kernel<false, false, 8>);
+  hipLaunchKernelGGL(kern, dim3((unsigned)p.tk, (unsigned)p.tn, (unsigned)p.sp), dim3(kBlock), 0, as_stream(stream), gY,
+                     keep, scale, F, M, K, N, p.ms, P, (int64_t)N * K, bpart);
+  MMSSL_LAUNCH_CHECK();
+  *n_parts = p.sp;
+  *bias_offset = (int64_t)p.sp * N * K;
   return 0;
 }
 

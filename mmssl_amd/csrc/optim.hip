@@ -17,6 +17,8 @@ struct AdamTensors {
   float* m[MMSSL_ADAMW_MAX_TENSORS];
   float* v[MMSSL_ADAMW_MAX_TENSORS];
   int64_t n[MMSSL_ADAMW_MAX_TENSORS];
+  int64_t gstride[MMSSL_ADAMW_MAX_TENSORS];           // floats between the slices of a sliced gradient
+  int32_t slices[MMSSL_ADAMW_MAX_TENSORS];            // 1 = plain gradient; s > 1: g = g[0] + g[stride] + ... (in order)
   int32_t first_block[MMSSL_ADAMW_MAX_TENSORS + 1];   // prefix of per-tensor block counts
   int32_t count;
 };
@@ -32,34 +34,33 @@ __global__ void tick_u64_kernel(uint64_t* __restrict__ counter) { counter[0] += 
 
 // `pre_ticked`: state[0] already is the number of THIS step (a stream-ordered launch before this one advanced it:
 // mmssl_step_tick / mmssl_loss_assemble_tick_f32); otherwise state[0] counts completed steps.
-__global__ __launch_bounds__(kBlock) void adamw_kernel(AdamTensors T, const float* __restrict__ state, float lr,
-                                                       float beta1, float beta2, float eps, float wd, int pre_ticked) {
-  int t = 0;
-  while (t + 1 < T.count && (int)blockIdx.x >= T.first_block[t + 1]) ++t;
-  const int64_t base = (int64_t)(blockIdx.x - T.first_block[t]) * kAdamPerBlock;
-  const int64_t n = T.n[t];
-  float* __restrict__ p = T.p[t];
-  const float* __restrict__ g = T.g[t];
-  float* __restrict__ m = T.m[t];
-  float* __restrict__ v = T.v[t];
-  // bias corrections once per block (powf is ~100s of instructions), broadcast through LDS;
-  // same operation order as torch's _single_tensor_adamw / fused kernel in fp32
-  __shared__ float sh[2];
-  if (threadIdx.x == 0) {
-    const float step = pre_ticked ? state[0] : state[0] + 1.0f;
-    sh[0] = lr / (1.0f - powf(beta1, step));
-    sh[1] = sqrtf(1.0f - powf(beta2, step));
-  }
-  __syncthreads();
-  const float step_size = sh[0];
-  const float bc2_sqrt = sh[1];
-  const float decay = 1.0f - lr * wd;
+template <bool SLICED>
+__device__ __forceinline__ void adamw_block(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                            float* __restrict__ v, int64_t n, int64_t base, int nsl, int64_t gst,
+                                            float step_size, float bc2_sqrt, float decay, float beta1, float beta2,
+                                            float eps) {
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int64_t i = base + ((int64_t)r * kBlock + threadIdx.x) * kAdamPerThread;
     if (i + kAdamPerThread <= n) {
       float4 pp = *reinterpret_cast<float4*>(p + i);
-      const float4 gg = *reinterpret_cast<const float4*>(g + i);
+      float4 gg = *reinterpret_cast<const float4*>(g + i);
+      if (SLICED) {
+        // split-K partial gradients, added in slice order; eight loads are requested before the first add (one memory
+        // latency per eight slices instead of one per slice)
+        for (int s0 = 1; s0 < nsl; s0 += 8) {
+          float4 q[8];
+#pragma unroll
+          for (int k = 0; k < 8; ++k)
+            q[k] = s0 + k < nsl ? *reinterpret_cast<const float4*>(g + (int64_t)(s0 + k) * gst + i)
+                                : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+          for (int k = 0; k < 8; ++k)
+            if (s0 + k < nsl) {
+              gg.x += q[k].x; gg.y += q[k].y; gg.z += q[k].z; gg.w += q[k].w;
+            }
+        }
+      }
       float4 mm = *reinterpret_cast<float4*>(m + i);
       float4 vv = *reinterpret_cast<float4*>(v + i);
       float* P = &pp.x;
@@ -80,7 +81,9 @@ __global__ __launch_bounds__(kBlock) void adamw_kernel(AdamTensors T, const floa
     } else {
       for (int64_t j = i; j < n && j < i + kAdamPerThread; ++j) {
         float P = p[j] * decay;
-        const float G = g[j];
+        float G = g[j];
+        if (SLICED)
+          for (int sl = 1; sl < nsl; ++sl) G += g[(int64_t)sl * gst + j];
         const float M = m[j] + (G - m[j]) * (1.0f - beta1);
         const float V = v[j] * beta2 + (1.0f - beta2) * G * G;
         P -= step_size * (M / (sqrtf(V) / bc2_sqrt + eps));
@@ -90,6 +93,29 @@ __global__ __launch_bounds__(kBlock) void adamw_kernel(AdamTensors T, const floa
       }
     }
   }
+}
+
+__global__ __launch_bounds__(kBlock) void adamw_kernel(AdamTensors T, const float* __restrict__ state, float lr,
+                                                       float beta1, float beta2, float eps, float wd, int pre_ticked) {
+  int t = 0;
+  while (t + 1 < T.count && (int)blockIdx.x >= T.first_block[t + 1]) ++t;
+  const int64_t base = (int64_t)(blockIdx.x - T.first_block[t]) * kAdamPerBlock;
+  // bias corrections once per block (powf is ~100s of instructions), broadcast through LDS;
+  // same operation order as torch's _single_tensor_adamw / fused kernel in fp32
+  __shared__ float sh[2];
+  if (threadIdx.x == 0) {
+    const float step = pre_ticked ? state[0] : state[0] + 1.0f;
+    sh[0] = lr / (1.0f - powf(beta1, step));
+    sh[1] = sqrtf(1.0f - powf(beta2, step));
+  }
+  __syncthreads();
+  const float decay = 1.0f - lr * wd;
+  // the sliced form (a block-uniform choice) lives in its own copy of the loop so that the plain one stays as it was
+  if (T.slices[t] > 1)
+    adamw_block<true>(T.p[t], T.g[t], T.m[t], T.v[t], T.n[t], base, T.slices[t], T.gstride[t], sh[0], sh[1], decay, beta1,
+                      beta2, eps);
+  else
+    adamw_block<false>(T.p[t], T.g[t], T.m[t], T.v[t], T.n[t], base, 1, 0, sh[0], sh[1], decay, beta1, beta2, eps);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -135,11 +161,25 @@ __global__ __launch_bounds__(kBlock) void dropout_mask_kernel(const uint64_t* __
 
 using namespace mmssl;
 
+extern "C" int mmssl_adamw_sliced_f32(float* const* params, const float* const* grads, float* const* exp_avg,
+                                      float* const* exp_avg_sq, const int64_t* numel, const int32_t* slices,
+                                      const int64_t* gstride, int count, float* state, float lr, float beta1,
+                                      float beta2, float eps, float weight_decay, int external_tick, void* stream);
+
 extern "C" int mmssl_adamw_ex_f32(float* const* params, const float* const* grads, float* const* exp_avg,
                                   float* const* exp_avg_sq, const int64_t* numel, int count, float* state, float lr,
                                   float beta1, float beta2, float eps, float weight_decay, int external_tick,
                                   void* stream) {
+  return mmssl_adamw_sliced_f32(params, grads, exp_avg, exp_avg_sq, numel, nullptr, nullptr, count, state, lr, beta1,
+                                beta2, eps, weight_decay, external_tick, stream);
+}
+
+extern "C" int mmssl_adamw_sliced_f32(float* const* params, const float* const* grads, float* const* exp_avg,
+                                      float* const* exp_avg_sq, const int64_t* numel, const int32_t* slices,
+                                      const int64_t* gstride, int count, float* state, float lr, float beta1,
+                                      float beta2, float eps, float weight_decay, int external_tick, void* stream) {
   if (count < 0 || count > MMSSL_ADAMW_MAX_TENSORS || !state) return MMSSL_E_BADARG;
+  if ((slices == nullptr) != (gstride == nullptr)) return MMSSL_E_BADARG;
   if (count == 0) return 0;
   if (!params || !grads || !exp_avg || !exp_avg_sq || !numel) return MMSSL_E_BADARG;
   AdamTensors T;
@@ -154,6 +194,9 @@ extern "C" int mmssl_adamw_ex_f32(float* const* params, const float* const* grad
     T.m[t] = exp_avg[t];
     T.v[t] = exp_avg_sq[t];
     T.n[t] = numel[t];
+    T.slices[t] = slices ? slices[t] : 1;
+    T.gstride[t] = slices ? gstride[t] : 0;
+    if (T.slices[t] < 1 || (T.slices[t] > 1 && (T.gstride[t] < numel[t] || (T.gstride[t] & 3)))) return MMSSL_E_BADARG;
     T.first_block[t] = blocks;
     const int64_t nb = (numel[t] + kAdamPerBlock - 1) / kAdamPerBlock;
     if (nb > (1 << 24)) return MMSSL_E_UNSUPP;

@@ -401,6 +401,22 @@ def _linear_wgrad_split(gY0, keep, scale, F_, W):
 # the register-staged wgrad kernel (mmssl_linear_wgrad_f32), which is also what unregistered inputs use.
 _FT = {}
 
+# Weight gradients as row-range partials (hotpath.HotPathStep): with _WPARTS["on"] the fused weight-gradient path
+# returns no gradient tensors; it leaves (workspace, n_parts, weight stride, bias offset, N) under the weight's
+# data_ptr for the optimiser, which adds the slices while it reads them.
+_WPARTS = {"on": False, "map": {}}
+
+
+def wgrad_parts(flag):
+    prev = _WPARTS["on"]
+    _WPARTS["on"] = bool(flag)
+    return prev
+
+
+def take_wgrad_parts():
+    m, _WPARTS["map"] = _WPARTS["map"], {}
+    return m
+
 
 def wgrad_ft_enabled():
     """OPT-IN (MMSSL_WGRAD_FT=1). Measured on MI355X (tools/gemm_v6_probe.py, hipGraph replay): Baby image wgrad
@@ -454,6 +470,17 @@ def _linear_wgrad_raw(gY, keep, scale, F_, W):
     if ft is not None and N % 4 == 0 and N <= 256:
         return _linear_wgrad_ft(gY0, keep, scale, F_, W, ft[0], ft[1])
     fused = keep is not None and _lib.lib().mmssl_linear_wgrad_fuses_mask(M, K, N) == 1
+    if fused and _WPARTS["on"]:
+        # the caller's optimiser adds the row-range partials itself (mmssl_adamw_sliced_f32): no reduce launch, no
+        # materialised gW / gb; the partial buffers are handed over through take_wgrad_parts()
+        nb = _lib.lib().mmssl_linear_wgrad_workspace_bytes(M, K, N)
+        ws = torch.empty(max(nb // 4, 4), dtype=torch.float32, device=W.device)
+        n_parts, b_off = _ct.c_int(0), _ct.c_int64(0)
+        rc = _lib.lib().mmssl_linear_wgrad_parts_f32(_ptr(gY), _ptr(keep), float(scale), _ptr(F_), M, K, N, _ptr(ws), nb,
+                                                     _ct.byref(n_parts), _ct.byref(b_off), _lib.stream_ptr())
+        _lib.check(rc, "mmssl_linear_wgrad_parts_f32")
+        _WPARTS["map"][W.data_ptr()] = (ws, int(n_parts.value), N * K, int(b_off.value), N)
+        return None, None, None
     if fused:                   # register-direct kernel: dropout backward + bias gradient on the loaded fragments
         gW = torch.empty_like(W)
         gb = torch.empty(N, dtype=torch.float32, device=W.device)

@@ -32,9 +32,12 @@ class FusedAdamW(torch.optim.Optimizer):
         return st
 
     @torch.no_grad()
-    def step(self, closure=None, groups=None):
+    def step(self, closure=None, groups=None, sliced=None):
         """`groups`: optional iterable of param-group indices to update (each group has its own device step
-        counter, so groups may be stepped at different points of one iteration)."""
+        counter, so groups may be stepped at different points of one iteration).
+        `sliced`: {parameter: (buffer, float offset, n_slices, stride)} - gradients that exist only as split-K partials
+        (ops.take_wgrad_parts): slice s of the gradient starts at buffer[offset + s * stride]; the kernel adds the
+        slices in order while it reads them. Such parameters need no `.grad`."""
         loss = None
         if closure is not None:
             with torch.enable_grad():
@@ -44,20 +47,28 @@ class FusedAdamW(torch.optim.Optimizer):
                 continue
             todo = []
             for p in group["params"]:
-                if p.grad is None:
+                sl = sliced.get(p) if sliced else None
+                if p.grad is None and sl is None:
                     continue
                 if not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous()):
                     raise _lib.MmsslError("FusedAdamW: parameters must be contiguous fp32 HIP tensors")
-                g = p.grad
-                if g.is_sparse:
-                    raise _lib.MmsslError("FusedAdamW: sparse gradients are not supported")
-                if not g.is_contiguous():
-                    g = g.contiguous()
+                if p.grad is not None:
+                    g = p.grad
+                    if g.is_sparse:
+                        raise _lib.MmsslError("FusedAdamW: sparse gradients are not supported")
+                    if not g.is_contiguous():
+                        g = g.contiguous()
+                    gptr, nsl, gst = g.data_ptr(), 1, 0
+                else:
+                    buf, off, nsl, gst = sl
+                    if buf.dtype != torch.float32 or not buf.is_contiguous() or off + (nsl - 1) * gst + p.numel() > buf.numel():
+                        raise _lib.MmsslError("FusedAdamW: sliced gradient does not fit its buffer")
+                    g, gptr = buf, buf.data_ptr() + 4 * off
                 st = self.state[p]
                 if not st:
                     st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                todo.append((p, g, st["exp_avg"], st["exp_avg_sq"]))
+                todo.append((p, g, st["exp_avg"], st["exp_avg_sq"], gptr, nsl, gst))
             if not todo:
                 continue
             state = self._group_state(gi, todo[0][0].device)
@@ -69,12 +80,15 @@ class FusedAdamW(torch.optim.Optimizer):
             n = len(todo)
             arr = lambda k: (_ct.c_void_p * n)(*[t[k].data_ptr() for t in todo])       # noqa: E731
             numel = (_ct.c_int64 * n)(*[t[0].numel() for t in todo])
+            gptrs = (_ct.c_void_p * n)(*[t[4] for t in todo])
+            slices = (_ct.c_int32 * n)(*[t[5] for t in todo])
+            gstride = (_ct.c_int64 * n)(*[t[6] for t in todo])
             from . import ops as _ops
-            rc = _lib.lib().mmssl_adamw_ex_f32(arr(0), arr(1), arr(2), arr(3), numel, n, state.data_ptr(),
-                                               float(group["lr"]), float(b1), float(b2), float(group["eps"]),
-                                               float(group["weight_decay"]), 1 if _ops.EXTERNAL["on"] else 0,
-                                               _lib.stream_ptr())
-            _lib.check(rc, "mmssl_adamw_ex_f32")
+            rc = _lib.lib().mmssl_adamw_sliced_f32(arr(0), gptrs, arr(2), arr(3), numel, slices, gstride, n,
+                                                   state.data_ptr(), float(group["lr"]), float(b1), float(b2),
+                                                   float(group["eps"]), float(group["weight_decay"]),
+                                                   1 if _ops.EXTERNAL["on"] else 0, _lib.stream_ptr())
+            _lib.check(rc, "mmssl_adamw_sliced_f32")
         return loss
 
     # torch.optim.AdamW-compatible checkpoint layout: per-parameter "step" tensors

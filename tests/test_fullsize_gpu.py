@@ -159,6 +159,7 @@ def _baby_case(modal):
         model.load_state_dict(state0)
         model = model.to(DEV).train()
         step = HotPathStep(model, graphs_g, 1024, decay=1e-5)
+        step.materialize_grads = True       # these tests read every `.grad` (default: the projection gradients stay partials)
         step.keep_masks = tuple(k.to(torch.uint8).to(DEV) for k in km)
         step.set_batch(users.to(DEV), pos.to(DEV), neg.to(DEV))
         return model, step

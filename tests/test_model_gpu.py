@@ -217,6 +217,9 @@ def test_hotpath_graph_replay_with_stream_overlap_matches_eager_sequential():
         model = MMSSL(U, I, 64, [64] * 3, [0.1] * 3, img, txt).to(DEV).train()
         e1, e2 = GraphPlan(sp.csr_matrix((U, I), dtype=np.float32)), GraphPlan(sp.csr_matrix((I, U), dtype=np.float32))
         step = HotPathStep(model, (GraphPlan(ui), GraphPlan(iu), e1, e2, e1, e2), B)
+        # the eager-loss runs keep the projection gradients as split-K partials added inside AdamW (the default), the
+        # autograd-loss run materialises them through the reduce launch: same trajectory either way
+        step.materialize_grads = not eager_loss
         step.set_batch(*[t.to(DEV) for t in batches[0]])
         if capture:
             assert step.capture(warmup=1), getattr(step, "capture_error", "")

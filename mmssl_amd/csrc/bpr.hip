@@ -197,6 +197,16 @@ __global__ __launch_bounds__(kBlock) void bpr_step_kernel(const float4* __restri
   }
   const float t0 = block_sum_256(ls, red);
   const float t1 = block_sum_256(sq, red);
+  // the extra term given as partial sums (the forward's regulariser partials): block 0 reduces them (the arithmetic of
+  // sum_partials_kernel) next to the other blocks' work and parks the value behind the BPR partials
+  if (xparts && blockIdx.x == 0) {
+    float e = 0.f;
+    for (int64_t i = threadIdx.x; i < n_xparts; i += kBlock) e += xparts[i];
+    const float xsum = block_sum_256(e, red);
+    if (threadIdx.x == 0)
+      __hip_atomic_store(reinterpret_cast<unsigned*>(part) + 2 * gridDim.x, __float_as_uint(xsum), __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_AGENT);
+  }
   if (threadIdx.x == 0) {
     __hip_atomic_store(reinterpret_cast<unsigned*>(part) + 2 * blockIdx.x + 0, __float_as_uint(t0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(reinterpret_cast<unsigned*>(part) + 2 * blockIdx.x + 1, __float_as_uint(t1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -215,13 +225,10 @@ __global__ __launch_bounds__(kBlock) void bpr_step_kernel(const float4* __restri
   }
   const float lsum = block_sum_256(a, red);
   const float qsum = block_sum_256(c, red);
-  // the extra term given as partial sums (the forward's regulariser partials): reduced here with the arithmetic of
-  // sum_partials_kernel instead of by a launch of its own in front of the loss chain
   float xs = 0.f;
   if (xparts) {
-    float e = 0.f;
-    for (int64_t i = threadIdx.x; i < n_xparts; i += kBlock) e += xparts[i];
-    xs = block_sum_256(e, red);
+    xs = __uint_as_float(__hip_atomic_load(reinterpret_cast<unsigned*>(part) + 2 * gridDim.x, __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_AGENT));
     if (threadIdx.x == 0 && extra_out) extra_out[0] = xs;
   } else if (extra) {
     xs = extra[0];

@@ -318,8 +318,8 @@ def graph_capture_works(a):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--workload", default="baby")
     ap.add_argument("--d", type=int, default=64)
     ap.add_argument("--gcn-layers", type=int, default=3, dest="gcn_layers")

@@ -428,9 +428,9 @@ def main():
         with torch.cuda.stream(step.stream):
             comm["comm_only_ms"] = round(mdist.comm_replay_ms(log, None, dev), 4)
         rngb = np.random.default_rng(2022)          # identical batches on every rank (global ids)
-        batches = [tuple(torch.from_numpy(x).to(dev) for x in (
+        batches = [(torch.stack([torch.from_numpy(x).to(dev) for x in (                   # packed [3, B]: one copy per step
             rngb.choice(n_users, a.batch, replace=a.batch > n_users).astype(np.int64),
-            rngb.integers(0, n_items, a.batch).astype(np.int64), rngb.integers(0, n_items, a.batch).astype(np.int64)))
+            rngb.integers(0, n_items, a.batch).astype(np.int64), rngb.integers(0, n_items, a.batch).astype(np.int64))]),)
             for _ in range(8)]
 
     def run_steps(n):

@@ -216,6 +216,7 @@ class GatherBatchRowsMulti(torch.autograd.Function):
                 bk.gather_owned(t.detach().contiguous(), idx, lo, packed[o:o + sz])
                 o += sz
             ctx.meta = [(idx, lo, t.shape[0]) for t, idx, lo in zip(tables, idxs, los)]
+            ctx.tkeys = [(t.data_ptr(), tuple(t.shape)) for t in tables]      # repeated tables share one gradient
         else:
             pieces, meta = [], []
             for t, idx, lo in zip(tables, idxs, los):
@@ -234,6 +235,28 @@ class GatherBatchRowsMulti(torch.autograd.Function):
     @staticmethod
     def backward(ctx, *gs):
         outs = []
+        if ctx.fast:
+            # ONE zero fill for all table gradients; pieces gathered from the same table (pos / neg items) scatter-add
+            # into the same gradient, which is returned once (the other positions get None = zero)
+            first, rows = {}, 0
+            for k, (g, m) in enumerate(zip(gs, ctx.meta)):
+                if g is not None and ctx.tkeys[k] not in first:
+                    first[ctx.tkeys[k]] = (k, rows)
+                    rows += m[2]
+            live = [g for g in gs if g is not None]
+            if not live:
+                return (None, None, None) + (None,) * (3 * len(ctx.meta))
+            buf = torch.zeros((rows, live[0].shape[1]), dtype=live[0].dtype, device=live[0].device)
+            for k, (g, m) in enumerate(zip(gs, ctx.meta)):
+                if g is None:
+                    outs.append(None)
+                    continue
+                idx, lo, per = m
+                k0, r0 = first[ctx.tkeys[k]]
+                ctx.bk.scatter_owned(g.contiguous(), idx, lo, buf[r0:r0 + per])
+                outs.append(buf[r0:r0 + per] if k == k0 else None)
+            n = len(ctx.meta)
+            return (None, None, None) + tuple(outs) + (None,) * (2 * n)
         for g, m in zip(gs, ctx.meta):
             if g is None:
                 outs.append(None)
@@ -589,9 +612,8 @@ class ShardedHotPathStep:
         self.model, self.graphs, self.group = model, tuple(graphs), group
         self.batch_size, self.n_items, self.modal_empty = int(batch_size), int(n_items), modal_empty
         dev = model.E_u.device
-        self.users = torch.zeros(batch_size, dtype=torch.int64, device=dev)
-        self.pos = torch.zeros(batch_size, dtype=torch.int64, device=dev)
-        self.neg = torch.zeros(batch_size, dtype=torch.int64, device=dev)
+        self.batch = torch.zeros((3, batch_size), dtype=torch.int64, device=dev)         # users / pos / neg
+        self.users, self.pos, self.neg = self.batch[0], self.batch[1], self.batch[2]
         on_gpu = dev.type == "cuda"
         if not optimizer:
             self.optimizer = None
@@ -611,11 +633,14 @@ class ShardedHotPathStep:
         import contextlib
         return torch.cuda.stream(self.stream) if self.stream is not None else contextlib.nullcontext()
 
-    def set_batch(self, users, pos, neg):
+    def set_batch(self, users, pos=None, neg=None):
         with self._ctx():
-            self.users.copy_(users)
-            self.pos.copy_(pos)
-            self.neg.copy_(neg)
+            if pos is None:                  # packed [3, B] batch: one device-to-device copy instead of three
+                self.batch.copy_(users, non_blocking=True)
+            else:
+                self.users.copy_(users)
+                self.pos.copy_(pos)
+                self.neg.copy_(neg)
 
     def losses(self, keep_masks=None):
         m, bk, c, g = self.model, self.model.bk, self.model.cfg, self.group

@@ -449,6 +449,20 @@ int mmssl_bpr_step_f32(const float* Eu, const float* Ei, const int64_t* users, c
                        float* const* f32_ticks, int n_f32, uint64_t* const* u64_ticks, int n_u64,
                        void* workspace, size_t workspace_bytes, int* ticket, const float* extra_parts,
                        int64_t n_extra_parts, void* stream);
+/* Phase 1 of mmssl_infonce_multi_bwd_phase_f32 (the backward pair tiles, fp32-MFMA shapes d <= 64 only) with the whole
+ * of mmssl_bpr_step_f32 riding along as extra blocks of the same launch: the BPR tail depends on nothing the pair tiles
+ * compute, and as a launch of its own it adds its full duration to the loss chain. Arguments: those of the two entry
+ * points (bpr_workspace / ticket as for mmssl_bpr_step_f32). Follow with phases = 2 of mmssl_infonce_multi_bwd_phase_f32. */
+int mmssl_infonce_bwd_tiles_bpr_f32(const int64_t* idx, int n_problems, int64_t n, int d, float tau,
+                                    const float* gloss, float* const* gz1s, float* gz2, void* workspace,
+                                    size_t workspace_bytes, const float* Eu, const float* Ei,
+                                    const int64_t* users, const int64_t* pos, const int64_t* neg, int64_t B,
+                                    float decay, int64_t batch_size, const float* g_mf, const float* g_emb,
+                                    float* gEu, float* gEi, float* terms, const float* w, int n_terms,
+                                    const float* extra, float c, float* total, float* const* f32_ticks,
+                                    int n_f32, uint64_t* const* u64_ticks, int n_u64, void* bpr_workspace,
+                                    size_t bpr_workspace_bytes, int* ticket, const float* extra_parts,
+                                    int64_t n_extra_parts, void* stream);
 
 #ifdef __cplusplus
 }

@@ -8,6 +8,7 @@
 // The backward scatters into the dense table gradients with hardware fp32 atomics (only
 // rows that repeat inside a batch — possible for items — see their add order vary).
 #include "common.hpp"
+#include "bpr_step.hpp"
 
 using namespace mmssl;
 
@@ -144,107 +145,9 @@ __global__ __launch_bounds__(kBlock) void bpr_bwd_kernel(const float4* __restric
 // block order (same arithmetic as bpr_finalize_kernel), writes terms[0..2], assembles
 //   total = sum_k w[k] * terms[k] + c * extra        (main.py:420; terms[3..] are read: the InfoNCE losses)
 // and advances the step's counters. `ticket` must be 0 on entry and is left 0.
-struct StepTicks {
-  float* f32[4];
-  unsigned long long* u64[4];
-  int n_f32, n_u64;
-};
-
 template <int LPR>
-__global__ __launch_bounds__(kBlock) void bpr_step_kernel(const float4* __restrict__ Eu, const float4* __restrict__ Ei,
-                                                          const int64_t* __restrict__ users,
-                                                          const int64_t* __restrict__ pos,
-                                                          const int64_t* __restrict__ neg, int64_t B, float decay,
-                                                          int64_t batch_size, const float* __restrict__ g_mf,
-                                                          const float* __restrict__ g_emb, float* __restrict__ gEu,
-                                                          float* __restrict__ gEi, float* __restrict__ part,
-                                                          int* __restrict__ ticket, float* __restrict__ terms,
-                                                          const float* __restrict__ w, int n_terms,
-                                                          const float* __restrict__ extra, float cex,
-                                                          float* __restrict__ total, StepTicks T,
-                                                          const float* __restrict__ xparts, int64_t n_xparts,
-                                                          float* __restrict__ extra_out) {
-  __shared__ float red[4];
-  __shared__ int s_last;
-  constexpr int GPB = kBlock / LPR;
-  constexpr int D = LPR * 4;
-  const int lig = threadIdx.x & (LPR - 1);
-  const int64_t b = (int64_t)blockIdx.x * GPB + threadIdx.x / LPR;
-  float ls = 0.f, sq = 0.f;
-  if (b < B) {
-    const int64_t ru = users[b], rp = pos[b], rn = neg[b];
-    const float4 u = Eu[ru * LPR + lig], p = Ei[rp * LPR + lig], n = Ei[rn * LPR + lig];
-    const float sp = group_sum<LPR>(f4_dot(u, p));
-    const float sn = group_sum<LPR>(f4_dot(u, n));
-    const float q = group_sum<LPR>(f4_dot(u, u) + f4_dot(p, p) + f4_dot(n, n));
-    const float diff = sp - sn;
-    if (lig == 0) {
-      ls = log_sigmoid(diff);
-      sq = q;
-    }
-    const float sig_neg = 1.f / (1.f + expf(diff));
-    const float cm = -g_mf[0] * sig_neg / (float)B;
-    const float ce = g_emb[0] * decay / (float)batch_size;
-    float* du = gEu + ru * D + lig * 4;
-    float* dp = gEi + rp * D + lig * 4;
-    float* dn = gEi + rn * D + lig * 4;
-    unsafeAtomicAdd(du + 0, cm * (p.x - n.x) + ce * u.x); unsafeAtomicAdd(du + 1, cm * (p.y - n.y) + ce * u.y);
-    unsafeAtomicAdd(du + 2, cm * (p.z - n.z) + ce * u.z); unsafeAtomicAdd(du + 3, cm * (p.w - n.w) + ce * u.w);
-    unsafeAtomicAdd(dp + 0, cm * u.x + ce * p.x); unsafeAtomicAdd(dp + 1, cm * u.y + ce * p.y);
-    unsafeAtomicAdd(dp + 2, cm * u.z + ce * p.z); unsafeAtomicAdd(dp + 3, cm * u.w + ce * p.w);
-    unsafeAtomicAdd(dn + 0, -cm * u.x + ce * n.x); unsafeAtomicAdd(dn + 1, -cm * u.y + ce * n.y);
-    unsafeAtomicAdd(dn + 2, -cm * u.z + ce * n.z); unsafeAtomicAdd(dn + 3, -cm * u.w + ce * n.w);
-  }
-  const float t0 = block_sum_256(ls, red);
-  const float t1 = block_sum_256(sq, red);
-  // the extra term given as partial sums (the forward's regulariser partials): block 0 reduces them (the arithmetic of
-  // sum_partials_kernel) next to the other blocks' work and parks the value behind the BPR partials
-  if (xparts && blockIdx.x == 0) {
-    float e = 0.f;
-    for (int64_t i = threadIdx.x; i < n_xparts; i += kBlock) e += xparts[i];
-    const float xsum = block_sum_256(e, red);
-    if (threadIdx.x == 0)
-      __hip_atomic_store(reinterpret_cast<unsigned*>(part) + 2 * gridDim.x, __float_as_uint(xsum), __ATOMIC_RELAXED,
-                         __HIP_MEMORY_SCOPE_AGENT);
-  }
-  if (threadIdx.x == 0) {
-    __hip_atomic_store(reinterpret_cast<unsigned*>(part) + 2 * blockIdx.x + 0, __float_as_uint(t0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(reinterpret_cast<unsigned*>(part) + 2 * blockIdx.x + 1, __float_as_uint(t1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __threadfence();
-    const int prev = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-    s_last = (prev == (int)gridDim.x - 1);
-    if (s_last) __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // re-arm
-  }
-  __syncthreads();
-  if (!s_last) return;
-  __threadfence();
-  float a = 0.f, c = 0.f;
-  for (int i = threadIdx.x; i < (int)gridDim.x; i += kBlock) {
-    a += __uint_as_float(__hip_atomic_load(reinterpret_cast<unsigned*>(part) + 2 * i + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-    c += __uint_as_float(__hip_atomic_load(reinterpret_cast<unsigned*>(part) + 2 * i + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-  }
-  const float lsum = block_sum_256(a, red);
-  const float qsum = block_sum_256(c, red);
-  float xs = 0.f;
-  if (xparts) {
-    xs = __uint_as_float(__hip_atomic_load(reinterpret_cast<unsigned*>(part) + 2 * gridDim.x, __ATOMIC_RELAXED,
-                                           __HIP_MEMORY_SCOPE_AGENT));
-    if (threadIdx.x == 0 && extra_out) extra_out[0] = xs;
-  } else if (extra) {
-    xs = extra[0];
-  }
-  if (threadIdx.x == 0) {
-    const float t_mf = -(lsum / (float)B), t_emb = decay * ((0.5f * qsum) / (float)batch_size);
-    terms[0] = t_mf;
-    terms[1] = t_emb;
-    terms[2] = 0.f;
-    float t = w[0] * t_mf + w[1] * t_emb + w[2] * 0.f;          // same order as loss_assemble_kernel
-    for (int k = 3; k < n_terms; ++k) t += w[k] * terms[k];
-    if (extra || xparts) t += cex * xs;
-    total[0] = t;
-    for (int k = 0; k < T.n_f32; ++k) T.f32[k][0] += 1.0f;
-    for (int k = 0; k < T.n_u64; ++k) T.u64[k][0] += 1ull;
-  }
+__global__ __launch_bounds__(kBlock) void bpr_step_kernel(BprStepArgs A) {
+  bpr_step_block<LPR>(A, (int)blockIdx.x);
 }
 
 inline int64_t bpr_blocks(int64_t B, int d) {
@@ -317,33 +220,17 @@ extern "C" int mmssl_bpr_step_f32(const float* Eu, const float* Ei, const int64_
                                   float* const* f32_ticks, int n_f32, uint64_t* const* u64_ticks, int n_u64,
                                   void* workspace, size_t workspace_bytes, int* ticket, const float* extra_parts,
                                   int64_t n_extra_parts, void* stream) {
-  if (B <= 0 || batch_size <= 0 || !Eu || !Ei || !users || !pos || !neg || !g_mf || !g_emb || !gEu || !gEi)
-    return MMSSL_E_BADARG;
-  if (!terms || !w || !total || !ticket || n_terms < 3 || n_terms > 16) return MMSSL_E_BADARG;
-  if (extra_parts && (n_extra_parts <= 0 || !extra)) return MMSSL_E_BADARG;
-  float* extra_out = extra_parts ? const_cast<float*>(extra) : nullptr;       // the reduced value is stored there
-  const float* extra_in = extra_parts ? nullptr : extra;
-  if (n_f32 < 0 || n_f32 > 4 || n_u64 < 0 || n_u64 > 4 || (n_f32 > 0 && !f32_ticks) || (n_u64 > 0 && !u64_ticks))
-    return MMSSL_E_BADARG;
-  if (!supported_d(d)) return MMSSL_E_UNSUPP;
-  if (!workspace || workspace_bytes < mmssl_bpr_workspace_bytes(B)) return MMSSL_E_WORKSPACE;
-  StepTicks T;
-  T.n_f32 = n_f32; T.n_u64 = n_u64;
-  for (int k = 0; k < 4; ++k) {
-    T.f32[k] = k < n_f32 ? f32_ticks[k] : nullptr;
-    T.u64[k] = k < n_u64 ? reinterpret_cast<unsigned long long*>(u64_ticks[k]) : nullptr;
-    if ((k < n_f32 && !T.f32[k]) || (k < n_u64 && !T.u64[k])) return MMSSL_E_BADARG;
-  }
+  BprStepArgs A;
+  const int rc = make_bpr_step_args(A, Eu, Ei, users, pos, neg, B, d, decay, batch_size, g_mf, g_emb, gEu, gEi, terms, w,
+                                    n_terms, extra, c, total, f32_ticks, n_f32, u64_ticks, n_u64, workspace,
+                                    workspace_bytes, mmssl_bpr_workspace_bytes(B), ticket, extra_parts, n_extra_parts);
+  if (rc != 0) return rc;
   hipStream_t s = as_stream(stream);
-  const int nb = (int)bpr_blocks(B, d);
-  float* part = reinterpret_cast<float*>(workspace);
-  const float4* a = reinterpret_cast<const float4*>(Eu);
-  const float4* b = reinterpret_cast<const float4*>(Ei);
   switch (d) {
-    case 32: hipLaunchKernelGGL((bpr_step_kernel<8>), dim3(nb), dim3(kBlock), 0, s, a, b, users, pos, neg, B, decay, batch_size, g_mf, g_emb, gEu, gEi, part, ticket, terms, w, n_terms, extra_in, c, total, T, extra_parts, n_extra_parts, extra_out); break;
-    case 64: hipLaunchKernelGGL((bpr_step_kernel<16>), dim3(nb), dim3(kBlock), 0, s, a, b, users, pos, neg, B, decay, batch_size, g_mf, g_emb, gEu, gEi, part, ticket, terms, w, n_terms, extra_in, c, total, T, extra_parts, n_extra_parts, extra_out); break;
-    case 128: hipLaunchKernelGGL((bpr_step_kernel<32>), dim3(nb), dim3(kBlock), 0, s, a, b, users, pos, neg, B, decay, batch_size, g_mf, g_emb, gEu, gEi, part, ticket, terms, w, n_terms, extra_in, c, total, T, extra_parts, n_extra_parts, extra_out); break;
-    case 256: hipLaunchKernelGGL((bpr_step_kernel<64>), dim3(nb), dim3(kBlock), 0, s, a, b, users, pos, neg, B, decay, batch_size, g_mf, g_emb, gEu, gEi, part, ticket, terms, w, n_terms, extra_in, c, total, T, extra_parts, n_extra_parts, extra_out); break;
+    case 32: hipLaunchKernelGGL((bpr_step_kernel<8>), dim3(A.n_blocks), dim3(kBlock), 0, s, A); break;
+    case 64: hipLaunchKernelGGL((bpr_step_kernel<16>), dim3(A.n_blocks), dim3(kBlock), 0, s, A); break;
+    case 128: hipLaunchKernelGGL((bpr_step_kernel<32>), dim3(A.n_blocks), dim3(kBlock), 0, s, A); break;
+    case 256: hipLaunchKernelGGL((bpr_step_kernel<64>), dim3(A.n_blocks), dim3(kBlock), 0, s, A); break;
   }
   MMSSL_LAUNCH_CHECK();
   return 0;

@@ -19,6 +19,7 @@
 //   gn2_t = (w_t/tau) n1_t - sum_s c_s b_st n1_s
 // followed by the F.normalize backward (incl. its g/eps branch for all-zero rows).
 #include "common.hpp"
+#include "bpr_step.hpp"
 
 using namespace mmssl;
 
@@ -605,7 +606,13 @@ __global__ __launch_bounds__(kBlock) void fwd_tiles_mfma_kernel(const float* __r
 // round-robin and add their g1/g2 tiles in a fixed order through LDS before one store per block.
 template <int D, bool SINGLE>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2))) void bwd_tiles_mfma_kernel(float* __restrict__ ws, size_t ws_stride, Layout L,
-                                                                int64_t n, float tau, int cs) {
+                                                                int64_t n, float tau, int cs, BprStepArgs bpr) {
+  // Guest blocks: the hot step's BPR tail (bpr_step.hpp) rides along behind the pair-tile blocks of problem 0 - nothing
+  // in it depends on this kernel, and as a launch of its own it would add its whole duration to the loss chain.
+  if (bpr.n_blocks > 0 && (int)blockIdx.x >= n_tiles(n) * cs) {
+    if (blockIdx.y == 0) bpr_step_block<D / 4>(bpr, (int)blockIdx.x - n_tiles(n) * cs);
+    return;
+  }
   float* __restrict__ wsp = ws + (size_t)blockIdx.y * ws_stride;
   const float* __restrict__ n1 = wsp + L.n1;
   const float* __restrict__ n2 = wsp + L.n2;
@@ -808,7 +815,7 @@ int infonce_fwd_impl(const float* const* z1s, const float* z2, const int64_t* id
 
 int infonce_bwd_impl(const int64_t* idx, int P, int64_t n, int d, float tau, const float* gloss,
                      float* const* gz1s, float* gz2, void* workspace, size_t workspace_bytes, void* stream,
-                     int phases = 3) {
+                     int phases = 3, const BprStepArgs* guest = nullptr) {
   if (P < 1 || P > kMaxProblems || n <= 0 || !gloss || !(tau > 0.f) || phases < 1 || phases > 3) return MMSSL_E_BADARG;
   if (!infonce_d_ok(d)) return MMSSL_E_UNSUPP;
   const Layout L = make_layout(n, d);
@@ -827,12 +834,17 @@ int infonce_bwd_impl(const int64_t* idx, int P, int64_t n, int d, float tau, con
   hipStream_t s = as_stream(stream);
   const int nt = n_tiles(n);
   const dim3 grid(nt * L.cs_b, P);
+  if (guest && !((phases & 1) && use_mfma(d))) return MMSSL_E_UNSUPP;
   if ((phases & 1) && use_mfma(d)) {
     const bool single = (nt + L.cs_b - 1) / L.cs_b <= 4;      // pair tiles per block <= waves per block
-    if (d == 32 && single) hipLaunchKernelGGL((bwd_tiles_mfma_kernel<32, true>), grid, dim3(kBlock), 0, s, ws, L.total, L, n, tau, L.cs_b);
-    else if (d == 32) hipLaunchKernelGGL((bwd_tiles_mfma_kernel<32, false>), grid, dim3(kBlock), 0, s, ws, L.total, L, n, tau, L.cs_b);
-    else if (single) hipLaunchKernelGGL((bwd_tiles_mfma_kernel<64, true>), grid, dim3(kBlock), 0, s, ws, L.total, L, n, tau, L.cs_b);
-    else hipLaunchKernelGGL((bwd_tiles_mfma_kernel<64, false>), grid, dim3(kBlock), 0, s, ws, L.total, L, n, tau, L.cs_b);
+    BprStepArgs G;
+    if (guest) G = *guest;
+    else G.n_blocks = 0;
+    const dim3 g2(nt * L.cs_b + (guest ? guest->n_blocks : 0), P);
+    if (d == 32 && single) hipLaunchKernelGGL((bwd_tiles_mfma_kernel<32, true>), g2, dim3(kBlock), 0, s, ws, L.total, L, n, tau, L.cs_b, G);
+    else if (d == 32) hipLaunchKernelGGL((bwd_tiles_mfma_kernel<32, false>), g2, dim3(kBlock), 0, s, ws, L.total, L, n, tau, L.cs_b, G);
+    else if (single) hipLaunchKernelGGL((bwd_tiles_mfma_kernel<64, true>), g2, dim3(kBlock), 0, s, ws, L.total, L, n, tau, L.cs_b, G);
+    else hipLaunchKernelGGL((bwd_tiles_mfma_kernel<64, false>), g2, dim3(kBlock), 0, s, ws, L.total, L, n, tau, L.cs_b, G);
     MMSSL_LAUNCH_CHECK();
   } else if (phases & 1) {
     switch (d) {
@@ -916,6 +928,27 @@ extern "C" int mmssl_infonce_multi_bwd_f32(const int64_t* idx, int n_problems, i
                                            const float* gloss, float* const* gz1s, float* gz2, void* workspace,
                                            size_t workspace_bytes, void* stream) {
   return infonce_bwd_impl(idx, n_problems, n, d, tau, gloss, gz1s, gz2, workspace, workspace_bytes, stream);
+}
+
+extern "C" size_t mmssl_bpr_workspace_bytes(int64_t B);
+
+extern "C" int mmssl_infonce_bwd_tiles_bpr_f32(const int64_t* idx, int n_problems, int64_t n, int d, float tau,
+                                               const float* gloss, float* const* gz1s, float* gz2, void* workspace,
+                                               size_t workspace_bytes, const float* Eu, const float* Ei,
+                                               const int64_t* users, const int64_t* pos, const int64_t* neg, int64_t B,
+                                               float decay, int64_t batch_size, const float* g_mf, const float* g_emb,
+                                               float* gEu, float* gEi, float* terms, const float* w, int n_terms,
+                                               const float* extra, float c, float* total, float* const* f32_ticks,
+                                               int n_f32, uint64_t* const* u64_ticks, int n_u64, void* bpr_workspace,
+                                               size_t bpr_workspace_bytes, int* ticket, const float* extra_parts,
+                                               int64_t n_extra_parts, void* stream) {
+  if (!infonce_d_ok(d) || !use_mfma(d)) return MMSSL_E_UNSUPP;
+  BprStepArgs A;
+  const int rc = make_bpr_step_args(A, Eu, Ei, users, pos, neg, B, d, decay, batch_size, g_mf, g_emb, gEu, gEi, terms, w,
+                                    n_terms, extra, c, total, f32_ticks, n_f32, u64_ticks, n_u64, bpr_workspace,
+                                    bpr_workspace_bytes, mmssl_bpr_workspace_bytes(B), ticket, extra_parts, n_extra_parts);
+  if (rc != 0) return rc;
+  return infonce_bwd_impl(idx, n_problems, n, d, tau, gloss, gz1s, gz2, workspace, workspace_bytes, stream, 1, &A);
 }
 
 extern "C" int mmssl_infonce_multi_bwd_phase_f32(const int64_t* idx, int n_problems, int64_t n, int d, float tau,

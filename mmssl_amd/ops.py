@@ -869,9 +869,6 @@ class _BatchLosses(torch.autograd.Function):
                                                            _ptr(ws1), nbw, _ptr(tickets), _lib.stream_ptr())
         _lib.check(rc, "mmssl_infonce_multi_fwd_ticket_f32")
         gz1s = (_ct.c_void_p * 2)(_ptr(g_img), _ptr(g_txt))
-        rc = _lib.lib().mmssl_infonce_multi_bwd_phase_f32(_ptr(users), 2, B, d, float(tau), _ptr(w[3:5]), gz1s, _ptr(g_ua),
-                                                          _ptr(ws1), ws1.numel() * 4, 3, _lib.stream_ptr())
-        _lib.check(rc, "mmssl_infonce_multi_bwd_phase_f32")
         f32s, u64s = ticks if ticks else ((), ())
         fa = (_ct.c_void_p * max(len(f32s), 1))(*[int(x) for x in f32s])
         ka = (_ct.c_void_p * max(len(u64s), 1))(*[int(x) for x in u64s])
@@ -880,6 +877,23 @@ class _BatchLosses(torch.autograd.Function):
         if last is not None and extra is not None and last[0].data_ptr() == extra.data_ptr():
             xparts, n_xparts = last[1], last[1].numel()       # `extra` is a forward's unreduced regulariser sum
             _DEFER_SS["last"] = None
+        if d <= 64 and _os.environ.get("MMSSL_BPR_GUEST", "1") == "1":
+            # the BPR tail as guest blocks of the InfoNCE backward pair-tile launch (it depends on nothing in it), then
+            # the InfoNCE finish: six launches, and the chain is shorter by the BPR tail's whole duration
+            rc = _lib.lib().mmssl_infonce_bwd_tiles_bpr_f32(
+                _ptr(users), 2, B, d, float(tau), _ptr(w[3:5]), gz1s, _ptr(g_ua), _ptr(ws1), ws1.numel() * 4,
+                _ptr(ua), _ptr(ia), _ptr(users), _ptr(pos), _ptr(neg), B, float(decay), int(batch_size), _ptr(w[0:1]),
+                _ptr(w[1:2]), _ptr(g_ua), _ptr(g_ia), _ptr(out), _ptr(w), 5, _ptr(extra), float(c), _ptr(total), fa,
+                len(f32s), ka, len(u64s), _ptr(wsb), nb, _ptr(tickets[2:]), _ptr(xparts), n_xparts, _lib.stream_ptr())
+            _lib.check(rc, "mmssl_infonce_bwd_tiles_bpr_f32")
+            rc = _lib.lib().mmssl_infonce_multi_bwd_phase_f32(_ptr(users), 2, B, d, float(tau), _ptr(w[3:5]), gz1s,
+                                                              _ptr(g_ua), _ptr(ws1), ws1.numel() * 4, 2, _lib.stream_ptr())
+            _lib.check(rc, "mmssl_infonce_multi_bwd_phase_f32")
+            ctx.eager = (g_ua, g_ia, g_img if ctx.needs_input_grad[2] else None, g_txt if ctx.needs_input_grad[3] else None)
+            return out
+        rc = _lib.lib().mmssl_infonce_multi_bwd_phase_f32(_ptr(users), 2, B, d, float(tau), _ptr(w[3:5]), gz1s, _ptr(g_ua),
+                                                          _ptr(ws1), ws1.numel() * 4, 3, _lib.stream_ptr())
+        _lib.check(rc, "mmssl_infonce_multi_bwd_phase_f32")
         rc = _lib.lib().mmssl_bpr_step_f32(_ptr(ua), _ptr(ia), _ptr(users), _ptr(pos), _ptr(neg), B, d, float(decay),
                                            int(batch_size), _ptr(w[0:1]), _ptr(w[1:2]), _ptr(g_ua), _ptr(g_ia), _ptr(out),
                                            _ptr(w), 5, _ptr(extra), float(c), _ptr(total), fa, len(f32s), ka, len(u64s),

@@ -217,6 +217,12 @@ int mmssl_layer_combine_f32(const float* const* layers, int n_layers, float inv,
 int mmssl_layer_combine_bwd_f32(const float* A, const float* B, const float* G, float r, float inv,
                                 const float* c_dev, float c_scale, int64_t rows, int d, float eps,
                                 float* gA, float* gB, float* gL, void* stream);
+/* Both sides of that backward (user tables: A0, B0, G0 ...; item tables: A1, B1, G1 ...) in ONE launch, each with the
+ * arithmetic of mmssl_layer_combine_bwd_f32 (bitwise the same results); gL0 / gL1 may be NULL. */
+int mmssl_layer_combine_bwd2_f32(const float* A0, const float* B0, const float* G0, int64_t rows0, float* gA0,
+                                 float* gB0, float* gL0, const float* A1, const float* B1, const float* G1,
+                                 int64_t rows1, float* gA1, float* gB1, float* gL1, float r, float inv,
+                                 const float* c_dev, float c_scale, int d, float eps, void* stream);
 /* out[0] = sum of `n` floats (fixed order, one block): second stage for the partials above. */
 int mmssl_sum_partials_f32(const float* part, int64_t n, float* out, void* stream);
 size_t mmssl_sumsq_workspace_bytes(int64_t n);

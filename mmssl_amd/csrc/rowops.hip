@@ -290,6 +290,82 @@ extern "C" int mmssl_layer_combine_f32(const float* const* layers, int n_layers,
   return 0;
 }
 
+namespace {
+struct CombineSide {
+  const float4* A;
+  const float4* B;
+  const float4* G;
+  float4* gA;
+  float4* gB;
+  float4* gL;
+  int64_t rows;
+  int blocks;
+};
+
+// both sides (user tables, item tables) of the fusion backward in ONE launch: blocks [0, S0.blocks) run side 0, the rest
+// side 1, each with the arithmetic (and the grid-stride order) of combine_bwd_kernel on its own grid
+template <int LPR>
+__global__ __launch_bounds__(kBlock) void combine_bwd2_kernel(CombineSide S0, CombineSide S1, float r, float inv,
+                                                              const float* __restrict__ c_dev, float c_scale, float eps) {
+  constexpr int GPB = kBlock / LPR;
+  const bool second = (int)blockIdx.x >= S0.blocks;
+  const CombineSide& S = second ? S1 : S0;
+  const int blk = second ? (int)blockIdx.x - S0.blocks : (int)blockIdx.x;
+  const int lig = threadIdx.x & (LPR - 1);
+  const int64_t stride = (int64_t)S.blocks * GPB;
+  const float c = c_dev ? c_scale * c_dev[0] : 0.f;
+  for (int64_t row = (int64_t)blk * GPB + threadIdx.x / LPR; row < S.rows; row += stride) {
+    const int64_t o = row * LPR + lig;
+    const float4 g = S.G[o];
+    if (S.gL) S.gL[o] = make_float4(inv * g.x, inv * g.y, inv * g.z, inv * g.w);
+#pragma unroll
+    for (int which = 0; which < 2; ++which) {
+      const float4 x = which ? S.B[o] : S.A[o];
+      const float ss = group_sum<LPR>(f4_dot(x, x));
+      const float xg = group_sum<LPR>(f4_dot(x, g));
+      const float norm = sqrtf(ss);
+      float a, b;                     // r*normalize_bwd = a*g - b*x
+      if (norm >= eps) {
+        a = r / norm;
+        b = r * xg / (norm * ss);
+      } else {
+        a = r / eps;
+        b = 0.f;
+      }
+      const float4 y = make_float4(a * g.x - (b - c) * x.x, a * g.y - (b - c) * x.y, a * g.z - (b - c) * x.z,
+                                   a * g.w - (b - c) * x.w);
+      (which ? S.gB : S.gA)[o] = y;
+    }
+  }
+}
+}  // namespace
+
+extern "C" int mmssl_layer_combine_bwd2_f32(const float* A0, const float* B0, const float* G0, int64_t rows0, float* gA0,
+                                            float* gB0, float* gL0, const float* A1, const float* B1, const float* G1,
+                                            int64_t rows1, float* gA1, float* gB1, float* gL1, float r, float inv,
+                                            const float* c_dev, float c_scale, int d, float eps, void* stream) {
+  if (rows0 <= 0 || rows1 <= 0 || !A0 || !B0 || !G0 || !gA0 || !gB0 || !A1 || !B1 || !G1 || !gA1 || !gB1)
+    return MMSSL_E_BADARG;
+  if (!supported_d(d)) return MMSSL_E_UNSUPP;
+  const int lpr = d / 4;
+  CombineSide S0{reinterpret_cast<const float4*>(A0), reinterpret_cast<const float4*>(B0),
+                 reinterpret_cast<const float4*>(G0), reinterpret_cast<float4*>(gA0), reinterpret_cast<float4*>(gB0),
+                 reinterpret_cast<float4*>(gL0), rows0, (int)row_grid(rows0, lpr)};
+  CombineSide S1{reinterpret_cast<const float4*>(A1), reinterpret_cast<const float4*>(B1),
+                 reinterpret_cast<const float4*>(G1), reinterpret_cast<float4*>(gA1), reinterpret_cast<float4*>(gB1),
+                 reinterpret_cast<float4*>(gL1), rows1, (int)row_grid(rows1, lpr)};
+  hipStream_t s = as_stream(stream);
+  const dim3 grid((unsigned)(S0.blocks + S1.blocks));
+  switch (d) {
+    case 32: hipLaunchKernelGGL((combine_bwd2_kernel<8>), grid, dim3(kBlock), 0, s, S0, S1, r, inv, c_dev, c_scale, eps); break;
+    case 64: hipLaunchKernelGGL((combine_bwd2_kernel<16>), grid, dim3(kBlock), 0, s, S0, S1, r, inv, c_dev, c_scale, eps); break;
+    case 128: hipLaunchKernelGGL((combine_bwd2_kernel<32>), grid, dim3(kBlock), 0, s, S0, S1, r, inv, c_dev, c_scale, eps); break;
+    case 256: hipLaunchKernelGGL((combine_bwd2_kernel<64>), grid, dim3(kBlock), 0, s, S0, S1, r, inv, c_dev, c_scale, eps); break;
+  }
+  MMSSL_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int mmssl_layer_combine_bwd_f32(const float* A, const float* B, const float* G, float r, float inv,
                                            const float* c_dev, float c_scale, int64_t rows, int d, float eps,
                                            float* gA, float* gB, float* gL, void* stream) {

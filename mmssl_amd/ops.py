@@ -1400,7 +1400,23 @@ class _HotForward(torch.autograd.Function):
             # but runs next to the weight-gradient GEMMs for longer and both stretch (wgrad 122 -> 174 us, SpMM 16 ->
             # 50-60 us): 0.640 vs 0.633 ms per Baby step, so the default keeps it after the exchange.
             chain_c()
-        if split:
+        if split and _os.environ.get("MMSSL_COMBINE2", "0") == "1":
+            # OPT-IN experiment: both sides in ONE launch on the current stream, then the forks (one launch and two
+            # cross-queue hops less than a launch per side on sA / sB with the exchange through the current stream).
+            # Measured 0.624 vs 0.568 ms per Baby step: the executor then starts all three chains later.
+            g_iu_, g_tu_, g_u0 = torch.empty_like(img_user), torch.empty_like(txt_user), torch.empty_like(img_user)
+            g_ii_, g_ti_ = torch.empty_like(img_item), torch.empty_like(txt_item)
+            rc = _lib.lib().mmssl_layer_combine_bwd2_f32(
+                _ptr(img_user), _ptr(txt_user), _ptr(Gu), img_user.shape[0], _ptr(g_iu_), _ptr(g_tu_), _ptr(g_u0),
+                _ptr(img_item), _ptr(txt_item), _ptr(Gi), img_item.shape[0], _ptr(g_ii_), _ptr(g_ti_), None,
+                float(r), float(inv), _ptr(g_ss), 2.0, img_user.shape[1], _NORM_EPS, _lib.stream_ptr())
+            _lib.check(rc, "mmssl_layer_combine_bwd2_f32")
+            for st in (sA, sB):
+                st.wait_stream(main)
+            for t, st in ((g_ii_, sA), (g_iu_, sA), (g_ti_, sB), (g_tu_, sB)):
+                if _os.environ.get("MMSSL_NO_RECORD_STREAM") != "1":
+                    t.record_stream(st)
+        elif split:
             with torch.cuda.stream(sA):
                 g_iu_, g_tu_, g_u0 = _combine_bwd(img_user, txt_user, Gu, r, inv, g_ss, 2.0, True)
             with torch.cuda.stream(sB):

@@ -94,6 +94,7 @@ class HotPathStep:
         # the forward leaves its regulariser sum unreduced; the loss tail reduces it (one launch less in front of the
         # loss chain). Only valid because the very next consumer of `ss` IS that tail.
         prev_ss = ops.defer_feat_sumsq(os.environ.get("MMSSL_DEFER_SS", "1") == "1")
+        ops._PREFILL["buf"] = None           # never inherit a buffer from a step that did not reach its loss section
         prev_pf = ops.prefill_loss_buffer((lambda nu, ni, d: (3 * nu + ni) * d + 4)
                                           if os.environ.get("MMSSL_PREFILL", "1") == "1" else None)
         try:

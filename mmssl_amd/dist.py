@@ -625,6 +625,8 @@ class ShardedHotPathStep:
         self.loss = torch.zeros((), device=dev)
         self._loss_w = None
         self._graph = None
+        # parity runs inject fixed uint8 dropout keep-masks (img, txt), each [per_items, d]; None = fresh Philox masks
+        self.keep_masks = None
         self.stream = torch.cuda.Stream(device=dev) if on_gpu else None
         if on_gpu:
             self.stream.wait_stream(torch.cuda.current_stream(dev))
@@ -684,7 +686,7 @@ class ShardedHotPathStep:
         return replicated, feat_local, False
 
     def backward(self, keep_masks=None):
-        first, feat_local, assembled = self.losses(keep_masks)
+        first, feat_local, assembled = self.losses(keep_masks if keep_masks is not None else self.keep_masks)
         for p in self.model.parameters():
             p.grad = None
         # assembled: `first` already is replicated + local regulariser (one kernel); else two autograd scalars

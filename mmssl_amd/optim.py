@@ -102,6 +102,16 @@ class FusedAdamW(torch.optim.Optimizer):
                                                 else torch.tensor(0.0))
         return sd
 
+    @torch.no_grad()
+    def reset_state(self):
+        """Zero the moments and the step counters IN PLACE (addresses stay valid for a captured hipGraph)."""
+        for st in self.state.values():
+            for v in st.values():
+                if torch.is_tensor(v):
+                    v.zero_()
+        for t in self._steps.values():
+            t.zero_()
+
     def step_counter(self, gi, device):
         """Device float[2] {completed steps, -} of param group `gi` (created on first use)."""
         return self._group_state(gi, device)

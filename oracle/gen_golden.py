@@ -14,6 +14,9 @@ Each fixture cites the reference call that produced it:
   G7  test_torch (Recall/NDCG/precision/hit @ Ks)       utility/batch_test.py:112-169
   G8  G-step loss assembly                              main.py:363-420
   G9  modal-graph maintenance inside Trainer.train()    main.py:378-405 (k = int(n_items*m_topk_rate) in {1, 2}, T in {1, 2})
+  G12 K-batch trajectory of Trainer.train() + evaluation  main.py:308-429 -> utility/batch_test.py:112-169
+      (python oracle/gen_golden.py g12: own process, discriminator dropout off so that every random draw of the loop
+       is one of the two recorded tensors)
 """
 import os
 import shutil
@@ -349,8 +352,148 @@ def gen_g9(ref, dg, n_batches=5):
     args.m_topk_rate, args.T, args.epoch = old
 
 
+def gen_g12(ref, dg, n_batches=8):
+    """G12: the reference's own Trainer.train() for `n_batches` batches (k = 1, T = 1: batches 0-1 on the interaction
+    graph, batch 2 on the B-edge top-1 graph, batch 3+ on empty modal graphs), then its own Trainer.test() on the
+    validation and test users. Recorded through wrappers (nothing of the loop is restated): the initial model /
+    discriminator parameters, every batch of Data.sample(), every random tensor the loop draws (the Gumbel uniforms of
+    main.py:350 and the gradient-penalty alpha of main.py:147; model dropout and discriminator dropout are 0, so these
+    are ALL draws), per-batch loss components, the final parameters, the eval-mode embeddings and the metric dict."""
+    args = ref.args
+    old = (args.m_topk_rate, args.T, args.epoch)
+    args.m_topk_rate, args.T, args.epoch = 0.011, 1, 1
+    ref.set_seed(2022)
+    tr = ref.Trainer(data_config={"n_users": dg.n_users, "n_items": dg.n_items})
+    skip = ("encoder.", "align.")
+    rec = {"n_batches": n_batches, "k": int(I * args.m_topk_rate), "T": 1, "m_topk_rate": args.m_topk_rate,
+           "lr": args.lr, "D_lr": args.D_lr, "G_rate": args.G_rate, "cl_rate": args.cl_rate, "gp_rate": args.gp_rate}
+    for k, v in tr.model.state_dict().items():
+        if not k.startswith(skip):
+            rec["m0." + k] = npy(v)
+    for k, v in tr.D.state_dict().items():
+        rec["D0." + k] = npy(v)
+    st = {"fwd": 0, "D": 0, "cl": 0, "uni": 0, "alpha": 0, "sample": 0, "on": False}
+    o_fwd, o_D, o_bpr, o_cl = tr.model.forward, tr.D.forward, tr.bpr_loss, tr.batched_contrastive_loss
+    o_feat, o_gp, o_sample = tr.feat_reg_loss_calculation, tr.gradient_penalty, dg.sample
+    o_uniform, o_rand = torch.Tensor.uniform_, torch.rand
+
+    def fwd(*graphs):
+        c = st["fwd"]
+        st["fwd"] += 1
+        if st["on"] and c % 2 == 0 and c // 2 >= n_batches:
+            raise _StopTraining()
+        return o_fwd(*graphs)
+
+    def D_fwd(x):
+        out = o_D(x)
+        if st["on"]:
+            b, j = divmod(st["D"], 4)         # D(inputf), D(inputr), D(interpolates) inside the penalty, D(G_inputf)
+            st["D"] += 1
+            rec["b%d.D%d_mean" % (b, j)] = np.float32(out.detach().mean().item())
+        return out
+
+    def bpr(u, p, n):
+        mf, emb, reg = o_bpr(u, p, n)
+        b = st["fwd"] // 2 - 1
+        rec["b%d.mf" % b], rec["b%d.emb" % b] = np.float32(mf.item()), np.float32(emb.item())
+        return mf, emb, reg
+
+    def cl(z1, z2):
+        out = o_cl(z1, z2)
+        b, j = divmod(st["cl"], 2)
+        st["cl"] += 1
+        rec["b%d.cl%d" % (b, j + 1)] = np.float32(out.item())
+        return out
+
+    def feat(a, b_, c, d):
+        out = o_feat(a, b_, c, d)
+        rec["b%d.feat" % (st["fwd"] // 2 - 1)] = np.float32(out.item())
+        return out
+
+    def gp(D, xr, xf):
+        out = o_gp(D, xr, xf)
+        rec["b%d.gp" % (st["fwd"] // 2)] = np.float32(out.item())
+        return out
+
+    def sample():
+        out = o_sample()
+        b = st["sample"]
+        st["sample"] += 1
+        if b < n_batches:
+            rec["b%d.users" % b] = np.array(out[0], np.int64)
+            rec["b%d.pos" % b] = np.array(out[1], np.int64)
+            rec["b%d.neg" % b] = np.array(out[2], np.int64)
+        return out
+
+    def uniform_(self, *a, **k):
+        out = o_uniform(self, *a, **k)
+        if st["on"]:
+            rec["b%d.gumbel_u" % st["uni"]] = npy(out).copy()
+            st["uni"] += 1
+        return out
+
+    def rand(*a, **k):
+        out = o_rand(*a, **k)
+        if st["on"]:
+            rec["b%d.gp_alpha" % st["alpha"]] = npy(out).copy()
+            st["alpha"] += 1
+        return out
+
+    tr.model.forward, tr.D.forward, tr.bpr_loss, tr.batched_contrastive_loss = fwd, D_fwd, bpr, cl
+    tr.feat_reg_loss_calculation, tr.gradient_penalty, dg.sample = feat, gp, sample
+    torch.Tensor.uniform_, torch.rand = uniform_, rand
+    st["on"] = True
+    try:
+        tr.train()
+    except _StopTraining:
+        pass
+    finally:
+        st["on"] = False
+        torch.Tensor.uniform_, torch.rand = o_uniform, o_rand
+        dg.sample = o_sample
+        tr.model.forward, tr.D.forward = o_fwd, o_D
+    assert st["uni"] == n_batches and st["alpha"] == n_batches and st["D"] == 4 * n_batches, st
+    for b in range(n_batches):
+        G_lossf = -float(rec["b%d.D3_mean" % b])
+        rec["b%d.G_lossf" % b] = np.float32(G_lossf)
+        rec["b%d.loss_D" % b] = np.float32(-float(rec["b%d.D1_mean" % b]) + float(rec["b%d.D0_mean" % b])
+                                           + args.gp_rate * float(rec["b%d.gp" % b]))
+        rec["b%d.batch_loss" % b] = np.float32(
+            float(rec["b%d.mf" % b]) + float(rec["b%d.emb" % b]) + float(rec["b%d.feat" % b])
+            + args.cl_rate * (float(rec["b%d.cl1" % b]) + float(rec["b%d.cl2" % b])) + args.G_rate * G_lossf)
+    for k, v in tr.model.state_dict().items():
+        if not k.startswith(skip) and not k.startswith(("image_embedding", "text_embedding")):
+            rec["m1." + k] = npy(v)
+    for k, v in tr.D.state_dict().items():
+        rec["D1." + k] = npy(v)
+    for nm, g in zip(("img_ui", "img_iu", "txt_ui", "txt_iu"),
+                     (tr.image_ui_graph, tr.image_iu_graph, tr.text_ui_graph, tr.text_iu_graph)):
+        rec["final.%s_nnz" % nm] = int(g._nnz())
+    tr.model.eval()
+    with torch.no_grad():
+        outs = tr.model(tr.ui_graph, tr.iu_graph, tr.image_ui_graph, tr.image_iu_graph, tr.text_ui_graph, tr.text_iu_graph)
+    rec["eval.ua"], rec["eval.ia"] = npy(outs[0]), npy(outs[1])
+    for is_val, nm in ((True, "val"), (False, "test")):
+        users = list((dg.val_set if is_val else dg.test_set).keys())
+        res = tr.test(users, is_val)
+        for k in ("precision", "recall", "ndcg", "hit_ratio"):
+            rec["%s.%s" % (nm, k)] = np.asarray(res[k], np.float64)
+        rec["%s.users" % nm] = np.array(users, np.int64)
+    np.savez_compressed(os.path.join(OUT, "g12_train_trajectory.npz"), **rec)
+    args.m_topk_rate, args.T, args.epoch = old
+    print("G12: batch losses", [float(rec["b%d.batch_loss" % b]) for b in range(n_batches)])
+    print("G12: val recall", rec["val.recall"], "test recall", rec["test.recall"])
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "g9":      # only (re)generate G9; same data set, same seeds
+    if len(sys.argv) > 1 and sys.argv[1] == "g12":     # own process: discriminator dropout must be 0 at import time
+        if os.path.isdir(TMP):
+            shutil.rmtree(TMP)
+        synth_data.write_dataset(TMP, "tiny", U, I, E, DV, DT, seed=1)
+        _ref = ref_shim.load(TMP, "tiny", ["--batch_size", str(B), "--drop_rate", "0.0", "--G_drop1", "0.0",
+                                           "--G_drop2", "0.0"])
+        gen_g12(_ref, _ref.data_generator)
+    elif len(sys.argv) > 1 and sys.argv[1] == "g9":      # only (re)generate G9; same data set, same seeds
         if os.path.isdir(TMP):
             shutil.rmtree(TMP)
         synth_data.write_dataset(TMP, "tiny", U, I, E, DV, DT, seed=1)

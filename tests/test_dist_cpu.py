@@ -152,13 +152,13 @@ def test_spawn_rank_probe(mode):
     assert r.returncode == 0, r.stderr[-2000:]
 
 
-def _graph_worker(rank, world, port, scaling, out_dir):
+def _graph_worker(rank, world, port, scaling, out_dir, workload="tiny"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import types
     from mmssl_amd import dist as md
-    a = types.SimpleNamespace(workload="tiny")
+    a = types.SimpleNamespace(workload=workload)
     ui_l, iu_l, ush, ish, U, I, E, dv, dt = md.build_sharded_graph(a, rank, world, torch.device("cpu"), scaling)
     torch.save({"ui": ui_l, "iu": iu_l, "U": U, "I": I, "E": E, "per": (ush.per, ish.per)},
                os.path.join(out_dir, "g%d.pt" % rank))
@@ -186,3 +186,27 @@ def test_sharded_graph_generation_is_one_consistent_global_graph(tmp_path, world
     assert abs(A_ui - ref_ui).max() < 1e-6 and abs(A_iu - ref_iu).max() < 1e-6
     if scaling == "weak":
         assert (U, I) == (600 * world, 400 * world)
+
+
+def test_baby_strong_scaling_partition_world8(tmp_path):
+    """BASELINE configs[3]: the Amazon-Baby graph itself cut 8 ways (`bench.py --gpus 8 --scaling strong`). The eight
+    row blocks reassemble to the one global graph, every rank holds ceil(n / 8) rows (the last one zero-padded), and
+    the column space is padded to a multiple of 8 (what the all-gathered tables have)."""
+    import scipy.sparse as sp
+    from mmssl_amd import synth
+    world = 8
+    port = _free_port()
+    mp.spawn(_graph_worker, args=(world, port, "strong", str(tmp_path), "baby"), nprocs=world, join=True)
+    outs = [torch.load(os.path.join(str(tmp_path), "g%d.pt" % r), weights_only=False) for r in range(world)]
+    U, I, E, _, _ = synth.SHAPES["baby"]
+    per_u, per_i = -(-U // world), -(-I // world)
+    for o in outs:
+        assert (o["U"], o["I"]) == (U, I) and o["per"] == (per_u, per_i)
+        assert o["ui"].shape == (per_u, per_i * world) and o["iu"].shape == (per_i, per_u * world)
+    raw = synth.interaction_matrix(U, I, E, seed=1)
+    ref_ui, ref_iu = synth.normalised_pair(raw)
+    A_ui = sp.vstack([o["ui"] for o in outs]).tocsr()
+    A_iu = sp.vstack([o["iu"] for o in outs]).tocsr()
+    assert A_ui[U:].nnz == 0 and A_ui[:, I:].nnz == 0 and A_iu[I:].nnz == 0 and A_iu[:, U:].nnz == 0     # padding is empty
+    assert (A_ui[:U, :I] != ref_ui).nnz == 0 and (A_iu[:I, :U] != ref_iu).nnz == 0                          # bit-identical values
+    assert outs[0]["E"] == raw.nnz == sum(o["ui"].nnz for o in outs) == sum(o["iu"].nnz for o in outs)

@@ -122,6 +122,7 @@ int mmssl_plan_fill_host(const int32_t* rowptr, int32_t rows, int32_t* group_ite
  * chain (Models.py:199-214: layer mean + last-layer softmax) consist of SpMM launches alone */
 #define MMSSL_EPI_AXPY             2  /* Y = A.X + alpha * Z[row]                               */
 #define MMSSL_EPI_AXPY_SOFTMAX_BWD 3  /* t = A.X + alpha * Z[row]; Y = S[row] * (t - <t, S[row]>)  (softmax bwd) */
+#define MMSSL_EPI_MASK             4  /* Y = keep ? A.X * scale : 0  (mmssl_spmm_mask_f32 only)                  */
 
 /* ---- batch rows of the interaction pattern (SURVEY.md 8f "next #1") --------------------------------
  * The reference builds `torch.tensor(self.ui_graph_raw[users].todense()).cuda()` — a dense
@@ -186,6 +187,13 @@ int mmssl_spmm_f32(const mmssl_graph* g, int transpose, const float* X, int d, f
 int mmssl_spmm_ex_f32(const mmssl_graph* g, int transpose, const float* X, int d, float* Y,
                       int epilogue, const float* Z, float alpha, const float* S, void* workspace,
                       size_t workspace_bytes, void* stream);
+/* Y = keep ? (op(A).X) * scale : 0 — the dropout backward of the modality projection (nn.Dropout, Models.py:54,
+ * 173-174) fused into the SpMM that produces the projection's output gradient (autograd of Models.py:177, 182).
+ * Y [R, d] packs d / dm modalities of dm features side by side; keep is the uint8 [d / dm, R, dm] mask layout of
+ * mmssl_proj_fwd_f32. */
+int mmssl_spmm_mask_f32(const mmssl_graph* g, int transpose, const float* X, int d, float* Y,
+                        const uint8_t* keep, int dm, float scale, void* workspace, size_t workspace_bytes,
+                        void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Row kernels
@@ -225,6 +233,23 @@ int mmssl_layer_combine_bwd2_f32(const float* A0, const float* B0, const float* 
                                  const float* c_dev, float c_scale, int d, float eps, void* stream);
 /* out[0] = sum of `n` floats (fixed order, one block): second stage for the partials above. */
 int mmssl_sum_partials_f32(const float* part, int64_t n, float* out, void* stream);
+/* Layer mean + modality fusion over PACKED modal features (Models.py:213-218 for a modality list), up to two SIDES
+ * (user tables, item tables) in one launch:
+ *   out[k][row, :] = inv * sum_l layers[k][l][row, :] + r * sum_m normalize(Mod[k][row, m d : (m+1) d])
+ * Mod[k] [rows[k], nm * d] holds the nm modal feature tables side by side (the output layout of the d * nm modal SpMM
+ * chains); sumsq_part[k] (mmssl_fuse_blocks(rows[k], d, nm) entries; the array or an entry may be NULL) receives the
+ * blocks' shares of sum |Mod[k]|^2 — the feature regulariser of main.py:252-257 — in a fixed order.
+ * nm in {1, 2, 4}, d in {32, 64, 128, 256}, nm * d <= 256.
+ *   backward: gMod[k][row, m-th slice] = r * normalize_bwd(Mod_m, G[k]) + (c_scale * c_dev[0]) * Mod_m
+ *   (+ Gx[k][row, m-th slice] when given: gradients that arrive on the modal features themselves), gL[k] = inv * G[k]
+ *   (the arrays Gx / gL or their entries may be NULL). */
+int mmssl_fuse_blocks(int64_t rows, int d, int nm);
+int mmssl_fuse_fwd_f32(int sides, const float* const* const* layers, int n_layers, float inv,
+                       const float* const* Mod, int nm, float r, const int64_t* rows, int d, float eps,
+                       float* const* out, float* const* sumsq_part, void* stream);
+int mmssl_fuse_bwd_f32(int sides, const float* const* Mod, int nm, const float* const* G, const float* const* Gx,
+                       float r, float inv, const float* c_dev, float c_scale, const int64_t* rows, int d, float eps,
+                       float* const* gMod, float* const* gL, void* stream);
 size_t mmssl_sumsq_workspace_bytes(int64_t n);
 int mmssl_sumsq_f32(const float* X, int64_t n, float* out, void* workspace,
                     size_t workspace_bytes, void* stream);
@@ -293,6 +318,32 @@ int mmssl_split_transpose_bf16_f32(const float* G, const uint8_t* keep, float sc
 size_t mmssl_transpose_mask_workspace_bytes(int64_t Mp, int N);
 int mmssl_transpose_mask_f32(const float* G, const uint8_t* keep, float scale, int64_t M, int N, int64_t Mp,
                              float* T, float* colsum, void* workspace, size_t workspace_bytes, void* stream);
+/* ------------------------------------------------------------------------------------
+ * Grouped modality projection: ALL modality problems of one step in one stream-K launch (csrc/projection.hip).
+ *   image_trans / text_trans (+ further modalities) + nn.Dropout and their autograd, Models.py:28-29, 54, 173-174,
+ *   for the whole modality list at once. Every problem g has the same M (items) and N == 64 channels:
+ *     forward  Y[m, 64 g + n] = dropout(F_g[M, K_g] . W_g[64, K_g]^T + b_g)      Y is [M, ldy], ldy >= 64 n_prob
+ *              (the modalities side by side: the layout the d = 64 n_prob modal SpMM chains consume); K_g % 32 == 0.
+ *              Dropout: `keep` = given uint8 masks [n_prob, M, 64] (1 = keep), OR `keep_out` + `rng_state` + p_drop:
+ *              the masks are drawn in the epilogue with the generator of mmssl_dropout_mask_u8 (same bytes as ONE
+ *              mmssl_dropout_mask_u8 launch over n_prob * M * 64 elements with the same state) and written to keep_out
+ *              for the backward; the caller advances rng_state[1] (mmssl_dropout_mask_ex_u8's external-tick contract).
+ *              keep == keep_out == NULL: no dropout. Kept entries are scaled by `scale`.
+ *     wgrad    gW_g[64, K_g] = G[:, 64 g : 64 g + 64]^T . F_g,  gb_g[64] = column sums of that slice of G; G [M, ldg] is
+ *              the ALREADY dropout-masked output gradient (mmssl_spmm_ex_f32's MMSSL_EPI_MASK epilogue); K_g % 4 == 0.
+ *   mmssl_proj_supported: 1 if the shape runs here (else use mmssl_linear_f32 / mmssl_linear_wgrad_f32 per problem).
+ *   fp32 MFMA (v_mfma_f32_32x32x2_f32), exact fp32, deterministic (fixed-order partial sums).
+ * ---------------------------------------------------------------------------------- */
+#define MMSSL_PROJ_MAX_PROBLEMS 4
+int mmssl_proj_supported(int n_prob, const int* K, int64_t M, int N, int wgrad);
+size_t mmssl_proj_workspace_bytes(int n_prob, const int* K, int64_t M, int N, int wgrad);
+int mmssl_proj_fwd_f32(int n_prob, const float* const* F, const float* const* W, const float* const* bias,
+                       const int* K, int64_t M, int N, const uint8_t* keep, uint8_t* keep_out,
+                       const uint64_t* rng_state, float p_drop, float scale, float* Y, int64_t ldy,
+                       void* workspace, size_t workspace_bytes, void* stream);
+int mmssl_proj_wgrad_f32(int n_prob, const float* G, int64_t ldg, const float* const* F, const int* K, int64_t M,
+                         int N, float* const* gW, float* const* gb, void* workspace, size_t workspace_bytes,
+                         void* stream);
 size_t mmssl_linear_wgrad_workspace_bytes(int64_t M, int K, int N);
 /* 1 when mmssl_linear_wgrad_f32 will run this shape on the register-direct kernel, which applies keep/scale and
  * sums the bias gradient on the fragments it loads (pass `keep`; no separate dropout-backward pass is needed);
@@ -361,6 +412,9 @@ int mmssl_adamw_sliced_f32(float* const* params, const float* const* grads, floa
                            float beta2, float eps, float weight_decay, int external_tick, void* stream);
 int mmssl_dropout_mask_ex_u8(uint64_t* rng_state, float p, int64_t n, uint8_t* keep, int external_tick,
                              void* stream);
+/* counter[0] += 1 on the stream: advances a generator's launch counter (rng_state + 1) when the masks were drawn inside
+ * another kernel (mmssl_proj_fwd_f32's epilogue) or with external_tick set. */
+int mmssl_tick_u64(uint64_t* counter, void* stream);
 /* Backward of the above: gterms[k] = g[0] * w[k], gextra[0] = g[0] * c (gextra may be NULL). */
 int mmssl_loss_assemble_bwd_f32(const float* g, const float* w, int n, float c, float* gterms,
                                 float* gextra, void* stream);

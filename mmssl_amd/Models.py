@@ -206,46 +206,54 @@ class MMSSL(nn.Module):
         return tuple(out)
 
     # ---- forward -----------------------------------------------------------------------------
+    def hot_ctx(self):
+        """The hotnode.HotCtx (side streams + hand-offs) of plain model(...) calls; a step object passes its own."""
+        dev = self.user_id_embedding.weight.device
+        c = getattr(self, "_hot_ctx", None)
+        if c is None or c.device != dev:
+            from .hotnode import HotCtx
+            c = self._hot_ctx = HotCtx(dev)
+        return c
+
     def forward(self, ui_graph, iu_graph, image_ui_graph, image_iu_graph, text_ui_graph, text_iu_graph,
-                keep_masks=None, extra_graphs=None):
-        """Returns the 12-tuple of Models.py:220. `keep_masks=(img, txt)` injects uint8 dropout
-        keep-masks [n_items, d] (parity runs); by default both masks are drawn by one Philox launch
-        (ops.dropout_masks; seed with ops.seed_dropout / main.set_seed) in training mode.
-        With extra modalities (ctor `extra_feats`) the tuple is followed by (item_feats, user_feats, user_id,
-        item_id) of each extra modality; `extra_graphs` = {name: (ui_graph, iu_graph)} are their modal graphs
-        (default: the interaction graphs, like the reference's initial image / text graphs, main.py:69-72)."""
+                keep_masks=None, extra_graphs=None, hot=None):
+        """Returns the 12-tuple of Models.py:220. `keep_masks` injects uint8 dropout keep-masks (parity runs): a pair
+        (img, txt) of [n_items, d] tensors or one [2, n_items, d] tensor; by default the masks are drawn inside the
+        projection's epilogue by the generator of ops.dropout_masks (seed with ops.seed_dropout / main.set_seed) in
+        training mode. With extra modalities (ctor `extra_feats`) the tuple is followed by (item_feats, user_feats,
+        user_id, item_id) of each extra modality; `extra_graphs` = {name: (ui_graph, iu_graph)} are their modal graphs
+        (default: the interaction graphs, like the reference's initial image / text graphs, main.py:69-72).
+        `hot`: the hotnode.HotCtx of a step object that owns the whole step (default: this model's own)."""
+        from . import hotnode
         ui, iu = _plan_of(ui_graph), _plan_of(iu_graph)
-        if self.extra_names:
+        d = args.embed_size
+        packed = hotnode.packed_supported([self.image_feats.shape[1], self.text_feats.shape[1]], self.n_items, d)
+        if self.extra_names or not packed:
+            # the modality LIST out of differentiable HIP ops (a third modality, or shapes the packed node does not take)
             modal = [(_plan_of(image_ui_graph).twin(3), _plan_of(image_iu_graph).twin(3)),
                      (_plan_of(text_ui_graph).twin(3), _plan_of(text_iu_graph).twin(3))]
             for nm in self.extra_names:
                 g = (extra_graphs or {}).get(nm, (ui_graph, iu_graph))
                 modal.append((_plan_of(g[0]).twin(3), _plan_of(g[1]).twin(3)))
             return self._forward_multi(ui, iu, modal, keep_masks)
+        hot = hot if hot is not None else self.hot_ctx()
         img_ui, img_iu = _plan_of(image_ui_graph), _plan_of(image_iu_graph)
         txt_ui, txt_iu = _plan_of(text_ui_graph), _plan_of(text_iu_graph)
-        # The modal-id SpMMs (and their autograd backward) run on the caller's stream while ops.hot_forward's
-        # chains may still be running on its side streams (deferred wgrad join, hotpath.HotPathStep). A caller
-        # may pass the SAME plan as ui_graph and image_ui_graph (Trainer's initial state, main.py:69-72): give
-        # the modal launches their own partial-sum workspace + arrival counters (lanes 0-2 belong to hot_forward).
+        # The modal-id SpMMs (and their autograd backward) run on the caller's stream while the hot node's chains may
+        # still be running on its side streams (deferred join, hotpath.HotPathStep). A caller may pass the SAME plan as
+        # ui_graph and image_ui_graph (Trainer's initial state, main.py:69-72): give the modal launches their own
+        # partial-sum workspace + arrival counters (lanes 0 and 2 belong to the hot node).
         img_ui, img_iu, txt_ui, txt_iu = img_ui.twin(3), img_iu.twin(3), txt_ui.twin(3), txt_iu.twin(3)
         p = float(args.drop_rate)
-        km_img = km_txt = None
-        scale = 1.0
+        keep, scale, p_draw = None, 1.0, 0.0
         if self.training and p > 0.0:
             scale = 1.0 / (1.0 - p)
-            if keep_masks is not None:
-                km_img, km_txt = keep_masks
+            if keep_masks is None:
+                p_draw = p
+            elif torch.is_tensor(keep_masks):
+                keep = keep_masks.contiguous()
             else:
-                km_img, km_txt = ops.dropout_masks(2, self.n_items, args.embed_size, p,
-                                                   self.image_trans.weight.device)              # 1 = keep
-        if self.training and (ops.wgrad_ft_enabled() or ops.fwd_ft_enabled()) and torch.is_grad_enabled():
-            # weight gradients of the projections run on the forward kernel against F^T (built once)
-            ops.register_transposed_features(self.image_feats)
-            ops.register_transposed_features(self.text_feats)
-        if ops.split_projection_enabled():       # opt-in split-precision projection (MMSSL_GEMM_SPLIT=1)
-            ops.register_split_features(self.image_feats)
-            ops.register_split_features(self.text_feats)
+                keep = torch.stack(tuple(keep_masks)).contiguous()
         E_u, E_i = self.user_id_embedding.weight, self.item_id_embedding.weight
         # the reference repeats this block args.layers times without feeding anything back
         # (Models.py:176-186): the result is that of one pass.
@@ -258,14 +266,14 @@ class MMSSL(nn.Module):
         items_empty = img_iu.nnz == 0 and txt_iu.nnz == 0
         if users_empty:
             image_user_id = text_user_id = self._zeros(self.n_users, E_u)
-            u = ops.zero_grad_anchor(E_u, wcat)
+            u = ops.zero_grad_anchor(E_u, wcat, hot)
         else:
             image_user_id = ops.spmm(img_ui, E_i)
             text_user_id = ops.spmm(txt_ui, E_i)
             u = ops.l2norm_rows(self._modality_fusion(image_user_id, text_user_id), E_u, args.id_cat_rate)
         if items_empty:
             image_item_id = text_item_id = self._zeros(self.n_items, E_i)
-            i = E_i if users_empty else ops.zero_grad_anchor(E_i, wcat)    # one anchor is enough
+            i = E_i if users_empty else ops.zero_grad_anchor(E_i, wcat, hot)    # one anchor is enough
         else:
             image_item_id = ops.spmm(img_iu, E_u)
             text_item_id = ops.spmm(txt_iu, E_u)
@@ -275,13 +283,16 @@ class MMSSL(nn.Module):
         self.embedding_dict["item"]["image"] = image_item_id
         self.embedding_dict["item"]["text"] = text_item_id
 
-        # projection, modal SpMM chains, G-layer propagation, layer mean and "+ rate * normalize(modal
-        # feats)" as one fused node on three forked streams; its by-product `ss` is the feature
-        # regulariser's sum of squares (main.py:252-257)
-        (u_g, i_g, ss, image_item_feats, text_item_feats, image_user_feats, text_user_feats) = ops.hot_forward(
-            self.image_feats, self.image_trans.weight, self.image_trans.bias, km_img,
-            self.text_feats, self.text_trans.weight, self.text_trans.bias, km_txt, scale,
+        # projection of both modalities (one grouped launch), packed modal SpMM chain, G-layer propagation, layer mean
+        # and "+ rate * normalize(modal feats)" as one fused node on two forked streams; its by-product `ss` is the
+        # feature regulariser's sum of squares (main.py:252-257)
+        lins = (self.image_trans, self.text_trans)
+        u_g, i_g, ss, MI, MU = hotnode.hot_node(
+            hot, (self.image_feats, self.text_feats), [l.weight for l in lins], [l.bias for l in lins], keep, p_draw, scale,
             u, i, ui, iu, self.n_ui_layers, args.model_cat_rate)
+        # the reference's four modal feature outputs are column slices of the packed tables
+        image_item_feats, text_item_feats = MI[:, :d], MI[:, d:2 * d]
+        image_user_feats, text_user_feats = MU[:, :d], MU[:, d:2 * d]
         self._feat_sumsq = (ss, (image_item_feats, text_item_feats, image_user_feats, text_user_feats))
         return (u_g, i_g, image_item_feats, text_item_feats, image_user_feats, text_user_feats, u_g, i_g,
                 image_user_id, text_user_id, image_item_id, text_item_id)

@@ -14,7 +14,8 @@ import torch  # noqa: F401
 from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmmssl_hip.so")
+# MMSSL_LIB: another build of the same library (tools/ decomposition builds only; tests and bench never set it)
+LIB_PATH = os.environ.get("MMSSL_LIB") or os.path.join(_HERE, "libmmssl_hip.so")
 
 _i32p = POINTER(c_int32)
 _i64p = POINTER(c_int64)
@@ -66,6 +67,13 @@ SIGNATURES = {
     "mmssl_softmax_rows_bwd_f32": (c_int, [c_void_p, c_void_p, c_float, c_int64, c_int, c_void_p, c_void_p]),
     "mmssl_spmm_ex_f32": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_float, c_void_p,
                                   c_void_p, c_size_t, c_void_p]),
+    "mmssl_spmm_mask_f32": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_float, c_void_p, c_size_t,
+                                    c_void_p]),
+    "mmssl_fuse_blocks": (c_int, [c_int64, c_int, c_int]),
+    "mmssl_fuse_fwd_f32": (c_int, [c_int, c_void_p, c_int, c_float, c_void_p, c_int, c_float, c_void_p, c_int, c_float,
+                                   c_void_p, c_void_p, c_void_p]),
+    "mmssl_fuse_bwd_f32": (c_int, [c_int, c_void_p, c_int, c_void_p, c_void_p, c_float, c_float, c_void_p, c_float, c_void_p,
+                                   c_int, c_float, c_void_p, c_void_p, c_void_p]),
     "mmssl_layer_combine_blocks": (c_int, [c_int64, c_int]),
     "mmssl_layer_combine_f32": (c_int, [c_void_p, c_int, c_float, c_void_p, c_void_p, c_float, c_int64, c_int,
                                         c_float, c_void_p, c_void_p, c_void_p]),
@@ -87,6 +95,12 @@ SIGNATURES = {
     "mmssl_transpose_mask_workspace_bytes": (c_size_t, [c_int64, c_int]),
     "mmssl_transpose_mask_f32": (c_int, [c_void_p, c_void_p, c_float, c_int64, c_int, c_int64, c_void_p, c_void_p,
                                          c_void_p, c_size_t, c_void_p]),
+    "mmssl_proj_supported": (c_int, [c_int, c_void_p, c_int64, c_int, c_int]),
+    "mmssl_proj_workspace_bytes": (c_size_t, [c_int, c_void_p, c_int64, c_int, c_int]),
+    "mmssl_proj_fwd_f32": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p,
+                                   c_void_p, c_float, c_float, c_void_p, c_int64, c_void_p, c_size_t, c_void_p]),
+    "mmssl_proj_wgrad_f32": (c_int, [c_int, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p,
+                                     c_void_p, c_size_t, c_void_p]),
     "mmssl_linear_wgrad_workspace_bytes": (c_size_t, [c_int64, c_int, c_int]),
     "mmssl_linear_ticket_count": (c_int64, [c_int64, c_int, c_int]),
     "mmssl_linear_tk_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int64, c_int, c_int, c_void_p,
@@ -112,6 +126,7 @@ SIGNATURES = {
     "mmssl_adamw_ex_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_float, c_float,
                                    c_float, c_float, c_float, c_int, c_void_p]),
     "mmssl_dropout_mask_ex_u8": (c_int, [c_void_p, c_float, c_int64, c_void_p, c_int, c_void_p]),
+    "mmssl_tick_u64": (c_int, [c_void_p, c_void_p]),
     "mmssl_loss_assemble_bwd_f32": (c_int, [c_void_p, c_void_p, c_int, c_float, c_void_p, c_void_p, c_void_p]),
     "mmssl_loss_assemble_f32": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_float, c_void_p, c_void_p]),
     "mmssl_infonce_workspace_bytes": (c_size_t, [c_int64, c_int]),

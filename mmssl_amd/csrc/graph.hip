@@ -378,15 +378,30 @@ __device__ __forceinline__ float4 row_softmax(float4 a) {
 //   SOFTMAX           y = softmax(acc)                                   (last GCN layer, fwd)
 //   AXPY              y = acc + alpha * Z[row]                           (bwd: + layer-mean grad)
 //   AXPY_SOFTMAX_BWD  t = acc + alpha * Z[row];  y = S[row] * (t - <t, S[row]>)   (bwd through softmax)
+//   MASK              y = keep[m][row][c] ? acc * alpha : 0   (dropout backward fused into the SpMM that produces the
+//                     projection's output gradient; Y packs nm modalities of dm features side by side: column
+//                     m * dm + c of row `row` reads keep[(m * rows + row) * dm + c], the [nm, rows, dm] mask layout)
 struct EpiArgs {
   const float4* Z;
   const float4* S;
   float alpha;
+  const uint8_t* keep;
+  int dm;
+  int64_t rows;
 };
 
 template <int LPR, int EPI>
 __device__ __forceinline__ float4 apply_epilogue(float4 acc, int row, int lig, const EpiArgs& e) {
   if (EPI == MMSSL_EPI_SOFTMAX) return row_softmax<LPR>(acc);
+  if (EPI == MMSSL_EPI_MASK) {
+    const int col = 4 * lig, m = col / e.dm;
+    const uint32_t k4 = *reinterpret_cast<const uint32_t*>(e.keep + ((int64_t)m * e.rows + row) * e.dm + (col - m * e.dm));
+    acc.x = (k4 & 0x000000ffu) ? acc.x * e.alpha : 0.f;
+    acc.y = (k4 & 0x0000ff00u) ? acc.y * e.alpha : 0.f;
+    acc.z = (k4 & 0x00ff0000u) ? acc.z * e.alpha : 0.f;
+    acc.w = (k4 & 0xff000000u) ? acc.w * e.alpha : 0.f;
+    return acc;
+  }
   if (EPI == MMSSL_EPI_AXPY || EPI == MMSSL_EPI_AXPY_SOFTMAX_BWD) {
     const float4 z = e.Z[(size_t)row * LPR + lig];
     acc.x = fmaf(e.alpha, z.x, acc.x);
@@ -613,6 +628,7 @@ int dispatch_epi(const DirPlan& p, const float* X, float* Y, float* partials, in
     case MMSSL_EPI_SOFTMAX: return launch_spmm<LPR, MMSSL_EPI_SOFTMAX>(p, X, Y, partials, e, s);
     case MMSSL_EPI_AXPY: return launch_spmm<LPR, MMSSL_EPI_AXPY>(p, X, Y, partials, e, s);
     case MMSSL_EPI_AXPY_SOFTMAX_BWD: return launch_spmm<LPR, MMSSL_EPI_AXPY_SOFTMAX_BWD>(p, X, Y, partials, e, s);
+    case MMSSL_EPI_MASK: return launch_spmm<LPR, MMSSL_EPI_MASK>(p, X, Y, partials, e, s);
   }
   return MMSSL_E_BADARG;
 }
@@ -625,9 +641,28 @@ extern "C" size_t mmssl_spmm_workspace_bytes(const mmssl_graph* g, int transpose
   return p.n_slots > 0 ? ws_total_bytes(p, d) : 0;
 }
 
+static int spmm_impl(const mmssl_graph* g, int transpose, const float* X, int d, float* Y, int epilogue, const float* Z,
+                     float alpha, const float* S, const uint8_t* keep, int dm, void* workspace, size_t workspace_bytes,
+                     void* stream);
+
 extern "C" int mmssl_spmm_ex_f32(const mmssl_graph* g, int transpose, const float* X, int d, float* Y,
                                  int epilogue, const float* Z, float alpha, const float* S, void* workspace,
                                  size_t workspace_bytes, void* stream) {
+  if (epilogue == MMSSL_EPI_MASK) return MMSSL_E_BADARG;          // has its own entry point (needs the mask geometry)
+  return spmm_impl(g, transpose, X, d, Y, epilogue, Z, alpha, S, nullptr, 0, workspace, workspace_bytes, stream);
+}
+
+extern "C" int mmssl_spmm_mask_f32(const mmssl_graph* g, int transpose, const float* X, int d, float* Y,
+                                   const uint8_t* keep, int dm, float scale, void* workspace, size_t workspace_bytes,
+                                   void* stream) {
+  if (!keep || dm < 4 || (dm & 3) || d % dm != 0 || ((uintptr_t)keep & 3)) return MMSSL_E_BADARG;
+  return spmm_impl(g, transpose, X, d, Y, MMSSL_EPI_MASK, nullptr, scale, nullptr, keep, dm, workspace, workspace_bytes,
+                   stream);
+}
+
+static int spmm_impl(const mmssl_graph* g, int transpose, const float* X, int d, float* Y, int epilogue, const float* Z,
+                     float alpha, const float* S, const uint8_t* keep, int dm, void* workspace, size_t workspace_bytes,
+                     void* stream) {
   if (!g || !Y) return MMSSL_E_BADARG;
   if (!supported_d(d)) return MMSSL_E_UNSUPP;
   const DirPlan& p = transpose ? g->bwd : g->fwd;
@@ -644,6 +679,9 @@ extern "C" int mmssl_spmm_ex_f32(const mmssl_graph* g, int transpose, const floa
   e.Z = reinterpret_cast<const float4*>(Z);
   e.S = reinterpret_cast<const float4*>(S);
   e.alpha = alpha;
+  e.keep = keep;
+  e.dm = dm > 0 ? dm : d;
+  e.rows = p.rows;
   switch (d) {
     case 32: return dispatch_epi<8>(p, X, Y, ws, epilogue, e, s);
     case 64: return dispatch_epi<16>(p, X, Y, ws, epilogue, e, s);

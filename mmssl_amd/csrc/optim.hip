@@ -104,7 +104,8 @@ __global__ __launch_bounds__(kBlock) void adamw_kernel(AdamTensors T, const floa
   // same operation order as torch's _single_tensor_adamw / fused kernel in fp32
   __shared__ float sh[2];
   if (threadIdx.x == 0) {
-    const float step = pre_ticked ? state[0] : state[0] + 1.0f;
+    // pre-ticked with a counter nobody advanced would make the bias corrections divide by zero: treat it as step 1
+    const float step = pre_ticked ? fmaxf(state[0], 1.0f) : state[0] + 1.0f;
     sh[0] = lr / (1.0f - powf(beta1, step));
     sh[1] = sqrtf(1.0f - powf(beta2, step));
   }
@@ -235,6 +236,13 @@ extern "C" int mmssl_dropout_mask_ex_u8(uint64_t* rng_state, float p, int64_t n,
     hipLaunchKernelGGL(tick_u64_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, rng_state + 1);
     MMSSL_LAUNCH_CHECK();
   }
+  return 0;
+}
+
+extern "C" int mmssl_tick_u64(uint64_t* counter, void* stream) {
+  if (!counter || (reinterpret_cast<uintptr_t>(counter) & 7)) return MMSSL_E_BADARG;
+  hipLaunchKernelGGL(tick_u64_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, counter);
+  MMSSL_LAUNCH_CHECK();
   return 0;
 }
 

@@ -1,0 +1,694 @@
+// Grouped modality projection for gfx950 (MI355X): ALL modality problems of one step in ONE stream-K launch,
+// forward and weight gradient (fp32 MFMA, exact fp32).
+//
+// Replaces nn.Linear image_trans / text_trans (+ nn.Dropout) and their autograd for the whole modality list at once
+// (/root/reference/MMSSL/Models.py:28-29, 54, 173-174):
+//
+//   forward  Y[:, 64g:64g+64] = dropout(F_g[M,K_g] . W_g[64,K_g]^T + b_g)        g = 0 .. n_prob-1
+//   wgrad    gW_g[64,K_g] = G[:, 64g:64g+64]^T . F_g[M,K_g],  gb_g = column sums of G[:, 64g:64g+64]
+//            (G = the already dropout-masked output gradient: the producing SpMM applies the mask in its epilogue)
+//
+// Why these kernels (profiles/r03_gemm_pmc_default.txt, r03_proj_ablation.txt): the 64x64-tile kernels of
+// csrc/linear.hip re-read the SMALL operand (W, 1 MB; gY, 4.7 MB) once per 64 rows / 64 columns of the big one —
+// 287 MB of L2->LDS traffic next to the 301 MB of F itself — and run the two modality problems as two launches that
+// stretch each other. Here a block owns a 256 x 64 output tile (8 waves), so the small operand is re-read 4x less,
+// and every problem shares one launch: the (tile, 32-deep slice) units of all problems lie on one axis that is cut
+// into as many equal ranges as there are CUs — one balanced tail, no second GEMM next to the first.
+//
+// Pipeline (one 512-thread block per CU, two waves per SIMD): a 3-stage LDS ring of 40 KB slices (256 x 32 of the long
+// operand, 64 x 32 of the short one) filled by LDS-DMA three slices ahead, one raw s_barrier per slice, and the step's
+// DMA issue and fragment reads slotted BETWEEN the MFMAs (one scheduling region per quarter of a slice): issued up
+// front they would leave the matrix pipe idle for their whole issue time, because the two waves of a SIMD pass the
+// barrier together.
+//   forward  row-major images F[i][k], W[j][k]: XOR-swizzled 128-B rows, ds_read_b128 fragments, v_mfma_f32_32x32x2,
+//            wave w = rows 32w..32w+31 x 64 columns (two accumulators); a wave DMAs exactly the 32 rows it reads. ONE
+//            fragment register set refilled in place (135 VGPRs): the GCN chain's SpMMs that run beside this kernel
+//            keep waves resident (a second set = 211 VGPRs = the whole register file at two waves per SIMD).
+//   wgrad    k-major images F[m][i], G[m][j] (the reduction index m is the ROW of both operands): one DMA piece = one
+//            1 KB row; v_mfma_f32_16x16x4 with the output-permutation trick — a lane's ds_read_b128 of F[m][4i'..4i'+3]
+//            feeds FOUR MFMAs whose row slot i' stands for rows 4i'+e (un-permuted for free in the epilogue), so a
+//            k-group of 8 MFMAs costs two LDS instructions (32x32x2 on these images needs one ds_read_b32 per operand
+//            per MFMA: 25 us of the kernel, measured). Waves 4 (rows) x 2 (columns), 64 x 32 each.
+// Every range leaves its accumulator image in a partial slot; the reduce kernels add a tile's slots in block order
+// (deterministic) and apply the epilogue: bias + dropout (the mask either given or drawn HERE with the generator of
+// mmssl_dropout_mask_u8 — no separate mask launch in front of the GEMM) / the transposed store + bias-gradient sums.
+#include <algorithm>
+#include <cstdlib>
+
+#include "lds_dma.hpp"
+
+using namespace mmssl;
+
+// Decomposition builds for tools/proj_ablate.sh (never set in the product build): bit 0 = no DMA in the steady loop,
+// bit 1 = no MFMAs, bit 2 = no fragment reads.
+#ifndef MMSSL_PROJ_DBG
+#define MMSSL_PROJ_DBG 0
+#endif
+
+namespace {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+constexpr int PT = 256;                          // tile rows (index of the long operand)
+constexpr int PJ = 64;                           // tile columns = N (index of the short operand)
+constexpr int PBK = 32;                          // reduction slice
+constexpr int PST = 3;                           // LDS stages
+constexpr int kThreads = 512;                    // 8 waves
+constexpr int kStageFloats = (PT + PJ) * PBK;    // 10240 floats = 40 KB
+constexpr int kLdsBytes = PST * kStageFloats * 4;
+constexpr int kSlotFloats = PT * PJ;             // one partial slot: the block's accumulator image (64 KB)
+constexpr int kPieces = 5;                       // DMA instructions per wave per slice (4 long + 1 short)
+constexpr int kMaxProb = MMSSL_PROJ_MAX_PROBLEMS;
+
+struct Group {
+  const float* A[kMaxProb];       // long operand (F_g)
+  const float* B[kMaxProb];       // short operand (forward: W_g; wgrad: G + 64 g)
+  int64_t lda[kMaxProb], ldb[kMaxProb];
+  int64_t I[kMaxProb];            // extent of the tile axis (forward: M; wgrad: K_g)
+  int64_t R[kMaxProb];            // reduction length (forward: K_g; wgrad: M)
+  int64_t unit0[kMaxProb + 1];    // first (tile, slice) unit of problem g
+  int S[kMaxProb];                // slices per tile = ceil(R / 32)
+  int tile0[kMaxProb + 1];        // first tile of problem g
+  int n;
+};
+
+__device__ __forceinline__ int prob_of_unit(const Group& P, int64_t u) {
+  int g = 0;
+  while (g + 1 < P.n && u >= P.unit0[g + 1]) ++g;
+  return g;
+}
+__device__ __forceinline__ int prob_of_tile(const Group& P, int t) {
+  int g = 0;
+  while (g + 1 < P.n && t >= P.tile0[g + 1]) ++g;
+  return g;
+}
+__device__ __forceinline__ int tile_of_unit(const Group& P, int64_t u) {
+  const int g = prob_of_unit(P, u);
+  return P.tile0[g] + (int)((u - P.unit0[g]) / P.S[g]);
+}
+
+struct FwdPtrs {
+  const float* bias[kMaxProb];
+};
+struct WgradPtrs {
+  float* gW[kMaxProb];
+  float* gb[kMaxProb];
+};
+
+// what a block's range [u, u_end) does next: one segment = the slices [s0, s0 + nk) of tile `tip` of problem g
+struct Segment {
+  int g, tip, s0, nk;
+};
+__device__ __forceinline__ Segment segment_at(const Group& P, int64_t u, int64_t u_end) {
+  Segment sg;
+  sg.g = prob_of_unit(P, u);
+  const int S = P.S[sg.g];
+  const int64_t rel = u - P.unit0[sg.g];
+  sg.tip = (int)(rel / S);
+  sg.s0 = (int)(rel - (int64_t)sg.tip * S);
+  sg.nk = (int)min((int64_t)S, sg.s0 + (u_end - u)) - sg.s0;
+  return sg;
+}
+
+// waits in front of a step that reads slice kt+1: its pieces landed (mine: vmcnt; everyone's: barrier); my fragment
+// reads of slice kt are done, so after the barrier stage kt % 3 may be refilled
+__device__ __forceinline__ void step_sync(bool two_in_flight) {
+  if (two_in_flight) vm_wait_n<kPieces>();
+  else vm_wait_n<0>();
+  lgkm_wait0();
+  bare_barrier();
+}
+
+// =====================================================================================================================
+// forward: row-major images, v_mfma_f32_32x32x2
+// =====================================================================================================================
+struct FragF {
+  float a[16], b0[16], b1[16];      // operand values of the 16 MFMA steps of one slice (this lane's k half)
+};
+
+__global__ __launch_bounds__(kThreads) void proj_fwd_sk_kernel(Group P, int upb, int64_t total, int max_segs,
+                                                               float* __restrict__ partials) {
+  extern __shared__ __attribute__((aligned(16))) float ring[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int h = lane >> 5, lr = lane & 31;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  const unsigned ring_lds = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)ring);
+  const int64_t u_begin = (int64_t)blockIdx.x * upb;
+  const int64_t u_end = min(total, u_begin + upb);
+  int64_t u = u_begin;
+  int seg = 0;
+  while (u < u_end) {
+    const Segment sg = segment_at(P, u, u_end);
+    const int nk = sg.nk;
+    const int64_t i0 = (int64_t)sg.tip * PT;
+    const int64_t I = P.I[sg.g], lda = P.lda[sg.g], ldb = P.ldb[sg.g];
+    // DMA source addresses of this wave's five pieces (slice 0 of the segment): long operand rows 32w + 8j + (lane >> 3),
+    // 16-byte chunk (lane & 7) of the 128-byte row slice, XOR-swizzled; short operand rows 8w + (lane >> 3)
+    const float* pa[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int r = 32 * wave + 8 * j + (lane >> 3);
+      const int c = (lane & 7) ^ ((r >> 1) & 7);
+      pa[j] = P.A[sg.g] + min(i0 + r, I - 1) * lda + (int64_t)sg.s0 * PBK + 4 * c;
+    }
+    const float* pb;
+    {
+      const int r = 8 * wave + (lane >> 3);
+      const int c = (lane & 7) ^ ((r >> 1) & 7);
+      pb = P.B[sg.g] + (int64_t)r * ldb + (int64_t)sg.s0 * PBK + 4 * c;
+    }
+    auto issue_piece = [&](int kt, int e) {
+      const unsigned st = ring_lds + (unsigned)(kt % PST) * (kStageFloats * 4);
+      if (e < 4) glds16(pa[e] + (int64_t)kt * PBK, st + (unsigned)((32 * wave_u + 8 * e) * PBK * 4));
+      else glds16(pb + (int64_t)kt * PBK, st + (unsigned)(PT * PBK * 4 + 8 * wave_u * PBK * 4));
+    };
+    auto issue = [&](int kt) {
+#pragma unroll
+      for (int e = 0; e < kPieces; ++e) issue_piece(kt, e);
+    };
+    // fragment values of MFMA steps 4q .. 4q+3 of slice kt (q = 0 .. 3)
+    auto read_quarter = [&](int kt, int q, FragF& f) {
+      const float* st = ring + (kt % PST) * kStageFloats;
+      const int sw = (lr >> 1) & 7;
+      const int pos = ((2 * q + h) ^ sw) * 4;
+      const float4 va = *reinterpret_cast<const float4*>(st + (32 * wave + lr) * PBK + pos);
+      const float4 v0 = *reinterpret_cast<const float4*>(st + PT * PBK + lr * PBK + pos);
+      const float4 v1 = *reinterpret_cast<const float4*>(st + PT * PBK + (32 + lr) * PBK + pos);
+      f.a[4 * q] = va.x; f.a[4 * q + 1] = va.y; f.a[4 * q + 2] = va.z; f.a[4 * q + 3] = va.w;
+      f.b0[4 * q] = v0.x; f.b0[4 * q + 1] = v0.y; f.b0[4 * q + 2] = v0.z; f.b0[4 * q + 3] = v0.w;
+      f.b1[4 * q] = v1.x; f.b1[4 * q + 1] = v1.y; f.b1[4 * q + 2] = v1.z; f.b1[4 * q + 3] = v1.w;
+    };
+    floatx16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+    // One pipeline step = the 32 MFMAs of slice kt with the step's other work slotted between them, one scheduling region
+    // per quarter: the DMA pieces of slice kt+3, the 8 MFMAs of the quarter, then the fragment reads of slice kt+1's
+    // quarter INTO THE REGISTERS THOSE MFMAs JUST READ (one fragment set, refilled in place).
+    auto step = [&](int kt, FragF& f, bool more1, bool more3) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if (more3 && !(MMSSL_PROJ_DBG & 1)) {
+#pragma unroll
+          for (int e = 0; e < kPieces; ++e)
+            if (e * 4 / kPieces == q) issue_piece(kt + 3, e);
+        }
+#pragma unroll
+        for (int p = 4 * q; p < 4 * q + 4; ++p) {
+          if (MMSSL_PROJ_DBG & 2) {            // decomposition build: keep the operands alive with two plain FMAs
+            acc0[p] = fmaf(f.a[p], f.b0[p], acc0[p]);
+            acc1[p] = fmaf(f.a[p], f.b1[p], acc1[p]);
+          } else {
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[p], f.b0[p], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[p], f.b1[p], acc1, 0, 0, 0);
+          }
+        }
+        if (more1 && !(MMSSL_PROJ_DBG & 4)) read_quarter(kt + 1, q, f);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    };
+    // the previous segment's slot stores and fragment reads must be done before the ring is refilled
+    vm_wait_n<0>();
+    lgkm_wait0();
+    bare_barrier();
+    issue(0);
+    if (nk > 1) issue(1);
+    if (nk > 2) issue(2);
+    if (nk > 2) vm_wait_n<2 * kPieces>();
+    else if (nk > 1) vm_wait_n<kPieces>();
+    else vm_wait_n<0>();
+    bare_barrier();
+    FragF f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) read_quarter(0, q, f);
+    int kt = 0;
+    for (; kt + 3 < nk; ++kt) {                  // steady state: slices kt+1 .. kt+3 exist, branch-free
+      step_sync(true);
+      step(kt, f, true, true);
+    }
+    for (; kt < nk; ++kt) {                      // drain
+      if (kt + 1 < nk) step_sync(kt + 2 < nk);
+      step(kt, f, kt + 1 < nk, false);
+    }
+    // the segment's accumulator image -> its partial slot: plane q (0..7) holds, at thread tid, the float4 of rows
+    // 32w + 8(q & 3) + 4h + {0..3}, column 32(q >> 2) + (lane & 31)
+    float4* Pq = reinterpret_cast<float4*>(partials + ((size_t)blockIdx.x * max_segs + seg) * kSlotFloats);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      Pq[q * kThreads + tid] = make_float4(acc0[4 * q], acc0[4 * q + 1], acc0[4 * q + 2], acc0[4 * q + 3]);
+      Pq[(4 + q) * kThreads + tid] = make_float4(acc1[4 * q], acc1[4 * q + 1], acc1[4 * q + 2], acc1[4 * q + 3]);
+    }
+    u += nk;
+    ++seg;
+  }
+}
+
+// =====================================================================================================================
+// weight gradient: k-major images, v_mfma_f32_16x16x4 with permuted output slots
+// =====================================================================================================================
+struct FragW {
+  float4 a[8];        // k-group p: F[m = 4p + g][64 wi + 4 i' .. + 3]   (row slots 4 i' + e of MFMA e)
+  float2 b[8];        // k-group p: G[m = 4p + g][32 wj + 2 j' .. + 1]
+};
+
+__global__ __launch_bounds__(kThreads) void proj_wgrad_sk_kernel(Group P, int upb, int64_t total, int max_segs,
+                                                                 float* __restrict__ partials,
+                                                                 float* __restrict__ bpart) {
+  extern __shared__ __attribute__((aligned(16))) float ring[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g4 = lane >> 4, l16 = lane & 15;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  const int wi = wave >> 1, wj = wave & 1;
+  const int wi_u = wave_u >> 1;
+  const unsigned ring_lds = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)ring);
+  const int64_t u_begin = (int64_t)blockIdx.x * upb;
+  const int64_t u_end = min(total, u_begin + upb);
+  int64_t u = u_begin;
+  int seg = 0;
+  while (u < u_end) {
+    const Segment sg = segment_at(P, u, u_end);
+    const int nk = sg.nk, s0 = sg.s0;
+    const int64_t i0 = (int64_t)sg.tip * PT;
+    const int64_t I = P.I[sg.g], R = P.R[sg.g], lda = P.lda[sg.g], ldb = P.ldb[sg.g];
+    // long operand image [m][256]: piece e of wave w = reduction row 4w + e, one whole 1 KB row (lane -> float4 column);
+    // short operand image [m][64]: wave w's piece = rows 4w + (lane >> 4), 16-byte chunk (lane & 15), stored at chunk
+    // position c ^ 8 on odd rows (the fragment read below takes 2 words per lane from rows m and m + 1 in one 32-lane
+    // group: unswizzled they would share banks)
+    const float* pa = P.A[sg.g] + min(i0 + 4 * lane, I - 4);
+    const float* pb = P.B[sg.g] + 4 * ((lane & 15) ^ (8 * ((lane >> 4) & 1)));
+    auto issue_piece = [&](int kt, int e) {
+      const unsigned st = ring_lds + (unsigned)(kt % PST) * (kStageFloats * 4);
+      const int64_t m0 = (int64_t)(s0 + kt) * PBK;
+      if (e < 4) {
+        const int64_t m = min(m0 + 4 * wave_u + e, R - 1);              // rows past the end: finite data x zeroed G
+        glds16(pa + m * lda, st + (unsigned)((4 * wave_u + e) * PT * 4));
+      } else {
+        const int64_t m = min(m0 + 4 * wave_u + (lane >> 4), R - 1);    // clamped here, zeroed at fragment read
+        glds16(pb + m * ldb, st + (unsigned)(PT * PBK * 4 + 4 * wave_u * PJ * 4));
+      }
+    };
+    auto issue = [&](int kt) {
+#pragma unroll
+      for (int e = 0; e < kPieces; ++e) issue_piece(kt, e);
+    };
+    // k-groups 2q, 2q+1 of slice kt
+    auto read_quarter = [&](int kt, int q, FragW& f) {
+      const float* st = ring + (kt % PST) * kStageFloats;
+      const int64_t m0 = (int64_t)(s0 + kt) * PBK;
+      const bool ragged = m0 + PBK > R;       // the reduction's last slice (block-uniform): rows >= R contribute 0
+#pragma unroll
+      for (int p = 2 * q; p < 2 * q + 2; ++p) {
+        const int m = 4 * p + g4;
+        f.a[p] = *reinterpret_cast<const float4*>(st + m * PT + 64 * wi + 4 * l16);
+        f.b[p] = *reinterpret_cast<const float2*>(st + PT * PBK + m * PJ + 4 * ((8 * wj + (l16 >> 1)) ^ (8 * (g4 & 1))) +
+                                                  2 * (l16 & 1));
+        if (ragged && m0 + m >= R) f.b[p] = make_float2(0.f, 0.f);
+      }
+    };
+    floatx4 acc[4][2];
+#pragma unroll
+    for (int ea = 0; ea < 4; ++ea)
+#pragma unroll
+      for (int eb = 0; eb < 2; ++eb) acc[ea][eb] = floatx4{0.f, 0.f, 0.f, 0.f};
+    float bs0 = 0.f, bs1 = 0.f;                           // this wave's share of the bias-gradient column sums
+    const bool want_bias = bpart != nullptr && sg.tip == 0;
+    auto step = [&](int kt, const FragW& cur, FragW& nxt, bool more1, bool more3) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if (more3 && !(MMSSL_PROJ_DBG & 1)) {
+#pragma unroll
+          for (int e = 0; e < kPieces; ++e)
+            if (e * 4 / kPieces == q) issue_piece(kt + 3, e);
+        }
+        if (more1 && !(MMSSL_PROJ_DBG & 4)) read_quarter(kt + 1, q, nxt);
+#pragma unroll
+        for (int p = 2 * q; p < 2 * q + 2; ++p) {
+          const float av[4] = {cur.a[p].x, cur.a[p].y, cur.a[p].z, cur.a[p].w};
+          const float bv[2] = {cur.b[p].x, cur.b[p].y};
+#pragma unroll
+          for (int ea = 0; ea < 4; ++ea)
+#pragma unroll
+            for (int eb = 0; eb < 2; ++eb) {
+              if (MMSSL_PROJ_DBG & 2) acc[ea][eb][0] = fmaf(av[ea], bv[eb], acc[ea][eb][0]);
+              else acc[ea][eb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ea], bv[eb], acc[ea][eb], 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (want_bias) {                 // the four row-waves of a column half share the k-groups: p % 4 == wi
+#pragma unroll
+        for (int p = 0; p < 8; ++p)
+          if ((p & 3) == wi_u) { bs0 += cur.b[p].x; bs1 += cur.b[p].y; }
+      }
+    };
+    vm_wait_n<0>();
+    lgkm_wait0();
+    bare_barrier();
+    issue(0);
+    if (nk > 1) issue(1);
+    if (nk > 2) issue(2);
+    if (nk > 2) vm_wait_n<2 * kPieces>();
+    else if (nk > 1) vm_wait_n<kPieces>();
+    else vm_wait_n<0>();
+    bare_barrier();
+    FragW f0, f1;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) read_quarter(0, q, f0);
+    int kt = 0;
+    for (; kt + 4 < nk; kt += 2) {               // steady state: slices kt+1 .. kt+4 exist, branch-free
+      step_sync(true);
+      step(kt, f0, f1, true, true);
+      step_sync(true);
+      step(kt + 1, f1, f0, true, true);
+    }
+    for (; kt < nk; kt += 2) {                   // drain
+      if (kt + 1 < nk) step_sync(kt + 2 < nk);
+      step(kt, f0, f1, kt + 1 < nk, kt + 3 < nk);
+      if (kt + 1 < nk) {
+        if (kt + 2 < nk) step_sync(kt + 3 < nk);
+        step(kt + 1, f1, f0, kt + 2 < nk, kt + 4 < nk);
+      }
+    }
+    // acc[ea][eb][r] at lane (g, j') = C[row 64 wi + 16 g + 4 r + ea][col 32 wj + 2 j' + eb]: plane 4 eb + r holds, at
+    // thread tid, the float4 of the FOUR CONSECUTIVE rows ea = 0..3 (the permuted row slots fall back into place)
+    const size_t slot = (size_t)blockIdx.x * max_segs + seg;
+    float4* Pq = reinterpret_cast<float4*>(partials + slot * kSlotFloats);
+#pragma unroll
+    for (int eb = 0; eb < 2; ++eb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        Pq[(4 * eb + r) * kThreads + tid] = make_float4(acc[0][eb][r], acc[1][eb][r], acc[2][eb][r], acc[3][eb][r]);
+    if (want_bias) {
+      // sum over the reduction rows this lane saw (g), then the eight waves' shares meet in LDS (the ring is idle:
+      // everyone is past its last fragment read after the barrier)
+      bs0 += __shfl_xor(bs0, 16, kWave);
+      bs0 += __shfl_xor(bs0, 32, kWave);
+      bs1 += __shfl_xor(bs1, 16, kWave);
+      bs1 += __shfl_xor(bs1, 32, kWave);
+      lgkm_wait0();
+      bare_barrier();
+      if (g4 == 0) {
+        ring[wave * 32 + 2 * l16] = bs0;
+        ring[wave * 32 + 2 * l16 + 1] = bs1;
+      }
+      lgkm_wait0();
+      bare_barrier();
+      if (tid < PJ) {                  // column tid: half wj = tid >> 5, waves 2 wi + wj
+        const int half = tid >> 5, c = tid & 31;
+        bpart[slot * PJ + tid] = ((ring[(0 + half) * 32 + c] + ring[(2 + half) * 32 + c]) + ring[(4 + half) * 32 + c]) +
+                                 ring[(6 + half) * 32 + c];
+      }
+    }
+    u += nk;
+    ++seg;
+  }
+}
+
+// =====================================================================================================================
+// epilogue kernels
+// =====================================================================================================================
+// Philox4x32-10 exactly as mmssl_dropout_mask_u8 draws it (csrc/optim.hip): counter = (group of 4 mask bytes,
+// launch counter), key = seed; byte e of the group keeps iff the top 24 bits of word e are >= p * 2^24.
+__device__ __forceinline__ uint32_t philox_keep_byte(uint64_t seed, uint64_t launch, uint64_t elem, uint32_t thr) {
+  const uint64_t i = elem >> 2;
+  uint32_t c[4] = {(uint32_t)i, (uint32_t)(i >> 32), (uint32_t)launch, (uint32_t)(launch >> 32)};
+  uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint64_t a = (uint64_t)0xD2511F53u * c[0];
+    const uint64_t b = (uint64_t)0xCD9E8D57u * c[2];
+    const uint32_t n0 = (uint32_t)(b >> 32) ^ c[1] ^ k0;
+    const uint32_t n2 = (uint32_t)(a >> 32) ^ c[3] ^ k1;
+    c[1] = (uint32_t)b;
+    c[3] = (uint32_t)a;
+    c[0] = n0;
+    c[2] = n2;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  return (c[elem & 3] >> 8) >= thr ? 1u : 0u;
+}
+
+// the slots of tile t, plane q, in block order (fixed: the result does not depend on the schedule)
+__device__ __forceinline__ float4 sum_slots(const Group& P, int t, int g, int tip, int q, int upb, int max_segs,
+                                            const float* __restrict__ partials, int tid) {
+  const int64_t U0 = P.unit0[g] + (int64_t)tip * P.S[g], U1 = U0 + P.S[g];
+  const int64_t b_first = U0 / upb, b_last = (U1 - 1) / upb;
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int64_t b = b_first; b <= b_last; ++b) {
+    const int seg = b == b_first ? t - tile_of_unit(P, b * upb) : 0;
+    const float4 p = reinterpret_cast<const float4*>(partials + ((size_t)b * max_segs + seg) * kSlotFloats)[q * kThreads + tid];
+    v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
+  }
+  return v;
+}
+
+// forward epilogue: grid = tiles x 8 planes
+__global__ __launch_bounds__(kThreads) void proj_fwd_reduce_kernel(Group P, int upb, int max_segs,
+                                                                   const float* __restrict__ partials, int64_t M,
+                                                                   float* __restrict__ Y, int64_t ldy, FwdPtrs ptrs,
+                                                                   const uint8_t* __restrict__ keep_in,
+                                                                   uint8_t* __restrict__ keep_out,
+                                                                   const uint64_t* __restrict__ rng, float p_drop,
+                                                                   float scale) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int t = (int)blockIdx.x >> 3, q = (int)blockIdx.x & 7;
+  const int g = prob_of_tile(P, t), tip = t - P.tile0[g];
+  const float4 v = sum_slots(P, t, g, tip, q, upb, max_segs, partials, tid);
+  const int col = 32 * (q >> 2) + (lane & 31);
+  const int64_t row0 = (int64_t)tip * PT + 32 * wave + 8 * (q & 3) + 4 * (lane >> 5);
+  const float* bias = ptrs.bias[g];
+  const float bv = bias ? bias[col] : 0.f;
+  const bool gen = keep_out != nullptr && rng != nullptr;
+  uint64_t seed = 0, launch = 0;
+  uint32_t thr = 0;
+  if (gen) {
+    seed = rng[0];
+    launch = rng[1];
+    thr = (uint32_t)(p_drop * 16777216.0f);
+  }
+  const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const int64_t row = row0 + c;
+    if (row >= M) break;
+    float x = e[c] + bv;
+    const int64_t mi = ((int64_t)g * M + row) * PJ + col;
+    if (gen) {
+      const uint32_t k = philox_keep_byte(seed, launch, (uint64_t)mi, thr);
+      keep_out[mi] = (uint8_t)k;
+      x = k ? x * scale : 0.f;
+    } else if (keep_in) {
+      x = keep_in[mi] ? x * scale : 0.f;
+    }
+    Y[row * ldy + (int64_t)g * PJ + col] = x;
+  }
+}
+
+// weight-gradient epilogue: the tile is C[i = feature column][j = channel]; gW[j][i .. i+3] is one float4
+__global__ __launch_bounds__(kThreads) void proj_wgrad_reduce_kernel(Group P, int upb, int max_segs,
+                                                                     const float* __restrict__ partials,
+                                                                     const float* __restrict__ bpart, WgradPtrs ptrs) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int t = (int)blockIdx.x >> 3, q = (int)blockIdx.x & 7;
+  const int g = prob_of_tile(P, t), tip = t - P.tile0[g];
+  const float4 v = sum_slots(P, t, g, tip, q, upb, max_segs, partials, tid);
+  const int col = 32 * (wave & 1) + 2 * (lane & 15) + (q >> 2);
+  const int64_t i = (int64_t)tip * PT + 64 * (wave >> 1) + 16 * (lane >> 4) + 4 * (q & 3);
+  const int64_t K = P.I[g];
+  if (i < K) *reinterpret_cast<float4*>(ptrs.gW[g] + (int64_t)col * K + i) = v;
+  if (tip == 0 && q == 0 && tid < PJ && ptrs.gb[g]) {
+    const int64_t U0 = P.unit0[g], U1 = U0 + P.S[g];
+    const int64_t b_first = U0 / upb, b_last = (U1 - 1) / upb;
+    float s = 0.f;
+    for (int64_t b = b_first; b <= b_last; ++b) {
+      const int seg = b == b_first ? t - tile_of_unit(P, b * upb) : 0;
+      s += bpart[((size_t)b * max_segs + seg) * PJ + tid];
+    }
+    ptrs.gb[g][tid] = s;
+  }
+}
+
+// =====================================================================================================================
+// host side
+// =====================================================================================================================
+struct Plan {
+  Group P;
+  int upb, blocks, max_segs, tiles;
+  int64_t total;
+};
+
+int n_cus() {
+  static int n = [] {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 256;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) return 256;
+    return v;
+  }();
+  return n;
+}
+
+// tile axis extents I[g], reduction lengths R[g]
+bool make_plan(int n_prob, const int64_t* I, const int64_t* R, Plan& pl) {
+  if (n_prob < 1 || n_prob > kMaxProb) return false;
+  Group& P = pl.P;
+  P.n = n_prob;
+  int64_t units = 0;
+  int tiles = 0, min_s = 1 << 30;
+  for (int g = 0; g < n_prob; ++g) {
+    if (I[g] <= 0 || R[g] <= 0) return false;
+    P.I[g] = I[g];
+    P.R[g] = R[g];
+    P.S[g] = (int)((R[g] + PBK - 1) / PBK);
+    const int tg = (int)((I[g] + PT - 1) / PT);
+    P.unit0[g] = units;
+    P.tile0[g] = tiles;
+    units += (int64_t)tg * P.S[g];
+    tiles += tg;
+    min_s = std::min(min_s, P.S[g]);
+  }
+  for (int g = n_prob; g <= kMaxProb; ++g) {
+    P.unit0[g] = units;
+    P.tile0[g] = tiles;
+  }
+  for (int g = n_prob; g < kMaxProb; ++g) {
+    P.A[g] = P.B[g] = nullptr;
+    P.lda[g] = P.ldb[g] = P.I[g] = P.R[g] = 0;
+    P.S[g] = 1;
+  }
+  if (units > (1ll << 40) || tiles > (1 << 20)) return false;
+  int64_t upb = (units + n_cus() - 1) / n_cus();
+  const int64_t floor_ = std::min<int64_t>(min_s, 8);       // a range is at least 8 slices deep (or one whole tile)
+  if (upb < floor_) upb = floor_;
+  pl.upb = (int)upb;
+  pl.total = units;
+  pl.blocks = (int)((units + upb - 1) / upb);
+  pl.max_segs = (int)(upb / min_s) + 2;
+  pl.tiles = tiles;
+  return true;
+}
+
+size_t plan_ws_bytes(const Plan& pl) {
+  // [partial slots | bias partials]
+  return (size_t)pl.blocks * pl.max_segs * (kSlotFloats + PJ) * sizeof(float) + 64;
+}
+
+int lds_ready() {
+  static const int rc = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(proj_fwd_sk_kernel),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes) |
+                        (int)hipFuncSetAttribute(reinterpret_cast<const void*>(proj_wgrad_sk_kernel),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
+  return rc;
+}
+
+bool fwd_shape_ok(int n_prob, const int* K, int64_t M, int N) {
+  if (n_prob < 1 || n_prob > kMaxProb || N != PJ || M <= 0) return false;
+  for (int g = 0; g < n_prob; ++g)
+    if (K[g] < PBK || K[g] % PBK != 0) return false;
+  return true;
+}
+bool wgrad_shape_ok(int n_prob, const int* K, int64_t M, int N) {
+  if (n_prob < 1 || n_prob > kMaxProb || N != PJ || M <= 0) return false;
+  for (int g = 0; g < n_prob; ++g)
+    if (K[g] < 4 || K[g] % 4 != 0) return false;
+  return true;
+}
+
+}  // namespace
+
+extern "C" int mmssl_proj_supported(int n_prob, const int* K, int64_t M, int N, int wgrad) {
+  if (!K) return 0;
+  return (wgrad ? wgrad_shape_ok(n_prob, K, M, N) : fwd_shape_ok(n_prob, K, M, N)) ? 1 : 0;
+}
+
+extern "C" size_t mmssl_proj_workspace_bytes(int n_prob, const int* K, int64_t M, int N, int wgrad) {
+  if (!mmssl_proj_supported(n_prob, K, M, N, wgrad)) return 0;
+  int64_t I[kMaxProb], R[kMaxProb];
+  for (int g = 0; g < n_prob; ++g) {
+    I[g] = wgrad ? K[g] : M;
+    R[g] = wgrad ? M : K[g];
+  }
+  Plan pl;
+  if (!make_plan(n_prob, I, R, pl)) return 0;
+  return plan_ws_bytes(pl);
+}
+
+extern "C" int mmssl_proj_fwd_f32(int n_prob, const float* const* F, const float* const* W, const float* const* bias,
+                                  const int* K, int64_t M, int N, const uint8_t* keep, uint8_t* keep_out,
+                                  const uint64_t* rng_state, float p_drop, float scale, float* Y, int64_t ldy,
+                                  void* workspace, size_t workspace_bytes, void* stream) {
+  if (!F || !W || !K || !Y || !workspace) return MMSSL_E_BADARG;
+  if (!fwd_shape_ok(n_prob, K, M, N)) return MMSSL_E_UNSUPP;
+  if (ldy < (int64_t)n_prob * N || (ldy & 3) || ((uintptr_t)Y & 15) || ((uintptr_t)workspace & 15)) return MMSSL_E_BADARG;
+  if (keep && keep_out) return MMSSL_E_BADARG;
+  if (keep_out && (!rng_state || !(p_drop >= 0.f && p_drop < 1.f))) return MMSSL_E_BADARG;
+  int64_t I[kMaxProb], R[kMaxProb];
+  for (int g = 0; g < n_prob; ++g) {
+    if (!F[g] || !W[g] || (((uintptr_t)F[g] | (uintptr_t)W[g]) & 15)) return MMSSL_E_BADARG;
+    I[g] = M;
+    R[g] = K[g];
+  }
+  Plan pl;
+  if (!make_plan(n_prob, I, R, pl)) return MMSSL_E_UNSUPP;
+  if (workspace_bytes < plan_ws_bytes(pl)) return MMSSL_E_WORKSPACE;
+  if (lds_ready() != 0) return MMSSL_E_UNSUPP;
+  for (int g = 0; g < n_prob; ++g) {
+    pl.P.A[g] = F[g];
+    pl.P.B[g] = W[g];
+    pl.P.lda[g] = K[g];
+    pl.P.ldb[g] = K[g];
+  }
+  hipStream_t s = as_stream(stream);
+  float* part = reinterpret_cast<float*>(workspace);
+  FwdPtrs ptrs;
+  for (int g = 0; g < kMaxProb; ++g) ptrs.bias[g] = (bias && g < n_prob) ? bias[g] : nullptr;
+  hipLaunchKernelGGL(proj_fwd_sk_kernel, dim3((unsigned)pl.blocks), dim3(kThreads), kLdsBytes, s, pl.P, pl.upb, pl.total,
+                     pl.max_segs, part);
+  MMSSL_LAUNCH_CHECK();
+  hipLaunchKernelGGL(proj_fwd_reduce_kernel, dim3((unsigned)pl.tiles * 8), dim3(kThreads), 0, s, pl.P, pl.upb,
+                     pl.max_segs, (const float*)part, M, Y, ldy, ptrs, keep, keep_out, rng_state, p_drop, scale);
+  MMSSL_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int mmssl_proj_wgrad_f32(int n_prob, const float* G, int64_t ldg, const float* const* F, const int* K,
+                                    int64_t M, int N, float* const* gW, float* const* gb, void* workspace,
+                                    size_t workspace_bytes, void* stream) {
+  if (!G || !F || !K || !gW || !workspace) return MMSSL_E_BADARG;
+  if (!wgrad_shape_ok(n_prob, K, M, N)) return MMSSL_E_UNSUPP;
+  if (ldg < (int64_t)n_prob * N || (ldg & 3) || ((uintptr_t)G & 15) || ((uintptr_t)workspace & 15)) return MMSSL_E_BADARG;
+  int64_t I[kMaxProb], R[kMaxProb];
+  for (int g = 0; g < n_prob; ++g) {
+    if (!F[g] || !gW[g] || (((uintptr_t)F[g] | (uintptr_t)gW[g]) & 15)) return MMSSL_E_BADARG;
+    I[g] = K[g];
+    R[g] = M;
+  }
+  Plan pl;
+  if (!make_plan(n_prob, I, R, pl)) return MMSSL_E_UNSUPP;
+  if (workspace_bytes < plan_ws_bytes(pl)) return MMSSL_E_WORKSPACE;
+  if (lds_ready() != 0) return MMSSL_E_UNSUPP;
+  for (int g = 0; g < n_prob; ++g) {
+    pl.P.A[g] = F[g];
+    pl.P.B[g] = G + (int64_t)g * N;
+    pl.P.lda[g] = K[g];
+    pl.P.ldb[g] = ldg;
+  }
+  hipStream_t s = as_stream(stream);
+  float* part = reinterpret_cast<float*>(workspace);
+  const size_t slots = (size_t)pl.blocks * pl.max_segs;
+  float* bpart = part + slots * kSlotFloats;
+  WgradPtrs ptrs;
+  bool any_b = false;
+  for (int g = 0; g < kMaxProb; ++g) {
+    ptrs.gW[g] = g < n_prob ? gW[g] : nullptr;
+    ptrs.gb[g] = (g < n_prob && gb) ? gb[g] : nullptr;
+    any_b = any_b || ptrs.gb[g] != nullptr;
+  }
+  hipLaunchKernelGGL(proj_wgrad_sk_kernel, dim3((unsigned)pl.blocks), dim3(kThreads), kLdsBytes, s, pl.P, pl.upb,
+                     pl.total, pl.max_segs, part, any_b ? bpart : (float*)nullptr);
+  MMSSL_LAUNCH_CHECK();
+  hipLaunchKernelGGL(proj_wgrad_reduce_kernel, dim3((unsigned)pl.tiles * 8), dim3(kThreads), 0, s, pl.P, pl.upb,
+                     pl.max_segs, (const float*)part, (const float*)bpart, ptrs);
+  MMSSL_LAUNCH_CHECK();
+  return 0;
+}

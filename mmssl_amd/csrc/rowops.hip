@@ -154,6 +154,103 @@ __global__ __launch_bounds__(kBlock) void combine_bwd_kernel(const float4* __res
   }
 }
 
+// ---- the same over PACKED modal features: Mod [rows, NM * d], NM modalities side by side --------------------------
+// One lane group of LPR * NM lanes per row: sub-group m (LPR lanes) owns the row's slice of modality m (its norm is a
+// sub-group reduction), the modalities meet by xor-shuffles across sub-groups; sub-group m also adds the layers
+// m, m + NM, ... so that every lane streams. Up to two SIDES (user tables, item tables) share one launch:
+// blocks [0, S0.blocks) run side 0, the rest side 1.
+struct FuseSide {
+  LayerPtrs L;
+  const float4* Mod;
+  const float4* G;      // backward only
+  const float4* Gx;     // backward only, may be NULL
+  float4* out;          // forward: fused rows; backward: gMod
+  float4* gL;           // backward only, may be NULL
+  float* part;          // forward only, may be NULL: per-block sums of |Mod|^2
+  int64_t rows;
+  int n_layers;
+  int blocks;
+};
+
+template <int LPR, int NM>
+__global__ __launch_bounds__(kBlock) void fuse_fwd_kernel(FuseSide S0, FuseSide S1, float inv, float r, float eps) {
+  __shared__ float red[4];
+  constexpr int GL = LPR * NM;                 // lanes per row
+  constexpr int GPB = kBlock / GL;
+  const bool second = (int)blockIdx.x >= S0.blocks;
+  const FuseSide& S = second ? S1 : S0;
+  const int blk = second ? (int)blockIdx.x - S0.blocks : (int)blockIdx.x;
+  const int lig = threadIdx.x & (LPR - 1);
+  const int m = (threadIdx.x & (GL - 1)) / LPR;
+  const int64_t stride = (int64_t)S.blocks * GPB;
+  float ss = 0.f;
+  for (int64_t row = (int64_t)blk * GPB + threadIdx.x / GL; row < S.rows; row += stride) {
+    const int64_t o = row * LPR + lig;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int k = m; k < S.n_layers; k += NM) {
+      const float4 v = S.L.p[k][o];
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    const float4 a = S.Mod[(row * NM + m) * LPR + lig];
+    const float sa = group_sum<LPR>(f4_dot(a, a));
+    const float ca = r / fmaxf(sqrtf(sa), eps);
+    float4 y = make_float4(fmaf(inv, acc.x, ca * a.x), fmaf(inv, acc.y, ca * a.y), fmaf(inv, acc.z, ca * a.z),
+                           fmaf(inv, acc.w, ca * a.w));
+    float srow = sa;
+#pragma unroll
+    for (int w = LPR; w < GL; w <<= 1) {       // sub-groups meet: butterfly over the modality index (fixed order)
+      y.x += __shfl_xor(y.x, w, kWave); y.y += __shfl_xor(y.y, w, kWave);
+      y.z += __shfl_xor(y.z, w, kWave); y.w += __shfl_xor(y.w, w, kWave);
+      srow += __shfl_xor(srow, w, kWave);
+    }
+    if (m == 0) S.out[o] = y;
+    if ((threadIdx.x & (GL - 1)) == 0) ss += srow;
+  }
+  if (S.part) {                     // block-uniform branch
+    const float t = block_sum_256(ss, red);
+    if (threadIdx.x == 0) S.part[blk] = t;
+  }
+}
+
+template <int LPR, int NM>
+__global__ __launch_bounds__(kBlock) void fuse_bwd_kernel(FuseSide S0, FuseSide S1, float r, float inv,
+                                                          const float* __restrict__ c_dev, float c_scale, float eps) {
+  constexpr int GL = LPR * NM;
+  constexpr int GPB = kBlock / GL;
+  const bool second = (int)blockIdx.x >= S0.blocks;
+  const FuseSide& S = second ? S1 : S0;
+  const int blk = second ? (int)blockIdx.x - S0.blocks : (int)blockIdx.x;
+  const int lig = threadIdx.x & (LPR - 1);
+  const int m = (threadIdx.x & (GL - 1)) / LPR;
+  const int64_t stride = (int64_t)S.blocks * GPB;
+  const float c = c_dev ? c_scale * c_dev[0] : 0.f;
+  for (int64_t row = (int64_t)blk * GPB + threadIdx.x / GL; row < S.rows; row += stride) {
+    const int64_t o = row * LPR + lig;
+    const int64_t mo = (row * NM + m) * LPR + lig;
+    const float4 g = S.G[o];
+    const float4 x = S.Mod[mo];
+    if (S.gL && m == 0) S.gL[o] = make_float4(inv * g.x, inv * g.y, inv * g.z, inv * g.w);
+    const float ss = group_sum<LPR>(f4_dot(x, x));
+    const float xg = group_sum<LPR>(f4_dot(x, g));
+    const float norm = sqrtf(ss);
+    float a, b;                     // r*normalize_bwd = a*g - b*x
+    if (norm >= eps) {
+      a = r / norm;
+      b = r * xg / (norm * ss);
+    } else {
+      a = r / eps;
+      b = 0.f;
+    }
+    float4 y = make_float4(a * g.x - (b - c) * x.x, a * g.y - (b - c) * x.y, a * g.z - (b - c) * x.z,
+                           a * g.w - (b - c) * x.w);
+    if (S.Gx) {
+      const float4 e = S.Gx[mo];
+      y.x += e.x; y.y += e.y; y.z += e.z; y.w += e.w;
+    }
+    S.out[mo] = y;
+  }
+}
+
 __global__ __launch_bounds__(kBlock) void sum_partials_kernel(const float* __restrict__ part, int64_t n,
                                                               float* __restrict__ out) {
   __shared__ float red[4];
@@ -286,6 +383,97 @@ extern "C" int mmssl_layer_combine_f32(const float* const* layers, int n_layers,
   hipStream_t s = as_stream(stream);
   ROW_DISPATCH(combine_fwd_kernel, L, n_layers, inv, reinterpret_cast<const float4*>(A),
                reinterpret_cast<const float4*>(B), r, rows, eps, reinterpret_cast<float4*>(out), sumsq_part);
+  MMSSL_LAUNCH_CHECK();
+  return 0;
+}
+
+namespace {
+inline int fuse_grid(int64_t rows, int lanes_per_row) {
+  const int64_t gpb = kBlock / lanes_per_row;
+  const int64_t nb = (rows + gpb - 1) / gpb;
+  return (int)(nb < 1 ? 1 : (nb > 256 * 16 ? 256 * 16 : nb));
+}
+inline bool fuse_shape_ok(int d, int nm) {
+  return supported_d(d) && (nm == 1 || nm == 2 || nm == 4) && (d / 4) * nm <= 64;
+}
+
+#define FUSE_DISPATCH(KERNEL, ...)                                                                            \
+  switch ((d / 4) * 8 + nm) {                                                                                 \
+    case 8 * 8 + 1: hipLaunchKernelGGL((KERNEL<8, 1>), grid, dim3(kBlock), 0, s, __VA_ARGS__); break;         \
+    case 8 * 8 + 2: hipLaunchKernelGGL((KERNEL<8, 2>), grid, dim3(kBlock), 0, s, __VA_ARGS__); break;         \
+    case 8 * 8 + 4: hipLaunchKernelGGL((KERNEL<8, 4>), grid, dim3(kBlock), 0, s, __VA_ARGS__); break;         \
+    case 16 * 8 + 1: hipLaunchKernelGGL((KERNEL<16, 1>), grid, dim3(kBlock), 0, s, __VA_ARGS__); break;       \
+    case 16 * 8 + 2: hipLaunchKernelGGL((KERNEL<16, 2>), grid, dim3(kBlock), 0, s, __VA_ARGS__); break;       \
+    case 16 * 8 + 4: hipLaunchKernelGGL((KERNEL<16, 4>), grid, dim3(kBlock), 0, s, __VA_ARGS__); break;       \
+    case 32 * 8 + 1: hipLaunchKernelGGL((KERNEL<32, 1>), grid, dim3(kBlock), 0, s, __VA_ARGS__); break;       \
+    case 32 * 8 + 2: hipLaunchKernelGGL((KERNEL<32, 2>), grid, dim3(kBlock), 0, s, __VA_ARGS__); break;       \
+    case 64 * 8 + 1: hipLaunchKernelGGL((KERNEL<64, 1>), grid, dim3(kBlock), 0, s, __VA_ARGS__); break;       \
+    default: return MMSSL_E_UNSUPP;                                                                           \
+  }
+}  // namespace
+
+// sides: 1 or 2 (user tables, item tables) in one launch
+extern "C" int mmssl_fuse_fwd_f32(int sides, const float* const* const* layers, int n_layers, float inv,
+                                  const float* const* Mod, int nm, float r, const int64_t* rows, int d, float eps,
+                                  float* const* out, float* const* sumsq_part, void* stream) {
+  if (sides < 1 || sides > 2 || n_layers < 1 || n_layers > kMaxLayers || !layers || !Mod || !rows || !out)
+    return MMSSL_E_BADARG;
+  if (!fuse_shape_ok(d, nm)) return MMSSL_E_UNSUPP;
+  FuseSide S[2] = {};
+  int total = 0;
+  for (int k = 0; k < sides; ++k) {
+    if (rows[k] <= 0 || !layers[k] || !Mod[k] || !out[k]) return MMSSL_E_BADARG;
+    if (((uintptr_t)Mod[k] | (uintptr_t)out[k]) & 15) return MMSSL_E_BADARG;
+    for (int l = 0; l < n_layers; ++l)
+      if (!layers[k][l]) return MMSSL_E_BADARG;
+    for (int l = 0; l < kMaxLayers; ++l)
+      S[k].L.p[l] = reinterpret_cast<const float4*>(layers[k][l < n_layers ? l : 0]);
+    S[k].Mod = reinterpret_cast<const float4*>(Mod[k]);
+    S[k].out = reinterpret_cast<float4*>(out[k]);
+    S[k].part = sumsq_part ? sumsq_part[k] : nullptr;
+    S[k].rows = rows[k];
+    S[k].n_layers = n_layers;
+    S[k].blocks = fuse_grid(rows[k], (d / 4) * nm);
+    total += S[k].blocks;
+  }
+  hipStream_t s = as_stream(stream);
+  const dim3 grid((unsigned)total);
+  FUSE_DISPATCH(fuse_fwd_kernel, S[0], S[1], inv, r, eps);
+  MMSSL_LAUNCH_CHECK();
+  return 0;
+}
+
+// number of per-block partial sums side k of mmssl_fuse_fwd_f32 writes
+extern "C" int mmssl_fuse_blocks(int64_t rows, int d, int nm) {
+  if (!fuse_shape_ok(d, nm) || rows <= 0) return 0;
+  return fuse_grid(rows, (d / 4) * nm);
+}
+
+extern "C" int mmssl_fuse_bwd_f32(int sides, const float* const* Mod, int nm, const float* const* G,
+                                  const float* const* Gx, float r, float inv, const float* c_dev, float c_scale,
+                                  const int64_t* rows, int d, float eps, float* const* gMod, float* const* gL,
+                                  void* stream) {
+  if (sides < 1 || sides > 2 || !Mod || !G || !rows || !gMod) return MMSSL_E_BADARG;
+  if (!fuse_shape_ok(d, nm)) return MMSSL_E_UNSUPP;
+  FuseSide S[2] = {};
+  int total = 0;
+  for (int k = 0; k < sides; ++k) {
+    if (rows[k] <= 0 || !Mod[k] || !G[k] || !gMod[k]) return MMSSL_E_BADARG;
+    const float* gx = Gx ? Gx[k] : nullptr;
+    float* gl = gL ? gL[k] : nullptr;
+    if (((uintptr_t)Mod[k] | (uintptr_t)G[k] | (uintptr_t)gx | (uintptr_t)gMod[k] | (uintptr_t)gl) & 15) return MMSSL_E_BADARG;
+    S[k].Mod = reinterpret_cast<const float4*>(Mod[k]);
+    S[k].G = reinterpret_cast<const float4*>(G[k]);
+    S[k].Gx = reinterpret_cast<const float4*>(gx);
+    S[k].out = reinterpret_cast<float4*>(gMod[k]);
+    S[k].gL = reinterpret_cast<float4*>(gl);
+    S[k].rows = rows[k];
+    S[k].blocks = fuse_grid(rows[k], (d / 4) * nm);
+    total += S[k].blocks;
+  }
+  hipStream_t s = as_stream(stream);
+  const dim3 grid((unsigned)total);
+  FUSE_DISPATCH(fuse_bwd_kernel, S[0], S[1], r, inv, c_dev, c_scale, eps);
   MMSSL_LAUNCH_CHECK();
   return 0;
 }

@@ -43,7 +43,7 @@ class HipBackend:
         self.EPI_NONE, self.EPI_SOFTMAX = ops.EPI_NONE, ops.EPI_SOFTMAX
         for name in ("spmm", "l2norm_rows", "linear", "bpr", "infonce", "sumsq"):
             setattr(self, name, getattr(ops, name))
-        # non-autograd kernels for the fused sharded node (same helpers ops._HotForward uses)
+        # non-autograd kernels for the fused sharded node
         self.spmm_raw = ops._spmm_raw
         self.linear_raw = ops._linear_raw
         self.linear_wgrad_raw = ops._linear_wgrad_raw
@@ -52,6 +52,7 @@ class HipBackend:
         self.dropout_masks = ops.dropout_masks
         self.loss_assemble = ops.loss_assemble
         self._ar = {}
+        self._streams = {}
 
     def gather_owned(self, table, idx, lo, out):
         from . import _lib
@@ -66,10 +67,12 @@ class HipBackend:
         _lib.check(rc, "mmssl_scatter_owned_rows_f32")
 
     def side_streams(self, device):
-        """Three side streams for the sharded node's chains (the same objects ops._HotForward forks)."""
-        if os.environ.get("MMSSL_DIST_STREAMS", "1") == "0":
-            return None
-        return self.ops._side_streams(device)
+        """Three side streams for the sharded node's chains, owned by this backend object."""
+        key = (device.type, device.index)
+        st = self._streams.get(key)
+        if st is None:
+            st = self._streams[key] = [torch.cuda.Stream(device=device) for _ in range(3)]
+        return st
 
     def batch_losses_rows(self, u, p, n, z_img, z_txt, decay, batch_size, tau):
         """[mf, emb, 0, cl_img, cl_txt] from already gathered [B, d] rows: ONE fused node (BPR + both InfoNCE
@@ -81,9 +84,7 @@ class HipBackend:
             ar = (base, base + B)
             self._ar[(B, dev)] = ar
         ia = torch.cat((p, n), 0)
-        # N > 1: single stream (forked side streams next to the RCCL stream inside a captured step measured +0.2 ms)
-        return self.ops.batch_losses_vec(u, ia, z_img, z_txt, ar[0], ar[0], ar[1], decay, batch_size, tau,
-                                         overlap=None if dist.get_world_size() == 1 else False)
+        return self.ops.batch_losses_vec(u, ia, z_img, z_txt, ar[0], ar[0], ar[1], decay, batch_size, tau)
 
     def combine_fwd(self, layers, inv, A, B, r):
         """(out, ss) with ss = |A|^2 + |B|^2 over the local rows (0-dim tensor)."""
@@ -304,10 +305,8 @@ class ShardedMMSSL(nn.Module):
             if keep_masks is not None:
                 km_i, km_t = keep_masks
             else:
-                km_i, km_t = bk.dropout_masks(2, self.ish.per, c.embed_size, c.drop_rate, self.E_i.device)
-        if self.training and hasattr(bk, "ops") and bk.ops.wgrad_ft_enabled() and self.image_feats.is_cuda:
-            bk.ops.register_transposed_features(self.image_feats)
-            bk.ops.register_transposed_features(self.text_feats)
+                km_i, km_t = bk.dropout_masks(2, self.ish.per, c.embed_size, c.drop_rate, self.E_i.device,
+                                              **({"external_tick": True} if getattr(self, "_external_ticks", False) else {}))
         if modal_empty:
             z = getattr(self, "_zero_views", None)
             if z is None or z[0].device != self.E_u.device:
@@ -461,7 +460,7 @@ class _Streams:
 
 
 class _ShardedHotForward(torch.autograd.Function):
-    """Row-sharded counterpart of ops._HotForward: projection of the local item rows, modal SpMM
+    """Row-sharded counterpart of hotnode._HotNode: projection of the local item rows, modal SpMM
     chains, G-layer GCN chain and the layer-mean / modality fusion, with an all-gather of the row
     shards before every A_r . X and — in the hand-written backward — a reduce-scatter of every
     A_r^T . gY_r. One autograd node. The three independent chains (image, text, GCN) run on three forked
@@ -669,7 +668,7 @@ class ShardedHotPathStep:
                 # one rank: the local regulariser is the global one -> the step's loss lands in self.loss directly and
                 # the assembly launch also advances the step-owned counters (see hotpath.HotPathStep)
                 total_local = bk.loss_assemble(terms, self._loss_w, m._feat_ss_local, feat_c, out=self.loss,
-                                               ticks=getattr(self, "_ticks", None) if bk.ops.EXTERNAL["on"] else None)
+                                               ticks=getattr(self, "_ticks", None))
                 return total_local, None, True
             total_local = bk.loss_assemble(terms, self._loss_w, m._feat_ss_local, feat_c)
             feat_local = (feat_c * m._feat_ss_local).detach()
@@ -726,17 +725,21 @@ class ShardedHotPathStep:
         ops_ = getattr(self.model.bk, "ops", None)
         own_ticks = (ops_ is not None and self.optimizer is not None and self.fused and _solo(self.group)
                      and hasattr(self.optimizer, "step_counter"))
+        self._ticks = None
         if own_ticks:          # the loss-assembly launch advances the RNG and AdamW counters (no tick launches)
             dev = self.loss.device
             self._ticks = ([self.optimizer.step_counter(0, dev).data_ptr()], [ops_._rng_state(dev).data_ptr() + 8])
-            prev = ops_.external_ticks(True)
+        self.model._external_ticks = bool(own_ticks)        # the mask draw leaves its counter to that launch too
         try:
             total = self.backward()
             if self.optimizer is not None:
-                self.optimizer.step()
+                if own_ticks:
+                    self.optimizer.step(external_tick=True)
+                else:
+                    self.optimizer.step()
         finally:
-            if own_ticks:
-                ops_.external_ticks(prev)
+            self._ticks = None
+            self.model._external_ticks = False
         return total
 
     def step(self):

@@ -5,19 +5,28 @@ u_sim / gradient penalty: SURVEY.md section 2 rows 3 and 7, out of the hot-path 
 
 All launches (hand-written HIP kernels through the C ABI + a few torch elementwise/optimizer
 kernels) go to one stream and can be captured once into a hipGraph and replayed, which removes
-the host launch gaps that dominate at these problem sizes (a Baby-shape SpMM is ~15 us).
+the host launch gaps that dominate at these problem sizes (a Baby-shape SpMM is ~11 us).
 """
-import os
-
 import torch
 
 from . import ops
+from .hotnode import HotCtx
 from .optim import FusedAdamW
 from .config import args
 
 
 class HotPathStep:
-    def __init__(self, model, graphs, batch_size, decay=1e-5, lr=None, capturable=True):
+    """One step = forward -> losses -> backward -> AdamW on this object's own stream and its own hotnode.HotCtx (side
+    streams + the hand-offs between the forward node, the loss tail and the optimiser): nothing here is process-global,
+    so several step objects (models, devices, host threads) can be built, captured and run side by side.
+
+    Options (constructor arguments, fixed for the object's life; the defaults are the measured-best forms):
+      overlap       fork the projection / modal chain and the GCN chain onto two side streams (False: one stream)
+      eager_loss    root the backward at the loss TERMS with their known gradients, so that the loss section is one
+                    chain of launches whose tail also assembles the loss and ticks the step's counters
+                    (False: autograd through ops.loss_assemble, the op-by-op structure)"""
+
+    def __init__(self, model, graphs, batch_size, decay=1e-5, lr=None, capturable=True, overlap=True, eager_loss=True):
         self.model = model
         self.graphs = tuple(graphs)
         self.batch_size = int(batch_size)
@@ -30,30 +39,16 @@ class HotPathStep:
         # same update rule as the reference's optim.AdamW (main.py:76-80) as ONE launch over all tensors
         # with a gradient; the step counter lives on the device so the step can be replayed in a hipGraph.
         # (`capturable` is kept for signature compatibility: the kernel always is.)
-        # Two groups with the same hyper-parameters: the embedding tables (their gradients are complete when the
-        # GCN backward chain is) are updated while the projection wgrad GEMMs are still running.
-        tables = [model.user_id_embedding.weight, model.item_id_embedding.weight]
-        tid = {id(p) for p in tables}
-        rest = [p for p in model.parameters() if id(p) not in tid]
-        # One launch for everything after the join (default since the register-direct weight gradient ends about when
-        # the GCN backward chain does: 0.606 vs 0.613 ms per Baby step). MMSSL_ADAMW_GROUPS=2: the embedding tables in
-        # their own launch next to the wgrad GEMMs, the projection weights after the join.
-        self._one_group = os.environ.get("MMSSL_ADAMW_GROUPS", "1") == "1"
-        if self._one_group:
-            self.optimizer = FusedAdamW([{"params": tables + rest}], lr=lr or args.lr)
-        else:
-            self.optimizer = FusedAdamW([{"params": tables}, {"params": rest}], lr=lr or args.lr)
+        self.optimizer = FusedAdamW([{"params": list(model.parameters())}], lr=lr or args.lr)
         self.loss = torch.zeros((), device=dev)
         self._one = torch.ones((), device=dev)
-        # True (default): materialised `.grad`s. False (MMSSL_WGRAD_PARTS=1): the projection weight / bias gradients stay
-        # split-K partials that the optimiser adds while it reads them (no reduce launch, `.grad` of those four
-        # parameters stays None) - measured equal (0.5845 vs 0.5853 ms per Baby step), so the simpler form is the default
-        self.materialize_grads = os.environ.get("MMSSL_WGRAD_PARTS", "0") != "1"
         self._feat_c, self._feat_c_val = None, None
         self.parts = {}
         self._graph = None
-        # parity runs inject fixed uint8 dropout keep-masks (img, txt), each [n_items, d]; None = one Philox launch
-        # per step (fresh masks on every replay)
+        self.eager_loss = bool(eager_loss)
+        self.hot = HotCtx(dev, overlap=overlap)
+        # parity runs inject fixed uint8 dropout keep-masks (img, txt), each [n_items, d]; None = drawn inside the
+        # projection's epilogue (fresh masks on every replay)
         self.keep_masks = None
         # ONE stream for everything this object launches (eager steps, capture, replays): autograd
         # binds each parameter's AccumulateGrad node to the stream of its first backward, and a
@@ -71,44 +66,45 @@ class HotPathStep:
                 self.pos.copy_(pos, non_blocking=True)
                 self.neg.copy_(neg, non_blocking=True)
 
-    def losses(self):
+    def _feat_coeff(self):
+        c = args.feat_reg_decay * 0.5 / self.model.n_items
+        if self._feat_c is None or self._feat_c_val != c:
+            self._feat_c, self._feat_c_val = torch.full((), c, dtype=torch.float32, device=self.loss.device), c
+        return c
+
+    def losses(self, ticks=None):
+        """Forward + loss assembly through autograd-visible ops; returns (total, parts). The step's loss lands in the
+        persistent buffer self.loss (read back by callers after a replay)."""
         m = self.model
-        (ua, ia, img_item, txt_item, img_user, txt_user, uemb, _, img_uid, txt_uid, _, _) = m(*self.graphs, keep_masks=self.keep_masks)
+        (ua, ia, img_item, txt_item, img_user, txt_user, uemb, _, img_uid, txt_uid, _, _) = m(
+            *self.graphs, keep_masks=self.keep_masks, hot=self.hot)
         terms = ops.batch_losses_vec(ua, ia, img_uid, txt_uid, self.users, self.pos, self.neg, self.decay,
                                      self.batch_size, args.tau)                 # [mf, emb, 0, cl_img, cl_txt]
         ss = m.feat_sumsq(img_item, txt_item, img_user, txt_user)
-        # the step's loss lands in the persistent buffer self.loss (read back by callers after a replay)
-        c = args.feat_reg_decay * 0.5 / m.n_items
-        if self._feat_c is None or self._feat_c_val != c:
-            self._feat_c, self._feat_c_val = torch.full((), c, dtype=torch.float32, device=self.loss.device), c
+        c = self._feat_coeff()
         # _step() backpropagates the persistent ones tensor: the assembly's gradients are the constants
-        total = ops.loss_assemble(terms, self.loss_w, ss, c, out=self.loss, unit_grad_c=self._feat_c,
-                                  ticks=self._ticks if ops.EXTERNAL["on"] else None)
+        total = ops.loss_assemble(terms, self.loss_w, ss, c, out=self.loss, unit_grad_c=self._feat_c, ticks=ticks)
         return total, dict(terms=terms, ss=ss)
 
-    def _losses_eager(self):
+    def _losses_eager(self, ticks):
         """losses() for _step(): the terms' and the regulariser's gradients are known constants (loss_w, c), so the
         backward is rooted at them directly; the loss value (self.loss) and the step's counter ticks come out of the
         last launch of the loss section (ops._BatchLosses._forward_eager)."""
-        m = self.model
+        m, hot = self.model, self.hot
         # the forward leaves its regulariser sum unreduced; the loss tail reduces it (one launch less in front of the
-        # loss chain). Only valid because the very next consumer of `ss` IS that tail.
-        prev_ss = ops.defer_feat_sumsq(os.environ.get("MMSSL_DEFER_SS", "1") == "1")
-        ops._PREFILL["buf"] = None           # never inherit a buffer from a step that did not reach its loss section
-        prev_pf = ops.prefill_loss_buffer((lambda nu, ni, d: (3 * nu + ni) * d + 4)
-                                          if os.environ.get("MMSSL_PREFILL", "1") == "1" else None)
+        # loss chain). Only valid because the very next consumer of `ss` IS that tail - which checks it.
+        hot.defer_ss, hot.ss_parts, hot.prefill_buf = True, None, None
+        hot.prefill_floats = lambda nu, ni, d: (3 * nu + ni) * d + 4
         try:
-            (ua, ia, img_item, txt_item, img_user, txt_user, uemb, _, img_uid, txt_uid, _, _) = m(*self.graphs, keep_masks=self.keep_masks)
+            (ua, ia, img_item, txt_item, img_user, txt_user, uemb, _, img_uid, txt_uid, _, _) = m(
+                *self.graphs, keep_masks=self.keep_masks, hot=hot)
         finally:
-            ops._DEFER_SS["on"] = prev_ss
-            ops._PREFILL["floats"] = prev_pf
+            hot.defer_ss, hot.prefill_floats = False, None
         ss = m.feat_sumsq(img_item, txt_item, img_user, txt_user)
-        c = args.feat_reg_decay * 0.5 / m.n_items
-        if self._feat_c is None or self._feat_c_val != c:
-            self._feat_c, self._feat_c_val = torch.full((), c, dtype=torch.float32, device=self.loss.device), c
+        c = self._feat_coeff()
         terms = ops.batch_losses_vec(ua, ia, img_uid, txt_uid, self.users, self.pos, self.neg, self.decay,
-                                     self.batch_size, args.tau, eager_w=self.loss_w,
-                                     tail=(ss.detach(), c, self.loss, self._ticks if ops.EXTERNAL["on"] else None))
+                                     self.batch_size, args.tau, hot=hot, eager_w=self.loss_w,
+                                     tail=(ss.detach(), c, self.loss, ticks))
         self.parts = dict(terms=terms, ss=ss)
         return [terms, ss], [self.loss_w, self._feat_c]
 
@@ -119,59 +115,27 @@ class HotPathStep:
 
     def _step(self):
         self.optimizer.zero_grad(set_to_none=True)
-        # the step owns its counters: the dropout launch and both AdamW launches run without their one-thread tick
-        # kernels, the loss-assembly launch (between them in stream order) advances the RNG launch counter and
-        # both AdamW step counters
+        # the step owns its counters: the projection's mask draw and the AdamW launch run without their one-thread tick
+        # kernels, the loss section's last launch (between them in stream order) advances the RNG launch counter and
+        # the AdamW step counter
         dev = self.loss.device
+        hot = self.hot
         counters = [self.optimizer.step_counter(gi, dev).data_ptr() for gi in range(len(self.optimizer.param_groups))]
-        self._ticks = (counters, [ops._rng_state(dev).data_ptr() + 8])
-        prev_t = ops.external_ticks(True)
-        prev = ops.defer_wgrad_join(True)
-        # zero gradients of skipped branches: persistent tensors, no fill launch (MMSSL_LAZY_ANCHOR=0: a fill per step)
-        prev_a = ops.lazy_anchors(os.environ.get("MMSSL_LAZY_ANCHOR", "1") == "1")
-        prev_p = ops.wgrad_parts(not self.materialize_grads)
+        ticks = (counters, [ops._rng_state(dev).data_ptr() + 8])
+        hot.external_ticks, hot.lazy_anchors = True, True
         try:
-            if ops.eager_loss_backward_enabled():
-                roots, grads = self._losses_eager()
+            if self.eager_loss:
+                roots, grads = self._losses_eager(ticks)
                 torch.autograd.backward(roots, grads)
             else:
-                total, parts = self.losses()
+                total, parts = self.losses(ticks)
                 total.backward(gradient=self._one)       # persistent root gradient: no ones_like fill per step
-            ops.defer_wgrad_join(prev)
-            ops.assign_anchored_zero_grads()
-            if self._one_group:
-                ops.join_side_streams(dev)
-                self.optimizer.step(sliced=self._sliced_grads(dev))
-            else:
-                self.optimizer.step(groups=(0,))         # embedding tables, next to the wgrad GEMMs
-                ops.join_side_streams(dev)
-                self.optimizer.step(groups=(1,), sliced=self._sliced_grads(dev))
+            hot.assign_anchored_zero_grads()
+            self.optimizer.step(external_tick=True)
         finally:
-            ops.defer_wgrad_join(prev)
-            ops.external_ticks(prev_t)
-            ops.lazy_anchors(prev_a)
-            ops.wgrad_parts(prev_p)
+            hot.external_ticks, hot.lazy_anchors = False, False
+            hot.anchored = []
         return self.loss
-
-    def _sliced_grads(self, dev):
-        """{parameter: (buffer, offset, slices, stride)} for the projection weights / biases whose gradients the
-        backward left as row-range partials (ops.take_wgrad_parts); call after the side streams are joined."""
-        parts = ops.take_wgrad_parts()
-        if not parts:
-            return None
-        out = {}
-        cur = torch.cuda.current_stream(dev)
-        for lin in (self.model.image_trans, self.model.text_trans):
-            hit = parts.get(lin.weight.data_ptr())
-            if hit is None:
-                continue
-            ws, n_parts, w_stride, b_off, n = hit
-            ws.record_stream(cur)
-            if lin.weight.grad is None:
-                out[lin.weight] = (ws, 0, n_parts, w_stride)
-            if lin.bias is not None and lin.bias.grad is None:
-                out[lin.bias] = (ws, b_off, n_parts, n)
-        return out or None
 
     # ---- hipGraph capture ---------------------------------------------------------------------
     def capture(self, warmup=3):

@@ -90,6 +90,9 @@ class Trainer(object):
         self.scheduler_D = self.set_lr_scheduler()
         self._idx_cache = (None, None)
         self._empty_plans = None
+        # Parity runs: `noise_hook(kind, shape)` -> CPU float tensor replaces the two random draws of a batch
+        # ("gumbel": the uniforms of main.py:350, "gp_alpha": torch.rand of main.py:147). None = device generator.
+        self.noise_hook = None
         if batch_test.data_generator is None:
             batch_test.init_data()
         self.data_generator = batch_test.data_generator
@@ -125,7 +128,11 @@ class Trainer(object):
     def gradient_penalty(self, D, xr, xf):
         lam = 0.3
         xf, xr = xf.detach(), xr.detach()
-        alpha = torch.rand(args.batch_size * 2, 1, device=xr.device).expand_as(xr)
+        if self.noise_hook is not None:
+            alpha = self.noise_hook("gp_alpha", (args.batch_size * 2, 1)).to(xr.device)
+        else:
+            alpha = torch.rand(args.batch_size * 2, 1, device=xr.device)
+        alpha = alpha.expand_as(xr)
         inter = (alpha * xr + (1 - alpha) * xf).requires_grad_()
         out = D(inter)
         grads = autograd.grad(outputs=out, inputs=inter, grad_outputs=torch.ones_like(out), create_graph=True,
@@ -199,7 +206,9 @@ class Trainer(object):
                             self.u_sim_calculation(users, txt_user, txt_item).detach()), dim=0)
         lossf = self.D(inputf).mean()
         u_ui = self._seen_rows(users)
-        if os.environ.get("MMSSL_REF_NOISE", "0") == "1":
+        if self.noise_hook is not None:
+            noise = self.noise_hook("gumbel", tuple(u_ui.shape)).to(u_ui.device)
+        elif os.environ.get("MMSSL_REF_NOISE", "0") == "1":
             # the reference draws the Gumbel noise from the CPU generator and uploads it (main.py:350): with the same
             # set_seed the discriminator then sees the reference's noise stream (costs a [B, n_items] host draw + copy)
             noise = torch.empty(u_ui.shape, dtype=torch.float32).uniform_(0, 1).pin_memory().to(u_ui.device, non_blocking=True)
@@ -258,7 +267,10 @@ class Trainer(object):
         from .graph import DeviceGraphPair
         if os.environ.get("MMSSL_DEVICE_GRAPHS", "1") == "0" or k < 1 or k > 64:
             return False
-        return n_batch_users * k * max(int(args.T), 1) <= DeviceGraphPair.MAX_PAIRS and self.n_items <= 36864
+        # collected pairs carry over the epoch boundary like the reference's lists (cleared only by a rebuild): up to T-1
+        # batches are left after an epoch's last rebuild and idx 0..T-1 of the next epoch add T more
+        worst = (2 * max(int(args.T), 1) - 1) * n_batch_users * k
+        return worst <= DeviceGraphPair.MAX_PAIRS and self.n_items <= 36864
 
     def _maintain_modal_graphs(self, idx, users, img_sim, txt_sim):
         """main.py:378-405: every T-th batch (idx != 0) rebuild the four modal graphs from the collected (user, top-k

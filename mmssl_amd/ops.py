@@ -155,129 +155,16 @@ def sumsq(X):
 # ---------------------------------------------------------------------------------------
 # modality projection          nn.Linear + nn.Dropout, Models.py:28-29,54,173-174
 # ---------------------------------------------------------------------------------------
-# OPT-IN split-precision projection (MMSSL_GEMM_SPLIT=1; default OFF = exact fp32 MFMA arithmetic).
-# The constant feature matrix is split ONCE into bf16 (hi, lo) pairs (same bytes as fp32), forward and
-# transposed-for-wgrad; W and gY are split per call. See csrc/linear.hip (gemm_split_kernel) and DESIGN.md.
-_SPLIT = {}
-
-
-def split_projection_enabled():
-    return _os.environ.get("MMSSL_GEMM_SPLIT", "0") == "1"
-
-
-def _bf16_pair(x):
-    hi = x.to(torch.bfloat16)
-    lo = (x - hi.float()).to(torch.bfloat16)
-    return hi.contiguous(), lo.contiguous()
-
-
-def register_split_features(F_):
-    """Declare `F_` a CONSTANT feature matrix and build its split copies once: (F_hi, F_lo [M, K]) and the
-    transposed pair padded along M to a multiple of 128 (the wgrad reduction runs over M). Only registered
-    tensors take the split path (anything else - activations, test inputs - stays on the exact fp32 kernels)."""
-    key = (F_.data_ptr(), tuple(F_.shape))
-    if key not in _SPLIT:
-        M, K = F_.shape
-        Mp = (M + 127) // 128 * 128
-        FT = torch.zeros((K, Mp), dtype=torch.float32, device=F_.device)
-        FT[:, :M] = F_.t()
-        _SPLIT[key] = (_bf16_pair(F_), _bf16_pair(FT), Mp, F_)          # keeps F_ alive: the key stays valid
-        del FT
-    return _SPLIT[key]
-
-
-def _split_features(F_):
-    return _SPLIT.get((F_.data_ptr(), tuple(F_.shape)))
-
-
-def _use_split(F_):
-    K = F_.shape[1]
-    return split_projection_enabled() and K % 32 == 0 and K >= 96 and _split_features(F_) is not None
-
-
-def _split_call(Ah, Al, Bh, Bl, b, keep, scale, M, K, N):
-    Y = torch.empty((M, N), dtype=torch.float32, device=Ah.device)
-    nb = _lib.lib().mmssl_linear_split_workspace_bytes(M, K, N)
-    ws = torch.empty(max(nb // 4, 4), dtype=torch.float32, device=Ah.device)
-    rc = _lib.lib().mmssl_linear_split_f32(_ptr(Ah), _ptr(Al), _ptr(Bh), _ptr(Bl), _ptr(b), _ptr(keep), float(scale), M, K,
-                                           N, _ptr(Y), _ptr(ws), ws.numel() * 4, _lib.stream_ptr())
-    _lib.check(rc, "mmssl_linear_split_f32")
-    return Y
-
-
-def _split_pair_dev(x):
-    """(hi, lo) bf16 pair of a contiguous fp32 tensor in one launch."""
-    hi = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
-    lo = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
-    rc = _lib.lib().mmssl_split_bf16_f32(_ptr(x), x.numel(), _ptr(hi), _ptr(lo), _lib.stream_ptr())
-    _lib.check(rc, "mmssl_split_bf16_f32")
-    return hi, lo
-
-
 def _linear_raw(F_, W, b, keep, scale):
     M, K = F_.shape
     N = W.shape[0]
-    if _use_split(F_):
-        (Fh, Fl) = _split_features(F_)[0]
-        Wh, Wl = _split_pair_dev(W)
-        return _split_call(Fh, Fl, Wh, Wl, b, keep, scale, M, K, N)
     Y = torch.empty((M, N), dtype=torch.float32, device=F_.device)
-    ft = _FT.get((F_.data_ptr(), tuple(F_.shape))) if fwd_ft_enabled() else None
-    if ft is not None:
-        nbf = _lib.lib().mmssl_linear_ft_workspace_bytes(M, K, N, ft[1])
-        if nbf > 0:
-            wsf = torch.empty(nbf // 4, dtype=torch.float32, device=F_.device)
-            rc = _lib.lib().mmssl_linear_ft_f32(_ptr(ft[0]), ft[1], _ptr(W), _ptr(b), _ptr(keep), float(scale), M, K, N,
-                                                _ptr(Y), _ptr(wsf), nbf, _lib.stream_ptr())
-            _lib.check(rc, "mmssl_linear_ft_f32")
-            return Y
     nb = _lib.lib().mmssl_linear_workspace_bytes(M, K, N)
     ws = torch.empty(max(nb // 4, 4), dtype=torch.float32, device=F_.device)
-    tk = _linear_tickets(F_, M, K, N)
-    if tk is not None:
-        tk, ws = tk               # the fix-up form owns its partial slots (see _linear_tickets)
-        rc = _lib.lib().mmssl_linear_tk_f32(_ptr(F_), _ptr(W), _ptr(b), _ptr(keep), float(scale), M, K, N, _ptr(Y),
-                                            _ptr(ws), ws.numel() * 4, _ptr(tk), _lib.stream_ptr())
-        _lib.check(rc, "mmssl_linear_tk_f32")
-        return Y
     rc = _lib.lib().mmssl_linear_f32(_ptr(F_), _ptr(W), _ptr(b), _ptr(keep), float(scale), M, K, N, _ptr(Y),
                                      _ptr(ws), ws.numel() * 4, _lib.stream_ptr())
     _lib.check(rc, "mmssl_linear_f32")
     return Y
-
-
-# Arrival tickets of the in-kernel stream-K fix-up (mmssl_linear_tk_f32): zero-initialised once, left zero by every
-# call, one set per (shape, stream) so that products that run side by side never share one.
-_TICKETS = {}
-
-
-def linear_fixup_enabled():
-    """OPT-IN (MMSSL_GEMM_FIXUP=1): the stream-K fix-up inside the kernel instead of the separate reduce launch.
-    Measured: Baby image forward alone 102.3 vs 104.7 us, but the whole step 0.641 vs 0.625 ms, so the default stays
-    the two-launch form. (The same fix-up for the weight gradient measured 0.604 vs 0.592 ms and was dropped.)"""
-    return _os.environ.get("MMSSL_GEMM_FIXUP", "0") == "1"
-
-
-def _linear_tickets(F_, M, K, N):
-    if not linear_fixup_enabled():
-        return None
-    # launches on one stream are ordered, so one set per (shape, stream) is never in use twice at a time; the sets are
-    # kept for the life of the process (a captured graph holds their addresses)
-    key = (F_.device.index, M, K, N, torch.cuda.current_stream(F_.device).cuda_stream)
-    tk = _TICKETS.get(key)
-    if tk is None:
-        n = int(_lib.lib().mmssl_linear_ticket_count(M, K, N))
-        if n <= 0:
-            _TICKETS[key] = False
-            return None
-        # tickets AND partial slots are private to this key for the life of the process: the fix-up's write-through
-        # stores / cache-bypassing loads are not ordered against ordinary cached accesses other kernels may have made to
-        # recycled allocator memory (a transient workspace showed order-dependent wrong results in a long test run)
-        nb = _lib.lib().mmssl_linear_workspace_bytes(M, K, N)
-        tk = (torch.zeros(n, dtype=torch.int32, device=F_.device),
-              torch.zeros(max(nb // 4, 4), dtype=torch.float32, device=F_.device))
-        _TICKETS[key] = tk
-    return tk if tk is not False else None
 
 
 # Dropout keep-masks: one Philox launch for any number of equally shaped masks (nn.Dropout, Models.py:54).
@@ -305,21 +192,17 @@ def seed_dropout(seed, device=None):
         _RNG_STATE[key].copy_(val)
 
 
-# Step-owned counter ticks (hotpath.HotPathStep): with EXTERNAL["on"] the dropout launch and the fused AdamW do not
-# launch their own one-thread counter kernels; the step's loss-assembly launch advances all counters instead
-# (loss_assemble(..., ticks=...)). Off by default: every other caller keeps self-advancing launches.
-EXTERNAL = {"on": False}
+def tick_rng(device):
+    """Advance the mask generator's launch counter by one (what a dropout_masks launch does by itself; callers that
+    draw masks inside another kernel - hotnode - or own the step's counters advance it explicitly)."""
+    st = _rng_state(torch.device(device))
+    rc = _lib.lib().mmssl_tick_u64(st.data_ptr() + 8, _lib.stream_ptr())
+    _lib.check(rc, "mmssl_tick_u64")
 
 
-def external_ticks(flag):
-    prev = EXTERNAL["on"]
-    EXTERNAL["on"] = bool(flag)
-    return prev
-
-
-def dropout_masks(count, rows, cols, p, device):
+def dropout_masks(count, rows, cols, p, device, external_tick=False):
     """uint8 [count, rows, cols], 1 = keep with probability 1-p; the generator state lives on the device and
-    advances by itself, so a captured step draws fresh masks on every replay."""
+    advances by itself (external_tick: the caller advances it), so a captured step draws fresh masks on every replay."""
     device = torch.device(device)
     if device.type != "cuda":
         raise _lib.MmsslError("dropout_masks: needs a CUDA (HIP) device")
@@ -327,7 +210,7 @@ def dropout_masks(count, rows, cols, p, device):
     pad = (-n) % 4
     buf = torch.empty(n + pad, dtype=torch.uint8, device=device)
     rc = _lib.lib().mmssl_dropout_mask_ex_u8(_ptr(_rng_state(device)), float(p), n + pad, _ptr(buf),
-                                             1 if EXTERNAL["on"] else 0, _lib.stream_ptr())
+                                             1 if external_tick else 0, _lib.stream_ptr())
     _lib.check(rc, "mmssl_dropout_mask_ex_u8")
     return buf[:n].view(count, rows, cols)
 
@@ -359,7 +242,7 @@ class _Linear(torch.autograd.Function):
         gY, gW, gb = _linear_wgrad_raw(gY, keep, ctx.scale, F_, W)
         gF = None
         if ctx.needs_input_grad[0]:
-            if gY is None:                 # the transposed-feature path does not return the masked gradient
+            if gY is None:                 # the register-direct kernel masks on its fragments: no masked copy exists
                 gY = gY_in
                 if keep is not None:
                     gY = torch.empty_like(gY_in)
@@ -374,136 +257,89 @@ class _Linear(torch.autograd.Function):
         return gF, gW, (gb if ctx.has_bias else None), None, None
 
 
-def _linear_wgrad_split(gY0, keep, scale, F_, W):
-    M, K = F_.shape
-    N = W.shape[0]
-    # gW [N, K] = gY^T [N, Mp] . F^T [K, Mp]^T through the same split kernel (reduction over the padded M);
-    # one preparation launch transposes, masks and splits gY and sums its columns (bias gradient)
-    _, (FTh, FTl), Mp, _keep_alive = _split_features(F_)
-    dev = gY0.device
-    gTh = torch.empty((N, Mp), dtype=torch.bfloat16, device=dev)
-    gTl = torch.empty((N, Mp), dtype=torch.bfloat16, device=dev)
-    gb = torch.empty(N, dtype=torch.float32, device=dev)
-    nbt = _lib.lib().mmssl_split_transpose_workspace_bytes(Mp, N)
-    wst = torch.empty(max(nbt // 4, 4), dtype=torch.float32, device=dev)
-    rc = _lib.lib().mmssl_split_transpose_bf16_f32(_ptr(gY0), _ptr(keep), float(scale), M, N, Mp, _ptr(gTh),
-                                                   _ptr(gTl), _ptr(gb), _ptr(wst), wst.numel() * 4,
-                                                   _lib.stream_ptr())
-    _lib.check(rc, "mmssl_split_transpose_bf16_f32")
-    gW = _split_call(gTh, gTl, FTh, FTl, None, None, 1.0, N, Mp, K)
-    return None, gW, gb
-
-
-# Weight gradient through the FORWARD kernel: gW [N, K] = gYm^T [N, Mp] . (F^T [K, Mp])^T. The feature matrices are
-# constants (Models.py:46-47), so F^T is built once (register_transposed_features, + M*K*4 bytes of HBM); per call one
-# kernel transposes + dropout-masks gY and sums its columns (the bias gradient). Both projection GEMMs then run on
-# the same stream-K LDS-DMA kernel (csrc/linear.hip, gemm_sk_kernel). Opt-in (see wgrad_ft_enabled); the default is
-# the register-staged wgrad kernel (mmssl_linear_wgrad_f32), which is also what unregistered inputs use.
-_FT = {}
-
-# Weight gradients as row-range partials (hotpath.HotPathStep): with _WPARTS["on"] the fused weight-gradient path
-# returns no gradient tensors; it leaves (workspace, n_parts, weight stride, bias offset, N) under the weight's
-# data_ptr for the optimiser, which adds the slices while it reads them.
-_WPARTS = {"on": False, "map": {}}
-
-
-def wgrad_parts(flag):
-    prev = _WPARTS["on"]
-    _WPARTS["on"] = bool(flag)
-    return prev
-
-
-def take_wgrad_parts():
-    m, _WPARTS["map"] = _WPARTS["map"], {}
-    return m
-
-
-def wgrad_ft_enabled():
-    """OPT-IN (MMSSL_WGRAD_FT=1). Measured on MI355X (tools/gemm_v6_probe.py, hipGraph replay): Baby image wgrad
-    130-135 us vs 138-141 us for the register-staged kernel, Baby text 59 vs 52 us, and no difference in the whole
-    step (0.623 vs 0.620 ms) for +376 MB of HBM, so the default stays the register-staged kernel."""
-    return _os.environ.get("MMSSL_WGRAD_FT", "0") == "1"
-
-
-def fwd_ft_enabled():
-    """OPT-IN (MMSSL_FWD_FT=1): the projection forward from the transposed feature copy (mmssl_linear_ft_f32) for
-    matrices registered with register_transposed_features."""
-    return _os.environ.get("MMSSL_FWD_FT", "0") == "1"
-
-
-def register_transposed_features(F_):
-    key = (F_.data_ptr(), tuple(F_.shape))
-    hit = _FT.get(key)
-    if hit is None:
-        M, K = F_.shape
-        Mp = (M + 63) // 64 * 64
-        FT = torch.zeros((K, Mp), dtype=torch.float32, device=F_.device)
-        FT[:, :M] = F_.t()
-        hit = (FT, Mp, F_)                      # keeps F_ alive: the key stays valid
-        _FT[key] = hit
-    return hit
-
-
-def _linear_wgrad_ft(gY, keep, scale, F_, W, FT, Mp):
-    M, K = F_.shape
-    N = W.shape[0]
-    dev = gY.device
-    gT = torch.empty((N, Mp), dtype=torch.float32, device=dev)
-    gb = torch.empty(N, dtype=torch.float32, device=dev)
-    nbt = _lib.lib().mmssl_transpose_mask_workspace_bytes(Mp, N)
-    wst = torch.empty(max(nbt // 4, 4), dtype=torch.float32, device=dev)
-    rc = _lib.lib().mmssl_transpose_mask_f32(_ptr(gY), _ptr(keep), float(scale), M, N, Mp, _ptr(gT), _ptr(gb),
-                                             _ptr(wst), wst.numel() * 4, _lib.stream_ptr())
-    _lib.check(rc, "mmssl_transpose_mask_f32")
-    gW = _linear_raw(gT, FT, None, None, 1.0)          # [N, Mp] x [K, Mp]^T -> [N, K]
-    return None, gW, gb
-
-
 def _linear_wgrad_raw(gY, keep, scale, F_, W):
     """(masked gY or None, gW, gb) for Y = dropout(F W^T + b): dropout backward, then the wgrad GEMM."""
     M, K = F_.shape
     N = W.shape[0]
-    gY0 = gY
-    if _use_split(F_):
-        return _linear_wgrad_split(gY0, keep, scale, F_, W)
-    ft = _FT.get((F_.data_ptr(), tuple(F_.shape))) if wgrad_ft_enabled() else None
-    if ft is not None and N % 4 == 0 and N <= 256:
-        return _linear_wgrad_ft(gY0, keep, scale, F_, W, ft[0], ft[1])
     fused = keep is not None and _lib.lib().mmssl_linear_wgrad_fuses_mask(M, K, N) == 1
-    if fused and _WPARTS["on"]:
-        # the caller's optimiser adds the row-range partials itself (mmssl_adamw_sliced_f32): no reduce launch, no
-        # materialised gW / gb; the partial buffers are handed over through take_wgrad_parts()
-        nb = _lib.lib().mmssl_linear_wgrad_workspace_bytes(M, K, N)
-        ws = torch.empty(max(nb // 4, 4), dtype=torch.float32, device=W.device)
-        n_parts, b_off = _ct.c_int(0), _ct.c_int64(0)
-        rc = _lib.lib().mmssl_linear_wgrad_parts_f32(_ptr(gY), _ptr(keep), float(scale), _ptr(F_), M, K, N, _ptr(ws), nb,
-                                                     _ct.byref(n_parts), _ct.byref(b_off), _lib.stream_ptr())
-        _lib.check(rc, "mmssl_linear_wgrad_parts_f32")
-        _WPARTS["map"][W.data_ptr()] = (ws, int(n_parts.value), N * K, int(b_off.value), N)
-        return None, None, None
-    if fused:                   # register-direct kernel: dropout backward + bias gradient on the loaded fragments
-        gW = torch.empty_like(W)
-        gb = torch.empty(N, dtype=torch.float32, device=W.device)
-        nb = _lib.lib().mmssl_linear_wgrad_workspace_bytes(M, K, N)
-        ws = torch.empty(max(nb // 4, 4), dtype=torch.float32, device=W.device)
-        rc = _lib.lib().mmssl_linear_wgrad_f32(_ptr(gY), _ptr(keep), float(scale), _ptr(F_), M, K, N, _ptr(gW), _ptr(gb),
-                                               _ptr(ws), nb, _lib.stream_ptr())
-        _lib.check(rc, "mmssl_linear_wgrad_f32")
-        return None, gW, gb
-    if keep is not None:        # register-staged kernel: one dropout-backward pass first (its in-fetch variant is slower)
+    if keep is not None and not fused:   # register-staged kernel: one dropout-backward pass first
         gYm = torch.empty_like(gY)
-        rc = _lib.lib().mmssl_mask_scale_f32(_ptr(gY), _ptr(keep), float(scale), gY.numel(), _ptr(gYm),
-                                             _lib.stream_ptr())
+        rc = _lib.lib().mmssl_mask_scale_f32(_ptr(gY), _ptr(keep), float(scale), gY.numel(), _ptr(gYm), _lib.stream_ptr())
         _lib.check(rc, "mmssl_mask_scale_f32")
         gY = gYm
     gW = torch.empty_like(W)
     gb = torch.empty(N, dtype=torch.float32, device=W.device)
     nb = _lib.lib().mmssl_linear_wgrad_workspace_bytes(M, K, N)
     ws = torch.empty(max(nb // 4, 4), dtype=torch.float32, device=W.device)
-    rc = _lib.lib().mmssl_linear_wgrad_f32(_ptr(gY), None, 1.0, _ptr(F_), M, K, N, _ptr(gW), _ptr(gb), _ptr(ws), nb,
-                                           _lib.stream_ptr())
+    # register-direct kernel (fused): dropout backward + bias gradient on the loaded fragments
+    rc = _lib.lib().mmssl_linear_wgrad_f32(_ptr(gY), _ptr(keep) if fused else None, float(scale) if fused else 1.0, _ptr(F_),
+                                           M, K, N, _ptr(gW), _ptr(gb), _ptr(ws), nb, _lib.stream_ptr())
     _lib.check(rc, "mmssl_linear_wgrad_f32")
-    return gY, gW, gb
+    return (None if fused else gY), gW, gb
+
+
+# ---------------------------------------------------------------------------------------
+# grouped projection: every modality of one step in ONE stream-K launch (csrc/projection.hip)
+# ---------------------------------------------------------------------------------------
+def _c_int_arr(vals):
+    return (_ct.c_int * len(vals))(*[int(v) for v in vals])
+
+
+def _c_ptr_arr(tensors):
+    return (_ct.c_void_p * len(tensors))(*[None if t is None else t.data_ptr() for t in tensors])
+
+
+def proj_supported(Ks, M, N, wgrad=False):
+    """True when mmssl_proj_fwd_f32 / mmssl_proj_wgrad_f32 run this modality list (N == 64, K % 32 == 0 forward)."""
+    return len(Ks) >= 1 and _lib.lib().mmssl_proj_supported(len(Ks), _c_int_arr(Ks), int(M), int(N), int(bool(wgrad))) == 1
+
+
+def proj_forward(Fs, Ws, bs, keep=None, draw=None, scale=1.0):
+    """Y [M, 64 * n] = the projections dropout(F_g W_g^T + b_g) of all modalities side by side, one launch + one
+    epilogue launch. `keep`: uint8 [n, M, 64] given masks; `draw` = (p, device rng state tensor): the masks are drawn in
+    the epilogue (same bytes as ops.dropout_masks(n, M, 64, p) at the same generator state) and returned; the caller
+    advances the generator (dropout_masks's external-tick contract). Returns (Y, keep or None)."""
+    n = len(Fs)
+    M, N = Fs[0].shape[0], Ws[0].shape[0]
+    Ks = [f.shape[1] for f in Fs]
+    dev = Fs[0].device
+    Y = torch.empty((M, N * n), dtype=torch.float32, device=dev)
+    nb = _lib.lib().mmssl_proj_workspace_bytes(n, _c_int_arr(Ks), M, N, 0)
+    if nb == 0:
+        raise _lib.MmsslError("proj_forward: unsupported modality list K=%s M=%d N=%d" % (Ks, M, N))
+    ws = torch.empty(nb // 4 + 4, dtype=torch.float32, device=dev)
+    keep_out, rng, p = None, None, 0.0
+    if draw is not None:
+        p, rng = float(draw[0]), draw[1]
+        keep_out = torch.empty((n, M, N), dtype=torch.uint8, device=dev)
+    elif keep is not None:
+        if keep.dtype != torch.uint8 or tuple(keep.shape) != (n, M, N) or not keep.is_contiguous():
+            raise _lib.MmsslError("proj_forward: keep must be a contiguous uint8 [n, M, 64] tensor")
+    rc = _lib.lib().mmssl_proj_fwd_f32(n, _c_ptr_arr(Fs), _c_ptr_arr(Ws), _c_ptr_arr(bs), _c_int_arr(Ks), M, N, _ptr(keep),
+                                       _ptr(keep_out), _ptr(rng), p, float(scale), _ptr(Y), N * n, _ptr(ws),
+                                       ws.numel() * 4, _lib.stream_ptr())
+    _lib.check(rc, "mmssl_proj_fwd_f32")
+    return Y, (keep_out if draw is not None else keep)
+
+
+def proj_wgrad(G, Fs, want_bias=True):
+    """([gW_g [64, K_g]], [gb_g [64]]) from the ALREADY masked output gradient G [M, 64 * n] (modalities side by side)
+    and the feature matrices, one launch + one epilogue launch."""
+    n = len(Fs)
+    M = Fs[0].shape[0]
+    N = G.shape[1] // n
+    Ks = [f.shape[1] for f in Fs]
+    dev = G.device
+    gW = [torch.empty((N, k), dtype=torch.float32, device=dev) for k in Ks]
+    gb = [torch.empty(N, dtype=torch.float32, device=dev) for _ in Ks] if want_bias else None
+    nb = _lib.lib().mmssl_proj_workspace_bytes(n, _c_int_arr(Ks), M, N, 1)
+    if nb == 0:
+        raise _lib.MmsslError("proj_wgrad: unsupported modality list K=%s M=%d N=%d" % (Ks, M, N))
+    ws = torch.empty(nb // 4 + 4, dtype=torch.float32, device=dev)
+    rc = _lib.lib().mmssl_proj_wgrad_f32(n, _ptr(G), G.stride(0), _c_ptr_arr(Fs), _c_int_arr(Ks), M, N, _c_ptr_arr(gW),
+                                         _c_ptr_arr(gb) if gb else None, _ptr(ws), ws.numel() * 4, _lib.stream_ptr())
+    _lib.check(rc, "mmssl_proj_wgrad_f32")
+    return gW, gb
 
 
 def linear(F_, W, b=None, keep=None, scale=1.0):
@@ -789,7 +625,7 @@ class _BatchLosses(torch.autograd.Function):
     summed by autograd)."""
 
     @staticmethod
-    def forward(ctx, ua, ia, img_uid, txt_uid, users, pos, neg, decay, batch_size, tau, overlap=None, eager_w=None,
+    def forward(ctx, ua, ia, img_uid, txt_uid, users, pos, neg, decay, batch_size, tau, hot=None, eager_w=None,
                 tail=None):
         ua, ia = _chk(ua, "ua"), _chk(ia, "ia")
         img_uid, txt_uid = _chk(img_uid, "img_uid"), _chk(txt_uid, "txt_uid")
@@ -801,25 +637,14 @@ class _BatchLosses(torch.autograd.Function):
         need_grad = any(ctx.needs_input_grad[:4])
         if eager_w is not None and tail is not None and need_grad:
             return _BatchLosses._forward_eager(ctx, ua, ia, img_uid, txt_uid, users, pos, neg, decay, batch_size, tau,
-                                               eager_w, tail, out, wsb, nb)
+                                               eager_w, tail, out, wsb, nb, hot)
         ctx.eager = None
-        # the table gradients the backward scatter-adds into are allocated here and zero-filled on a side
-        # stream, next to the BPR forward, while the (longer) InfoNCE forward runs on the current stream
-        g_ua = torch.empty_like(ua) if need_grad else None
-        g_ia = torch.empty_like(ia) if need_grad else None
-        overlap = loss_overlap_enabled() if overlap is None else bool(overlap)
-        main = torch.cuda.current_stream(dev)
-        side = _side_streams(dev)[0] if overlap else main
-        if overlap:
-            side.wait_stream(main)
-        with torch.cuda.stream(side):
-            rc = _lib.lib().mmssl_bpr_fwd_f32(_ptr(ua), _ptr(ia), None, _ptr(users), _ptr(pos), _ptr(neg), B, d,
-                                              float(decay), int(batch_size), _ptr(out), _ptr(wsb), nb,
-                                              _lib.stream_ptr())
-            _lib.check(rc, "mmssl_bpr_fwd_f32")
-            if need_grad:
-                g_ua.zero_()
-                g_ia.zero_()
+        # the table gradients the backward scatter-adds into are allocated and zero-filled here
+        g_ua = torch.zeros_like(ua) if need_grad else None
+        g_ia = torch.zeros_like(ia) if need_grad else None
+        rc = _lib.lib().mmssl_bpr_fwd_f32(_ptr(ua), _ptr(ia), None, _ptr(users), _ptr(pos), _ptr(neg), B, d,
+                                          float(decay), int(batch_size), _ptr(out), _ptr(wsb), nb, _lib.stream_ptr())
+        _lib.check(rc, "mmssl_bpr_fwd_f32")
         # both InfoNCE problems (image / text view vs the same user table) in ONE set of launches,
         # losses written straight into out[3], out[4]
         nbw = _lib.lib().mmssl_infonce_multi_workspace_bytes(2, B, d)
@@ -830,29 +655,31 @@ class _BatchLosses(torch.autograd.Function):
         rc = _lib.lib().mmssl_infonce_multi_fwd_f32(z1s, _ptr(ua), _ptr(users), 2, B, d, float(tau), _ptr(out[3:5]),
                                                     _ptr(ws1), nbw, _lib.stream_ptr())
         _lib.check(rc, "mmssl_infonce_multi_fwd_f32")
-        if overlap:
-            main.wait_stream(side)
         ctx.save_for_backward(ua, ia, users, pos, neg, ws1)
         ctx.gbuf = (g_ua, g_ia)
-        ctx.cfg = (B, d, float(decay), int(batch_size), float(tau), img_uid.shape, txt_uid.shape, overlap)
+        ctx.cfg = (B, d, float(decay), int(batch_size), float(tau), img_uid.shape, txt_uid.shape)
         return out
 
     @staticmethod
-    def _forward_eager(ctx, ua, ia, img_uid, txt_uid, users, pos, neg, decay, batch_size, tau, w, tail, out, wsb, nb):
+    def _forward_eager(ctx, ua, ia, img_uid, txt_uid, users, pos, neg, decay, batch_size, tau, w, tail, out, wsb, nb, hot):
         """The caller PROMISES that the result is backpropagated with exactly the gradient `w` (a persistent [5]
         tensor: HotPathStep's loss weights, total = w . terms + c * extra backpropagated with 1). The gradients of
         the loss terms are then known before the loss scalars are, and the whole loss section becomes ONE chain of
         seven launches on the current stream, no fork / join (a cross-queue edge of a replayed hipGraph costs 10-15 us):
           zero fill (all four gradients + the tickets), InfoNCE prep, pair tiles, row terms (the last block also reduces
           the two losses), backward pair tiles, backward finish, BPR backward + BPR loss + loss assembly + counter ticks.
-        tail = (extra, c, total, ticks): see mmssl_bpr_step_f32. backward() returns the stored gradients."""
+        tail = (extra, c, total, ticks): see mmssl_bpr_step_f32. backward() returns the stored gradients.
+        `hot` (hotnode.HotCtx of the step, may be None): hands over the zero-filled buffer the forward prepared on an idle
+        stream (hot.prefill_buf) and the forward's unreduced regulariser partials (hot.ss_parts)."""
         B, d = users.shape[0], ua.shape[1]
         dev = ua.device
         if w.dtype != torch.float32 or w.numel() != 5 or w.device != dev:
             raise _lib.MmsslError("batch_losses: eager_w must be a [5] fp32 tensor on the tables' device")
         extra, c, total, ticks = tail
         n_ua, n_ia, n_im, n_tx = ua.numel(), ia.numel(), img_uid.numel(), txt_uid.numel()
-        gbuf, _PREFILL["buf"] = _PREFILL["buf"], None          # zero-filled by the forward (see _PREFILL), if enabled
+        gbuf = None
+        if hot is not None:
+            gbuf, hot.prefill_buf = hot.prefill_buf, None          # zero-filled by the forward, if enabled
         if gbuf is None or gbuf.numel() != n_ua + n_ia + n_im + n_tx + 4 or gbuf.device != dev:
             gbuf = torch.zeros(n_ua + n_ia + n_im + n_tx + 4, dtype=torch.float32, device=dev)
         g_ua = gbuf[:n_ua].view_as(ua)
@@ -873,11 +700,13 @@ class _BatchLosses(torch.autograd.Function):
         fa = (_ct.c_void_p * max(len(f32s), 1))(*[int(x) for x in f32s])
         ka = (_ct.c_void_p * max(len(u64s), 1))(*[int(x) for x in u64s])
         xparts, n_xparts = None, 0
-        last = _DEFER_SS["last"]
+        last = hot.ss_parts if hot is not None else None
         if last is not None and extra is not None and last[0].data_ptr() == extra.data_ptr():
             xparts, n_xparts = last[1], last[1].numel()       # `extra` is a forward's unreduced regulariser sum
-            _DEFER_SS["last"] = None
-        if d <= 64 and _os.environ.get("MMSSL_BPR_GUEST", "1") == "1":
+            hot.ss_parts = None
+        elif last is not None:
+            raise _lib.MmsslError("batch_losses: the forward left an unreduced regulariser sum that this tail does not consume")
+        if d <= 64:
             # the BPR tail as guest blocks of the InfoNCE backward pair-tile launch (it depends on nothing in it), then
             # the InfoNCE finish: six launches, and the chain is shorter by the BPR tail's whole duration
             rc = _lib.lib().mmssl_infonce_bwd_tiles_bpr_f32(
@@ -909,7 +738,7 @@ class _BatchLosses(torch.autograd.Function):
             ctx.eager = None
             return g_ua, g_ia, g_img, g_txt, None, None, None, None, None, None, None, None, None
         ua, ia, users, pos, neg, ws1 = ctx.saved_tensors
-        B, d, decay, batch_size, tau, s_img, s_txt, overlap = ctx.cfg
+        B, d, decay, batch_size, tau, s_img, s_txt = ctx.cfg
         g = g.contiguous().to(torch.float32)
         g_ua, g_ia = ctx.gbuf
         ctx.gbuf = None
@@ -919,46 +748,33 @@ class _BatchLosses(torch.autograd.Function):
         g_img = torch.zeros(s_img, dtype=torch.float32, device=dev) if ctx.needs_input_grad[2] else None
         g_txt = torch.zeros(s_txt, dtype=torch.float32, device=dev) if ctx.needs_input_grad[3] else None
         gz1s = (_ct.c_void_p * 2)(_ptr(g_img), _ptr(g_txt))
-        main = torch.cuda.current_stream(dev)
-        side = _side_streams(dev)[0] if overlap else main
-        if overlap:
-            side.wait_stream(main)
-        # BPR backward (scatter-add into g_ua / g_ia) next to the InfoNCE pair tiles (workspace only);
-        # the InfoNCE finish scatter-adds into g_ua AFTER the join: same accumulation order as serial
-        with torch.cuda.stream(side):
-            rc = _lib.lib().mmssl_bpr_bwd_f32(_ptr(ua), _ptr(ia), None, _ptr(users), _ptr(pos), _ptr(neg), B, d,
-                                              decay, batch_size, _ptr(g[0:1]), _ptr(g[1:2]), _ptr(g_ua), _ptr(g_ia),
-                                              None, _lib.stream_ptr())
-            _lib.check(rc, "mmssl_bpr_bwd_f32")
+        # BPR backward (scatter-add into g_ua / g_ia), the InfoNCE pair tiles (workspace only), then the InfoNCE finish
+        # (scatter-adds into g_ua)
+        rc = _lib.lib().mmssl_bpr_bwd_f32(_ptr(ua), _ptr(ia), None, _ptr(users), _ptr(pos), _ptr(neg), B, d,
+                                          decay, batch_size, _ptr(g[0:1]), _ptr(g[1:2]), _ptr(g_ua), _ptr(g_ia),
+                                          None, _lib.stream_ptr())
+        _lib.check(rc, "mmssl_bpr_bwd_f32")
         call = _lib.lib().mmssl_infonce_multi_bwd_phase_f32
         rc = call(_ptr(users), 2, B, d, tau, _ptr(g[3:5]), gz1s, _ptr(g_ua), _ptr(ws1), ws1.numel() * 4, 1,
                   _lib.stream_ptr())
         _lib.check(rc, "mmssl_infonce_multi_bwd_phase_f32")
-        if overlap:
-            main.wait_stream(side)
         rc = call(_ptr(users), 2, B, d, tau, _ptr(g[3:5]), gz1s, _ptr(g_ua), _ptr(ws1), ws1.numel() * 4, 2,
                   _lib.stream_ptr())
         _lib.check(rc, "mmssl_infonce_multi_bwd_phase_f32")
         return g_ua, g_ia, g_img, g_txt, None, None, None, None, None, None, None, None, None
 
 
-def eager_loss_backward_enabled():
-    """MMSSL_EAGER_LOSS_BWD=0: the loss backward waits for autograd (the round-1 structure)."""
-    return _os.environ.get("MMSSL_EAGER_LOSS_BWD", "1") == "1"
-
-
-def batch_losses_vec(ua, ia, img_uid, txt_uid, users, pos, neg, decay, batch_size, tau, overlap=None, eager_w=None,
+def batch_losses_vec(ua, ia, img_uid, txt_uid, users, pos, neg, decay, batch_size, tau, hot=None, eager_w=None,
                      tail=None):
     """[mf_loss, emb_loss, 0, cl_img, cl_txt] as ONE tensor (see _BatchLosses / loss_assemble).
-    overlap=False keeps every launch on the current stream (None: the MMSSL_STREAMS default).
     eager_w + tail=(extra, c, total, ticks): the caller's promise that the result is backpropagated with exactly the
     [5] gradient eager_w, total = eager_w . terms + c * extra being written to `total` by the same launches
-    (see _BatchLosses._forward_eager)."""
+    (see _BatchLosses._forward_eager); `hot` = the step's hotnode.HotCtx (hand-offs from the forward node)."""
     dev = ua.device
-    if eager_w is not None and (tail is None or not eager_loss_backward_enabled()):
-        eager_w = tail = None
+    if eager_w is not None and tail is None:
+        eager_w = None
     return _BatchLosses.apply(ua, ia, img_uid, txt_uid, _idx(users, "users", dev), _idx(pos, "pos", dev),
-                              _idx(neg, "neg", dev), decay, batch_size, tau, overlap, eager_w, tail)
+                              _idx(neg, "neg", dev), decay, batch_size, tau, hot, eager_w, tail)
 
 
 def batch_losses(ua, ia, img_uid, txt_uid, users, pos, neg, decay, batch_size, tau):
@@ -1026,53 +842,31 @@ def loss_assemble(terms, w, extra=None, c=0.0, out=None, unit_grad_c=None, ticks
 class _ZeroGradAnchor(torch.autograd.Function):
     """Identity on `x` that also makes the result depend on `w` with an exactly-zero gradient
     (used when a provably-zero branch of the reference graph is skipped, so that the optimiser
-    still sees a zero — not a missing — gradient for `w`, like the reference's autograd)."""
+    still sees a zero — not a missing — gradient for `w`, like the reference's autograd).
+    With a context whose `lazy_anchors` is set (hotnode.HotCtx of a step object) the backward launches nothing: the step
+    assigns a persistent all-zero `.grad` afterwards (HotCtx.assign_anchored_zero_grads)."""
 
     @staticmethod
-    def forward(ctx, x, w):
+    def forward(ctx, x, w, hot):
         ctx.wshape, ctx.wdev = w.shape, w.device
-        ctx.lazy = _ANCHOR["lazy"]
+        ctx.lazy = hot is not None and hot.lazy_anchors
         if ctx.lazy:
-            _ANCHOR["params"].append(w)
+            hot.anchored.append(w)
         return x.view_as(x)
 
     @staticmethod
     def backward(ctx, g):
-        if ctx.lazy:          # the caller assigns the (persistent) zero gradient itself: no fill launch in the backward
-            return g, None
-        return g, torch.zeros(ctx.wshape, dtype=torch.float32, device=ctx.wdev)
+        if ctx.lazy:
+            return g, None, None
+        return g, torch.zeros(ctx.wshape, dtype=torch.float32, device=ctx.wdev), None
 
 
-# Lazy anchors (hotpath.HotPathStep): the anchor's backward launches nothing; after the backward the step points the
-# `.grad` of every anchored parameter that got no gradient at a persistent all-zero tensor (take_anchored_params).
-_ANCHOR = {"lazy": False, "params": [], "zeros": {}}
-
-
-def lazy_anchors(flag):
-    prev = _ANCHOR["lazy"]
-    _ANCHOR["lazy"] = bool(flag)
-    return prev
-
-
-def assign_anchored_zero_grads():
-    """Give every parameter anchored since the last call an exactly-zero gradient if autograd produced none."""
-    params, _ANCHOR["params"] = _ANCHOR["params"], []
-    for w in params:
-        if w.grad is None:
-            key = (w.data_ptr(), tuple(w.shape))
-            z = _ANCHOR["zeros"].get(key)
-            if z is None:
-                z = torch.zeros_like(w)
-                _ANCHOR["zeros"][key] = z
-            w.grad = z
-
-
-def zero_grad_anchor(x, w):
-    return _ZeroGradAnchor.apply(x, w)
+def zero_grad_anchor(x, w, hot=None):
+    return _ZeroGradAnchor.apply(x, w, hot)
 
 
 # ---------------------------------------------------------------------------------------
-# GCN propagation + layer mean + modality fusion as ONE autograd node       Models.py:199-218
+# layer mean + modality fusion kernels (Models.py:213-218) and the projection's mask epilogue
 # ---------------------------------------------------------------------------------------
 def _combine_fwd(layers, inv, A, B, r, part):
     out = torch.empty_like(A)
@@ -1093,424 +887,65 @@ def _combine_bwd(A, B, G, r, inv, c_dev, c_scale, want_gL):
     return gA, gB, gL
 
 
-class _PropagateFuse(torch.autograd.Function):
-    """Everything after the projection, as one autograd node (Models.py:177-178,182-183,199-218):
-         img_user = A_ui.x_img, img_item = A_iu.img_user          (and the text pair)
-         u_l = A_ui.i_{l-1}, i_l = A_iu.u_l (row softmax on the last layer)
-         u_g = mean_l(u_l) + r*normalize(img_user) + r*normalize(txt_user)        (items alike)
-         ss  = |img_user|^2+|txt_user|^2+|img_item|^2+|txt_item|^2 (feature-regulariser sum)
-    Forward: 4 + 2G SpMM + 2 combine + 1 tiny reduce. Backward: 2 combine + 1 softmax-bwd + 4 + 2G SpMM
-    whose epilogues add the other gradient branch / the layer-mean gradient and apply the softmax
-    backward, so no separate accumulation or scaling kernels run."""
-
-    @staticmethod
-    def forward(ctx, u0, i0, x_img, x_txt, ui, iu, n_layers, r):
-        u0, i0, x_img, x_txt = _chk(u0, "u0"), _chk(i0, "i0"), _chk(x_img, "x_img"), _chk(x_txt, "x_txt")
-        img_user = _spmm_raw(ui, False, x_img, EPI_NONE)
-        img_item = _spmm_raw(iu, False, img_user, EPI_NONE)
-        txt_user = _spmm_raw(ui, False, x_txt, EPI_NONE)
-        txt_item = _spmm_raw(iu, False, txt_user, EPI_NONE)
-        us, its = [u0], [i0]
-        u, i = u0, i0
-        for l in range(n_layers):
-            epi = EPI_SOFTMAX if l == n_layers - 1 else EPI_NONE
-            u = _spmm_raw(ui, False, i, epi)
-            i = _spmm_raw(iu, False, u, epi)
-            us.append(u)
-            its.append(i)
-        inv = 1.0 / (n_layers + 1)
-        d = u0.shape[1]
-        nbu = _lib.lib().mmssl_layer_combine_blocks(u0.shape[0], d)
-        nbi = _lib.lib().mmssl_layer_combine_blocks(i0.shape[0], d)
-        part = torch.empty(nbu + nbi, dtype=torch.float32, device=u0.device)
-        u_g = _combine_fwd(us, inv, img_user, txt_user, r, part[:nbu])
-        i_g = _combine_fwd(its, inv, img_item, txt_item, r, part[nbu:])
-        ss = torch.empty((), dtype=torch.float32, device=u0.device)
-        rc = _lib.lib().mmssl_sum_partials_f32(_ptr(part), nbu + nbi, _ptr(ss), _lib.stream_ptr())
-        _lib.check(rc, "mmssl_sum_partials_f32")
-        ctx.save_for_backward(img_user, txt_user, img_item, txt_item, us[-1], its[-1])
-        ctx.cfg = (ui, iu, n_layers, float(r), inv)
-        ctx.set_materialize_grads(False)     # unused outputs arrive as None, not as zero-filled tensors
-        return u_g, i_g, ss, img_item, txt_item, img_user, txt_user
-
-    @staticmethod
-    def backward(ctx, Gu, Gi, g_ss, G_img_item, G_txt_item, G_img_user, G_txt_user):
-        img_user, txt_user, img_item, txt_item, uG, iG = ctx.saved_tensors
-        ui, iu, n_layers, r, inv = ctx.cfg
-        Gu = _chk(Gu, "Gu") if Gu is not None else torch.zeros_like(img_user)
-        Gi = _chk(Gi, "Gi") if Gi is not None else torch.zeros_like(img_item)
-        g_ss = g_ss.contiguous().to(torch.float32) if g_ss is not None else None
-        # d(ss)/dx = 2x; normalize-backward and the regulariser term share one pass over A, B
-        g_iu_, g_tu_, g_u0 = _combine_bwd(img_user, txt_user, Gu, r, inv, g_ss, 2.0, True)
-        g_ii_, g_ti_, _ = _combine_bwd(img_item, txt_item, Gi, r, inv, g_ss, 2.0, False)
-        # gradients that arrive on the modal outputs themselves (only if a caller used them elsewhere)
-        if G_img_item is not None:
-            g_ii_ = g_ii_ + G_img_item
-        if G_txt_item is not None:
-            g_ti_ = g_ti_ + G_txt_item
-        if G_img_user is not None:
-            g_iu_ = g_iu_ + G_img_user
-        if G_txt_user is not None:
-            g_tu_ = g_tu_ + G_txt_user
-        # modal chains: g(img_user) = A_iu^T g(img_item) + own branch (AXPY epilogue); g(x) = A_ui^T g(img_user)
-        g_x_img = _spmm_raw(ui, True, _spmm_raw(iu, True, g_ii_, EPI_AXPY, g_iu_, 1.0), EPI_NONE)
-        g_x_txt = _spmm_raw(ui, True, _spmm_raw(iu, True, g_ti_, EPI_AXPY, g_tu_, 1.0), EPI_NONE)
-        # GCN chain. last layer: i_G only feeds the mean; u_G feeds the mean and A_iu.u_G
-        gi = softmax_rows_bwd(iG, Gi, inv)
-        gu = _spmm_raw(iu, True, gi, EPI_AXPY_SOFTMAX_BWD, Gu, inv, uG)
-        gi = _spmm_raw(ui, True, gu, EPI_AXPY, Gi, inv)            # total gradient of i_{G-1}
-        for _ in range(n_layers - 1):
-            gu = _spmm_raw(iu, True, gi, EPI_AXPY, Gu, inv)
-            gi = _spmm_raw(ui, True, gu, EPI_AXPY, Gi, inv)
-        return g_u0, gi, g_x_img, g_x_txt, None, None, None, None
+def spmm_mask_raw(plan, transpose, X, keep, dm, scale):
+    """Y = keep ? (op(A) . X) * scale : 0 with Y [rows, d] packing d / dm modalities side by side and keep the uint8
+    [d / dm, rows, dm] mask of proj_forward: the projection's dropout backward fused into the SpMM store."""
+    rows = plan.shape[1] if transpose else plan.shape[0]
+    cols = plan.shape[0] if transpose else plan.shape[1]
+    if X.dim() != 2 or X.shape[0] != cols:
+        raise _lib.MmsslError("spmm: X has shape %s, expected [%d, d]" % (tuple(X.shape), cols))
+    d = X.shape[1]
+    if keep.dtype != torch.uint8 or keep.numel() != rows * d or not keep.is_contiguous():
+        raise _lib.MmsslError("spmm_mask: keep must be a contiguous uint8 [d / dm, rows, dm] tensor")
+    if STATS["enabled"]:
+        STATS["spmm_launches"] += 1
+        STATS["edge_layers"] += plan.nnz
+        STATS["spmm_bytes"] += plan.nnz * (8 + 4 * d) + rows * 4 * d + (rows + 1) * 4
+    Y = torch.empty((rows, d), dtype=torch.float32, device=X.device)
+    ws = plan.workspace(transpose, d)
+    rc = _lib.lib().mmssl_spmm_mask_f32(plan.handle, int(transpose), _ptr(X), d, _ptr(Y), _ptr(keep), int(dm), float(scale),
+                                        _ptr(ws), ws.numel() * 4, _lib.stream_ptr())
+    _lib.check(rc, "mmssl_spmm_mask_f32")
+    return Y
 
 
-def propagate_fuse(ui, iu, u0, i0, x_img, x_txt, n_layers, r):
-    """(u_g, i_g, ss, img_item, txt_item, img_user, txt_user): see _PropagateFuse. `ui`, `iu` are
-    GraphPlans; x_img / x_txt are the projected (and dropped-out) modality features [n_items, d]."""
-    out = _PropagateFuse.apply(u0, i0, x_img, x_txt, ui, iu, int(n_layers), float(r))
-    return out
+def fuse_blocks(rows, d, nm):
+    """Number of per-block |Mod|^2 partial sums fuse_fwd writes for a side of `rows` rows."""
+    return int(_lib.lib().mmssl_fuse_blocks(int(rows), int(d), int(nm)))
 
 
-# ---------------------------------------------------------------------------------------
-# projection + modal chains + GCN chain + fusion as ONE node, three forked streams
-# ---------------------------------------------------------------------------------------
-import os as _os
-
-_SIDE_STREAMS = {}
-
-
-def _side_streams(device, n=3):
-    key = (device.type, device.index)
-    st = _SIDE_STREAMS.get(key)
-    if st is None:
-        prio = [int(x) for x in _os.environ.get("MMSSL_STREAM_PRIO", "0,0,0").split(",")]
-        st = [torch.cuda.Stream(device=device, priority=prio[k % len(prio)]) for k in range(n + 1)]
-        _SIDE_STREAMS[key] = st
-    return st[:n]
-
-
-def scalar_stream(device):
-    """A fourth forked stream for launches nothing on the step's critical path waits for (loss scalars)."""
-    device = torch.device(device)
-    _side_streams(device)
-    return _SIDE_STREAMS[(device.type, device.index)][3]
+def fuse_fwd(sides, inv, nm, r):
+    """Layer mean + modality fusion over packed modal features, one launch for all `sides` (1 or 2: user tables, item
+    tables). sides = [(layers, Mod [rows, nm * d], part or None), ...]: out = inv * sum(layers) + r * sum_m
+    normalize(Mod[:, m-th slice]); part (fuse_blocks(rows, d, nm) floats) receives the partial sums of |Mod|^2.
+    Returns the list of outputs."""
+    n = len(sides)
+    outs = [torch.empty_like(sd[0][0]) for sd in sides]
+    d = outs[0].shape[1]
+    lay = [(_ct.c_void_p * len(sd[0]))(*[t.data_ptr() for t in sd[0]]) for sd in sides]
+    lay_arr = (_ct.c_void_p * n)(*[_ct.cast(a, _ct.c_void_p).value for a in lay])
+    mods = (_ct.c_void_p * n)(*[sd[1].data_ptr() for sd in sides])
+    rows = (_ct.c_int64 * n)(*[o.shape[0] for o in outs])
+    oarr = (_ct.c_void_p * n)(*[o.data_ptr() for o in outs])
+    parr = (_ct.c_void_p * n)(*[None if sd[2] is None else sd[2].data_ptr() for sd in sides])
+    rc = _lib.lib().mmssl_fuse_fwd_f32(n, lay_arr, len(sides[0][0]), float(inv), mods, int(nm), float(r), rows, d, _NORM_EPS,
+                                       oarr, parr, _lib.stream_ptr())
+    _lib.check(rc, "mmssl_fuse_fwd_f32")
+    return outs
 
 
-def _branch_order(var, default):
-    """Enqueue order of the three chains (A image, B text, C GCN): the order in which a captured graph's
-    branches were recorded influences how the hipGraph executor interleaves them."""
-    o = _os.environ.get(var, default).upper()
-    return o if sorted(o) == ["A", "B", "C"] else default
-
-
-def overlap_enabled():
-    return _os.environ.get("MMSSL_STREAMS", "1") != "0"
-
-
-def loss_overlap_enabled():
-    """BPR next to InfoNCE on a forked stream inside the loss node (MMSSL_LOSS_OVERLAP=0: one stream). Measured on the
-    Baby step under hipGraph replay: forked 0.636 ms, one stream 0.654 ms."""
-    return overlap_enabled() and _os.environ.get("MMSSL_LOSS_OVERLAP", "1") == "1"
-
-
-# Deferred join of the weight-gradient chains. By default _HotForward.backward returns with every side
-# stream joined. A caller that owns the whole step (hotpath.HotPathStep) may set this flag: backward then
-# returns as soon as the embedding-table gradients are complete, the projection wgrad GEMMs still running on
-# their side streams, and the caller must call join_side_streams() before anything reads image_trans /
-# text_trans gradients (it updates the embedding tables in between).
-_DEFER = {"on": False}
-
-# Deferred regulariser sum. A caller whose loss tail is mmssl_bpr_step_f32 (hotpath.HotPathStep) may set this flag:
-# _HotForward.forward then returns `ss` UNREDUCED (its partial sums are handed to the tail through _DEFER_SS["last"],
-# which reduces them and stores the value into the same tensor), and one launch leaves the front of the loss chain.
-_DEFER_SS = {"on": False, "last": None}
-
-
-# Pre-filled loss buffer: with _PREFILL["floats"] set (a function (n_users, n_items, d) -> float count), the forward
-# zero-fills a buffer of that size on the GCN chain's stream and leaves it in _PREFILL["buf"] for the loss tail.
-_PREFILL = {"floats": None, "buf": None}
-
-
-def prefill_loss_buffer(fn):
-    prev = _PREFILL["floats"]
-    _PREFILL["floats"] = fn
-    if fn is None:
-        _PREFILL["buf"] = None
-    return prev
-
-
-def defer_feat_sumsq(flag):
-    prev = _DEFER_SS["on"]
-    _DEFER_SS["on"] = bool(flag)
-    if not flag:
-        _DEFER_SS["last"] = None
-    return prev
-
-
-def defer_wgrad_join(flag):
-    prev = _DEFER["on"]
-    _DEFER["on"] = bool(flag)
-    return prev
-
-
-def join_side_streams(device):
-    """Make the current stream wait for everything queued on this package's side streams."""
-    device = torch.device(device)
-    main = torch.cuda.current_stream(device)
-    for st in _SIDE_STREAMS.get((device.type, device.index), ()):
-        main.wait_stream(st)
-
-
-class _HotForward(torch.autograd.Function):
-    """x_m = dropout(F_m W_m^T + b_m) -> modal SpMM chains -> G-layer GCN -> layer mean + modality
-    fusion (+ regulariser sum): the complete MMSSL.forward after the id-embedding fusion
-    (Models.py:173-174,177-178,182-183,199-218) as one autograd node.
-
-    Three chains are independent and bound by different resources — image projection + its modal chain
-    (fp32 MFMA, then gather), text projection + chain, and the GCN chain (gather, latency) — so the
-    node forks three HIP streams from the current one, runs one chain on each and joins before the
-    combine kernels; the backward mirrors that (GCN backward || image wgrad path || text wgrad path).
-    Every side-stream region starts with wait_stream(current) and ends joined into the current
-    stream, so the node looks single-stream from outside (autograd, caching allocator, hipGraph
-    capture all see ordinary fork/join edges)."""
-
-    @staticmethod
-    def forward(ctx, F_img, W_img, b_img, keep_img, F_txt, W_txt, b_txt, keep_txt, scale, u0, i0, ui, iu,
-                n_layers, r, overlap):
-        F_img, W_img, F_txt, W_txt = _chk(F_img, "F_img"), _chk(W_img, "W_img"), _chk(F_txt, "F_txt"), _chk(W_txt, "W_txt")
-        u0, i0 = _chk(u0, "u0"), _chk(i0, "i0")
-        dev = u0.device
-        main = torch.cuda.current_stream(dev)
-        sA, sB, sC = _side_streams(dev) if overlap else (main, main, main)
-        if overlap:
-            for st in (sA, sB, sC):
-                st.wait_stream(main)
-        out = {}
-
-        def chain_a():
-            with torch.cuda.stream(sA):
-                x_img = _linear_raw(F_img, W_img, b_img, keep_img, scale)
-                out["img_user"] = _spmm_raw(ui, False, x_img, EPI_NONE)
-                out["img_item"] = _spmm_raw(iu, False, out["img_user"], EPI_NONE)
-
-        def chain_b():
-            with torch.cuda.stream(sB):
-                x_txt = _linear_raw(F_txt, W_txt, b_txt, keep_txt, scale)
-                out["txt_user"] = _spmm_raw(ui.twin(), False, x_txt, EPI_NONE)
-                out["txt_item"] = _spmm_raw(iu.twin(), False, out["txt_user"], EPI_NONE)
-
-        def chain_c():
-            with torch.cuda.stream(sC):
-                us, its = [u0], [i0]
-                u, i = u0, i0
-                uic, iuc = ui.twin(2), iu.twin(2)
-                for l in range(n_layers):
-                    epi = EPI_SOFTMAX if l == n_layers - 1 else EPI_NONE
-                    u = _spmm_raw(uic, False, i, epi)
-                    i = _spmm_raw(iuc, False, u, epi)
-                    us.append(u)
-                    its.append(i)
-                out["us"], out["its"] = us, its
-                if overlap and _PREFILL["floats"] is not None:
-                    # the loss section's zero-filled gradient buffer: the GCN chain's stream is idle from here to the
-                    # join (the modal chains end later), so the fill costs nothing on the critical path
-                    buf = torch.zeros(_PREFILL["floats"](u0.shape[0], i0.shape[0], u0.shape[1]), dtype=torch.float32,
-                                      device=dev)
-                    buf.record_stream(main)
-                    _PREFILL["buf"] = buf
-
-        chains = {"A": chain_a, "B": chain_b, "C": chain_c}
-        for c in _branch_order("MMSSL_FWD_ORDER", "ABC"):
-            chains[c]()
-        img_user, img_item, txt_user, txt_item = out["img_user"], out["img_item"], out["txt_user"], out["txt_item"]
-        us, its = out["us"], out["its"]
-        if overlap:
-            for st in (sA, sB, sC):
-                main.wait_stream(st)
-        inv = 1.0 / (n_layers + 1)
-        d = u0.shape[1]
-        nbu = _lib.lib().mmssl_layer_combine_blocks(u0.shape[0], d)
-        nbi = _lib.lib().mmssl_layer_combine_blocks(i0.shape[0], d)
-        part = torch.empty(nbu + nbi, dtype=torch.float32, device=dev)
-        # the two combines are independent: item side next to the user side (MMSSL_COMBINE_FORK=0: one stream; measured
-        # equal within noise on the Baby step, 0.654 vs 0.656 ms)
-        if overlap and _os.environ.get("MMSSL_COMBINE_FORK", "1") == "1":
-            sA.wait_stream(main)
-            with torch.cuda.stream(sA):
-                i_g = _combine_fwd(its, inv, img_item, txt_item, r, part[nbu:])
-            u_g = _combine_fwd(us, inv, img_user, txt_user, r, part[:nbu])
-            main.wait_stream(sA)
-        else:
-            u_g = _combine_fwd(us, inv, img_user, txt_user, r, part[:nbu])
-            i_g = _combine_fwd(its, inv, img_item, txt_item, r, part[nbu:])
-        ss = torch.empty((), dtype=torch.float32, device=dev)
-        if _DEFER_SS["on"]:
-            # the caller's loss tail (mmssl_bpr_step_f32) reduces the partials and stores the sum into `ss`
-            _DEFER_SS["last"] = (ss, part)
-        else:
-            rc = _lib.lib().mmssl_sum_partials_f32(_ptr(part), nbu + nbi, _ptr(ss), _lib.stream_ptr())
-            _lib.check(rc, "mmssl_sum_partials_f32")
-        ctx.save_for_backward(F_img, W_img, keep_img, F_txt, W_txt, keep_txt, img_user, txt_user, img_item, txt_item,
-                              us[-1], its[-1])
-        ctx.cfg = (ui, iu, n_layers, float(r), inv, float(scale), bool(overlap), b_img is not None, b_txt is not None)
-        ctx.set_materialize_grads(False)
-        return u_g, i_g, ss, img_item, txt_item, img_user, txt_user
-
-    @staticmethod
-    def backward(ctx, Gu, Gi, g_ss, G_img_item, G_txt_item, G_img_user, G_txt_user):
-        (F_img, W_img, keep_img, F_txt, W_txt, keep_txt, img_user, txt_user, img_item, txt_item, uG,
-         iG) = ctx.saved_tensors
-        ui, iu, n_layers, r, inv, scale, overlap, has_bi, has_bt = ctx.cfg
-        Gu = _chk(Gu, "Gu") if Gu is not None else torch.zeros_like(img_user)
-        Gi = _chk(Gi, "Gi") if Gi is not None else torch.zeros_like(img_item)
-        g_ss = g_ss.contiguous().to(torch.float32) if g_ss is not None else None
-        dev = Gu.device
-        main = torch.cuda.current_stream(dev)
-        sA, sB, sC = _side_streams(dev) if overlap else (main, main, main)
-        extra = (G_img_item, G_txt_item, G_img_user, G_txt_user)
-        # normalise-backward + regulariser gradient of the user side on sA and of the item side on sB, next to each
-        # other and next to the GCN chain (which only needs Gu / Gi); each modal chain then needs one tensor from the
-        # other stream. (Measured, Baby step under hipGraph replay: this form 0.62 ms; both combines on the current
-        # stream followed by ONE fork 0.65 ms - the extra cross-stream hops cost less than the serialised kernels.)
-        split = overlap and all(t is None for t in extra)
-        if overlap:
-            for st in (sA, sB, sC):
-                st.wait_stream(main)
-            for t, st in ((keep_img, sA), (keep_txt, sB), (img_user, sA), (txt_user, sA), (img_item, sB),
-                          (txt_item, sB), (uG, sC), (iG, sC), (Gu, sA), (Gu, sC), (Gi, sB), (Gi, sC)):
-                if t is not None and _os.environ.get("MMSSL_NO_RECORD_STREAM") != "1":
-                    t.record_stream(st)     # main-pool tensors read on side streams, possibly after this backward returned
-        out = {}
-
-        def chain_c():
-            with torch.cuda.stream(sC):
-                uic, iuc = ui.twin(2), iu.twin(2)
-                gi = softmax_rows_bwd(iG, Gi, inv)
-                gu = _spmm_raw(iuc, True, gi, EPI_AXPY_SOFTMAX_BWD, Gu, inv, uG)
-                gi = _spmm_raw(uic, True, gu, EPI_AXPY, Gi, inv)
-                for _ in range(n_layers - 1):
-                    gu = _spmm_raw(iuc, True, gi, EPI_AXPY, Gu, inv)
-                    gi = _spmm_raw(uic, True, gu, EPI_AXPY, Gi, inv)
-                out["gi"] = gi
-
-        c_first = overlap and _os.environ.get("MMSSL_BWD_C_FIRST", "0") == "1"
-        if c_first:
-            # experiment (MMSSL_BWD_C_FIRST=1): record the GCN chain before the combines. It then starts 70 us earlier,
-            # but runs next to the weight-gradient GEMMs for longer and both stretch (wgrad 122 -> 174 us, SpMM 16 ->
-            # 50-60 us): 0.640 vs 0.633 ms per Baby step, so the default keeps it after the exchange.
-            chain_c()
-        if split and _os.environ.get("MMSSL_COMBINE2", "0") == "1":
-            # OPT-IN experiment: both sides in ONE launch on the current stream, then the forks (one launch and two
-            # cross-queue hops less than a launch per side on sA / sB with the exchange through the current stream).
-            # Measured 0.624 vs 0.568 ms per Baby step: the executor then starts all three chains later.
-            g_iu_, g_tu_, g_u0 = torch.empty_like(img_user), torch.empty_like(txt_user), torch.empty_like(img_user)
-            g_ii_, g_ti_ = torch.empty_like(img_item), torch.empty_like(txt_item)
-            rc = _lib.lib().mmssl_layer_combine_bwd2_f32(
-                _ptr(img_user), _ptr(txt_user), _ptr(Gu), img_user.shape[0], _ptr(g_iu_), _ptr(g_tu_), _ptr(g_u0),
-                _ptr(img_item), _ptr(txt_item), _ptr(Gi), img_item.shape[0], _ptr(g_ii_), _ptr(g_ti_), None,
-                float(r), float(inv), _ptr(g_ss), 2.0, img_user.shape[1], _NORM_EPS, _lib.stream_ptr())
-            _lib.check(rc, "mmssl_layer_combine_bwd2_f32")
-            for st in (sA, sB):
-                st.wait_stream(main)
-            for t, st in ((g_ii_, sA), (g_iu_, sA), (g_ti_, sB), (g_tu_, sB)):
-                if _os.environ.get("MMSSL_NO_RECORD_STREAM") != "1":
-                    t.record_stream(st)
-        elif split:
-            with torch.cuda.stream(sA):
-                g_iu_, g_tu_, g_u0 = _combine_bwd(img_user, txt_user, Gu, r, inv, g_ss, 2.0, True)
-            with torch.cuda.stream(sB):
-                g_ii_, g_ti_, _ = _combine_bwd(img_item, txt_item, Gi, r, inv, g_ss, 2.0, False)
-            # each modal chain needs one tensor of the other side: exchange through the current stream
-            # (a direct sA <-> sB event pair crashes hipGraph capture in this ROCm build)
-            main.wait_stream(sA)
-            main.wait_stream(sB)
-            sA.wait_stream(main)
-            sB.wait_stream(main)
-        else:
-            # gradients arrive on the modal outputs themselves (a caller used them elsewhere, e.g. u_sim -> D): both
-            # combines and the adds on the current stream, then one fork
-            g_iu_, g_tu_, g_u0 = _combine_bwd(img_user, txt_user, Gu, r, inv, g_ss, 2.0, True)
-            g_ii_, g_ti_, _ = _combine_bwd(img_item, txt_item, Gi, r, inv, g_ss, 2.0, False)
-            if G_img_item is not None:
-                g_ii_ = g_ii_ + G_img_item
-            if G_txt_item is not None:
-                g_ti_ = g_ti_ + G_txt_item
-            if G_img_user is not None:
-                g_iu_ = g_iu_ + G_img_user
-            if G_txt_user is not None:
-                g_tu_ = g_tu_ + G_txt_user
-            if overlap:
-                for st in (sA, sB):
-                    st.wait_stream(main)
-                for t, st in ((g_ii_, sA), (g_iu_, sA), (g_ti_, sB), (g_tu_, sB)):
-                    if _os.environ.get("MMSSL_NO_RECORD_STREAM") != "1":
-                        t.record_stream(st)
-        def chain_a1():
-            with torch.cuda.stream(sA):
-                out["g_x_img"] = _spmm_raw(ui, True, _spmm_raw(iu, True, g_ii_, EPI_AXPY, g_iu_, 1.0), EPI_NONE)
-
-        def chain_a2():
-            with torch.cuda.stream(sA):
-                _, out["gW_img"], out["gb_img"] = _linear_wgrad_raw(out["g_x_img"], keep_img, scale, F_img, W_img)
-
-        def chain_b1():
-            with torch.cuda.stream(sB):
-                out["g_x_txt"] = _spmm_raw(ui.twin(), True, _spmm_raw(iu.twin(), True, g_ti_, EPI_AXPY, g_tu_, 1.0), EPI_NONE)
-
-        def chain_b2():
-            with torch.cuda.stream(sB):
-                _, out["gW_txt"], out["gb_txt"] = _linear_wgrad_raw(out["g_x_txt"], keep_txt, scale, F_txt, W_txt)
-
-        def chain_a():
-            chain_a1()
-            chain_a2()
-
-        def chain_b():
-            chain_b1()
-            chain_b2()
-
-        # MMSSL_BWD_SCHED (experiments; needs the split form): 1 = the GCN chain starts when both modal SpMM pairs are
-        # done, 2 = the weight-gradient GEMMs start when the GCN chain is done (the register-direct wgrad and the SpMMs
-        # stretch each other when they run side by side), 0 = only the data dependencies
-        sched = int(_os.environ.get("MMSSL_BWD_SCHED", "0")) if (split and not c_first) else 0
-        if sched == 1:
-            chain_a1()
-            chain_b1()
-            main.wait_stream(sA)
-            main.wait_stream(sB)
-            sC.wait_stream(main)
-            chain_c()
-            chain_a2()
-            chain_b2()
-        elif sched == 2:
-            chain_c()
-            chain_a1()
-            chain_b1()
-            main.wait_stream(sC)
-            sA.wait_stream(main)
-            sB.wait_stream(main)
-            chain_a2()
-            chain_b2()
-        else:
-            chains = {"A": chain_a, "B": chain_b, "C": chain_c}
-            for c in _branch_order("MMSSL_BWD_ORDER", "CAB"):
-                if not (c == "C" and c_first):
-                    chains[c]()
-        gi, gW_img, gb_img, gW_txt, gb_txt = out["gi"], out["gW_img"], out["gb_img"], out["gW_txt"], out["gb_txt"]
-        if overlap:
-            # g_u0 (sA before the exchange, or the current stream) and gi (sC) are what the embedding tables need; in
-            # deferred mode the wgrad chains on sA / sB are left running (see defer_wgrad_join)
-            for st in ((sC,) if (split and _DEFER["on"]) else (sA, sB, sC)):
-                main.wait_stream(st)
-        return (None, gW_img, gb_img if has_bi else None, None, None, gW_txt, gb_txt if has_bt else None, None, None,
-                g_u0, gi, None, None, None, None, None)
-
-
-def hot_forward(F_img, W_img, b_img, keep_img, F_txt, W_txt, b_txt, keep_txt, scale, u0, i0, ui, iu, n_layers, r,
-                overlap=None):
-    """(u_g, i_g, ss, img_item, txt_item, img_user, txt_user): see _HotForward."""
-    if overlap is None:
-        overlap = overlap_enabled()
-    return _HotForward.apply(F_img, W_img, b_img, keep_img, F_txt, W_txt, b_txt, keep_txt, float(scale), u0, i0,
-                             ui, iu, int(n_layers), float(r), bool(overlap))
+def fuse_bwd(sides, nm, r, inv, c_dev, c_scale):
+    """The backward of fuse_fwd, one launch for all sides. sides = [(Mod, G, Gx or None, want_gL), ...]; returns
+    [(gMod [rows, nm * d], gL or None), ...]: gMod = r * normalize_bwd(Mod_m, G) + (c_scale * c_dev) * Mod_m (+ Gx),
+    gL = inv * G."""
+    n = len(sides)
+    gMods = [torch.empty_like(sd[0]) for sd in sides]
+    gLs = [torch.empty_like(sd[1]) if sd[3] else None for sd in sides]
+    d = sides[0][1].shape[1]
+    arr = lambda ts: (_ct.c_void_p * n)(*[None if t is None else t.data_ptr() for t in ts])       # noqa: E731
+    rows = (_ct.c_int64 * n)(*[sd[1].shape[0] for sd in sides])
+    rc = _lib.lib().mmssl_fuse_bwd_f32(n, arr([sd[0] for sd in sides]), int(nm), arr([sd[1] for sd in sides]),
+                                       arr([sd[2] for sd in sides]), float(r), float(inv), _ptr(c_dev), float(c_scale), rows,
+                                       d, _NORM_EPS, arr(gMods), arr(gLs), _lib.stream_ptr())
+    _lib.check(rc, "mmssl_fuse_bwd_f32")
+    return list(zip(gMods, gLs))

@@ -32,12 +32,14 @@ class FusedAdamW(torch.optim.Optimizer):
         return st
 
     @torch.no_grad()
-    def step(self, closure=None, groups=None, sliced=None):
+    def step(self, closure=None, groups=None, sliced=None, external_tick=False):
         """`groups`: optional iterable of param-group indices to update (each group has its own device step
         counter, so groups may be stepped at different points of one iteration).
         `sliced`: {parameter: (buffer, float offset, n_slices, stride)} - gradients that exist only as split-K partials
         (ops.take_wgrad_parts): slice s of the gradient starts at buffer[offset + s * stride]; the kernel adds the
-        slices in order while it reads them. Such parameters need no `.grad`."""
+        slices in order while it reads them. Such parameters need no `.grad`.
+        `external_tick`: the caller already advanced this step's counter (step_counter) on the stream - a step object
+        whose loss tail ticks every counter of the step in one launch - so no tick launch follows the update."""
         loss = None
         if closure is not None:
             with torch.enable_grad():
@@ -83,11 +85,10 @@ class FusedAdamW(torch.optim.Optimizer):
             gptrs = (_ct.c_void_p * n)(*[t[4] for t in todo])
             slices = (_ct.c_int32 * n)(*[t[5] for t in todo])
             gstride = (_ct.c_int64 * n)(*[t[6] for t in todo])
-            from . import ops as _ops
             rc = _lib.lib().mmssl_adamw_sliced_f32(arr(0), gptrs, arr(2), arr(3), numel, slices, gstride, n,
                                                    state.data_ptr(), float(group["lr"]), float(b1), float(b2),
                                                    float(group["eps"]), float(group["weight_decay"]),
-                                                   1 if _ops.EXTERNAL["on"] else 0, _lib.stream_ptr())
+                                                   1 if external_tick else 0, _lib.stream_ptr())
             _lib.check(rc, "mmssl_adamw_sliced_f32")
         return loss
 

@@ -369,9 +369,9 @@ def gen_g12(ref, dg, n_batches=8):
            "lr": args.lr, "D_lr": args.D_lr, "G_rate": args.G_rate, "cl_rate": args.cl_rate, "gp_rate": args.gp_rate}
     for k, v in tr.model.state_dict().items():
         if not k.startswith(skip):
-            rec["m0." + k] = npy(v)
+            rec["m0." + k] = npy(v).copy()          # a copy: the numpy view would follow the training in place
     for k, v in tr.D.state_dict().items():
-        rec["D0." + k] = npy(v)
+        rec["D0." + k] = npy(v).copy()
     st = {"fwd": 0, "D": 0, "cl": 0, "uni": 0, "alpha": 0, "sample": 0, "on": False}
     o_fwd, o_D, o_bpr, o_cl = tr.model.forward, tr.D.forward, tr.bpr_loss, tr.batched_contrastive_loss
     o_feat, o_gp, o_sample = tr.feat_reg_loss_calculation, tr.gradient_penalty, dg.sample

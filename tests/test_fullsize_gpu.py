@@ -159,7 +159,6 @@ def _baby_case(modal):
         model.load_state_dict(state0)
         model = model.to(DEV).train()
         step = HotPathStep(model, graphs_g, 1024, decay=1e-5)
-        step.materialize_grads = True       # these tests read every `.grad` (default: the projection gradients stay partials)
         step.keep_masks = tuple(k.to(torch.uint8).to(DEV) for k in km)
         step.set_batch(users.to(DEV), pos.to(DEV), neg.to(DEV))
         return model, step
@@ -262,3 +261,85 @@ def test_tiktok_three_modalities_v_a_t_match_oracle_extension():
               "item_id_embedding.weight", "weight_dict.w_self_attention_cat"):
         e = H.rel_err(model.get_parameter(k).grad.cpu(), P[k].grad)
         assert e < 5e-4, (k, e)
+
+
+def test_tiktok_20_step_trajectory_matches_oracle_with_torch_adamw():
+    """configs[1] as a TRAJECTORY: 20 hot-path steps (forward, BPR + 2x InfoNCE + regulariser, backward, fused AdamW) on the
+    Tiktok shape against 20 steps of the oracle driven by torch.optim.AdamW on the CPU — a different batch every step,
+    fixed injected dropout masks, sparse modal graphs (so the InfoNCE views and w_self_attention_cat carry gradient).
+    Eager steps and hipGraph replays: every step's loss within 1e-4, the final parameters within 5e-4 of the largest
+    entry (1/100 of their movement) and every row of the embedding tables within 1 % of its own movement."""
+    from mmssl_amd.graph import GraphPlan
+    from mmssl_amd.hotpath import HotPathStep
+    from mmssl_amd.Models import MMSSL
+    from mmssl_amd import config
+    U, I, dv, dt, raw, ui, iu, P_ui, P_iu = _setup("tiktok")
+    config.configure([], drop_rate=0.2, batch_size=1024, weight_size=str([64] * 3), debug=True)
+    g = torch.Generator().manual_seed(0)
+    img, txt = torch.randn(I, dv, generator=g), torch.randn(I, dt, generator=g)
+    torch.manual_seed(4)
+    cpu_model = MMSSL(U, I, 64, [64] * 3, [0.1] * 3, img.numpy(), txt.numpy())
+    state0 = {k: v.detach().clone() for k, v in cpu_model.state_dict().items()}
+    del cpu_model
+    km = [(torch.rand(I, 64, generator=g) >= 0.2) for _ in range(2)]
+    rng = np.random.default_rng(1)
+    us = rng.choice(U, 1024, replace=False)
+    modal = sp.csr_matrix((np.ones(1024, np.float32), (us, rng.integers(0, I, 1024))), shape=(U, I))
+    m_ui, m_iu = O.csr_norm(modal, True).tocsr(), O.csr_norm(modal.T, True).tocsr()
+    A = [O.to_torch_sparse(x) for x in (ui, iu, m_ui, m_iu, m_ui, m_iu)]
+    steps = 20
+    batches = [(torch.from_numpy(rng.choice(U, 1024, replace=False)), torch.from_numpy(rng.integers(0, I, 1024)),
+                torch.from_numpy(rng.integers(0, I, 1024))) for _ in range(steps)]
+    names = ("image_trans.weight", "image_trans.bias", "text_trans.weight", "text_trans.bias", "user_id_embedding.weight",
+             "item_id_embedding.weight", "weight_dict.w_self_attention_cat")
+    # ---- oracle trajectory -------------------------------------------------------------------------------------
+    P = {k: v.clone().requires_grad_(k in names) for k, v in state0.items()
+         if not k.startswith(("image_embedding", "text_embedding", "batch_norm", "encoder.", "align."))}
+    opt = torch.optim.AdamW([P[k] for k in names], lr=5.5e-4)          # main.py:76-80 (default betas / eps / weight decay)
+    cfg = O.Cfg(drop_rate=0.2, n_ui_layers=3, batch_size=1024)
+    ref_losses = []
+    for users, pos, neg in batches:
+        opt.zero_grad()
+        o = O.forward(P, img, txt, A, cfg, training=True, keep_masks=[k.float() for k in km])
+        mf, emb, _ = O.bpr(o[0][users], o[1][pos], o[1][neg], 1e-5, 1024)
+        loss = mf + emb + O.feat_reg(o[2], o[3], o[4], o[5], I, 1e-5) + 0.03 * (
+            O.infonce(o[8][users], o[6][users], 0.5) + O.infonce(o[9][users], o[6][users], 0.5))
+        loss.backward()
+        opt.step()
+        ref_losses.append(float(loss))
+    assert ref_losses[-1] != ref_losses[0]
+    # ---- HIP: eager steps, then replays of the captured step from the same start -----------------------------------
+    graphs_g = (P_ui, P_iu, GraphPlan(m_ui), GraphPlan(m_iu), GraphPlan(m_ui), GraphPlan(m_iu))
+    for mode in ("eager", "graph"):
+        model = MMSSL(U, I, 64, [64] * 3, [0.1] * 3, img.numpy(), txt.numpy())
+        model.load_state_dict(state0)
+        model = model.to(DEV).train()
+        step = HotPathStep(model, graphs_g, 1024, decay=1e-5)
+        step.keep_masks = tuple(k.to(torch.uint8).to(DEV) for k in km)
+        if mode == "graph":
+            step.set_batch(*(x.to(DEV) for x in batches[0]))
+            assert step.capture(warmup=2), getattr(step, "capture_error", "")
+            with torch.no_grad():
+                for k, p in model.named_parameters():
+                    p.copy_(state0[k])
+            step.optimizer.reset_state()
+        got = []
+        for users, pos, neg in batches:
+            step.set_batch(users.to(DEV), pos.to(DEV), neg.to(DEV))
+            step.run()
+            torch.cuda.synchronize()
+            got.append(float(step.loss))
+        np.testing.assert_allclose(got, ref_losses, rtol=1e-4, atol=0, err_msg=mode)
+        named = dict(model.named_parameters())
+        for k in names:
+            # AdamW normalises every element's step to ~lr whatever its gradient's size, so an element whose gradient
+            # is small next to the fp32 rounding of either implementation may move differently by O(lr): the bound is
+            # 5e-4 of the largest entry and at most 1/100 of how far training moved the tensor
+            e = H.rel_err(named[k].detach().cpu(), P[k].detach())
+            moved = H.rel_err(state0[k], P[k].detach())
+            assert e < 5e-4 and moved > 100 * e, (mode, k, e, moved)
+        for k in ("user_id_embedding.weight", "item_id_embedding.weight"):
+            a, b = named[k].detach().cpu().double(), P[k].detach().double()
+            d0 = (b - state0[k].double()).abs().amax(1)                     # how far the oracle moved each row
+            err = (a - b).abs().amax(1)
+            assert float((err / (d0 + 1e-2 * float(d0.max()))).max()) < 1e-2, (mode, k)

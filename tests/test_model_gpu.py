@@ -192,16 +192,17 @@ def test_train_step_with_injected_dropout_matches_oracle(tmp_path):
 
 
 def test_hotpath_graph_replay_with_stream_overlap_matches_eager_sequential():
-    """The whole step captured into a hipGraph with the three forked streams of ops.hot_forward must
-    give the same training trajectory as eager, single-stream execution of the same ops."""
-    import os
+    """The whole step captured into a hipGraph with the forked streams of the hot node must give the same training
+    trajectory as eager, single-stream execution of the same ops. drop_rate 0.2 with masks drawn inside the projection:
+    every variant starts from the same generator state, so all of them see the same masks."""
     import scipy.sparse as sp
     from mmssl_amd import synth
     from mmssl_amd.graph import GraphPlan
     from mmssl_amd.hotpath import HotPathStep
     from mmssl_amd.Models import MMSSL
     U, I, E, dv, dt, B = 3000, 1700, 30000, 256, 128, 512
-    _configure(drop_rate=0.0, batch_size=B, weight_size="[64, 64, 64]")
+    _configure(drop_rate=0.2, batch_size=B, weight_size="[64, 64, 64]")
+    from mmssl_amd import ops
     raw = synth.interaction_matrix(U, I, E, seed=5)
     ui, iu = synth.normalised_pair(raw)
     g = torch.Generator().manual_seed(3)
@@ -211,17 +212,13 @@ def test_hotpath_graph_replay_with_stream_overlap_matches_eager_sequential():
 
     def run(overlap, capture, eager_loss=True):
         """One warm-up step on batch 0 (eager; inside capture() for the captured run), then the 4 batches."""
-        os.environ["MMSSL_STREAMS"] = "1" if overlap else "0"
-        os.environ["MMSSL_EAGER_LOSS_BWD"] = "1" if eager_loss else "0"
         torch.manual_seed(11)
+        ops.seed_dropout(11)
         model = MMSSL(U, I, 64, [64] * 3, [0.1] * 3, img, txt).to(DEV).train()
         e1, e2 = GraphPlan(sp.csr_matrix((U, I), dtype=np.float32)), GraphPlan(sp.csr_matrix((I, U), dtype=np.float32))
-        step = HotPathStep(model, (GraphPlan(ui), GraphPlan(iu), e1, e2, e1, e2), B)
-        # the eager-loss runs keep the projection gradients as split-K partials added inside AdamW (the default), the
-        # autograd-loss run materialises them through the reduce launch: same trajectory either way
-        step.materialize_grads = not eager_loss
+        step = HotPathStep(model, (GraphPlan(ui), GraphPlan(iu), e1, e2, e1, e2), B, overlap=overlap, eager_loss=eager_loss)
         step.set_batch(*[t.to(DEV) for t in batches[0]])
-        if capture:
+        if capture:            # one executed warm-up step (the capture pass itself only records)
             assert step.capture(warmup=1), getattr(step, "capture_error", "")
         else:
             step.step()
@@ -233,16 +230,12 @@ def test_hotpath_graph_replay_with_stream_overlap_matches_eager_sequential():
             losses.append(float(step.loss))
         return losses, model.item_id_embedding.weight.detach().cpu().clone(), model.image_trans.weight.detach().cpu().clone()
 
-    try:
-        ref_l, ref_e, ref_w = run(overlap=False, capture=False)          # one stream, eager
-        got_l, got_e, got_w = run(overlap=True, capture=True)            # forked streams inside a hipGraph
-        ov_l, ov_e, ov_w = run(overlap=True, capture=False)              # forked streams, eager
-        # the loss section as autograd launches it (separate loss kernels, backward after the loss assembly) instead of
-        # the single chain with the gradients launched in the forward (ops._BatchLosses._forward_eager)
-        ag_l, ag_e, ag_w = run(overlap=True, capture=True, eager_loss=False)
-    finally:
-        os.environ.pop("MMSSL_STREAMS", None)
-        os.environ.pop("MMSSL_EAGER_LOSS_BWD", None)
+    ref_l, ref_e, ref_w = run(overlap=False, capture=False)          # one stream, eager
+    got_l, got_e, got_w = run(overlap=True, capture=True)            # forked streams inside a hipGraph
+    ov_l, ov_e, ov_w = run(overlap=True, capture=False)              # forked streams, eager
+    # the loss section as autograd launches it (separate loss kernels, backward after the loss assembly) instead of
+    # the single chain with the gradients launched in the forward (ops._BatchLosses._forward_eager)
+    ag_l, ag_e, ag_w = run(overlap=True, capture=True, eager_loss=False)
     assert all(np.isfinite(got_l)) and all(np.isfinite(ref_l))
     # Streams and graph replay change WHEN kernels run, never what they compute (every reduction has a fixed
     # order): the three trajectories agree to rounding. In a replayed graph the chains really overlap on the
@@ -361,3 +354,83 @@ def test_baselines_match_reference_classes(name):
     assert H.rel_err(outs2[1].detach().cpu(), fx["o.ia"]) < 2e-5
     outs2[1].sum().backward()
     assert model.image_trs.weight.grad is None or float(model.image_trs.weight.grad.abs().max()) == 0.0
+
+
+# ---------------------------------------------------------------------------------------------------
+# G12: the reference's own Trainer.train() for 8 batches + its evaluation, recorded by oracle/gen_golden.py g12
+# (every random tensor of the loop injected): K-step trajectory and Recall@20 parity of the product Trainer
+# ---------------------------------------------------------------------------------------------------
+def _g12_run(tmp_path, graph_flag):
+    import os
+    from mmssl_amd import config
+    from mmssl_amd.utility import batch_test
+    fx = H.load("g12_train_trajectory.npz")
+    n = int(fx["n_batches"])
+    root = H.write_dataset_dir(str(tmp_path))
+    _configure(data_path=root, dataset="tiny", drop_rate=0.0, G_drop1=0.0, G_drop2=0.0, m_topk_rate=float(fx["m_topk_rate"]),
+               T=1, epoch=1)
+    dg = batch_test.init_data()
+    from mmssl_amd.main import Trainer, set_seed
+    set_seed(2022)
+    os.environ["MMSSL_TRAINER_GRAPH"] = graph_flag
+    try:
+        tr = Trainer(data_config={})
+        # the sampler after set_seed + Trainer(): the same batches the reference's loop drew
+        for b in range(n):
+            u, p, q = dg.sample()
+            assert [int(x) for x in u] == fx["b%d.users" % b].tolist() and [int(x) for x in p] == fx["b%d.pos" % b].tolist() \
+                and [int(x) for x in q] == fx["b%d.neg" % b].tolist(), b
+        missing = tr.model.load_state_dict({k[3:]: torch.from_numpy(fx[k]) for k in fx.files if k.startswith("m0.")}, strict=False)
+        assert all(k.startswith(("encoder.", "align.")) for k in missing.missing_keys), missing
+        tr.D.load_state_dict({k[3:]: torch.from_numpy(fx[k]) for k in fx.files if k.startswith("D0.")})
+        cur = {"b": 0}
+        tr.noise_hook = lambda kind, shape: torch.from_numpy(fx["b%d.%s" % (cur["b"], "gumbel_u" if kind == "gumbel" else "gp_alpha")]).reshape(shape)
+        rows, used = [], []
+        for b in range(n):
+            cur["b"] = b
+            tr.model.train()
+            users, pos, neg = (fx["b%d.%s" % (b, k)].tolist() for k in ("users", "pos", "neg"))
+            out = tr.train_batch(b, users, pos, neg)
+            rows.append([float(out[0]), float(out[1]), float(out[2]), float(out[4]), float(out[5])])
+            used.append(getattr(tr, "_split", None) not in (None, False))
+        torch.cuda.synchronize()
+        want = np.array([[float(fx["b%d.%s" % (b, k)]) for k in ("batch_loss", "mf", "emb")]
+                         + [float(fx["b%d.cl1" % b]) + float(fx["b%d.cl2" % b]), float(fx["b%d.G_lossf" % b])] for b in range(n)])
+        got = np.array(rows)
+        P = {k: v.detach().cpu() for k, v in tr.model.state_dict().items()}
+        assert tr.image_ui_graph._nnz() == int(fx["final.img_ui_nnz"]) == 0
+        tr.model.eval()
+        with torch.no_grad():
+            outs = tr.model(*tr._graphs())
+        ev = {}
+        for nm, is_val in (("val", True), ("test", False)):
+            ev[nm] = tr.test([int(u) for u in fx[nm + ".users"]], is_val)
+        return fx, got, want, used, P, outs[0].cpu(), outs[1].cpu(), ev
+    finally:
+        os.environ.pop("MMSSL_TRAINER_GRAPH", None)
+
+
+@pytest.mark.parametrize("graph_flag", ["0", "1"])
+def test_g12_trainer_trajectory_and_recall_match_reference(tmp_path, graph_flag):
+    """8 batches of the REFERENCE loop (batches 0-1 on the interaction graph, 2 on the top-1 graph, 3+ on empty modal
+    graphs; discriminator step, gradient penalty, generator step, AdamW / Adam) against the product Trainer with the
+    reference's Gumbel uniforms and penalty alphas injected: every batch loss component 1e-4, the final parameters
+    1e-4, the eval-mode embeddings 1e-4, and Recall / NDCG / precision / hit @ 10, 20, 50 EXACTLY - op by op
+    (graph_flag 0) and on the captured hot path (SplitHotPath from the fifth batch on)."""
+    fx, got, want, used, P, ua, ia, ev = _g12_run(tmp_path, graph_flag)
+    if graph_flag == "1":
+        assert used[-1] and used.count(True) >= 3, used
+    else:
+        assert not any(used)
+    np.testing.assert_allclose(got[:, :4], want[:, :4], rtol=1e-4, atol=1e-7)
+    np.testing.assert_allclose(got[:, 4], want[:, 4], rtol=1e-4, atol=1e-5)           # -mean(100 * sigmoid(.))
+    for k in ("image_trans.weight", "image_trans.bias", "text_trans.weight", "text_trans.bias", "user_id_embedding.weight",
+              "item_id_embedding.weight", "weight_dict.w_self_attention_cat"):
+        e = H.rel_err(P[k], fx["m1." + k])
+        assert e < 1e-4, (k, e)
+        moved = H.rel_err(fx["m0." + k], fx["m1." + k])
+        assert moved > 10 * e, (k, moved, e)                     # the comparison is not vacuous: training moved it
+    assert H.rel_err(ua, fx["eval.ua"]) < 1e-4 and H.rel_err(ia, fx["eval.ia"]) < 1e-4
+    for nm in ("val", "test"):
+        for k in ("precision", "recall", "ndcg", "hit_ratio"):
+            np.testing.assert_allclose(ev[nm][k], fx["%s.%s" % (nm, k)], rtol=1e-12, atol=1e-15, err_msg=nm + k)

@@ -334,78 +334,99 @@ def test_batch_losses_eager_chain_matches_oracle_and_autograd_form():
         assert H.rel_err(a.grad.cpu(), b.grad.cpu()) < 1e-5
 
 
-_OPTIN_SNIPPET = r"""
-import sys, torch
-sys.path.insert(0, %r)
-from mmssl_amd import ops
-g = torch.Generator().manual_seed(5)
-worst = 0.0
-for M, K, N in ((1000, 128, 64), (777, 4096, 64), (2049, 768, 128), (18357, 1024, 64)):
-    F_ = torch.randn(M, K, generator=g); W = torch.randn(N, K, generator=g) / K ** 0.5; b = torch.randn(N, generator=g)
-    keep = (torch.rand(M, N, generator=g) >= 0.2).to(torch.uint8); C = torch.randn(M, N, generator=g)
-    Wr = W.clone().requires_grad_(True); br = b.clone().requires_grad_(True)
-    yr = torch.nn.functional.linear(F_, Wr, br) * keep * 1.25
-    (yr * C).sum().backward()
-    Wg = W.clone().cuda().requires_grad_(True); bg = b.clone().cuda().requires_grad_(True)
-    yg = ops.linear(F_.cuda(), Wg, bg, keep.cuda(), 1.25)
-    (yg * C.cuda()).sum().backward()
-    rel = lambda a, r: float((a.cpu() - r).norm() / r.norm())
-    worst = max(worst, rel(yg.detach(), yr.detach()), rel(Wg.grad, Wr.grad) / 3, rel(bg.grad, br.grad) / 3)
-    tol = 3e-6 * max(1.0, (K / 128.0) ** 0.5)
-    assert worst < tol, (M, K, N, worst, tol)
-print("OK", worst)
-"""
-
-
-@pytest.mark.parametrize("env", [{"MMSSL_GEMM_V": "9"}, {"MMSSL_GEMM_FIXUP": "1"}, {"MMSSL_GEMM_NT": "1"},
-                                 {"MMSSL_WGRAD_V": "5"}, {"MMSSL_WG10_BLOCKS": "256"}])
-def test_linear_optin_kernel_generations(env):
-    """The projection's opt-in kernels (chosen by environment variables that the library reads once per process):
-    register-direct forward (v9), in-kernel stream-K fix-up, non-temporal streaming, the register-staged weight
-    gradient (v5) and the one-block-per-CU decomposition of the default one, each against torch in its own process."""
-    import os, subprocess, sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    e = dict(os.environ); e.update(env)
-    r = subprocess.run([sys.executable, "-c", _OPTIN_SNIPPET % root], env=e, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0 and "OK" in r.stdout, (env, r.stdout[-500:], r.stderr[-1500:])
-
-
-@pytest.mark.parametrize("G", [1, 2, 3])
-def test_propagate_fuse_matches_oracle(G):
-    """The fused post-projection node (modal SpMM chains + 2G GCN SpMM + layer mean + modality fusion
-    + regulariser sum; backward made of epilogue-fused SpMMs only) vs the oracle's op-by-op autograd."""
+@pytest.mark.parametrize("G,overlap", [(1, True), (2, False), (3, True)])
+def test_hot_node_matches_oracle(G, overlap):
+    """The packed forward node (hotnode._HotNode: grouped projection + dropout, modal SpMM chain of width 2 d, 2G GCN
+    SpMMs, layer mean + modality fusion + regulariser sum; backward = epilogue-fused SpMMs with the dropout backward in
+    the last one, grouped weight gradient) vs the oracle's op-by-op autograd, incl. a gradient that arrives on a modal
+    feature output itself."""
     ops, graph = _ops()
     import torch.nn.functional as F
+    from mmssl_amd import hotnode
     raw = _rand_graph(500, 330, 7, seed=40 + G, heavy=[(3, 200), (9, 40)], empty=[1])
     raw.data[:] = 1.0
     ui_m, iu_m = O.csr_norm(raw, True).tocsr(), O.csr_norm(raw.T, True).tocsr()
     ui, iu = graph.GraphPlan(ui_m), graph.GraphPlan(iu_m)
     A_ui, A_iu = O.to_torch_sparse(ui_m), O.to_torch_sparse(iu_m)
     gen = torch.Generator().manual_seed(G)
-    U, I, d = 500, 330, 64
-    names = ["u0", "i0", "x_img", "x_txt"]
-    base = [torch.randn(U, d, generator=gen), torch.randn(I, d, generator=gen), torch.randn(I, d, generator=gen),
-            torch.randn(I, d, generator=gen)]
+    U, I, d, Ks = 500, 330, 64, (96, 160)
+    Fs = [torch.randn(I, k, generator=gen) for k in Ks]
+    base = [torch.randn(U, d, generator=gen), torch.randn(I, d, generator=gen)] + \
+           [torch.randn(d, k, generator=gen) / k ** 0.5 for k in Ks] + [torch.randn(d, generator=gen) * 0.1 for _ in Ks]
+    names = ["u0", "i0", "W_img", "W_txt", "b_img", "b_txt"]
+    keep = (torch.rand(2, I, d, generator=gen) >= 0.2)
+    scale = 1.25
     Cu, Ci = torch.randn(U, d, generator=gen), torch.randn(I, d, generator=gen)
     Cx = torch.randn(U, d, generator=gen)
     R = [t.clone().requires_grad_(True) for t in base]
-    img_u = O.spmm(A_ui, R[2]); img_i = O.spmm(A_iu, img_u)
-    txt_u = O.spmm(A_ui, R[3]); txt_i = O.spmm(A_iu, txt_u)
+    x = [(Fs[m] @ R[2 + m].t() + R[4 + m]) * keep[m].float() * scale for m in range(2)]
+    img_u = O.spmm(A_ui, x[0]); img_i = O.spmm(A_iu, img_u)
+    txt_u = O.spmm(A_ui, x[1]); txt_i = O.spmm(A_iu, txt_u)
     u_ref, i_ref = O.gcn_propagate(A_ui, A_iu, R[0], R[1], G)
     u_ref = u_ref + 0.55 * F.normalize(img_u) + 0.55 * F.normalize(txt_u)
     i_ref = i_ref + 0.55 * F.normalize(img_i) + 0.55 * F.normalize(txt_i)
     ss_ref = (img_u ** 2).sum() + (txt_u ** 2).sum() + (img_i ** 2).sum() + (txt_i ** 2).sum()
-    # the modal outputs are also consumed directly (exercise the extra-gradient branch)
     ((u_ref * Cu).sum() + (i_ref * Ci).sum() + 0.37 * ss_ref + (txt_u * Cx).sum()).backward()
     Gt = [t.clone().to(DEV).requires_grad_(True) for t in base]
-    u_g, i_g, ss, o_ii, o_ti, o_iu, o_tu = ops.propagate_fuse(ui, iu, Gt[0], Gt[1], Gt[2], Gt[3], G, 0.55)
-    assert H.rel_err(u_g.detach().cpu(), u_ref.detach()) < 3e-6
-    assert H.rel_err(i_g.detach().cpu(), i_ref.detach()) < 3e-6
-    assert H.rel_err(o_ii.detach().cpu(), img_i.detach()) < 3e-6 and H.rel_err(o_tu.detach().cpu(), txt_u.detach()) < 3e-6
-    assert abs(float(ss) - float(ss_ref)) <= 2e-6 * float(ss_ref)
-    ((u_g * Cu.to(DEV)).sum() + (i_g * Ci.to(DEV)).sum() + 0.37 * ss + (o_tu * Cx.to(DEV)).sum()).backward()
+    hot = hotnode.HotCtx(torch.device(DEV, torch.cuda.current_device()), overlap=overlap)
+    u_g, i_g, ss, MI, MU = hotnode.hot_node(hot, [f.to(DEV) for f in Fs], Gt[2:4], Gt[4:6], keep.to(torch.uint8).to(DEV), 0.0,
+                                            scale, Gt[0], Gt[1], ui, iu, G, 0.55)
+    assert MI.shape == (I, 2 * d) and MU.shape == (U, 2 * d)
+    assert H.rel_err(u_g.detach().cpu(), u_ref.detach()) < 1e-5
+    assert H.rel_err(i_g.detach().cpu(), i_ref.detach()) < 1e-5
+    assert H.rel_err(MI[:, :d].detach().cpu(), img_i.detach()) < 1e-5 and H.rel_err(MU[:, d:].detach().cpu(), txt_u.detach()) < 1e-5
+    assert abs(float(ss) - float(ss_ref)) <= 1e-5 * float(ss_ref)
+    ((u_g * Cu.to(DEV)).sum() + (i_g * Ci.to(DEV)).sum() + 0.37 * ss + (MU[:, d:] * Cx.to(DEV)).sum()).backward()
+    torch.cuda.synchronize()
     for n, a, b in zip(names, Gt, R):
-        assert H.rel_err(a.grad.cpu(), b.grad) < 2e-5, n
+        assert H.rel_err(a.grad.cpu(), b.grad) < 5e-5, n
+
+
+def test_hot_node_draws_masks_and_two_contexts_do_not_interfere():
+    """p_drop > 0 without given masks: the node draws them in the projection's epilogue (same bytes as
+    ops.dropout_masks at that generator state) and advances the generator itself; and two HotCtx objects used
+    alternately on two streams reproduce what each gives alone (no shared state between step objects)."""
+    ops, graph = _ops()
+    from mmssl_amd import hotnode
+    raw = _rand_graph(300, 200, 5, seed=3)
+    raw.data[:] = 1.0
+    ui, iu = graph.GraphPlan(O.csr_norm(raw, True).tocsr()), graph.GraphPlan(O.csr_norm(raw.T, True).tocsr())
+    gen = torch.Generator().manual_seed(0)
+    U, I, d, Ks = 300, 200, 64, (64, 128)
+    dev = torch.device(DEV, torch.cuda.current_device())
+    Fs = [torch.randn(I, k, generator=gen).to(DEV) for k in Ks]
+    Ws = [(torch.randn(d, k, generator=gen) / k ** 0.5).to(DEV) for k in Ks]
+    bs = [torch.zeros(d, device=DEV) for _ in Ks]
+    u0, i0 = torch.randn(U, d, generator=gen).to(DEV), torch.randn(I, d, generator=gen).to(DEV)
+
+    def run(hot, keep, p):
+        with torch.no_grad():
+            return hotnode.hot_node(hot, Fs, Ws, bs, keep, p, 1.25, u0, i0, ui, iu, 2, 0.55)
+    ops.seed_dropout(5, dev)
+    want = ops.dropout_masks(2, I, d, 0.2, dev)              # counter 0 -> these bytes; counter is 1 afterwards
+    ref = run(hotnode.HotCtx(dev), want.contiguous(), 0.0)
+    ops.seed_dropout(5, dev)
+    got = run(hotnode.HotCtx(dev), None, 0.2)                # draws with counter 0, then ticks
+    for a, b in zip(got, ref):
+        assert torch.equal(a, b)
+    assert int(ops._rng_state(dev)[1]) == 1
+    # two contexts, two streams, interleaved
+    h1, h2 = hotnode.HotCtx(dev), hotnode.HotCtx(dev)
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    k1 = want.contiguous()
+    k2 = (1 - want).contiguous()
+    solo1, solo2 = run(hotnode.HotCtx(dev), k1, 0.0), run(hotnode.HotCtx(dev), k2, 0.0)
+    torch.cuda.synchronize()
+    outs = []
+    for _ in range(3):
+        with torch.cuda.stream(s1):
+            o1 = run(h1, k1, 0.0)
+        with torch.cuda.stream(s2):
+            o2 = run(h2, k2, 0.0)
+        outs.append((o1, o2))
+    torch.cuda.synchronize()
+    for o1, o2 in outs:
+        assert all(torch.equal(a, b) for a, b in zip(o1, solo1)) and all(torch.equal(a, b) for a, b in zip(o2, solo2))
 
 
 @pytest.mark.parametrize("d", [64, 128])
@@ -599,50 +620,6 @@ def test_spmm_concurrent_launches_on_one_plan_do_not_share_state():
             torch.cuda.synchronize()
             for k in range(3):
                 assert torch.equal(outs[k], refs[(k + rnd) % 3]), (rnd, k)
-
-
-def test_split_precision_projection_kernels():
-    """OPT-IN split-precision product (mmssl_linear_split_f32 and its two preparation kernels; the default path
-    does not use them): hi + lo reproduces x to 2^-16, the transposing preparation equals its definition, and the
-    three-product result is within 2e-5 (max-norm relative) of an fp64 reference, forward and wgrad form."""
-    from mmssl_amd import ops, _lib
-    L = _lib.lib()
-    torch.manual_seed(9)
-    M, K, N = 1000, 512, 64
-    F_ = torch.randn(M, K, device=DEV)
-    W = torch.randn(N, K, device=DEV) * 0.05
-    b = torch.randn(N, device=DEV)
-    hi, lo = ops._split_pair_dev(F_)
-    assert hi.dtype == torch.bfloat16 and torch.equal(hi, F_.to(torch.bfloat16))            # round-to-nearest-even
-    rec = hi.float() + lo.float()
-    assert float(((rec - F_).abs() / F_.abs().clamp_min(1e-30)).max()) < 2.0 ** -15
-    Wh, Wl = ops._split_pair_dev(W)
-    keep = (torch.rand(M, N, device=DEV) > 0.2).to(torch.uint8)
-    Y = ops._split_call(hi, lo, Wh, Wl, b, keep, 1.25, M, K, N)
-    ref = ((F_.double() @ W.double().t()) + b.double()) * keep.double() * 1.25
-    assert float((Y.double() - ref).abs().max() / ref.abs().max()) < 2e-5
-    # wgrad form: gW [N, K] = gY^T . F with the reduction padded to Mp, operands prepared by the fused kernel
-    gY = torch.randn(M, N, device=DEV)
-    Mp = (M + 127) // 128 * 128
-    FT = torch.zeros(K, Mp, device=DEV)
-    FT[:, :M] = F_.t()
-    FTh, FTl = ops._bf16_pair(FT)
-    gTh = torch.empty(N, Mp, dtype=torch.bfloat16, device=DEV)
-    gTl = torch.empty_like(gTh)
-    gb = torch.empty(N, device=DEV)
-    nb = L.mmssl_split_transpose_workspace_bytes(Mp, N)
-    ws = torch.empty(nb // 4 + 4, device=DEV)
-    rc = L.mmssl_split_transpose_bf16_f32(gY.data_ptr(), keep.data_ptr(), 1.25, M, N, Mp, gTh.data_ptr(), gTl.data_ptr(),
-                                          gb.data_ptr(), ws.data_ptr(), ws.numel() * 4, _lib.stream_ptr())
-    assert rc == 0
-    gYm = gY * keep.float() * 1.25
-    exp_hi, exp_lo = ops._bf16_pair(gYm.t().contiguous())
-    assert torch.equal(gTh[:, :M], exp_hi) and torch.equal(gTl[:, :M], exp_lo)
-    assert float(gTh[:, M:].float().abs().max()) == 0.0 and float(gTl[:, M:].float().abs().max()) == 0.0
-    assert torch.allclose(gb, gYm.sum(0), rtol=1e-5, atol=1e-5)
-    gW = ops._split_call(gTh, gTl, FTh, FTl, None, None, 1.0, N, Mp, K)
-    refw = gYm.double().t() @ F_.double()
-    assert float((gW.double() - refw).abs().max() / refw.abs().max()) < 2e-5
 
 
 # ---------------------------------------------------------------------------------------------------

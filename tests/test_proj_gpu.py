@@ -1,0 +1,99 @@
+"""Grouped projection kernels (csrc/projection.hip: all modalities of a step in one stream-K launch) against torch-CPU
+fp32 of the same op: nn.Linear + nn.Dropout of every modality (Models.py:28-29, 54, 173-174) and its weight / bias
+gradients. Shapes: Baby (configs[2]), Tiktok V/A/T (configs[1]), ragged row counts, a single problem."""
+import numpy as np
+import pytest
+import torch
+
+import helpers as H
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _problem(M, Ks, seed):
+    g = torch.Generator().manual_seed(seed)
+    Fs = [torch.randn(M, k, generator=g) for k in Ks]
+    Ws = [torch.randn(64, k, generator=g) * (1.0 / k ** 0.5) for k in Ks]
+    bs = [torch.randn(64, generator=g) * 0.1 for _ in Ks]
+    keep = (torch.rand(len(Ks), M, 64, generator=g) >= 0.2).to(torch.uint8)
+    return Fs, Ws, bs, keep
+
+
+@pytest.mark.parametrize("M,Ks", [(18357, (4096, 1024)), (6710, (128, 768, 128)), (1000, (64,)), (257, (32, 96)),
+                                  (256, (4096,))])
+def test_proj_forward_matches_torch(M, Ks):
+    from mmssl_amd import ops
+    assert ops.proj_supported(Ks, M, 64)
+    Fs, Ws, bs, keep = _problem(M, Ks, 1)
+    Fd, Wd, bd = [f.to(DEV) for f in Fs], [w.to(DEV) for w in Ws], [b.to(DEV) for b in bs]
+    scale = 1.25
+    Y, _ = ops.proj_forward(Fd, Wd, bd, keep=keep.to(DEV), scale=scale)
+    assert Y.shape == (M, 64 * len(Ks))
+    Y2, _ = ops.proj_forward(Fd, Wd, bd, keep=keep.to(DEV), scale=scale)
+    assert torch.equal(Y, Y2)                                   # fixed-order partial sums: bitwise reproducible
+    Yn, _ = ops.proj_forward(Fd, Wd, [None] * len(Ks), scale=1.0)       # eval mode: no bias here, no dropout
+    for g in range(len(Ks)):
+        lin = Fs[g] @ Ws[g].t()
+        ref = (lin + bs[g]) * keep[g].float() * scale
+        assert H.rel_err(Y[:, 64 * g:64 * g + 64].cpu(), ref) < 2e-5, (g, Ks[g])
+        assert H.rel_err(Yn[:, 64 * g:64 * g + 64].cpu(), lin) < 2e-5, (g, Ks[g])
+        # the same numbers as the per-modality kernel of ops.linear (same fp32 MFMA arithmetic, other summation order)
+        one = ops.linear(Fd[g], Wd[g], bd[g], keep[g].to(DEV), scale)
+        assert H.rel_err(Y[:, 64 * g:64 * g + 64].cpu(), one.cpu()) < 2e-5
+
+
+def test_proj_forward_draws_the_masks_of_dropout_masks():
+    """draw=(p, state): the epilogue's inline generator reproduces ops.dropout_masks at the same generator state, the
+    output is the given-mask result for those masks, and the state itself is left to the caller (external tick)."""
+    from mmssl_amd import ops
+    M, Ks = 5000, (96, 160)
+    Fs, Ws, bs, _ = _problem(M, Ks, 2)
+    Fd, Wd, bd = [f.to(DEV) for f in Fs], [w.to(DEV) for w in Ws], [b.to(DEV) for b in bs]
+    dev = torch.device(DEV, torch.cuda.current_device())
+    ops.seed_dropout(77, dev)
+    st = ops._rng_state(dev)
+    before = st.clone()
+    Y, keep = ops.proj_forward(Fd, Wd, bd, draw=(0.2, st), scale=1.25)
+    assert torch.equal(st, before)
+    want = ops.dropout_masks(len(Ks), M, 64, 0.2, dev)          # same state -> same bytes; advances the counter
+    assert torch.equal(keep, want)
+    assert 0.78 < float(keep.float().mean()) < 0.82
+    Yg, _ = ops.proj_forward(Fd, Wd, bd, keep=want.contiguous(), scale=1.25)
+    assert torch.equal(Y, Yg)
+    _, keep2 = ops.proj_forward(Fd, Wd, bd, draw=(0.2, st), scale=1.25)     # next counter value: other masks
+    assert not torch.equal(keep2, keep)
+
+
+@pytest.mark.parametrize("M,Ks", [(18357, (4096, 1024)), (6710, (128, 768, 128)), (1000, (64,)), (257, (32, 96)),
+                                  (33, (260,))])
+def test_proj_wgrad_matches_torch(M, Ks):
+    from mmssl_amd import ops
+    assert ops.proj_supported(Ks, M, 64, wgrad=True)
+    Fs, _, _, _ = _problem(M, Ks, 3)
+    g = torch.Generator().manual_seed(9)
+    G = torch.randn(M, 64 * len(Ks), generator=g)
+    G[G.abs() < 0.25] = 0.0                                       # like a dropout-masked gradient
+    Fd, Gd = [f.to(DEV) for f in Fs], G.to(DEV)
+    gW, gb = ops.proj_wgrad(Gd, Fd)
+    gW2, gb2 = ops.proj_wgrad(Gd, Fd)
+    for k in range(len(Ks)):
+        Gk = G[:, 64 * k:64 * k + 64]
+        assert H.rel_err(gW[k].cpu(), Gk.t() @ Fs[k]) < 2e-5, (k, Ks[k])
+        assert H.rel_err(gb[k].cpu(), Gk.sum(0)) < 2e-5, (k, Ks[k])
+        assert torch.equal(gW[k], gW2[k]) and torch.equal(gb[k], gb2[k])
+    # a G that is a column slice of a wider buffer (row pitch > 64 n)
+    wide = torch.zeros(M, 64 * len(Ks) + 64, device=DEV)
+    wide[:, :64 * len(Ks)] = Gd
+    gW3, _ = ops.proj_wgrad(wide[:, :64 * len(Ks)], Fd)
+    assert all(torch.equal(a, b) for a, b in zip(gW, gW3))
+
+
+def test_proj_rejects_what_it_cannot_run():
+    from mmssl_amd import ops, _lib
+    assert not ops.proj_supported((100,), 1000, 64)               # forward: K % 32
+    assert not ops.proj_supported((128,), 1000, 32)               # N != 64
+    assert ops.proj_supported((100,), 1000, 64, wgrad=True)
+    F_ = torch.randn(100, 100, device=DEV)
+    with pytest.raises(_lib.MmsslError):
+        ops.proj_forward([F_], [torch.randn(64, 100, device=DEV)], [None])

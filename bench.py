@@ -16,8 +16,9 @@ are row-sharded with an RCCL all-gather before every propagation layer (reduce-s
 `--scaling strong` = the Baby graph itself cut N ways (BASELINE configs[3]); `--workload synth` = the 100M-edge
 d=128 stress shape of configs[4] (2M x 1M over 8 ranks: 250K users x 125K items x 12.5M edges per rank).
 
-metric = edge.layers/s: nonzeros summed over EVERY SpMM launch of the step (forward and
-backward) / step time, whole job. One JSON line is printed by rank 0. Besides the contract fields it carries
+metric = edge.layers/s: d-wide multiply-adds per nonzero summed over EVERY SpMM launch of the step (forward and backward;
+a launch over the packed 2d-wide modal features counts two per nonzero, like the two d-wide launches it replaces) / step
+time, whole job. One JSON line is printed by rank 0. Besides the contract fields it carries
 `roofline` (the CSR SpMM, isolated, HIP events), `gcn_forward` (the 6-SpMM 3-layer propagation alone under hipGraph:
 the quantity north_star's ">= 60 % of the HBM roofline" target is stated on), `loss_check` (the first step's loss
 with injected dropout masks against the CPU oracle), `cpu_baseline`, and at N>1 `comm`.
@@ -82,13 +83,13 @@ def build_single_gpu(a, dev):
     txt = torch.randn(I, dt, generator=g).numpy()
     model = MMSSL(U, I, a.d, [a.d] * a.gcn_layers, [0.1] * a.gcn_layers, img, txt).to(dev)
     model.train()
-    step = HotPathStep(model, graphs, a.batch, decay=1e-5)
+    step = HotPathStep(model, graphs, a.batch, decay=1e-5, fuse_adam=not a.no_fuse_adam)
     return step, raw, (ui, iu), plans
 
 
-def count_edge_layers(step):
+def count_edge_layers(step, d):
     from mmssl_amd import ops
-    ops.STATS.update(enabled=True, spmm_launches=0, edge_layers=0, spmm_bytes=0)
+    ops.STATS.update(enabled=True, spmm_launches=0, edge_layers=0, spmm_bytes=0, unit_d=d)
     step.step()
     torch.cuda.synchronize()
     ops.STATS["enabled"] = False
@@ -185,6 +186,49 @@ def gcn_forward_record(plans, mats, d, n_layers, iters=200):
             "target_frac": 0.6}
 
 
+def projection_record(step, iters=40):
+    """The grouped modality projection alone (both modalities in one stream-K launch + epilogue): forward with bias +
+    dropout drawn in the epilogue, weight gradient + bias gradient from a masked output gradient; HIP events around
+    hipGraph replays. fp32 MFMA peak 157.3 TFLOP/s (guides/MI355X_MICROARCH.md)."""
+    from mmssl_amd import ops
+    m = step.model
+    Fs = [m.image_feats, m.text_feats]
+    Ws = [m.image_trans.weight.detach(), m.text_trans.weight.detach()]
+    bs = [m.image_trans.bias.detach(), m.text_trans.bias.detach()]
+    M = Fs[0].shape[0]
+    dev = Fs[0].device
+    flops = sum(2.0 * M * f.shape[1] * 64 for f in Fs)
+    st = ops._rng_state(dev).clone()
+    G = torch.randn(M, 128, device=dev)
+    out = {"what": "grouped projection of both modalities, one stream-K launch + epilogue each way", "GFLOP": round(flops * 1e-9, 3),
+           "peak_TFLOPs": 157.3}
+    with torch.no_grad():
+        for name, fn in (("forward", lambda: ops.proj_forward(Fs, Ws, bs, draw=(0.2, st), scale=1.25)),
+                         ("weight_gradient", lambda: ops.proj_wgrad(G, Fs))):
+            for _ in range(3):
+                fn()
+            g = torch.cuda.CUDAGraph()
+            s = torch.cuda.Stream()
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                torch.cuda.synchronize()
+                with torch.cuda.graph(g, stream=s, capture_error_mode="thread_local"):
+                    for _ in range(5):
+                        fn()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            with torch.cuda.stream(s):
+                g.replay()
+                e0.record()
+                for _ in range(iters):
+                    g.replay()
+                e1.record()
+            torch.cuda.synchronize()
+            us = e0.elapsed_time(e1) * 1e3 / (iters * 5)
+            out[name] = {"us": round(us, 1), "TFLOPs": round(flops / us * 1e-6, 1), "frac_mfma": round(flops / us * 1e-6 / 157.3, 3)}
+    return out
+
+
 def first_step_loss(a, step, raw, batch):
     """HIP side of the loss check: the loss of ONE hot-path forward on the bench model's initial parameters with
     injected dropout masks. Returns (loss, snapshot of the inputs) — cpu_baseline() evaluates the CPU oracle on the
@@ -209,7 +253,7 @@ def first_step_loss(a, step, raw, batch):
 
 def load_traffic():
     """HBM bytes per SpMM launch from the committed rocprofv3 PMC pass (profiles/*_pmc.json), if any."""
-    p = os.path.join(ROOT, "profiles", "spmm_pmc.json")
+    p = os.path.join(ROOT, "profiles", "r03_spmm_pmc.json")
     if os.path.exists(p):
         try:
             return json.load(open(p)).get("hbm_bytes_per_launch")
@@ -330,6 +374,8 @@ def main():
                     help="N>1: weak = shape x N (per-rank work fixed); strong = the shape itself cut N ways")
     ap.add_argument("--only", choices=["all", "steps", "roofline"], default="all",
                     help="profiling aid: run only the timed steps, or only the isolated SpMM roofline loop")
+    ap.add_argument("--no-fuse-adam", action="store_true", dest="no_fuse_adam",
+                    help="A/B aid: one AdamW launch after the backward instead of the fused / side-stream updates")
     ap.add_argument("--graph-probe", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--dist-graph", choices=["auto", "on", "off"], default="auto", nargs="?", const="on",
                     help="sharded path: capture the step (RCCL collectives included) into a hipGraph. auto = "
@@ -369,7 +415,7 @@ def main():
     comm = None
     if not sharded:
         step, raw, mats, plans = build_single_gpu(a, dev)
-        stats = count_edge_layers(step)
+        stats = count_edge_layers(step, a.d)
         if a.graph_probe:            # child process: does whole-step hipGraph capture + replay work here?
             ok = step.capture()
             if ok:
@@ -379,13 +425,17 @@ def main():
         first = None
         if rank == 0 and a.only == "all" and not a.no_cpu_baseline:
             first = first_step_loss(a, step, raw, make_batches(raw, 1, a.batch, seed=5)[0])
+        batches = [(torch.stack([torch.from_numpy(x).to(dev) for x in b]),)      # packed [3, B]
+                   for b in make_batches(raw, 8, a.batch, seed=2022)]
+        # the eight batches stay resident as a ring: every step picks slot (optimiser step mod 8) by a launch of its own
+        # (HotPathStep.set_batch_ring; BEFORE the capture: that launch is part of the step), so two replays are not
+        # separated by a host-issued copy
+        step.set_batch_ring(torch.stack([b[0] for b in batches]))
         captured = (not a.no_graph) and graph_capture_works(a) and step.capture()
         edge_layers_total = stats["edge_layers"]
         parallelism = "single"
         n_users, n_items, n_edges = int(raw.shape[0]), int(raw.shape[1]), int(raw.nnz)
         scaling = "weak"
-        batches = [(torch.stack([torch.from_numpy(x).to(dev) for x in b]),)      # packed [3, B]: one copy per step
-                   for b in make_batches(raw, 8, a.batch, seed=2022)]
     else:
         from mmssl_amd import dist as mdist
         scaling = "weak" if a.workload == "synth" else a.scaling
@@ -435,11 +485,18 @@ def main():
 
     def run_steps(n):
         for i in range(n):
-            step.set_batch(*batches[i % len(batches)])
+            if sharded:
+                step.set_batch(*batches[i % len(batches)])
             step.run()
 
     if a.only == "roofline":
         a.warmup, a.steps = 1, 1
+    # the isolated-kernel records first (they also bring the clocks up before the short timed region)
+    extra = {}
+    if rank == 0 and not sharded and a.only != "steps":
+        extra["roofline"] = spmm_roofline(plans, mats, a.d)
+        extra["gcn_forward"] = gcn_forward_record(plans, mats, a.d, a.gcn_layers)
+        extra["projection"] = projection_record(step)
     run_steps(a.warmup)
     if sharded:
         dist.barrier()
@@ -460,7 +517,7 @@ def main():
     shape_note = "" if world == 1 else (" x%d (weak: per-rank share fixed)" % world if scaling == "weak"
                                         else " cut %d ways (strong)" % world)
     out = {
-        "metric": "edge.layers/s (nonzeros of every SpMM launch per hot-path step / step time)",
+        "metric": "edge.layers/s (d-wide multiply-adds per nonzero over every SpMM launch of a hot-path step / step time)",
         "value": round(edge_layers_total / (ms * 1e-3), 1), "unit": "edge.layers/s", "n_gpus": world,
         "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 4), "higher_is_better": True,
         "scaling": scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -474,13 +531,14 @@ def main():
     if rank == 0:
         if not sharded:
             if a.only != "steps":
-                rf = spmm_roofline(plans, mats, a.d)
+                rf = extra["roofline"]
                 # the same byte model over the WHOLE step: every SpMM launch's algorithmic bytes / step time. The
                 # step is not SpMM-bound (projection GEMMs and the loss section share it), so this is far lower.
                 rf["step_spmm_GBps"] = round(stats["spmm_bytes"] / (ms * 1e-3) * 1e-9, 1)
                 rf["step_frac"] = round(rf["step_spmm_GBps"] / HBM_PEAK_GBPS, 4)
                 out["roofline"] = rf
-                out["gcn_forward"] = gcn_forward_record(plans, mats, a.d, a.gcn_layers)
+                out["gcn_forward"] = extra["gcn_forward"]
+                out["projection"] = extra["projection"]
             if not a.no_cpu_baseline and a.only == "all":
                 out["cpu_baseline"] = cpu_baseline(a, raw, mats, first=first)
                 out["loss_check"] = out["cpu_baseline"].pop("loss_check")

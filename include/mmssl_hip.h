@@ -344,6 +344,15 @@ int mmssl_proj_fwd_f32(int n_prob, const float* const* F, const float* const* W,
 int mmssl_proj_wgrad_f32(int n_prob, const float* G, int64_t ldg, const float* const* F, const int* K, int64_t M,
                          int N, float* const* gW, float* const* gb, void* workspace, size_t workspace_bytes,
                          void* stream);
+/* The same, with the AdamW update of the projection weights and biases (mmssl_adamw_ex_f32's rule and step-counter
+ * contract: state[0], external_tick -> pre_ticked) applied by the epilogue to the gradient it has just summed:
+ * W_g, b_g and their moments are updated in place, gW / gb (arrays or entries may be NULL) still receive the gradients.
+ * b / mb / vb may be NULL (no bias). The optimiser launch for these tensors disappears from the step's critical path. */
+int mmssl_proj_wgrad_adamw_f32(int n_prob, const float* G, int64_t ldg, const float* const* F, const int* K, int64_t M,
+                               int N, float* const* gW, float* const* gb, float* const* W, float* const* mW,
+                               float* const* vW, float* const* b, float* const* mb, float* const* vb,
+                               const float* state, float lr, float beta1, float beta2, float eps, float weight_decay,
+                               int pre_ticked, void* workspace, size_t workspace_bytes, void* stream);
 size_t mmssl_linear_wgrad_workspace_bytes(int64_t M, int K, int N);
 /* 1 when mmssl_linear_wgrad_f32 will run this shape on the register-direct kernel, which applies keep/scale and
  * sums the bias gradient on the fragments it loads (pass `keep`; no separate dropout-backward pass is needed);
@@ -415,6 +424,11 @@ int mmssl_dropout_mask_ex_u8(uint64_t* rng_state, float p, int64_t n, uint8_t* k
 /* counter[0] += 1 on the stream: advances a generator's launch counter (rng_state + 1) when the masks were drawn inside
  * another kernel (mmssl_proj_fwd_f32's epilogue) or with external_tick set. */
 int mmssl_tick_u64(uint64_t* counter, void* stream);
+/* dst[0 .. count) = ring[((int64) step_counter[0] % n_slots) * count ...]: a captured step reads its batch indices
+ * (Data.sample() output, load_data.py:153-191, uploaded ahead of time) from a device-resident ring by the optimiser's own
+ * device step counter - no host-side copy between two replays. */
+int mmssl_select_slot_i64(const int64_t* ring, int n_slots, int64_t count, const float* step_counter, int64_t* dst,
+                          void* stream);
 /* Backward of the above: gterms[k] = g[0] * w[k], gextra[0] = g[0] * c (gextra may be NULL). */
 int mmssl_loss_assemble_bwd_f32(const float* g, const float* w, int n, float c, float* gterms,
                                 float* gextra, void* stream);

@@ -101,6 +101,9 @@ SIGNATURES = {
                                    c_void_p, c_float, c_float, c_void_p, c_int64, c_void_p, c_size_t, c_void_p]),
     "mmssl_proj_wgrad_f32": (c_int, [c_int, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p,
                                      c_void_p, c_size_t, c_void_p]),
+    "mmssl_proj_wgrad_adamw_f32": (c_int, [c_int, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p,
+                                           c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float,
+                                           c_float, c_float, c_float, c_float, c_int, c_void_p, c_size_t, c_void_p]),
     "mmssl_linear_wgrad_workspace_bytes": (c_size_t, [c_int64, c_int, c_int]),
     "mmssl_linear_ticket_count": (c_int64, [c_int64, c_int, c_int]),
     "mmssl_linear_tk_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int64, c_int, c_int, c_void_p,
@@ -127,6 +130,7 @@ SIGNATURES = {
                                    c_float, c_float, c_float, c_int, c_void_p]),
     "mmssl_dropout_mask_ex_u8": (c_int, [c_void_p, c_float, c_int64, c_void_p, c_int, c_void_p]),
     "mmssl_tick_u64": (c_int, [c_void_p, c_void_p]),
+    "mmssl_select_slot_i64": (c_int, [c_void_p, c_int, c_int64, c_void_p, c_void_p, c_void_p]),
     "mmssl_loss_assemble_bwd_f32": (c_int, [c_void_p, c_void_p, c_int, c_float, c_void_p, c_void_p, c_void_p]),
     "mmssl_loss_assemble_f32": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_float, c_void_p, c_void_p]),
     "mmssl_infonce_workspace_bytes": (c_size_t, [c_int64, c_int]),

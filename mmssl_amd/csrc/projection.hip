@@ -29,10 +29,13 @@
 //            feeds FOUR MFMAs whose row slot i' stands for rows 4i'+e (un-permuted for free in the epilogue), so a
 //            k-group of 8 MFMAs costs two LDS instructions (32x32x2 on these images needs one ds_read_b32 per operand
 //            per MFMA: 25 us of the kernel, measured). Waves 4 (rows) x 2 (columns), 64 x 32 each.
+// A segment switch inside a block's range drains and refills the ring (measured: keeping the DMA running across the
+// switch - one pipeline over the whole range - costs more in registers and branches than the ~2 us per switch it saves).
 // Every range leaves its accumulator image in a partial slot; the reduce kernels add a tile's slots in block order
 // (deterministic) and apply the epilogue: bias + dropout (the mask either given or drawn HERE with the generator of
 // mmssl_dropout_mask_u8 — no separate mask launch in front of the GEMM) / the transposed store + bias-gradient sums.
 #include <algorithm>
+#include <cmath>
 #include <cstdlib>
 
 #include "lds_dma.hpp"
@@ -95,6 +98,21 @@ struct WgradPtrs {
   float* gW[kMaxProb];
   float* gb[kMaxProb];
 };
+// optional AdamW update of the projection weights / biases applied by the weight-gradient epilogue itself (the rule of
+// csrc/optim.hip's adamw_kernel = torch.optim.AdamW, main.py:76-80): the step's optimiser launch leaves the critical path
+struct AdamSlots {
+  float* W[kMaxProb];
+  float* mW[kMaxProb];
+  float* vW[kMaxProb];
+  float* b[kMaxProb];
+  float* mb[kMaxProb];
+  float* vb[kMaxProb];
+  const float* state;       // state[0] = step counter (see adamw_kernel); NULL = no update
+  float lr, beta1, beta2, eps, wd;
+  float log2_beta1, log2_beta2;
+  int pre_ticked;
+};
+
 
 // what a block's range [u, u_end) does next: one segment = the slices [s0, s0 + nk) of tile `tip` of problem g
 struct Segment {
@@ -251,6 +269,8 @@ struct FragW {
   float2 b[8];        // k-group p: G[m = 4p + g][32 wj + 2 j' .. + 1]
 };
 
+// One fragment register set refilled in place, like the forward (172 instead of 226 VGPRs: SpMM waves of the GCN chain
+// stay resident beside this kernel; measured 0.558 vs 0.571 ms per step against two alternating sets).
 __global__ __launch_bounds__(kThreads) void proj_wgrad_sk_kernel(Group P, int upb, int64_t total, int max_segs,
                                                                  float* __restrict__ partials,
                                                                  float* __restrict__ bpart) {
@@ -312,7 +332,7 @@ __global__ __launch_bounds__(kThreads) void proj_wgrad_sk_kernel(Group P, int up
       for (int eb = 0; eb < 2; ++eb) acc[ea][eb] = floatx4{0.f, 0.f, 0.f, 0.f};
     float bs0 = 0.f, bs1 = 0.f;                           // this wave's share of the bias-gradient column sums
     const bool want_bias = bpart != nullptr && sg.tip == 0;
-    auto step = [&](int kt, const FragW& cur, FragW& nxt, bool more1, bool more3) {
+    auto step = [&](int kt, FragW& cur, bool more1, bool more3) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         if (more3 && !(MMSSL_PROJ_DBG & 1)) {
@@ -320,7 +340,11 @@ __global__ __launch_bounds__(kThreads) void proj_wgrad_sk_kernel(Group P, int up
           for (int e = 0; e < kPieces; ++e)
             if (e * 4 / kPieces == q) issue_piece(kt + 3, e);
         }
-        if (more1 && !(MMSSL_PROJ_DBG & 4)) read_quarter(kt + 1, q, nxt);
+        if (want_bias) {               // the four row-waves of a column half share the k-groups: p % 4 == wi
+#pragma unroll
+          for (int p = 2 * q; p < 2 * q + 2; ++p)
+            if ((p & 3) == wi_u) { bs0 += cur.b[p].x; bs1 += cur.b[p].y; }
+        }
 #pragma unroll
         for (int p = 2 * q; p < 2 * q + 2; ++p) {
           const float av[4] = {cur.a[p].x, cur.a[p].y, cur.a[p].z, cur.a[p].w};
@@ -333,12 +357,8 @@ __global__ __launch_bounds__(kThreads) void proj_wgrad_sk_kernel(Group P, int up
               else acc[ea][eb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ea], bv[eb], acc[ea][eb], 0, 0, 0);
             }
         }
+        if (more1 && !(MMSSL_PROJ_DBG & 4)) read_quarter(kt + 1, q, cur);      // into the registers just consumed
         __builtin_amdgcn_sched_barrier(0);
-      }
-      if (want_bias) {                 // the four row-waves of a column half share the k-groups: p % 4 == wi
-#pragma unroll
-        for (int p = 0; p < 8; ++p)
-          if ((p & 3) == wi_u) { bs0 += cur.b[p].x; bs1 += cur.b[p].y; }
       }
     };
     vm_wait_n<0>();
@@ -351,23 +371,17 @@ __global__ __launch_bounds__(kThreads) void proj_wgrad_sk_kernel(Group P, int up
     else if (nk > 1) vm_wait_n<kPieces>();
     else vm_wait_n<0>();
     bare_barrier();
-    FragW f0, f1;
+    FragW f;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) read_quarter(0, q, f0);
+    for (int q = 0; q < 4; ++q) read_quarter(0, q, f);
     int kt = 0;
-    for (; kt + 4 < nk; kt += 2) {               // steady state: slices kt+1 .. kt+4 exist, branch-free
+    for (; kt + 3 < nk; ++kt) {                  // steady state: slices kt+1 .. kt+3 exist, branch-free
       step_sync(true);
-      step(kt, f0, f1, true, true);
-      step_sync(true);
-      step(kt + 1, f1, f0, true, true);
+      step(kt, f, true, true);
     }
-    for (; kt < nk; kt += 2) {                   // drain
+    for (; kt < nk; ++kt) {                      // drain
       if (kt + 1 < nk) step_sync(kt + 2 < nk);
-      step(kt, f0, f1, kt + 1 < nk, kt + 3 < nk);
-      if (kt + 1 < nk) {
-        if (kt + 2 < nk) step_sync(kt + 3 < nk);
-        step(kt + 1, f1, f0, kt + 2 < nk, kt + 4 < nk);
-      }
+      step(kt, f, kt + 1 < nk, false);
     }
     // acc[ea][eb][r] at lane (g, j') = C[row 64 wi + 16 g + 4 r + ea][col 32 wj + 2 j' + eb]: plane 4 eb + r holds, at
     // thread tid, the float4 of the FOUR CONSECUTIVE rows ea = 0..3 (the permuted row slots fall back into place)
@@ -485,19 +499,56 @@ __global__ __launch_bounds__(kThreads) void proj_fwd_reduce_kernel(Group P, int 
   }
 }
 
+__device__ __forceinline__ void adamw_update(float& p, float g, float& m, float& v, float step_size, float bc2_sqrt,
+                                             float decay, float beta1, float beta2, float eps) {
+  p *= decay;
+  m = m + (g - m) * (1.0f - beta1);                 // exp_avg.lerp_(grad, 1 - beta1)
+  v = v * beta2 + (1.0f - beta2) * g * g;
+  p -= step_size * (m / (sqrtf(v) / bc2_sqrt + eps));
+}
+
 // weight-gradient epilogue: the tile is C[i = feature column][j = channel]; gW[j][i .. i+3] is one float4
 __global__ __launch_bounds__(kThreads) void proj_wgrad_reduce_kernel(Group P, int upb, int max_segs,
                                                                      const float* __restrict__ partials,
-                                                                     const float* __restrict__ bpart, WgradPtrs ptrs) {
+                                                                     const float* __restrict__ bpart, WgradPtrs ptrs,
+                                                                     AdamSlots ad) {
+  __shared__ float sh[2];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int t = (int)blockIdx.x >> 3, q = (int)blockIdx.x & 7;
   const int g = prob_of_tile(P, t), tip = t - P.tile0[g];
+  if (ad.state) {
+    // bias corrections once per block. beta^step as exp2(step * log2(beta)) on the hardware exp2 (a few ulp from the
+    // powf of adamw_kernel, i.e. ~1e-7 relative on the step size): a libm powf here made every block of this short
+    // epilogue wait ~3 us for one thread (27 us instead of 12 for the launch)
+    if (tid == 0) {
+      const float step = ad.pre_ticked ? fmaxf(ad.state[0], 1.0f) : ad.state[0] + 1.0f;
+      sh[0] = ad.lr / (1.0f - __builtin_amdgcn_exp2f(step * ad.log2_beta1));
+      sh[1] = sqrtf(1.0f - __builtin_amdgcn_exp2f(step * ad.log2_beta2));
+    }
+    __syncthreads();
+  }
+  const float decay = 1.0f - ad.lr * ad.wd;
   const float4 v = sum_slots(P, t, g, tip, q, upb, max_segs, partials, tid);
   const int col = 32 * (wave & 1) + 2 * (lane & 15) + (q >> 2);
   const int64_t i = (int64_t)tip * PT + 64 * (wave >> 1) + 16 * (lane >> 4) + 4 * (q & 3);
   const int64_t K = P.I[g];
-  if (i < K) *reinterpret_cast<float4*>(ptrs.gW[g] + (int64_t)col * K + i) = v;
-  if (tip == 0 && q == 0 && tid < PJ && ptrs.gb[g]) {
+  if (i < K) {
+    const int64_t o = (int64_t)col * K + i;
+    if (ptrs.gW[g]) *reinterpret_cast<float4*>(ptrs.gW[g] + o) = v;
+    if (ad.state && ad.W[g]) {
+      float4 pp = *reinterpret_cast<float4*>(ad.W[g] + o);
+      float4 mm = *reinterpret_cast<float4*>(ad.mW[g] + o);
+      float4 vv = *reinterpret_cast<float4*>(ad.vW[g] + o);
+      adamw_update(pp.x, v.x, mm.x, vv.x, sh[0], sh[1], decay, ad.beta1, ad.beta2, ad.eps);
+      adamw_update(pp.y, v.y, mm.y, vv.y, sh[0], sh[1], decay, ad.beta1, ad.beta2, ad.eps);
+      adamw_update(pp.z, v.z, mm.z, vv.z, sh[0], sh[1], decay, ad.beta1, ad.beta2, ad.eps);
+      adamw_update(pp.w, v.w, mm.w, vv.w, sh[0], sh[1], decay, ad.beta1, ad.beta2, ad.eps);
+      *reinterpret_cast<float4*>(ad.W[g] + o) = pp;
+      *reinterpret_cast<float4*>(ad.mW[g] + o) = mm;
+      *reinterpret_cast<float4*>(ad.vW[g] + o) = vv;
+    }
+  }
+  if (tip == 0 && q == 0 && tid < PJ && (ptrs.gb[g] || (ad.state && ad.b[g]))) {
     const int64_t U0 = P.unit0[g], U1 = U0 + P.S[g];
     const int64_t b_first = U0 / upb, b_last = (U1 - 1) / upb;
     float s = 0.f;
@@ -505,7 +556,14 @@ __global__ __launch_bounds__(kThreads) void proj_wgrad_reduce_kernel(Group P, in
       const int seg = b == b_first ? t - tile_of_unit(P, b * upb) : 0;
       s += bpart[((size_t)b * max_segs + seg) * PJ + tid];
     }
-    ptrs.gb[g][tid] = s;
+    if (ptrs.gb[g]) ptrs.gb[g][tid] = s;
+    if (ad.state && ad.b[g]) {
+      float pp = ad.b[g][tid], mm = ad.mb[g][tid], vv = ad.vb[g][tid];
+      adamw_update(pp, s, mm, vv, sh[0], sh[1], decay, ad.beta1, ad.beta2, ad.eps);
+      ad.b[g][tid] = pp;
+      ad.mb[g][tid] = mm;
+      ad.vb[g][tid] = vv;
+    }
   }
 }
 
@@ -651,15 +709,56 @@ extern "C" int mmssl_proj_fwd_f32(int n_prob, const float* const* F, const float
   return 0;
 }
 
+static int wgrad_impl(int n_prob, const float* G, int64_t ldg, const float* const* F, const int* K, int64_t M, int N,
+                      float* const* gW, float* const* gb, const AdamSlots& ad, void* workspace, size_t workspace_bytes,
+                      void* stream);
+
 extern "C" int mmssl_proj_wgrad_f32(int n_prob, const float* G, int64_t ldg, const float* const* F, const int* K,
                                     int64_t M, int N, float* const* gW, float* const* gb, void* workspace,
                                     size_t workspace_bytes, void* stream) {
-  if (!G || !F || !K || !gW || !workspace) return MMSSL_E_BADARG;
+  AdamSlots ad = {};
+  return wgrad_impl(n_prob, G, ldg, F, K, M, N, gW, gb, ad, workspace, workspace_bytes, stream);
+}
+
+extern "C" int mmssl_proj_wgrad_adamw_f32(int n_prob, const float* G, int64_t ldg, const float* const* F, const int* K,
+                                          int64_t M, int N, float* const* gW, float* const* gb, float* const* W,
+                                          float* const* mW, float* const* vW, float* const* b, float* const* mb,
+                                          float* const* vb, const float* state, float lr, float beta1, float beta2,
+                                          float eps, float weight_decay, int pre_ticked, void* workspace,
+                                          size_t workspace_bytes, void* stream) {
+  if (!state || !W || !mW || !vW || n_prob < 1 || n_prob > kMaxProb) return MMSSL_E_BADARG;
+  AdamSlots ad = {};
+  for (int g = 0; g < n_prob; ++g) {
+    if (!W[g] || !mW[g] || !vW[g]) return MMSSL_E_BADARG;
+    if (((uintptr_t)W[g] | (uintptr_t)mW[g] | (uintptr_t)vW[g]) & 15) return MMSSL_E_BADARG;
+    ad.W[g] = W[g];
+    ad.mW[g] = mW[g];
+    ad.vW[g] = vW[g];
+    if (b && b[g]) {
+      if (!mb || !vb || !mb[g] || !vb[g]) return MMSSL_E_BADARG;
+      ad.b[g] = b[g];
+      ad.mb[g] = mb[g];
+      ad.vb[g] = vb[g];
+    }
+  }
+  ad.state = state;
+  ad.lr = lr; ad.beta1 = beta1; ad.beta2 = beta2; ad.eps = eps; ad.wd = weight_decay;
+  ad.log2_beta1 = (float)std::log2((double)beta1);
+  ad.log2_beta2 = (float)std::log2((double)beta2);
+  ad.pre_ticked = pre_ticked ? 1 : 0;
+  return wgrad_impl(n_prob, G, ldg, F, K, M, N, gW, gb, ad, workspace, workspace_bytes, stream);
+}
+
+static int wgrad_impl(int n_prob, const float* G, int64_t ldg, const float* const* F, const int* K, int64_t M, int N,
+                      float* const* gW, float* const* gb, const AdamSlots& ad, void* workspace, size_t workspace_bytes,
+                      void* stream) {
+  if (!G || !F || !K || !workspace || (!gW && !ad.state)) return MMSSL_E_BADARG;
   if (!wgrad_shape_ok(n_prob, K, M, N)) return MMSSL_E_UNSUPP;
   if (ldg < (int64_t)n_prob * N || (ldg & 3) || ((uintptr_t)G & 15) || ((uintptr_t)workspace & 15)) return MMSSL_E_BADARG;
   int64_t I[kMaxProb], R[kMaxProb];
   for (int g = 0; g < n_prob; ++g) {
-    if (!F[g] || !gW[g] || (((uintptr_t)F[g] | (uintptr_t)gW[g]) & 15)) return MMSSL_E_BADARG;
+    float* gw = gW ? gW[g] : nullptr;
+    if (!F[g] || (!gw && !ad.state) || (((uintptr_t)F[g] | (uintptr_t)gw) & 15)) return MMSSL_E_BADARG;
     I[g] = K[g];
     R[g] = M;
   }
@@ -680,15 +779,15 @@ extern "C" int mmssl_proj_wgrad_f32(int n_prob, const float* G, int64_t ldg, con
   WgradPtrs ptrs;
   bool any_b = false;
   for (int g = 0; g < kMaxProb; ++g) {
-    ptrs.gW[g] = g < n_prob ? gW[g] : nullptr;
+    ptrs.gW[g] = (g < n_prob && gW) ? gW[g] : nullptr;
     ptrs.gb[g] = (g < n_prob && gb) ? gb[g] : nullptr;
-    any_b = any_b || ptrs.gb[g] != nullptr;
+    any_b = any_b || ptrs.gb[g] != nullptr || (ad.state && g < n_prob && ad.b[g] != nullptr);
   }
   hipLaunchKernelGGL(proj_wgrad_sk_kernel, dim3((unsigned)pl.blocks), dim3(kThreads), kLdsBytes, s, pl.P, pl.upb,
                      pl.total, pl.max_segs, part, any_b ? bpart : (float*)nullptr);
   MMSSL_LAUNCH_CHECK();
   hipLaunchKernelGGL(proj_wgrad_reduce_kernel, dim3((unsigned)pl.tiles * 8), dim3(kThreads), 0, s, pl.P, pl.upb,
-                     pl.max_segs, (const float*)part, (const float*)bpart, ptrs);
+                     pl.max_segs, (const float*)part, (const float*)bpart, ptrs, ad);
   MMSSL_LAUNCH_CHECK();
   return 0;
 }

@@ -922,7 +922,7 @@ def build_bench_step(a, rank, world, dev, scaling="weak"):
     model = model.to(dev).train()
     step = ShardedHotPathStep(model, (plans[0], plans[1], e_ui, e_iu, e_ui, e_iu), a.batch, I, modal_empty=True)
     from . import ops
-    ops.STATS.update(enabled=True, spmm_launches=0, edge_layers=0, spmm_bytes=0)
+    ops.STATS.update(enabled=True, spmm_launches=0, edge_layers=0, spmm_bytes=0, unit_d=a.d)
     COMM["log"] = []
     step.step()
     torch.cuda.synchronize()

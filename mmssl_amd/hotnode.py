@@ -36,11 +36,17 @@ class HotCtx:
         self.prefill_buf = None       # filled on the GCN chain's idle stream by the forward, consumed by the loss tail
         self.external_ticks = False   # the step's loss tail advances the RNG / AdamW counters: no tick launches here
         self.lazy_anchors = False     # zero gradients of skipped branches: assigned after the backward, no fill launch
+        self.adam = None              # optim.FusedAdamW.fused_slots of the projection weights: the weight-gradient
+        #                               epilogue applies their AdamW update itself (the caller excludes them from step())
+        self.side_prologue = None     # callable run first on the GCN chain's side stream in the forward (a step object's
+        #                               small launches that must precede the loss section but not the projection)
+        self.after_fuse_bwd = None    # event on the current stream after the backward's fuse kernel: from there on the
+        #                               gradient of u_0 exists (the GCN chain's side stream holds the one of i_0)
         self.anchored = []
         self._zero_grads = {}
 
     def streams(self):
-        """(modal chain stream, GCN chain stream), created on first use."""
+        """(auxiliary stream, GCN chain stream), created on first use."""
         if self._streams is None:
             self._streams = (torch.cuda.Stream(device=self.device), torch.cuda.Stream(device=self.device))
         return self._streams
@@ -99,13 +105,20 @@ class _HotNode(torch.autograd.Function):
             sC.wait_event(fork)
             u0.record_stream(sC)
             i0.record_stream(sC)
-        with torch.cuda.stream(sC):
-            if hot.overlap and hot.prefill_floats is not None:
-                # the loss section's zero-filled gradient buffer, filled on the side stream while the projection's first
-                # blocks ramp up on the current one: off the critical path
+        # a third stream for what only the loss section needs (the step's batch selection, the zero-filled gradient
+        # buffer): off the projection's AND off the GCN chain's path
+        sA = hot.streams()[0] if hot.overlap else main
+        if hot.overlap and (hot.side_prologue is not None or hot.prefill_floats is not None):
+            sA.wait_event(fork)
+        with torch.cuda.stream(sA):
+            if hot.side_prologue is not None:
+                hot.side_prologue()
+            if hot.prefill_floats is not None:
                 buf = torch.zeros(hot.prefill_floats(u0.shape[0], i0.shape[0], d), dtype=torch.float32, device=dev)
-                buf.record_stream(main)
+                if hot.overlap:
+                    buf.record_stream(main)
                 hot.prefill_buf = buf
+        with torch.cuda.stream(sC):
             us, its = [u0], [i0]
             u, i = u0, i0
             uic, iuc = ui.twin(2), iu.twin(2)
@@ -119,6 +132,8 @@ class _HotNode(torch.autograd.Function):
         MI = ops._spmm_raw(iu, False, MU, ops.EPI_NONE)
         if hot.overlap:
             main.wait_stream(sC)
+            if hot.side_prologue is not None or hot.prefill_floats is not None:
+                main.wait_stream(sA)
             for t in tuple(us[1:]) + tuple(its[1:]):
                 t.record_stream(main)
         inv = 1.0 / (n_layers + 1)
@@ -155,6 +170,8 @@ class _HotNode(torch.autograd.Function):
         # side also yields the gradient of u_0), the two modal SpMMs, the grouped weight gradient
         (gMU, g_u0), (gMI, _) = ops.fuse_bwd([(MU, Gu, G_MU, True), (MI, Gi, G_MI, False)], nm, r, inv, g_ss, 2.0)
         if hot.overlap:
+            hot.after_fuse_bwd = main.record_event()
+            g_u0.record_stream(sC)             # a step object may run the tables' optimiser launch on the side stream
             sC.wait_event(fork)
             for t in (uG, iG, Gu, Gi):
                 t.record_stream(sC)            # main-pool tensors read on the side stream, possibly after this returns
@@ -173,7 +190,7 @@ class _HotNode(torch.autograd.Function):
             gX = ops.spmm_mask_raw(ui, True, t, keep, d, scale)
         else:
             gX = ops._spmm_raw(ui, True, t, ops.EPI_NONE)
-        gW, gb = ops.proj_wgrad(gX, Fs, want_bias=any(has_b))
+        gW, gb = ops.proj_wgrad(gX, Fs, want_bias=any(has_b), adam=hot.adam)
         if hot.overlap:
             # the embedding-table gradient (GCN chain) is complete before anything downstream of this node runs: the
             # chain ends long before the weight gradient above does, so the join never waits

@@ -24,9 +24,14 @@ class HotPathStep:
       overlap       fork the projection / modal chain and the GCN chain onto two side streams (False: one stream)
       eager_loss    root the backward at the loss TERMS with their known gradients, so that the loss section is one
                     chain of launches whose tail also assembles the loss and ticks the step's counters
-                    (False: autograd through ops.loss_assemble, the op-by-op structure)"""
+                    (False: autograd through ops.loss_assemble, the op-by-op structure)
+      fuse_adam     the projection weights' AdamW update is applied by the weight-gradient epilogue itself and — when the
+                    modal graphs are empty, i.e. the embedding tables' gradients come from the hot node alone — every
+                    other parameter is updated on the GCN chain's side stream while the weight gradient still runs: no
+                    optimiser launch is left on the step's critical path (False: one launch after the backward)"""
 
-    def __init__(self, model, graphs, batch_size, decay=1e-5, lr=None, capturable=True, overlap=True, eager_loss=True):
+    def __init__(self, model, graphs, batch_size, decay=1e-5, lr=None, capturable=True, overlap=True, eager_loss=True,
+                 fuse_adam=True):
         self.model = model
         self.graphs = tuple(graphs)
         self.batch_size = int(batch_size)
@@ -46,10 +51,17 @@ class HotPathStep:
         self.parts = {}
         self._graph = None
         self.eager_loss = bool(eager_loss)
+        self.fuse_adam = bool(fuse_adam)
         self.hot = HotCtx(dev, overlap=overlap)
+        self._proj = [model.image_trans, model.text_trans]
+        # tables first: with empty modal graphs their gradients are complete as soon as the GCN chain is
+        self._modal_empty = (not getattr(model, "extra_names", None)
+                             and all(getattr(g, "nnz", 1) == 0 and not hasattr(g, "_pair") for g in self.graphs[2:6]))
+        self._tables_early = self.fuse_adam and self.hot.overlap and self._modal_empty
         # parity runs inject fixed uint8 dropout keep-masks (img, txt), each [n_items, d]; None = drawn inside the
         # projection's epilogue (fresh masks on every replay)
         self.keep_masks = None
+        self._ring = None
         # ONE stream for everything this object launches (eager steps, capture, replays): autograd
         # binds each parameter's AccumulateGrad node to the stream of its first backward, and a
         # later capture on a different stream would have to synchronise across streams.
@@ -65,6 +77,25 @@ class HotPathStep:
                 self.users.copy_(users, non_blocking=True)
                 self.pos.copy_(pos, non_blocking=True)
                 self.neg.copy_(neg, non_blocking=True)
+
+    def set_batch_ring(self, batches):
+        """`batches`: int64 [n, 3, B] device tensor of upcoming batches (users / pos / neg each). From now on every step
+        copies slot (completed optimiser steps mod n) into its index buffers by a launch of its own on the GCN chain's
+        side stream: replays need no set_batch() (no host-issued copy between two replays). None switches back."""
+        if batches is None:
+            self._ring = None
+            return
+        if batches.dtype != torch.int64 or batches.dim() != 3 or tuple(batches.shape[1:]) != (3, self.batch_size) \
+                or batches.device != self.batch.device:
+            raise ops._lib.MmsslError("set_batch_ring: int64 [n, 3, batch_size] tensor on the model's device expected")
+        self._ring = batches.contiguous()
+
+    def _select_batch(self):
+        dev = self.loss.device
+        rc = ops._lib.lib().mmssl_select_slot_i64(self._ring.data_ptr(), self._ring.shape[0], 3 * self.batch_size,
+                                                  self.optimizer.step_counter(0, dev).data_ptr(), self.batch.data_ptr(),
+                                                  ops._lib.stream_ptr())
+        ops._lib.check(rc, "mmssl_select_slot_i64")
 
     def _feat_coeff(self):
         c = args.feat_reg_decay * 0.5 / self.model.n_items
@@ -94,7 +125,10 @@ class HotPathStep:
         # the forward leaves its regulariser sum unreduced; the loss tail reduces it (one launch less in front of the
         # loss chain). Only valid because the very next consumer of `ss` IS that tail - which checks it.
         hot.defer_ss, hot.ss_parts, hot.prefill_buf = True, None, None
-        hot.prefill_floats = lambda nu, ni, d: (3 * nu + ni) * d + 4
+        # [g_ua | g_ia | g_img_uid | g_txt_uid | 3 tickets]: the modal id views only get gradients when they are not the
+        # cached zeros of empty modal graphs
+        n_views = 0 if self._modal_empty else 2
+        hot.prefill_floats = lambda nu, ni, d: ((1 + n_views) * nu + ni) * d + 4
         try:
             (ua, ia, img_item, txt_item, img_user, txt_user, uemb, _, img_uid, txt_uid, _, _) = m(
                 *self.graphs, keep_masks=self.keep_masks, hot=hot)
@@ -123,6 +157,12 @@ class HotPathStep:
         counters = [self.optimizer.step_counter(gi, dev).data_ptr() for gi in range(len(self.optimizer.param_groups))]
         ticks = (counters, [ops._rng_state(dev).data_ptr() + 8])
         hot.external_ticks, hot.lazy_anchors = True, True
+        hot.side_prologue = self._select_batch if self._ring is not None else None
+        fused = []
+        if self.fuse_adam:
+            fused = [l.weight for l in self._proj] + [l.bias for l in self._proj if l.bias is not None]
+            hot.adam = self.optimizer.fused_slots([l.weight for l in self._proj], [l.bias for l in self._proj],
+                                                  pre_ticked=True)
         try:
             if self.eager_loss:
                 roots, grads = self._losses_eager(ticks)
@@ -131,10 +171,18 @@ class HotPathStep:
                 total, parts = self.losses(ticks)
                 total.backward(gradient=self._one)       # persistent root gradient: no ones_like fill per step
             hot.assign_anchored_zero_grads()
-            self.optimizer.step(external_tick=True)
+            if self._tables_early and hot.after_fuse_bwd is not None:
+                main = torch.cuda.current_stream(dev)
+                sC = hot.streams()[1]
+                sC.wait_event(hot.after_fuse_bwd)
+                with torch.cuda.stream(sC):
+                    self.optimizer.step(external_tick=True, exclude=fused)
+                main.wait_stream(sC)
+            else:
+                self.optimizer.step(external_tick=True, exclude=fused)
         finally:
             hot.external_ticks, hot.lazy_anchors = False, False
-            hot.anchored = []
+            hot.anchored, hot.adam, hot.after_fuse_bwd, hot.side_prologue = [], None, None, None
         return self.loss
 
     # ---- hipGraph capture ---------------------------------------------------------------------

@@ -18,7 +18,16 @@ EPI_SOFTMAX = 1
 EPI_AXPY = 2
 EPI_AXPY_SOFTMAX_BWD = 3
 # launch accounting for bench.py (edge.layers = nonzeros of every SpMM launch)
-STATS = {"enabled": False, "spmm_launches": 0, "edge_layers": 0, "spmm_bytes": 0}
+# One edge.layer = one nonzero of one SpMM launch doing a d-wide fp32 multiply-add with d = the embedding width
+# (SURVEY 8d); a launch over w-wide rows (the packed modal chain: w = 2 d) does w / d of them per nonzero. `unit_d` = d
+# (None: every launch counts its nonzeros once).
+STATS = {"enabled": False, "spmm_launches": 0, "edge_layers": 0, "spmm_bytes": 0, "unit_d": None}
+
+
+def _count_spmm(plan, rows, d):
+    STATS["spmm_launches"] += 1
+    STATS["edge_layers"] += plan.nnz * (max(1, d // STATS["unit_d"]) if STATS["unit_d"] else 1)
+    STATS["spmm_bytes"] += plan.nnz * (8 + 4 * d) + rows * 4 * d + (rows + 1) * 4
 _NORM_EPS = 1e-12        # F.normalize default eps
 
 
@@ -44,9 +53,7 @@ def _spmm_raw(plan, transpose, X, epilogue, Z=None, alpha=0.0, S=None):
         raise _lib.MmsslError("spmm: X has shape %s, expected [%d, d]" % (tuple(X.shape), cols))
     d = X.shape[1]
     if STATS["enabled"]:
-        STATS["spmm_launches"] += 1
-        STATS["edge_layers"] += plan.nnz
-        STATS["spmm_bytes"] += plan.nnz * (8 + 4 * d) + rows * 4 * d + (rows + 1) * 4
+        _count_spmm(plan, rows, d)
     Y = torch.empty((rows, d), dtype=torch.float32, device=X.device)
     ws = plan.workspace(transpose, d)
     rc = _lib.lib().mmssl_spmm_ex_f32(plan.handle, int(transpose), _ptr(X), d, _ptr(Y), epilogue, _ptr(Z),
@@ -322,9 +329,10 @@ def proj_forward(Fs, Ws, bs, keep=None, draw=None, scale=1.0):
     return Y, (keep_out if draw is not None else keep)
 
 
-def proj_wgrad(G, Fs, want_bias=True):
+def proj_wgrad(G, Fs, want_bias=True, adam=None):
     """([gW_g [64, K_g]], [gb_g [64]]) from the ALREADY masked output gradient G [M, 64 * n] (modalities side by side)
-    and the feature matrices, one launch + one epilogue launch."""
+    and the feature matrices, one launch + one epilogue launch. `adam` (optim.FusedAdamW.fused_slots): the epilogue also
+    applies the AdamW update of the projection weights / biases to the gradient it has just summed."""
     n = len(Fs)
     M = Fs[0].shape[0]
     N = G.shape[1] // n
@@ -336,9 +344,19 @@ def proj_wgrad(G, Fs, want_bias=True):
     if nb == 0:
         raise _lib.MmsslError("proj_wgrad: unsupported modality list K=%s M=%d N=%d" % (Ks, M, N))
     ws = torch.empty(nb // 4 + 4, dtype=torch.float32, device=dev)
-    rc = _lib.lib().mmssl_proj_wgrad_f32(n, _ptr(G), G.stride(0), _c_ptr_arr(Fs), _c_int_arr(Ks), M, N, _c_ptr_arr(gW),
-                                         _c_ptr_arr(gb) if gb else None, _ptr(ws), ws.numel() * 4, _lib.stream_ptr())
-    _lib.check(rc, "mmssl_proj_wgrad_f32")
+    if adam is None:
+        rc = _lib.lib().mmssl_proj_wgrad_f32(n, _ptr(G), G.stride(0), _c_ptr_arr(Fs), _c_int_arr(Ks), M, N, _c_ptr_arr(gW),
+                                             _c_ptr_arr(gb) if gb else None, _ptr(ws), ws.numel() * 4, _lib.stream_ptr())
+        _lib.check(rc, "mmssl_proj_wgrad_f32")
+        return gW, gb
+    a = adam
+    bias = a["b"] if any(t is not None for t in a["b"]) else None
+    rc = _lib.lib().mmssl_proj_wgrad_adamw_f32(
+        n, _ptr(G), G.stride(0), _c_ptr_arr(Fs), _c_int_arr(Ks), M, N, _c_ptr_arr(gW), _c_ptr_arr(gb) if gb else None,
+        _c_ptr_arr(a["W"]), _c_ptr_arr(a["mW"]), _c_ptr_arr(a["vW"]), _c_ptr_arr(a["b"]) if bias else None,
+        _c_ptr_arr(a["mb"]) if bias else None, _c_ptr_arr(a["vb"]) if bias else None, _ptr(a["state"]), a["lr"], a["beta1"],
+        a["beta2"], a["eps"], a["weight_decay"], 1 if a["pre_ticked"] else 0, _ptr(ws), ws.numel() * 4, _lib.stream_ptr())
+    _lib.check(rc, "mmssl_proj_wgrad_adamw_f32")
     return gW, gb
 
 
@@ -676,7 +694,11 @@ class _BatchLosses(torch.autograd.Function):
         if w.dtype != torch.float32 or w.numel() != 5 or w.device != dev:
             raise _lib.MmsslError("batch_losses: eager_w must be a [5] fp32 tensor on the tables' device")
         extra, c, total, ticks = tail
-        n_ua, n_ia, n_im, n_tx = ua.numel(), ia.numel(), img_uid.numel(), txt_uid.numel()
+        # gradients of the modal views only where they are wanted (the cached all-zero views of empty modal graphs need
+        # none: no buffer, no fill, no store)
+        need_im, need_tx = bool(ctx.needs_input_grad[2]), bool(ctx.needs_input_grad[3])
+        n_ua, n_ia = ua.numel(), ia.numel()
+        n_im, n_tx = (img_uid.numel() if need_im else 0), (txt_uid.numel() if need_tx else 0)
         gbuf = None
         if hot is not None:
             gbuf, hot.prefill_buf = hot.prefill_buf, None          # zero-filled by the forward, if enabled
@@ -684,8 +706,8 @@ class _BatchLosses(torch.autograd.Function):
             gbuf = torch.zeros(n_ua + n_ia + n_im + n_tx + 4, dtype=torch.float32, device=dev)
         g_ua = gbuf[:n_ua].view_as(ua)
         g_ia = gbuf[n_ua:n_ua + n_ia].view_as(ia)
-        g_img = gbuf[n_ua + n_ia:n_ua + n_ia + n_im].view_as(img_uid)
-        g_txt = gbuf[n_ua + n_ia + n_im:n_ua + n_ia + n_im + n_tx].view_as(txt_uid)
+        g_img = gbuf[n_ua + n_ia:n_ua + n_ia + n_im].view_as(img_uid) if need_im else None
+        g_txt = gbuf[n_ua + n_ia + n_im:n_ua + n_ia + n_im + n_tx].view_as(txt_uid) if need_tx else None
         tickets = gbuf[n_ua + n_ia + n_im + n_tx:]              # three zeroed ints (InfoNCE x2, BPR)
         nbw = _lib.lib().mmssl_infonce_multi_workspace_bytes(2, B, d)
         if nbw == 0:
@@ -718,7 +740,7 @@ class _BatchLosses(torch.autograd.Function):
             rc = _lib.lib().mmssl_infonce_multi_bwd_phase_f32(_ptr(users), 2, B, d, float(tau), _ptr(w[3:5]), gz1s,
                                                               _ptr(g_ua), _ptr(ws1), ws1.numel() * 4, 2, _lib.stream_ptr())
             _lib.check(rc, "mmssl_infonce_multi_bwd_phase_f32")
-            ctx.eager = (g_ua, g_ia, g_img if ctx.needs_input_grad[2] else None, g_txt if ctx.needs_input_grad[3] else None)
+            ctx.eager = (g_ua, g_ia, g_img, g_txt)
             return out
         rc = _lib.lib().mmssl_infonce_multi_bwd_phase_f32(_ptr(users), 2, B, d, float(tau), _ptr(w[3:5]), gz1s, _ptr(g_ua),
                                                           _ptr(ws1), ws1.numel() * 4, 3, _lib.stream_ptr())
@@ -728,7 +750,7 @@ class _BatchLosses(torch.autograd.Function):
                                            _ptr(w), 5, _ptr(extra), float(c), _ptr(total), fa, len(f32s), ka, len(u64s),
                                            _ptr(wsb), nb, _ptr(tickets[2:]), _ptr(xparts), n_xparts, _lib.stream_ptr())
         _lib.check(rc, "mmssl_bpr_step_f32")
-        ctx.eager = (g_ua, g_ia, g_img if ctx.needs_input_grad[2] else None, g_txt if ctx.needs_input_grad[3] else None)
+        ctx.eager = (g_ua, g_ia, g_img, g_txt)
         return out
 
     @staticmethod
@@ -898,9 +920,7 @@ def spmm_mask_raw(plan, transpose, X, keep, dm, scale):
     if keep.dtype != torch.uint8 or keep.numel() != rows * d or not keep.is_contiguous():
         raise _lib.MmsslError("spmm_mask: keep must be a contiguous uint8 [d / dm, rows, dm] tensor")
     if STATS["enabled"]:
-        STATS["spmm_launches"] += 1
-        STATS["edge_layers"] += plan.nnz
-        STATS["spmm_bytes"] += plan.nnz * (8 + 4 * d) + rows * 4 * d + (rows + 1) * 4
+        _count_spmm(plan, rows, d)
     Y = torch.empty((rows, d), dtype=torch.float32, device=X.device)
     ws = plan.workspace(transpose, d)
     rc = _lib.lib().mmssl_spmm_mask_f32(plan.handle, int(transpose), _ptr(X), d, _ptr(Y), _ptr(keep), int(dm), float(scale),

@@ -32,14 +32,46 @@ class FusedAdamW(torch.optim.Optimizer):
         return st
 
     @torch.no_grad()
-    def step(self, closure=None, groups=None, sliced=None, external_tick=False):
+    def fused_slots(self, weights, biases, pre_ticked=False):
+        """What a kernel that applies this optimiser's update itself needs (ops.proj_wgrad(adam=...)): the tensors and
+        moments of `weights` / `biases` (lists of parameters of ONE param group; bias entries may be None), the group's
+        hyper-parameters and its device step counter. The caller excludes these parameters from step()."""
+        gi = None
+        for k, group in enumerate(self.param_groups):
+            ids = {id(p) for p in group["params"]}
+            if all(id(p) in ids for p in list(weights) + [b for b in biases if b is not None]):
+                gi = k
+                break
+        if gi is None:
+            raise _lib.MmsslError("FusedAdamW.fused_slots: the parameters must belong to one param group")
+        group = self.param_groups[gi]
+
+        def st(p):
+            s = self.state[p]
+            if not s:
+                s["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                s["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            return s
+        b1, b2 = group["betas"]
+        return {"W": [p.data for p in weights], "mW": [st(p)["exp_avg"] for p in weights],
+                "vW": [st(p)["exp_avg_sq"] for p in weights],
+                "b": [None if p is None else p.data for p in biases],
+                "mb": [None if p is None else st(p)["exp_avg"] for p in biases],
+                "vb": [None if p is None else st(p)["exp_avg_sq"] for p in biases],
+                "state": self._group_state(gi, weights[0].device), "lr": float(group["lr"]), "beta1": float(b1),
+                "beta2": float(b2), "eps": float(group["eps"]), "weight_decay": float(group["weight_decay"]),
+                "pre_ticked": bool(pre_ticked)}
+
+    def step(self, closure=None, groups=None, sliced=None, external_tick=False, exclude=None):
         """`groups`: optional iterable of param-group indices to update (each group has its own device step
         counter, so groups may be stepped at different points of one iteration).
         `sliced`: {parameter: (buffer, float offset, n_slices, stride)} - gradients that exist only as split-K partials
         (ops.take_wgrad_parts): slice s of the gradient starts at buffer[offset + s * stride]; the kernel adds the
         slices in order while it reads them. Such parameters need no `.grad`.
         `external_tick`: the caller already advanced this step's counter (step_counter) on the stream - a step object
-        whose loss tail ticks every counter of the step in one launch - so no tick launch follows the update."""
+        whose loss tail ticks every counter of the step in one launch - so no tick launch follows the update.
+        `exclude`: parameters some other kernel of the step has already updated (fused_slots)."""
+        skip = {id(p) for p in exclude} if exclude else ()
         loss = None
         if closure is not None:
             with torch.enable_grad():
@@ -50,7 +82,7 @@ class FusedAdamW(torch.optim.Optimizer):
             todo = []
             for p in group["params"]:
                 sl = sliced.get(p) if sliced else None
-                if p.grad is None and sl is None:
+                if (p.grad is None and sl is None) or id(p) in skip:
                     continue
                 if not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous()):
                     raise _lib.MmsslError("FusedAdamW: parameters must be contiguous fp32 HIP tensors")

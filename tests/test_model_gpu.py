@@ -356,6 +356,50 @@ def test_baselines_match_reference_classes(name):
     assert model.image_trs.weight.grad is None or float(model.image_trs.weight.grad.abs().max()) == 0.0
 
 
+def test_hotpath_batch_ring_equals_set_batch():
+    """HotPathStep.set_batch_ring: every step picks slot (completed optimiser steps mod n) of a device-resident ring by a
+    launch inside the (captured) step. Same trajectory as set_batch() of the same slot before every replay."""
+    import scipy.sparse as sp
+    from mmssl_amd import ops, synth
+    from mmssl_amd.graph import GraphPlan
+    from mmssl_amd.hotpath import HotPathStep
+    from mmssl_amd.Models import MMSSL
+    U, I, E, dv, dt, B = 2000, 1200, 20000, 128, 64, 256
+    _configure(drop_rate=0.2, batch_size=B, weight_size="[64, 64]")
+    raw = synth.interaction_matrix(U, I, E, seed=6)
+    ui, iu = synth.normalised_pair(raw)
+    g = torch.Generator().manual_seed(4)
+    img, txt = torch.randn(I, dv, generator=g).numpy(), torch.randn(I, dt, generator=g).numpy()
+    ring = torch.stack([torch.stack([torch.randperm(U, generator=g)[:B], torch.randint(0, I, (B,), generator=g),
+                                     torch.randint(0, I, (B,), generator=g)]) for _ in range(3)]).to(DEV)
+
+    def run(use_ring):
+        torch.manual_seed(12)
+        ops.seed_dropout(12)
+        model = MMSSL(U, I, 64, [64] * 2, [0.1] * 2, img, txt).to(DEV).train()
+        e1, e2 = GraphPlan(sp.csr_matrix((U, I), dtype=np.float32)), GraphPlan(sp.csr_matrix((I, U), dtype=np.float32))
+        step = HotPathStep(model, (GraphPlan(ui), GraphPlan(iu), e1, e2, e1, e2), B)
+        if use_ring:
+            step.set_batch_ring(ring)
+        else:
+            step.set_batch(ring[0])
+        assert step.capture(warmup=1), getattr(step, "capture_error", "")      # one executed step: slot 0
+        losses = []
+        for k in range(1, 8):
+            if not use_ring:
+                step.set_batch(ring[k % 3])
+            step.run()
+            torch.cuda.synchronize()
+            losses.append(float(step.loss))
+        return losses, model.user_id_embedding.weight.detach().cpu().clone()
+    la, ea = run(True)
+    lb, eb = run(False)
+    assert len(set(round(x, 6) for x in la)) > 3           # the batches really change
+    for a, b in zip(la, lb):
+        assert abs(a - b) <= 1e-5 * abs(b), (la, lb)
+    assert H.rel_err(ea, eb) < 1e-5
+
+
 # ---------------------------------------------------------------------------------------------------
 # G12: the reference's own Trainer.train() for 8 batches + its evaluation, recorded by oracle/gen_golden.py g12
 # (every random tensor of the loop injected): K-step trajectory and Recall@20 parity of the product Trainer

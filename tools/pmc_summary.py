@@ -1,6 +1,7 @@
 """Summarise rocprofv3 counter_collection CSVs of tools/spmm_pmc.py into profiles/spmm_pmc.json.
-FETCH_SIZE / WRITE_SIZE are reported in KiB; on gfx950 FETCH_SIZE tallies the 128-B requests of wide
-(16 B/lane) coalesced reads at 64 B, so it is doubled (guides/MI355X_MICROARCH.md, section HBM)."""
+FETCH_SIZE / WRITE_SIZE are reported in KiB; on gfx950 FETCH_SIZE tallies the 128-B requests at 64 B, so it is doubled
+(guides/MI355X_MICROARCH.md, section HBM, calibrated there for wide streaming reads; profiles/r03_fetch_calibration.json
+calibrates it for THIS kernel's 256-B / 512-B row gathers on a gather of known size: ratio 2.00 / 1.97; WRITE_SIZE exact)."""
 import csv
 import json
 import sys
@@ -38,8 +39,10 @@ def main(fetch_csv, write_csv, out):
     res["fetch_bytes_per_launch_x2_gfx950"] = int(2 * tot_f * 1024 / n_main)
     res["write_bytes_per_launch"] = int(tot_w * 1024 / n_main)
     res["hbm_bytes_per_launch"] = res["fetch_bytes_per_launch_x2_gfx950"] + res["write_bytes_per_launch"]
-    res["note"] = ("fabric-side (L2 miss) traffic: tables and CSR of the Baby shape are Infinity-Cache resident, so this "
-                   "is far below the algorithmic gather-per-edge bytes (74.7 MB/launch)")
+    res["level"] = "L2-miss / fabric requests (TCC_EA0): Infinity-Cache hits are included, so this is NOT an HBM byte count"
+    res["note"] = ("tables and CSR of the Baby shape are Infinity-Cache resident: this fabric traffic is below the algorithmic "
+                   "gather-per-edge bytes (74.7 MB/launch at d = 64) but above the compulsory once-through bytes (~16 MB) - "
+                   "every XCD's L2 pulls its own copy of the gathered table")
     json.dump(res, open(out, "w"), indent=1)
     print(json.dumps(res, indent=1))
 

@@ -31,6 +31,10 @@
 //            per MFMA: 25 us of the kernel, measured). Waves 4 (rows) x 2 (columns), 64 x 32 each.
 // A segment switch inside a block's range drains and refills the ring (measured: keeping the DMA running across the
 // switch - one pipeline over the whole range - costs more in registers and branches than the ~2 us per switch it saves).
+// (Also measured and dropped: the last-arriving block adding a tile's slots itself - write-through slot stores + arrival
+// tickets, no second launch. Every range of these shapes ends inside a tile, so all 26 MB of slots go out as 8-byte
+// write-through stores: forward 159 instead of 114 + 21 us, weight gradient 183 instead of 140 + 18 us in the step,
+// profiles/r03/step_timeline_inkernel_fixup_rejected.txt.)
 // Every range leaves its accumulator image in a partial slot; the reduce kernels add a tile's slots in block order
 // (deterministic) and apply the epilogue: bias + dropout (the mask either given or drawn HERE with the generator of
 // mmssl_dropout_mask_u8 — no separate mask launch in front of the GEMM) / the transposed store + bias-gradient sums.
@@ -443,16 +447,26 @@ __device__ __forceinline__ uint32_t philox_keep_byte(uint64_t seed, uint64_t lau
   return (c[elem & 3] >> 8) >= thr ? 1u : 0u;
 }
 
-// the slots of tile t, plane q, in block order (fixed: the result does not depend on the schedule)
+// the slots of tile t, plane q, in block order (fixed: the result does not depend on the schedule). The loads of up to
+// eight slots are issued together (a weight-gradient tile has ~14 of them: one load latency per slot, back to back, was
+// most of the epilogue launch's time); the additions keep the block order.
 __device__ __forceinline__ float4 sum_slots(const Group& P, int t, int g, int tip, int q, int upb, int max_segs,
                                             const float* __restrict__ partials, int tid) {
   const int64_t U0 = P.unit0[g] + (int64_t)tip * P.S[g], U1 = U0 + P.S[g];
   const int64_t b_first = U0 / upb, b_last = (U1 - 1) / upb;
+  const int seg_first = t - tile_of_unit(P, b_first * upb);
   float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int64_t b = b_first; b <= b_last; ++b) {
-    const int seg = b == b_first ? t - tile_of_unit(P, b * upb) : 0;
-    const float4 p = reinterpret_cast<const float4*>(partials + ((size_t)b * max_segs + seg) * kSlotFloats)[q * kThreads + tid];
-    v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
+  for (int64_t b0 = b_first; b0 <= b_last; b0 += 8) {
+    float4 p[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int64_t b = min(b0 + k, b_last);                    // clamped: a repeated (cached) load, not added
+      const int seg = b == b_first ? seg_first : 0;
+      p[k] = reinterpret_cast<const float4*>(partials + ((size_t)b * max_segs + seg) * kSlotFloats)[q * kThreads + tid];
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+      if (b0 + k <= b_last) { v.x += p[k].x; v.y += p[k].y; v.z += p[k].z; v.w += p[k].w; }
   }
   return v;
 }

@@ -269,46 +269,6 @@ size_t mmssl_linear_workspace_bytes(int64_t M, int K, int N);   /* split-K parti
 int mmssl_linear_f32(const float* F, const float* W, const float* b, const uint8_t* keep,
                      float scale, int64_t M, int K, int N, float* Y, void* workspace,
                      size_t workspace_bytes, void* stream);
-/* The same product with the stream-K fix-up done inside the kernel: `tickets` = mmssl_linear_ticket_count(M, K, N)
- * ints (one per output tile), ZERO before the first call and left zero by every call, private to calls that may run
- * concurrently. The last block to deliver a partial of a tile adds the tile's partials in block order (bitwise the
- * result of mmssl_linear_f32) and applies bias + dropout: no second launch between the product and its consumer.
- * ticket_count == 0: this shape / kernel generation has no fix-up form, call mmssl_linear_f32. tickets == NULL is
- * mmssl_linear_f32. With tickets the WORKSPACE must be private to this entry point as well (memory no other kernel
- * has touched with ordinary cached accesses since it was allocated): the partial tiles travel as write-through stores
- * and cache-bypassing loads, which are not ordered against stale cached copies of recycled memory. */
-int64_t mmssl_linear_ticket_count(int64_t M, int K, int N);
-int mmssl_linear_tk_f32(const float* F, const float* W, const float* b, const uint8_t* keep,
-                        float scale, int64_t M, int K, int N, float* Y, void* workspace,
-                        size_t workspace_bytes, int* tickets, void* stream);
-/* OPT-IN: the same projection Y = dropout(F W^T + b) computed from a TRANSPOSED copy of the constant feature matrix,
- * FT [K, Mp] (row k = column k of F, Mp >= M a multiple of 64, columns M..Mp-1 zero). The product then reduces over the
- * ROWS of both operands (FT and W^T, which the call builds), the form the register-direct weight-gradient kernel
- * streams with fully coalesced loads. N % 64 == 0; workspace_bytes() == 0 means the shape is not supported. */
-size_t mmssl_linear_ft_workspace_bytes(int64_t M, int K, int N, int64_t Mp);
-int mmssl_linear_ft_f32(const float* FT, int64_t Mp, const float* W, const float* b, const uint8_t* keep,
-                        float scale, int64_t M, int K, int N, float* Y, void* workspace,
-                        size_t workspace_bytes, void* stream);
-/* OPT-IN split-precision product (not used unless the caller asks for it): Y[M,N] = A . B^T (+ bias, dropout
- * as in mmssl_linear_f32) with A [M,K] and B [N,K] each given as TWO bf16 matrices (hi = bf16(x),
- * lo = bf16(x - hi)); the result is hi*hi + hi*lo + lo*hi accumulated in fp32 on the bf16 matrix cores
- * (relative error of a product ~2^-16). K % 32 == 0. Motivation and numbers: DESIGN.md section 4. */
-size_t mmssl_linear_split_workspace_bytes(int64_t M, int K, int N);
-/* N may exceed 256 when b and keep are NULL: the weight gradient gW [N_out, K_in] is this product with
- * A = gY^T pair [N_out, Mp], B = F^T pair [K_in, Mp] (reduction over the padded M). */
-int mmssl_linear_split_f32(const uint16_t* A_hi, const uint16_t* A_lo, const uint16_t* B_hi,
-                           const uint16_t* B_lo, const float* b, const uint8_t* keep, float scale,
-                           int64_t M, int K, int N, float* Y, void* workspace, size_t workspace_bytes,
-                           void* stream);
-/* Operand preparation for the above: X (n fp32 values, n % 4 == 0) -> hi = bf16(X), lo = bf16(X - hi). */
-int mmssl_split_bf16_f32(const float* X, int64_t n, uint16_t* hi, uint16_t* lo, void* stream);
-/* G [M, N] fp32 (optionally dropout-masked: keep/scale) -> T_hi, T_lo [N, Mp] bf16 = the transposed pair, zero
- * in columns M..Mp-1 (Mp % 64 == 0: the reduction of the wgrad product runs over Mp); colsum (may be NULL)
- * receives the column sums of the masked G, i.e. the bias gradient. */
-size_t mmssl_split_transpose_workspace_bytes(int64_t Mp, int N);
-int mmssl_split_transpose_bf16_f32(const float* G, const uint8_t* keep, float scale, int64_t M, int N,
-                                   int64_t Mp, uint16_t* T_hi, uint16_t* T_lo, float* colsum,
-                                   void* workspace, size_t workspace_bytes, void* stream);
 /* G [M, N] fp32 (optionally dropout-masked: keep/scale) -> T [N, Mp] fp32 = G^T, zero in columns M..Mp-1
  * (Mp % 4 == 0); colsum (may be NULL) receives the column sums of the masked G, i.e. the bias gradient.
  * With it the weight gradient of the projection (autograd of Models.py:173-174) is the FORWARD product
@@ -358,13 +318,6 @@ size_t mmssl_linear_wgrad_workspace_bytes(int64_t M, int K, int N);
  * sums the bias gradient on the fragments it loads (pass `keep`; no separate dropout-backward pass is needed);
  * 0 when it runs the register-staged kernel, for which a pre-masked gY (mmssl_mask_scale_f32) measured faster. */
 int mmssl_linear_wgrad_fuses_mask(int64_t M, int K, int N);
-/* The weight gradient left as its row-range partials (register-direct kernel only: returns MMSSL_E_UNSUPP where
- * mmssl_linear_wgrad_fuses_mask is 0): workspace (mmssl_linear_wgrad_workspace_bytes) receives gW partials
- * [*n_parts][N][K] at its start and the bias-gradient partials [*n_parts][N] at float offset *bias_offset; no reduce is
- * launched - the optimiser adds the slices (mmssl_adamw_sliced_f32). */
-int mmssl_linear_wgrad_parts_f32(const float* gY, const uint8_t* keep, float scale, const float* F,
-                                 int64_t M, int K, int N, void* workspace, size_t workspace_bytes,
-                                 int* n_parts, int64_t* bias_offset, void* stream);
 int mmssl_linear_wgrad_f32(const float* gY, const uint8_t* keep, float scale, const float* F,
                            int64_t M, int K, int N, float* gW, float* gb, void* workspace,
                            size_t workspace_bytes, void* stream);
@@ -413,8 +366,8 @@ int mmssl_adamw_ex_f32(float* const* params, const float* const* grads, float* c
                        float* const* exp_avg_sq, const int64_t* numel, int count, float* state, float lr,
                        float beta1, float beta2, float eps, float weight_decay, int external_tick, void* stream);
 /* The same update with SLICED gradients: tensor t's gradient is grads[t][i] + grads[t][gstride[t] + i] + ... over
- * slices[t] slices, added in slice order - the row-range partials mmssl_linear_wgrad_parts_f32 leaves behind, consumed
- * without a reduce launch (bitwise the result of reducing first). slices == gstride == NULL is mmssl_adamw_ex_f32. */
+ * slices[t] slices, added in slice order - split partials a producer leaves behind, consumed without a reduce launch
+ * (bitwise the result of reducing first). slices == gstride == NULL is mmssl_adamw_ex_f32. */
 int mmssl_adamw_sliced_f32(float* const* params, const float* const* grads, float* const* exp_avg,
                            float* const* exp_avg_sq, const int64_t* numel, const int32_t* slices,
                            const int64_t* gstride, int n_tensors, float* state, float lr, float beta1,

@@ -85,13 +85,6 @@ SIGNATURES = {
     "mmssl_linear_workspace_bytes": (c_size_t, [c_int64, c_int, c_int]),
     "mmssl_linear_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int64, c_int, c_int,
                                  c_void_p, c_void_p, c_size_t, c_void_p]),
-    "mmssl_linear_split_workspace_bytes": (c_size_t, [c_int64, c_int, c_int]),
-    "mmssl_linear_split_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int64,
-                                       c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
-    "mmssl_split_bf16_f32": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
-    "mmssl_split_transpose_workspace_bytes": (c_size_t, [c_int64, c_int]),
-    "mmssl_split_transpose_bf16_f32": (c_int, [c_void_p, c_void_p, c_float, c_int64, c_int, c_int64, c_void_p, c_void_p,
-                                               c_void_p, c_void_p, c_size_t, c_void_p]),
     "mmssl_transpose_mask_workspace_bytes": (c_size_t, [c_int64, c_int]),
     "mmssl_transpose_mask_f32": (c_int, [c_void_p, c_void_p, c_float, c_int64, c_int, c_int64, c_void_p, c_void_p,
                                          c_void_p, c_size_t, c_void_p]),
@@ -105,15 +98,7 @@ SIGNATURES = {
                                            c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float,
                                            c_float, c_float, c_float, c_float, c_int, c_void_p, c_size_t, c_void_p]),
     "mmssl_linear_wgrad_workspace_bytes": (c_size_t, [c_int64, c_int, c_int]),
-    "mmssl_linear_ticket_count": (c_int64, [c_int64, c_int, c_int]),
-    "mmssl_linear_tk_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int64, c_int, c_int, c_void_p,
-                                    c_void_p, c_size_t, c_void_p, c_void_p]),
-    "mmssl_linear_ft_workspace_bytes": (c_size_t, [c_int64, c_int, c_int, c_int64]),
-    "mmssl_linear_ft_f32": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_float, c_int64, c_int, c_int,
-                                    c_void_p, c_void_p, c_size_t, c_void_p]),
     "mmssl_linear_wgrad_fuses_mask": (c_int, [c_int64, c_int, c_int]),
-    "mmssl_linear_wgrad_parts_f32": (c_int, [c_void_p, c_void_p, c_float, c_void_p, c_int64, c_int, c_int, c_void_p,
-                                             c_size_t, c_void_p, c_void_p, c_void_p]),
     "mmssl_adamw_sliced_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                                        c_void_p, c_float, c_float, c_float, c_float, c_float, c_int, c_void_p]),
     "mmssl_linear_wgrad_f32": (c_int, [c_void_p, c_void_p, c_float, c_void_p, c_int64, c_int, c_int, c_void_p,

@@ -27,19 +27,14 @@ using namespace mmssl;
 
 namespace {
 
-int env_int(const char* name, int dflt) {
-  const char* s = getenv(name);
-  return (s && *s) ? atoi(s) : dflt;
-}
-int short_max() { static int v = std::max(1, env_int("MMSSL_PLAN_SHORT_MAX", 32)); return v; }
-int task_nnz() { static int v = std::max(short_max(), env_int("MMSSL_PLAN_TASK_NNZ", 128)); return v; }
-int plan_sort() { static int v = env_int("MMSSL_PLAN_SORT", 1); return v; }
-// 0 (default) = rows that span several heavy blocks are combined by the last-arriving block inside the
-// SpMM kernel (write-through partials + arrival ticket); 1 = by a small second kernel.
-// Measured on MI355X (Baby shape) with the block-grouped plan (only rows > 512 nnz span blocks: 2 + 30 rows):
-// in-kernel 75.2 us vs two-stage 76.7 us for the 6-SpMM forward chain, 12.8 vs 16.3 us for one eager launch.
-// (With one slot per 128-nnz slice — 183 multi rows on the item side — the in-kernel form was the slower one.)
-int two_stage() { static int v = env_int("MMSSL_SPMM_TWO_STAGE", 0); return v; }
+// Work-list shaping of the graph plan (swept in round 2, tools/kbench.py at that revision): rows of at most 32 nonzeros
+// are "short" (lane-group items), longer rows are cut into tasks of 128 nonzeros, items sorted by length.
+constexpr int short_max() { return 32; }
+constexpr int task_nnz() { return 128; }
+constexpr int plan_sort() { return 1; }
+// Rows that span several heavy blocks are combined by the last-arriving block inside the SpMM kernel (write-through
+// partials + arrival ticket). The second-kernel form measured slower with the block-grouped plan (76.7 vs 75.2 us for the
+// 6-SpMM forward chain, 16.3 vs 12.8 us for one eager launch) and was removed.
 
 }  // namespace
 
@@ -491,10 +486,6 @@ __global__ __launch_bounds__(kBlock) void spmm_kernel(const int4* __restrict__ g
     }
     {
       const int slot = code0;
-      if (arrivals == nullptr) {           // two-stage mode: spmm_multi_kernel combines
-        if (lane < LPR) partials[(size_t)slot * LPR + lig] = acc;
-        return;
-      }
       // ---- in-kernel combine by the LAST-arriving block of this row (split-K arrival pattern) ----
       // The protocol below (write-through sc1 stores drained with vmcnt, relaxed ticket, sc1 re-reads; no
       // release/acquire fence) relies on gfx9 store accounting (stores retire through vmcnt) and on agent-scope
@@ -551,42 +542,6 @@ __global__ __launch_bounds__(kBlock) void spmm_kernel(const int4* __restrict__ g
   }
 }
 
-// second stage for rows that span several heavy blocks: one block per such row. Lane group g
-// adds slots g, g+GPB, ... (independent loads), the GPB group sums are combined through LDS in a
-// fixed order -> bitwise reproducible, and the serial depth is slots/GPB instead of slots.
-template <int LPR, int EPI>
-__global__ __launch_bounds__(kBlock) void spmm_multi_kernel(const int4* __restrict__ multi, int n_multi,
-                                                            const float4* __restrict__ partials,
-                                                            float4* __restrict__ Y, EpiArgs epi) {
-  constexpr int GPB = kBlock / LPR;
-  __shared__ float4 red[kBlock];
-  const int lig = threadIdx.x & (LPR - 1);
-  const int grp = threadIdx.x / LPR;
-  const int4 it = multi[blockIdx.x];
-  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int k = grp; k < it.z; k += GPB) {
-    const float4 p = partials[(size_t)(it.y + k) * LPR + lig];
-    acc.x += p.x;
-    acc.y += p.y;
-    acc.z += p.z;
-    acc.w += p.w;
-  }
-  red[threadIdx.x] = acc;
-  __syncthreads();
-  if (grp == 0) {
-    const int used = it.z < GPB ? it.z : GPB;
-    for (int g = 1; g < used; ++g) {
-      const float4 p = red[g * LPR + lig];
-      acc.x += p.x;
-      acc.y += p.y;
-      acc.z += p.z;
-      acc.w += p.w;
-    }
-    acc = apply_epilogue<LPR, EPI>(acc, it.x, lig, epi);
-    Y[(size_t)it.x * LPR + lig] = acc;
-  }
-}
-
 // Workspace of one SpMM launch: [partial slots: n_slots * d floats | arrival counters: n_multi int32].
 // The counters belong to the WORKSPACE, not to the plan: launches that overlap on different streams use
 // different workspaces (GraphPlan.twin), and each must count its own arrivals. They must be zero before the
@@ -608,13 +563,7 @@ int launch_spmm(const DirPlan& p, const float* X, float* Y, float* partials, con
                        p.gitems, (int)p.n_g, p.witems, (int)p.n_w, n_wblocks, p.edges,
                        reinterpret_cast<const float4*>(X), reinterpret_cast<float4*>(Y),
                        reinterpret_cast<float4*>(partials), epi, p.multi, p.slot2multi,
-                       (two_stage() && !p.dyn) ? (int32_t*)nullptr : arrivals, p.dyn);
-    MMSSL_LAUNCH_CHECK();
-  }
-  if (p.n_multi > 0 && two_stage() && !p.dyn) {
-    hipLaunchKernelGGL((spmm_multi_kernel<LPR, EPI>), dim3((unsigned)p.n_multi), dim3(kBlock), 0, s, p.multi,
-                       (int)p.n_multi, reinterpret_cast<const float4*>(partials),
-                       reinterpret_cast<float4*>(Y), epi);
+                       arrivals, p.dyn);
     MMSSL_LAUNCH_CHECK();
   }
   return 0;

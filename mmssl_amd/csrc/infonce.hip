@@ -756,10 +756,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2))) voi
   }
 }
 
-inline bool use_mfma(int d) {
-  static const int off = getenv("MMSSL_INFONCE_VALU") ? atoi(getenv("MMSSL_INFONCE_VALU")) : 0;
-  return !off && (d == 32 || d == 64);
-}
+inline bool use_mfma(int d) { return d == 32 || d == 64; }     // wider rows: the fp32-VALU tile kernels
 
 inline bool infonce_d_ok(int d) { return d == 32 || d == 64 || d == 128 || d == 256; }
 

@@ -432,8 +432,7 @@ def test_hot_node_draws_masks_and_two_contexts_do_not_interfere():
 @pytest.mark.parametrize("d", [64, 128])
 def test_spmm_inkernel_combine_stress(d):
     """Rows that span several heavy blocks are combined by the last-arriving block inside the kernel
-    (write-through partials + arrival ticket; the default) or by the second-stage kernel
-    (MMSSL_SPMM_TWO_STAGE=1). Alternate inputs launch after launch, so a stale partial from the previous
+    (write-through partials + arrival ticket). Alternate inputs launch after launch, so a stale partial from the previous
     launch (L1/L2 not refreshed) would show up as a wrong row; also check bit-reproducibility."""
     ops, graph = _ops()
     rng = np.random.default_rng(d)

@@ -322,6 +322,11 @@ int mmssl_linear_wgrad_f32(const float* gY, const uint8_t* keep, float scale, co
                            int64_t M, int K, int N, float* gW, float* gb, void* workspace,
                            size_t workspace_bytes, void* stream);
 /* out = g * keep * scale over n (multiple of 4) elements: the dropout backward as one pass. */
+/* The same for PACKED modal rows: G [rows, nm * dm] = nm modalities side by side, keep = the uint8 [nm, rows, dm] masks of
+ * mmssl_proj_fwd_f32 (dm % 4 == 0); out may alias G. The row-sharded step applies it after the reduce-scatter of the
+ * partial A^T products (the unsharded step uses mmssl_spmm_mask_f32's epilogue instead). */
+int mmssl_mask_packed_f32(const float* G, const uint8_t* keep, float scale, int64_t rows, int nm, int dm, float* out,
+                          void* stream);
 int mmssl_mask_scale_f32(const float* g, const uint8_t* keep, float scale, int64_t n, float* out,
                          void* stream);
 /* Dropout keep-mask (nn.Dropout(p), Models.py:54): keep[i] = 1 with probability 1-p, from

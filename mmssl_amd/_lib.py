@@ -104,6 +104,7 @@ SIGNATURES = {
     "mmssl_linear_wgrad_f32": (c_int, [c_void_p, c_void_p, c_float, c_void_p, c_int64, c_int, c_int, c_void_p,
                                        c_void_p, c_void_p, c_size_t, c_void_p]),
     "mmssl_mask_scale_f32": (c_int, [c_void_p, c_void_p, c_float, c_int64, c_void_p, c_void_p]),
+    "mmssl_mask_packed_f32": (c_int, [c_void_p, c_void_p, c_float, c_int64, c_int, c_int, c_void_p, c_void_p]),
     "mmssl_dropout_mask_u8": (c_int, [c_void_p, c_float, c_int64, c_void_p, c_void_p]),
     "mmssl_adamw_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_float, c_float,
                                 c_float, c_float, c_float, c_void_p]),

@@ -680,6 +680,41 @@ extern "C" int mmssl_mask_scale_f32(const float* g, const uint8_t* keep, float s
   return 0;
 }
 
+// Dropout backward of PACKED modal rows: G [rows, nm * dm] holds nm modalities side by side, keep is the uint8
+// [nm, rows, dm] mask of mmssl_proj_fwd_f32. out may alias G. (The unsharded step gets this from the SpMM's mask
+// epilogue; the row-sharded step applies it after the reduce-scatter of the partial products.)
+namespace {
+__global__ __launch_bounds__(kBlock) void mask_packed_kernel(const float4* __restrict__ G, const uchar4* __restrict__ keep,
+                                                             float scale, int64_t rows, int nm, int dm4,
+                                                             float4* __restrict__ out) {
+  const int64_t n4 = rows * nm * dm4;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n4; i += (int64_t)gridDim.x * kBlock) {
+    const int64_t row = i / (nm * dm4);
+    const int c = (int)(i - row * (nm * dm4));
+    const int m = c / dm4, cc = c - m * dm4;
+    const uchar4 k = keep[((int64_t)m * rows + row) * dm4 + cc];
+    const float4 g = G[i];
+    out[i] = make_float4(k.x ? g.x * scale : 0.f, k.y ? g.y * scale : 0.f, k.z ? g.z * scale : 0.f,
+                         k.w ? g.w * scale : 0.f);
+  }
+}
+}  // namespace
+
+extern "C" int mmssl_mask_packed_f32(const float* G, const uint8_t* keep, float scale, int64_t rows, int nm, int dm,
+                                     float* out, void* stream) {
+  if (rows < 0 || nm < 1 || dm < 4 || (dm & 3) || (rows > 0 && (!G || !keep || !out))) return MMSSL_E_BADARG;
+  if ((((uintptr_t)G | (uintptr_t)out) & 15) || ((uintptr_t)keep & 3)) return MMSSL_E_BADARG;
+  if (rows == 0) return 0;
+  const int64_t n4 = rows * nm * (dm / 4);
+  int64_t nb = (n4 + kBlock - 1) / kBlock;
+  nb = nb > 4096 ? 4096 : nb;
+  hipLaunchKernelGGL(mask_packed_kernel, dim3((unsigned)nb), dim3(kBlock), 0, as_stream(stream),
+                     reinterpret_cast<const float4*>(G), reinterpret_cast<const uchar4*>(keep), scale, rows, nm, dm / 4,
+                     reinterpret_cast<float4*>(out));
+  MMSSL_LAUNCH_CHECK();
+  return 0;
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // Rows of a ROW-SHARDED table for a batch of global indices (mmssl_amd/dist.py: the batch rows of BPR / InfoNCE
 // are assembled from the row owners by an all-reduce of zero-padded buffers): out[j] = table[idx[j] - lo] when this

@@ -45,10 +45,8 @@ class HipBackend:
             setattr(self, name, getattr(ops, name))
         # non-autograd kernels for the fused sharded node
         self.spmm_raw = ops._spmm_raw
-        self.linear_raw = ops._linear_raw
-        self.linear_wgrad_raw = ops._linear_wgrad_raw
-        self.combine_bwd = ops._combine_bwd
         self.softmax_rows_bwd = ops.softmax_rows_bwd
+        self.EPI_AXPY, self.EPI_AXPY_SOFTMAX_BWD = ops.EPI_AXPY, ops.EPI_AXPY_SOFTMAX_BWD
         self.dropout_masks = ops.dropout_masks
         self.loss_assemble = ops.loss_assemble
         self._ar = {}
@@ -74,29 +72,64 @@ class HipBackend:
             st = self._streams[key] = [torch.cuda.Stream(device=device) for _ in range(3)]
         return st
 
-    def batch_losses_rows(self, u, p, n, z_img, z_txt, decay, batch_size, tau):
-        """[mf, emb, 0, cl_img, cl_txt] from already gathered [B, d] rows: ONE fused node (BPR + both InfoNCE
-        problems, see ops._BatchLosses) fed with identity indices."""
-        B, dev = u.shape[0], u.device
+    def _identity(self, B, dev):
         ar = self._ar.get((B, dev))
         if ar is None:
             base = torch.arange(B, dtype=torch.int64, device=dev)
             ar = (base, base + B)
             self._ar[(B, dev)] = ar
-        ia = torch.cat((p, n), 0)
-        return self.ops.batch_losses_vec(u, ia, z_img, z_txt, ar[0], ar[0], ar[1], decay, batch_size, tau)
+        return ar
 
-    def combine_fwd(self, layers, inv, A, B, r):
-        """(out, ss) with ss = |A|^2 + |B|^2 over the local rows (0-dim tensor)."""
-        import torch as _t
+    def batch_losses_rows(self, u, ia, z_img, z_txt, decay, batch_size, tau, eager_w=None, tail=None):
+        """[mf, emb, 0, cl_img, cl_txt] from already gathered rows (u [B, d]; ia [2B, d] = positive then negative items):
+        ONE fused node (BPR + both InfoNCE problems, see ops._BatchLosses) fed with identity indices. eager_w + tail: the
+        single-chain form whose last launch also assembles the loss and ticks the step's counters (ops.batch_losses_vec)."""
+        ar = self._identity(u.shape[0], u.device)
+        return self.ops.batch_losses_vec(u, ia, z_img, z_txt, ar[0], ar[0], ar[1], decay, batch_size, tau,
+                                         eager_w=eager_w, tail=tail)
+
+    # ---- the packed node's kernels (the grouped projection and the two-sided fuse kernels of the unsharded hot node) ----
+    def packed_supported(self, feat_dims, rows, d):
+        from . import hotnode
+        return hotnode.packed_supported(feat_dims, rows, d)
+
+    def proj_forward(self, Fs, Ws, bs, keep, scale, draw_p=0.0, external_tick=False):
+        """(X, keep). keep None and draw_p > 0: the masks are drawn in the projection's epilogue (no mask launch)."""
+        ops = self.ops
+        if keep is None and draw_p > 0.0:
+            dev = Fs[0].device
+            X, keep = ops.proj_forward(Fs, Ws, bs, draw=(draw_p, ops._rng_state(dev)), scale=scale)
+            if not external_tick:
+                ops.tick_rng(dev)
+            return X, keep
+        return ops.proj_forward(Fs, Ws, bs, keep=keep, scale=scale)[0], keep
+
+    def proj_wgrad(self, G, Fs, want_bias):
+        return self.ops.proj_wgrad(G, Fs, want_bias=want_bias)
+
+    def fuse_fwd(self, us, MU, its, MI, inv, nm, r):
+        """(u_g, i_g, ss): both sides in one launch; ss = |MU|^2 + |MI|^2 over the local rows (0-dim tensor)."""
         from . import _lib
-        nb = _lib.lib().mmssl_layer_combine_blocks(A.shape[0], A.shape[1])
-        part = _t.empty(nb, dtype=_t.float32, device=A.device)
-        out = self.ops._combine_fwd(layers, inv, A, B, r, part)
-        ss = _t.empty((), dtype=_t.float32, device=A.device)
-        _lib.check(_lib.lib().mmssl_sum_partials_f32(part.data_ptr(), nb, ss.data_ptr(), _lib.stream_ptr()),
+        ops = self.ops
+        d = us[0].shape[1]
+        nbu, nbi = ops.fuse_blocks(us[0].shape[0], d, nm), ops.fuse_blocks(its[0].shape[0], d, nm)
+        part = torch.empty(nbu + nbi, dtype=torch.float32, device=MU.device)
+        u_g, i_g = ops.fuse_fwd([(us, MU, part[:nbu]), (its, MI, part[nbu:])], inv, nm, r)
+        ss = torch.empty((), dtype=torch.float32, device=MU.device)
+        _lib.check(_lib.lib().mmssl_sum_partials_f32(part.data_ptr(), nbu + nbi, ss.data_ptr(), _lib.stream_ptr()),
                    "mmssl_sum_partials_f32")
-        return out, ss
+        return u_g, i_g, ss
+
+    def fuse_bwd(self, MU, Gu, G_MU, MI, Gi, G_MI, nm, r, inv, g_ss):
+        """(gMU, g_u0, gMI): normalise backward + regulariser gradient of both sides in one launch."""
+        (gMU, g_u0), (gMI, _) = self.ops.fuse_bwd([(MU, Gu, G_MU, True), (MI, Gi, G_MI, False)], nm, r, inv, g_ss, 2.0)
+        return gMU, g_u0, gMI
+
+    def spmm_mask(self, plan, X, keep, dm, scale):
+        return self.ops.spmm_mask_raw(plan, True, X, keep, dm, scale)
+
+    def mask_packed(self, G, keep, dm, scale):
+        return self.ops.mask_packed(G, keep, dm, scale)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -168,10 +201,12 @@ class AllGatherRows(torch.autograd.Function):
         world = dist.get_world_size(group)
         out = torch.empty((world * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
         dist.all_gather_into_tensor(out, x.contiguous(), group=group)
+        _log_comm("all_gather", out)
         return out
 
     @staticmethod
     def backward(ctx, g):
+        _log_comm("reduce_scatter", g)
         return _reduce_scatter_sum(g, ctx.per, ctx.group), None
 
 
@@ -299,14 +334,13 @@ class ShardedMMSSL(nn.Module):
     def _forward_fused(self, graphs, keep_masks, modal_empty):
         bk, c = self.bk, self.cfg
         ui, iu, img_ui, img_iu, txt_ui, txt_iu = graphs
-        scale, km_i, km_t = 1.0, None, None
+        scale, keep = 1.0, None
         if self.training and c.drop_rate > 0:
             scale = 1.0 / (1.0 - c.drop_rate)
-            if keep_masks is not None:
-                km_i, km_t = keep_masks
-            else:
-                km_i, km_t = bk.dropout_masks(2, self.ish.per, c.embed_size, c.drop_rate, self.E_i.device,
-                                              **({"external_tick": True} if getattr(self, "_external_ticks", False) else {}))
+            if keep_masks is not None:           # injected (parity runs): [2, per_items, d] as the projection takes it
+                keep = torch.stack(tuple(keep_masks)) if isinstance(keep_masks, (tuple, list)) else keep_masks
+            else:                                # drawn by the projection's epilogue from the device generator
+                keep = ("draw", float(c.drop_rate), bool(getattr(self, "_external_ticks", False)))
         if modal_empty:
             z = getattr(self, "_zero_views", None)
             if z is None or z[0].device != self.E_u.device:
@@ -323,10 +357,12 @@ class ShardedMMSSL(nn.Module):
             txt_uid, txt_iid = bk.spmm(txt_ui, Ei_full), bk.spmm(txt_iu, Eu_full)
             u = bk.l2norm_rows(self._fusion(img_uid, txt_uid), self.E_u, c.id_cat_rate)
             i = bk.l2norm_rows(self._fusion(img_iid, txt_iid), self.E_i, c.id_cat_rate)
-        (u_g, i_g, ss, img_item, txt_item, img_user, txt_user) = _ShardedHotForward.apply(
-            self.image_feats, self.img_w, self.img_b, km_i, self.text_feats, self.txt_w, self.txt_b, km_t, scale,
-            u, i, ui, iu, c.n_ui_layers, c.model_cat_rate, bk, self.group)
+        d = c.embed_size
+        u_g, i_g, ss, MI, MU = _ShardedHotForward.apply(
+            2, scale, keep, ui, iu, c.n_ui_layers, c.model_cat_rate, bk, self.group, u, i,
+            self.image_feats, self.text_feats, self.img_w, self.txt_w, self.img_b, self.txt_b)
         self._feat_ss_local = ss
+        img_item, txt_item, img_user, txt_user = MI[:, :d], MI[:, d:], MU[:, :d], MU[:, d:]
         return (u_g, i_g, img_item, txt_item, img_user, txt_user, u_g, i_g, img_uid, txt_uid, img_iid, txt_iid)
 
     def replicated_parameters(self):
@@ -345,9 +381,12 @@ class ShardedMMSSL(nn.Module):
         reference's 12 outputs (0/6 and 1/7 identical). `fused` selects the single-node
         implementation (_ShardedHotForward); fused=False composes differentiable backend ops and
         AllGatherRows (the same math, kept as the cross-check)."""
-        if fused:
-            return self._forward_fused(graphs, keep_masks, modal_empty)
         bk, c = self.bk, self.cfg
+        self.last_fused = bool(fused and bk.packed_supported([self.image_feats.shape[1], self.text_feats.shape[1]],
+                                                             self.ish.per, c.embed_size))
+        if self.last_fused:
+            return self._forward_fused(graphs, keep_masks, modal_empty)
+        # (feature widths the grouped projection does not take: the composed form below runs them)
         ui, iu, img_ui, img_iu, txt_ui, txt_iu = graphs
         scale = 1.0
         km_i = km_t = None
@@ -419,186 +458,242 @@ def _all_gather_raw(x, group):
     return out
 
 
-def _run_interleaved(chains):
-    """Drive generator `chains` round-robin: each chain does its compute (on its own stream) and YIELDS right
-    before every collective it is about to issue. One process group executes collectives in issue order, so
-    issuing them depth by depth (C1 B1 A1 C2 B2 A2 ...) instead of chain by chain lets one chain's kernels run
-    under another chain's collective, and the order is the same on every rank by construction."""
-    live = list(chains)
-    while live:
-        nxt = []
-        for c in live:
-            try:
-                next(c)
-                nxt.append(c)
-            except StopIteration:
-                pass
-        live = nxt
+def _coalesced(group, device):
+    """One grouped launch for the collectives issued inside (RCCL: ncclGroupStart / End); None where the backend has no
+    grouped form (gloo: the calls simply run one after the other)."""
+    import contextlib
+    if dist.get_backend(group) != "nccl" or not hasattr(dist, "_coalescing_manager"):
+        return contextlib.nullcontext(), False
+    return dist._coalescing_manager(group=group, device=device, async_ops=False), True
 
 
-class _Streams:
-    """Fork/join helper around three side streams (None on CPU: everything runs inline)."""
+def _all_gather_pair(xa, xb, group):
+    """Row shards xa, xb (same sharding, different widths) -> their gathered forms, as ONE grouped launch."""
+    if _solo(group):
+        if COMM["log"] is not None:
+            COMM["log"].append(("all_gather", (tuple(xa.shape), tuple(xb.shape)), 4 * (xa.numel() + xb.numel())))
+        return xa, xb
+    world = dist.get_world_size(group)
+    outs = [torch.empty((world * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device) for x in (xa, xb)]
+    cm, grouped = _coalesced(group, xa.device)
+    with cm:
+        for o, x in zip(outs, (xa, xb)):
+            dist.all_gather_into_tensor(o, x.contiguous(), group=group)
+    if COMM["log"] is not None:
+        if grouped:
+            COMM["log"].append(("all_gather", tuple(tuple(o.shape) for o in outs), 4 * sum(o.numel() for o in outs)))
+        else:
+            for o in outs:
+                _log_comm("all_gather", o)
+    return outs[0], outs[1]
+
+
+def _reduce_scatter_pair(fa, fb, per, group):
+    """Full partial products fa, fb (same row count) -> this rank's rows of their sums, as ONE grouped launch."""
+    if _solo(group) or dist.get_backend(group) == "gloo":
+        outs = (_reduce_scatter_sum(fa, per, group), _reduce_scatter_sum(fb, per, group))
+        if COMM["log"] is not None:
+            if _solo(group):
+                COMM["log"].append(("reduce_scatter", (tuple(fa.shape), tuple(fb.shape)), 4 * (fa.numel() + fb.numel())))
+            else:
+                _log_comm("reduce_scatter", fa)
+                _log_comm("reduce_scatter", fb)
+        return outs
+    outs = [torch.empty((per,) + tuple(f.shape[1:]), dtype=f.dtype, device=f.device) for f in (fa, fb)]
+    cm, grouped = _coalesced(group, fa.device)
+    with cm:
+        for o, f in zip(outs, (fa, fb)):
+            dist.reduce_scatter_tensor(o, f.contiguous(), group=group)
+    if COMM["log"] is not None:
+        if grouped:
+            COMM["log"].append(("reduce_scatter", (tuple(fa.shape), tuple(fb.shape)), 4 * (fa.numel() + fb.numel())))
+        else:
+            _log_comm("reduce_scatter", fa)
+            _log_comm("reduce_scatter", fb)
+    return outs[0], outs[1]
+
+
+class _Side:
+    """The GCN chain's side stream next to the current one (None on CPU: everything runs inline)."""
 
     def __init__(self, bk, ref):
-        self.side = bk.side_streams(ref.device) if (hasattr(bk, "side_streams") and ref.is_cuda) else None
-        self.side = self.side or None
-        self.main = torch.cuda.current_stream(ref.device) if self.side else None
+        side = bk.side_streams(ref.device) if (hasattr(bk, "side_streams") and ref.is_cuda) else None
+        self.side = side[2] if side else None
+        self.main = torch.cuda.current_stream(ref.device) if side else None
+
+    def gcn(self):
+        import contextlib
+        return torch.cuda.stream(self.side) if self.side is not None else contextlib.nullcontext()
 
     def fork(self):
-        if self.side:
-            for st in self.side:
-                st.wait_stream(self.main)
+        if self.side is not None:
+            self.side.wait_stream(self.main)
 
     def join(self):
-        if self.side:
-            for st in self.side:
-                self.main.wait_stream(st)
+        if self.side is not None:
+            self.main.wait_stream(self.side)
 
-    def on(self, k):
-        import contextlib
-        return torch.cuda.stream(self.side[k]) if self.side else contextlib.nullcontext()
+    def meet(self, solo):
+        """Both chains' operands of one GROUPED collective must exist on the stream that issues it (the current one);
+        afterwards the side stream continues behind it. One rank without forced collectives: nothing is issued, the
+        chains stay independent."""
+        if self.side is not None and not solo:
+            self.main.wait_stream(self.side)
+
+    def part(self, solo):
+        if self.side is not None and not solo:
+            self.side.wait_stream(self.main)
 
 
 class _ShardedHotForward(torch.autograd.Function):
-    """Row-sharded counterpart of hotnode._HotNode: projection of the local item rows, modal SpMM
-    chains, G-layer GCN chain and the layer-mean / modality fusion, with an all-gather of the row
-    shards before every A_r . X and — in the hand-written backward — a reduce-scatter of every
-    A_r^T . gY_r. One autograd node. The three independent chains (image, text, GCN) run on three forked
-    streams and their collectives are issued interleaved (see _run_interleaved), so a gather of one chain is
-    hidden behind the kernels of the other two."""
+    """Row-sharded counterpart of hotnode._HotNode, one autograd node: the grouped projection of the local item rows,
+    the PACKED modal chain (all modalities side by side: one d = 64 nm SpMM pair instead of nm of them), the GCN chain
+    on a side stream and the two-sided fuse kernels - with an all-gather of the row shards before every A_r . X and, in
+    the hand-written backward, a reduce-scatter of every A_r^T . gY_r.
+
+    Collectives per step (L GCN layers): forward 2L gathers for the GCN chain; the modal chain's two gathers are GROUPED
+    with the GCN gathers of the same sharding (items / users) at the point where the projection has typically finished
+    (GCN gathers 2 and 3 for L >= 2: the first GCN layer runs under the GEMM), so they cost no launch of their own.
+    Backward: the modal chain's two reduce-scatters are on the critical path (the weight gradient waits for them) and are
+    grouped with the FIRST two GCN reduce-scatters. 2L + 2L collectives instead of (2L + 2 nm) twice."""
 
     @staticmethod
-    def forward(ctx, F_img, W_img, b_img, keep_img, F_txt, W_txt, b_txt, keep_txt, scale, u0, i0, ui, iu,
-                n_layers, r, bk, group):
+    def forward(ctx, nm, scale, keep, ui, iu, n_layers, r, bk, group, u0, i0, *flat):
+        Fs, Ws, bs = flat[:nm], flat[nm:2 * nm], flat[2 * nm:3 * nm]
+        draw_p, ext_tick = 0.0, False
+        if isinstance(keep, tuple):                  # ("draw", p, external_tick): fresh masks from the device generator
+            _, draw_p, ext_tick = keep
+            keep = None
         g = group
-        st = _Streams(bk, u0)
+        solo = _solo(g)
+        st = _Side(bk, u0)
         twin = (lambda p, k: p.twin(k)) if hasattr(ui, "twin") else (lambda p, k: p)
-        out = {}
-
-        def modal_chain(k, F_, W, b, keep, key):
-            with st.on(k):
-                x = bk.linear_raw(F_, W, b, keep, scale)
-            yield
-            with st.on(k):
-                user = bk.spmm_raw(twin(ui, k), False, _all_gather_raw(x, g), bk.EPI_NONE)
-            yield
-            with st.on(k):
-                item = bk.spmm_raw(twin(iu, k), False, _all_gather_raw(user, g), bk.EPI_NONE)
-            out[key] = (user, item)
-
-        def gcn_chain():
-            us, its = [u0], [i0]
-            u, i = u0, i0
-            for l in range(n_layers):
-                epi = bk.EPI_SOFTMAX if l == n_layers - 1 else bk.EPI_NONE
-                yield
-                with st.on(2):
-                    u = bk.spmm_raw(twin(ui, 2), False, _all_gather_raw(i, g), epi)
-                yield
-                with st.on(2):
-                    i = bk.spmm_raw(twin(iu, 2), False, _all_gather_raw(u, g), epi)
-                us.append(u)
-                its.append(i)
-            out["gcn"] = (us, its)
-
         st.fork()
-        # issue order per depth: GCN first (ready at once), then text (short GEMM), then image (long GEMM)
-        _run_interleaved([gcn_chain(), modal_chain(1, F_txt, W_txt, b_txt, keep_txt, "txt"),
-                          modal_chain(0, F_img, W_img, b_img, keep_img, "img")])
+        X, keep = bk.proj_forward(list(Fs), list(Ws), list(bs), keep, scale, draw_p, ext_tick)      # [per_i, 64 nm]
+        pair_at = min(2, 2 * n_layers - 2)           # GCN gather (even = item rows) the modal chain's first one rides on
+        us, its = [u0], [i0]
+        u, i = u0, i0
+        MU = MI = None
+        k = 0
+        for l in range(n_layers):
+            epi = bk.EPI_SOFTMAX if l == n_layers - 1 else bk.EPI_NONE
+            # ---- item rows -> user rows
+            if k == pair_at:
+                st.meet(solo)
+                i_full, X_full = _all_gather_pair(i, X, g)
+                st.part(solo)
+                MU = bk.spmm_raw(ui, False, X_full, bk.EPI_NONE)
+            else:
+                with st.gcn():
+                    i_full = _all_gather_raw(i, g)
+            with st.gcn():
+                u = bk.spmm_raw(twin(ui, 2), False, i_full, epi)
+            k += 1
+            # ---- user rows -> item rows
+            if k == pair_at + 1:
+                st.meet(solo)
+                u_full, MU_full = _all_gather_pair(u, MU, g)
+                st.part(solo)
+                MI = bk.spmm_raw(iu, False, MU_full, bk.EPI_NONE)
+            else:
+                with st.gcn():
+                    u_full = _all_gather_raw(u, g)
+            with st.gcn():
+                i = bk.spmm_raw(twin(iu, 2), False, u_full, epi)
+            k += 1
+            us.append(u)
+            its.append(i)
         st.join()
-        (img_user, img_item), (txt_user, txt_item), (us, its) = out["img"], out["txt"], out["gcn"]
         inv = 1.0 / (n_layers + 1)
-        u_g, ss_u = bk.combine_fwd(us, inv, img_user, txt_user, r)
-        i_g, ss_i = bk.combine_fwd(its, inv, img_item, txt_item, r)
-        ctx.save_for_backward(F_img, W_img, keep_img, F_txt, W_txt, keep_txt, img_user, txt_user, img_item, txt_item,
-                              us[-1], its[-1])
-        ctx.cfg = (ui, iu, n_layers, float(r), inv, float(scale), bk, g, b_img is not None, b_txt is not None)
+        u_g, i_g, ss = bk.fuse_fwd(us, MU, its, MI, inv, nm, r)
+        ctx.save_for_backward(MU, MI, us[-1], its[-1], keep, *Fs)
+        ctx.cfg = (nm, float(scale), ui, iu, n_layers, float(r), inv, bk, g, [b is not None for b in bs])
         ctx.set_materialize_grads(False)
-        return u_g, i_g, ss_u + ss_i, img_item, txt_item, img_user, txt_user
+        return u_g, i_g, ss, MI, MU
 
     @staticmethod
-    def backward(ctx, Gu, Gi, g_ss, G_img_item, G_txt_item, G_img_user, G_txt_user):
-        (F_img, W_img, keep_img, F_txt, W_txt, keep_txt, img_user, txt_user, img_item, txt_item, uG,
-         iG) = ctx.saved_tensors
-        ui, iu, n_layers, r, inv, scale, bk, g, has_bi, has_bt = ctx.cfg
-        per_u, per_i = img_user.shape[0], img_item.shape[0]
-        Gu = Gu.contiguous() if Gu is not None else torch.zeros_like(img_user)
-        Gi = Gi.contiguous() if Gi is not None else torch.zeros_like(img_item)
+    def backward(ctx, Gu, Gi, g_ss, G_MI, G_MU):
+        MU, MI, uG, iG, keep = ctx.saved_tensors[:5]
+        Fs = ctx.saved_tensors[5:]
+        nm, scale, ui, iu, n_layers, r, inv, bk, g, has_b = ctx.cfg
+        per_u, per_i = MU.shape[0], MI.shape[0]
+        d = uG.shape[1]
+        Gu = Gu.contiguous() if Gu is not None else torch.zeros_like(uG)
+        Gi = Gi.contiguous() if Gi is not None else torch.zeros_like(iG)
         g_ss = g_ss.contiguous().to(torch.float32) if g_ss is not None else None
-        g_iu_, g_tu_, g_u0 = bk.combine_bwd(img_user, txt_user, Gu, r, inv, g_ss, 2.0, True)
-        g_ii_, g_ti_, _ = bk.combine_bwd(img_item, txt_item, Gi, r, inv, g_ss, 2.0, False)
-        if G_img_item is not None:
-            g_ii_ = g_ii_ + G_img_item
-        if G_txt_item is not None:
-            g_ti_ = g_ti_ + G_txt_item
-        if G_img_user is not None:
-            g_iu_ = g_iu_ + G_img_user
-        if G_txt_user is not None:
-            g_tu_ = g_tu_ + G_txt_user
-        st = _Streams(bk, Gu)
+        G_MI = G_MI.contiguous() if G_MI is not None else None
+        G_MU = G_MU.contiguous() if G_MU is not None else None
+        solo = _solo(g)
+        fused_epi = solo and hasattr(bk, "ops")      # one rank: the scatter is the identity, the add rides in the SpMM store
+        st = _Side(bk, Gu)
         twin = (lambda p, k: p.twin(k)) if hasattr(ui, "twin") else (lambda p, k: p)
-        if st.side:                      # main-pool tensors read on the side streams
-            for t in (keep_img, keep_txt, img_user, txt_user, img_item, txt_item, uG, iG, Gu, Gi, g_iu_, g_tu_,
-                      g_ii_, g_ti_):
-                if t is not None:
-                    for s_ in st.side:
-                        t.record_stream(s_)
-        out = {}
-
-        solo = _solo(g) and hasattr(bk, "ops")
-        EPI_AXPY = 2                      # ops.EPI_AXPY: y = A^T.x + alpha * Z fused into the SpMM store
-
-        def t_add(plan, x, per, k, Z, alpha):
-            """reduce_scatter(A_r^T . x) + alpha * Z. One rank: the scatter is the identity and the add rides in the
-            SpMM's epilogue (as in the unsharded node); else SpMM -> reduce-scatter -> one fused add."""
-            if solo:
-                _log_comm("reduce_scatter", Z)
-                return bk.spmm_raw(plan, True, x, EPI_AXPY, Z, alpha)
-            part = bk.spmm_raw(plan, True, x, bk.EPI_NONE)
-            _log_comm("reduce_scatter", part)
-            return torch.add(_reduce_scatter_sum(part, per, g), Z, alpha=alpha)
-
-        def t_plain(plan, x, per, k):
-            part = bk.spmm_raw(plan, True, x, bk.EPI_NONE)
-            _log_comm("reduce_scatter", part)
-            return _reduce_scatter_sum(part, per, g)
-
-        def modal_chain(k, g_item, g_user, keep, F_, W, key):
-            # g(x) = A_ui_r^T . (A_iu_r^T . g(item feats) + g(user feats)), each A_r^T product reduce-scattered
-            yield
-            with st.on(k):
-                gu_ = t_add(twin(iu, k), g_item, per_u, k, g_user, 1.0)
-            yield
-            with st.on(k):
-                gx = t_plain(twin(ui, k), gu_, per_i, k)
-                _, gW, gb = bk.linear_wgrad_raw(gx, keep, scale, F_, W)
-            out[key] = (gW, gb)
-
-        def gcn_chain():
-            with st.on(2):
-                gi = bk.softmax_rows_bwd(iG, Gi, inv)
-            yield
-            with st.on(2):
-                gu = bk.softmax_rows_bwd(uG, t_add(twin(iu, 2), gi, per_u, 2, Gu, inv), 1.0)
-            yield
-            with st.on(2):
-                gi = t_add(twin(ui, 2), gu, per_i, 2, Gi, inv)
-            for _ in range(n_layers - 1):
-                yield
-                with st.on(2):
-                    gu = t_add(twin(iu, 2), gi, per_u, 2, Gu, inv)
-                yield
-                with st.on(2):
-                    gi = t_add(twin(ui, 2), gu, per_i, 2, Gi, inv)
-            out["gi"] = gi
-
         st.fork()
-        _run_interleaved([gcn_chain(), modal_chain(0, g_ii_, g_iu_, keep_img, F_img, W_img, "img"),
-                          modal_chain(1, g_ti_, g_tu_, keep_txt, F_txt, W_txt, "txt")])
+        gMU, g_u0, gMI = bk.fuse_bwd(MU, Gu, G_MU, MI, Gi, G_MI, nm, r, inv, g_ss)
+        if st.side is not None:
+            for t in (uG, iG, Gu, Gi):
+                t.record_stream(st.side)
+
+        def rs_add(plan, x, per, Z, alpha, epi=None, S=None, log=True):
+            """reduce_scatter(A_r^T . x) + alpha * Z (then the softmax backward against S when epi asks for it)."""
+            if fused_epi:
+                if log:
+                    _log_comm("reduce_scatter", Z)
+                if epi is not None:
+                    return bk.spmm_raw(plan, True, x, epi, Z, alpha, S)
+                return bk.spmm_raw(plan, True, x, bk.EPI_AXPY, Z, alpha)
+            part = bk.spmm_raw(plan, True, x, bk.EPI_NONE)
+            _log_comm("reduce_scatter", part)
+            y = _reduce_scatter_sum(part, per, g).add_(Z, alpha=alpha)
+            return bk.softmax_rows_bwd(S, y, 1.0) if S is not None else y
+
+        # ---- depth 1 (user rows): GCN A_iu_r^T g(i_G) and modal A_iu_r^T g(MI), one grouped reduce-scatter
+        with st.gcn():
+            gi = bk.softmax_rows_bwd(iG, Gi, inv)
+        if fused_epi:
+            with st.gcn():
+                gu = rs_add(twin(iu, 2), gi, per_u, Gu, inv, bk.EPI_AXPY_SOFTMAX_BWD, uG, log=False)
+            t = bk.spmm_raw(iu, True, gMI, bk.EPI_AXPY, gMU, 1.0)
+            if COMM["log"] is not None:
+                COMM["log"].append(("reduce_scatter", (tuple(Gu.shape), tuple(gMU.shape)), 4 * (Gu.numel() + gMU.numel())))
+        else:
+            with st.gcn():
+                part_g = bk.spmm_raw(twin(iu, 2), True, gi, bk.EPI_NONE)
+            part_m = bk.spmm_raw(iu, True, gMI, bk.EPI_NONE)
+            st.meet(solo)
+            rg, rm = _reduce_scatter_pair(part_g, part_m, per_u, g)
+            st.part(solo)
+            t = rm.add_(gMU)
+            with st.gcn():
+                gu = bk.softmax_rows_bwd(uG, rg.add_(Gu, alpha=inv), 1.0)
+        # ---- depth 2 (item rows): GCN A_ui_r^T g(u) and modal A_ui_r^T t (+ the projection's dropout backward)
+        if fused_epi:
+            with st.gcn():
+                gi = rs_add(twin(ui, 2), gu, per_i, Gi, inv, log=False)
+            if COMM["log"] is not None:
+                COMM["log"].append(("reduce_scatter", (tuple(Gi.shape), tuple(gMI.shape)), 4 * (Gi.numel() + gMI.numel())))
+            gX = bk.spmm_mask(ui, t, keep, d, scale) if keep is not None else bk.spmm_raw(ui, True, t, bk.EPI_NONE)
+        else:
+            with st.gcn():
+                part_g = bk.spmm_raw(twin(ui, 2), True, gu, bk.EPI_NONE)
+            part_m = bk.spmm_raw(ui, True, t, bk.EPI_NONE)
+            st.meet(solo)
+            rg, gX = _reduce_scatter_pair(part_g, part_m, per_i, g)
+            st.part(solo)
+            if keep is not None:
+                gX = bk.mask_packed(gX, keep, d, scale)
+            with st.gcn():
+                gi = rg.add_(Gi, alpha=inv)
+        # ---- the weight gradient (current stream) next to the rest of the GCN chain (side stream)
+        gW, gb = bk.proj_wgrad(gX, list(Fs), any(has_b))
+        with st.gcn():
+            for _ in range(n_layers - 1):
+                gu = rs_add(twin(iu, 2), gi, per_u, Gu, inv)
+                gi = rs_add(twin(ui, 2), gu, per_i, Gi, inv)
         st.join()
-        (gW_img, gb_img), (gW_txt, gb_txt), gi = out["img"], out["txt"], out["gi"]
-        return (None, gW_img, gb_img if has_bi else None, None, None, gW_txt, gb_txt if has_bt else None, None, None,
-                g_u0, gi, None, None, None, None, None, None)
+        if st.side is not None:
+            gi.record_stream(st.main)
+        grads_b = [(gb[k] if (gb is not None and has_b[k]) else None) for k in range(nm)]
+        return (None,) * 9 + (g_u0, gi) + (None,) * nm + tuple(gW) + tuple(grads_b)
 
 
 class ShardedHotPathStep:
@@ -644,86 +739,91 @@ class ShardedHotPathStep:
                 self.neg.copy_(neg)
 
     def losses(self, keep_masks=None):
+        """Returns (roots, grads, local_total, feat_local): torch.autograd.backward(roots, grads) is the step's backward;
+        local_total = replicated loss terms + THIS rank's share of the regulariser."""
         m, bk, c, g = self.model, self.model.bk, self.model.cfg, self.group
         o = m(self.graphs, keep_masks=keep_masks, modal_empty=self.modal_empty, fused=self.fused)
+        fused = self.fused and m.last_fused
+        items = self.batch[1:3].reshape(-1)           # positive then negative items: one [2B] index list, one piece
         if self.modal_empty:       # the id views are exact zeros: nothing to gather for them
-            u, p, n = GatherBatchRowsMulti.apply(g, 3, bk, o[0], o[1], o[1], self.users, self.pos, self.neg,
-                                                 m.ush.lo, m.ish.lo, m.ish.lo)
+            u, ia = GatherBatchRowsMulti.apply(g, 2, bk, o[0], o[1], self.users, items, m.ush.lo, m.ish.lo)
             zc = getattr(self, "_zero_rows", None)
             if zc is None or zc.shape != u.shape or zc.device != u.device:
                 zc = self._zero_rows = torch.zeros_like(u)
             z_img = z_txt = zc
         else:
-            u, p, n, z_img, z_txt = GatherBatchRowsMulti.apply(
-                g, 5, bk, o[0], o[1], o[1], o[8], o[9], self.users, self.pos, self.neg, self.users, self.users,
-                m.ush.lo, m.ish.lo, m.ish.lo, m.ush.lo, m.ush.lo)
-        if self.fused:
-            # one fused loss node + one-launch assembly; the regulariser enters with this rank's local sum
-            terms = bk.batch_losses_rows(u, p, n, z_img, z_txt, c.decay, self.batch_size, c.tau)
-            if self._loss_w is None or self._loss_w.device != terms.device:
-                self._loss_w = torch.tensor([1.0, 1.0, 1.0, c.cl_rate, c.cl_rate], dtype=torch.float32,
-                                            device=terms.device)
-            feat_c = c.feat_reg_decay * 0.5 / self.n_items
-            if _solo(g) and hasattr(bk, "ops"):
-                # one rank: the local regulariser is the global one -> the step's loss lands in self.loss directly and
-                # the assembly launch also advances the step-owned counters (see hotpath.HotPathStep)
-                total_local = bk.loss_assemble(terms, self._loss_w, m._feat_ss_local, feat_c, out=self.loss,
-                                               ticks=getattr(self, "_ticks", None))
-                return total_local, None, True
-            total_local = bk.loss_assemble(terms, self._loss_w, m._feat_ss_local, feat_c)
-            feat_local = (feat_c * m._feat_ss_local).detach()
-            return total_local, feat_local, True
-        mf, emb = bk.bpr(u, p, n, c.decay, self.batch_size)
-        if self.fused:
-            feat_local = (c.feat_reg_decay * 0.5 / self.n_items) * m._feat_ss_local
-        else:
-            feat_local = c.feat_reg_decay * ((0.5 * bk.sumsq(o[2]) + 0.5 * bk.sumsq(o[3]) + 0.5 * bk.sumsq(o[4])
-                                              + 0.5 * bk.sumsq(o[5])) / self.n_items)
+            u, ia, z_img, z_txt = GatherBatchRowsMulti.apply(
+                g, 4, bk, o[0], o[1], o[8], o[9], self.users, items, self.users, self.users,
+                m.ush.lo, m.ish.lo, m.ush.lo, m.ush.lo)
+        feat_c = c.feat_reg_decay * 0.5 / self.n_items
+        if fused:
+            if self._loss_w is None or self._loss_w.device != u.device:
+                self._loss_w = torch.tensor([1.0, 1.0, 1.0, c.cl_rate, c.cl_rate], dtype=torch.float32, device=u.device)
+                self._feat_c = torch.full((), feat_c, dtype=torch.float32, device=u.device)
+            ss = m._feat_ss_local
+            if hasattr(bk, "ops"):
+                # product backend: the loss section as ONE chain of launches rooted at the terms' known gradients (the
+                # loss weights); its last launch assembles replicated terms + c * local regulariser into self.loss and
+                # advances the step-owned counters (see hotpath.HotPathStep._losses_eager)
+                terms = bk.batch_losses_rows(u, ia, z_img, z_txt, c.decay, self.batch_size, c.tau, eager_w=self._loss_w,
+                                             tail=(ss.detach(), feat_c, self.loss, getattr(self, "_ticks", None)))
+                return [terms, ss], [self._loss_w, self._feat_c], self.loss, (feat_c * ss).detach()
+            terms = bk.batch_losses_rows(u, ia, z_img, z_txt, c.decay, self.batch_size, c.tau)
+            total_local = bk.loss_assemble(terms, self._loss_w, ss, feat_c)
+            return [total_local], [None], total_local.detach(), (feat_c * ss).detach()
+        B = self.batch_size
+        mf, emb = bk.bpr(u, ia[:B], ia[B:], c.decay, self.batch_size)
+        feat_local = c.feat_reg_decay * ((0.5 * bk.sumsq(o[2]) + 0.5 * bk.sumsq(o[3]) + 0.5 * bk.sumsq(o[4])
+                                          + 0.5 * bk.sumsq(o[5])) / self.n_items)
         cl1 = bk.infonce(z_img, u, c.tau)
         cl2 = bk.infonce(z_txt, u, c.tau)
-        replicated = mf + emb + c.cl_rate * (cl1 + cl2)
-        return replicated, feat_local, False
+        total_local = mf + emb + c.cl_rate * (cl1 + cl2) + feat_local
+        return [total_local], [None], total_local.detach(), feat_local.detach()
 
     def backward(self, keep_masks=None):
-        first, feat_local, assembled = self.losses(keep_masks if keep_masks is not None else self.keep_masks)
+        roots, grads, local_total, feat_local = self.losses(keep_masks if keep_masks is not None else self.keep_masks)
         for p in self.model.parameters():
             p.grad = None
-        # assembled: `first` already is replicated + local regulariser (one kernel); else two autograd scalars
-        local_total = first if assembled else first + feat_local
-        local_total.backward()
-        # replicated dense parameters: partial (local-row) gradients -> one bucketed all-reduce
+        torch.autograd.backward(roots, grads)
+        # replicated dense parameters: partial (local-row) gradients -> ONE all-reduce of a persistent flat bucket that also
+        # carries this rank's regulariser share in its last slot (no second collective for one scalar); the gradients are
+        # packed by one multi-tensor copy and afterwards ARE views of the bucket (no copy back)
         params = [p for p in self.model.replicated_parameters() if p.grad is not None]
         solo = _solo(self.group)
-        if params:
-            if solo:                     # one rank: the local gradients ARE the global ones (only the accounting stays)
-                if COMM["log"] is not None:
-                    COMM["log"].append(("all_reduce", (sum(p.grad.numel() for p in params),),
-                                        4 * sum(p.grad.numel() for p in params)))
-            else:
-                flat = torch.cat([p.grad.reshape(-1) for p in params])
-                _all_reduce(flat, self.group)
-                _log_comm("all_reduce", flat)
-                k = 0
-                for p in params:
-                    n = p.grad.numel()
-                    p.grad.copy_(flat[k:k + n].view_as(p.grad))
-                    k += n
-        if solo:
-            if COMM["log"] is not None:
-                COMM["log"].append(("all_reduce", (1,), 4))
-            if feat_local is not None or not assembled:
-                self.loss.copy_(local_total.detach())
+        if solo:                         # one rank: the local values ARE the global ones (only the accounting stays)
+            if COMM["log"] is not None and params:
+                n = sum(p.grad.numel() for p in params) + 1
+                COMM["log"].append(("all_reduce", (n,), 4 * n))
+            if local_total is not self.loss:
+                self.loss.copy_(local_total)
             return self.loss
-        feat = feat_local.detach().clone()
-        _all_reduce(feat, self.group)
-        _log_comm("all_reduce", feat)
-        total = local_total.detach() - feat_local.detach() + feat      # replicated part + GLOBAL regulariser
+        sizes = [p.grad.numel() for p in params]
+        key = tuple(sizes)
+        if getattr(self, "_bucket_key", None) != key:
+            self._bucket = torch.empty(sum(sizes) + 1, dtype=torch.float32, device=self.loss.device)
+            self._bucket_key = key
+        flat = self._bucket
+        views, k = [], 0
+        for p, n in zip(params, sizes):
+            views.append(flat[k:k + n].view_as(p.grad))
+            k += n
+        if params:
+            torch._foreach_copy_(views, [p.grad for p in params])
+        flat[-1:].copy_(feat_local.reshape(1))
+        _all_reduce(flat, self.group)
+        _log_comm("all_reduce", flat)
+        for p, v in zip(params, views):
+            p.grad = v
+        total = local_total - feat_local + flat[-1]      # replicated part + GLOBAL regulariser
         self.loss.copy_(total)
         return total
 
     def _step(self):
         ops_ = getattr(self.model.bk, "ops", None)
-        own_ticks = (ops_ is not None and self.optimizer is not None and self.fused and _solo(self.group)
+        m = self.model
+        packed = self.fused and m.bk.packed_supported([m.image_feats.shape[1], m.text_feats.shape[1]], m.ish.per,
+                                                      m.cfg.embed_size)
+        own_ticks = (ops_ is not None and self.optimizer is not None and packed
                      and hasattr(self.optimizer, "step_counter"))
         self._ticks = None
         if own_ticks:          # the loss-assembly launch advances the RNG and AdamW counters (no tick launches)
@@ -804,18 +904,26 @@ def comm_replay_ms(log, group, dev, iters=10):
     world = dist.get_world_size(group)
     bufs = []
     for kind, shape, _ in log:
-        full = torch.zeros(shape, dtype=torch.float32, device=dev)
-        per = (shape[0] // world,) + tuple(shape[1:]) if kind != "all_reduce" else shape
-        bufs.append((kind, full, torch.zeros(per, dtype=torch.float32, device=dev)))
+        shapes = shape if (len(shape) and isinstance(shape[0], tuple)) else (shape,)      # grouped pair: several tensors
+        members = []
+        for sh in shapes:
+            full = torch.zeros(sh, dtype=torch.float32, device=dev)
+            per = (sh[0] // world,) + tuple(sh[1:]) if kind != "all_reduce" else sh
+            members.append((full, torch.zeros(per, dtype=torch.float32, device=dev)))
+        bufs.append((kind, members))
 
     def once():
-        for kind, full, part in bufs:
-            if kind == "all_gather":
-                dist.all_gather_into_tensor(full, part, group=group)
-            elif kind == "reduce_scatter":
-                dist.reduce_scatter_tensor(part, full, group=group)
-            else:
-                dist.all_reduce(full, group=group)
+        import contextlib
+        for kind, members in bufs:
+            cm = _coalesced(group, dev)[0] if len(members) > 1 else contextlib.nullcontext()
+            with cm:
+                for full, part in members:
+                    if kind == "all_gather":
+                        dist.all_gather_into_tensor(full, part, group=group)
+                    elif kind == "reduce_scatter":
+                        dist.reduce_scatter_tensor(part, full, group=group)
+                    else:
+                        dist.all_reduce(full, group=group)
     once()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

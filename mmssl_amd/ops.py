@@ -929,6 +929,18 @@ def spmm_mask_raw(plan, transpose, X, keep, dm, scale):
     return Y
 
 
+def mask_packed(G, keep, dm, scale):
+    """keep ? G * scale : 0 for packed modal rows G [rows, nm * dm] and the uint8 [nm, rows, dm] masks of proj_forward
+    (in place: the dropout backward of the row-sharded step, after its reduce-scatter)."""
+    rows, d = G.shape
+    if keep.dtype != torch.uint8 or keep.numel() != rows * d or not keep.is_contiguous() or not G.is_contiguous():
+        raise _lib.MmsslError("mask_packed: contiguous G [rows, nm * dm] and uint8 keep [nm, rows, dm] expected")
+    rc = _lib.lib().mmssl_mask_packed_f32(_ptr(G), _ptr(keep), float(scale), rows, d // dm, int(dm), _ptr(G),
+                                          _lib.stream_ptr())
+    _lib.check(rc, "mmssl_mask_packed_f32")
+    return G
+
+
 def fuse_blocks(rows, d, nm):
     """Number of per-block |Mod|^2 partial sums fuse_fwd writes for a side of `rows` rows."""
     return int(_lib.lib().mmssl_fuse_blocks(int(rows), int(d), int(nm)))

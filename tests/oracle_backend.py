@@ -53,7 +53,9 @@ class OracleBackend:
         return (x ** 2).sum()
 
     @staticmethod
-    def batch_losses_rows(u, p, n, z_img, z_txt, decay, batch_size, tau):
+    def batch_losses_rows(u, ia, z_img, z_txt, decay, batch_size, tau):
+        B = u.shape[0]
+        p, n = ia[:B], ia[B:]
         mf, emb, _ = O.bpr(u, p, n, decay, batch_size)
         zero = torch.zeros((), dtype=u.dtype)
         return torch.stack([mf, emb, zero, O.infonce(z_img, u, tau), O.infonce(z_txt, u, tau)])
@@ -76,36 +78,70 @@ class OracleBackend:
                     Y = S * (Y - (Y * S).sum(1, keepdim=True))
             return Y
 
-    @staticmethod
-    def linear_raw(F_, W, b, keep, scale):
-        with torch.no_grad():
-            return OracleBackend.linear(F_, W, b, keep, scale)
+    # ---- the packed node (dist._ShardedHotForward): modalities side by side, 64-wide each ---------------------------
+    EPI_AXPY, EPI_AXPY_SOFTMAX_BWD = 2, 3
 
     @staticmethod
-    def linear_wgrad_raw(gY, keep, scale, F_, W):
-        with torch.no_grad():
-            if keep is not None:
-                gY = gY * keep.to(gY.dtype) * scale
-            return gY, gY.t() @ F_, gY.sum(0)
+    def packed_supported(feat_dims, rows, d):
+        return True
 
     @staticmethod
-    def combine_fwd(layers, inv, A, B, r):
+    def proj_forward(Fs, Ws, bs, keep, scale, draw_p=0.0, external_tick=False):
         with torch.no_grad():
-            out = inv * torch.stack(list(layers)).sum(0) + r * F.normalize(A) + r * F.normalize(B)
-            return out, (A ** 2).sum() + (B ** 2).sum()
+            if keep is None and draw_p > 0.0:
+                keep = OracleBackend.dropout_masks(len(Fs), Fs[0].shape[0], Ws[0].shape[0], draw_p, Fs[0].device)
+            cols = []
+            for k, (F_, W, b) in enumerate(zip(Fs, Ws, bs)):
+                cols.append(OracleBackend.linear(F_, W, b, None if keep is None else keep[k], scale))
+            return torch.cat(cols, 1), keep
 
     @staticmethod
-    def combine_bwd(A, B, G, r, inv, c_dev, c_scale, want_gL):
+    def proj_wgrad(G, Fs, want_bias):
+        with torch.no_grad():
+            dm = G.shape[1] // len(Fs)
+            gW = [G[:, k * dm:(k + 1) * dm].t() @ F_ for k, F_ in enumerate(Fs)]
+            gb = [G[:, k * dm:(k + 1) * dm].sum(0) for k in range(len(Fs))] if want_bias else None
+            return gW, gb
+
+    @staticmethod
+    def _fuse_side(layers, Mod, inv, nm, r):
+        dm = Mod.shape[1] // nm
+        out = inv * torch.stack(list(layers)).sum(0)
+        for m in range(nm):
+            out = out + r * F.normalize(Mod[:, m * dm:(m + 1) * dm])
+        return out
+
+    @staticmethod
+    def fuse_fwd(us, MU, its, MI, inv, nm, r):
+        with torch.no_grad():
+            return (OracleBackend._fuse_side(us, MU, inv, nm, r), OracleBackend._fuse_side(its, MI, inv, nm, r),
+                    (MU ** 2).sum() + (MI ** 2).sum())
+
+    @staticmethod
+    def fuse_bwd(MU, Gu, G_MU, MI, Gi, G_MI, nm, r, inv, g_ss):
         outs = []
-        for X in (A, B):
-            with torch.enable_grad():          # we are inside a custom Function's backward
-                x = X.detach().clone().requires_grad_(True)
-                y = r * F.normalize(x)
-                (gx,) = torch.autograd.grad(y, x, G)
-            if c_dev is not None:
-                gx = gx + (c_scale * float(c_dev)) * X
-            outs.append(gx)
-        return outs[0], outs[1], (inv * G if want_gL else None)
+        for Mod, G, Gx in ((MU, Gu, G_MU), (MI, Gi, G_MI)):
+            dm = Mod.shape[1] // nm
+            cols = []
+            for m in range(nm):
+                with torch.enable_grad():          # we are inside a custom Function's backward
+                    x = Mod[:, m * dm:(m + 1) * dm].detach().clone().requires_grad_(True)
+                    (gx,) = torch.autograd.grad(r * F.normalize(x), x, G)
+                cols.append(gx)
+            gMod = torch.cat(cols, 1)
+            if g_ss is not None:
+                gMod = gMod + (2.0 * float(g_ss)) * Mod
+            if Gx is not None:
+                gMod = gMod + Gx
+            outs.append(gMod)
+        return outs[0], inv * Gu, outs[1]
+
+    @staticmethod
+    def mask_packed(G, keep, dm, scale):
+        with torch.no_grad():
+            nm = G.shape[1] // dm
+            k = torch.cat([keep[m] for m in range(nm)], 1).to(G.dtype)
+            return G * k * scale
 
     @staticmethod
     def softmax_rows_bwd(Y, gY, scale=1.0):

@@ -37,6 +37,26 @@ def _global_problem(modal):
     return fx, d, raw, U, I, state, users, pos, neg, img_raw, txt_raw
 
 
+def _pad_text_to_slices(d, state, width=64):
+    """The G8 text features are 48 wide; the grouped projection kernels take whole 32-deep slices. Zero-padding the
+    feature columns AND the weight columns leaves every output, the loss and every other gradient unchanged (the padded
+    weight columns get an exactly-zero gradient): GPU tests use it so that the packed node is the one that runs."""
+    import numpy as np
+    tf = np.asarray(d["text_feat"], dtype=np.float32)
+    k = tf.shape[1]
+    d2 = dict(d)
+    d2["text_feat"] = np.concatenate([tf, np.zeros((tf.shape[0], width - k), np.float32)], 1)
+    st = dict(state)
+    w = state["text_trans.weight"]
+    st["text_trans.weight"] = torch.cat([w, torch.zeros(w.shape[0], width - k, dtype=w.dtype)], 1)
+    return d2, st, k
+
+
+def _global_masks(I, d=64):
+    g = torch.Generator().manual_seed(77)
+    return [(torch.rand(I, d, generator=g) >= 0.2) for _ in range(2)]
+
+
 def _worker(rank, world, port, modal, out_dir, fused=True):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -48,7 +68,9 @@ def _worker(rank, world, port, modal, out_dir, fused=True):
     fx, d, raw, U, I, state, users, pos, neg, img_raw, txt_raw = _global_problem(modal)
     ush, ish = md.RowShard(U, world, rank), md.RowShard(I, world, rank)
     bk = OracleBackend()
-    cfg = O.Cfg(drop_rate=0.0, batch_size=48, n_ui_layers=2)
+    drop = modal.endswith("_drop")           # injected dropout masks: the packed keep layout and its backward
+    modal = modal.replace("_drop", "")
+    cfg = O.Cfg(drop_rate=0.2 if drop else 0.0, batch_size=48, n_ui_layers=2)
 
     def local_pair(m):
         ui, iu = O.csr_norm(m, True), O.csr_norm(m.T, True)
@@ -60,6 +82,8 @@ def _worker(rank, world, port, modal, out_dir, fused=True):
     step = md.ShardedHotPathStep(model, (ui, iu, a, b, c, e), 48, I, modal_empty=(modal == "empty_shortcut"),
                                  optimizer=False, fused=fused)
     step.set_batch(users, pos, neg)
+    if drop:
+        step.keep_masks = tuple(ish.slice_rows(k.to(torch.uint8)) for k in _global_masks(I))
     total = step.backward()
     torch.save({"loss": float(total), "ush": (ush.lo, ush.hi, ush.n), "ish": (ish.lo, ish.hi, ish.n),
                 "g": {n: p.grad.clone() if p.grad is not None else None for n, p in model.named_parameters()}},
@@ -70,15 +94,17 @@ def _worker(rank, world, port, modal, out_dir, fused=True):
 
 def _reference(modal):
     import mmssl_oracle as O
+    drop = modal.endswith("_drop")
+    modal = modal.replace("_drop", "")
     fx, d, raw, U, I, state, users, pos, neg, img_raw, txt_raw = _global_problem(modal)
     P = {k: v.clone().requires_grad_(True) for k, v in state.items()}
-    cfg = O.Cfg(drop_rate=0.0, batch_size=48, n_ui_layers=2)
+    cfg = O.Cfg(drop_rate=0.2 if drop else 0.0, batch_size=48, n_ui_layers=2)
     pair = lambda m: O.graph_pair(m)     # noqa: E731
     ui, iu = pair(raw)
     a, b = pair(img_raw)
     c, e = pair(txt_raw)
     o = O.forward(P, torch.from_numpy(d["image_feat"]), torch.from_numpy(d["text_feat"]), (ui, iu, a, b, c, e), cfg,
-                  training=False)
+                  training=drop, keep_masks=[k.float() for k in _global_masks(I)] if drop else None)
     mf, emb, _ = O.bpr(o[0][users], o[1][pos], o[1][neg], cfg.decay, 48)
     loss = mf + emb + O.feat_reg(o[2], o[3], o[4], o[5], I, cfg.feat_reg_decay) + cfg.cl_rate * (
         O.infonce(o[8][users], o[6][users], cfg.tau) + O.infonce(o[9][users], o[6][users], cfg.tau))
@@ -87,7 +113,8 @@ def _reference(modal):
 
 
 @pytest.mark.parametrize("world,modal,fused", [(2, "full", True), (3, "full", True), (2, "empty", True),
-                                               (2, "empty_shortcut", True), (2, "full", False), (3, "full", False)])
+                                               (2, "empty_shortcut", True), (2, "full", False), (3, "full", False),
+                                               (3, "full_drop", True)])
 def test_sharded_step_equals_single_process(tmp_path, world, modal, fused):
     port = _free_port()
     mp.spawn(_worker, args=(world, port, modal, str(tmp_path), fused), nprocs=world, join=True)
@@ -103,7 +130,7 @@ def test_sharded_step_equals_single_process(tmp_path, world, modal, fused):
                       ("txt_b", "text_trans.bias")):
         for o in outs:
             assert rel(o["g"][name], P[key].grad) < 1e-4, name
-    if modal == "full":
+    if modal.startswith("full"):
         for o in outs:
             assert rel(o["g"]["w_cat"], P["weight_dict.w_self_attention_cat"].grad) < 1e-4
     # sharded tables: each rank holds the gradient rows it owns

@@ -45,6 +45,7 @@ def test_sharded_step_on_hip_backend_world1_equals_oracle(solo_group, modal, fus
         ui, iu = O.csr_norm(m, True), O.csr_norm(m.T, True)
         return bk.make_graph(md.shard_graph(ui, ush, ish)), bk.make_graph(md.shard_graph(iu, ish, ush))
     graphs = local_pair(raw) + local_pair(img_raw) + local_pair(txt_raw)
+    d, state, k_txt = T._pad_text_to_slices(d, state)
     model = md.ShardedMMSSL(bk, cfg, ush, ish, state, d["image_feat"], d["text_feat"]).to(dev).train()
     step = md.ShardedHotPathStep(model, graphs, 48, I, modal_empty=(modal == "empty_shortcut"), optimizer=False,
                                  fused=fused)
@@ -56,7 +57,10 @@ def test_sharded_step_on_hip_backend_world1_equals_oracle(solo_group, modal, fus
 
     def rel(a, b):
         return float((a.cpu() - b).abs().max() / (b.abs().max() + 1e-30))
+    assert model.last_fused == fused                 # the packed node really ran
     g = {n: p.grad for n, p in model.named_parameters()}
+    assert float(g["txt_w"][:, k_txt:].abs().max()) == 0.0
+    g["txt_w"] = g["txt_w"][:, :k_txt]
     for name, key in (("img_w", "image_trans.weight"), ("img_b", "image_trans.bias"), ("txt_w", "text_trans.weight"),
                       ("txt_b", "text_trans.bias"), ("E_u", "user_id_embedding.weight"), ("E_i", "item_id_embedding.weight")):
         k = P[key].grad.shape[0]

@@ -39,7 +39,11 @@ def test_g8_sharded_step_with_real_rccl_collectives_eager_and_captured(tmp_path)
     rec = _run("g8", tmp_path, 600)
     for modal in ("full", "empty_shortcut"):
         kinds = rec["g8/%s/collectives" % modal]
-        assert kinds["all_gather"] >= 8 and kinds["reduce_scatter"] >= 8 and kinds["all_reduce"] >= 3, kinds
+        # 2 GCN layers: 4 gathers / 4 reduce-scatters (the packed modal chain's ride along as grouped pairs), the batch-row
+        # all-reduce and the flat gradient bucket (which carries the regulariser share); the non-empty modal graphs add
+        # the two table gathers of the id views and their two reduce-scatters
+        extra = 2 if modal == "full" else 0
+        assert kinds == {"all_gather": 4 + extra, "reduce_scatter": 4 + extra, "all_reduce": 2}, kinds
         assert rec["g8/%s/captured" % modal], rec.get("g8/%s/capture_error" % modal)
         for tag in ("eager", "replay"):
             r = rec["g8/%s/%s" % (modal, tag)]
@@ -55,7 +59,7 @@ def test_g8_sharded_step_with_real_rccl_collectives_eager_and_captured(tmp_path)
 def test_baby_strong_shape_sharded_step_with_real_rccl_matches_oracle(tmp_path):
     rec = _run("baby", tmp_path, 900)
     kinds = rec["baby/collectives"]
-    assert kinds["all_gather"] >= 10 and kinds["reduce_scatter"] >= 10, kinds
+    assert kinds == {"all_gather": 6, "reduce_scatter": 6, "all_reduce": 2}, kinds      # 14 launches per step
     assert rec["baby/captured"], rec.get("baby/capture_error")
     for tag in ("eager", "replay"):
         r = rec["baby/" + tag]

@@ -147,14 +147,15 @@ int mmssl_graph_rows_dense_f32(const mmssl_graph* g, const int64_t* rows, int64_
  *   Trainer.u_sim_calculation     main.py:283-298   (scores . (1 - R[users]), then F.normalize(dim=1))
  *   evaluation scoring + ranking  utility/batch_test.py:21-36, 91-100, 150-152
  * mmssl_sim_rows_f32: out[b, j] = < Q[qidx[b], :], T[j, :] > (qidx NULL: row b itself), fp32 MFMA tiles, d in
- *   {32, 64, 128}; entries (b, c) with c in the CSR row qidx[b] of (mask_rowptr, mask_cols: int32, sorted per row;
+ *   {32, 64, 128, 256}; entries (b, c) with c in the CSR row qidx[b] of (mask_rowptr, mask_cols: int32, sorted per row;
  *   both NULL = no mask) become mask_value (0 for u_sim, -inf for the evaluation). out has row pitch ldo >= n_items.
  *   sumsq_part (may be NULL): [B, mmssl_sim_rows_parts(n_items)] partial sums of squares of the unmasked scores;
  *   mmssl_rows_scale_parts_f32 turns them into the row factors 1/max(norm, eps), applies them in place and
  *   returns them (inv_out may be NULL). mmssl_graph_sim_rows_f32: the same with a graph plan's CSR as the mask.
  * mmssl_topk_rows_f32: idx_out[b, 0..K) = columns of the K largest entries of row b in DESCENDING value, ties by
- *   ASCENDING column (heapq.nlargest over an ascending-id dict); K <= 64, n_cols <= 36864; rows shorter than K are
- *   padded with -1. val_out (may be NULL) receives the values.
+ *   ASCENDING column (heapq.nlargest over an ascending-id dict); K <= 256, n_cols <= 36864 per launch (wider rows:
+ *   one launch per column block, then one over the blocks' winners - ops.topk_rows does that); rows shorter than K
+ *   are padded with -1. val_out (may be NULL) receives the values.
  * mmssl_rows_membership_u8: out[b, k] = 1 iff cand[b, k] is a column of CSR row rows[b] (sorted columns): the
  *   hit matrix of the evaluation without a dense [users, items] positives matrix.
  * ---------------------------------------------------------------------------------- */

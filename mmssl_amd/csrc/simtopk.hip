@@ -152,7 +152,7 @@ __global__ __launch_bounds__(kBlock) void rows_scale_parts_kernel(float* __restr
 // per-row top-K
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int kTopkMaxCols = 36864;        // 144 KB of keys in LDS
-constexpr int kTopkMaxK = 64;
+constexpr int kTopkMaxK = 256;             // K <= 64: one wave sorts the winners; up to 256: the block does
 
 __device__ __forceinline__ uint32_t order_key(float x) {      // monotone: a < b  <=>  key(a) < key(b); -0 == +0 apart
   const uint32_t b = __float_as_uint(x);
@@ -178,6 +178,7 @@ __global__ __launch_bounds__(kBlock) void topk_rows_kernel(const float* __restri
   __shared__ int scan_gt[kBlock], scan_eq[kBlock];
   __shared__ uint32_t win_key[kTopkMaxK];
   __shared__ int32_t win_idx[kTopkMaxK];
+  static_assert(kTopkMaxK == kBlock, "the block-wide sort gives every thread one winner slot");
   const int tid = threadIdx.x;
   const int64_t b = blockIdx.x;
   const float* __restrict__ row = X + b * ldx;
@@ -235,6 +236,33 @@ __global__ __launch_bounds__(kBlock) void topk_rows_kernel(const float* __restri
     }
   }
   __syncthreads();
+  if (K > 64) {                             // block-uniform: up to 256 winners, bitonic network through LDS
+    uint32_t k = tid < Ke ? win_key[tid] : 0u;
+    int32_t id = tid < Ke ? win_idx[tid] : 0x7fffffff;
+    for (int size = 2; size <= kBlock; size <<= 1) {
+      for (int stride = size >> 1; stride > 0; stride >>= 1) {
+        __syncthreads();
+        win_key[tid] = k;
+        win_idx[tid] = id;
+        __syncthreads();
+        const uint32_t ok = win_key[tid ^ stride];
+        const int32_t oid = win_idx[tid ^ stride];
+        const bool mine_first = (k > ok) || (k == ok && id < oid);
+        const bool lower = (tid & stride) == 0;
+        const bool asc = (tid & size) == 0;
+        const bool keep_mine = (lower == asc) ? mine_first : !mine_first;
+        if (!keep_mine) { k = ok; id = oid; }
+      }
+    }
+    if (tid < Ke) {
+      idx_out[b * K + tid] = id;
+      if (val_out) val_out[b * K + tid] = key_value(k);
+    } else if (tid < K) {
+      idx_out[b * K + tid] = -1;
+      if (val_out) val_out[b * K + tid] = 0.f;
+    }
+    return;
+  }
   if (tid < 64) {                           // one wave sorts the <= 64 winners: key descending, id ascending
     uint32_t k = win_key[tid];
     int32_t id = win_idx[tid];
@@ -281,6 +309,98 @@ __global__ __launch_bounds__(kBlock) void rows_membership_kernel(const int32_t* 
   out[i] = (lo < rowptr[r + 1] && cols[lo] == c) ? 1 : 0;
 }
 
+
+// d = 256 (embed_size 256): the same tiles with the reduction walked in two 128-deep halves; both operands of a half
+// are read when the half starts (the batch rows stay in L1/L2), no register double buffer - a rare shape, kept exact.
+__global__ __launch_bounds__(kBlock) void sim_tiles_wide_kernel(const float* __restrict__ Q, const int64_t* __restrict__ qidx,
+                                                                int64_t B, const float* __restrict__ T, int64_t I,
+                                                                const int32_t* __restrict__ m_rowptr,
+                                                                const void* __restrict__ m_cols, int m_stride,
+                                                                float mask_value, float* __restrict__ out, int64_t ldo,
+                                                                float* __restrict__ sumsq_part, int nparts) {
+  constexpr int d = 256, DCH = 16;           // chunks per half
+  __shared__ uint32_t bitmap[kSimChunk];
+  __shared__ float red[4][32];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n = lane & 31, kh = lane >> 5;
+  const int64_t u0 = (int64_t)blockIdx.x * 32;
+  const int64_t c0 = (int64_t)blockIdx.y * kSimChunk;
+  const int64_t c1 = min(I, c0 + kSimChunk);
+  for (int i = tid; i < kSimChunk; i += kBlock) bitmap[i] = 0u;
+  __syncthreads();
+  if (m_rowptr) {
+    const int ui = tid & 31, part = tid >> 5;
+    if (u0 + ui < B) {
+      const int64_t r = qidx ? qidx[u0 + ui] : (u0 + ui);
+      int lo = m_rowptr[r], hi = m_rowptr[r + 1];
+      const int end = hi;
+      while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (mask_col(m_cols, m_stride, mid) < c0) lo = mid + 1;
+        else hi = mid;
+      }
+      for (int e = lo + part; e < end; e += 8) {
+        const int32_t c = mask_col(m_cols, m_stride, e);
+        if (c >= c1) break;
+        atomicOr(&bitmap[c - c0], 1u << ui);
+      }
+    }
+  }
+  const int64_t ub = u0 + n;
+  const float4* qrow = ub < B ? reinterpret_cast<const float4*>(Q + (qidx ? qidx[ub] : ub) * d) : nullptr;
+  __syncthreads();
+  float sq[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) sq[r] = 0.f;
+  const int n_tiles = (int)((c1 - c0 + kSimTile - 1) / kSimTile);
+  for (int tile = wave; tile < n_tiles; tile += 4) {
+    const int64_t j = c0 + (int64_t)tile * kSimTile + n;
+    const float4* trow = reinterpret_cast<const float4*>(T + min(j, I - 1) * d);
+    floatx16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      float4 qf[DCH], tf[DCH];
+#pragma unroll
+      for (int q = 0; q < DCH; ++q) {
+        qf[q] = qrow ? qrow[2 * (half * DCH + q) + kh] : make_float4(0.f, 0.f, 0.f, 0.f);
+        tf[q] = trow[2 * (half * DCH + q) + kh];
+      }
+#pragma unroll
+      for (int q = 0; q < DCH; ++q) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qf[q].x, tf[q].x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qf[q].y, tf[q].y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qf[q].z, tf[q].z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qf[q].w, tf[q].w, acc, 0, 0, 0);
+      }
+    }
+    const uint32_t word = bitmap[tile * kSimTile + n];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = (r & 3) + 8 * (r >> 2) + 4 * kh;
+      const bool masked = (word >> m) & 1u;
+      const float v = masked ? mask_value : acc[r];
+      if (u0 + m < B && j < I) {
+        out[(u0 + m) * ldo + j] = v;
+        if (!masked) sq[r] = fmaf(v, v, sq[r]);
+      }
+    }
+  }
+  if (sumsq_part) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float v = sq[r];
+#pragma unroll
+      for (int mk = 1; mk < 32; mk <<= 1) v += __shfl_xor(v, mk, kWave);
+      if (n == 0) red[wave][(r & 3) + 8 * (r >> 2) + 4 * kh] = v;
+    }
+    __syncthreads();
+    if (tid < 32 && u0 + tid < B)
+      sumsq_part[(u0 + tid) * nparts + blockIdx.y] = ((red[0][tid] + red[1][tid]) + red[2][tid]) + red[3][tid];
+  }
+}
+
 }  // namespace
 
 namespace mmssl {
@@ -297,6 +417,10 @@ int sim_launch(const float* Q, const int64_t* qidx, int64_t B, const float* T, i
     case 32: SIM_CASE(4); break;
     case 64: SIM_CASE(8); break;
     case 128: SIM_CASE(16); break;
+    case 256:
+      hipLaunchKernelGGL(sim_tiles_wide_kernel, grid, dim3(kBlock), 0, s, Q, qidx, B, T, I, m_rowptr, m_cols, m_stride,
+                         mask_value, out, ldo, sumsq_part, nparts);
+      break;
     default: return MMSSL_E_UNSUPP;
   }
 #undef SIM_CASE

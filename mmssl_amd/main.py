@@ -265,12 +265,13 @@ class Trainer(object):
 
     def _device_graphs_ok(self, k, n_batch_users):
         from .graph import DeviceGraphPair
-        if os.environ.get("MMSSL_DEVICE_GRAPHS", "1") == "0" or k < 1 or k > 64:
+        if os.environ.get("MMSSL_DEVICE_GRAPHS", "1") == "0" or k < 1 or k > ops.TOPK_MAX_K:
             return False
         # collected pairs carry over the epoch boundary like the reference's lists (cleared only by a rebuild): up to T-1
         # batches are left after an epoch's last rebuild and idx 0..T-1 of the next epoch add T more
         worst = (2 * max(int(args.T), 1) - 1) * n_batch_users * k
-        return worst <= DeviceGraphPair.MAX_PAIRS and self.n_items <= 36864
+        # (catalogues wider than one top-k launch are ranked block by block inside ops.topk_rows)
+        return worst <= DeviceGraphPair.MAX_PAIRS and k * (-(-self.n_items // ops.TOPK_MAX_COLS)) <= ops.TOPK_MAX_COLS
 
     def _maintain_modal_graphs(self, idx, users, img_sim, txt_sim):
         """main.py:378-405: every T-th batch (idx != 0) rebuild the four modal graphs from the collected (user, top-k

@@ -532,16 +532,48 @@ def sim_rows(Q, T, qidx=None, mask=None, mask_value=0.0, normalize=False, eps=_N
     return (out if ld == n else out[:, :n]), inv
 
 
-def topk_rows(X, k, values=False):
-    """Columns of the k largest entries of every row, descending value, ties by ascending column (the order
-    heapq.nlargest gives the reference's evaluation, batch_test.py:21-36). X may be a row-pitched view."""
-    if not (X.is_cuda and X.dtype == torch.float32 and X.dim() == 2 and X.stride(1) == 1):
-        raise _lib.MmsslError("topk_rows: fp32 [B, n] HIP tensor with unit column stride expected")
+TOPK_MAX_COLS = 36864        # columns one mmssl_topk_rows_f32 launch ranks (144 KB of keys in LDS)
+TOPK_MAX_K = 256
+
+
+def _topk_launch(X, k, want_val):
     B, n = X.shape
     idx = torch.empty((B, k), dtype=torch.int64, device=X.device)
-    val = torch.empty((B, k), dtype=torch.float32, device=X.device) if values else None
+    val = torch.empty((B, k), dtype=torch.float32, device=X.device) if want_val else None
     rc = _lib.lib().mmssl_topk_rows_f32(_ptr(X), B, n, X.stride(0), int(k), _ptr(idx), _ptr(val), _lib.stream_ptr())
     _lib.check(rc, "mmssl_topk_rows_f32")
+    return idx, val
+
+
+def topk_rows(X, k, values=False):
+    """Columns of the k largest entries of every row, descending value, ties by ascending column (the order
+    heapq.nlargest gives the reference's evaluation, batch_test.py:21-36). X may be a row-pitched view. k <= 256.
+    Rows wider than one launch ranks (36864 columns) go block by block: every column block's k winners, then one more
+    launch over the winners (a winner of the whole row is a winner of its block; blocks and their winners are in
+    ascending column order at equal value, so ties still break by ascending column)."""
+    if not (X.is_cuda and X.dtype == torch.float32 and X.dim() == 2 and X.stride(1) == 1):
+        raise _lib.MmsslError("topk_rows: fp32 [B, n] HIP tensor with unit column stride expected")
+    if k < 1 or k > TOPK_MAX_K:
+        raise _lib.MmsslError("topk_rows: 1 <= k <= %d expected, got %d" % (TOPK_MAX_K, k))
+    B, n = X.shape
+    if n <= TOPK_MAX_COLS:
+        idx, val = _topk_launch(X, k, values)
+        return (idx, val) if values else idx
+    # equal blocks of at most TOPK_MAX_COLS columns, each a multiple of 4 wide (16-byte aligned starts)
+    nblk = -(-n // TOPK_MAX_COLS)
+    width = (-(-n // nblk) + 3) // 4 * 4
+    cand_i, cand_v = [], []
+    for c0 in range(0, n, width):
+        i, v = _topk_launch(X[:, c0:min(n, c0 + width)], k, True)
+        v = torch.where(i < 0, torch.full_like(v, float("-inf")), v)        # padding of a block narrower than k
+        cand_i.append(torch.where(i < 0, i, i + c0))
+        cand_v.append(v)
+    ci, cv = torch.cat(cand_i, 1), torch.cat(cand_v, 1).contiguous()
+    if ci.shape[1] > TOPK_MAX_COLS:
+        raise _lib.MmsslError("topk_rows: %d columns x k = %d exceeds the merge launch" % (n, k))
+    pos, val = _topk_launch(cv, k, True)
+    idx = torch.gather(ci, 1, pos.clamp_min(0))
+    idx = torch.where(pos < 0, pos, idx)
     return (idx, val) if values else idx
 
 

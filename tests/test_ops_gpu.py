@@ -624,7 +624,7 @@ def test_spmm_concurrent_launches_on_one_plan_do_not_share_state():
 # ---------------------------------------------------------------------------------------------------
 # fused similarity rows + top-K selection (csrc/simtopk.hip): evaluation scoring / ranking and u_sim forward
 # ---------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("Q,n,d,B", [(500, 4500, 64, 77), (90, 33, 32, 90), (300, 2049, 128, 64)])
+@pytest.mark.parametrize("Q,n,d,B", [(500, 4500, 64, 77), (90, 33, 32, 90), (300, 2049, 128, 64), (200, 2100, 256, 45)])
 def test_sim_rows_matches_fp64_product_with_csr_mask(Q, n, d, B):
     """scores of a batch against every row of the table (several 2048-item chunks, ragged last tile, batch not a
     multiple of 32), masked entries exactly mask_value, row norms from the in-kernel partials."""
@@ -659,11 +659,14 @@ def _heapq_topk(row, k):
     return heapq.nlargest(k, score, key=score.get)
 
 
-@pytest.mark.parametrize("n,k", [(18357, 50), (700, 50), (40, 50), (5000, 1), (36864, 64)])
+@pytest.mark.parametrize("n,k", [(18357, 50), (700, 50), (40, 50), (5000, 1), (36864, 64), (3000, 100), (300, 256),
+                                 (90000, 100), (36865, 20)])
 def test_topk_rows_is_heapq_nlargest_including_ties(n, k):
+    """Incl. k > 64 (block-wide winner sort) and rows wider than one launch ranks (36864 columns: block-by-block
+    winners, then one launch over the winners) - the catalogue sizes / Ks the single-launch form used to refuse."""
     from mmssl_amd import ops
     gen = torch.Generator().manual_seed(n + k)
-    B = 37
+    B = 37 if n < 50000 else 9
     X = torch.randn(B, n, generator=gen)
     X[:, ::7] = X[:, 3:4]                      # many exact ties per row (every 7th column equals column 3)
     X[1] = 0.25                                # a constant row: the first k ids win

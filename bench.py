@@ -83,7 +83,7 @@ def build_single_gpu(a, dev):
     txt = torch.randn(I, dt, generator=g).numpy()
     model = MMSSL(U, I, a.d, [a.d] * a.gcn_layers, [0.1] * a.gcn_layers, img, txt).to(dev)
     model.train()
-    step = HotPathStep(model, graphs, a.batch, decay=1e-5, fuse_adam=not a.no_fuse_adam)
+    step = HotPathStep(model, graphs, a.batch, decay=1e-5, fuse_adam=not a.no_fuse_adam, batch_rows=not a.dense_fuse)
     return step, raw, (ui, iu), plans
 
 
@@ -374,6 +374,9 @@ def main():
                     help="N>1: weak = shape x N (per-rank work fixed); strong = the shape itself cut N ways")
     ap.add_argument("--only", choices=["all", "steps", "roofline"], default="all",
                     help="profiling aid: run only the timed steps, or only the isolated SpMM roofline loop")
+    ap.add_argument("--dense-fuse", action="store_true", dest="dense_fuse",
+                    help="A/B: the dense two-sided fuse launch in front of the loss chain (default: batch rows only, the "
+                         "regulariser sums on the side stream)")
     ap.add_argument("--no-fuse-adam", action="store_true", dest="no_fuse_adam",
                     help="A/B aid: one AdamW launch after the backward instead of the fused / side-stream updates")
     ap.add_argument("--graph-probe", action="store_true", help=argparse.SUPPRESS)

@@ -248,9 +248,19 @@ int mmssl_fuse_blocks(int64_t rows, int d, int nm);
 int mmssl_fuse_fwd_f32(int sides, const float* const* const* layers, int n_layers, float inv,
                        const float* const* Mod, int nm, float r, const int64_t* rows, int d, float eps,
                        float* const* out, float* const* sumsq_part, void* stream);
+/* mmssl_fuse_fwd_f32's rows for a LIST of rows per side (idx[k]: n_idx[k] int64 row numbers, repeats allowed): only those
+ * rows of out[k] are written, bit for bit the dense launch's values. A training step reads the fused tables at its batch
+ * rows only, so the dense launch can leave its critical path: the regulariser's |Mod|^2 sums then fall out of
+ * mmssl_fuse_bwd_f32 (sumsq_part[k]: mmssl_fuse_blocks(rows, d, nm) per-block partials of side k, may be NULL; it reads
+ * every row of Mod for the norms anyway) and join the loss by mmssl_loss_add_partials_f32 (total[0] += c * sum(part);
+ * sum_out, may be NULL, receives the sum). */
+int mmssl_fuse_fwd_rows_f32(int sides, const float* const* const* layers, int n_layers, float inv,
+                            const float* const* Mod, int nm, float r, const int64_t* const* idx, const int64_t* n_idx,
+                            int d, float eps, float* const* out, void* stream);
+int mmssl_loss_add_partials_f32(const float* part, int64_t n, float c, float* total, float* sum_out, void* stream);
 int mmssl_fuse_bwd_f32(int sides, const float* const* Mod, int nm, const float* const* G, const float* const* Gx,
                        float r, float inv, const float* c_dev, float c_scale, const int64_t* rows, int d, float eps,
-                       float* const* gMod, float* const* gL, void* stream);
+                       float* const* gMod, float* const* gL, float* const* sumsq_part, void* stream);
 size_t mmssl_sumsq_workspace_bytes(int64_t n);
 int mmssl_sumsq_f32(const float* X, int64_t n, float* out, void* workspace,
                     size_t workspace_bytes, void* stream);

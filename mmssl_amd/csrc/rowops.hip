@@ -166,7 +166,8 @@ struct FuseSide {
   const float4* Gx;     // backward only, may be NULL
   float4* out;          // forward: fused rows; backward: gMod
   float4* gL;           // backward only, may be NULL
-  float* part;          // forward only, may be NULL: per-block sums of |Mod|^2
+  float* part;          // may be NULL: per-block sums of |Mod|^2 (both directions see every row of Mod)
+  const int64_t* idx;   // forward only, may be NULL: the rows to compute (then `rows` = their number)
   int64_t rows;
   int n_layers;
   int blocks;
@@ -184,7 +185,8 @@ __global__ __launch_bounds__(kBlock) void fuse_fwd_kernel(FuseSide S0, FuseSide 
   const int m = (threadIdx.x & (GL - 1)) / LPR;
   const int64_t stride = (int64_t)S.blocks * GPB;
   float ss = 0.f;
-  for (int64_t row = (int64_t)blk * GPB + threadIdx.x / GL; row < S.rows; row += stride) {
+  for (int64_t it = (int64_t)blk * GPB + threadIdx.x / GL; it < S.rows; it += stride) {
+    const int64_t row = S.idx ? S.idx[it] : it;
     const int64_t o = row * LPR + lig;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int k = m; k < S.n_layers; k += NM) {
@@ -224,6 +226,8 @@ __global__ __launch_bounds__(kBlock) void fuse_bwd_kernel(FuseSide S0, FuseSide 
   const int m = (threadIdx.x & (GL - 1)) / LPR;
   const int64_t stride = (int64_t)S.blocks * GPB;
   const float c = c_dev ? c_scale * c_dev[0] : 0.f;
+  __shared__ float red[4];
+  float ssacc = 0.f;
   for (int64_t row = (int64_t)blk * GPB + threadIdx.x / GL; row < S.rows; row += stride) {
     const int64_t o = row * LPR + lig;
     const int64_t mo = (row * NM + m) * LPR + lig;
@@ -232,6 +236,7 @@ __global__ __launch_bounds__(kBlock) void fuse_bwd_kernel(FuseSide S0, FuseSide 
     if (S.gL && m == 0) S.gL[o] = make_float4(inv * g.x, inv * g.y, inv * g.z, inv * g.w);
     const float ss = group_sum<LPR>(f4_dot(x, x));
     const float xg = group_sum<LPR>(f4_dot(x, g));
+    if (lig == 0) ssacc += ss;
     const float norm = sqrtf(ss);
     float a, b;                     // r*normalize_bwd = a*g - b*x
     if (norm >= eps) {
@@ -248,6 +253,10 @@ __global__ __launch_bounds__(kBlock) void fuse_bwd_kernel(FuseSide S0, FuseSide 
       y.x += e.x; y.y += e.y; y.z += e.z; y.w += e.w;
     }
     S.out[mo] = y;
+  }
+  if (S.part) {                     // block-uniform branch: the regulariser's |Mod|^2 sums fall out of the norms
+    const float t = block_sum_256(ssacc, red);
+    if (threadIdx.x == 0) S.part[blk] = t;
   }
 }
 
@@ -449,10 +458,69 @@ extern "C" int mmssl_fuse_blocks(int64_t rows, int d, int nm) {
   return fuse_grid(rows, (d / 4) * nm);
 }
 
+// The same rows arithmetic for a LIST of rows per side (idx[k]: n_idx[k] int64 row numbers, repeats allowed): only those
+// rows of out[k] are written, bit for bit what mmssl_fuse_fwd_f32 writes there. A training step needs the fused tables
+// at its batch rows only; the dense launch can then leave the step's critical path (the |Mod|^2 sums of the regulariser
+// come out of mmssl_fuse_bwd_f32).
+extern "C" int mmssl_fuse_fwd_rows_f32(int sides, const float* const* const* layers, int n_layers, float inv,
+                                       const float* const* Mod, int nm, float r, const int64_t* const* idx,
+                                       const int64_t* n_idx, int d, float eps, float* const* out, void* stream) {
+  if (sides < 1 || sides > 2 || n_layers < 1 || n_layers > kMaxLayers || !layers || !Mod || !idx || !n_idx || !out)
+    return MMSSL_E_BADARG;
+  if (!fuse_shape_ok(d, nm)) return MMSSL_E_UNSUPP;
+  FuseSide S[2] = {};
+  int total = 0;
+  for (int k = 0; k < sides; ++k) {
+    if (n_idx[k] <= 0 || !layers[k] || !Mod[k] || !out[k] || !idx[k]) return MMSSL_E_BADARG;
+    if (((uintptr_t)Mod[k] | (uintptr_t)out[k]) & 15) return MMSSL_E_BADARG;
+    for (int l = 0; l < n_layers; ++l)
+      if (!layers[k][l]) return MMSSL_E_BADARG;
+    for (int l = 0; l < kMaxLayers; ++l)
+      S[k].L.p[l] = reinterpret_cast<const float4*>(layers[k][l < n_layers ? l : 0]);
+    S[k].Mod = reinterpret_cast<const float4*>(Mod[k]);
+    S[k].out = reinterpret_cast<float4*>(out[k]);
+    S[k].part = nullptr;
+    S[k].idx = idx[k];
+    S[k].rows = n_idx[k];
+    S[k].n_layers = n_layers;
+    S[k].blocks = fuse_grid(n_idx[k], (d / 4) * nm);
+    total += S[k].blocks;
+  }
+  hipStream_t s = as_stream(stream);
+  const dim3 grid((unsigned)total);
+  FUSE_DISPATCH(fuse_fwd_kernel, S[0], S[1], inv, r, eps);
+  MMSSL_LAUNCH_CHECK();
+  return 0;
+}
+
+namespace {
+// total[0] += c * sum(part), sum_out[0] = sum(part): the regulariser joins a loss that was assembled without it
+__global__ __launch_bounds__(kBlock) void loss_add_partials_kernel(const float* __restrict__ part, int64_t n, float c,
+                                                                   float* __restrict__ total,
+                                                                   float* __restrict__ sum_out) {
+  __shared__ float red[4];
+  float acc = 0.f;
+  for (int64_t i = threadIdx.x; i < n; i += kBlock) acc += part[i];
+  const float t = block_sum_256(acc, red);
+  if (threadIdx.x == 0) {
+    total[0] += c * t;
+    if (sum_out) sum_out[0] = t;
+  }
+}
+}  // namespace
+
+extern "C" int mmssl_loss_add_partials_f32(const float* part, int64_t n, float c, float* total, float* sum_out,
+                                           void* stream) {
+  if (!part || n < 1 || !total) return MMSSL_E_BADARG;
+  hipLaunchKernelGGL(loss_add_partials_kernel, dim3(1), dim3(kBlock), 0, as_stream(stream), part, n, c, total, sum_out);
+  MMSSL_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int mmssl_fuse_bwd_f32(int sides, const float* const* Mod, int nm, const float* const* G,
                                   const float* const* Gx, float r, float inv, const float* c_dev, float c_scale,
                                   const int64_t* rows, int d, float eps, float* const* gMod, float* const* gL,
-                                  void* stream) {
+                                  float* const* sumsq_part, void* stream) {
   if (sides < 1 || sides > 2 || !Mod || !G || !rows || !gMod) return MMSSL_E_BADARG;
   if (!fuse_shape_ok(d, nm)) return MMSSL_E_UNSUPP;
   FuseSide S[2] = {};
@@ -467,6 +535,7 @@ extern "C" int mmssl_fuse_bwd_f32(int sides, const float* const* Mod, int nm, co
     S[k].Gx = reinterpret_cast<const float4*>(gx);
     S[k].out = reinterpret_cast<float4*>(gMod[k]);
     S[k].gL = reinterpret_cast<float4*>(gl);
+    S[k].part = sumsq_part ? sumsq_part[k] : nullptr;
     S[k].rows = rows[k];
     S[k].blocks = fuse_grid(rows[k], (d / 4) * nm);
     total += S[k].blocks;

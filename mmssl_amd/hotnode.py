@@ -42,6 +42,13 @@ class HotCtx:
         #                               small launches that must precede the loss section but not the projection)
         self.after_fuse_bwd = None    # event on the current stream after the backward's fuse kernel: from there on the
         #                               gradient of u_0 exists (the GCN chain's side stream holds the one of i_0)
+        self.batch_rows = None        # (user rows [B], item rows [2B]) int64 device tensors: the ONLY rows of the fused
+        #                               tables the caller will read (a training step's loss). The forward then computes
+        #                               just those rows on the critical path and sums |Mod|^2 on the side stream; the
+        #                               regulariser joins the loss by a launch on the side stream in the backward
+        #                               (reg_target = (c, total buffer) names where).
+        self.reg_parts = None         # (partials, ss tensor) left by such a forward
+        self.reg_target = None
         self.anchored = []
         self._zero_grads = {}
 
@@ -137,15 +144,22 @@ class _HotNode(torch.autograd.Function):
             for t in tuple(us[1:]) + tuple(its[1:]):
                 t.record_stream(main)
         inv = 1.0 / (n_layers + 1)
-        nbu, nbi = ops.fuse_blocks(u0.shape[0], d, nm), ops.fuse_blocks(i0.shape[0], d, nm)
-        part = torch.empty(nbu + nbi, dtype=torch.float32, device=dev)
-        u_g, i_g = ops.fuse_fwd([(us, MU, part[:nbu]), (its, MI, part[nbu:])], inv, nm, r)      # both sides, one launch
         ss = torch.empty((), dtype=torch.float32, device=dev)
-        if hot.defer_ss:
-            hot.ss_parts = (ss, part)      # the caller's loss tail reduces the partials and stores the sum into `ss`
+        if hot.batch_rows is not None:
+            # the loss reads the fused tables at its batch rows only: those rows now (one small launch, the same arithmetic
+            # as the dense kernel); the |Mod|^2 sums of the regulariser come out of the backward's fuse kernel and join the
+            # loss value on the side stream
+            u_g, i_g = ops.fuse_fwd_rows([(us, MU, hot.batch_rows[0]), (its, MI, hot.batch_rows[1])], inv, nm, r)
+            hot.reg_parts = (None, ss)         # the backward's fuse kernel leaves the |Mod|^2 partials (it needs the norms)
         else:
-            rc = _lib.lib().mmssl_sum_partials_f32(part.data_ptr(), nbu + nbi, ss.data_ptr(), _lib.stream_ptr())
-            _lib.check(rc, "mmssl_sum_partials_f32")
+            nbu, nbi = ops.fuse_blocks(u0.shape[0], d, nm), ops.fuse_blocks(i0.shape[0], d, nm)
+            part = torch.empty(nbu + nbi, dtype=torch.float32, device=dev)
+            u_g, i_g = ops.fuse_fwd([(us, MU, part[:nbu]), (its, MI, part[nbu:])], inv, nm, r)   # both sides, one launch
+            if hot.defer_ss:
+                hot.ss_parts = (ss, part)  # the caller's loss tail reduces the partials and stores the sum into `ss`
+            else:
+                rc = _lib.lib().mmssl_sum_partials_f32(part.data_ptr(), nbu + nbi, ss.data_ptr(), _lib.stream_ptr())
+                _lib.check(rc, "mmssl_sum_partials_f32")
         ctx.save_for_backward(MU, MI, us[-1], its[-1], keep_used, *Fs)
         ctx.cfg = (hot, nm, float(scale), ui, iu, n_layers, float(r), inv, [b is not None for b in bs])
         ctx.set_materialize_grads(False)
@@ -168,13 +182,23 @@ class _HotNode(torch.autograd.Function):
         fork = main.record_event() if hot.overlap else None        # see forward: the critical launch is recorded first
         # critical chain (current stream): normalise-backward + regulariser gradient of both sides in one launch (the user
         # side also yields the gradient of u_0), the two modal SpMMs, the grouped weight gradient
-        (gMU, g_u0), (gMI, _) = ops.fuse_bwd([(MU, Gu, G_MU, True), (MI, Gi, G_MI, False)], nm, r, inv, g_ss, 2.0)
+        reg = hot.reg_parts
+        part = None
+        if reg is not None:
+            nbu, nbi = ops.fuse_blocks(MU.shape[0], d, nm), ops.fuse_blocks(MI.shape[0], d, nm)
+            part = torch.empty(nbu + nbi, dtype=torch.float32, device=dev)
+        (gMU, g_u0), (gMI, _) = ops.fuse_bwd([(MU, Gu, G_MU, True), (MI, Gi, G_MI, False)], nm, r, inv, g_ss, 2.0,
+                                             sumsq_part=None if part is None else [part[:nbu], part[nbu:]])
         if hot.overlap:
             hot.after_fuse_bwd = main.record_event()
             g_u0.record_stream(sC)             # a step object may run the tables' optimiser launch on the side stream
             sC.wait_event(fork)
-            for t in (uG, iG, Gu, Gi):
-                t.record_stream(sC)            # main-pool tensors read on the side stream, possibly after this returns
+            for t_ in (uG, iG, Gu, Gi):
+                t_.record_stream(sC)           # main-pool tensors read on the side stream, possibly after this returns
+        # g(MU) = A_iu^T g(MI) + own branch (AXPY epilogue). Recorded BEFORE anything on the side stream that depends on the
+        # fuse kernel: the replayed graph keeps a node's first-recorded dependent on the node's queue, and that must be
+        # this critical launch, not the regulariser's small add below
+        t = ops._spmm_raw(iu, True, gMI, ops.EPI_AXPY, gMU, 1.0)
         # GCN chain (side stream): needs Gu / Gi only. last layer: i_G only feeds the mean; u_G feeds the mean and A_iu.u_G
         with torch.cuda.stream(sC):
             uic, iuc = ui.twin(2), iu.twin(2)
@@ -184,8 +208,18 @@ class _HotNode(torch.autograd.Function):
             for _ in range(n_layers - 1):
                 gu = ops._spmm_raw(iuc, True, gi, ops.EPI_AXPY, Gu, inv)
                 gi = ops._spmm_raw(uic, True, gu, ops.EPI_AXPY, Gi, inv)
-        # g(MU) = A_iu^T g(MI) + own branch (AXPY epilogue); g(X) = dropout-backward(A_ui^T g(MU)) (mask epilogue)
-        t = ops._spmm_raw(iu, True, gMI, ops.EPI_AXPY, gMU, 1.0)
+            if reg is not None:
+                # the regulariser joins the loss value: total += c * sum |Mod|^2 from the fuse kernel's partials, behind
+                # the GCN chain on its stream (nothing waits for the loss value inside the step)
+                if hot.reg_target is None:
+                    raise _lib.MmsslError("hot node: a batch-rows forward needs reg_target = (c, total) before its backward")
+                if hot.overlap:
+                    sC.wait_event(hot.after_fuse_bwd)
+                    part.record_stream(sC)
+                    reg[1].record_stream(sC)
+                ops.loss_add_partials(part, hot.reg_target[0], hot.reg_target[1], reg[1])
+                hot.reg_parts, hot.reg_target = None, None
+        # g(X) = dropout-backward(A_ui^T g(MU)) (mask epilogue)
         if keep is not None:
             gX = ops.spmm_mask_raw(ui, True, t, keep, d, scale)
         else:

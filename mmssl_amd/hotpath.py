@@ -25,13 +25,17 @@ class HotPathStep:
       eager_loss    root the backward at the loss TERMS with their known gradients, so that the loss section is one
                     chain of launches whose tail also assembles the loss and ticks the step's counters
                     (False: autograd through ops.loss_assemble, the op-by-op structure)
+      batch_rows    (with eager_loss) the fused tables are computed at the batch's rows only before the loss chain - all
+                    the loss reads - and the regulariser's |.|^2 sums run on the side stream next to that chain, joining
+                    the loss value by one launch there in the backward: the dense fuse launch leaves the critical path
+                    (False: the dense two-sided fuse kernel in front of the loss chain)
       fuse_adam     the projection weights' AdamW update is applied by the weight-gradient epilogue itself and — when the
                     modal graphs are empty, i.e. the embedding tables' gradients come from the hot node alone — every
                     other parameter is updated on the GCN chain's side stream while the weight gradient still runs: no
                     optimiser launch is left on the step's critical path (False: one launch after the backward)"""
 
     def __init__(self, model, graphs, batch_size, decay=1e-5, lr=None, capturable=True, overlap=True, eager_loss=True,
-                 fuse_adam=True):
+                 fuse_adam=True, batch_rows=True):
         self.model = model
         self.graphs = tuple(graphs)
         self.batch_size = int(batch_size)
@@ -52,6 +56,7 @@ class HotPathStep:
         self._graph = None
         self.eager_loss = bool(eager_loss)
         self.fuse_adam = bool(fuse_adam)
+        self.batch_rows = bool(batch_rows)
         self.hot = HotCtx(dev, overlap=overlap)
         self._proj = [model.image_trans, model.text_trans]
         # tables first: with empty modal graphs their gradients are complete as soon as the GCN chain is
@@ -122,9 +127,13 @@ class HotPathStep:
         backward is rooted at them directly; the loss value (self.loss) and the step's counter ticks come out of the
         last launch of the loss section (ops._BatchLosses._forward_eager)."""
         m, hot = self.model, self.hot
-        # the forward leaves its regulariser sum unreduced; the loss tail reduces it (one launch less in front of the
-        # loss chain). Only valid because the very next consumer of `ss` IS that tail - which checks it.
-        hot.defer_ss, hot.ss_parts, hot.prefill_buf = True, None, None
+        # batch-rows form: the forward fuses the batch's rows only and sums |.|^2 on the side stream (see __init__).
+        # Otherwise it leaves its regulariser sum unreduced and the loss tail reduces it (one launch less in front of the
+        # loss chain) - only valid because the very next consumer of `ss` IS that tail, which checks it.
+        rows_mode = self.batch_rows and not getattr(m, "extra_names", None)
+        hot.defer_ss, hot.ss_parts, hot.prefill_buf = (not rows_mode), None, None
+        hot.reg_parts, hot.reg_target = None, None
+        hot.batch_rows = (self.users, self.batch[1:3].reshape(-1)) if rows_mode else None
         # [g_ua | g_ia | g_img_uid | g_txt_uid | 3 tickets]: the modal id views only get gradients when they are not the
         # cached zeros of empty modal graphs
         n_views = 0 if self._modal_empty else 2
@@ -133,12 +142,15 @@ class HotPathStep:
             (ua, ia, img_item, txt_item, img_user, txt_user, uemb, _, img_uid, txt_uid, _, _) = m(
                 *self.graphs, keep_masks=self.keep_masks, hot=hot)
         finally:
-            hot.defer_ss, hot.prefill_floats = False, None
+            hot.defer_ss, hot.prefill_floats, hot.batch_rows = False, None, None
         ss = m.feat_sumsq(img_item, txt_item, img_user, txt_user)
         c = self._feat_coeff()
+        rows_mode = hot.reg_parts is not None          # the packed node ran in batch-rows form
         terms = ops.batch_losses_vec(ua, ia, img_uid, txt_uid, self.users, self.pos, self.neg, self.decay,
                                      self.batch_size, args.tau, hot=hot, eager_w=self.loss_w,
-                                     tail=(ss.detach(), c, self.loss, ticks))
+                                     tail=((None if rows_mode else ss.detach()), c, self.loss, ticks))
+        if rows_mode:
+            hot.reg_target = (c, self.loss)            # the node's backward adds c * |.|^2 on its side stream
         self.parts = dict(terms=terms, ss=ss)
         return [terms, ss], [self.loss_w, self._feat_c]
 

@@ -998,10 +998,39 @@ def fuse_fwd(sides, inv, nm, r):
     return outs
 
 
-def fuse_bwd(sides, nm, r, inv, c_dev, c_scale):
+def fuse_fwd_rows(sides, inv, nm, r):
+    """fuse_fwd for a LIST of rows per side: sides = [(layers, Mod [rows, nm * d], idx int64 [n]), ...]. Returns full-size
+    output tables of which ONLY the listed rows are defined (bit for bit fuse_fwd's values there)."""
+    n = len(sides)
+    outs = [torch.empty_like(sd[0][0]) for sd in sides]
+    d = outs[0].shape[1]
+    lay = [(_ct.c_void_p * len(sd[0]))(*[t.data_ptr() for t in sd[0]]) for sd in sides]
+    lay_arr = (_ct.c_void_p * n)(*[_ct.cast(a, _ct.c_void_p).value for a in lay])
+    mods = (_ct.c_void_p * n)(*[sd[1].data_ptr() for sd in sides])
+    idxs = (_ct.c_void_p * n)(*[sd[2].data_ptr() for sd in sides])
+    nidx = (_ct.c_int64 * n)(*[sd[2].numel() for sd in sides])
+    oarr = (_ct.c_void_p * n)(*[o.data_ptr() for o in outs])
+    for sd in sides:
+        if sd[2].dtype != torch.int64 or not sd[2].is_contiguous():
+            raise _lib.MmsslError("fuse_fwd_rows: contiguous int64 row lists expected")
+    rc = _lib.lib().mmssl_fuse_fwd_rows_f32(n, lay_arr, len(sides[0][0]), float(inv), mods, int(nm), float(r), idxs, nidx, d,
+                                            _NORM_EPS, oarr, _lib.stream_ptr())
+    _lib.check(rc, "mmssl_fuse_fwd_rows_f32")
+    return outs
+
+
+def loss_add_partials(part, c, total, sum_out=None):
+    """total += c * sum(part) (one launch); sum_out receives the sum."""
+    rc = _lib.lib().mmssl_loss_add_partials_f32(_ptr(part), part.numel(), float(c), _ptr(total), _ptr(sum_out),
+                                                _lib.stream_ptr())
+    _lib.check(rc, "mmssl_loss_add_partials_f32")
+
+
+def fuse_bwd(sides, nm, r, inv, c_dev, c_scale, sumsq_part=None):
     """The backward of fuse_fwd, one launch for all sides. sides = [(Mod, G, Gx or None, want_gL), ...]; returns
     [(gMod [rows, nm * d], gL or None), ...]: gMod = r * normalize_bwd(Mod_m, G) + (c_scale * c_dev) * Mod_m (+ Gx),
-    gL = inv * G."""
+    gL = inv * G. `sumsq_part`: one float tensor of fuse_blocks(rows, d, nm) entries per side, receives the per-block
+    sums of |Mod|^2 (the norms the kernel computes anyway)."""
     n = len(sides)
     gMods = [torch.empty_like(sd[0]) for sd in sides]
     gLs = [torch.empty_like(sd[1]) if sd[3] else None for sd in sides]
@@ -1010,6 +1039,7 @@ def fuse_bwd(sides, nm, r, inv, c_dev, c_scale):
     rows = (_ct.c_int64 * n)(*[sd[1].shape[0] for sd in sides])
     rc = _lib.lib().mmssl_fuse_bwd_f32(n, arr([sd[0] for sd in sides]), int(nm), arr([sd[1] for sd in sides]),
                                        arr([sd[2] for sd in sides]), float(r), float(inv), _ptr(c_dev), float(c_scale), rows,
-                                       d, _NORM_EPS, arr(gMods), arr(gLs), _lib.stream_ptr())
+                                       d, _NORM_EPS, arr(gMods), arr(gLs), arr(sumsq_part) if sumsq_part else None,
+                                       _lib.stream_ptr())
     _lib.check(rc, "mmssl_fuse_bwd_f32")
     return list(zip(gMods, gLs))

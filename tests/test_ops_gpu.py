@@ -839,3 +839,32 @@ def test_spmm_inkernel_combine_under_graph_replay_with_five_concurrent_launches(
             torch.cuda.synchronize()
             for k in range(5):
                 assert torch.equal(outs[k], want[k]), (it, k)
+
+
+def test_fuse_rows_equals_dense_rows_and_bwd_partials_sum_the_squares():
+    """ops.fuse_fwd_rows writes exactly the dense kernel's values at the listed rows (repeats allowed); fuse_bwd's per-block
+    partials add up to |Mod|^2; loss_add_partials joins c * that sum to a loss assembled without it."""
+    from mmssl_amd import ops
+    gen = torch.Generator().manual_seed(3)
+    U, I, d, nm = 3001, 1777, 64, 2
+    us = [torch.randn(U, d, generator=gen).to(DEV) for _ in range(3)]
+    its = [torch.randn(I, d, generator=gen).to(DEV) for _ in range(3)]
+    MU, MI = torch.randn(U, nm * d, generator=gen).to(DEV), torch.randn(I, nm * d, generator=gen).to(DEV)
+    ru = torch.randint(0, U, (257,), generator=gen).to(DEV)
+    ri = torch.randint(0, I, (514,), generator=gen).to(DEV)
+    ri[5] = ri[6]
+    dense_u, dense_i = ops.fuse_fwd([(us, MU, None), (its, MI, None)], 1 / 3, nm, 0.55)
+    rows_u, rows_i = ops.fuse_fwd_rows([(us, MU, ru), (its, MI, ri)], 1 / 3, nm, 0.55)
+    assert torch.equal(rows_u[ru], dense_u[ru]) and torch.equal(rows_i[ri], dense_i[ri])
+    Gu, Gi = torch.randn(U, d, generator=gen).to(DEV), torch.randn(I, d, generator=gen).to(DEV)
+    nbu, nbi = ops.fuse_blocks(U, d, nm), ops.fuse_blocks(I, d, nm)
+    part = torch.full((nbu + nbi,), float("nan"), device=DEV)
+    a = ops.fuse_bwd([(MU, Gu, None, True), (MI, Gi, None, False)], nm, 0.55, 1 / 3, None, 2.0,
+                     sumsq_part=[part[:nbu], part[nbu:]])
+    b = ops.fuse_bwd([(MU, Gu, None, True), (MI, Gi, None, False)], nm, 0.55, 1 / 3, None, 2.0)
+    assert torch.equal(a[0][0], b[0][0]) and torch.equal(a[1][0], b[1][0]) and torch.equal(a[0][1], b[0][1])
+    want = float((MU.double() ** 2).sum() + (MI.double() ** 2).sum())
+    total, ss = torch.full((), 1.5, device=DEV), torch.zeros((), device=DEV)
+    ops.loss_add_partials(part, 1e-3, total, ss)
+    assert abs(float(ss) - want) <= 2e-6 * want
+    assert abs(float(total) - (1.5 + 1e-3 * want)) <= 1e-6 * (1.5 + 1e-3 * want)

@@ -507,6 +507,32 @@ int mmssl_infonce_bwd_tiles_bpr_f32(const int64_t* idx, int n_problems, int64_t 
                                     size_t bpr_workspace_bytes, int* ticket, const float* extra_parts,
                                     int64_t n_extra_parts, void* stream);
 
+/* ------------------------------------------------------------------------------------
+ * Baseline models next to MMSSL (csrc/baselines.hip; SURVEY.md 8f "next #4")
+ *   item-graph product  LATTICE/codes/Models.py:103-104, MICRO/codes/Models.py:60-64, 112-118: h' = item_adj . h with the
+ *   kNN item graph kept as LISTS idx [rows, k] (int64 neighbour ids) / w [rows, k] instead of a dense or COO N x N matrix:
+ *     mmssl_ell_spmm_f32      Y[i] = sum_j w[i, j] * H[idx[i, j]]                      (list order: deterministic)
+ *     mmssl_ell_spmm_bwd_f32  gW[i, j] = < gY[i], H[idx[i, j]] > (the learned graph's gradient; may be NULL),
+ *                             gH[idx[i, j]] += w[i, j] * gY[i] (fp32 atomics into the caller-ZEROED gH; may be NULL)
+ *   NGCF layer  LATTICE/codes/Models.py:106-118, MICRO/codes/Models.py:126-139, 195-204:
+ *     mmssl_mul_f32 / _bwd    bi_in = ego * side and its two gradients
+ *     mmssl_ngcf_combine_f32  ego' = dropout(leaky_relu(G) + leaky_relu(B)) (keep: uint8 [rows, d] or NULL, kept entries
+ *                             scaled), norm = ego' / max(|ego'|, eps) per row; _bwd: gradients of G and B from those of
+ *                             ego' and norm (either may be NULL)
+ *   d in {32, 64, 128, 256}; rows 16-byte aligned.
+ * ---------------------------------------------------------------------------------- */
+int mmssl_ell_spmm_f32(const int64_t* idx, const float* w, int64_t rows, int k, const float* H, int d, float* Y,
+                       void* stream);
+int mmssl_ell_spmm_bwd_f32(const int64_t* idx, const float* w, int64_t rows, int k, const float* H, int d,
+                           const float* gY, float* gW, float* gH, void* stream);
+int mmssl_mul_f32(const float* a, const float* b, int64_t n, float* out, void* stream);
+int mmssl_mul_bwd_f32(const float* a, const float* b, const float* g, int64_t n, float* ga, float* gb, void* stream);
+int mmssl_ngcf_combine_f32(const float* G, const float* B, const uint8_t* keep, float scale, int64_t rows, int d,
+                           float eps, float* ego, float* norm, void* stream);
+int mmssl_ngcf_combine_bwd_f32(const float* G, const float* B, const uint8_t* keep, float scale, const float* ego,
+                               const float* g_ego, const float* g_norm, int64_t rows, int d, float eps, float* gG,
+                               float* gB, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -106,6 +106,15 @@ SIGNATURES = {
                                        c_void_p, c_float, c_float, c_float, c_float, c_float, c_int, c_void_p]),
     "mmssl_linear_wgrad_f32": (c_int, [c_void_p, c_void_p, c_float, c_void_p, c_int64, c_int, c_int, c_void_p,
                                        c_void_p, c_void_p, c_size_t, c_void_p]),
+    "mmssl_ell_spmm_f32": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_int, c_void_p, c_void_p]),
+    "mmssl_ell_spmm_bwd_f32": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
+                                       c_void_p]),
+    "mmssl_mul_f32": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
+    "mmssl_mul_bwd_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
+    "mmssl_ngcf_combine_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_int64, c_int, c_float, c_void_p, c_void_p,
+                                       c_void_p]),
+    "mmssl_ngcf_combine_bwd_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_int64,
+                                           c_int, c_float, c_void_p, c_void_p, c_void_p]),
     "mmssl_mask_scale_f32": (c_int, [c_void_p, c_void_p, c_float, c_int64, c_void_p, c_void_p]),
     "mmssl_mask_packed_f32": (c_int, [c_void_p, c_void_p, c_float, c_int64, c_int, c_int, c_void_p, c_void_p]),
     "mmssl_dropout_mask_u8": (c_int, [c_void_p, c_float, c_int64, c_void_p, c_void_p]),

@@ -1043,3 +1043,99 @@ def fuse_bwd(sides, nm, r, inv, c_dev, c_scale, sumsq_part=None):
                                        _lib.stream_ptr())
     _lib.check(rc, "mmssl_fuse_bwd_f32")
     return list(zip(gMods, gLs))
+
+
+# ---------------------------------------------------------------------------------------
+# Baseline models (csrc/baselines.hip): kNN-list item-graph product, NGCF layer tail
+# ---------------------------------------------------------------------------------------
+class _EllSpmm(torch.autograd.Function):
+    """y[i] = sum_j w[i, j] * h[idx[i, j]] (LATTICE Models.py:103-104 / MICRO Models.py:112-118 on neighbour LISTS);
+    backward: the transposed product for h (fp32 atomics) and one dot product per stored entry for the learned weights."""
+
+    @staticmethod
+    def forward(ctx, idx, w, h):
+        w, h = _chk(w, "w"), _chk(h, "h")
+        idx = _idx(idx, "idx", h.device)
+        if idx.dim() != 2 or tuple(w.shape) != tuple(idx.shape):
+            raise _lib.MmsslError("ell_spmm: idx / w must be [rows, k]")
+        rows, k = idx.shape
+        y = torch.empty((rows, h.shape[1]), dtype=torch.float32, device=h.device)
+        rc = _lib.lib().mmssl_ell_spmm_f32(_ptr(idx), _ptr(w), rows, k, _ptr(h), h.shape[1], _ptr(y), _lib.stream_ptr())
+        _lib.check(rc, "mmssl_ell_spmm_f32")
+        ctx.save_for_backward(idx, w, h)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        idx, w, h = ctx.saved_tensors
+        gy = _chk(gy, "gy")
+        rows, k = idx.shape
+        gw = torch.empty_like(w) if ctx.needs_input_grad[1] else None
+        gh = torch.zeros_like(h) if ctx.needs_input_grad[2] else None
+        if gw is not None or gh is not None:
+            rc = _lib.lib().mmssl_ell_spmm_bwd_f32(_ptr(idx), _ptr(w), rows, k, _ptr(h), h.shape[1], _ptr(gy), _ptr(gw),
+                                                   _ptr(gh), _lib.stream_ptr())
+            _lib.check(rc, "mmssl_ell_spmm_bwd_f32")
+        return None, gw, gh
+
+
+def ell_spmm(idx, w, h):
+    return _EllSpmm.apply(idx, w, h)
+
+
+class _Mul(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = _chk(a, "a"), _chk(b, "b")
+        out = torch.empty_like(a)
+        _lib.check(_lib.lib().mmssl_mul_f32(_ptr(a), _ptr(b), a.numel(), _ptr(out), _lib.stream_ptr()), "mmssl_mul_f32")
+        ctx.save_for_backward(a, b)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        g = _chk(g, "g")
+        ga, gb = torch.empty_like(a), torch.empty_like(b)
+        rc = _lib.lib().mmssl_mul_bwd_f32(_ptr(a), _ptr(b), _ptr(g), a.numel(), _ptr(ga), _ptr(gb), _lib.stream_ptr())
+        _lib.check(rc, "mmssl_mul_bwd_f32")
+        return ga, gb
+
+
+def mul(a, b):
+    """Elementwise product of two [rows, d] fp32 tensors (NGCF's ego * side) with its two gradients in one launch."""
+    return _Mul.apply(a, b)
+
+
+class _NGCFCombine(torch.autograd.Function):
+    """(ego', norm) = (dropout(leaky_relu(G) + leaky_relu(B)), normalize(ego')) in one launch; one launch backward."""
+
+    @staticmethod
+    def forward(ctx, G, B, keep, scale):
+        G, B = _chk(G, "G"), _chk(B, "B")
+        ego, norm = torch.empty_like(G), torch.empty_like(G)
+        rc = _lib.lib().mmssl_ngcf_combine_f32(_ptr(G), _ptr(B), _ptr(keep), float(scale), G.shape[0], G.shape[1], _NORM_EPS,
+                                               _ptr(ego), _ptr(norm), _lib.stream_ptr())
+        _lib.check(rc, "mmssl_ngcf_combine_f32")
+        ctx.save_for_backward(G, B, keep, ego)
+        ctx.scale = float(scale)
+        ctx.set_materialize_grads(False)
+        return ego, norm
+
+    @staticmethod
+    def backward(ctx, g_ego, g_norm):
+        G, B, keep, ego = ctx.saved_tensors
+        if g_ego is None and g_norm is None:
+            return None, None, None, None
+        g_ego = _chk(g_ego, "g_ego") if g_ego is not None else None
+        g_norm = _chk(g_norm, "g_norm") if g_norm is not None else None
+        gG, gB = torch.empty_like(G), torch.empty_like(B)
+        rc = _lib.lib().mmssl_ngcf_combine_bwd_f32(_ptr(G), _ptr(B), _ptr(keep), ctx.scale, _ptr(ego), _ptr(g_ego),
+                                                   _ptr(g_norm), G.shape[0], G.shape[1], _NORM_EPS, _ptr(gG), _ptr(gB),
+                                                   _lib.stream_ptr())
+        _lib.check(rc, "mmssl_ngcf_combine_bwd_f32")
+        return gG, gB, None, None
+
+
+def ngcf_combine(G, B, keep=None, scale=1.0):
+    return _NGCFCombine.apply(G, B, keep, scale)

@@ -303,8 +303,13 @@ def test_trainer_captured_hot_path_matches_eager_trainer(tmp_path):
 # ---------------------------------------------------------------------------------------------------
 # f-4: the LATTICE / MICRO baselines (mmssl_amd/baselines.py) against goldens recorded from the reference classes
 # ---------------------------------------------------------------------------------------------------
+_BASELINE_FILES = {"lattice": "g10_lattice_lightgcn.npz", "micro": "g11_micro_lightgcn.npz",
+                   "lattice_ngcf": "g13_lattice_ngcf.npz", "ngcf": "g13_ngcf.npz",
+                   "micro_ngcf_sparse": "g14_micro_ngcf_sparse.npz"}
+
+
 def _baseline_case(name):
-    fx = H.load("g1%d_%s_lightgcn.npz" % (0 if name == "lattice" else 1, name))
+    fx = H.load(_BASELINE_FILES[name])
     U, I = int(fx["n_users"]), int(fx["n_items"])
     A = sp.csr_matrix((fx["adj_val"], (fx["adj_row"], fx["adj_col"])), shape=(U + I, U + I))
     from mmssl_amd.graph import GraphPlan
@@ -317,25 +322,32 @@ def _cot(U, I, D=64):
     return torch.from_numpy(np.sin(0.37 * i_ + 1.3 * j_).astype(np.float32)).to(DEV)
 
 
-@pytest.mark.parametrize("name", ["lattice", "micro"])
+@pytest.mark.parametrize("name", ["lattice", "micro", "lattice_ngcf", "ngcf", "micro_ngcf_sparse"])
 def test_baselines_match_reference_classes(name):
-    """G10 / G11: forward(adj, build_item_graph=True) of the reference's LATTICE / MICRO (lightgcn) on a tiny problem:
-    every output, MICRO's contrastive loss, and the gradients that flow through the LEARNED item graph (projection
-    weights, modal weights / attention query, id embeddings)."""
+    """G10 / G11 / G13 / G14: forward(adj, build_item_graph=True) of the reference's LATTICE / MICRO (lightgcn and ngcf;
+    MICRO's ngcf golden recorded on its --sparse 1 path) and its NGCF class on a tiny problem: every output, MICRO's
+    contrastive loss, and the gradients - through the LEARNED item graph (projection weights, modal weights / attention
+    query, id embeddings) and through the NGCF layers' transforms."""
     from mmssl_amd import baselines
     fx, U, I, plan = _baseline_case(name)
-    cls = baselines.LATTICE if name == "lattice" else baselines.MICRO
-    model = cls(U, I, 64, [64, 64], [0.1, 0.1], fx["image_feat"], fx["text_feat"], topk=int(fx["topk"]))
-    missing = model.load_state_dict({k[2:]: torch.from_numpy(fx[k]) for k in fx.files if k.startswith("p.")}, strict=True)
+    cf = "ngcf" if "ngcf" in name else "lightgcn"
+    drops = [0.0, 0.0] if cf == "ngcf" else [0.1, 0.1]
+    if name == "ngcf":
+        model = baselines.NGCF(U, I, 64, [64, 64], drops)
+    else:
+        cls = baselines.LATTICE if name.startswith("lattice") else baselines.MICRO
+        model = cls(U, I, 64, [64, 64], drops, fx["image_feat"], fx["text_feat"], topk=int(fx["topk"]), cf_model=cf)
+    model.load_state_dict({k[2:]: torch.from_numpy(fx[k]) for k in fx.files if k.startswith("p.")}, strict=True)
     model = model.to(DEV).train()
     outs = model(plan, build_item_graph=True)
-    names = ["ua", "ia"] if name == "lattice" else ["ua", "ia", "image_item", "text_item", "h"]
+    names = ["ua", "ia"] if not name.startswith("micro") else ["ua", "ia", "image_item", "text_item", "h"]
     assert len(outs) == len(names)
     for n, o in zip(names, outs):
+        assert tuple(o.shape) == tuple(fx["o." + n].shape), (n, o.shape)
         assert H.rel_err(o.detach().cpu(), fx["o." + n]) < 2e-5, (n, H.rel_err(o.detach().cpu(), fx["o." + n]))
-    cot = _cot(U, I)
+    cot = _cot(U, I, outs[0].shape[1])
     scalar = (outs[0] * cot[:U]).sum() + (outs[1] * cot[U:]).sum()
-    if name == "micro":
+    if name.startswith("micro"):
         cl = model.batched_contrastive_loss(outs[2], outs[4]) + model.batched_contrastive_loss(outs[3], outs[4])
         assert abs(float(cl) - float(fx["cl"])) <= 1e-4 * abs(float(fx["cl"]))
         scalar = scalar + 0.03 * cl
@@ -347,13 +359,49 @@ def test_baselines_match_reference_classes(name):
             e = H.rel_err(model.get_parameter(k[2:]).grad.cpu(), fx[k])
             assert e < 5e-4, (k, e)
             checked += 1
-    assert checked >= 6
+    assert checked >= (10 if cf == "ngcf" else 6)
+    if name == "ngcf":
+        return
     # a second forward without rebuilding keeps the (detached) graph: same values, no gradient into the projections
     model.zero_grad()
     outs2 = model(plan, build_item_graph=False)
     assert H.rel_err(outs2[1].detach().cpu(), fx["o.ia"]) < 2e-5
     outs2[1].sum().backward()
     assert model.image_trs.weight.grad is None or float(model.image_trs.weight.grad.abs().max()) == 0.0
+
+
+def test_ell_spmm_and_ngcf_tail_match_torch():
+    """ops.ell_spmm (kNN-list product: forward, SDDMM gradient of the weights, scattered gradient of h), ops.mul and
+    ops.ngcf_combine (leaky_relu + sum + dropout + normalize) against the same expressions in torch autograd on the CPU."""
+    from mmssl_amd import ops
+    gen = torch.Generator().manual_seed(5)
+    N, k, d = 777, 10, 64
+    idx = torch.randint(0, N, (N, k), generator=gen)
+    w = torch.rand(N, k, generator=gen).requires_grad_(True)
+    h = torch.randn(N, d, generator=gen).requires_grad_(True)
+    cot = torch.randn(N, d, generator=gen)
+    ref = (w.unsqueeze(-1) * h[idx]).sum(1)
+    ref.backward(cot)
+    wd, hd = w.detach().to(DEV).requires_grad_(True), h.detach().to(DEV).requires_grad_(True)
+    y = ops.ell_spmm(idx.to(DEV), wd, hd)
+    y.backward(cot.to(DEV))
+    assert H.rel_err(y.detach().cpu(), ref.detach()) < 2e-6
+    assert H.rel_err(wd.grad.cpu(), w.grad) < 2e-6 and H.rel_err(hd.grad.cpu(), h.grad) < 5e-6
+    # NGCF tail with an injected dropout mask
+    a, b = torch.randn(N, d, generator=gen).requires_grad_(True), torch.randn(N, d, generator=gen).requires_grad_(True)
+    keep = (torch.rand(N, d, generator=gen) >= 0.3)
+    c1, c2 = torch.randn(N, d, generator=gen), torch.randn(N, d, generator=gen)
+    F_ = torch.nn.functional
+    m = a * b
+    ego = (F_.leaky_relu(a) + F_.leaky_relu(m)) * keep.float() / 0.7
+    norm = F_.normalize(ego, p=2, dim=1)
+    ((ego * c1).sum() + (norm * c2).sum()).backward()
+    ad, bd = a.detach().to(DEV).requires_grad_(True), b.detach().to(DEV).requires_grad_(True)
+    md = ops.mul(ad, bd)
+    ego_d, norm_d = ops.ngcf_combine(ad, md, keep.to(torch.uint8).to(DEV), 1.0 / 0.7)
+    ((ego_d * c1.to(DEV)).sum() + (norm_d * c2.to(DEV)).sum()).backward()
+    assert H.rel_err(ego_d.detach().cpu(), ego.detach()) < 2e-6 and H.rel_err(norm_d.detach().cpu(), norm.detach()) < 2e-6
+    assert H.rel_err(ad.grad.cpu(), a.grad) < 5e-6 and H.rel_err(bd.grad.cpu(), b.grad) < 5e-6
 
 
 def test_hotpath_batch_ring_equals_set_batch():

@@ -186,10 +186,11 @@ def gcn_forward_record(plans, mats, d, n_layers, iters=200):
             "target_frac": 0.6}
 
 
-def projection_record(step, iters=40):
+def projection_record(step, iters=600):
     """The grouped modality projection alone (both modalities in one stream-K launch + epilogue): forward with bias +
-    dropout drawn in the epilogue, weight gradient + bias gradient from a masked output gradient; HIP events around
-    hipGraph replays. fp32 MFMA peak 157.3 TFLOP/s (guides/MI355X_MICROARCH.md)."""
+    dropout drawn in the epilogue, weight gradient + bias gradient from a dropout-masked output gradient; HIP events
+    around hipGraph replays, ~0.4 s per direction (a burst of a few hundred launches reads 10-20 % slower than the
+    sustained rate: the clocks are still settling). fp32 MFMA peak 157.3 TFLOP/s (guides/MI355X_MICROARCH.md)."""
     from mmssl_amd import ops
     m = step.model
     Fs = [m.image_feats, m.text_feats]
@@ -199,7 +200,7 @@ def projection_record(step, iters=40):
     dev = Fs[0].device
     flops = sum(2.0 * M * f.shape[1] * 64 for f in Fs)
     st = ops._rng_state(dev).clone()
-    G = torch.randn(M, 128, device=dev)
+    G = torch.randn(M, 128, device=dev) * (torch.rand(M, 128, device=dev) >= 0.2)      # like the step's masked gradient
     out = {"what": "grouped projection of both modalities, one stream-K launch + epilogue each way", "GFLOP": round(flops * 1e-9, 3),
            "peak_TFLOPs": 157.3}
     with torch.no_grad():

@@ -51,6 +51,12 @@ using namespace mmssl;
 #ifndef MMSSL_PROJ_DBG
 #define MMSSL_PROJ_DBG 0
 #endif
+// the streamed feature operand is loaded with the non-temporal hint (read once per launch: it should not push the SpMM
+// chains' tables out of L2); 0 = plain loads, for A/B builds (tools/proj_variants.sh: 117 vs 120 us forward, 133.5 vs 134.6
+// weight gradient, DMA stream alone 74 vs 82 us)
+#ifndef MMSSL_PROJ_NT
+#define MMSSL_PROJ_NT 1
+#endif
 
 namespace {
 
@@ -60,7 +66,10 @@ typedef float floatx4 __attribute__((ext_vector_type(4)));
 constexpr int PT = 256;                          // tile rows (index of the long operand)
 constexpr int PJ = 64;                           // tile columns = N (index of the short operand)
 constexpr int PBK = 32;                          // reduction slice
-constexpr int PST = 3;                           // LDS stages
+#ifndef MMSSL_PROJ_PST
+#define MMSSL_PROJ_PST 3
+#endif
+constexpr int PST = MMSSL_PROJ_PST;              // LDS stages (4 = the whole LDS of a CU: measured no faster, 122 / 141 us)
 constexpr int kThreads = 512;                    // 8 waves
 constexpr int kStageFloats = (PT + PJ) * PBK;    // 10240 floats = 40 KB
 constexpr int kLdsBytes = PST * kStageFloats * 4;
@@ -135,9 +144,15 @@ __device__ __forceinline__ Segment segment_at(const Group& P, int64_t u, int64_t
 
 // waits in front of a step that reads slice kt+1: its pieces landed (mine: vmcnt; everyone's: barrier); my fragment
 // reads of slice kt are done, so after the barrier stage kt % 3 may be refilled
-__device__ __forceinline__ void step_sync(bool two_in_flight) {
-  if (two_in_flight) vm_wait_n<kPieces>();
-  else vm_wait_n<0>();
+// at most `slices` whole slices (kPieces DMA instructions each) of this wave still in flight
+__device__ __forceinline__ void wait_outstanding(int slices) {
+  if (slices <= 0) vm_wait_n<0>();
+  else if (slices == 1) vm_wait_n<kPieces>();
+  else if (slices == 2) vm_wait_n<2 * kPieces>();
+  else vm_wait_n<3 * kPieces>();
+}
+__device__ __forceinline__ void step_sync(int outstanding) {
+  wait_outstanding(outstanding);
   lgkm_wait0();
   bare_barrier();
 }
@@ -182,7 +197,10 @@ __global__ __launch_bounds__(kThreads) void proj_fwd_sk_kernel(Group P, int upb,
     }
     auto issue_piece = [&](int kt, int e) {
       const unsigned st = ring_lds + (unsigned)(kt % PST) * (kStageFloats * 4);
-      if (e < 4) glds16(pa[e] + (int64_t)kt * PBK, st + (unsigned)((32 * wave_u + 8 * e) * PBK * 4));
+      if (e < 4) {
+        if (MMSSL_PROJ_NT) glds16_nt(pa[e] + (int64_t)kt * PBK, st + (unsigned)((32 * wave_u + 8 * e) * PBK * 4));
+        else glds16(pa[e] + (int64_t)kt * PBK, st + (unsigned)((32 * wave_u + 8 * e) * PBK * 4));
+      }
       else glds16(pb + (int64_t)kt * PBK, st + (unsigned)(PT * PBK * 4 + 8 * wave_u * PBK * 4));
     };
     auto issue = [&](int kt) {
@@ -213,7 +231,7 @@ __global__ __launch_bounds__(kThreads) void proj_fwd_sk_kernel(Group P, int upb,
         if (more3 && !(MMSSL_PROJ_DBG & 1)) {
 #pragma unroll
           for (int e = 0; e < kPieces; ++e)
-            if (e * 4 / kPieces == q) issue_piece(kt + 3, e);
+            if (e * 4 / kPieces == q) issue_piece(kt + PST, e);
         }
 #pragma unroll
         for (int p = 4 * q; p < 4 * q + 4; ++p) {
@@ -233,23 +251,21 @@ __global__ __launch_bounds__(kThreads) void proj_fwd_sk_kernel(Group P, int upb,
     vm_wait_n<0>();
     lgkm_wait0();
     bare_barrier();
-    issue(0);
-    if (nk > 1) issue(1);
-    if (nk > 2) issue(2);
-    if (nk > 2) vm_wait_n<2 * kPieces>();
-    else if (nk > 1) vm_wait_n<kPieces>();
-    else vm_wait_n<0>();
+#pragma unroll
+    for (int j = 0; j < PST; ++j)
+      if (j < nk) issue(j);
+    wait_outstanding(min(nk, PST) - 1);          // slice 0 has landed
     bare_barrier();
     FragF f;
 #pragma unroll
     for (int q = 0; q < 4; ++q) read_quarter(0, q, f);
     int kt = 0;
-    for (; kt + 3 < nk; ++kt) {                  // steady state: slices kt+1 .. kt+3 exist, branch-free
-      step_sync(true);
+    for (; kt + PST < nk; ++kt) {                // steady state: slices kt+1 .. kt+PST exist, branch-free
+      step_sync(PST - 2);
       step(kt, f, true, true);
     }
     for (; kt < nk; ++kt) {                      // drain
-      if (kt + 1 < nk) step_sync(kt + 2 < nk);
+      if (kt + 1 < nk) step_sync(min(nk - kt - 2, PST - 2));
       step(kt, f, kt + 1 < nk, false);
     }
     // the segment's accumulator image -> its partial slot: plane q (0..7) holds, at thread tid, the float4 of rows
@@ -305,7 +321,8 @@ __global__ __launch_bounds__(kThreads) void proj_wgrad_sk_kernel(Group P, int up
       const int64_t m0 = (int64_t)(s0 + kt) * PBK;
       if (e < 4) {
         const int64_t m = min(m0 + 4 * wave_u + e, R - 1);              // rows past the end: finite data x zeroed G
-        glds16(pa + m * lda, st + (unsigned)((4 * wave_u + e) * PT * 4));
+        if (MMSSL_PROJ_NT) glds16_nt(pa + m * lda, st + (unsigned)((4 * wave_u + e) * PT * 4));
+        else glds16(pa + m * lda, st + (unsigned)((4 * wave_u + e) * PT * 4));
       } else {
         const int64_t m = min(m0 + 4 * wave_u + (lane >> 4), R - 1);    // clamped here, zeroed at fragment read
         glds16(pb + m * ldb, st + (unsigned)(PT * PBK * 4 + 4 * wave_u * PJ * 4));
@@ -342,7 +359,7 @@ __global__ __launch_bounds__(kThreads) void proj_wgrad_sk_kernel(Group P, int up
         if (more3 && !(MMSSL_PROJ_DBG & 1)) {
 #pragma unroll
           for (int e = 0; e < kPieces; ++e)
-            if (e * 4 / kPieces == q) issue_piece(kt + 3, e);
+            if (e * 4 / kPieces == q) issue_piece(kt + PST, e);
         }
         if (want_bias) {               // the four row-waves of a column half share the k-groups: p % 4 == wi
 #pragma unroll
@@ -368,23 +385,21 @@ __global__ __launch_bounds__(kThreads) void proj_wgrad_sk_kernel(Group P, int up
     vm_wait_n<0>();
     lgkm_wait0();
     bare_barrier();
-    issue(0);
-    if (nk > 1) issue(1);
-    if (nk > 2) issue(2);
-    if (nk > 2) vm_wait_n<2 * kPieces>();
-    else if (nk > 1) vm_wait_n<kPieces>();
-    else vm_wait_n<0>();
+#pragma unroll
+    for (int j = 0; j < PST; ++j)
+      if (j < nk) issue(j);
+    wait_outstanding(min(nk, PST) - 1);          // slice 0 has landed
     bare_barrier();
     FragW f;
 #pragma unroll
     for (int q = 0; q < 4; ++q) read_quarter(0, q, f);
     int kt = 0;
-    for (; kt + 3 < nk; ++kt) {                  // steady state: slices kt+1 .. kt+3 exist, branch-free
-      step_sync(true);
+    for (; kt + PST < nk; ++kt) {                // steady state: slices kt+1 .. kt+PST exist, branch-free
+      step_sync(PST - 2);
       step(kt, f, true, true);
     }
     for (; kt < nk; ++kt) {                      // drain
-      if (kt + 1 < nk) step_sync(kt + 2 < nk);
+      if (kt + 1 < nk) step_sync(min(nk - kt - 2, PST - 2));
       step(kt, f, kt + 1 < nk, false);
     }
     // acc[ea][eb][r] at lane (g, j') = C[row 64 wi + 16 g + 4 r + ea][col 32 wj + 2 j' + eb]: plane 4 eb + r holds, at

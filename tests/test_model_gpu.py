@@ -404,6 +404,62 @@ def test_ell_spmm_and_ngcf_tail_match_torch():
     assert H.rel_err(ad.grad.cpu(), a.grad) < 5e-6 and H.rel_err(bd.grad.cpu(), b.grad) < 5e-6
 
 
+def test_two_hotpath_steps_interleaved_on_two_streams_reproduce_their_solo_trajectories():
+    """Re-entrancy of the Python layer: two HotPathStep objects - different models, graphs, batches and
+    injected masks - stepped alternately in one process (each on its own stream) give, step for step, the losses and the
+    final parameters each gives alone. Nothing a step hands from its forward to its loss section / backward is global."""
+    from mmssl_amd import ops, synth
+    from mmssl_amd.graph import GraphPlan
+    from mmssl_amd.hotpath import HotPathStep
+    from mmssl_amd.Models import MMSSL
+    _configure(drop_rate=0.2, batch_size=128, weight_size="[64, 64]")
+
+    def make(seed, U, I, dv, dt, sparse_modal):
+        g = torch.Generator().manual_seed(seed)
+        raw = synth.interaction_matrix(U, I, 6 * U, seed=seed)
+        ui, iu = synth.normalised_pair(raw)
+        img, txt = torch.randn(I, dv, generator=g).numpy(), torch.randn(I, dt, generator=g).numpy()
+        torch.manual_seed(seed)
+        model = MMSSL(U, I, 64, [64] * 2, [0.1] * 2, img, txt).to(DEV).train()
+        if sparse_modal:
+            m = sp.csr_matrix((np.ones(64, np.float32), (np.arange(64), np.arange(64) % I)), shape=(U, I))
+        else:
+            m = sp.csr_matrix((U, I), dtype=np.float32)
+        a, b = GraphPlan(O.csr_norm(m, True).tocsr()), GraphPlan(O.csr_norm(m.T, True).tocsr())
+        step = HotPathStep(model, (GraphPlan(ui), GraphPlan(iu), a, b, a, b), 128)
+        step.keep_masks = tuple((torch.rand(I, 64, generator=g) >= 0.2).to(torch.uint8).to(DEV) for _ in range(2))
+        batches = [(torch.randperm(U, generator=g)[:128].to(DEV), torch.randint(0, I, (128,), generator=g).to(DEV),
+                    torch.randint(0, I, (128,), generator=g).to(DEV)) for _ in range(5)]
+        return step, batches
+
+    def solo(args):
+        step, batches = make(*args)
+        losses = []
+        for b in batches:
+            step.set_batch(*b)
+            step.step()
+            torch.cuda.synchronize()
+            losses.append(float(step.loss))
+        return losses, {k: v.detach().clone() for k, v in step.model.named_parameters()}
+    A, B = (1, 700, 300, 64, 96, False), (2, 500, 420, 128, 32, True)
+    la, pa = solo(A)
+    lb, pb = solo(B)
+    (sa, ba), (sb, bb) = make(*A), make(*B)
+    ga, gb = [], []
+    for k in range(5):                                   # interleaved, no synchronisation between the two objects
+        sa.set_batch(*ba[k])
+        sb.set_batch(*bb[k])
+        sa.step()
+        sb.step()
+        ga.append(sa.loss.clone())
+        gb.append(sb.loss.clone())
+    torch.cuda.synchronize()
+    assert [float(x) for x in ga] == la and [float(x) for x in gb] == lb, (ga, la, gb, lb)
+    for step, want in ((sa, pa), (sb, pb)):
+        for k, v in step.model.named_parameters():
+            assert H.rel_err(v.detach().cpu(), want[k].cpu()) < 2e-6, k
+
+
 def test_hotpath_batch_ring_equals_set_batch():
     """HotPathStep.set_batch_ring: every step picks slot (completed optimiser steps mod n) of a device-resident ring by a
     launch inside the (captured) step. Same trajectory as set_batch() of the same slot before every replay."""

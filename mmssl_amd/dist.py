@@ -51,6 +51,7 @@ class HipBackend:
         self.loss_assemble = ops.loss_assemble
         self._ar = {}
         self._streams = {}
+        self.after_fuse_bwd = None      # event of the latest packed node's backward (see _ShardedHotForward.backward)
 
     def gather_owned(self, table, idx, lo, out):
         from . import _lib
@@ -630,6 +631,10 @@ class _ShardedHotForward(torch.autograd.Function):
         st.fork()
         gMU, g_u0, gMI = bk.fuse_bwd(MU, Gu, G_MU, MI, Gi, G_MI, nm, r, inv, g_ss)
         if st.side is not None:
+            # from here on the gradient of u_0 exists; a step object may update the (sharded, never all-reduced) embedding
+            # tables on the side stream as soon as the GCN chain there has produced the gradient of i_0
+            bk.after_fuse_bwd = st.main.record_event()
+            g_u0.record_stream(st.side)
             for t in (uG, iG, Gu, Gi):
                 t.record_stream(st.side)
 
@@ -785,6 +790,14 @@ class ShardedHotPathStep:
         for p in self.model.parameters():
             p.grad = None
         torch.autograd.backward(roots, grads)
+        side = getattr(self, "_tables_early", None)
+        if side is not None and self.optimizer is not None and self.model.bk.after_fuse_bwd is not None:
+            m = self.model
+            main = torch.cuda.current_stream(self.loss.device)
+            side.wait_event(m.bk.after_fuse_bwd)
+            with torch.cuda.stream(side):
+                self.optimizer.step(external_tick=True, exclude=m.replicated_parameters())
+            self._tables_join = (main, side)
         # replicated dense parameters: partial (local-row) gradients -> ONE all-reduce of a persistent flat bucket that also
         # carries this rank's regulariser share in its last slot (no second collective for one scalar); the gradients are
         # packed by one multi-tensor copy and afterwards ARE views of the bucket (no copy back)
@@ -830,15 +843,26 @@ class ShardedHotPathStep:
             dev = self.loss.device
             self._ticks = ([self.optimizer.step_counter(0, dev).data_ptr()], [ops_._rng_state(dev).data_ptr() + 8])
         self.model._external_ticks = bool(own_ticks)        # the mask draw leaves its counter to that launch too
+        # The embedding tables are sharded: their gradients need no all-reduce and (with empty modal graphs) are complete
+        # when the node's GCN chain ends - their AdamW launch runs on that chain's stream while the weight gradient and
+        # the gradient bucket's all-reduce are still under way; only the replicated tensors are updated behind the
+        # all-reduce on the step's own stream (same rule, same counter: the loss tail ticked it once for the step).
+        bk = m.bk
+        side = bk.side_streams(self.loss.device)[2] if (own_ticks and self.modal_empty and hasattr(bk, "side_streams")) else None
+        self._tables_early = side
         try:
             total = self.backward()
             if self.optimizer is not None:
                 if own_ticks:
-                    self.optimizer.step(external_tick=True)
+                    self.optimizer.step(external_tick=True, exclude=[m.E_u, m.E_i] if side is not None else None)
                 else:
                     self.optimizer.step()
+            tj, self._tables_join = getattr(self, "_tables_join", None), None
+            if tj is not None:
+                tj[0].wait_stream(tj[1])
         finally:
             self._ticks = None
+            self._tables_early = None
             self.model._external_ticks = False
         return total
 

@@ -52,6 +52,7 @@ class HipBackend:
         self._ar = {}
         self._streams = {}
         self.after_fuse_bwd = None      # event of the latest packed node's backward (see _ShardedHotForward.backward)
+        self.defer_ss, self.ss_parts = False, None      # hand-off of the regulariser partials to a step's loss tail
 
     def gather_owned(self, table, idx, lo, out):
         from . import _lib
@@ -81,13 +82,13 @@ class HipBackend:
             self._ar[(B, dev)] = ar
         return ar
 
-    def batch_losses_rows(self, u, ia, z_img, z_txt, decay, batch_size, tau, eager_w=None, tail=None):
+    def batch_losses_rows(self, u, ia, z_img, z_txt, decay, batch_size, tau, eager_w=None, tail=None, hot=None):
         """[mf, emb, 0, cl_img, cl_txt] from already gathered rows (u [B, d]; ia [2B, d] = positive then negative items):
         ONE fused node (BPR + both InfoNCE problems, see ops._BatchLosses) fed with identity indices. eager_w + tail: the
         single-chain form whose last launch also assembles the loss and ticks the step's counters (ops.batch_losses_vec)."""
         ar = self._identity(u.shape[0], u.device)
         return self.ops.batch_losses_vec(u, ia, z_img, z_txt, ar[0], ar[0], ar[1], decay, batch_size, tau,
-                                         eager_w=eager_w, tail=tail)
+                                         hot=hot, eager_w=eager_w, tail=tail)
 
     # ---- the packed node's kernels (the grouped projection and the two-sided fuse kernels of the unsharded hot node) ----
     def packed_supported(self, feat_dims, rows, d):
@@ -117,8 +118,11 @@ class HipBackend:
         part = torch.empty(nbu + nbi, dtype=torch.float32, device=MU.device)
         u_g, i_g = ops.fuse_fwd([(us, MU, part[:nbu]), (its, MI, part[nbu:])], inv, nm, r)
         ss = torch.empty((), dtype=torch.float32, device=MU.device)
-        _lib.check(_lib.lib().mmssl_sum_partials_f32(part.data_ptr(), nbu + nbi, ss.data_ptr(), _lib.stream_ptr()),
-                   "mmssl_sum_partials_f32")
+        if self.defer_ss:            # the step's loss tail reduces the partials (and stores the sum into ss): one launch less
+            self.ss_parts = (ss, part)
+        else:
+            _lib.check(_lib.lib().mmssl_sum_partials_f32(part.data_ptr(), nbu + nbi, ss.data_ptr(), _lib.stream_ptr()),
+                       "mmssl_sum_partials_f32")
         return u_g, i_g, ss
 
     def fuse_bwd(self, MU, Gu, G_MU, MI, Gi, G_MI, nm, r, inv, g_ss):
@@ -747,7 +751,14 @@ class ShardedHotPathStep:
         """Returns (roots, grads, local_total, feat_local): torch.autograd.backward(roots, grads) is the step's backward;
         local_total = replicated loss terms + THIS rank's share of the regulariser."""
         m, bk, c, g = self.model, self.model.bk, self.model.cfg, self.group
-        o = m(self.graphs, keep_masks=keep_masks, modal_empty=self.modal_empty, fused=self.fused)
+        eager = self.fused and hasattr(bk, "ops")
+        if eager:
+            bk.defer_ss, bk.ss_parts = True, None
+        try:
+            o = m(self.graphs, keep_masks=keep_masks, modal_empty=self.modal_empty, fused=self.fused)
+        finally:
+            if eager:
+                bk.defer_ss = False
         fused = self.fused and m.last_fused
         items = self.batch[1:3].reshape(-1)           # positive then negative items: one [2B] index list, one piece
         if self.modal_empty:       # the id views are exact zeros: nothing to gather for them
@@ -770,8 +781,12 @@ class ShardedHotPathStep:
                 # product backend: the loss section as ONE chain of launches rooted at the terms' known gradients (the
                 # loss weights); its last launch assembles replicated terms + c * local regulariser into self.loss and
                 # advances the step-owned counters (see hotpath.HotPathStep._losses_eager)
+                import types
+                holder = types.SimpleNamespace(ss_parts=bk.ss_parts, prefill_buf=None)      # the node's unreduced |.|^2
+                bk.ss_parts = None
                 terms = bk.batch_losses_rows(u, ia, z_img, z_txt, c.decay, self.batch_size, c.tau, eager_w=self._loss_w,
-                                             tail=(ss.detach(), feat_c, self.loss, getattr(self, "_ticks", None)))
+                                             tail=(ss.detach(), feat_c, self.loss, getattr(self, "_ticks", None)),
+                                             hot=holder)
                 return [terms, ss], [self._loss_w, self._feat_c], self.loss, (feat_c * ss).detach()
             terms = bk.batch_losses_rows(u, ia, z_img, z_txt, c.decay, self.batch_size, c.tau)
             total_local = bk.loss_assemble(terms, self._loss_w, ss, feat_c)

@@ -75,6 +75,23 @@ constexpr int kStageFloats = (PT + PJ) * PBK;    // 10240 floats = 40 KB
 constexpr int kLdsBytes = PST * kStageFloats * 4;
 constexpr int kSlotFloats = PT * PJ;             // one partial slot: the block's accumulator image (64 KB)
 constexpr int kPieces = 5;                       // DMA instructions per wave per slice (4 long + 1 short)
+// forward tile height: 256 rows = one 8-wave block per CU (default); 128 = two independent 4-wave blocks per CU (one
+// block's barrier waits under the other's MFMAs; twice the W re-reads). Measured (tools/proj_variants.sh,
+// profiles/r03/proj_variants.txt): 125.0 vs 121.5 us alone, 0.5146 vs 0.5127 ms per step - the barrier coupling of the
+// eight waves is NOT what keeps the MFMA and DMA streams from overlapping fully; kept as a build option only.
+#ifndef MMSSL_PROJ_FPT
+#define MMSSL_PROJ_FPT 256
+#endif
+constexpr int FPT = MMSSL_PROJ_FPT;
+constexpr int kFWaves = FPT / 32;                // a wave = 32 rows x 64 columns
+constexpr int kFThreads = 64 * kFWaves;
+constexpr int kFBPieces = 8 / kFWaves;           // short-operand pieces per wave: 64 rows / (8 rows per piece) / waves
+constexpr int kFPieces = 4 + kFBPieces;
+constexpr int kFStageFloats = (FPT + PJ) * PBK;
+constexpr int kFLdsBytes = PST * kFStageFloats * 4;
+constexpr int kFSlotFloats = FPT * PJ;
+constexpr int kFBlocksPerCU = 256 / FPT;
+static_assert(FPT == 256 || FPT == 128, "forward tile height");
 constexpr int kMaxProb = MMSSL_PROJ_MAX_PROBLEMS;
 
 struct Group {
@@ -144,15 +161,17 @@ __device__ __forceinline__ Segment segment_at(const Group& P, int64_t u, int64_t
 
 // waits in front of a step that reads slice kt+1: its pieces landed (mine: vmcnt; everyone's: barrier); my fragment
 // reads of slice kt are done, so after the barrier stage kt % 3 may be refilled
-// at most `slices` whole slices (kPieces DMA instructions each) of this wave still in flight
+// at most `slices` whole slices (PCS DMA instructions each) of this wave still in flight
+template <int PCS = kPieces>
 __device__ __forceinline__ void wait_outstanding(int slices) {
   if (slices <= 0) vm_wait_n<0>();
-  else if (slices == 1) vm_wait_n<kPieces>();
-  else if (slices == 2) vm_wait_n<2 * kPieces>();
-  else vm_wait_n<3 * kPieces>();
+  else if (slices == 1) vm_wait_n<PCS>();
+  else if (slices == 2) vm_wait_n<2 * PCS>();
+  else vm_wait_n<3 * PCS>();
 }
+template <int PCS = kPieces>
 __device__ __forceinline__ void step_sync(int outstanding) {
-  wait_outstanding(outstanding);
+  wait_outstanding<PCS>(outstanding);
   lgkm_wait0();
   bare_barrier();
 }
@@ -164,7 +183,7 @@ struct FragF {
   float a[16], b0[16], b1[16];      // operand values of the 16 MFMA steps of one slice (this lane's k half)
 };
 
-__global__ __launch_bounds__(kThreads) void proj_fwd_sk_kernel(Group P, int upb, int64_t total, int max_segs,
+__global__ __launch_bounds__(kFThreads) void proj_fwd_sk_kernel(Group P, int upb, int64_t total, int max_segs,
                                                                float* __restrict__ partials) {
   extern __shared__ __attribute__((aligned(16))) float ring[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -178,7 +197,7 @@ __global__ __launch_bounds__(kThreads) void proj_fwd_sk_kernel(Group P, int upb,
   while (u < u_end) {
     const Segment sg = segment_at(P, u, u_end);
     const int nk = sg.nk;
-    const int64_t i0 = (int64_t)sg.tip * PT;
+    const int64_t i0 = (int64_t)sg.tip * FPT;
     const int64_t I = P.I[sg.g], lda = P.lda[sg.g], ldb = P.ldb[sg.g];
     // DMA source addresses of this wave's five pieces (slice 0 of the segment): long operand rows 32w + 8j + (lane >> 3),
     // 16-byte chunk (lane & 7) of the 128-byte row slice, XOR-swizzled; short operand rows 8w + (lane >> 3)
@@ -189,32 +208,33 @@ __global__ __launch_bounds__(kThreads) void proj_fwd_sk_kernel(Group P, int upb,
       const int c = (lane & 7) ^ ((r >> 1) & 7);
       pa[j] = P.A[sg.g] + min(i0 + r, I - 1) * lda + (int64_t)sg.s0 * PBK + 4 * c;
     }
-    const float* pb;
-    {
-      const int r = 8 * wave + (lane >> 3);
+    const float* pb[kFBPieces];
+#pragma unroll
+    for (int j = 0; j < kFBPieces; ++j) {
+      const int r = 8 * kFBPieces * wave + 8 * j + (lane >> 3);
       const int c = (lane & 7) ^ ((r >> 1) & 7);
-      pb = P.B[sg.g] + (int64_t)r * ldb + (int64_t)sg.s0 * PBK + 4 * c;
+      pb[j] = P.B[sg.g] + (int64_t)r * ldb + (int64_t)sg.s0 * PBK + 4 * c;
     }
     auto issue_piece = [&](int kt, int e) {
-      const unsigned st = ring_lds + (unsigned)(kt % PST) * (kStageFloats * 4);
+      const unsigned st = ring_lds + (unsigned)(kt % PST) * (kFStageFloats * 4);
       if (e < 4) {
         if (MMSSL_PROJ_NT) glds16_nt(pa[e] + (int64_t)kt * PBK, st + (unsigned)((32 * wave_u + 8 * e) * PBK * 4));
         else glds16(pa[e] + (int64_t)kt * PBK, st + (unsigned)((32 * wave_u + 8 * e) * PBK * 4));
       }
-      else glds16(pb + (int64_t)kt * PBK, st + (unsigned)(PT * PBK * 4 + 8 * wave_u * PBK * 4));
+      else glds16(pb[e - 4] + (int64_t)kt * PBK, st + (unsigned)(FPT * PBK * 4 + (8 * kFBPieces * wave_u + 8 * (e - 4)) * PBK * 4));
     };
     auto issue = [&](int kt) {
 #pragma unroll
-      for (int e = 0; e < kPieces; ++e) issue_piece(kt, e);
+      for (int e = 0; e < kFPieces; ++e) issue_piece(kt, e);
     };
     // fragment values of MFMA steps 4q .. 4q+3 of slice kt (q = 0 .. 3)
     auto read_quarter = [&](int kt, int q, FragF& f) {
-      const float* st = ring + (kt % PST) * kStageFloats;
+      const float* st = ring + (kt % PST) * kFStageFloats;
       const int sw = (lr >> 1) & 7;
       const int pos = ((2 * q + h) ^ sw) * 4;
       const float4 va = *reinterpret_cast<const float4*>(st + (32 * wave + lr) * PBK + pos);
-      const float4 v0 = *reinterpret_cast<const float4*>(st + PT * PBK + lr * PBK + pos);
-      const float4 v1 = *reinterpret_cast<const float4*>(st + PT * PBK + (32 + lr) * PBK + pos);
+      const float4 v0 = *reinterpret_cast<const float4*>(st + FPT * PBK + lr * PBK + pos);
+      const float4 v1 = *reinterpret_cast<const float4*>(st + FPT * PBK + (32 + lr) * PBK + pos);
       f.a[4 * q] = va.x; f.a[4 * q + 1] = va.y; f.a[4 * q + 2] = va.z; f.a[4 * q + 3] = va.w;
       f.b0[4 * q] = v0.x; f.b0[4 * q + 1] = v0.y; f.b0[4 * q + 2] = v0.z; f.b0[4 * q + 3] = v0.w;
       f.b1[4 * q] = v1.x; f.b1[4 * q + 1] = v1.y; f.b1[4 * q + 2] = v1.z; f.b1[4 * q + 3] = v1.w;
@@ -230,8 +250,8 @@ __global__ __launch_bounds__(kThreads) void proj_fwd_sk_kernel(Group P, int upb,
       for (int q = 0; q < 4; ++q) {
         if (more3 && !(MMSSL_PROJ_DBG & 1)) {
 #pragma unroll
-          for (int e = 0; e < kPieces; ++e)
-            if (e * 4 / kPieces == q) issue_piece(kt + PST, e);
+          for (int e = 0; e < kFPieces; ++e)
+            if (e * 4 / kFPieces == q) issue_piece(kt + PST, e);
         }
 #pragma unroll
         for (int p = 4 * q; p < 4 * q + 4; ++p) {
@@ -254,27 +274,27 @@ __global__ __launch_bounds__(kThreads) void proj_fwd_sk_kernel(Group P, int upb,
 #pragma unroll
     for (int j = 0; j < PST; ++j)
       if (j < nk) issue(j);
-    wait_outstanding(min(nk, PST) - 1);          // slice 0 has landed
+    wait_outstanding<kFPieces>(min(nk, PST) - 1);          // slice 0 has landed
     bare_barrier();
     FragF f;
 #pragma unroll
     for (int q = 0; q < 4; ++q) read_quarter(0, q, f);
     int kt = 0;
     for (; kt + PST < nk; ++kt) {                // steady state: slices kt+1 .. kt+PST exist, branch-free
-      step_sync(PST - 2);
+      step_sync<kFPieces>(PST - 2);
       step(kt, f, true, true);
     }
     for (; kt < nk; ++kt) {                      // drain
-      if (kt + 1 < nk) step_sync(min(nk - kt - 2, PST - 2));
+      if (kt + 1 < nk) step_sync<kFPieces>(min(nk - kt - 2, PST - 2));
       step(kt, f, kt + 1 < nk, false);
     }
     // the segment's accumulator image -> its partial slot: plane q (0..7) holds, at thread tid, the float4 of rows
     // 32w + 8(q & 3) + 4h + {0..3}, column 32(q >> 2) + (lane & 31)
-    float4* Pq = reinterpret_cast<float4*>(partials + ((size_t)blockIdx.x * max_segs + seg) * kSlotFloats);
+    float4* Pq = reinterpret_cast<float4*>(partials + ((size_t)blockIdx.x * max_segs + seg) * kFSlotFloats);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      Pq[q * kThreads + tid] = make_float4(acc0[4 * q], acc0[4 * q + 1], acc0[4 * q + 2], acc0[4 * q + 3]);
-      Pq[(4 + q) * kThreads + tid] = make_float4(acc1[4 * q], acc1[4 * q + 1], acc1[4 * q + 2], acc1[4 * q + 3]);
+      Pq[q * kFThreads + tid] = make_float4(acc0[4 * q], acc0[4 * q + 1], acc0[4 * q + 2], acc0[4 * q + 3]);
+      Pq[(4 + q) * kFThreads + tid] = make_float4(acc1[4 * q], acc1[4 * q + 1], acc1[4 * q + 2], acc1[4 * q + 3]);
     }
     u += nk;
     ++seg;
@@ -465,6 +485,7 @@ __device__ __forceinline__ uint32_t philox_keep_byte(uint64_t seed, uint64_t lau
 // the slots of tile t, plane q, in block order (fixed: the result does not depend on the schedule). The loads of up to
 // eight slots are issued together (a weight-gradient tile has ~14 of them: one load latency per slot, back to back, was
 // most of the epilogue launch's time); the additions keep the block order.
+template <int SLOT = kSlotFloats, int THREADS = kThreads>
 __device__ __forceinline__ float4 sum_slots(const Group& P, int t, int g, int tip, int q, int upb, int max_segs,
                                             const float* __restrict__ partials, int tid) {
   const int64_t U0 = P.unit0[g] + (int64_t)tip * P.S[g], U1 = U0 + P.S[g];
@@ -477,7 +498,7 @@ __device__ __forceinline__ float4 sum_slots(const Group& P, int t, int g, int ti
     for (int k = 0; k < 8; ++k) {
       const int64_t b = min(b0 + k, b_last);                    // clamped: a repeated (cached) load, not added
       const int seg = b == b_first ? seg_first : 0;
-      p[k] = reinterpret_cast<const float4*>(partials + ((size_t)b * max_segs + seg) * kSlotFloats)[q * kThreads + tid];
+      p[k] = reinterpret_cast<const float4*>(partials + ((size_t)b * max_segs + seg) * SLOT)[q * THREADS + tid];
     }
 #pragma unroll
     for (int k = 0; k < 8; ++k)
@@ -487,7 +508,7 @@ __device__ __forceinline__ float4 sum_slots(const Group& P, int t, int g, int ti
 }
 
 // forward epilogue: grid = tiles x 8 planes
-__global__ __launch_bounds__(kThreads) void proj_fwd_reduce_kernel(Group P, int upb, int max_segs,
+__global__ __launch_bounds__(kFThreads) void proj_fwd_reduce_kernel(Group P, int upb, int max_segs,
                                                                    const float* __restrict__ partials, int64_t M,
                                                                    float* __restrict__ Y, int64_t ldy, FwdPtrs ptrs,
                                                                    const uint8_t* __restrict__ keep_in,
@@ -497,9 +518,9 @@ __global__ __launch_bounds__(kThreads) void proj_fwd_reduce_kernel(Group P, int 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int t = (int)blockIdx.x >> 3, q = (int)blockIdx.x & 7;
   const int g = prob_of_tile(P, t), tip = t - P.tile0[g];
-  const float4 v = sum_slots(P, t, g, tip, q, upb, max_segs, partials, tid);
+  const float4 v = sum_slots<kFSlotFloats, kFThreads>(P, t, g, tip, q, upb, max_segs, partials, tid);
   const int col = 32 * (q >> 2) + (lane & 31);
-  const int64_t row0 = (int64_t)tip * PT + 32 * wave + 8 * (q & 3) + 4 * (lane >> 5);
+  const int64_t row0 = (int64_t)tip * FPT + 32 * wave + 8 * (q & 3) + 4 * (lane >> 5);
   const float* bias = ptrs.bias[g];
   const float bv = bias ? bias[col] : 0.f;
   const bool gen = keep_out != nullptr && rng != nullptr;
@@ -615,8 +636,8 @@ int n_cus() {
   return n;
 }
 
-// tile axis extents I[g], reduction lengths R[g]
-bool make_plan(int n_prob, const int64_t* I, const int64_t* R, Plan& pl) {
+// tile axis extents I[g], reduction lengths R[g]; tile height pt, `per_cu` unit ranges per CU
+bool make_plan(int n_prob, const int64_t* I, const int64_t* R, Plan& pl, int pt = PT, int per_cu = 1) {
   if (n_prob < 1 || n_prob > kMaxProb) return false;
   Group& P = pl.P;
   P.n = n_prob;
@@ -627,7 +648,7 @@ bool make_plan(int n_prob, const int64_t* I, const int64_t* R, Plan& pl) {
     P.I[g] = I[g];
     P.R[g] = R[g];
     P.S[g] = (int)((R[g] + PBK - 1) / PBK);
-    const int tg = (int)((I[g] + PT - 1) / PT);
+    const int tg = (int)((I[g] + pt - 1) / pt);
     P.unit0[g] = units;
     P.tile0[g] = tiles;
     units += (int64_t)tg * P.S[g];
@@ -644,7 +665,8 @@ bool make_plan(int n_prob, const int64_t* I, const int64_t* R, Plan& pl) {
     P.S[g] = 1;
   }
   if (units > (1ll << 40) || tiles > (1 << 20)) return false;
-  int64_t upb = (units + n_cus() - 1) / n_cus();
+  const int64_t slots_ = (int64_t)n_cus() * per_cu;
+  int64_t upb = (units + slots_ - 1) / slots_;
   const int64_t floor_ = std::min<int64_t>(min_s, 8);       // a range is at least 8 slices deep (or one whole tile)
   if (upb < floor_) upb = floor_;
   pl.upb = (int)upb;
@@ -655,14 +677,14 @@ bool make_plan(int n_prob, const int64_t* I, const int64_t* R, Plan& pl) {
   return true;
 }
 
-size_t plan_ws_bytes(const Plan& pl) {
+size_t plan_ws_bytes(const Plan& pl, int slot_floats = kSlotFloats) {
   // [partial slots | bias partials]
-  return (size_t)pl.blocks * pl.max_segs * (kSlotFloats + PJ) * sizeof(float) + 64;
+  return (size_t)pl.blocks * pl.max_segs * (slot_floats + PJ) * sizeof(float) + 64;
 }
 
 int lds_ready() {
   static const int rc = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(proj_fwd_sk_kernel),
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes) |
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, kFLdsBytes) |
                         (int)hipFuncSetAttribute(reinterpret_cast<const void*>(proj_wgrad_sk_kernel),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
   return rc;
@@ -696,8 +718,8 @@ extern "C" size_t mmssl_proj_workspace_bytes(int n_prob, const int* K, int64_t M
     R[g] = wgrad ? M : K[g];
   }
   Plan pl;
-  if (!make_plan(n_prob, I, R, pl)) return 0;
-  return plan_ws_bytes(pl);
+  if (wgrad) return make_plan(n_prob, I, R, pl) ? plan_ws_bytes(pl) : 0;
+  return make_plan(n_prob, I, R, pl, FPT, kFBlocksPerCU) ? plan_ws_bytes(pl, kFSlotFloats) : 0;
 }
 
 extern "C" int mmssl_proj_fwd_f32(int n_prob, const float* const* F, const float* const* W, const float* const* bias,
@@ -716,8 +738,8 @@ extern "C" int mmssl_proj_fwd_f32(int n_prob, const float* const* F, const float
     R[g] = K[g];
   }
   Plan pl;
-  if (!make_plan(n_prob, I, R, pl)) return MMSSL_E_UNSUPP;
-  if (workspace_bytes < plan_ws_bytes(pl)) return MMSSL_E_WORKSPACE;
+  if (!make_plan(n_prob, I, R, pl, FPT, kFBlocksPerCU)) return MMSSL_E_UNSUPP;
+  if (workspace_bytes < plan_ws_bytes(pl, kFSlotFloats)) return MMSSL_E_WORKSPACE;
   if (lds_ready() != 0) return MMSSL_E_UNSUPP;
   for (int g = 0; g < n_prob; ++g) {
     pl.P.A[g] = F[g];
@@ -729,10 +751,10 @@ extern "C" int mmssl_proj_fwd_f32(int n_prob, const float* const* F, const float
   float* part = reinterpret_cast<float*>(workspace);
   FwdPtrs ptrs;
   for (int g = 0; g < kMaxProb; ++g) ptrs.bias[g] = (bias && g < n_prob) ? bias[g] : nullptr;
-  hipLaunchKernelGGL(proj_fwd_sk_kernel, dim3((unsigned)pl.blocks), dim3(kThreads), kLdsBytes, s, pl.P, pl.upb, pl.total,
+  hipLaunchKernelGGL(proj_fwd_sk_kernel, dim3((unsigned)pl.blocks), dim3(kFThreads), kFLdsBytes, s, pl.P, pl.upb, pl.total,
                      pl.max_segs, part);
   MMSSL_LAUNCH_CHECK();
-  hipLaunchKernelGGL(proj_fwd_reduce_kernel, dim3((unsigned)pl.tiles * 8), dim3(kThreads), 0, s, pl.P, pl.upb,
+  hipLaunchKernelGGL(proj_fwd_reduce_kernel, dim3((unsigned)pl.tiles * 8), dim3(kFThreads), 0, s, pl.P, pl.upb,
                      pl.max_segs, (const float*)part, M, Y, ldy, ptrs, keep, keep_out, rng_state, p_drop, scale);
   MMSSL_LAUNCH_CHECK();
   return 0;

@@ -46,15 +46,13 @@ __device__ __forceinline__ float bpr_log_sigmoid(float x) {
   return fminf(x, 0.f) - log1pf(expf(-fabsf(x)));
 }
 
-// One BPR block of the tail; `block` in [0, A.n_blocks). The LAST block to arrive reduces the partials in block order
-// (the arithmetic of bpr_finalize_kernel), writes terms[0..2], assembles total and advances the counters.
+// ---- the tail in two parts ------------------------------------------------------------------------------------------
+// rows part: one BPR block, `block` in [0, A.n_blocks): gathers, scores, the scatter-added gradients and this block's two
+// partial sums (log-sigmoid, squared norms). Returns them (valid in thread 0).
 template <int LPR>
-__device__ __forceinline__ void bpr_step_block(const BprStepArgs& A, int block) {
-  __shared__ float red[4];
-  __shared__ int s_last;
+__device__ __forceinline__ void bpr_rows_part(const BprStepArgs& A, int block, float* red, float& t0, float& t1) {
   constexpr int GPB = kBlock / LPR;
   constexpr int D = LPR * 4;
-  const int nblocks = A.n_blocks;
   const int lig = threadIdx.x & (LPR - 1);
   const int64_t b = (int64_t)block * GPB + threadIdx.x / LPR;
   float ls = 0.f, sq = 0.f;
@@ -82,8 +80,62 @@ __device__ __forceinline__ void bpr_step_block(const BprStepArgs& A, int block) 
     unsafeAtomicAdd(dn + 0, -cm * u.x + ce * n.x); unsafeAtomicAdd(dn + 1, -cm * u.y + ce * n.y);
     unsafeAtomicAdd(dn + 2, -cm * u.z + ce * n.z); unsafeAtomicAdd(dn + 3, -cm * u.w + ce * n.w);
   }
-  const float t0 = block_sum_256(ls, red);
-  const float t1 = block_sum_256(sq, red);
+  t0 = block_sum_256(ls, red);
+  t1 = block_sum_256(sq, red);
+}
+
+// assembly part (ONE block, every block's partials visible): reduces the partials in block order (the arithmetic of
+// bpr_finalize_kernel), the extra term's partials if given, writes terms[0..2], assembles total, advances the counters.
+// `xsum_ready`: the extra term's sum already sits behind the partials (the one-launch form's block 0 put it there).
+__device__ __forceinline__ void bpr_assemble_part(const BprStepArgs& A, float* red, bool atomic_loads, bool xsum_ready) {
+  const int nblocks = A.n_blocks;
+  const unsigned* part = reinterpret_cast<const unsigned*>(A.part);
+  auto ld = [&](int i) {
+    return atomic_loads ? __uint_as_float(__hip_atomic_load(part + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+                        : A.part[i];
+  };
+  float a = 0.f, c = 0.f;
+  for (int i = threadIdx.x; i < nblocks; i += kBlock) {
+    a += ld(2 * i + 0);
+    c += ld(2 * i + 1);
+  }
+  const float lsum = block_sum_256(a, red);
+  const float qsum = block_sum_256(c, red);
+  float xs = 0.f;
+  if (A.xparts) {
+    if (xsum_ready) {
+      xs = ld(2 * nblocks);
+    } else {                        // the arithmetic of sum_partials_kernel
+      float e = 0.f;
+      for (int64_t i = threadIdx.x; i < A.n_xparts; i += kBlock) e += A.xparts[i];
+      xs = block_sum_256(e, red);
+    }
+    if (threadIdx.x == 0 && A.extra_out) A.extra_out[0] = xs;
+  } else if (A.extra) {
+    xs = A.extra[0];
+  }
+  if (threadIdx.x == 0) {
+    const float t_mf = -(lsum / (float)A.B), t_emb = A.decay * ((0.5f * qsum) / (float)A.batch_size);
+    A.terms[0] = t_mf;
+    A.terms[1] = t_emb;
+    A.terms[2] = 0.f;
+    float t = A.w[0] * t_mf + A.w[1] * t_emb + A.w[2] * 0.f;          // same order as loss_assemble_kernel
+    for (int k = 3; k < A.n_terms; ++k) t += A.w[k] * A.terms[k];
+    if (A.extra || A.xparts) t += A.cex * xs;
+    A.total[0] = t;
+    for (int k = 0; k < A.T.n_f32; ++k) A.T.f32[k][0] += 1.0f;
+    for (int k = 0; k < A.T.n_u64; ++k) A.T.u64[k][0] += 1ull;
+  }
+}
+
+// One BPR block of the ONE-launch tail; `block` in [0, A.n_blocks). The LAST block to arrive runs the assembly part.
+template <int LPR>
+__device__ __forceinline__ void bpr_step_block(const BprStepArgs& A, int block) {
+  __shared__ float red[4];
+  __shared__ int s_last;
+  const int nblocks = A.n_blocks;
+  float t0, t1;
+  bpr_rows_part<LPR>(A, block, red, t0, t1);
   unsigned* part = reinterpret_cast<unsigned*>(A.part);
   // the extra term given as partial sums (the forward's regulariser partials): block 0 reduces them (the arithmetic of
   // sum_partials_kernel) next to the other blocks' work and parks the value behind the BPR partials
@@ -105,32 +157,24 @@ __device__ __forceinline__ void bpr_step_block(const BprStepArgs& A, int block) 
   __syncthreads();
   if (!s_last) return;
   __threadfence();
-  float a = 0.f, c = 0.f;
-  for (int i = threadIdx.x; i < nblocks; i += kBlock) {
-    a += __uint_as_float(__hip_atomic_load(part + 2 * i + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-    c += __uint_as_float(__hip_atomic_load(part + 2 * i + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-  }
-  const float lsum = block_sum_256(a, red);
-  const float qsum = block_sum_256(c, red);
-  float xs = 0.f;
-  if (A.xparts) {
-    xs = __uint_as_float(__hip_atomic_load(part + 2 * nblocks, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-    if (threadIdx.x == 0 && A.extra_out) A.extra_out[0] = xs;
-  } else if (A.extra) {
-    xs = A.extra[0];
-  }
+  bpr_assemble_part(A, red, true, true);
+}
+
+// The TWO-launch form (the hot step's loss chain): the rows part rides as guest blocks of an EARLY launch of the chain
+// (the InfoNCE prep: it depends on nothing there), the assembly part as one guest block of the chain's LAST launch.
+template <int LPR>
+__device__ __forceinline__ void bpr_rows_block(const BprStepArgs& A, int block) {
+  __shared__ float red[4];
+  float t0, t1;
+  bpr_rows_part<LPR>(A, block, red, t0, t1);
   if (threadIdx.x == 0) {
-    const float t_mf = -(lsum / (float)A.B), t_emb = A.decay * ((0.5f * qsum) / (float)A.batch_size);
-    A.terms[0] = t_mf;
-    A.terms[1] = t_emb;
-    A.terms[2] = 0.f;
-    float t = A.w[0] * t_mf + A.w[1] * t_emb + A.w[2] * 0.f;          // same order as loss_assemble_kernel
-    for (int k = 3; k < A.n_terms; ++k) t += A.w[k] * A.terms[k];
-    if (A.extra || A.xparts) t += A.cex * xs;
-    A.total[0] = t;
-    for (int k = 0; k < A.T.n_f32; ++k) A.T.f32[k][0] += 1.0f;
-    for (int k = 0; k < A.T.n_u64; ++k) A.T.u64[k][0] += 1ull;
+    A.part[2 * block + 0] = t0;
+    A.part[2 * block + 1] = t1;
   }
+}
+__device__ __forceinline__ void bpr_assemble_block(const BprStepArgs& A) {
+  __shared__ float red[4];
+  bpr_assemble_part(A, red, false, false);
 }
 
 // Validates the C-ABI arguments of mmssl_bpr_step_f32 and fills the kernel argument block (host side).

@@ -84,9 +84,19 @@ struct Z1Ptrs {          // per-problem first operand (forward) / its gradient (
 
 // blockIdx.y = problem: problems share z2 and differ in z1 (the reference calls the loss once per
 // modality with the same user embeddings, main.py:411-412); each has its own workspace slice.
+// Guest blocks (bpr.n_blocks > 0, blockIdx.x >= prep_blocks): the ROWS part of the hot step's BPR tail (bpr_step.hpp) -
+// it depends on nothing this launch computes, and this short launch has three quarters of the chip free.
 __global__ __launch_bounds__(kBlock) void prep_kernel(Z1Ptrs Z, const float* __restrict__ z2,
                                                       const int64_t* __restrict__ idx, int64_t n, int d,
-                                                      float* __restrict__ ws, size_t ws_stride, Layout L) {
+                                                      float* __restrict__ ws, size_t ws_stride, Layout L,
+                                                      int prep_blocks, BprStepArgs bpr) {
+  if ((int)blockIdx.x >= prep_blocks) {
+    if (blockIdx.y == 0) {
+      if (d == 64) bpr_rows_block<16>(bpr, (int)blockIdx.x - prep_blocks);
+      else bpr_rows_block<8>(bpr, (int)blockIdx.x - prep_blocks);
+    }
+    return;
+  }
   const float* __restrict__ z1 = Z.z1[blockIdx.y];
   float* __restrict__ wsp = ws + (size_t)blockIdx.y * ws_stride;
   float* __restrict__ n1 = wsp + L.n1;
@@ -397,7 +407,14 @@ __global__ __launch_bounds__(kBlock) void bwd_finish_kernel(const float* __restr
                                                             int P, int cs, const int64_t* __restrict__ idx,
                                                             int64_t n, int d, float tau,
                                                             const float* __restrict__ gloss, Z1Ptrs Z,
-                                                            float* __restrict__ gz2) {
+                                                            float* __restrict__ gz2, int finish_blocks,
+                                                            BprStepArgs bpr) {
+  // Guest block (the one behind the finish blocks): the ASSEMBLY part of the hot step's BPR tail - the rows part ran
+  // as guests of the prep launch, the InfoNCE loss values were written by the row-terms launch: BPR loss, total, ticks.
+  if ((int)blockIdx.x >= finish_blocks) {
+    bpr_assemble_block(bpr);
+    return;
+  }
   constexpr int MAXC = 4;                      // d <= 256 -> at most 4 float4 chunks per lane
   const int lig = threadIdx.x & 15;
   const int64_t r = (int64_t)blockIdx.x * (kBlock / 16) + threadIdx.x / 16;
@@ -766,7 +783,7 @@ namespace {
 
 int infonce_fwd_impl(const float* const* z1s, const float* z2, const int64_t* idx, int P, int64_t n, int d,
                      float tau, float* losses, void* workspace, size_t workspace_bytes, void* stream,
-                     float log_eps = 1e-8f, int phases = 3, int* tickets = nullptr) {
+                     float log_eps = 1e-8f, int phases = 3, int* tickets = nullptr, const BprStepArgs* rows_guest = nullptr) {
   if (P < 1 || P > kMaxProblems || n <= 0 || !z1s || !z2 || !losses || !(tau > 0.f)) return MMSSL_E_BADARG;
   if (!infonce_d_ok(d)) return MMSSL_E_UNSUPP;
   const Layout L = make_layout(n, d);
@@ -788,7 +805,14 @@ int infonce_fwd_impl(const float* const* z1s, const float* z2, const int64_t* id
     MMSSL_LAUNCH_CHECK();
     return 0;
   }
-  hipLaunchKernelGGL(prep_kernel, dim3(rb, P), dim3(kBlock), 0, s, Z, z2, idx, n, d, ws, L.total, L);
+  BprStepArgs G;
+  if (rows_guest) {
+    if (d != 32 && d != 64) return MMSSL_E_UNSUPP;
+    G = *rows_guest;
+  } else {
+    G.n_blocks = 0;
+  }
+  hipLaunchKernelGGL(prep_kernel, dim3(rb + G.n_blocks, P), dim3(kBlock), 0, s, Z, z2, idx, n, d, ws, L.total, L, rb, G);
   MMSSL_LAUNCH_CHECK();
   const dim3 grid(nt * L.cs_f, P);
   if (use_mfma(d)) {
@@ -812,7 +836,7 @@ int infonce_fwd_impl(const float* const* z1s, const float* z2, const int64_t* id
 
 int infonce_bwd_impl(const int64_t* idx, int P, int64_t n, int d, float tau, const float* gloss,
                      float* const* gz1s, float* gz2, void* workspace, size_t workspace_bytes, void* stream,
-                     int phases = 3, const BprStepArgs* guest = nullptr) {
+                     int phases = 3, const BprStepArgs* guest = nullptr, const BprStepArgs* assemble_guest = nullptr) {
   if (P < 1 || P > kMaxProblems || n <= 0 || !gloss || !(tau > 0.f) || phases < 1 || phases > 3) return MMSSL_E_BADARG;
   if (!infonce_d_ok(d)) return MMSSL_E_UNSUPP;
   const Layout L = make_layout(n, d);
@@ -854,8 +878,11 @@ int infonce_bwd_impl(const int64_t* idx, int P, int64_t n, int d, float tau, con
   }
   if (!(phases & 2)) return 0;
   const int rb = (int)((n + 15) / 16);
-  hipLaunchKernelGGL(bwd_finish_kernel, dim3(rb), dim3(kBlock), 0, s, ws, L.total, L, P, L.cs_b, idx, n, d, tau, gloss,
-                     Z, gz2);
+  BprStepArgs AG;
+  if (assemble_guest) AG = *assemble_guest;
+  else AG.n_blocks = 0;
+  hipLaunchKernelGGL(bwd_finish_kernel, dim3(rb + (assemble_guest ? 1 : 0)), dim3(kBlock), 0, s, ws, L.total, L, P, L.cs_b,
+                     idx, n, d, tau, gloss, Z, gz2, rb, AG);
   MMSSL_LAUNCH_CHECK();
   return 0;
 }
@@ -946,6 +973,55 @@ extern "C" int mmssl_infonce_bwd_tiles_bpr_f32(const int64_t* idx, int n_problem
                                     bpr_workspace_bytes, mmssl_bpr_workspace_bytes(B), ticket, extra_parts, n_extra_parts);
   if (rc != 0) return rc;
   return infonce_bwd_impl(idx, n_problems, n, d, tau, gloss, gz1s, gz2, workspace, workspace_bytes, stream, 1, &A);
+}
+
+// ---- the hot step's loss chain with the BPR tail in two parts (d in {32, 64}) ---------------------------------------
+// As guest blocks of the backward PAIR TILES (mmssl_infonce_bwd_tiles_bpr_f32) the tail's B/16 blocks push that launch
+// past one round of resident blocks (512 pair-tile blocks fill the chip at two blocks per CU: the last 64 wait for a
+// slot). Here the ROWS part rides in the short prep launch and the one-block ASSEMBLY part in the backward finish: same
+// arithmetic, same bits; measured pair tiles 34.7 -> 29.4 us, prep 5.7 -> 8.4 us (profiles/r03/step_timeline_bpr_two_parts.txt).
+extern "C" int mmssl_infonce_multi_fwd_ticket_bpr_f32(const float* const* z1s, const float* z2, const int64_t* idx,
+                                                      int n_problems, int64_t n, int d, float tau, float* losses,
+                                                      void* workspace, size_t workspace_bytes, int* tickets,
+                                                      const float* Eu, const float* Ei, const int64_t* users,
+                                                      const int64_t* pos, const int64_t* neg, int64_t B, float decay,
+                                                      int64_t batch_size, const float* g_mf, const float* g_emb, float* gEu,
+                                                      float* gEi, void* bpr_workspace, size_t bpr_workspace_bytes,
+                                                      void* stream) {
+  if (!tickets) return MMSSL_E_BADARG;
+  if (!infonce_d_ok(d) || !use_mfma(d)) return MMSSL_E_UNSUPP;
+  BprStepArgs A;
+  float dummy_terms[4];
+  int dummy_ticket = 0;
+  // only the rows part's fields are used by this launch; the rest is validated by the finish entry
+  const int rc = make_bpr_step_args(A, Eu, Ei, users, pos, neg, B, d, decay, batch_size, g_mf, g_emb, gEu, gEi, dummy_terms,
+                                    dummy_terms, 3, nullptr, 0.f, dummy_terms, nullptr, 0, nullptr, 0, bpr_workspace,
+                                    bpr_workspace_bytes, mmssl_bpr_workspace_bytes(B), &dummy_ticket, nullptr, 0);
+  if (rc != 0) return rc;
+  return infonce_fwd_impl(z1s, z2, idx, n_problems, n, d, tau, losses, workspace, workspace_bytes, stream, 1e-8f, 3,
+                          tickets, &A);
+}
+
+extern "C" int mmssl_infonce_multi_bwd_finish_bpr_f32(const int64_t* idx, int n_problems, int64_t n, int d, float tau,
+                                                      const float* gloss, float* const* gz1s, float* gz2, void* workspace,
+                                                      size_t workspace_bytes, const float* Eu, const float* Ei,
+                                                      const int64_t* users, const int64_t* pos, const int64_t* neg,
+                                                      int64_t B, float decay, int64_t batch_size, const float* g_mf,
+                                                      const float* g_emb, float* gEu, float* gEi, float* terms,
+                                                      const float* w, int n_terms, const float* extra, float c,
+                                                      float* total, float* const* f32_ticks, int n_f32,
+                                                      uint64_t* const* u64_ticks, int n_u64, void* bpr_workspace,
+                                                      size_t bpr_workspace_bytes, const float* extra_parts,
+                                                      int64_t n_extra_parts, void* stream) {
+  if (!infonce_d_ok(d) || !use_mfma(d)) return MMSSL_E_UNSUPP;
+  BprStepArgs A;
+  int dummy_ticket = 0;
+  const int rc = make_bpr_step_args(A, Eu, Ei, users, pos, neg, B, d, decay, batch_size, g_mf, g_emb, gEu, gEi, terms, w,
+                                    n_terms, extra, c, total, f32_ticks, n_f32, u64_ticks, n_u64, bpr_workspace,
+                                    bpr_workspace_bytes, mmssl_bpr_workspace_bytes(B), &dummy_ticket, extra_parts,
+                                    n_extra_parts);
+  if (rc != 0) return rc;
+  return infonce_bwd_impl(idx, n_problems, n, d, tau, gloss, gz1s, gz2, workspace, workspace_bytes, stream, 2, nullptr, &A);
 }
 
 extern "C" int mmssl_infonce_multi_bwd_phase_f32(const int64_t* idx, int n_problems, int64_t n, int d, float tau,

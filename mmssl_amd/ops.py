@@ -746,9 +746,6 @@ class _BatchLosses(torch.autograd.Function):
             raise _lib.MmsslError("infonce: unsupported shape n=%d d=%d" % (B, d))
         ws1 = torch.empty(nbw // 4, dtype=torch.float32, device=dev)
         z1s = (_ct.c_void_p * 2)(img_uid.data_ptr(), txt_uid.data_ptr())
-        rc = _lib.lib().mmssl_infonce_multi_fwd_ticket_f32(z1s, _ptr(ua), _ptr(users), 2, B, d, float(tau), _ptr(out[3:5]),
-                                                           _ptr(ws1), nbw, _ptr(tickets), _lib.stream_ptr())
-        _lib.check(rc, "mmssl_infonce_multi_fwd_ticket_f32")
         gz1s = (_ct.c_void_p * 2)(_ptr(g_img), _ptr(g_txt))
         f32s, u64s = ticks if ticks else ((), ())
         fa = (_ct.c_void_p * max(len(f32s), 1))(*[int(x) for x in f32s])
@@ -761,19 +758,29 @@ class _BatchLosses(torch.autograd.Function):
         elif last is not None:
             raise _lib.MmsslError("batch_losses: the forward left an unreduced regulariser sum that this tail does not consume")
         if d <= 64:
-            # the BPR tail as guest blocks of the InfoNCE backward pair-tile launch (it depends on nothing in it), then
-            # the InfoNCE finish: six launches, and the chain is shorter by the BPR tail's whole duration
-            rc = _lib.lib().mmssl_infonce_bwd_tiles_bpr_f32(
+            # FIVE launches: InfoNCE prep (+ the BPR tail's ROWS part as guest blocks: it depends on nothing there and
+            # the short launch leaves most of the chip free), forward pair tiles, row terms (the last block also reduces
+            # the two losses), backward pair tiles (exactly one round of resident blocks without guests), backward finish
+            # (+ the tail's one-block ASSEMBLY part: BPR loss, loss assembly, counter ticks)
+            rc = _lib.lib().mmssl_infonce_multi_fwd_ticket_bpr_f32(
+                z1s, _ptr(ua), _ptr(users), 2, B, d, float(tau), _ptr(out[3:5]), _ptr(ws1), nbw, _ptr(tickets),
+                _ptr(ua), _ptr(ia), _ptr(users), _ptr(pos), _ptr(neg), B, float(decay), int(batch_size), _ptr(w[0:1]),
+                _ptr(w[1:2]), _ptr(g_ua), _ptr(g_ia), _ptr(wsb), nb, _lib.stream_ptr())
+            _lib.check(rc, "mmssl_infonce_multi_fwd_ticket_bpr_f32")
+            rc = _lib.lib().mmssl_infonce_multi_bwd_phase_f32(_ptr(users), 2, B, d, float(tau), _ptr(w[3:5]), gz1s,
+                                                              _ptr(g_ua), _ptr(ws1), ws1.numel() * 4, 1, _lib.stream_ptr())
+            _lib.check(rc, "mmssl_infonce_multi_bwd_phase_f32")
+            rc = _lib.lib().mmssl_infonce_multi_bwd_finish_bpr_f32(
                 _ptr(users), 2, B, d, float(tau), _ptr(w[3:5]), gz1s, _ptr(g_ua), _ptr(ws1), ws1.numel() * 4,
                 _ptr(ua), _ptr(ia), _ptr(users), _ptr(pos), _ptr(neg), B, float(decay), int(batch_size), _ptr(w[0:1]),
                 _ptr(w[1:2]), _ptr(g_ua), _ptr(g_ia), _ptr(out), _ptr(w), 5, _ptr(extra), float(c), _ptr(total), fa,
-                len(f32s), ka, len(u64s), _ptr(wsb), nb, _ptr(tickets[2:]), _ptr(xparts), n_xparts, _lib.stream_ptr())
-            _lib.check(rc, "mmssl_infonce_bwd_tiles_bpr_f32")
-            rc = _lib.lib().mmssl_infonce_multi_bwd_phase_f32(_ptr(users), 2, B, d, float(tau), _ptr(w[3:5]), gz1s,
-                                                              _ptr(g_ua), _ptr(ws1), ws1.numel() * 4, 2, _lib.stream_ptr())
-            _lib.check(rc, "mmssl_infonce_multi_bwd_phase_f32")
+                len(f32s), ka, len(u64s), _ptr(wsb), nb, _ptr(xparts), n_xparts, _lib.stream_ptr())
+            _lib.check(rc, "mmssl_infonce_multi_bwd_finish_bpr_f32")
             ctx.eager = (g_ua, g_ia, g_img, g_txt)
             return out
+        rc = _lib.lib().mmssl_infonce_multi_fwd_ticket_f32(z1s, _ptr(ua), _ptr(users), 2, B, d, float(tau), _ptr(out[3:5]),
+                                                           _ptr(ws1), nbw, _ptr(tickets), _lib.stream_ptr())
+        _lib.check(rc, "mmssl_infonce_multi_fwd_ticket_f32")
         rc = _lib.lib().mmssl_infonce_multi_bwd_phase_f32(_ptr(users), 2, B, d, float(tau), _ptr(w[3:5]), gz1s, _ptr(g_ua),
                                                           _ptr(ws1), ws1.numel() * 4, 3, _lib.stream_ptr())
         _lib.check(rc, "mmssl_infonce_multi_bwd_phase_f32")

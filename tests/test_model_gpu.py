@@ -451,8 +451,10 @@ def test_two_hotpath_steps_interleaved_on_two_streams_reproduce_their_solo_traje
         sb.set_batch(*bb[k])
         sa.step()
         sb.step()
-        ga.append(sa.loss.clone())
-        gb.append(sb.loss.clone())
+        with torch.cuda.stream(sa.stream):            # the loss buffer is written on the step's own stream
+            ga.append(sa.loss.clone())
+        with torch.cuda.stream(sb.stream):
+            gb.append(sb.loss.clone())
     torch.cuda.synchronize()
     # (not bit-exact: the loss backward scatter-adds with fp32 atomics, whose order may differ between two runs)
     for got, want in ((ga, la), (gb, lb)):

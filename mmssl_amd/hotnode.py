@@ -5,7 +5,7 @@
     MU  [U, nm d] = A_ui . X          MI [I, nm d] = A_iu . MU          two SpMMs of width nm d instead of 2 nm of width d:
                                                                         the edge lists are read once for all modalities
     u_l = A_ui . i_{l-1}, i_l = A_iu . u_l (softmax on the last layer)   the G-layer GCN chain, next to the modal chain
-    u_g = mean_l(u_l) + r sum_m normalize(MU_m)   (items alike)          one fuse kernel per side, which also leaves
+    u_g = mean_l(u_l) + r sum_m normalize(MU_m)   (items alike)          ONE fuse launch for both sides, which also leaves
     ss  = sum |MU|^2 + |MI|^2                                            the feature regulariser's sum of squares
 
 Two chains are independent and bound by different resources - projection + modal SpMMs (fp32 MFMA, then gather) and the
@@ -44,10 +44,10 @@ class HotCtx:
         #                               gradient of u_0 exists (the GCN chain's side stream holds the one of i_0)
         self.batch_rows = None        # (user rows [B], item rows [2B]) int64 device tensors: the ONLY rows of the fused
         #                               tables the caller will read (a training step's loss). The forward then computes
-        #                               just those rows on the critical path and sums |Mod|^2 on the side stream; the
-        #                               regulariser joins the loss by a launch on the side stream in the backward
-        #                               (reg_target = (c, total buffer) names where).
-        self.reg_parts = None         # (partials, ss tensor) left by such a forward
+        #                               just those rows (the other rows of u_g / i_g stay UNDEFINED); the regulariser's
+        #                               |Mod|^2 sums come out of the backward's fuse kernel and join the loss value by a
+        #                               launch on the side stream there (reg_target = (c, total buffer) names where).
+        self.reg_parts = None         # (None, ss tensor) left by such a forward: its backward owes the regulariser
         self.reg_target = None
         self.anchored = []
         self._zero_grads = {}

@@ -399,7 +399,7 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
-    sharded = world > 1 or a.force_dist or a.workload == "synth"
+    sharded = world > 1 or a.force_dist or a.workload == "synth" or a.dist_graph_probe
     if sharded:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if world == 1:

@@ -92,22 +92,50 @@ class HipBackend:
 
     # ---- the packed node's kernels (the grouped projection and the two-sided fuse kernels of the unsharded hot node) ----
     def packed_supported(self, feat_dims, rows, d):
-        from . import hotnode
-        return hotnode.packed_supported(feat_dims, rows, d)
+        """The packed node runs every modality list whose packed width nm * d the SpMM / fuse kernels have; the projection
+        runs grouped (csrc/projection.hip: d == 64, feature widths in whole 32-deep slices) or per modality
+        (csrc/linear.hip: any width % 4, e.g. configs[4]'s d = 128)."""
+        nm = len(feat_dims)
+        return (1 <= nm <= 4 and (nm * d) in (32, 64, 128, 256) and d in (32, 64, 128, 256) and (d // 4) * nm <= 64
+                and all(int(k) % 4 == 0 for k in feat_dims))
+
+    def _grouped(self, Ks, M, d):
+        return self.ops.proj_supported(Ks, M, d) and self.ops.proj_supported(Ks, M, d, wgrad=True)
 
     def proj_forward(self, Fs, Ws, bs, keep, scale, draw_p=0.0, external_tick=False):
-        """(X, keep). keep None and draw_p > 0: the masks are drawn in the projection's epilogue (no mask launch)."""
+        """(X [M, nm d], keep). keep None and draw_p > 0: fresh masks from the device generator (drawn in the grouped
+        projection's epilogue, or by one mask launch in front of the per-modality kernels)."""
         ops = self.ops
+        M, d = Fs[0].shape[0], Ws[0].shape[0]
+        dev = Fs[0].device
+        if self._grouped([f.shape[1] for f in Fs], M, d):
+            if keep is None and draw_p > 0.0:
+                X, keep = ops.proj_forward(Fs, Ws, bs, draw=(draw_p, ops._rng_state(dev)), scale=scale)
+                if not external_tick:
+                    ops.tick_rng(dev)
+                return X, keep
+            return ops.proj_forward(Fs, Ws, bs, keep=keep, scale=scale)[0], keep
         if keep is None and draw_p > 0.0:
-            dev = Fs[0].device
-            X, keep = ops.proj_forward(Fs, Ws, bs, draw=(draw_p, ops._rng_state(dev)), scale=scale)
-            if not external_tick:
-                ops.tick_rng(dev)
-            return X, keep
-        return ops.proj_forward(Fs, Ws, bs, keep=keep, scale=scale)[0], keep
+            keep = ops.dropout_masks(len(Fs), M, d, draw_p, dev, **({"external_tick": True} if external_tick else {}))
+        cols = [ops._linear_raw(F_, W, b, None if keep is None else keep[m], scale)
+                for m, (F_, W, b) in enumerate(zip(Fs, Ws, bs))]
+        return torch.cat(cols, 1), keep
 
     def proj_wgrad(self, G, Fs, want_bias):
-        return self.ops.proj_wgrad(G, Fs, want_bias=want_bias)
+        """([gW_m], [gb_m] or None) from the already masked packed gradient G [M, nm d]."""
+        ops = self.ops
+        nm = len(Fs)
+        M, d = Fs[0].shape[0], G.shape[1] // nm
+        if self._grouped([f.shape[1] for f in Fs], M, d):
+            return ops.proj_wgrad(G, Fs, want_bias=want_bias)
+        gWs, gbs = [], []
+        for m, F_ in enumerate(Fs):
+            Gm = G[:, m * d:(m + 1) * d].contiguous()
+            W_like = torch.empty((d, F_.shape[1]), dtype=torch.float32, device=G.device)
+            _, gW, gb = ops._linear_wgrad_raw(Gm, None, 1.0, F_, W_like)
+            gWs.append(gW)
+            gbs.append(gb)
+        return gWs, (gbs if want_bias else None)
 
     def fuse_fwd(self, us, MU, its, MI, inv, nm, r):
         """(u_g, i_g, ss): both sides in one launch; ss = |MU|^2 + |MI|^2 over the local rows (0-dim tensor)."""

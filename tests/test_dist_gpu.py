@@ -67,3 +67,64 @@ def test_sharded_step_on_hip_backend_world1_equals_oracle(solo_group, modal, fus
         assert rel(g[name][:k], P[key].grad) < 1e-4, name
     if modal == "full":
         assert rel(g["w_cat"], P["weight_dict.w_self_attention_cat"].grad) < 1e-4
+
+
+@pytest.mark.parametrize("forced", [False, True])
+def test_sharded_packed_node_at_d128_per_modality_projection_equals_oracle(solo_group, forced, monkeypatch):
+    """configs[4]'s width (d = 128): the grouped projection kernels are 64 channels wide, so the packed node runs the
+    projection per modality (csrc/linear.hip) around the same packed d = 256 modal chain and two-sided fuse kernels. One
+    sharded step (empty modal graphs, injected dropout masks) against the oracle; `forced`: the N > 1 branches (separate
+    reduce-scatter adds, mask after the scatter) with identity collectives on the gloo group."""
+    import scipy.sparse as sp
+    import numpy as np
+    import mmssl_oracle as O
+    from mmssl_amd import dist as md
+    if forced:
+        monkeypatch.setenv("MMSSL_DIST_FORCE_COLLECTIVES", "1")
+    dev = torch.device("cuda")
+    U, I, d, dv, dt, B = 700, 420, 128, 96, 40, 64
+    g = torch.Generator().manual_seed(8)
+    rng = np.random.default_rng(8)
+    raw = sp.csr_matrix((np.ones(4000, np.float32), (rng.integers(0, U, 4000), rng.integers(0, I, 4000))), shape=(U, I))
+    raw.data[:] = 1.0
+    img, txt = torch.randn(I, dv, generator=g), torch.randn(I, dt, generator=g)
+    state = {"image_trans.weight": torch.randn(d, dv, generator=g) / dv ** 0.5, "image_trans.bias": torch.randn(d, generator=g) * 0.1,
+             "text_trans.weight": torch.randn(d, dt, generator=g) / dt ** 0.5, "text_trans.bias": torch.randn(d, generator=g) * 0.1,
+             "user_id_embedding.weight": torch.randn(U, d, generator=g) * 0.1,
+             "item_id_embedding.weight": torch.randn(I, d, generator=g) * 0.1,
+             "weight_dict.w_q": torch.randn(d, d, generator=g) * 0.05, "weight_dict.w_k": torch.randn(d, d, generator=g) * 0.05,
+             "weight_dict.w_self_attention_cat": torch.randn(4 * d, d, generator=g) * 0.05}
+    cfg = O.Cfg(embed_size=d, drop_rate=0.2, batch_size=B, n_ui_layers=2)
+    km = [(torch.rand(I, d, generator=g) >= 0.2) for _ in range(2)]
+    users = torch.randperm(U, generator=g)[:B]
+    pos, neg = torch.randint(0, I, (B,), generator=g), torch.randint(0, I, (B,), generator=g)
+    empty = sp.csr_matrix((U, I), dtype=np.float32)
+    # oracle
+    P = {k: v.clone().requires_grad_(True) for k, v in state.items()}
+    A = [O.to_torch_sparse(O.csr_norm(raw, True)), O.to_torch_sparse(O.csr_norm(raw.T, True))]
+    E = [O.to_torch_sparse(empty), O.to_torch_sparse(empty.T.tocsr())]
+    o = O.forward(P, img, txt, (A[0], A[1], E[0], E[1], E[0], E[1]), cfg, training=True, keep_masks=[k.float() for k in km])
+    mf, emb, _ = O.bpr(o[0][users], o[1][pos], o[1][neg], cfg.decay, B)
+    ref = mf + emb + O.feat_reg(o[2], o[3], o[4], o[5], I, cfg.feat_reg_decay) + cfg.cl_rate * (
+        O.infonce(o[8][users], o[6][users], cfg.tau) + O.infonce(o[9][users], o[6][users], cfg.tau))
+    ref.backward()
+    # sharded step, one rank
+    bk = md.HipBackend()
+    ush, ish = md.RowShard(U, 1, 0), md.RowShard(I, 1, 0)
+    graphs = tuple(bk.make_graph(m) for m in (O.csr_norm(raw, True), O.csr_norm(raw.T, True), empty, empty.T.tocsr(),
+                                              empty, empty.T.tocsr()))
+    model = md.ShardedMMSSL(bk, cfg, ush, ish, state, img.numpy(), txt.numpy()).to(dev).train()
+    step = md.ShardedHotPathStep(model, graphs, B, I, modal_empty=True, optimizer=False)
+    step.set_batch(torch.stack([users, pos, neg]).to(dev))
+    step.keep_masks = tuple(k.to(torch.uint8).to(dev) for k in km)
+    total = step.backward()
+    torch.cuda.synchronize()
+    assert model.last_fused and not bk._grouped([dv, dt], I, d)          # packed node, per-modality projection
+    assert abs(float(total) - float(ref)) <= 2e-5 * abs(float(ref)), (float(total), float(ref))
+
+    def rel(a, b):
+        return float((a.cpu() - b).abs().max() / (b.abs().max() + 1e-30))
+    gp = {n: p.grad for n, p in model.named_parameters()}
+    for name, key in (("img_w", "image_trans.weight"), ("img_b", "image_trans.bias"), ("txt_w", "text_trans.weight"),
+                      ("txt_b", "text_trans.bias"), ("E_u", "user_id_embedding.weight"), ("E_i", "item_id_embedding.weight")):
+        assert rel(gp[name], P[key].grad) < 1e-4, (name, rel(gp[name], P[key].grad))

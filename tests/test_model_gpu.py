@@ -357,7 +357,7 @@ def test_baselines_match_reference_classes(name):
     for k in fx.files:
         if k.startswith("g."):
             e = H.rel_err(model.get_parameter(k[2:]).grad.cpu(), fx[k])
-            assert e < 5e-4, (k, e)
+            assert e < 1e-4, (k, e)               # observed: up to 2.5e-6
             checked += 1
     assert checked >= (10 if cf == "ngcf" else 6)
     if name == "ngcf":
@@ -458,13 +458,19 @@ def test_two_hotpath_steps_interleaved_on_two_streams_reproduce_their_solo_traje
     torch.cuda.synchronize()
     # Not bit-exact: the loss backward scatter-adds with fp32 atomics, whose order differs from run to run; where a
     # gradient entry nearly cancels, AdamW's g / sqrt(v) turns that last-bit noise into a visible difference of a few
-    # entries after a handful of steps (seen on one box in three). Interference between the two objects would be gross.
+    # entries after a handful of steps (observed: losses to 1e-7, parameters to 2.5e-6 of their largest entry).
+    # Interference between the two objects would be gross.
     for got, want in ((ga, la), (gb, lb)):
         for x, y in zip(got, want):
             assert abs(float(x) - y) <= 2e-5 * abs(y), (ga, la, gb, lb)
+    worst = 0.0
     for step, want in ((sa, pa), (sb, pb)):
         for k, v in step.model.named_parameters():
-            assert H.rel_err(v.detach().cpu(), want[k].cpu()) < 5e-4, k
+            e = H.rel_err(v.detach().cpu(), want[k].cpu())
+            worst = max(worst, e)
+            assert e < 1e-4, (k, e)               # observed: up to 2.5e-6
+    print("interleaved vs solo: worst loss dev %.2e, worst parameter dev %.2e" % (
+        max(abs(float(x) - y) / abs(y) for got, want in ((ga, la), (gb, lb)) for x, y in zip(got, want)), worst))
 
 
 def test_hotpath_batch_ring_equals_set_batch():

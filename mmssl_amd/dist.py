@@ -577,6 +577,12 @@ class _Side:
         if self.side is not None and not solo:
             self.side.wait_stream(self.main)
 
+    def lend(self, t, solo):
+        """A grouped collective's output (allocated on the current stream) that the SIDE stream consumes: tell the
+        allocator, or the block could be handed out again on the current stream while the side stream still reads it."""
+        if self.side is not None and not solo and t.is_cuda:
+            t.record_stream(self.side)
+
 
 class _ShardedHotForward(torch.autograd.Function):
     """Row-sharded counterpart of hotnode._HotNode, one autograd node: the grouped projection of the local item rows,
@@ -615,6 +621,7 @@ class _ShardedHotForward(torch.autograd.Function):
                 st.meet(solo)
                 i_full, X_full = _all_gather_pair(i, X, g)
                 st.part(solo)
+                st.lend(i_full, solo)
                 MU = bk.spmm_raw(ui, False, X_full, bk.EPI_NONE)
             else:
                 with st.gcn():
@@ -627,6 +634,7 @@ class _ShardedHotForward(torch.autograd.Function):
                 st.meet(solo)
                 u_full, MU_full = _all_gather_pair(u, MU, g)
                 st.part(solo)
+                st.lend(u_full, solo)
                 MI = bk.spmm_raw(iu, False, MU_full, bk.EPI_NONE)
             else:
                 with st.gcn():
@@ -699,6 +707,7 @@ class _ShardedHotForward(torch.autograd.Function):
             st.meet(solo)
             rg, rm = _reduce_scatter_pair(part_g, part_m, per_u, g)
             st.part(solo)
+            st.lend(rg, solo)
             t = rm.add_(gMU)
             with st.gcn():
                 gu = bk.softmax_rows_bwd(uG, rg.add_(Gu, alpha=inv), 1.0)
@@ -716,6 +725,7 @@ class _ShardedHotForward(torch.autograd.Function):
             st.meet(solo)
             rg, gX = _reduce_scatter_pair(part_g, part_m, per_i, g)
             st.part(solo)
+            st.lend(rg, solo)
             if keep is not None:
                 gX = bk.mask_packed(gX, keep, d, scale)
             with st.gcn():

@@ -144,6 +144,81 @@ def test_sharded_step_equals_single_process(tmp_path, world, modal, fused):
                 assert float(o["g"][name][k:].abs().max()) == 0.0
 
 
+def _traj_worker(rank, world, port, out_dir, steps):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    import mmssl_oracle as O
+    from mmssl_amd import dist as md
+    from oracle_backend import OracleBackend
+    fx, d, raw, U, I, state, users, pos, neg, img_raw, txt_raw = _global_problem("full")
+    ush, ish = md.RowShard(U, world, rank), md.RowShard(I, world, rank)
+    bk = OracleBackend()
+    cfg = O.Cfg(drop_rate=0.0, batch_size=48, n_ui_layers=2)
+
+    def local_pair(m):
+        ui, iu = O.csr_norm(m, True), O.csr_norm(m.T, True)
+        return bk.make_graph(md.shard_graph(ui, ush, ish)), bk.make_graph(md.shard_graph(iu, ish, ush))
+    graphs = local_pair(raw) + local_pair(img_raw) + local_pair(txt_raw)
+    model = md.ShardedMMSSL(bk, cfg, ush, ish, state, d["image_feat"], d["text_feat"]).train()
+    step = md.ShardedHotPathStep(model, graphs, 48, I, lr=1e-2)          # CPU: torch.optim.AdamW on the local tensors
+    losses = []
+    g = torch.Generator().manual_seed(5)
+    for _ in range(steps):                                                # identical batches on every rank (global ids)
+        step.set_batch(torch.randperm(U, generator=g)[:48], torch.randint(0, I, (48,), generator=g),
+                       torch.randint(0, I, (48,), generator=g))
+        losses.append(float(step.step()))
+    torch.save({"losses": losses, "ush": (ush.lo, ush.hi, ush.n), "ish": (ish.lo, ish.hi, ish.n),
+                "p": {n: p.detach().clone() for n, p in model.named_parameters()}}, os.path.join(out_dir, "t%d.pt" % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_trajectory_equals_single_process_adamw(tmp_path, world):
+    """Four sharded steps WITH the optimiser (gloo, world 2 / 3): every rank's losses, its rows of the embedding tables and
+    the replicated tensors follow the single-process oracle stepped by torch.optim.AdamW on the global problem - the
+    persistent gradient bucket (gradients = views of it, the regulariser share in its last slot) across several steps."""
+    import mmssl_oracle as O
+    steps = 4
+    port = _free_port()
+    mp.spawn(_traj_worker, args=(world, port, str(tmp_path), steps), nprocs=world, join=True)
+    fx, d, raw, U, I, state, users, pos, neg, img_raw, txt_raw = _global_problem("full")
+    names = ("image_trans.weight", "image_trans.bias", "text_trans.weight", "text_trans.bias", "user_id_embedding.weight",
+             "item_id_embedding.weight", "weight_dict.w_self_attention_cat")
+    P = {k: v.clone().requires_grad_(k in names) for k, v in state.items()}
+    opt = torch.optim.AdamW([P[k] for k in names], lr=1e-2)
+    cfg = O.Cfg(drop_rate=0.0, batch_size=48, n_ui_layers=2)
+    A = O.graph_pair(raw) + O.graph_pair(img_raw) + O.graph_pair(txt_raw)
+    g = torch.Generator().manual_seed(5)
+    ref = []
+    for _ in range(steps):
+        u_, p_, n_ = torch.randperm(U, generator=g)[:48], torch.randint(0, I, (48,), generator=g), torch.randint(0, I, (48,), generator=g)
+        opt.zero_grad()
+        o = O.forward(P, torch.from_numpy(d["image_feat"]), torch.from_numpy(d["text_feat"]), A, cfg, training=False)
+        mf, emb, _ = O.bpr(o[0][u_], o[1][p_], o[1][n_], cfg.decay, 48)
+        loss = mf + emb + O.feat_reg(o[2], o[3], o[4], o[5], I, cfg.feat_reg_decay) + cfg.cl_rate * (
+            O.infonce(o[8][u_], o[6][u_], cfg.tau) + O.infonce(o[9][u_], o[6][u_], cfg.tau))
+        loss.backward()
+        opt.step()
+        ref.append(float(loss))
+    assert ref[-1] != ref[0]
+    outs = [torch.load(os.path.join(str(tmp_path), "t%d.pt" % r)) for r in range(world)]
+
+    def rel(a, b):
+        return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+    for o in outs:
+        np.testing.assert_allclose(o["losses"], ref, rtol=2e-5)
+        for name, key in (("img_w", "image_trans.weight"), ("img_b", "image_trans.bias"), ("txt_w", "text_trans.weight"),
+                          ("txt_b", "text_trans.bias"), ("w_cat", "weight_dict.w_self_attention_cat")):
+            assert rel(o["p"][name], P[key].detach()) < 2e-4, name
+        for name, key, sh in (("E_u", "user_id_embedding.weight", o["ush"]), ("E_i", "item_id_embedding.weight", o["ish"])):
+            lo, hi, n = sh
+            k = max(0, min(hi, n) - lo)
+            assert rel(o["p"][name][:k], P[key].detach()[lo:lo + k]) < 2e-4, name
+
+
 def test_row_shard_and_graph_slicing():
     import scipy.sparse as sp
     from mmssl_amd import dist as md

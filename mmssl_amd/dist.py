@@ -33,7 +33,9 @@ import torch.nn as nn
 
 
 class HipBackend:
-    """The product compute backend: HIP kernels via mmssl_amd.ops."""
+    """The product compute backend: HIP kernels via mmssl_amd.ops. One backend object per sharded model / step: it owns
+    the node's side streams and the hand-offs between a step's forward, loss section and backward (the regulariser
+    partials, the event behind the backward's fuse kernel) - the sharded counterpart of hotnode.HotCtx."""
 
     def __init__(self):
         from . import ops

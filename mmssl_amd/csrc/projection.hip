@@ -57,6 +57,14 @@ using namespace mmssl;
 #ifndef MMSSL_PROJ_NT
 #define MMSSL_PROJ_NT 1
 #endif
+// quarters of a slice's MFMAs issued BEFORE the step's wait + barrier (their operands sit in registers since the previous
+// step), so that the matrix pipe has work while the wave waits. Build option only: measured no different (123.0 / 137.0 us
+// with one quarter, 124 / 138 with two, against 122.8 / 135.3: the pipe is not idle at the barrier) - the ~20 us between
+// the kernel and its MFMA time are the segment switches (~3.5 us each, 2.5 per block) and launch ramp / tail.
+#ifndef MMSSL_PROJ_PRESYNC
+#define MMSSL_PROJ_PRESYNC 0
+#endif
+constexpr int kPre = MMSSL_PROJ_PRESYNC;
 
 namespace {
 
@@ -245,24 +253,41 @@ __global__ __launch_bounds__(kFThreads) void proj_fwd_sk_kernel(Group P, int upb
     // One pipeline step = the 32 MFMAs of slice kt with the step's other work slotted between them, one scheduling region
     // per quarter: the DMA pieces of slice kt+3, the 8 MFMAs of the quarter, then the fragment reads of slice kt+1's
     // quarter INTO THE REGISTERS THOSE MFMAs JUST READ (one fragment set, refilled in place).
-    auto step = [&](int kt, FragF& f, bool more1, bool more3) {
+    auto mfma_quarter = [&](int q, FragF& f) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        if (more3 && !(MMSSL_PROJ_DBG & 1)) {
-#pragma unroll
-          for (int e = 0; e < kFPieces; ++e)
-            if (e * 4 / kFPieces == q) issue_piece(kt + PST, e);
+      for (int p = 4 * q; p < 4 * q + 4; ++p) {
+        if (MMSSL_PROJ_DBG & 2) {            // decomposition build: keep the operands alive with two plain FMAs
+          acc0[p] = fmaf(f.a[p], f.b0[p], acc0[p]);
+          acc1[p] = fmaf(f.a[p], f.b1[p], acc1[p]);
+        } else {
+          acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[p], f.b0[p], acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[p], f.b1[p], acc1, 0, 0, 0);
         }
+      }
+    };
+    auto issue_quarter = [&](int kt, int q) {
 #pragma unroll
-        for (int p = 4 * q; p < 4 * q + 4; ++p) {
-          if (MMSSL_PROJ_DBG & 2) {            // decomposition build: keep the operands alive with two plain FMAs
-            acc0[p] = fmaf(f.a[p], f.b0[p], acc0[p]);
-            acc1[p] = fmaf(f.a[p], f.b1[p], acc1[p]);
-          } else {
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[p], f.b0[p], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[p], f.b1[p], acc1, 0, 0, 0);
-          }
-        }
+      for (int e = 0; e < kFPieces; ++e)
+        if (e * 4 / kFPieces == q) issue_piece(kt + PST, e);
+    };
+    // sync_out >= 0: wait until at most that many slices of this wave's DMA are in flight, then the block barrier
+    auto step = [&](int kt, FragF& f, bool more1, bool more3, int sync_out) {
+#pragma unroll
+      for (int q = 0; q < kPre; ++q) {       // operands in registers since the previous step: ahead of the wait
+        mfma_quarter(q, f);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (sync_out >= 0) step_sync<kFPieces>(sync_out);
+#pragma unroll
+      for (int q = 0; q < kPre; ++q) {
+        if (more3 && !(MMSSL_PROJ_DBG & 1)) issue_quarter(kt, q);
+        if (more1 && !(MMSSL_PROJ_DBG & 4)) read_quarter(kt + 1, q, f);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int q = kPre; q < 4; ++q) {
+        if (more3 && !(MMSSL_PROJ_DBG & 1)) issue_quarter(kt, q);
+        mfma_quarter(q, f);
         if (more1 && !(MMSSL_PROJ_DBG & 4)) read_quarter(kt + 1, q, f);
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -280,14 +305,10 @@ __global__ __launch_bounds__(kFThreads) void proj_fwd_sk_kernel(Group P, int upb
 #pragma unroll
     for (int q = 0; q < 4; ++q) read_quarter(0, q, f);
     int kt = 0;
-    for (; kt + PST < nk; ++kt) {                // steady state: slices kt+1 .. kt+PST exist, branch-free
-      step_sync<kFPieces>(PST - 2);
-      step(kt, f, true, true);
-    }
-    for (; kt < nk; ++kt) {                      // drain
-      if (kt + 1 < nk) step_sync<kFPieces>(min(nk - kt - 2, PST - 2));
-      step(kt, f, kt + 1 < nk, false);
-    }
+    for (; kt + PST < nk; ++kt)                  // steady state: slices kt+1 .. kt+PST exist, branch-free
+      step(kt, f, true, true, PST - 2);
+    for (; kt < nk; ++kt)                        // drain
+      step(kt, f, kt + 1 < nk, false, kt + 1 < nk ? min(nk - kt - 2, PST - 2) : -1);
     // the segment's accumulator image -> its partial slot: plane q (0..7) holds, at thread tid, the float4 of rows
     // 32w + 8(q & 3) + 4h + {0..3}, column 32(q >> 2) + (lane & 31)
     float4* Pq = reinterpret_cast<float4*>(partials + ((size_t)blockIdx.x * max_segs + seg) * kFSlotFloats);
@@ -373,31 +394,48 @@ __global__ __launch_bounds__(kThreads) void proj_wgrad_sk_kernel(Group P, int up
       for (int eb = 0; eb < 2; ++eb) acc[ea][eb] = floatx4{0.f, 0.f, 0.f, 0.f};
     float bs0 = 0.f, bs1 = 0.f;                           // this wave's share of the bias-gradient column sums
     const bool want_bias = bpart != nullptr && sg.tip == 0;
-    auto step = [&](int kt, FragW& cur, bool more1, bool more3) {
+    auto work_quarter = [&](int q, FragW& cur) {
+      if (want_bias) {                 // the four row-waves of a column half share the k-groups: p % 4 == wi
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        if (more3 && !(MMSSL_PROJ_DBG & 1)) {
+        for (int p = 2 * q; p < 2 * q + 2; ++p)
+          if ((p & 3) == wi_u) { bs0 += cur.b[p].x; bs1 += cur.b[p].y; }
+      }
 #pragma unroll
-          for (int e = 0; e < kPieces; ++e)
-            if (e * 4 / kPieces == q) issue_piece(kt + PST, e);
-        }
-        if (want_bias) {               // the four row-waves of a column half share the k-groups: p % 4 == wi
+      for (int p = 2 * q; p < 2 * q + 2; ++p) {
+        const float av[4] = {cur.a[p].x, cur.a[p].y, cur.a[p].z, cur.a[p].w};
+        const float bv[2] = {cur.b[p].x, cur.b[p].y};
 #pragma unroll
-          for (int p = 2 * q; p < 2 * q + 2; ++p)
-            if ((p & 3) == wi_u) { bs0 += cur.b[p].x; bs1 += cur.b[p].y; }
-        }
+        for (int ea = 0; ea < 4; ++ea)
 #pragma unroll
-        for (int p = 2 * q; p < 2 * q + 2; ++p) {
-          const float av[4] = {cur.a[p].x, cur.a[p].y, cur.a[p].z, cur.a[p].w};
-          const float bv[2] = {cur.b[p].x, cur.b[p].y};
+          for (int eb = 0; eb < 2; ++eb) {
+            if (MMSSL_PROJ_DBG & 2) acc[ea][eb][0] = fmaf(av[ea], bv[eb], acc[ea][eb][0]);
+            else acc[ea][eb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ea], bv[eb], acc[ea][eb], 0, 0, 0);
+          }
+      }
+    };
+    auto issue_quarter = [&](int kt, int q) {
 #pragma unroll
-          for (int ea = 0; ea < 4; ++ea)
+      for (int e = 0; e < kPieces; ++e)
+        if (e * 4 / kPieces == q) issue_piece(kt + PST, e);
+    };
+    // sync_out >= 0: wait until at most that many slices of this wave's DMA are in flight, then the block barrier
+    auto step = [&](int kt, FragW& cur, bool more1, bool more3, int sync_out) {
 #pragma unroll
-            for (int eb = 0; eb < 2; ++eb) {
-              if (MMSSL_PROJ_DBG & 2) acc[ea][eb][0] = fmaf(av[ea], bv[eb], acc[ea][eb][0]);
-              else acc[ea][eb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ea], bv[eb], acc[ea][eb], 0, 0, 0);
-            }
-        }
+      for (int q = 0; q < kPre; ++q) {       // operands in registers since the previous step: ahead of the wait
+        work_quarter(q, cur);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (sync_out >= 0) step_sync(sync_out);
+#pragma unroll
+      for (int q = 0; q < kPre; ++q) {
+        if (more3 && !(MMSSL_PROJ_DBG & 1)) issue_quarter(kt, q);
+        if (more1 && !(MMSSL_PROJ_DBG & 4)) read_quarter(kt + 1, q, cur);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int q = kPre; q < 4; ++q) {
+        if (more3 && !(MMSSL_PROJ_DBG & 1)) issue_quarter(kt, q);
+        work_quarter(q, cur);
         if (more1 && !(MMSSL_PROJ_DBG & 4)) read_quarter(kt + 1, q, cur);      // into the registers just consumed
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -414,14 +452,10 @@ __global__ __launch_bounds__(kThreads) void proj_wgrad_sk_kernel(Group P, int up
 #pragma unroll
     for (int q = 0; q < 4; ++q) read_quarter(0, q, f);
     int kt = 0;
-    for (; kt + PST < nk; ++kt) {                // steady state: slices kt+1 .. kt+PST exist, branch-free
-      step_sync(PST - 2);
-      step(kt, f, true, true);
-    }
-    for (; kt < nk; ++kt) {                      // drain
-      if (kt + 1 < nk) step_sync(min(nk - kt - 2, PST - 2));
-      step(kt, f, kt + 1 < nk, false);
-    }
+    for (; kt + PST < nk; ++kt)                  // steady state: slices kt+1 .. kt+PST exist, branch-free
+      step(kt, f, true, true, PST - 2);
+    for (; kt < nk; ++kt)                        // drain
+      step(kt, f, kt + 1 < nk, false, kt + 1 < nk ? min(nk - kt - 2, PST - 2) : -1);
     // acc[ea][eb][r] at lane (g, j') = C[row 64 wi + 16 g + 4 r + ea][col 32 wj + 2 j' + eb]: plane 4 eb + r holds, at
     // thread tid, the float4 of the FOUR CONSECUTIVE rows ea = 0..3 (the permuted row slots fall back into place)
     const size_t slot = (size_t)blockIdx.x * max_segs + seg;

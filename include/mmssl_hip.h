@@ -453,8 +453,8 @@ int mmssl_infonce_multi_bwd_f32(const int64_t* idx, int n_problems, int64_t n, i
  * scatters into the same table gradient and must stay ordered before phase 2) can overlap phase 1:
  * phases bit 0 = pair tiles (workspace only), bit 1 = finish (diagonal terms, normalise-backward,
  * scatter-add into gz1s / gz2). phases == 3 is mmssl_infonce_multi_bwd_f32. */
-/* The hot step's loss chain with mmssl_bpr_step_f32 in TWO parts (d in {32, 64}; same arithmetic, same bits as the guest
- * form above): its ROWS part (gathers, scores, scatter-added gradients, per-block partials into bpr_workspace) rides as
+/* The hot step's loss chain with mmssl_bpr_step_f32 in TWO parts (d in {32, 64}; same arithmetic, same bits as
+ * mmssl_bpr_step_f32): its ROWS part (gathers, scores, scatter-added gradients, per-block partials into bpr_workspace) rides as
  * guest blocks of the forward chain's short prep launch - mmssl_infonce_multi_fwd_ticket_bpr_f32 = mmssl_infonce_multi_
  * fwd_ticket_f32 + those guests - and its one-block ASSEMBLY part (BPR loss, total = w . terms + c * extra, counter ticks)
  * as a guest of the backward finish: mmssl_infonce_multi_bwd_finish_bpr_f32 = mmssl_infonce_multi_bwd_phase_f32(phase 2)
@@ -518,20 +518,6 @@ int mmssl_bpr_step_f32(const float* Eu, const float* Ei, const int64_t* users, c
                        float* const* f32_ticks, int n_f32, uint64_t* const* u64_ticks, int n_u64,
                        void* workspace, size_t workspace_bytes, int* ticket, const float* extra_parts,
                        int64_t n_extra_parts, void* stream);
-/* Phase 1 of mmssl_infonce_multi_bwd_phase_f32 (the backward pair tiles, fp32-MFMA shapes d <= 64 only) with the whole
- * of mmssl_bpr_step_f32 riding along as extra blocks of the same launch: the BPR tail depends on nothing the pair tiles
- * compute, and as a launch of its own it adds its full duration to the loss chain. Arguments: those of the two entry
- * points (bpr_workspace / ticket as for mmssl_bpr_step_f32). Follow with phases = 2 of mmssl_infonce_multi_bwd_phase_f32. */
-int mmssl_infonce_bwd_tiles_bpr_f32(const int64_t* idx, int n_problems, int64_t n, int d, float tau,
-                                    const float* gloss, float* const* gz1s, float* gz2, void* workspace,
-                                    size_t workspace_bytes, const float* Eu, const float* Ei,
-                                    const int64_t* users, const int64_t* pos, const int64_t* neg, int64_t B,
-                                    float decay, int64_t batch_size, const float* g_mf, const float* g_emb,
-                                    float* gEu, float* gEi, float* terms, const float* w, int n_terms,
-                                    const float* extra, float c, float* total, float* const* f32_ticks,
-                                    int n_f32, uint64_t* const* u64_ticks, int n_u64, void* bpr_workspace,
-                                    size_t bpr_workspace_bytes, int* ticket, const float* extra_parts,
-                                    int64_t n_extra_parts, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Baseline models next to MMSSL (csrc/baselines.hip; SURVEY.md 8f "next #4")

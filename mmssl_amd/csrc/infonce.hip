@@ -20,11 +20,15 @@
 // followed by the F.normalize backward (incl. its g/eps branch for all-zero rows).
 #include "common.hpp"
 #include "bpr_step.hpp"
+#include "lds_dma.hpp"
 
 using namespace mmssl;
 
 namespace {
 
+#ifndef MMSSL_INFONCE_LDS_TILES
+#define MMSSL_INFONCE_LDS_TILES 1   // 0: the tile kernels with fragment-shaped global loads (A/B builds only)
+#endif
 constexpr int T = 32;        // tile edge (rows and columns)
 constexpr float kNormEps = 1e-12f;
 constexpr int CP = T + 4;    // padded row length of a coefficient tile
@@ -64,9 +68,10 @@ inline Layout make_layout(int64_t n, int d) {
   }
   size_t o = 0;
   auto take = [&](size_t cnt) { size_t r = o; o += (cnt + 3) & ~(size_t)3; return r; };
-  L.n1 = take((size_t)n * d);
-  L.n2 = take((size_t)n * d);
-  L.inv1 = take(n); L.inv2 = take(n); L.pos = take(n); L.w = take(n); L.c = take(n);
+  // n1 / n2 / c are padded to whole 32-row tiles (prep writes zero rows): the LDS-staged tile kernels move 32 x d images
+  L.n1 = take((size_t)nt * T * d);
+  L.n2 = take((size_t)nt * T * d);
+  L.inv1 = take(n); L.inv2 = take(n); L.pos = take(n); L.w = take(n); L.c = take((size_t)nt * T);
   L.rows_part = take((size_t)L.cs_f * n);
   L.loss = take((size_t)(n + kBlock - 1) / kBlock + 4);
   L.g1p = take((size_t)L.cs_b * n * d);
@@ -107,8 +112,15 @@ __global__ __launch_bounds__(kBlock) void prep_kernel(Z1Ptrs Z, const float* __r
   // one 16-lane group per row, lanes stride over the d/4 float4 chunks
   const int lig = threadIdx.x & 15;
   const int64_t r = (int64_t)blockIdx.x * (kBlock / 16) + threadIdx.x / 16;
-  if (r >= n) return;
   const int nch = d >> 2;
+  if (r >= n) {                                  // pad rows of the last tile: zeros (the tile kernels read whole tiles)
+    if (r < (int64_t)n_tiles(n) * T)
+      for (int k = lig; k < nch; k += 16) {
+        reinterpret_cast<float4*>(n1 + r * d)[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        reinterpret_cast<float4*>(n2 + r * d)[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    return;
+  }
   const int64_t src = idx ? idx[r] : r;          // fused gather: row r of the batch = table row idx[r]
   const float4* a = reinterpret_cast<const float4*>(z1 + src * d);
   const float4* b = reinterpret_cast<const float4*>(z2 + src * d);
@@ -623,13 +635,7 @@ __global__ __launch_bounds__(kBlock) void fwd_tiles_mfma_kernel(const float* __r
 // round-robin and add their g1/g2 tiles in a fixed order through LDS before one store per block.
 template <int D, bool SINGLE>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2))) void bwd_tiles_mfma_kernel(float* __restrict__ ws, size_t ws_stride, Layout L,
-                                                                int64_t n, float tau, int cs, BprStepArgs bpr) {
-  // Guest blocks: the hot step's BPR tail (bpr_step.hpp) rides along behind the pair-tile blocks of problem 0 - nothing
-  // in it depends on this kernel, and as a launch of its own it would add its whole duration to the loss chain.
-  if (bpr.n_blocks > 0 && (int)blockIdx.x >= n_tiles(n) * cs) {
-    if (blockIdx.y == 0) bpr_step_block<D / 4>(bpr, (int)blockIdx.x - n_tiles(n) * cs);
-    return;
-  }
+                                                                int64_t n, float tau, int cs) {
   float* __restrict__ wsp = ws + (size_t)blockIdx.y * ws_stride;
   const float* __restrict__ n1 = wsp + L.n1;
   const float* __restrict__ n2 = wsp + L.n2;
@@ -773,6 +779,314 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2))) voi
   }
 }
 
+// ---- tile images in LDS (D in {32, 64}) -----------------------------------------------------------------------------
+// A 32 x D tile of a row-major [rows, D] matrix is 32 D contiguous floats. Fragment-shaped loads straight from global
+// (lane = row, 16 B per lane: 64 cache lines per instruction) keep the CU's L1 busy for longer than the tile's MFMAs
+// take, so the tile goes to LDS in whole lines by LDS-DMA (1 KB per wave instruction, lane-linear destination) and the
+// fragments come from there. Image layout: row r at r * D floats, its 16-byte slots XOR-swizzled with the row number so
+// that ds_read_b128 with lane = row is conflict-free (its 16-lane groups hold rows distinct mod 16); the swizzle goes
+// on the SOURCE address of the DMA.
+template <int D>
+struct TileImg {
+  static constexpr int SL = D / 4;                  // 16-byte slots per row
+  static constexpr int RB = 64 / D;                 // rows per 256-byte bank row (1 or 2)
+  static constexpr int RPP = 256 / D;               // rows per 1 KB DMA piece
+  static constexpr int PIECES = T / RPP;
+  static constexpr int FLOATS = T * D;
+  __device__ static __forceinline__ int key(int row) { return (row / RB) & (SL - 1); }
+  // whole wave: tile rows [0, 32) at src -> image at LDS byte address dst
+  __device__ static __forceinline__ void stage(const float* __restrict__ src, unsigned dst, int lane) {
+#pragma unroll
+    for (int p = 0; p < PIECES; ++p) {
+      const int row = p * RPP + lane / SL;
+      const int slot = (lane % SL) ^ key(row);
+      glds16(src + row * D + slot * 4, dst + (unsigned)p * 1024u);
+    }
+  }
+  // one of several waves sharing the job: pieces p = first, first + step, ...
+  __device__ static __forceinline__ void stage_part(const float* __restrict__ src, unsigned dst, int lane, int first, int step) {
+    for (int p = first; p < PIECES; p += step) {
+      const int row = p * RPP + lane / SL;
+      const int slot = (lane % SL) ^ key(row);
+      glds16(src + row * D + slot * 4, dst + (unsigned)p * 1024u);
+    }
+  }
+  // MFMA fragment of lane (h, lr): row lr, features [h D/2, (h + 1) D/2)
+  __device__ static __forceinline__ void frag(const float* __restrict__ img, int lr, int h, float (&f)[D / 2]) {
+    const int k = key(lr);
+#pragma unroll
+    for (int q = 0; q < D / 8; ++q) {
+      const float4 v = *reinterpret_cast<const float4*>(img + lr * D + (((h * (SL / 2) + q) ^ k) << 2));
+      f[4 * q] = v.x; f[4 * q + 1] = v.y; f[4 * q + 2] = v.z; f[4 * q + 3] = v.w;
+    }
+  }
+  // element (row, col) - as a B operand: one row per half-wave, col = 32 f + lr: conflict-free ds_read_b32
+  __device__ static __forceinline__ float at(const float* __restrict__ img, int row, int col) {
+    return img[row * D + ((((col >> 2) ^ key(row))) << 2) + (col & 3)];
+  }
+};
+
+// ---- forward with LDS tile images: partial denominators per (row, block split). Similarity tiles are computed
+// transposed (A operand = column tile, B operand = the block's row tile): accumulator register r of lane (h, lr) is
+// the entry [row lr][column j(r, h)], so a row's partial sum is 16 in-register adds + one exchange between the
+// half-waves instead of a 32-lane shuffle tree per register. The 4 waves of a block share the row tile, take column
+// tiles round-robin (two per trip, both chains interleaved) and add their row sums through LDS in a fixed order.
+template <int D>
+__global__ __launch_bounds__(kBlock) void fwd_tiles_lds_kernel(const float* __restrict__ ws, size_t ws_stride,
+                                                               Layout L, int64_t n, float tau, int cs) {
+  using Img = TileImg<D>;
+  constexpr int TF = Img::FLOATS;
+  extern __shared__ __attribute__((aligned(16))) float lds[];         // [n1 row tile] [wave: two column tiles] x 4
+  __shared__ float red[4][T];
+  const float* __restrict__ wsp = ws + (size_t)blockIdx.y * ws_stride;
+  const float* __restrict__ n1 = wsp + L.n1;
+  const float* __restrict__ n2 = wsp + L.n2;
+  float* __restrict__ rows_part = const_cast<float*>(wsp) + L.rows_part;
+  const int nt = n_tiles(n);
+  const int ti = blockIdx.x % nt;
+  const int split = blockIdx.x / nt;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int h = lane >> 5, lr = lane & 31;
+  const int64_t i0 = (int64_t)ti * T;
+  const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)lds);
+  const float* __restrict__ C0 = lds + TF + wave * 2 * TF;
+  const float* __restrict__ C1 = C0 + TF;
+  const unsigned c_lds = lds0 + (unsigned)(TF + wave * 2 * TF) * 4u;
+  const int per = (2 * nt + cs - 1) / cs;
+  const int c_beg = split * per, c_end = min(2 * nt, c_beg + per);
+  const float inv_tau = 1.f / tau;
+  // column tile ct of the walk: the first nt are tiles of n1 (the reflexive block, diagonal excluded), then n2
+  auto stage_trip = [&](int ct) {
+    Img::stage((ct < nt ? n1 : n2) + (int64_t)(ct < nt ? ct : ct - nt) * T * D, c_lds, lane);
+    if (ct + 4 < c_end) {
+      const int c2 = ct + 4;
+      Img::stage((c2 < nt ? n1 : n2) + (int64_t)(c2 < nt ? c2 : c2 - nt) * T * D, c_lds + (unsigned)TF * 4u, lane);
+    }
+  };
+  Img::stage_part(n1 + i0 * D, lds0, lane, wave, 4);
+  int ct = c_beg + wave;
+  if (ct < c_end) stage_trip(ct);
+  vm_wait_n<0>();
+  __syncthreads();                       // the row tile's pieces come from all four waves
+  float a[D / 2];
+  Img::frag(lds, lr, h, a);
+  float rowsum = 0.f;
+  const int own = (int)(i0 + lr);        // this lane's row (n < 2^31 on this path: the tile grid is 32-bit)
+  auto accumulate = [&](const floatx16& acc, int ctile) {
+    const bool refl = ctile < nt;
+    const int j0 = (refl ? ctile : ctile - nt) * T;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int col = j0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      const float e = fast_exp(acc[r] * inv_tau);
+      rowsum += (col < (int)n && !(refl && col == own)) ? e : 0.f;
+    }
+  };
+  for (; ct < c_end; ct += 8) {
+    const bool two = ct + 4 < c_end;     // wave-uniform
+    floatx16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.f;
+    float b0[D / 2];
+    Img::frag(C0, lr, h, b0);
+    if (two) {
+      float b1[D / 2];
+      Img::frag(C1, lr, h, b1);
+#pragma unroll
+      for (int k = 0; k < D / 2; ++k) {
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(b0[k], a[k], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(b1[k], a[k], acc1, 0, 0, 0);
+      }
+      accumulate(acc0, ct);
+      accumulate(acc1, ct + 4);
+    } else {
+#pragma unroll
+      for (int k = 0; k < D / 2; ++k) acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(b0[k], a[k], acc0, 0, 0, 0);
+      accumulate(acc0, ct);
+    }
+    if (ct + 8 < c_end) {                // next trip's images into this wave's own region
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      stage_trip(ct + 8);
+      vm_wait_n<0>();
+    }
+  }
+  rowsum += __shfl_xor(rowsum, 32, kWave);
+  if (lane < T) red[wave][lane] = rowsum;
+  __syncthreads();
+  if (threadIdx.x < T) {
+    const int64_t gi = i0 + threadIdx.x;
+    if (gi < n)
+      rows_part[(size_t)split * n + gi] =
+          ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
+  }
+}
+template <int D>
+constexpr int fwd_tiles_lds_bytes() { return 9 * TileImg<D>::FLOATS * 4; }
+
+// ---- backward pair tiles. Per (t, s) tile pair and wave, with the similarity tiles computed TRANSPOSED
+// (A operand = tile s, B operand = tile t) so that accumulator register r of lane (h, lr) holds the entry
+// [i = lr][j = j(r, h)], j(r, h) = (r & 3) + 8 (r >> 2) + 4 h - which is exactly an A operand of the second stage if
+// MFMA step r contracts the rows {j(r, 0), j(r, 1)} of tile s (any pairing of k indices is valid as long as A and B
+// agree): the coefficient tiles never leave the registers.
+//   S12 = n1_t.n2_s^T, S11 = n1_t.n1_s^T, S21 = n2_t.n1_s^T            (3 x D/2 MFMAs)
+//   C1 = -c_t e^{S12/tau}, C2 = -(c_t+c_s) e^{S11/tau} [t != s], C3 = -c_s e^{S21/tau}
+//   g1_t += C1 . n2_s + C2 . n1_s ;  g2_t += C3 . n1_s                 (3 x 16 x D/32 MFMAs)
+// LDS: the images of n1_t | n2_t (shared by the block) and of n1_s | n2_s per wave; second-stage B operands are rows
+// of the s images. The 4 waves of a block share t, take s tiles round-robin and add their g1/g2 tiles in a fixed
+// order through LDS before one store per block.
+template <int D>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2))) void bwd_tiles_lds_kernel(
+    float* __restrict__ ws, size_t ws_stride, Layout L, int64_t n, float tau, int cs) {
+  using Img = TileImg<D>;
+  constexpr int TF = Img::FLOATS;
+  constexpr int FT = D / 32;
+  // [n1_t | n2_t] [wave: n1_s | n2_s] x 4 = 80 KB at D = 64: exactly two blocks per CU, so NO static LDS in this kernel
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* __restrict__ wsp = ws + (size_t)blockIdx.y * ws_stride;
+  const float* __restrict__ n1 = wsp + L.n1;
+  const float* __restrict__ n2 = wsp + L.n2;
+  const float* __restrict__ c = wsp + L.c;
+  float* __restrict__ g1p = wsp + L.g1p;
+  float* __restrict__ g2p = wsp + L.g2p;
+  const int nt = n_tiles(n);
+  const int tt = blockIdx.x % nt;
+  const int split = blockIdx.x / nt;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int h = lane >> 5, lr = lane & 31;
+  const int64_t t0 = (int64_t)tt * T;
+  const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)lds);
+  const float* __restrict__ T1 = lds;
+  const float* __restrict__ T2 = lds + TF;
+  const float* __restrict__ S1 = lds + 2 * TF + wave * 2 * TF;
+  const float* __restrict__ S2 = S1 + TF;
+  const unsigned s_lds = lds0 + (unsigned)(2 * TF + wave * 2 * TF) * 4u;
+  const int per = (nt + cs - 1) / cs;
+  const int s_beg = split * per, s_end = min(nt, s_beg + per);
+  // the block's t images: each wave moves a quarter of the pieces; its own first s images right behind
+  Img::stage_part(n1 + t0 * D, lds0, lane, wave, 4);
+  Img::stage_part(n2 + t0 * D, lds0 + (unsigned)TF * 4u, lane, wave, 4);
+  int st = s_beg + wave;
+  if (st < s_end) {
+    Img::stage(n2 + (int64_t)st * T * D, s_lds + (unsigned)TF * 4u, lane);
+    Img::stage(n1 + (int64_t)st * T * D, s_lds, lane);
+  }
+  const bool vi = t0 + lr < n;
+  const float ct = vi ? c[t0 + lr] : 0.f;
+  floatx16 g1[FT], g2[FT];
+#pragma unroll
+  for (int f = 0; f < FT; ++f)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) g1[f][r] = g2[f][r] = 0.f;
+  const float inv_tau = 1.f / tau;
+  vm_wait_n<0>();
+  __syncthreads();                       // t images complete (pieces of all four waves)
+  for (; st < s_end; st += 4) {
+    const int64_t s0 = (int64_t)st * T;
+    // column-side coefficients; everything past n is masked with 32-bit selects (c is padded to whole tiles, its pad
+    // entries are never written; the pad rows of n1 / n2 are zeros)
+    const int nj = (int)(n - s0 < T ? n - s0 : T);
+    const int dj = tt == st ? lr : -1;             // the column that is this lane's own row (S11's diagonal)
+    float cs_[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int j = (r & 3) + 8 * (r >> 2) + 4 * h;
+      const float v = c[s0 + j];
+      cs_[r] = j < nj ? v : 0.f;
+    }
+    floatx16 s12, s11, s21;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s12[r] = s11[r] = s21[r] = 0.f;
+    {
+      float a1[D / 2], b2[D / 2], b1[D / 2];
+      Img::frag(T1, lr, h, a1);
+      Img::frag(S2, lr, h, b2);
+      Img::frag(S1, lr, h, b1);
+#pragma unroll
+      for (int k = 0; k < D / 2; ++k) {          // two independent accumulation chains, interleaved
+        s12 = __builtin_amdgcn_mfma_f32_32x32x2f32(b2[k], a1[k], s12, 0, 0, 0);
+        s11 = __builtin_amdgcn_mfma_f32_32x32x2f32(b1[k], a1[k], s11, 0, 0, 0);
+      }
+      float a2[D / 2];
+      Img::frag(T2, lr, h, a2);
+#pragma unroll
+      for (int k = 0; k < D / 2; ++k) s21 = __builtin_amdgcn_mfma_f32_32x32x2f32(b1[k], a2[k], s21, 0, 0, 0);
+    }
+    // second-stage B operands (rows j(r, h) of the s images), requested while the last similarity MFMAs run: the
+    // fragment registers are dead by now
+    float q2[16][FT], q1[16][FT];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int j = (r & 3) + 8 * (r >> 2) + 4 * h;
+#pragma unroll
+      for (int f = 0; f < FT; ++f) {
+        q2[r][f] = Img::at(S2, j, 32 * f + lr);
+        q1[r][f] = Img::at(S1, j, 32 * f + lr);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int j = (r & 3) + 8 * (r >> 2) + 4 * h;
+      const float e12 = fast_exp(s12[r] * inv_tau), e11 = fast_exp(s11[r] * inv_tau), e21 = fast_exp(s21[r] * inv_tau);
+      const float ctj = j < nj ? ct : 0.f;          // ct is 0 for rows past n
+      const float c2 = (j < nj && j != dj) ? ct + cs_[r] : 0.f;
+      s12[r] = -ctj * e12;
+      s11[r] = vi ? -c2 * e11 : 0.f;
+      s21[r] = vi ? -cs_[r] * e21 : 0.f;
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+#pragma unroll
+      for (int f = 0; f < FT; ++f) {
+        g1[f] = __builtin_amdgcn_mfma_f32_32x32x2f32(s12[r], q2[r][f], g1[f], 0, 0, 0);
+        g2[f] = __builtin_amdgcn_mfma_f32_32x32x2f32(s21[r], q1[r][f], g2[f], 0, 0, 0);
+        g1[f] = __builtin_amdgcn_mfma_f32_32x32x2f32(s11[r], q1[r][f], g1[f], 0, 0, 0);
+      }
+    if (st + 4 < s_end) {                 // next s images of this wave (its own region: no block barrier needed)
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      Img::stage(n2 + (int64_t)(st + 4) * T * D, s_lds + (unsigned)TF * 4u, lane);
+      Img::stage(n1 + (int64_t)(st + 4) * T * D, s_lds, lane);
+      vm_wait_n<0>();
+    }
+  }
+  // block reduction: waves 1..3 park their tiles in LDS (over the images: all waves are done with them), wave 0 adds
+  // them in the order 1, 2, 3
+  __syncthreads();
+  constexpr int GW = 2 * T * D;           // floats per wave: g1 then g2, [row][feature]
+  if (wave > 0) {
+    float* dst = lds + (wave - 1) * GW;
+#pragma unroll
+    for (int f = 0; f < FT; ++f)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+        dst[row * D + 32 * f + lr] = g1[f][r];
+        dst[T * D + row * D + 32 * f + lr] = g2[f][r];
+      }
+  }
+  __syncthreads();
+  if (wave == 0) {
+    const size_t base = (size_t)split * n * D;
+#pragma unroll
+    for (int f = 0; f < FT; ++f)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+        const int o = row * D + 32 * f + lr;
+        const float v1 = ((g1[f][r] + lds[o]) + lds[GW + o]) + lds[2 * GW + o];
+        const float v2 = ((g2[f][r] + lds[T * D + o]) + lds[GW + T * D + o]) + lds[2 * GW + T * D + o];
+        const int64_t gt = t0 + row;
+        if (gt < n) {
+          g1p[base + gt * D + 32 * f + lr] = v1;
+          g2p[base + gt * D + 32 * f + lr] = v2;
+        }
+      }
+  }
+}
+template <int D>
+constexpr int bwd_tiles_lds_bytes() { return 10 * TileImg<D>::FLOATS * 4; }
+
 inline bool use_mfma(int d) { return d == 32 || d == 64; }     // wider rows: the fp32-VALU tile kernels
 
 inline bool infonce_d_ok(int d) { return d == 32 || d == 64 || d == 128 || d == 256; }
@@ -798,7 +1112,7 @@ int infonce_fwd_impl(const float* const* z1s, const float* z2, const int64_t* id
   float* ws = reinterpret_cast<float*>(workspace);
   hipStream_t s = as_stream(stream);
   const int nt = n_tiles(n);
-  const int rb = (int)((n + 15) / 16);
+  const int rb = 2 * nt;                    // 16 rows per block, whole tiles (pad rows are written as zeros)
   const int fb = (int)((n + kBlock - 1) / kBlock);
   if (!(phases & 1)) {                      // phase 2 alone: only the loss scalars from the row terms
     hipLaunchKernelGGL(finalize_loss_kernel, dim3(1, P), dim3(kBlock), 0, s, ws, L.total, L, fb, n, losses);
@@ -816,8 +1130,16 @@ int infonce_fwd_impl(const float* const* z1s, const float* z2, const int64_t* id
   MMSSL_LAUNCH_CHECK();
   const dim3 grid(nt * L.cs_f, P);
   if (use_mfma(d)) {
+#if MMSSL_INFONCE_LDS_TILES
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&fwd_tiles_lds_kernel<64>),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, fwd_tiles_lds_bytes<64>());
+    if (attr != hipSuccess) return (int)attr;
+    if (d == 32) hipLaunchKernelGGL((fwd_tiles_lds_kernel<32>), grid, dim3(kBlock), fwd_tiles_lds_bytes<32>(), s, ws, L.total, L, n, tau, L.cs_f);
+    else hipLaunchKernelGGL((fwd_tiles_lds_kernel<64>), grid, dim3(kBlock), fwd_tiles_lds_bytes<64>(), s, ws, L.total, L, n, tau, L.cs_f);
+#else
     if (d == 32) hipLaunchKernelGGL((fwd_tiles_mfma_kernel<32>), grid, dim3(kBlock), 0, s, ws, L.total, L, n, tau, L.cs_f);
     else hipLaunchKernelGGL((fwd_tiles_mfma_kernel<64>), grid, dim3(kBlock), 0, s, ws, L.total, L, n, tau, L.cs_f);
+#endif
   } else switch (d) {
     case 32: hipLaunchKernelGGL((fwd_tiles_kernel<32>), grid, dim3(kBlock), 0, s, ws, L.total, L, n, tau, L.cs_f); break;
     case 64: hipLaunchKernelGGL((fwd_tiles_kernel<64>), grid, dim3(kBlock), 0, s, ws, L.total, L, n, tau, L.cs_f); break;
@@ -836,7 +1158,7 @@ int infonce_fwd_impl(const float* const* z1s, const float* z2, const int64_t* id
 
 int infonce_bwd_impl(const int64_t* idx, int P, int64_t n, int d, float tau, const float* gloss,
                      float* const* gz1s, float* gz2, void* workspace, size_t workspace_bytes, void* stream,
-                     int phases = 3, const BprStepArgs* guest = nullptr, const BprStepArgs* assemble_guest = nullptr) {
+                     int phases = 3, const BprStepArgs* assemble_guest = nullptr) {
   if (P < 1 || P > kMaxProblems || n <= 0 || !gloss || !(tau > 0.f) || phases < 1 || phases > 3) return MMSSL_E_BADARG;
   if (!infonce_d_ok(d)) return MMSSL_E_UNSUPP;
   const Layout L = make_layout(n, d);
@@ -855,17 +1177,21 @@ int infonce_bwd_impl(const int64_t* idx, int P, int64_t n, int d, float tau, con
   hipStream_t s = as_stream(stream);
   const int nt = n_tiles(n);
   const dim3 grid(nt * L.cs_b, P);
-  if (guest && !((phases & 1) && use_mfma(d))) return MMSSL_E_UNSUPP;
   if ((phases & 1) && use_mfma(d)) {
+    const dim3 g2 = grid;
+#if MMSSL_INFONCE_LDS_TILES
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&bwd_tiles_lds_kernel<64>),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, bwd_tiles_lds_bytes<64>());
+    if (attr != hipSuccess) return (int)attr;
+    if (d == 32) hipLaunchKernelGGL((bwd_tiles_lds_kernel<32>), g2, dim3(kBlock), bwd_tiles_lds_bytes<32>(), s, ws, L.total, L, n, tau, L.cs_b);
+    else hipLaunchKernelGGL((bwd_tiles_lds_kernel<64>), g2, dim3(kBlock), bwd_tiles_lds_bytes<64>(), s, ws, L.total, L, n, tau, L.cs_b);
+#else
     const bool single = (nt + L.cs_b - 1) / L.cs_b <= 4;      // pair tiles per block <= waves per block
-    BprStepArgs G;
-    if (guest) G = *guest;
-    else G.n_blocks = 0;
-    const dim3 g2(nt * L.cs_b + (guest ? guest->n_blocks : 0), P);
-    if (d == 32 && single) hipLaunchKernelGGL((bwd_tiles_mfma_kernel<32, true>), g2, dim3(kBlock), 0, s, ws, L.total, L, n, tau, L.cs_b, G);
-    else if (d == 32) hipLaunchKernelGGL((bwd_tiles_mfma_kernel<32, false>), g2, dim3(kBlock), 0, s, ws, L.total, L, n, tau, L.cs_b, G);
-    else if (single) hipLaunchKernelGGL((bwd_tiles_mfma_kernel<64, true>), g2, dim3(kBlock), 0, s, ws, L.total, L, n, tau, L.cs_b, G);
-    else hipLaunchKernelGGL((bwd_tiles_mfma_kernel<64, false>), g2, dim3(kBlock), 0, s, ws, L.total, L, n, tau, L.cs_b, G);
+    if (d == 32 && single) hipLaunchKernelGGL((bwd_tiles_mfma_kernel<32, true>), g2, dim3(kBlock), 0, s, ws, L.total, L, n, tau, L.cs_b);
+    else if (d == 32) hipLaunchKernelGGL((bwd_tiles_mfma_kernel<32, false>), g2, dim3(kBlock), 0, s, ws, L.total, L, n, tau, L.cs_b);
+    else if (single) hipLaunchKernelGGL((bwd_tiles_mfma_kernel<64, true>), g2, dim3(kBlock), 0, s, ws, L.total, L, n, tau, L.cs_b);
+    else hipLaunchKernelGGL((bwd_tiles_mfma_kernel<64, false>), g2, dim3(kBlock), 0, s, ws, L.total, L, n, tau, L.cs_b);
+#endif
     MMSSL_LAUNCH_CHECK();
   } else if (phases & 1) {
     switch (d) {
@@ -956,30 +1282,12 @@ extern "C" int mmssl_infonce_multi_bwd_f32(const int64_t* idx, int n_problems, i
 
 extern "C" size_t mmssl_bpr_workspace_bytes(int64_t B);
 
-extern "C" int mmssl_infonce_bwd_tiles_bpr_f32(const int64_t* idx, int n_problems, int64_t n, int d, float tau,
-                                               const float* gloss, float* const* gz1s, float* gz2, void* workspace,
-                                               size_t workspace_bytes, const float* Eu, const float* Ei,
-                                               const int64_t* users, const int64_t* pos, const int64_t* neg, int64_t B,
-                                               float decay, int64_t batch_size, const float* g_mf, const float* g_emb,
-                                               float* gEu, float* gEi, float* terms, const float* w, int n_terms,
-                                               const float* extra, float c, float* total, float* const* f32_ticks,
-                                               int n_f32, uint64_t* const* u64_ticks, int n_u64, void* bpr_workspace,
-                                               size_t bpr_workspace_bytes, int* ticket, const float* extra_parts,
-                                               int64_t n_extra_parts, void* stream) {
-  if (!infonce_d_ok(d) || !use_mfma(d)) return MMSSL_E_UNSUPP;
-  BprStepArgs A;
-  const int rc = make_bpr_step_args(A, Eu, Ei, users, pos, neg, B, d, decay, batch_size, g_mf, g_emb, gEu, gEi, terms, w,
-                                    n_terms, extra, c, total, f32_ticks, n_f32, u64_ticks, n_u64, bpr_workspace,
-                                    bpr_workspace_bytes, mmssl_bpr_workspace_bytes(B), ticket, extra_parts, n_extra_parts);
-  if (rc != 0) return rc;
-  return infonce_bwd_impl(idx, n_problems, n, d, tau, gloss, gz1s, gz2, workspace, workspace_bytes, stream, 1, &A);
-}
-
 // ---- the hot step's loss chain with the BPR tail in two parts (d in {32, 64}) ---------------------------------------
-// As guest blocks of the backward PAIR TILES (mmssl_infonce_bwd_tiles_bpr_f32) the tail's B/16 blocks push that launch
-// past one round of resident blocks (512 pair-tile blocks fill the chip at two blocks per CU: the last 64 wait for a
-// slot). Here the ROWS part rides in the short prep launch and the one-block ASSEMBLY part in the backward finish: same
-// arithmetic, same bits; measured pair tiles 34.7 -> 29.4 us, prep 5.7 -> 8.4 us (profiles/r03/step_timeline_bpr_two_parts.txt).
+// As guest blocks of the backward PAIR TILES (an earlier form) the tail's B/16 blocks pushed that launch past one round
+// of resident blocks (512 pair-tile blocks fill the chip at two blocks per CU: the last 64 wait for a slot), and a
+// guest's static LDS would cost the pair tiles their second block per CU. Here the ROWS part rides in the short prep
+// launch and the one-block ASSEMBLY part in the backward finish: same arithmetic, same bits; measured pair tiles
+// 34.7 -> 29.4 us, prep 5.7 -> 8.4 us (profiles/r03/step_timeline_bpr_two_parts.txt).
 extern "C" int mmssl_infonce_multi_fwd_ticket_bpr_f32(const float* const* z1s, const float* z2, const int64_t* idx,
                                                       int n_problems, int64_t n, int d, float tau, float* losses,
                                                       void* workspace, size_t workspace_bytes, int* tickets,
@@ -1021,7 +1329,7 @@ extern "C" int mmssl_infonce_multi_bwd_finish_bpr_f32(const int64_t* idx, int n_
                                     bpr_workspace_bytes, mmssl_bpr_workspace_bytes(B), &dummy_ticket, extra_parts,
                                     n_extra_parts);
   if (rc != 0) return rc;
-  return infonce_bwd_impl(idx, n_problems, n, d, tau, gloss, gz1s, gz2, workspace, workspace_bytes, stream, 2, nullptr, &A);
+  return infonce_bwd_impl(idx, n_problems, n, d, tau, gloss, gz1s, gz2, workspace, workspace_bytes, stream, 2, &A);
 }
 
 extern "C" int mmssl_infonce_multi_bwd_phase_f32(const int64_t* idx, int n_problems, int64_t n, int d, float tau,

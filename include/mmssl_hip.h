@@ -461,7 +461,12 @@ int mmssl_infonce_multi_bwd_f32(const int64_t* idx, int n_problems, int64_t n, i
  * + that block. Between them the backward pair tiles run WITHOUT guests (mmssl_infonce_multi_bwd_phase_f32, phase 1):
  * 512 pair-tile blocks fill the chip exactly once at two blocks per CU, B/16 guests behind them open a second round
  * (measured: pair tiles 34.7 -> 29.4 us, prep 5.7 -> 8.4 us, the chain 3 us shorter). gEu / gEi must be zero-filled
- * before the first of the three calls. */
+ * before the first of the three calls.
+ * ROW TERMS ARE DEFERRED in this chain: mmssl_infonce_multi_fwd_ticket_bpr_f32 stops after the forward pair tiles (it
+ * does not write `losses`, `tickets` is unused), the backward pair tiles compute the per-row coefficients from the
+ * partial denominators on the fly (the row-terms launch, 8 us in the step for a few hundred flops per row, is gone) and
+ * mmssl_infonce_multi_bwd_finish_bpr_f32 writes the n_problems InfoNCE losses to `losses` - which may alias entries of
+ * `terms`: they are written before the assembly reads them. The three calls belong together, in this order. */
 int mmssl_infonce_multi_fwd_ticket_bpr_f32(const float* const* z1s, const float* z2, const int64_t* idx, int n_problems,
                                            int64_t n, int d, float tau, float* losses, void* workspace,
                                            size_t workspace_bytes, int* tickets, const float* Eu, const float* Ei,
@@ -470,7 +475,7 @@ int mmssl_infonce_multi_fwd_ticket_bpr_f32(const float* const* z1s, const float*
                                            float* gEu, float* gEi, void* bpr_workspace, size_t bpr_workspace_bytes,
                                            void* stream);
 int mmssl_infonce_multi_bwd_finish_bpr_f32(const int64_t* idx, int n_problems, int64_t n, int d, float tau,
-                                           const float* gloss, float* const* gz1s, float* gz2, void* workspace,
+                                           const float* gloss, float* losses, float* const* gz1s, float* gz2, void* workspace,
                                            size_t workspace_bytes, const float* Eu, const float* Ei, const int64_t* users,
                                            const int64_t* pos, const int64_t* neg, int64_t B, float decay,
                                            int64_t batch_size, const float* g_mf, const float* g_emb, float* gEu,

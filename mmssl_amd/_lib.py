@@ -151,7 +151,7 @@ SIGNATURES = {
                                                        c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p,
                                                        c_void_p, c_void_p, c_void_p, c_int64, c_float, c_int64, c_void_p,
                                                        c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
-    "mmssl_infonce_multi_bwd_finish_bpr_f32": (c_int, [c_void_p, c_int, c_int64, c_int, c_float, c_void_p, c_void_p,
+    "mmssl_infonce_multi_bwd_finish_bpr_f32": (c_int, [c_void_p, c_int, c_int64, c_int, c_float, c_void_p, c_void_p, c_void_p,
                                                        c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p,
                                                        c_void_p, c_void_p, c_int64, c_float, c_int64, c_void_p, c_void_p,
                                                        c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_float,

@@ -26,9 +26,6 @@ using namespace mmssl;
 
 namespace {
 
-#ifndef MMSSL_INFONCE_LDS_TILES
-#define MMSSL_INFONCE_LDS_TILES 1   // 0: the tile kernels with fragment-shaped global loads (A/B builds only)
-#endif
 constexpr int T = 32;        // tile edge (rows and columns)
 constexpr float kNormEps = 1e-12f;
 constexpr int CP = T + 4;    // padded row length of a coefficient tile
@@ -50,7 +47,7 @@ constexpr int kFwdTilesPerBlock = 8;
 constexpr int kBwdTilesPerBlock = 4;
 
 struct Layout {   // offsets in floats into the workspace
-  size_t n1, n2, inv1, inv2, pos, w, c, rows_part, loss, g1p, g2p, total;
+  size_t n1, n2, inv1, inv2, pos, w, c, rows_part, loss, meta, g1p, g2p, total;
   int cs_f, cs_b;
 };
 
@@ -73,7 +70,8 @@ inline Layout make_layout(int64_t n, int d) {
   L.n2 = take((size_t)nt * T * d);
   L.inv1 = take(n); L.inv2 = take(n); L.pos = take(n); L.w = take(n); L.c = take((size_t)nt * T);
   L.rows_part = take((size_t)L.cs_f * n);
-  L.loss = take((size_t)(n + kBlock - 1) / kBlock + 4);
+  L.loss = take((size_t)nt + 4);      // loss partials: per 256-row block (finalize_rows) or per row tile (deferred row terms)
+  L.meta = take(4);                   // [0] the constant inside the logarithm, [1] != 0: row terms deferred to the backward
   L.g1p = take((size_t)L.cs_b * n * d);
   L.g2p = take((size_t)L.cs_b * n * d);
   L.total = o;
@@ -94,7 +92,7 @@ struct Z1Ptrs {          // per-problem first operand (forward) / its gradient (
 __global__ __launch_bounds__(kBlock) void prep_kernel(Z1Ptrs Z, const float* __restrict__ z2,
                                                       const int64_t* __restrict__ idx, int64_t n, int d,
                                                       float* __restrict__ ws, size_t ws_stride, Layout L,
-                                                      int prep_blocks, BprStepArgs bpr) {
+                                                      int prep_blocks, float log_eps, int defer_rows, BprStepArgs bpr) {
   if ((int)blockIdx.x >= prep_blocks) {
     if (blockIdx.y == 0) {
       if (d == 64) bpr_rows_block<16>(bpr, (int)blockIdx.x - prep_blocks);
@@ -104,6 +102,10 @@ __global__ __launch_bounds__(kBlock) void prep_kernel(Z1Ptrs Z, const float* __r
   }
   const float* __restrict__ z1 = Z.z1[blockIdx.y];
   float* __restrict__ wsp = ws + (size_t)blockIdx.y * ws_stride;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    wsp[L.meta] = log_eps;
+    wsp[L.meta + 1] = defer_rows ? 1.f : 0.f;
+  }
   float* __restrict__ n1 = wsp + L.n1;
   float* __restrict__ n2 = wsp + L.n2;
   float* __restrict__ inv1 = wsp + L.inv1;
@@ -234,6 +236,27 @@ __global__ __launch_bounds__(kBlock) void fwd_tiles_kernel(const float* __restri
   }
 }
 
+// Row terms of row i from the forward's partial denominators: loss term li, w_i = dL/dlog-ratio / n, c_i = w_i / (D_i tau)
+// (returned). One arithmetic for finalize_rows_kernel and for the backward tiles that compute it on the fly.
+__device__ __forceinline__ float row_terms(const float* __restrict__ rows_part, const float* __restrict__ pos, int cs,
+                                           int64_t n, int64_t i, float tau, float log_eps, float& wi, float& li) {
+  const float ps = pos[i];
+  float Dn = 0.f;
+  int s = 0;
+  for (; s + 8 <= cs; s += 8) {          // eight partials per L2 round trip; the adds stay in the order s = 0, 1, ...
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = rows_part[(size_t)(s + e) * n + i];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) Dn += v[e];
+  }
+  for (; s < cs; ++s) Dn += rows_part[(size_t)s * n + i];
+  const float q = expf(ps / tau) / Dn;
+  li = -logf(q + log_eps);
+  wi = -(q / (q + log_eps)) / (float)n;
+  return wi / (Dn * tau);
+}
+
 // ---- finalize: per-row backward coefficients (row-parallel) + loss (fixed-order two-stage sum) ----
 // `tickets` (one int per problem, 0 on entry, left 0) != NULL: the last block of a problem to arrive also reduces the
 // row terms to the loss (the arithmetic of finalize_loss_kernel), which then is not launched.
@@ -250,13 +273,9 @@ __global__ __launch_bounds__(kBlock) void finalize_rows_kernel(float* __restrict
   const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   float li = 0.f;
   if (i < n) {
-    float Dn = 0.f;
-    for (int s = 0; s < cs; ++s) Dn += rows_part[(size_t)s * n + i];
-    const float q = expf(pos[i] / tau) / Dn;
-    li = -logf(q + log_eps);
-    const float wi = -(q / (q + log_eps)) / (float)n;
+    float wi;
+    c[i] = row_terms(rows_part, pos, cs, n, i, tau, log_eps, wi, li);
     w[i] = wi;
-    c[i] = wi / (Dn * tau);
   }
   const float t = block_sum_256(li, red);
   if (tickets == nullptr) {
@@ -420,10 +439,22 @@ __global__ __launch_bounds__(kBlock) void bwd_finish_kernel(const float* __restr
                                                             int64_t n, int d, float tau,
                                                             const float* __restrict__ gloss, Z1Ptrs Z,
                                                             float* __restrict__ gz2, int finish_blocks,
-                                                            BprStepArgs bpr) {
+                                                            float* __restrict__ losses, BprStepArgs bpr) {
   // Guest block (the one behind the finish blocks): the ASSEMBLY part of the hot step's BPR tail - the rows part ran
-  // as guests of the prep launch, the InfoNCE loss values were written by the row-terms launch: BPR loss, total, ticks.
+  // as guests of the prep launch. With deferred row terms (losses != NULL) the InfoNCE losses are reduced here first,
+  // from the per-row-tile partials the backward tiles left (fixed order: a block-wide tree over the tiles); thread 0
+  // writes them and thread 0 reads them back as terms of the assembly.
   if ((int)blockIdx.x >= finish_blocks) {
+    if (losses) {
+      __shared__ float red[4];
+      for (int p = 0; p < P; ++p) {
+        const float* __restrict__ part = ws + (size_t)p * ws_stride + L.loss;
+        float acc = 0.f;
+        for (int k = threadIdx.x; k < n_tiles(n); k += kBlock) acc += part[k];
+        const float tt = block_sum_256(acc, red);
+        if (threadIdx.x == 0) losses[p] = tt / (float)n;
+      }
+    }
     bpr_assemble_block(bpr);
     return;
   }
@@ -455,7 +486,23 @@ __global__ __launch_bounds__(kBlock) void bwd_finish_kernel(const float* __restr
         b[t] = reinterpret_cast<const float4*>(n2 + r * d)[k];
         float4 uu = make_float4(wt * b[t].x, wt * b[t].y, wt * b[t].z, wt * b[t].w);
         float4 vv = make_float4(wt * a[t].x, wt * a[t].y, wt * a[t].z, wt * a[t].w);
-        for (int s = 0; s < cs; ++s) {
+        // split partials: eight at a time, all sixteen loads in flight before the first add (one L2 round trip
+        // per group instead of one per split; the order of the adds stays s = 0, 1, ...)
+        int s = 0;
+        for (; s + 8 <= cs; s += 8) {
+          float4 x[8], y[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            x[e] = reinterpret_cast<const float4*>(g1p + ((size_t)(s + e) * n + r) * d)[k];
+            y[e] = reinterpret_cast<const float4*>(g2p + ((size_t)(s + e) * n + r) * d)[k];
+          }
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            uu.x += x[e].x; uu.y += x[e].y; uu.z += x[e].z; uu.w += x[e].w;
+            vv.x += y[e].x; vv.y += y[e].y; vv.z += y[e].z; vv.w += y[e].w;
+          }
+        }
+        for (; s < cs; ++s) {
           const float4 x = reinterpret_cast<const float4*>(g1p + ((size_t)s * n + r) * d)[k];
           const float4 y = reinterpret_cast<const float4*>(g2p + ((size_t)s * n + r) * d)[k];
           uu.x += x.x; uu.y += x.y; uu.z += x.z; uu.w += x.w;
@@ -503,287 +550,23 @@ __global__ __launch_bounds__(kBlock) void bwd_finish_kernel(const float* __restr
 // MFMA tile kernels (D in {32, 64}): the n x n similarity tiles and, in the backward, the
 // coefficient-tile x embedding products are fp32 matrix-core work (v_mfma_f32_32x32x2_f32).
 //
-// Both operands of a similarity tile S = X_t . Y_s^T are [rows, D] row-major with D contiguous, so
-// a wave loads them STRAIGHT from global (L2-resident, <= 256 KB per matrix) into MFMA fragment
-// layout: lane l owns row (l & 31) and the D/2 features [h*D/2, (h+1)*D/2), h = l >> 5, as D/8
-// float4 loads; MFMA step s then contracts features {s, D/2 + s} (any pairing of k indices is valid
-// as long as A and B agree). No LDS staging, no barriers in the tile loop.
+// MFMA fragment layout of a [rows, D] row-major operand: lane l owns row (l & 31) and the D/2 features
+// [h*D/2, (h+1)*D/2), h = l >> 5; MFMA step s then contracts features {s, D/2 + s} (any pairing of k indices is valid
+// as long as A and B agree). Loading that shape straight from global (16 B per lane, 64 cache lines per instruction:
+// the first form of these kernels) kept the CU's L1 busy for longer than the tile's MFMAs take - backward tiles 29.3 us,
+// forward rows 19.9 us against 20.1 / 17.0 us with the LDS tile images below (n = 1024, two problems).
 //
 // C/D layout of the 32x32 MFMA: lane l holds C[(r & 3) + 8 (r >> 2) + 4 h][l & 31], r = 0..15.
 // =================================================================================================
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 
-template <int D>
-__device__ __forceinline__ void load_frag(const float* __restrict__ src, int64_t row, int64_t n, int h,
-                                          float (&f)[D / 2]) {
-  if (row < n) {
-    const float4* p = reinterpret_cast<const float4*>(src + row * D + h * (D / 2));
-#pragma unroll
-    for (int q = 0; q < D / 8; ++q) {
-      const float4 v = p[q];
-      f[4 * q] = v.x; f[4 * q + 1] = v.y; f[4 * q + 2] = v.z; f[4 * q + 3] = v.w;
-    }
-  } else {
-#pragma unroll
-    for (int q = 0; q < D / 2; ++q) f[q] = 0.f;
-  }
-}
-
 // e^x for the similarity logits (|x| <= 1/tau: cosines): v_exp_f32 on x*log2(e), ~1 ulp; the full-range
 // expf costs as many VALU cycles per tile as the MFMAs that produced it.
 __device__ __forceinline__ float fast_exp(float x) { return __expf(x); }
 
-template <int D>
-__device__ __forceinline__ floatx16 sim_tile(const float (&a)[D / 2], const float (&b)[D / 2]) {
-  floatx16 acc;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-#pragma unroll
-  for (int s = 0; s < D / 2; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b[s], acc, 0, 0, 0);
-  return acc;
-}
-
-
-// ---- forward: partial denominators per (row, block split); the 4 waves of a block share a row tile,
-// take column tiles round-robin and reduce their row sums through LDS in a fixed order.
-template <int D>
-__global__ __launch_bounds__(kBlock) void fwd_tiles_mfma_kernel(const float* __restrict__ ws, size_t ws_stride,
-                                                                Layout L, int64_t n, float tau, int cs) {
-  const float* __restrict__ wsp = ws + (size_t)blockIdx.y * ws_stride;
-  const float* __restrict__ n1 = wsp + L.n1;
-  const float* __restrict__ n2 = wsp + L.n2;
-  float* __restrict__ rows_part = const_cast<float*>(wsp) + L.rows_part;
-  __shared__ float red[4][T];
-  const int nt = n_tiles(n);
-  const int ti = blockIdx.x % nt;
-  const int split = blockIdx.x / nt;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int h = lane >> 5, lr = lane & 31;
-  const int64_t i0 = (int64_t)ti * T;
-  float a[D / 2];
-  load_frag<D>(n1, i0 + lr, n, h, a);
-  const int per = (2 * nt + cs - 1) / cs;
-  const int c_beg = split * per, c_end = min(2 * nt, c_beg + per);
-  const float inv_tau = 1.f / tau;
-  float rowacc[16];
-#pragma unroll
-  for (int r = 0; r < 16; ++r) rowacc[r] = 0.f;
-  // two column tiles per trip: both B fragments are requested before the first MFMA so that the second
-  // load and the exponentials of the first tile hide behind matrix-core work
-  auto tile_src = [&](int ct, const float*& src, int64_t& j0, bool& refl) {
-    refl = ct < nt;
-    src = refl ? n1 : n2;
-    j0 = (int64_t)(refl ? ct : ct - nt) * T;
-  };
-  auto accumulate = [&](const floatx16& acc, int64_t j0, bool refl) {
-    const int64_t col = j0 + lr;
-    const bool vcol = col < n;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int64_t row = i0 + (r & 3) + 8 * (r >> 2) + 4 * h;
-      const float e = fast_exp(acc[r] * inv_tau);
-      rowacc[r] += (vcol && !(refl && col == row)) ? e : 0.f;
-    }
-  };
-  for (int ct = c_beg + wave; ct < c_end; ct += 8) {
-    const float* src0; const float* src1;
-    int64_t j0, j1;
-    bool refl0, refl1;
-    tile_src(ct, src0, j0, refl0);
-    const bool two = ct + 4 < c_end;
-    tile_src(two ? ct + 4 : ct, src1, j1, refl1);
-    float b0[D / 2], b1[D / 2];
-    load_frag<D>(src0, j0 + lr, n, h, b0);
-    if (two) load_frag<D>(src1, j1 + lr, n, h, b1);
-    const floatx16 acc0 = sim_tile<D>(a, b0);
-    if (two) {                          // wave-uniform
-      const floatx16 acc1 = sim_tile<D>(a, b1);
-      accumulate(acc0, j0, refl0);
-      accumulate(acc1, j1, refl1);
-    } else {
-      accumulate(acc0, j0, refl0);
-    }
-  }
-  // sum over the 32 lanes (columns) that share h; lane lr == 0 of each half then owns 16 rows
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    float v = rowacc[r];
-#pragma unroll
-    for (int m = 1; m < 32; m <<= 1) v += __shfl_xor(v, m, kWave);
-    rowacc[r] = v;
-  }
-  if (lr == 0) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) red[wave][(r & 3) + 8 * (r >> 2) + 4 * h] = rowacc[r];
-  }
-  __syncthreads();
-  if (threadIdx.x < T) {
-    const int64_t gi = i0 + threadIdx.x;
-    if (gi < n)
-      rows_part[(size_t)split * n + gi] =
-          ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
-  }
-}
-
-// ---- backward pair tiles. Per (t, s) tile pair and wave:
-//   S12 = n1_t.n2_s^T, S11 = n1_t.n1_s^T, S21 = n2_t.n1_s^T            (3 x D/2 MFMAs)
-//   C1 = -c_t e^{S12/tau}, C2 = -(c_t+c_s) e^{S11/tau} [t != s], C3 = -c_s e^{S21/tau}
-//   g1_t += C1 . n2_s + C2 . n1_s ;  g2_t += C3 . n1_s                 (3 x 16 x D/32 MFMAs)
-// The coefficient tiles go accumulator layout -> LDS ([32][33], private to the wave) -> A operand;
-// the embedding rows of tile s are read again from L2 in B-operand layout (row 2k + h, 32
-// consecutive features per half-wave: coalesced). The 4 waves of a block share t, take s tiles
-// round-robin and add their g1/g2 tiles in a fixed order through LDS before one store per block.
-template <int D, bool SINGLE>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2))) void bwd_tiles_mfma_kernel(float* __restrict__ ws, size_t ws_stride, Layout L,
-                                                                int64_t n, float tau, int cs) {
-  float* __restrict__ wsp = ws + (size_t)blockIdx.y * ws_stride;
-  const float* __restrict__ n1 = wsp + L.n1;
-  const float* __restrict__ n2 = wsp + L.n2;
-  const float* __restrict__ c = wsp + L.c;
-  float* __restrict__ g1p = wsp + L.g1p;
-  float* __restrict__ g2p = wsp + L.g2p;
-  constexpr int FT = D / 32;                 // 32-wide feature tiles of the gradient
-  constexpr int CS = T + 1;                  // coefficient tile row stride (conflict-free A-operand reads)
-  constexpr int CW = 3 * T * CS;             // floats of coefficient tiles per wave
-  __shared__ float lds[4 * CW];
-  static_assert(3 * 2 * T * D <= 4 * CW, "reduction buffers of waves 1..3 must fit the coefficient region");
-  const int nt = n_tiles(n);
-  const int tt = blockIdx.x % nt;
-  const int split = blockIdx.x / nt;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int h = lane >> 5, lr = lane & 31;
-  const int64_t t0 = (int64_t)tt * T;
-  float* __restrict__ C1 = lds + wave * CW;
-  float* __restrict__ C2 = C1 + T * CS;
-  float* __restrict__ C3 = C2 + T * CS;
-  float a1[D / 2], a2[D / 2];
-  load_frag<D>(n1, t0 + lr, n, h, a1);
-  load_frag<D>(n2, t0 + lr, n, h, a2);
-  float ct[16];
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int64_t gt = t0 + (r & 3) + 8 * (r >> 2) + 4 * h;
-    ct[r] = gt < n ? c[gt] : 0.f;
-  }
-  floatx16 g1[FT], g2[FT];
-#pragma unroll
-  for (int f = 0; f < FT; ++f)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) g1[f][r] = g2[f][r] = 0.f;
-  const float inv_tau = 1.f / tau;
-  const int per = (nt + cs - 1) / cs;
-  const int s_beg = split * per, s_end = min(nt, s_beg + per);
-  auto pair = [&](int st) {
-    const int64_t s0 = (int64_t)st * T;
-    const int64_t gs = s0 + lr;
-    const bool vs = gs < n;
-    const float cs_ = vs ? c[gs] : 0.f;
-    // every global load of the pair's first half is requested before the first MFMA
-    float b2[D / 2], b1[D / 2];
-    load_frag<D>(n2, gs, n, h, b2);
-    load_frag<D>(n1, gs, n, h, b1);
-    const floatx16 s12 = sim_tile<D>(a1, b2);
-    const floatx16 s11 = sim_tile<D>(a1, b1);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
-      const bool v = vs && (t0 + row) < n;
-      C1[row * CS + lr] = v ? -ct[r] * fast_exp(s12[r] * inv_tau) : 0.f;
-    }
-    const floatx16 s21 = sim_tile<D>(a2, b1);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
-      const bool v = vs && (t0 + row) < n;
-      C2[row * CS + lr] = (v && (t0 + row) != gs) ? -(ct[r] + cs_) * fast_exp(s11[r] * inv_tau) : 0.f;
-    }
-    // second-stage B operands (k = s index: step ks contracts rows {2 ks, 2 ks + 1} of tile s)
-    float q2[T / 2][FT], q1[T / 2][FT];
-#pragma unroll
-    for (int ks = 0; ks < T / 2; ++ks) {
-      const int64_t row = s0 + 2 * ks + h;
-#pragma unroll
-      for (int f = 0; f < FT; ++f) q2[ks][f] = row < n ? n2[row * D + 32 * f + lr] : 0.f;
-    }
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
-      const bool v = vs && (t0 + row) < n;
-      C3[row * CS + lr] = v ? -cs_ * fast_exp(s21[r] * inv_tau) : 0.f;
-    }
-#pragma unroll
-    for (int ks = 0; ks < T / 2; ++ks) {
-      const int64_t row = s0 + 2 * ks + h;
-#pragma unroll
-      for (int f = 0; f < FT; ++f) q1[ks][f] = row < n ? n1[row * D + 32 * f + lr] : 0.f;
-    }
-    // the coefficient tiles were written by this wave and are read by this wave only
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll
-    for (int ks = 0; ks < T / 2; ++ks) {
-      const float x = C1[lr * CS + 2 * ks + h];
-#pragma unroll
-      for (int f = 0; f < FT; ++f) g1[f] = __builtin_amdgcn_mfma_f32_32x32x2f32(x, q2[ks][f], g1[f], 0, 0, 0);
-    }
-#pragma unroll
-    for (int ks = 0; ks < T / 2; ++ks) {
-      const float x = C2[lr * CS + 2 * ks + h];
-      const float y = C3[lr * CS + 2 * ks + h];
-#pragma unroll
-      for (int f = 0; f < FT; ++f) {
-        g1[f] = __builtin_amdgcn_mfma_f32_32x32x2f32(x, q1[ks][f], g1[f], 0, 0, 0);
-        g2[f] = __builtin_amdgcn_mfma_f32_32x32x2f32(y, q1[ks][f], g2[f], 0, 0, 0);
-      }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();      // all lanes done reading before a next pair overwrites C*
-  };
-  if (SINGLE) {          // at most one pair per wave: a1/a2/ct die after the first half of the pair
-    if (s_beg + wave < s_end) pair(s_beg + wave);
-  } else {
-    for (int st = s_beg + wave; st < s_end; st += 4) pair(st);
-  }
-  // block reduction: waves 1..3 park their tiles in LDS, wave 0 adds them in the order 1, 2, 3
-  __syncthreads();
-  constexpr int GW = 2 * T * D;           // floats per wave: g1 then g2, [row][feature]
-  if (wave > 0) {
-    float* dst = lds + (wave - 1) * GW;
-#pragma unroll
-    for (int f = 0; f < FT; ++f)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
-        dst[row * D + 32 * f + lr] = g1[f][r];
-        dst[T * D + row * D + 32 * f + lr] = g2[f][r];
-      }
-  }
-  __syncthreads();
-  if (wave == 0) {
-    const size_t base = (size_t)split * n * D;
-#pragma unroll
-    for (int f = 0; f < FT; ++f)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
-        const int o = row * D + 32 * f + lr;
-        const float v1 = ((g1[f][r] + lds[o]) + lds[GW + o]) + lds[2 * GW + o];
-        const float v2 = ((g2[f][r] + lds[T * D + o]) + lds[GW + T * D + o]) + lds[2 * GW + T * D + o];
-        const int64_t gt = t0 + row;
-        if (gt < n) {
-          g1p[base + gt * D + 32 * f + lr] = v1;
-          g2p[base + gt * D + 32 * f + lr] = v2;
-        }
-      }
-  }
-}
-
 // ---- tile images in LDS (D in {32, 64}) -----------------------------------------------------------------------------
-// A 32 x D tile of a row-major [rows, D] matrix is 32 D contiguous floats. Fragment-shaped loads straight from global
-// (lane = row, 16 B per lane: 64 cache lines per instruction) keep the CU's L1 busy for longer than the tile's MFMAs
-// take, so the tile goes to LDS in whole lines by LDS-DMA (1 KB per wave instruction, lane-linear destination) and the
-// fragments come from there. Image layout: row r at r * D floats, its 16-byte slots XOR-swizzled with the row number so
+// A 32 x D tile of a row-major [rows, D] matrix is 32 D contiguous floats: it goes to LDS in whole lines by LDS-DMA
+// (1 KB per wave instruction, lane-linear destination) and the fragments come from there. Image layout: row r at r * D floats, its 16-byte slots XOR-swizzled with the row number so
 // that ds_read_b128 with lane = row is conflict-free (its 16-lane groups hold rows distinct mod 16); the swizzle goes
 // on the SOURCE address of the DMA.
 template <int D>
@@ -972,7 +755,35 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2))) voi
     Img::stage(n1 + (int64_t)st * T * D, s_lds, lane);
   }
   const bool vi = t0 + lr < n;
-  const float ct = vi ? c[t0 + lr] : 0.f;
+  // Row terms deferred by the forward chain (meta[1]): c comes from the partial denominators right here - the
+  // arithmetic of finalize_rows_kernel, which then was not launched - and the split-0 block of a row tile also leaves
+  // w / c (for the finish) and the tile's loss partial.
+  const bool defer = wsp[L.meta + 1] != 0.f;
+  const float log_eps = wsp[L.meta];
+  const float* __restrict__ rows_part = wsp + L.rows_part;
+  const float* __restrict__ pos = wsp + L.pos;
+  float ct = 0.f;
+  if (defer) {
+    float wi = 0.f, li = 0.f;
+    if (vi) ct = row_terms(rows_part, pos, L.cs_f, n, t0 + lr, tau, log_eps, wi, li);
+    if (split == 0 && wave == 0) {
+      if (vi && h == 0) {
+        wsp[L.w + t0 + lr] = wi;
+        wsp[L.c + t0 + lr] = ct;
+      }
+      li = group_sum<32>(li);                  // both half-waves hold the same 32 rows
+      if (lane == 0) wsp[L.loss + tt] = li;
+    }
+  } else if (vi) {
+    ct = c[t0 + lr];
+  }
+  // deferred: c of row (s tile's first row + lr) for the coming trip, requested together with that trip's images
+  auto s_terms = [&](int st_) {
+    const int64_t i = (int64_t)st_ * T + lr;
+    float wi, li;
+    return i < n ? row_terms(rows_part, pos, L.cs_f, n, i, tau, log_eps, wi, li) : 0.f;
+  };
+  float cl_next = (defer && st < s_end) ? s_terms(st) : 0.f;
   floatx16 g1[FT], g2[FT];
 #pragma unroll
   for (int f = 0; f < FT; ++f)
@@ -988,11 +799,16 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2))) voi
     const int nj = (int)(n - s0 < T ? n - s0 : T);
     const int dj = tt == st ? lr : -1;             // the column that is this lane's own row (S11's diagonal)
     float cs_[16];
+    if (defer) {                                   // wave-uniform
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int j = (r & 3) + 8 * (r >> 2) + 4 * h;
-      const float v = c[s0 + j];
-      cs_[r] = j < nj ? v : 0.f;
+      for (int r = 0; r < 16; ++r) cs_[r] = __shfl(cl_next, (r & 3) + 8 * (r >> 2) + 4 * h, kWave);     // 0 past n
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int j = (r & 3) + 8 * (r >> 2) + 4 * h;
+        const float v = c[s0 + j];
+        cs_[r] = j < nj ? v : 0.f;
+      }
     }
     floatx16 s12, s11, s21;
 #pragma unroll
@@ -1047,6 +863,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2))) voi
       __builtin_amdgcn_wave_barrier();
       Img::stage(n2 + (int64_t)(st + 4) * T * D, s_lds + (unsigned)TF * 4u, lane);
       Img::stage(n1 + (int64_t)(st + 4) * T * D, s_lds, lane);
+      if (defer) cl_next = s_terms(st + 4);
       vm_wait_n<0>();
     }
   }
@@ -1097,7 +914,8 @@ namespace {
 
 int infonce_fwd_impl(const float* const* z1s, const float* z2, const int64_t* idx, int P, int64_t n, int d,
                      float tau, float* losses, void* workspace, size_t workspace_bytes, void* stream,
-                     float log_eps = 1e-8f, int phases = 3, int* tickets = nullptr, const BprStepArgs* rows_guest = nullptr) {
+                     float log_eps = 1e-8f, int phases = 3, int* tickets = nullptr, const BprStepArgs* rows_guest = nullptr,
+                     bool defer_rows = false) {
   if (P < 1 || P > kMaxProblems || n <= 0 || !z1s || !z2 || !losses || !(tau > 0.f)) return MMSSL_E_BADARG;
   if (!infonce_d_ok(d)) return MMSSL_E_UNSUPP;
   const Layout L = make_layout(n, d);
@@ -1126,20 +944,17 @@ int infonce_fwd_impl(const float* const* z1s, const float* z2, const int64_t* id
   } else {
     G.n_blocks = 0;
   }
-  hipLaunchKernelGGL(prep_kernel, dim3(rb + G.n_blocks, P), dim3(kBlock), 0, s, Z, z2, idx, n, d, ws, L.total, L, rb, G);
+  if (defer_rows && !use_mfma(d)) return MMSSL_E_UNSUPP;
+  hipLaunchKernelGGL(prep_kernel, dim3(rb + G.n_blocks, P), dim3(kBlock), 0, s, Z, z2, idx, n, d, ws, L.total, L, rb, log_eps,
+                     defer_rows ? 1 : 0, G);
   MMSSL_LAUNCH_CHECK();
   const dim3 grid(nt * L.cs_f, P);
   if (use_mfma(d)) {
-#if MMSSL_INFONCE_LDS_TILES
     static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&fwd_tiles_lds_kernel<64>),
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, fwd_tiles_lds_bytes<64>());
     if (attr != hipSuccess) return (int)attr;
     if (d == 32) hipLaunchKernelGGL((fwd_tiles_lds_kernel<32>), grid, dim3(kBlock), fwd_tiles_lds_bytes<32>(), s, ws, L.total, L, n, tau, L.cs_f);
     else hipLaunchKernelGGL((fwd_tiles_lds_kernel<64>), grid, dim3(kBlock), fwd_tiles_lds_bytes<64>(), s, ws, L.total, L, n, tau, L.cs_f);
-#else
-    if (d == 32) hipLaunchKernelGGL((fwd_tiles_mfma_kernel<32>), grid, dim3(kBlock), 0, s, ws, L.total, L, n, tau, L.cs_f);
-    else hipLaunchKernelGGL((fwd_tiles_mfma_kernel<64>), grid, dim3(kBlock), 0, s, ws, L.total, L, n, tau, L.cs_f);
-#endif
   } else switch (d) {
     case 32: hipLaunchKernelGGL((fwd_tiles_kernel<32>), grid, dim3(kBlock), 0, s, ws, L.total, L, n, tau, L.cs_f); break;
     case 64: hipLaunchKernelGGL((fwd_tiles_kernel<64>), grid, dim3(kBlock), 0, s, ws, L.total, L, n, tau, L.cs_f); break;
@@ -1147,6 +962,7 @@ int infonce_fwd_impl(const float* const* z1s, const float* z2, const int64_t* id
     case 256: hipLaunchKernelGGL((fwd_tiles_kernel<256>), grid, dim3(kBlock), 0, s, ws, L.total, L, n, tau, L.cs_f); break;
   }
   MMSSL_LAUNCH_CHECK();
+  if (defer_rows) return 0;                 // row terms and losses: left to the backward tiles / finish
   hipLaunchKernelGGL(finalize_rows_kernel, dim3(fb, P), dim3(kBlock), 0, s, ws, L.total, L, L.cs_f, n, tau, log_eps,
                      tickets, losses);
   MMSSL_LAUNCH_CHECK();
@@ -1158,7 +974,7 @@ int infonce_fwd_impl(const float* const* z1s, const float* z2, const int64_t* id
 
 int infonce_bwd_impl(const int64_t* idx, int P, int64_t n, int d, float tau, const float* gloss,
                      float* const* gz1s, float* gz2, void* workspace, size_t workspace_bytes, void* stream,
-                     int phases = 3, const BprStepArgs* assemble_guest = nullptr) {
+                     int phases = 3, const BprStepArgs* assemble_guest = nullptr, float* deferred_losses = nullptr) {
   if (P < 1 || P > kMaxProblems || n <= 0 || !gloss || !(tau > 0.f) || phases < 1 || phases > 3) return MMSSL_E_BADARG;
   if (!infonce_d_ok(d)) return MMSSL_E_UNSUPP;
   const Layout L = make_layout(n, d);
@@ -1179,19 +995,11 @@ int infonce_bwd_impl(const int64_t* idx, int P, int64_t n, int d, float tau, con
   const dim3 grid(nt * L.cs_b, P);
   if ((phases & 1) && use_mfma(d)) {
     const dim3 g2 = grid;
-#if MMSSL_INFONCE_LDS_TILES
     static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&bwd_tiles_lds_kernel<64>),
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, bwd_tiles_lds_bytes<64>());
     if (attr != hipSuccess) return (int)attr;
     if (d == 32) hipLaunchKernelGGL((bwd_tiles_lds_kernel<32>), g2, dim3(kBlock), bwd_tiles_lds_bytes<32>(), s, ws, L.total, L, n, tau, L.cs_b);
     else hipLaunchKernelGGL((bwd_tiles_lds_kernel<64>), g2, dim3(kBlock), bwd_tiles_lds_bytes<64>(), s, ws, L.total, L, n, tau, L.cs_b);
-#else
-    const bool single = (nt + L.cs_b - 1) / L.cs_b <= 4;      // pair tiles per block <= waves per block
-    if (d == 32 && single) hipLaunchKernelGGL((bwd_tiles_mfma_kernel<32, true>), g2, dim3(kBlock), 0, s, ws, L.total, L, n, tau, L.cs_b);
-    else if (d == 32) hipLaunchKernelGGL((bwd_tiles_mfma_kernel<32, false>), g2, dim3(kBlock), 0, s, ws, L.total, L, n, tau, L.cs_b);
-    else if (single) hipLaunchKernelGGL((bwd_tiles_mfma_kernel<64, true>), g2, dim3(kBlock), 0, s, ws, L.total, L, n, tau, L.cs_b);
-    else hipLaunchKernelGGL((bwd_tiles_mfma_kernel<64, false>), g2, dim3(kBlock), 0, s, ws, L.total, L, n, tau, L.cs_b);
-#endif
     MMSSL_LAUNCH_CHECK();
   } else if (phases & 1) {
     switch (d) {
@@ -1208,7 +1016,7 @@ int infonce_bwd_impl(const int64_t* idx, int P, int64_t n, int d, float tau, con
   if (assemble_guest) AG = *assemble_guest;
   else AG.n_blocks = 0;
   hipLaunchKernelGGL(bwd_finish_kernel, dim3(rb + (assemble_guest ? 1 : 0)), dim3(kBlock), 0, s, ws, L.total, L, P, L.cs_b,
-                     idx, n, d, tau, gloss, Z, gz2, rb, AG);
+                     idx, n, d, tau, gloss, Z, gz2, rb, deferred_losses, AG);
   MMSSL_LAUNCH_CHECK();
   return 0;
 }
@@ -1307,11 +1115,11 @@ extern "C" int mmssl_infonce_multi_fwd_ticket_bpr_f32(const float* const* z1s, c
                                     bpr_workspace_bytes, mmssl_bpr_workspace_bytes(B), &dummy_ticket, nullptr, 0);
   if (rc != 0) return rc;
   return infonce_fwd_impl(z1s, z2, idx, n_problems, n, d, tau, losses, workspace, workspace_bytes, stream, 1e-8f, 3,
-                          tickets, &A);
+                          tickets, &A, true);
 }
 
 extern "C" int mmssl_infonce_multi_bwd_finish_bpr_f32(const int64_t* idx, int n_problems, int64_t n, int d, float tau,
-                                                      const float* gloss, float* const* gz1s, float* gz2, void* workspace,
+                                                      const float* gloss, float* losses, float* const* gz1s, float* gz2, void* workspace,
                                                       size_t workspace_bytes, const float* Eu, const float* Ei,
                                                       const int64_t* users, const int64_t* pos, const int64_t* neg,
                                                       int64_t B, float decay, int64_t batch_size, const float* g_mf,
@@ -1322,6 +1130,7 @@ extern "C" int mmssl_infonce_multi_bwd_finish_bpr_f32(const int64_t* idx, int n_
                                                       size_t bpr_workspace_bytes, const float* extra_parts,
                                                       int64_t n_extra_parts, void* stream) {
   if (!infonce_d_ok(d) || !use_mfma(d)) return MMSSL_E_UNSUPP;
+  if (!losses) return MMSSL_E_BADARG;
   BprStepArgs A;
   int dummy_ticket = 0;
   const int rc = make_bpr_step_args(A, Eu, Ei, users, pos, neg, B, d, decay, batch_size, g_mf, g_emb, gEu, gEi, terms, w,
@@ -1329,7 +1138,7 @@ extern "C" int mmssl_infonce_multi_bwd_finish_bpr_f32(const int64_t* idx, int n_
                                     bpr_workspace_bytes, mmssl_bpr_workspace_bytes(B), &dummy_ticket, extra_parts,
                                     n_extra_parts);
   if (rc != 0) return rc;
-  return infonce_bwd_impl(idx, n_problems, n, d, tau, gloss, gz1s, gz2, workspace, workspace_bytes, stream, 2, &A);
+  return infonce_bwd_impl(idx, n_problems, n, d, tau, gloss, gz1s, gz2, workspace, workspace_bytes, stream, 2, &A, losses);
 }
 
 extern "C" int mmssl_infonce_multi_bwd_phase_f32(const int64_t* idx, int n_problems, int64_t n, int d, float tau,

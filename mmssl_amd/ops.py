@@ -758,10 +758,11 @@ class _BatchLosses(torch.autograd.Function):
         elif last is not None:
             raise _lib.MmsslError("batch_losses: the forward left an unreduced regulariser sum that this tail does not consume")
         if d <= 64:
-            # FIVE launches: InfoNCE prep (+ the BPR tail's ROWS part as guest blocks: it depends on nothing there and
-            # the short launch leaves most of the chip free), forward pair tiles, row terms (the last block also reduces
-            # the two losses), backward pair tiles (exactly one round of resident blocks without guests), backward finish
-            # (+ the tail's one-block ASSEMBLY part: BPR loss, loss assembly, counter ticks)
+            # FOUR launches: InfoNCE prep (+ the BPR tail's ROWS part as guest blocks: it depends on nothing there and
+            # the short launch leaves most of the chip free), forward pair tiles, backward pair tiles (exactly one round
+            # of resident blocks without guests; the per-row terms come from the forward's partial denominators on the
+            # fly), backward finish (+ one guest block: the two InfoNCE losses from the per-tile partials, then the
+            # tail's ASSEMBLY part: BPR loss, loss assembly, counter ticks)
             rc = _lib.lib().mmssl_infonce_multi_fwd_ticket_bpr_f32(
                 z1s, _ptr(ua), _ptr(users), 2, B, d, float(tau), _ptr(out[3:5]), _ptr(ws1), nbw, _ptr(tickets),
                 _ptr(ua), _ptr(ia), _ptr(users), _ptr(pos), _ptr(neg), B, float(decay), int(batch_size), _ptr(w[0:1]),
@@ -771,7 +772,7 @@ class _BatchLosses(torch.autograd.Function):
                                                               _ptr(g_ua), _ptr(ws1), ws1.numel() * 4, 1, _lib.stream_ptr())
             _lib.check(rc, "mmssl_infonce_multi_bwd_phase_f32")
             rc = _lib.lib().mmssl_infonce_multi_bwd_finish_bpr_f32(
-                _ptr(users), 2, B, d, float(tau), _ptr(w[3:5]), gz1s, _ptr(g_ua), _ptr(ws1), ws1.numel() * 4,
+                _ptr(users), 2, B, d, float(tau), _ptr(w[3:5]), _ptr(out[3:5]), gz1s, _ptr(g_ua), _ptr(ws1), ws1.numel() * 4,
                 _ptr(ua), _ptr(ia), _ptr(users), _ptr(pos), _ptr(neg), B, float(decay), int(batch_size), _ptr(w[0:1]),
                 _ptr(w[1:2]), _ptr(g_ua), _ptr(g_ia), _ptr(out), _ptr(w), 5, _ptr(extra), float(c), _ptr(total), fa,
                 len(f32s), ka, len(u64s), _ptr(wsb), nb, _ptr(xparts), n_xparts, _lib.stream_ptr())

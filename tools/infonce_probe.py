@@ -36,6 +36,7 @@ g2 = torch.zeros_like(z2)
 z1s = (ct.c_void_p * P)(*[z.data_ptr() for z in z1])
 g1s = (ct.c_void_p * P)(*[g.data_ptr() for g in g1])
 sp = _lib.stream_ptr()
+tickets = torch.zeros(8, dtype=torch.int32, device=dev)
 
 
 def fwd():
@@ -43,9 +44,9 @@ def fwd():
                                                    ws.data_ptr(), nb, 3, sp), "fwd")
 
 
-def fwd_rows():
-    _lib.check(L.mmssl_infonce_multi_fwd_phase_f32(z1s, z2.data_ptr(), idx.data_ptr(), P, n, d, a.tau, losses.data_ptr(),
-                                                   ws.data_ptr(), nb, 1, sp), "fwd1")
+def fwd_rows():        # the hot chain's form: the loss comes out of the last block to arrive (no reduction launch)
+    _lib.check(L.mmssl_infonce_multi_fwd_ticket_f32(z1s, z2.data_ptr(), idx.data_ptr(), P, n, d, a.tau, losses.data_ptr(),
+                                                    ws.data_ptr(), nb, tickets.data_ptr(), sp), "fwd_ticket")
 
 
 def bwd(ph):
@@ -71,8 +72,12 @@ def sustained(fn):
 
 # ---- check ----
 fwd()
+l_plain = losses.clone()
+losses.zero_()
+fwd_rows()
 bwd(3)
 torch.cuda.synchronize()
+print("ticketed forward vs phased forward: loss difference %.2e" % (losses - l_plain).abs().max().item())
 ref_l, ref_g1, ref_g2 = [], [], torch.zeros_like(z2, dtype=torch.float64)
 for p in range(P):
     x = z1[p][idx].double().requires_grad_(True)

@@ -714,10 +714,12 @@ class _BatchLosses(torch.autograd.Function):
     def _forward_eager(ctx, ua, ia, img_uid, txt_uid, users, pos, neg, decay, batch_size, tau, w, tail, out, wsb, nb, hot):
         """The caller PROMISES that the result is backpropagated with exactly the gradient `w` (a persistent [5]
         tensor: HotPathStep's loss weights, total = w . terms + c * extra backpropagated with 1). The gradients of
-        the loss terms are then known before the loss scalars are, and the whole loss section becomes ONE chain of
-        seven launches on the current stream, no fork / join (a cross-queue edge of a replayed hipGraph costs 10-15 us):
-          zero fill (all four gradients + the tickets), InfoNCE prep, pair tiles, row terms (the last block also reduces
-          the two losses), backward pair tiles, backward finish, BPR backward + BPR loss + loss assembly + counter ticks.
+        the loss terms are then known before the loss scalars are, and the whole loss section becomes ONE chain on the
+        current stream, no fork / join (a cross-queue edge of a replayed hipGraph costs 10-15 us). d <= 64 (four launches
+        behind the zero fill of the gradients, which the step's forward already did on an idle stream): InfoNCE prep +
+        BPR rows, pair tiles, backward pair tiles (per-row terms on the fly), backward finish + InfoNCE losses + BPR loss
+        + loss assembly + counter ticks. Wider rows: prep, pair tiles, row terms (the last block also reduces the two
+        losses), backward pair tiles, backward finish, and mmssl_bpr_step_f32 as a launch of its own.
         tail = (extra, c, total, ticks): see mmssl_bpr_step_f32. backward() returns the stored gradients.
         `hot` (hotnode.HotCtx of the step, may be None): hands over the zero-filled buffer the forward prepared on an idle
         stream (hot.prefill_buf) and the forward's unreduced regulariser partials (hot.ss_parts)."""

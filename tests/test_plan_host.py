@@ -36,6 +36,26 @@ def test_library_exports_every_declared_symbol():
     assert b"workspace" in L.mmssl_strerror(-3)
 
 
+def test_documents_name_only_declared_entry_points():
+    """INTEGRATION.md / DESIGN.md / README.md / the Python layer refer to C entry points by name: every complete name they
+    use must be declared in the header (INTEGRATION.md's "Removed from the ABI" paragraph is the one place where
+    former names may appear)."""
+    hdr = open(os.path.join(ROOT, "include", "mmssl_hip.h")).read()
+    declared = set(re.findall(r"\b(mmssl_[a-z0-9_]+)\s*\(", hdr))
+    suffix = r"\b(mmssl_[a-z0-9_]+_(?:f32|u8|i64|bytes|create|destroy|rebuild))\b"
+    for doc in ("INTEGRATION.md", "DESIGN.md", "README.md"):
+        txt = open(os.path.join(ROOT, doc)).read()
+        if doc == "INTEGRATION.md":
+            txt = txt.split("Removed from the ABI in round 3")[0]
+        stale = sorted(n for n in set(re.findall(suffix, txt)) if n not in declared)
+        assert not stale, (doc, stale)
+    pkg = os.path.join(ROOT, "mmssl_amd")
+    for f in sorted(os.listdir(pkg)):
+        if f.endswith(".py"):
+            names = set(re.findall(r"lib\(\)\.(mmssl_[a-z0-9_]+)", open(os.path.join(pkg, f)).read()))
+            assert names <= declared, (f, sorted(names - declared))
+
+
 def test_transpose_matches_scipy():
     for seed, (r, c, dens) in enumerate([(50, 70, 0.1), (300, 20, 0.3), (1, 9, 0.5), (40, 40, 0.0)]):
         m = _rand_csr(r, c, dens, seed)

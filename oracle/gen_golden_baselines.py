@@ -6,6 +6,12 @@ package and a `Models` module). The committed .npz files are DATA: inputs + the 
   G11  MICRO.forward + batched_contrastive_loss     (cf_model lightgcn)   MICRO/codes/Models.py:13-160
   G13  LATTICE (cf_model ngcf) and the NGCF class                          LATTICE/codes/Models.py:106-118, MICRO/codes/Models.py:179-217
   G14  MICRO (cf_model ngcf) with --sparse 1                               MICRO/codes/Models.py:126-139, utility/norm.py:8-36
+  G15  Trainer.train() of LATTICE and of MICRO: 3 epochs x 7 batches on the tiny dataset of tests/golden/dataset_tiny.npz
+       (every sampled batch, per-batch loss terms, parameters before / after, eval-mode embeddings, the validation /
+       test metrics of every epoch)                                        LATTICE/codes/main.py:23-185, MICRO/codes/main.py:24-190
+       The same child then runs the PRODUCT loop (mmssl_amd/baselines_main.Trainer) over the reference's model class,
+       optim.Adam and test_torch on CPU and asserts the identical trajectory: the loop's bookkeeping (sampling order,
+       item-graph rebuild flag, scheduler, validation cadence) is pinned here, the HIP models by tests/test_model_gpu.py.
 Shims: argv before import (parse_args at import), .cuda() = identity. G10 / G11 use the dense item graph (--sparse 0).
 MICRO's sparse path imports torch_scatter, which this image lacks: for G14 THIS GENERATOR (and nothing else) installs a
 stand-in module whose scatter_add is index_add_ - the one function utility/norm.py takes from it - and also checks that
@@ -103,6 +109,159 @@ def child(which, cf_model="lightgcn", sparse=0, cls_name=None, tag=None):
           {k: v.shape for k, v in rec.items() if k.startswith("o.")}, sorted(k for k in rec if k.startswith("g.")))
 
 
+TRAINER_ARGV = ["--dataset", "tiny", "--batch_size", "128", "--epoch", "3", "--verbose", "1", "--topk", "10", "--seed", "7",
+                "--Ks", "[10, 20]", "--lr", "0.005"]
+
+
+def _shims(torch, sparse):
+    if sparse:
+        import types
+        ts = types.ModuleType("torch_scatter")
+
+        def scatter_add(src, index, dim=0, dim_size=None):
+            assert dim == 0
+            return torch.zeros(dim_size, dtype=src.dtype).index_add_(0, index, src)
+        ts.scatter_add = scatter_add
+        sys.modules["torch_scatter"] = ts
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    torch.nn.Module.cuda = lambda self, *a, **k: self
+    torch.cuda.manual_seed_all = lambda seed: None
+    import multiprocessing
+    if multiprocessing.cpu_count() < 5:          # batch_test.py: Pool(cpu_count() // 5)
+        multiprocessing.cpu_count = lambda: 5
+    if not hasattr(np, "asfarray"):
+        np.asfarray = lambda a, dtype=float: np.asarray(a, dtype=dtype)
+
+
+def trainer_child(which):
+    """G15: the reference's own Trainer.train() on the tiny dataset, everything it draws and computes recorded."""
+    import shutil
+    import torch
+    repo = os.path.join(HERE, "..")
+    sys.path.insert(0, os.path.join(repo, "tests"))
+    import helpers as H
+    tmp = "/tmp/mmssl_golden_bltr_%s/" % which
+    shutil.rmtree(tmp, ignore_errors=True)
+    H.write_dataset_dir(tmp)                      # the fixture's dataset, byte for byte what the GPU test rebuilds
+    root = "/root/reference/%s/codes" % which
+    sys.path.insert(0, root)
+    argv = ["--data_path", tmp] + TRAINER_ARGV + (["--sparse", "1"] if which == "MICRO" else [])
+    sys.argv = ["main.py"] + argv
+    _shims(torch, which == "MICRO")
+    import main as M
+    dg = M.data_generator
+    M.set_seed(M.args.seed)
+    config = {"n_users": dg.n_users, "n_items": dg.n_items}
+    _, norm_adj, _ = dg.get_adj_mat()
+    config["norm_adj"] = norm_adj
+    tr = M.Trainer(data_config=config)
+    npy = lambda t: t.detach().cpu().numpy().copy()           # noqa: E731
+    rec = {"argv": np.array(" ".join(argv[2:])), "n_users": dg.n_users, "n_items": dg.n_items}
+    na = norm_adj.tocoo()
+    rec["norm_adj_row"], rec["norm_adj_col"], rec["norm_adj_val"] = na.row.astype(np.int64), na.col.astype(np.int64), na.data.astype(np.float32)
+    for k, v in tr.model.state_dict().items():
+        rec["m0." + k] = npy(v)
+    batches, losses, cls, evals = [], [], [], []
+    sample0, bpr0, test0 = dg.sample, tr.bpr_loss, tr.test
+
+    def sample():
+        out = sample0()
+        batches.append([np.asarray(x, dtype=np.int64) for x in out])
+        return out
+
+    def bpr_loss(u, p, n):
+        out = bpr0(u, p, n)
+        losses.append((float(out[0]), float(out[1])))
+        return out
+
+    def test(users, is_val):
+        ret = test0(users, is_val)
+        evals.append((bool(is_val), np.asarray(users, dtype=np.int64), {k: np.asarray(v, dtype=np.float64) for k, v in ret.items()}))
+        return ret
+    dg.sample, tr.bpr_loss, tr.test = sample, bpr_loss, test
+    if which == "MICRO":
+        cl0 = tr.model.batched_contrastive_loss
+
+        def cl(z1, z2, *a, **k):
+            out = cl0(z1, z2, *a, **k)
+            cls.append(float(out))
+            return out
+        tr.model.batched_contrastive_loss = cl
+    tr.train()
+    dg.sample, tr.bpr_loss, tr.test = sample0, bpr0, test0
+    n = len(batches)
+    assert n == len(losses) == 21 and (which != "MICRO" or len(cls) == 2 * n)
+    rec["n_batches"] = n
+    for b in range(n):
+        for nm, x in zip(("users", "pos", "neg"), batches[b]):
+            rec["b%d.%s" % (b, nm)] = x
+        rec["b%d.mf" % b], rec["b%d.emb" % b] = np.float64(losses[b][0]), np.float64(losses[b][1])
+        if which == "MICRO":
+            rec["b%d.cl" % b] = np.float64(np.float32(np.float32(cls[2 * b]) + np.float32(cls[2 * b + 1])) * np.float32(M.args.loss_ratio))
+    for k, v in tr.model.state_dict().items():
+        rec["m1." + k] = npy(v)
+    rec["n_evals"] = len(evals)
+    for e, (is_val, users, ret) in enumerate(evals):
+        rec["e%d.is_val" % e] = np.int64(is_val)
+        rec["e%d.users" % e] = users
+        for k in ("precision", "recall", "ndcg", "hit_ratio"):
+            rec["e%d.%s" % (e, k)] = ret[k]
+    tr.model.eval()
+    with torch.no_grad():
+        outs = tr.model(tr.norm_adj, build_item_graph=True)
+    rec["eval.ua"], rec["eval.ia"] = npy(outs[0]), npy(outs[1])
+    rec["final_lr"] = np.float64(tr.optimizer.param_groups[0]["lr"])
+    np.savez_compressed(os.path.join(OUT, "g15_%s_trainer.npz" % which.lower()), **rec)
+    print("G15", which, "batches", n, "evals", len(evals), "first / last mf", losses[0][0], losses[-1][0],
+          "recall@20", [float(r[2]["recall"][1]) for r in evals])
+
+    # ---- the PRODUCT loop over the reference's classes (CPU): identical trajectory ---------------------------------
+    sys.path.insert(0, repo)
+    from mmssl_amd import baselines_main as BM
+    import Models
+
+    class CpuTrainer(BM.Trainer):
+        def _make_adj(self, a):
+            return tr.sparse_mx_to_torch_sparse_tensor(a).float()
+
+        def _make_model(self, img, txt):
+            return getattr(Models, which)(self.n_users, self.n_items, self.emb_dim, self.weight_size, self.mess_dropout, img, txt)
+
+        def _make_optimizer(self):
+            return torch.optim.Adam(self.model.parameters(), lr=self.lr)
+
+        def _evaluate(self, ua, ia, users, is_val):
+            return M.test_torch(ua, ia, users, is_val)
+
+        def _batch_losses(self, outs, users, pos, neg):
+            mf, emb, reg = tr.bpr_loss(outs[0][users], outs[1][pos], outs[1][neg])
+            cl_ = None
+            if which == "MICRO":
+                cl_ = (self.model.batched_contrastive_loss(outs[2], outs[4])
+                       + self.model.batched_contrastive_loss(outs[3], outs[4])) * self.args.loss_ratio
+            got.append((float(mf), float(emb), None if cl_ is None else float(cl_)))
+            return mf, emb, reg, cl_
+    got = []
+    a = BM.parse_args(which.lower(), argv)
+    M.set_seed(a.seed)
+    ptr = CpuTrainer(data_config=config, args=a, data=dg, device="cpu")
+    ptr.model.load_state_dict({k[3:]: torch.from_numpy(v) for k, v in rec.items() if k.startswith("m0.")})
+    M.set_seed(a.seed)
+    M.Trainer(data_config=config)                  # consume the same random stream the reference's constructor did
+    ptr.train()
+    assert len(got) == n
+    for b in range(n):
+        assert got[b][0] == losses[b][0] and got[b][1] == losses[b][1], (b, got[b], losses[b])
+        if which == "MICRO":
+            assert abs(got[b][2] - float(rec["b%d.cl" % b])) <= 1e-6 * abs(got[b][2]), b
+    for k, v in ptr.model.state_dict().items():
+        assert np.array_equal(npy(v), rec["m1." + k]), k
+    assert abs(ptr.optimizer.param_groups[0]["lr"] - float(rec["final_lr"])) < 1e-15
+    vals = [h for h in ptr.history]
+    assert len(vals) == sum(1 for e in evals if e[0]), (len(vals), len(evals))
+    print("G15", which, ": the product loop over the reference's classes reproduces the trajectory bit for bit")
+
+
 CASES = {"LATTICE": ("LATTICE", "lightgcn", 0, None, None),
          "MICRO": ("MICRO", "lightgcn", 0, None, None),
          "LATTICE_ngcf": ("LATTICE", "ngcf", 0, None, "g13_lattice_ngcf"),
@@ -112,9 +271,12 @@ CASES = {"LATTICE": ("LATTICE", "lightgcn", 0, None, None),
 
 
 if __name__ == "__main__":
-    if len(sys.argv) > 1:
+    if len(sys.argv) > 2 and sys.argv[1] == "trainer":
+        trainer_child(sys.argv[2])
+    elif len(sys.argv) > 1:
         child(*CASES[sys.argv[1]])
     else:
-        for w in CASES:
-            r = subprocess.run([sys.executable, os.path.abspath(__file__), w], capture_output=True, text=True)
+        jobs = [[w] for w in CASES] + [["trainer", "LATTICE"], ["trainer", "MICRO"]]
+        for w in jobs:
+            r = subprocess.run([sys.executable, os.path.abspath(__file__)] + w, capture_output=True, text=True)
             print(r.stdout[-600:], r.stderr[-1500:] if r.returncode else "")

@@ -215,3 +215,62 @@ def test_trainer_csr_norm_matches_reference_g1():
     assert (np.diff(cm.indptr) == 0).any()                      # the fixture has zero-degree rows
     assert _same_sparse(tr.csr_norm(cm, mean_flag=True), mat("cm_norm"), 1e-7)
     assert _same_sparse(tr.csr_norm(cm, mean_flag=False), mat("cm_sym"), 1e-7)
+
+
+# ---- the LATTICE / MICRO training loops (mmssl_amd/baselines_main.py): host side -----------------------------------
+G15_ARGV = ["--dataset", "tiny", "--batch_size", "128", "--epoch", "3", "--verbose", "1", "--topk", "10", "--seed", "7",
+            "--Ks", "[10, 20]", "--lr", "0.005"]
+
+
+@pytest.mark.parametrize("which", ["lattice", "micro"])
+def test_baseline_loop_inputs_match_reference_g15(tmp_path, which):
+    """G15 (recorded from the reference's Trainer.train()): the argument namespace the goldens were made with parses the
+    same way here, and Data.get_adj_mat() gives the reference's row-normalised (A + I) adjacency entry for entry
+    (LATTICE/codes/utility/load_data.py:98-170). The loop's own bookkeeping is pinned in the generator (the product loop
+    over the reference's classes reproduces the trajectory bit for bit), the HIP side in tests/test_model_gpu.py."""
+    import scipy.sparse as sp
+    from mmssl_amd import baselines_main as BM
+    from mmssl_amd.utility.load_data import Data
+    fx = H.load("g15_%s_trainer.npz" % which)
+    extra = ["--sparse", "1"] if which == "micro" else []
+    assert " ".join(G15_ARGV + extra) == str(fx["argv"])
+    root = H.write_dataset_dir(str(tmp_path))
+    a = BM.parse_args(which, ["--data_path", root] + G15_ARGV + extra)
+    assert (a.model_name, a.batch_size, a.epoch, a.lr, a.topk, a.lambda_coeff, a.cf_model) == (which, 128, 3, 0.005, 10, 0.9, "lightgcn")
+    assert (a.loss_ratio, a.layers, a.norm_type) == (0.03, 1, "sym") if which == "micro" else (a.n_layers, a.feat_embed_dim) == (1, 64)
+    data = Data(path=root + "tiny", batch_size=a.batch_size)
+    assert (data.n_users, data.n_items) == (int(fx["n_users"]), int(fx["n_items"]))
+    _, norm_adj, _ = data.get_adj_mat()
+    n = data.n_users + data.n_items
+    ref = sp.csr_matrix((fx["norm_adj_val"], (fx["norm_adj_row"], fx["norm_adj_col"])), shape=(n, n))
+    got = norm_adj.tocsr().astype(np.float32)
+    got.sort_indices()
+    ref.sort_indices()
+    assert np.array_equal(got.indptr, ref.indptr) and np.array_equal(got.indices, ref.indices)
+    np.testing.assert_allclose(got.data, ref.data, rtol=1e-6, atol=0)
+
+
+@pytest.mark.parametrize("which", ["LATTICE", "MICRO"])
+def test_baseline_parser_matches_reference_namespace(which):
+    """When the reference is present (build container only): same flags, same defaults as the baseline's own parser
+    (the product adds `model_name` to MICRO's namespace, which has none)."""
+    import importlib.util
+    import os
+    import sys
+    ref = "/root/reference/%s/codes/utility/parser.py" % which
+    if not os.path.exists(ref):
+        pytest.skip("reference not available on this box")
+    spec = importlib.util.spec_from_file_location("_ref_parser_" + which, ref)
+    mod = importlib.util.module_from_spec(spec)
+    argv = sys.argv
+    try:
+        sys.argv = ["x"]
+        spec.loader.exec_module(mod)
+        theirs = vars(mod.parse_args())
+    finally:
+        sys.argv = argv
+    from mmssl_amd.baselines_main import parse_args
+    ours = vars(parse_args(which.lower(), []))
+    if which == "MICRO":
+        assert ours.pop("model_name") == "micro"
+    assert ours == theirs

@@ -595,3 +595,82 @@ def test_g12_trainer_trajectory_and_recall_match_reference(tmp_path, graph_flag)
     for nm in ("val", "test"):
         for k in ("precision", "recall", "ndcg", "hit_ratio"):
             np.testing.assert_allclose(ev[nm][k], fx["%s.%s" % (nm, k)], rtol=1e-12, atol=1e-15, err_msg=nm + k)
+
+
+# ---------------------------------------------------------------------------------------------------
+# G15: the reference's own Trainer.train() of LATTICE and MICRO (3 epochs x 7 batches on the tiny dataset), recorded
+# by oracle/gen_golden_baselines.py trainer: the product loop (mmssl_amd/baselines_main.py) on the HIP models
+# ---------------------------------------------------------------------------------------------------
+G15_ARGV = ["--dataset", "tiny", "--batch_size", "128", "--epoch", "3", "--verbose", "1", "--topk", "10", "--seed", "7",
+            "--Ks", "[10, 20]", "--lr", "0.005"]
+
+
+@pytest.mark.parametrize("which", ["lattice", "micro"])
+def test_g15_baseline_trainers_match_reference(tmp_path, which):
+    """21 batches of the REFERENCE loop (item graph rebuilt in the first batch of every epoch and detached afterwards,
+    Adam with a per-epoch LambdaLR, MICRO's two contrastive terms, validation + test after every epoch) against
+    baselines_main.Trainer with the reference's initial parameters and its sampled batches replayed: every batch's loss
+    terms 1e-4, the final parameters 1e-4 (training moved them 10x further than that), the eval-mode embeddings 1e-4,
+    and precision / recall / NDCG / hit @ 10, 20 of all six evaluations EXACTLY."""
+    from mmssl_amd import baselines_main as BM
+    from mmssl_amd.utility.load_data import Data
+    fx = H.load("g15_%s_trainer.npz" % which)
+    extra = ["--sparse", "1"] if which == "micro" else []
+    assert " ".join(G15_ARGV + extra) == str(fx["argv"])
+    root = H.write_dataset_dir(str(tmp_path))
+    a = BM.parse_args(which, ["--data_path", root] + G15_ARGV + extra)
+    data = Data(path=root + "tiny", batch_size=a.batch_size)
+    _, norm_adj, _ = data.get_adj_mat()
+    BM.set_seed(a.seed)
+    tr = BM.Trainer({"n_users": data.n_users, "n_items": data.n_items, "norm_adj": norm_adj}, a, data=data)
+    tr.model.load_state_dict({k[3:]: torch.from_numpy(fx[k]) for k in fx.files if k.startswith("m0.")}, strict=True)
+    n = int(fx["n_batches"])
+    # the sampler is pinned bit for bit by G6; its stream position after the constructor depends on how many draws the
+    # parameter initialisation took, so the recorded batches are replayed
+    cur = {"b": 0}
+
+    def sample():
+        b = cur["b"]
+        cur["b"] += 1
+        return [fx["b%d.%s" % (b, k)].tolist() for k in ("users", "pos", "neg")]
+    data.sample = sample
+    rows, inner = [], tr._batch_losses
+
+    def batch_losses(outs, users, pos, neg):
+        out = inner(outs, users, pos, neg)
+        rows.append([float(out[0].detach()), float(out[1].detach())] + ([float(out[3].detach())] if which == "micro" else []))
+        return out
+    tr._batch_losses = batch_losses
+    evals, inner_test = [], tr.test
+
+    def test(users, is_val):
+        ret = inner_test(users, is_val)
+        evals.append((bool(is_val), [int(u) for u in users], ret))
+        return ret
+    tr.test = test
+    tr.train()
+    torch.cuda.synchronize()
+    assert cur["b"] == n == len(rows)
+    keys = ("mf", "emb") + (("cl",) if which == "micro" else ())
+    want = np.array([[float(fx["b%d.%s" % (b, k)]) for k in keys] for b in range(n)])
+    np.testing.assert_allclose(np.array(rows), want, rtol=1e-4, atol=1e-8)
+    P = {k: v.detach().cpu() for k, v in tr.model.state_dict().items()}
+    moved_any = 0
+    for k in P:
+        e = H.rel_err(P[k], fx["m1." + k])
+        assert e < 1e-4, (k, e)
+        moved = H.rel_err(fx["m0." + k], fx["m1." + k])
+        if moved > 10 * 1e-4:
+            moved_any += 1
+            assert moved > 10 * e, (k, moved, e)
+    assert moved_any >= 6, moved_any
+    assert abs(tr.optimizer.param_groups[0]["lr"] - float(fx["final_lr"])) <= 1e-12
+    assert len(evals) == int(fx["n_evals"]) == 6
+    for e, (is_val, users, ret) in enumerate(evals):
+        assert is_val == bool(fx["e%d.is_val" % e]) and users == fx["e%d.users" % e].tolist()
+        for k in ("precision", "recall", "ndcg", "hit_ratio"):
+            np.testing.assert_allclose(ret[k], fx["e%d.%s" % (e, k)], rtol=1e-12, atol=1e-15, err_msg="eval %d %s" % (e, k))
+    tr.model.eval()
+    with torch.no_grad():
+        outs = tr.model(tr.norm_adj, build_item_graph=True)
+    assert H.rel_err(outs[0].cpu(), fx["eval.ua"]) < 1e-4 and H.rel_err(outs[1].cpu(), fx["eval.ia"]) < 1e-4

@@ -239,5 +239,7 @@ def main(model_name="lattice", argv=None):
 
 if __name__ == "__main__":
     import sys
-    name = sys.argv[1] if len(sys.argv) > 1 and not sys.argv[1].startswith("-") else "lattice"
-    main(name, sys.argv[2:] if name == (sys.argv[1] if len(sys.argv) > 1 else None) else sys.argv[1:])
+    if len(sys.argv) > 1 and sys.argv[1].lower() in ("lattice", "micro"):
+        main(sys.argv[1], sys.argv[2:])
+    else:
+        main("lattice", sys.argv[1:])

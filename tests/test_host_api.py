@@ -274,3 +274,67 @@ def test_baseline_parser_matches_reference_namespace(which):
     if which == "MICRO":
         assert ours.pop("model_name") == "micro"
     assert ours == theirs
+
+
+@pytest.mark.parametrize("which", ["lattice", "micro"])
+def test_baseline_loop_cadence_and_early_stopping(tmp_path, which):
+    """The loop's control flow on CPU with a stand-in model (no kernels involved): validation every `verbose` epochs
+    (LATTICE: epoch % verbose == 0, MICRO: (epoch + 1) % verbose == 0 - main.py:118 / MICRO main.py:124), a test pass only
+    on a new best Recall@20, `early_stopping_patience` validations without one, then stop; lr = lr0 * 0.96 ** (epoch / 50)."""
+    from mmssl_amd import baselines_main as BM
+    from mmssl_amd.utility.load_data import Data
+    root = H.write_dataset_dir(str(tmp_path))
+    a = BM.parse_args(which, ["--data_path", root, "--dataset", "tiny", "--batch_size", "512", "--epoch", "40", "--verbose", "2",
+                              "--early_stopping_patience", "2", "--Ks", "[10, 20]"])
+    data = Data(path=root + "tiny", batch_size=a.batch_size)
+    recalls = iter([0.10, 0.20, 0.15, 0.20, 0.05, 0.30])          # validation Recall@20 in order; best at 2nd, then 3 misses
+    calls = {"val": [], "test": [], "build": [], "steps": 0}
+
+    class Toy(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.w = torch.nn.Parameter(torch.ones(4))
+
+        def forward(self, adj, build_item_graph=False):
+            calls["build"].append(bool(build_item_graph))
+            return (self.w.sum(), self.w.sum())
+
+    class Loop(BM.Trainer):
+        def _make_adj(self, m):
+            return None
+
+        def _make_model(self, img, txt):
+            return Toy()
+
+        def _make_optimizer(self):
+            return torch.optim.SGD(self.model.parameters(), lr=self.lr)
+
+        def _batch_losses(self, outs, users, pos, neg):
+            calls["steps"] += 1
+            z = outs[0] * 0.0
+            return outs[0], z, 0.0, (z if which == "micro" else None)
+
+        def test(self, users, is_val):
+            calls["val" if is_val else "test"].append(self.epoch_now)
+            r = next(recalls) if is_val else 0.5
+            return {k: np.array([r / 2, r]) for k in ("precision", "recall", "ndcg", "hit_ratio")}
+    _, norm_adj, _ = data.get_adj_mat()
+    tr = Loop({"n_users": data.n_users, "n_items": data.n_items, "norm_adj": norm_adj}, a, data=data, device="cpu")
+    tr.epoch_now = -1             # advanced by the scheduler step at the end of every epoch, i.e. before its validation
+    step0 = tr.lr_scheduler.step
+
+    def sched_step():
+        step0()
+        tr.epoch_now += 1
+    tr.lr_scheduler.step = sched_step
+    ret = tr.train()
+    n_batch = data.n_train // a.batch_size + 1
+    first = 0 if which == "lattice" else 1
+    val_epochs = [first + 2 * k for k in range(5)]               # best at the 2nd validation, misses at 3rd, 4th; 5th stops
+    assert calls["val"] == val_epochs, (calls["val"], val_epochs)
+    assert calls["test"] == [val_epochs[0], val_epochs[1]]       # new best twice (0.10, then 0.20)
+    last_epoch = val_epochs[4]
+    assert calls["steps"] == (last_epoch + 1) * n_batch
+    assert calls["build"][:n_batch] == [True] + [False] * (n_batch - 1)       # rebuild in the first batch of an epoch only
+    assert abs(tr.optimizer.param_groups[0]["lr"] - a.lr * 0.96 ** ((last_epoch + 1) / 50)) < 1e-15
+    assert ret["recall"][1] == 0.5 and len(tr.history) == 5

@@ -93,7 +93,7 @@ def count_edge_layers(step, d):
     step.step()
     torch.cuda.synchronize()
     ops.STATS["enabled"] = False
-    return dict(ops.STATS)
+    return dict(ops.STATS, edge_layers=int(round(ops.STATS["edge_layers"])))
 
 
 def spmm_roofline(plans, mats, d, iters=200, traffic=True):
@@ -362,6 +362,51 @@ def graph_capture_works(a):
         return False
 
 
+def free_port():
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` WITHOUT a launcher: start the N ranks ourselves - the same command line under
+    torch.distributed.run (one process per GPU, rendezvous on 127.0.0.1, a free port) - and pass its exit code on.
+    Rank 0's JSON line reaches this process's stdout through the launcher."""
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // max(n, 1))))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def launch_check(a, rank, world, local_rank):
+    """Dry run of the launch path: every rank joins the process group (gloo works without a GPU), one all-reduce and the
+    barrier / max-over-ranks timing skeleton of the real run; rank 0 prints ONE JSON line."""
+    import torch.distributed as dist
+    use_cuda = a.backend == "nccl"
+    if use_cuda:
+        torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank) if use_cuda else torch.device("cpu")
+    dist.init_process_group(a.backend, **({"device_id": dev} if use_cuda else {}))
+    dist.barrier()
+    t0 = time.perf_counter()
+    t = torch.tensor([float(rank + 1)], device=dev, dtype=torch.float64)
+    dist.all_reduce(t)
+    dist.barrier()
+    el = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+    dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    ok = float(t.item()) == world * (world + 1) / 2
+    if rank == 0:
+        print(json.dumps({"launch_check": bool(ok), "n_gpus": world, "backend": a.backend,
+                          "rank_sum": float(t.item()), "max_elapsed_s": round(float(el.item()), 4)}))
+    dist.destroy_process_group()
+    if not ok:
+        raise SystemExit(4)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -389,28 +434,41 @@ def main():
     ap.add_argument("--dist-graph-probe", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--force-dist", action="store_true",
                     help="use the row-sharded code path even with one rank (exercises RCCL + dist.py on 1 GPU)")
+    ap.add_argument("--launch-check", action="store_true", dest="launch_check",
+                    help="launcher dry run (no GPU needed): rendezvous of --gpus ranks on --backend, one all-reduce, one "
+                         "JSON line from rank 0")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl", help="process-group backend (gloo: --launch-check only)")
+    ap.add_argument("--no-stress", action="store_true", dest="no_stress",
+                    help="N>1: skip the `scaling_stress` record (configs[4]'s per-rank share x N after the timed region)")
+    ap.add_argument("--scheme", choices=["item-side", "gather-both"], default="item-side",
+                    help="sharded step: item-side = user-row blocks only, every collective of item-table size; "
+                         "gather-both = user AND item row blocks, all-gather of both tables (round-3 scheme)")
+    ap.add_argument("--chunks", type=int, default=0,
+                    help="sharded step: column chunks per collective (chunk c's SpMM runs under chunk c+1's collective); "
+                         "0 = by size (1 below 64 MB per collective, else 2-4)")
     a = ap.parse_args()
     if a.workload == "synth" and a.d == 64:
         a.d = 128                      # configs[4] is defined at d=128
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        sys.exit(self_launch(a.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit("--gpus %d needs the torch.distributed.run launcher (one rank per GPU)" % a.gpus)
+        raise SystemExit("--gpus %d but the launcher started %d rank(s)" % (a.gpus, world))
+    import torch.distributed as dist
+    if a.launch_check:
+        launch_check(a, rank, world, local_rank)
+        return
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    import torch.distributed as dist
     sharded = world > 1 or a.force_dist or a.workload == "synth" or a.dist_graph_probe
     if sharded:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if world == 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             if "MASTER_PORT" not in os.environ:          # a free port: back-to-back runs must not collide
-                import socket
-                with socket.socket() as so:
-                    so.bind(("127.0.0.1", 0))
-                    os.environ["MASTER_PORT"] = str(so.getsockname()[1])
+                os.environ["MASTER_PORT"] = str(free_port())
             os.environ.setdefault("RANK", "0")
             os.environ.setdefault("WORLD_SIZE", "1")
             dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)

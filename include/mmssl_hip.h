@@ -188,6 +188,14 @@ int mmssl_spmm_f32(const mmssl_graph* g, int transpose, const float* X, int d, f
 int mmssl_spmm_ex_f32(const mmssl_graph* g, int transpose, const float* X, int d, float* Y,
                       int epilogue, const float* Z, float alpha, const float* S, void* workspace,
                       size_t workspace_bytes, void* stream);
+/* The same product on COLUMN CHUNKS of wider row-major tables (no reference counterpart: the row-sharded step,
+ * mmssl_amd/dist.py, propagates a d-wide table as d / chunk independent column chunks so that chunk c's product runs
+ * under chunk c+1's RCCL collective - LightGCN propagation, Models.py:201-211, is independent per column):
+ * X row j starts at X + j * ldx, Y / Z row i at Y + i * ldy, Z + i * ldy (floats; multiples of 4, >= d; base pointers
+ * 16-byte aligned); d = the chunk's width. epilogue: MMSSL_EPI_NONE or MMSSL_EPI_AXPY (Y = op(A).X + alpha * Z). */
+int mmssl_spmm_ld_f32(const mmssl_graph* g, int transpose, const float* X, int64_t ldx, int d, float* Y, int64_t ldy,
+                      int epilogue, const float* Z, float alpha, void* workspace, size_t workspace_bytes,
+                      void* stream);
 /* Y = keep ? (op(A).X) * scale : 0 — the dropout backward of the modality projection (nn.Dropout, Models.py:54,
  * 173-174) fused into the SpMM that produces the projection's output gradient (autograd of Models.py:177, 182).
  * Y [R, d] packs d / dm modalities of dm features side by side; keep is the uint8 [d / dm, R, dm] mask layout of
@@ -212,6 +220,10 @@ int mmssl_l2norm_rows_bwd_f32(const float* X, const float* gY, float alpha, int6
                               float eps, float* gX, void* stream);
 int mmssl_softmax_rows_bwd_f32(const float* Y, const float* gY, float scale, int64_t rows, int d,
                                float* gX, void* stream);   /* gX = scale * Y*(gY - <gY,Y>) */
+/* Y = softmax(X) over the d features of every row (torch.softmax(.., dim=-1), Models.py:203-204) as a launch of its own
+ * - bit for bit the MMSSL_EPI_SOFTMAX store epilogue - for rows that are only complete after a reduce-scatter or after
+ * all column chunks of a product have been written. Y == X allowed. */
+int mmssl_softmax_rows_f32(const float* X, int64_t rows, int d, float* Y, void* stream);
 /* Layer mean + modality fusion of the final embeddings (Models.py:213-218) in one pass:
  *   out = inv * sum_k layers[k] + r * normalize(A) + r * normalize(B)
  * `layers` is a HOST array of n_layers (<= 8) device pointers. If sumsq_part != NULL the kernel
@@ -393,10 +405,11 @@ int mmssl_dropout_mask_ex_u8(uint64_t* rng_state, float p, int64_t n, uint8_t* k
 /* counter[0] += 1 on the stream: advances a generator's launch counter (rng_state + 1) when the masks were drawn inside
  * another kernel (mmssl_proj_fwd_f32's epilogue) or with external_tick set. */
 int mmssl_tick_u64(uint64_t* counter, void* stream);
-/* dst[0 .. count) = ring[((int64) step_counter[0] % n_slots) * count ...]: a captured step reads its batch indices
- * (Data.sample() output, load_data.py:153-191, uploaded ahead of time) from a device-resident ring by the optimiser's own
- * device step counter - no host-side copy between two replays. */
-int mmssl_select_slot_i64(const int64_t* ring, int n_slots, int64_t count, const float* step_counter, int64_t* dst,
+/* dst[0 .. count) = ring[(step_counter[0] % n_slots) * count ...]: a captured step reads its batch indices
+ * (Data.sample() output, load_data.py:153-191, uploaded ahead of time) from a device-resident ring by a uint64 count of
+ * completed steps that the step itself advances (mmssl_tick_u64, or the u64 tick list of its loss tail) - no host-side
+ * copy between two replays. (Not the fp32 AdamW step counter: that one saturates at 2^24 steps.) */
+int mmssl_select_slot_i64(const int64_t* ring, int n_slots, int64_t count, const uint64_t* step_counter, int64_t* dst,
                           void* stream);
 /* Backward of the above: gterms[k] = g[0] * w[k], gextra[0] = g[0] * c (gextra may be NULL). */
 int mmssl_loss_assemble_bwd_f32(const float* g, const float* w, int n, float c, float* gterms,

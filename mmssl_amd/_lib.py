@@ -64,6 +64,9 @@ SIGNATURES = {
                                       c_void_p]),
     "mmssl_l2norm_rows_bwd_f32": (c_int, [c_void_p, c_void_p, c_float, c_int64, c_int, c_float, c_void_p,
                                           c_void_p]),
+    "mmssl_softmax_rows_f32": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p]),
+    "mmssl_spmm_ld_f32": (c_int, [c_void_p, c_int, c_void_p, c_int64, c_int, c_void_p, c_int64, c_int, c_void_p, c_float,
+                                  c_void_p, c_size_t, c_void_p]),
     "mmssl_softmax_rows_bwd_f32": (c_int, [c_void_p, c_void_p, c_float, c_int64, c_int, c_void_p, c_void_p]),
     "mmssl_spmm_ex_f32": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_float, c_void_p,
                                   c_void_p, c_size_t, c_void_p]),

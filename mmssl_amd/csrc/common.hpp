@@ -61,6 +61,24 @@ __device__ __forceinline__ float f4_dot(float4 a, float4 b) {
   return fmaf(a.x, b.x, fmaf(a.y, b.y, fmaf(a.z, b.z, a.w * b.w)));
 }
 
+// softmax over the 4*LPR features of a row held by one lane group (the last GCN layer, Models.py:203-204): used by the
+// SpMM's store epilogue and by the stand-alone row kernel, which therefore agree bit for bit
+template <int LPR>
+__device__ __forceinline__ float4 row_softmax(float4 a) {
+  float m = fmaxf(fmaxf(a.x, a.y), fmaxf(a.z, a.w));
+  m = group_max<LPR>(m);
+  a.x = expf(a.x - m);
+  a.y = expf(a.y - m);
+  a.z = expf(a.z - m);
+  a.w = expf(a.w - m);
+  const float s = group_sum<LPR>((a.x + a.y) + (a.z + a.w));
+  a.x /= s;
+  a.y /= s;
+  a.z /= s;
+  a.w /= s;
+  return a;
+}
+
 // Deterministic block-wide sum for kBlock threads; result valid in thread 0. `red` = 4 floats LDS.
 __device__ __forceinline__ float block_sum_256(float v, float* red) {
   v = group_sum<64>(v);

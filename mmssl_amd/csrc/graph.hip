@@ -317,10 +317,12 @@ namespace {
 // Accumulate sum_e val[e] * X[col[e], :] over edges [beg,end), visiting LPR-edge tiles
 // first_tile, first_tile+tile_stride, ...  One lane group (LPR lanes) per call; `lig` = lane in
 // group. Each lane holds 4 consecutive features (one float4).
-template <int LPR>
+// LD: X rows are `ldx4` float4s apart (a column chunk of a wider row-major table) instead of LPR.
+template <int LPR, bool LD = false>
 __device__ __forceinline__ float4 gather_rows(const Edge* __restrict__ edges,
                                               const float4* __restrict__ X, int beg, int end,
-                                              int first_tile, int tile_stride, int lig) {
+                                              int first_tile, int tile_stride, int lig, int ldx4 = LPR) {
+  const size_t px = LD ? (size_t)ldx4 : (size_t)LPR;
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
   const int n = end - beg;
   for (int b0 = first_tile * LPR; b0 < n; b0 += tile_stride * LPR) {
@@ -339,10 +341,10 @@ __device__ __forceinline__ float4 gather_rows(const Edge* __restrict__ edges,
       const int c2 = __shfl(my.col, k + 2, LPR), c3 = __shfl(my.col, k + 3, LPR);
       const float v0 = __shfl(my.val, k + 0, LPR), v1 = __shfl(my.val, k + 1, LPR);
       const float v2 = __shfl(my.val, k + 2, LPR), v3 = __shfl(my.val, k + 3, LPR);
-      const float4 x0 = X[(size_t)c0 * LPR + lig];
-      const float4 x1 = X[(size_t)c1 * LPR + lig];
-      const float4 x2 = X[(size_t)c2 * LPR + lig];
-      const float4 x3 = X[(size_t)c3 * LPR + lig];
+      const float4 x0 = X[(size_t)c0 * px + lig];
+      const float4 x1 = X[(size_t)c1 * px + lig];
+      const float4 x2 = X[(size_t)c2 * px + lig];
+      const float4 x3 = X[(size_t)c3 * px + lig];
       acc = f4_fma(v0, x0, acc);
       acc = f4_fma(v1, x1, acc);
       acc = f4_fma(v2, x2, acc);
@@ -350,22 +352,6 @@ __device__ __forceinline__ float4 gather_rows(const Edge* __restrict__ edges,
     }
   }
   return acc;
-}
-
-template <int LPR>
-__device__ __forceinline__ float4 row_softmax(float4 a) {
-  float m = fmaxf(fmaxf(a.x, a.y), fmaxf(a.z, a.w));
-  m = group_max<LPR>(m);
-  a.x = expf(a.x - m);
-  a.y = expf(a.y - m);
-  a.z = expf(a.z - m);
-  a.w = expf(a.w - m);
-  const float s = group_sum<LPR>((a.x + a.y) + (a.z + a.w));
-  a.x /= s;
-  a.y /= s;
-  a.z /= s;
-  a.w /= s;
-  return a;
 }
 
 // Store-side epilogues (row-local, fused into the SpMM):
@@ -383,10 +369,12 @@ struct EpiArgs {
   const uint8_t* keep;
   int dm;
   int64_t rows;
+  int ldx4, ldy4;      // LD kernels: row pitch (in float4) of X and of Y / Z / S
 };
 
-template <int LPR, int EPI>
+template <int LPR, int EPI, bool LD = false>
 __device__ __forceinline__ float4 apply_epilogue(float4 acc, int row, int lig, const EpiArgs& e) {
+  const size_t py = LD ? (size_t)e.ldy4 : (size_t)LPR;
   if (EPI == MMSSL_EPI_SOFTMAX) return row_softmax<LPR>(acc);
   if (EPI == MMSSL_EPI_MASK) {
     const int col = 4 * lig, m = col / e.dm;
@@ -398,14 +386,14 @@ __device__ __forceinline__ float4 apply_epilogue(float4 acc, int row, int lig, c
     return acc;
   }
   if (EPI == MMSSL_EPI_AXPY || EPI == MMSSL_EPI_AXPY_SOFTMAX_BWD) {
-    const float4 z = e.Z[(size_t)row * LPR + lig];
+    const float4 z = e.Z[(size_t)row * py + lig];
     acc.x = fmaf(e.alpha, z.x, acc.x);
     acc.y = fmaf(e.alpha, z.y, acc.y);
     acc.z = fmaf(e.alpha, z.z, acc.z);
     acc.w = fmaf(e.alpha, z.w, acc.w);
   }
   if (EPI == MMSSL_EPI_AXPY_SOFTMAX_BWD) {
-    const float4 y = e.S[(size_t)row * LPR + lig];
+    const float4 y = e.S[(size_t)row * py + lig];
     const float dot = group_sum<LPR>(f4_dot(acc, y));
     acc = make_float4(y.x * (acc.x - dot), y.y * (acc.y - dot), y.z * (acc.z - dot), y.w * (acc.w - dot));
   }
@@ -413,7 +401,7 @@ __device__ __forceinline__ float4 apply_epilogue(float4 acc, int row, int lig, c
 }
 
 // grid = n_wblocks (4 wave items each, heaviest first) + n_gblocks (256/LPR group items each)
-template <int LPR, int EPI>
+template <int LPR, int EPI, bool LD = false>
 __global__ __launch_bounds__(kBlock) void spmm_kernel(const int4* __restrict__ gitems, int n_g,
                                                       const int4* __restrict__ witems, int n_w,
                                                       int n_wblocks, const Edge* __restrict__ edges,
@@ -434,13 +422,14 @@ __global__ __launch_bounds__(kBlock) void spmm_kernel(const int4* __restrict__ g
   constexpr int GPB = kBlock / LPR;  // lane groups per block
   const int lane = threadIdx.x & 63;
   const int lig = lane & (LPR - 1);
+  const size_t py = LD ? (size_t)epi.ldy4 : (size_t)LPR;
   if ((int)blockIdx.x >= n_wblocks) {
     const int gi = ((int)blockIdx.x - n_wblocks) * GPB + (int)threadIdx.x / LPR;
     if (gi >= n_g) return;
     const int4 it = gitems[gi];
-    float4 acc = gather_rows<LPR>(edges, X, it.y, it.z, 0, 1, lig);
-    acc = apply_epilogue<LPR, EPI>(acc, it.x, lig, epi);
-    Y[(size_t)it.x * LPR + lig] = acc;
+    float4 acc = gather_rows<LPR, LD>(edges, X, it.y, it.z, 0, 1, lig, epi.ldx4);
+    acc = apply_epilogue<LPR, EPI, LD>(acc, it.x, lig, epi);
+    Y[(size_t)it.x * py + lig] = acc;
   } else {
     const int wave = (int)threadIdx.x >> 6;
     const int wi = (int)blockIdx.x * 4 + wave;
@@ -448,13 +437,13 @@ __global__ __launch_bounds__(kBlock) void spmm_kernel(const int4* __restrict__ g
     if (code0 == -1) {                                      // four unrelated whole rows
       if (wi >= n_w) return;
       const int4 it = witems[wi];
-      float4 acc = gather_rows<LPR>(edges, X, it.y, it.z, lane / LPR, GPW, lig);
+      float4 acc = gather_rows<LPR, LD>(edges, X, it.y, it.z, lane / LPR, GPW, lig, epi.ldx4);
       acc.x = cross_group_sum<LPR>(acc.x);
       acc.y = cross_group_sum<LPR>(acc.y);
       acc.z = cross_group_sum<LPR>(acc.z);
       acc.w = cross_group_sum<LPR>(acc.w);
-      acc = apply_epilogue<LPR, EPI>(acc, it.x, lig, epi);
-      if (lane < LPR) Y[(size_t)it.x * LPR + lig] = acc;
+      acc = apply_epilogue<LPR, EPI, LD>(acc, it.x, lig, epi);
+      if (lane < LPR) Y[(size_t)it.x * py + lig] = acc;
       return;
     }
     // ---- heavy block: up to four slices of ONE row (the heavy section is padded to whole blocks) ----
@@ -462,7 +451,7 @@ __global__ __launch_bounds__(kBlock) void spmm_kernel(const int4* __restrict__ g
     const int4 it = witems[wi];
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     if (it.x >= 0) {
-      acc = gather_rows<LPR>(edges, X, it.y, it.z, lane / LPR, GPW, lig);
+      acc = gather_rows<LPR, LD>(edges, X, it.y, it.z, lane / LPR, GPW, lig, epi.ldx4);
       acc.x = cross_group_sum<LPR>(acc.x);
       acc.y = cross_group_sum<LPR>(acc.y);
       acc.z = cross_group_sum<LPR>(acc.z);
@@ -480,8 +469,8 @@ __global__ __launch_bounds__(kBlock) void spmm_kernel(const int4* __restrict__ g
       acc.w = ((acc.w + b1.w) + b2.w) + b3.w;
     }
     if (code0 == -2) {                                      // the whole row lives in this block
-      acc = apply_epilogue<LPR, EPI>(acc, row, lig, epi);
-      if (lane < LPR) Y[(size_t)row * LPR + lig] = acc;
+      acc = apply_epilogue<LPR, EPI, LD>(acc, row, lig, epi);
+      if (lane < LPR) Y[(size_t)row * py + lig] = acc;
       return;
     }
     {
@@ -536,8 +525,8 @@ __global__ __launch_bounds__(kBlock) void spmm_kernel(const int4* __restrict__ g
       sum.y = cross_group_sum<LPR>(sum.y);
       sum.z = cross_group_sum<LPR>(sum.z);
       sum.w = cross_group_sum<LPR>(sum.w);
-      sum = apply_epilogue<LPR, EPI>(sum, mr.x, lig, epi);
-      if (lane < LPR) Y[(size_t)mr.x * LPR + lig] = sum;
+      sum = apply_epilogue<LPR, EPI, LD>(sum, mr.x, lig, epi);
+      if (lane < LPR) Y[(size_t)mr.x * py + lig] = sum;
     }
   }
 }
@@ -551,7 +540,7 @@ inline size_t ws_total_bytes(const DirPlan& p, int d) {
   return ws_partials_bytes(p, d) + ((((size_t)p.n_multi * sizeof(int32_t)) + 15) & ~(size_t)15);
 }
 
-template <int LPR, int EPI>
+template <int LPR, int EPI, bool LD = false>
 int launch_spmm(const DirPlan& p, const float* X, float* Y, float* partials, const EpiArgs& epi,
                 hipStream_t s) {
   int32_t* arrivals = reinterpret_cast<int32_t*>(reinterpret_cast<char*>(partials) + ws_partials_bytes(p, LPR * 4));
@@ -559,7 +548,7 @@ int launch_spmm(const DirPlan& p, const float* X, float* Y, float* partials, con
   const int n_wblocks = (int)((p.n_w + 3) / 4);
   const int n_gblocks = (int)((p.n_g + GPB - 1) / GPB);
   if (n_wblocks + n_gblocks > 0) {
-    hipLaunchKernelGGL((spmm_kernel<LPR, EPI>), dim3(n_wblocks + n_gblocks), dim3(kBlock), 0, s,
+    hipLaunchKernelGGL((spmm_kernel<LPR, EPI, LD>), dim3(n_wblocks + n_gblocks), dim3(kBlock), 0, s,
                        p.gitems, (int)p.n_g, p.witems, (int)p.n_w, n_wblocks, p.edges,
                        reinterpret_cast<const float4*>(X), reinterpret_cast<float4*>(Y),
                        reinterpret_cast<float4*>(partials), epi, p.multi, p.slot2multi,
@@ -578,6 +567,17 @@ int dispatch_epi(const DirPlan& p, const float* X, float* Y, float* partials, in
     case MMSSL_EPI_AXPY: return launch_spmm<LPR, MMSSL_EPI_AXPY>(p, X, Y, partials, e, s);
     case MMSSL_EPI_AXPY_SOFTMAX_BWD: return launch_spmm<LPR, MMSSL_EPI_AXPY_SOFTMAX_BWD>(p, X, Y, partials, e, s);
     case MMSSL_EPI_MASK: return launch_spmm<LPR, MMSSL_EPI_MASK>(p, X, Y, partials, e, s);
+  }
+  return MMSSL_E_BADARG;
+}
+
+// pitched operands (column chunks of wider row-major tables): plain product and the AXPY epilogue only
+template <int LPR>
+int dispatch_epi_ld(const DirPlan& p, const float* X, float* Y, float* partials, int epi, const EpiArgs& e,
+                    hipStream_t s) {
+  switch (epi) {
+    case MMSSL_EPI_NONE: return launch_spmm<LPR, MMSSL_EPI_NONE, true>(p, X, Y, partials, e, s);
+    case MMSSL_EPI_AXPY: return launch_spmm<LPR, MMSSL_EPI_AXPY, true>(p, X, Y, partials, e, s);
   }
   return MMSSL_E_BADARG;
 }
@@ -631,11 +631,46 @@ static int spmm_impl(const mmssl_graph* g, int transpose, const float* X, int d,
   e.keep = keep;
   e.dm = dm > 0 ? dm : d;
   e.rows = p.rows;
+  e.ldx4 = e.ldy4 = d / 4;
   switch (d) {
     case 32: return dispatch_epi<8>(p, X, Y, ws, epilogue, e, s);
     case 64: return dispatch_epi<16>(p, X, Y, ws, epilogue, e, s);
     case 128: return dispatch_epi<32>(p, X, Y, ws, epilogue, e, s);
     case 256: return dispatch_epi<64>(p, X, Y, ws, epilogue, e, s);
+  }
+  return MMSSL_E_UNSUPP;
+}
+
+extern "C" int mmssl_spmm_ld_f32(const mmssl_graph* g, int transpose, const float* X, int64_t ldx, int d, float* Y,
+                                 int64_t ldy, int epilogue, const float* Z, float alpha, void* workspace,
+                                 size_t workspace_bytes, void* stream) {
+  if (!g || !Y) return MMSSL_E_BADARG;
+  if (!supported_d(d)) return MMSSL_E_UNSUPP;
+  if (epilogue != MMSSL_EPI_NONE && epilogue != MMSSL_EPI_AXPY) return MMSSL_E_BADARG;
+  if (ldx < d || ldy < d || (ldx & 3) || (ldy & 3) || ldx > 0x7fffffff || ldy > 0x7fffffff) return MMSSL_E_BADARG;
+  const DirPlan& p = transpose ? g->bwd : g->fwd;
+  if (p.rows == 0) return 0;
+  if (!X && p.nnz > 0) return MMSSL_E_BADARG;
+  if (epilogue == MMSSL_EPI_AXPY && !Z) return MMSSL_E_BADARG;
+  if (((uintptr_t)X | (uintptr_t)Y | (uintptr_t)workspace | (uintptr_t)Z) & 15) return MMSSL_E_BADARG;
+  const size_t need = p.n_slots > 0 ? ws_total_bytes(p, d) : 0;
+  if (need > 0 && (!workspace || workspace_bytes < need)) return MMSSL_E_WORKSPACE;
+  hipStream_t s = as_stream(stream);
+  float* ws = reinterpret_cast<float*>(workspace);
+  EpiArgs e;
+  e.Z = reinterpret_cast<const float4*>(Z);
+  e.S = nullptr;
+  e.alpha = alpha;
+  e.keep = nullptr;
+  e.dm = d;
+  e.rows = p.rows;
+  e.ldx4 = (int)(ldx / 4);
+  e.ldy4 = (int)(ldy / 4);
+  switch (d) {
+    case 32: return dispatch_epi_ld<8>(p, X, Y, ws, epilogue, e, s);
+    case 64: return dispatch_epi_ld<16>(p, X, Y, ws, epilogue, e, s);
+    case 128: return dispatch_epi_ld<32>(p, X, Y, ws, epilogue, e, s);
+    case 256: return dispatch_epi_ld<64>(p, X, Y, ws, epilogue, e, s);
   }
   return MMSSL_E_UNSUPP;
 }

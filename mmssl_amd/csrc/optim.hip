@@ -242,19 +242,21 @@ extern "C" int mmssl_dropout_mask_ex_u8(uint64_t* rng_state, float p, int64_t n,
 }
 
 namespace mmssl {
-// dst[0 .. count) = ring[(step % n) * count ...]: a step picks its batch from a device-resident ring by its own step counter
+// dst[0 .. count) = ring[(step % n) * count ...]: a step picks its batch from a device-resident ring by a uint64 step
+// counter of its own (the fp32 AdamW step counter stops incrementing at 2^24 steps and cannot index a ring for ever)
 __global__ __launch_bounds__(kBlock) void select_slot_kernel(const int64_t* __restrict__ ring, int n, int64_t count,
-                                                             const float* __restrict__ step_counter,
+                                                             const uint64_t* __restrict__ step_counter,
                                                              int64_t* __restrict__ dst) {
-  const int64_t k = (int64_t)step_counter[0] % n;
+  const int64_t k = (int64_t)(step_counter[0] % (uint64_t)n);
   const int64_t* src = ring + k * count;
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < count; i += (int64_t)gridDim.x * kBlock) dst[i] = src[i];
 }
 }  // namespace mmssl
 
-extern "C" int mmssl_select_slot_i64(const int64_t* ring, int n_slots, int64_t count, const float* step_counter,
+extern "C" int mmssl_select_slot_i64(const int64_t* ring, int n_slots, int64_t count, const uint64_t* step_counter,
                                      int64_t* dst, void* stream) {
   if (!ring || !dst || !step_counter || n_slots < 1 || count < 1) return MMSSL_E_BADARG;
+  if (reinterpret_cast<uintptr_t>(step_counter) & 7) return MMSSL_E_BADARG;
   const int blocks = (int)std::min<int64_t>((count + kBlock - 1) / kBlock, 64);
   hipLaunchKernelGGL(select_slot_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, ring, n_slots, count,
                      step_counter, dst);

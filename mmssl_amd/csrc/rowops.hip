@@ -62,6 +62,17 @@ __global__ __launch_bounds__(kBlock) void l2norm_bwd_kernel(const float4* __rest
   }
 }
 
+// Y = softmax(X) row by row (in place allowed): the SpMM epilogue's arithmetic as a launch of its own, for products whose
+// rows only become complete after a reduce-scatter / after all column chunks have arrived (mmssl_amd/dist.py)
+template <int LPR>
+__global__ __launch_bounds__(kBlock) void softmax_fwd_kernel(const float4* X, int64_t rows, float4* Y) {
+  constexpr int GPB = kBlock / LPR;
+  const int lig = threadIdx.x & (LPR - 1);
+  const int64_t stride = (int64_t)gridDim.x * GPB;
+  for (int64_t r = (int64_t)blockIdx.x * GPB + threadIdx.x / LPR; r < rows; r += stride)
+    Y[r * LPR + lig] = row_softmax<LPR>(X[r * LPR + lig]);
+}
+
 template <int LPR>
 __global__ __launch_bounds__(kBlock) void softmax_bwd_kernel(const float4* __restrict__ Yv,
                                                              const float4* __restrict__ G, float scale,
@@ -335,6 +346,17 @@ extern "C" int mmssl_l2norm_rows_bwd_f32(const float* X, const float* gY, float 
   hipStream_t s = as_stream(stream);
   ROW_DISPATCH(l2norm_bwd_kernel, reinterpret_cast<const float4*>(X), reinterpret_cast<const float4*>(gY),
                alpha, rows, eps, reinterpret_cast<float4*>(gX));
+  MMSSL_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int mmssl_softmax_rows_f32(const float* X, int64_t rows, int d, float* Y, void* stream) {
+  if (rows < 0 || (rows > 0 && (!X || !Y))) return MMSSL_E_BADARG;
+  if (!supported_d(d)) return MMSSL_E_UNSUPP;
+  if (((uintptr_t)X | (uintptr_t)Y) & 15) return MMSSL_E_BADARG;
+  if (rows == 0) return 0;
+  hipStream_t s = as_stream(stream);
+  ROW_DISPATCH(softmax_fwd_kernel, reinterpret_cast<const float4*>(X), rows, reinterpret_cast<float4*>(Y));
   MMSSL_LAUNCH_CHECK();
   return 0;
 }

@@ -45,6 +45,7 @@ class HipBackend:
         self.EPI_NONE, self.EPI_SOFTMAX = ops.EPI_NONE, ops.EPI_SOFTMAX
         for name in ("spmm", "l2norm_rows", "linear", "bpr", "infonce", "sumsq"):
             setattr(self, name, getattr(ops, name))
+        self.softmax_rows = ops.softmax_rows_fn
         # non-autograd kernels for the fused sharded node
         self.spmm_raw = ops._spmm_raw
         self.softmax_rows_bwd = ops.softmax_rows_bwd
@@ -54,6 +55,8 @@ class HipBackend:
         self._ar = {}
         self._streams = {}
         self.after_fuse_bwd = None      # event of the latest packed node's backward (see _ShardedHotForward.backward)
+        self.tables_stream = None       # the stream on which that backward completes the gradient of i_0
+        self.table_grads = None
         self.defer_ss, self.ss_parts = False, None      # hand-off of the regulariser partials to a step's loss tail
 
     def gather_owned(self, table, idx, lo, out):
@@ -75,6 +78,21 @@ class HipBackend:
         if st is None:
             st = self._streams[key] = [torch.cuda.Stream(device=device) for _ in range(3)]
         return st
+
+    def lane_streams(self, device, n):
+        """Streams for the column-chunk lanes of the item-side node (grown on demand, owned by this backend object)."""
+        key = ("lanes", device.type, device.index)
+        st = self._streams.setdefault(key, [])
+        while len(st) < n:
+            st.append(torch.cuda.Stream(device=device))
+        return st[:n]
+
+    def softmax_rows_(self, X):
+        return self.ops.softmax_rows(X, out=X)
+
+    @staticmethod
+    def chunk_ok(width, nc):
+        return nc >= 1 and width % nc == 0 and (width // nc) in (32, 64, 128, 256)
 
     def _identity(self, B, dev):
         ar = self._ar.get((B, dev))
@@ -199,6 +217,15 @@ def shard_graph(mat, row_shard, col_shard):
     return m[row_shard.lo:row_shard.hi].tocsr()
 
 
+def shard_graph_cols(mat, row_shard, col_shard):
+    """Local COLUMNS [lo, hi) of a global scipy matrix over ALL (padded) rows: [n_rows_pad, per]. The item-side scheme's
+    second graph: A_iu[:, U_r] - the edges of this rank's users seen from the item side, so that A_iu . X_u becomes a
+    local partial product over all items + a reduce-scatter."""
+    m = sp.csr_matrix(mat, dtype=np.float32).copy()
+    m.resize((row_shard.n_pad, col_shard.n_pad))
+    return m.tocsc()[:, col_shard.lo:col_shard.hi].tocsr()
+
+
 # ---------------------------------------------------------------------------------------------
 # collectives with autograd
 # ---------------------------------------------------------------------------------------------
@@ -243,6 +270,21 @@ class AllGatherRows(torch.autograd.Function):
     def backward(ctx, g):
         _log_comm("reduce_scatter", g)
         return _reduce_scatter_sum(g, ctx.per, ctx.group), None
+
+
+class ReduceScatterRows(torch.autograd.Function):
+    """[world*per, d] partial products -> this rank's [per, d] rows of their sum; backward = all-gather of the gradient
+    (the composed form of the item-side scheme: i_r = reduce_scatter(A_iu[:, U_r] . u_r))."""
+
+    @staticmethod
+    def forward(ctx, full, per, group):
+        ctx.group = group
+        _log_comm("reduce_scatter", full)
+        return _reduce_scatter_sum(full.contiguous(), per, group)
+
+    @staticmethod
+    def backward(ctx, g):
+        return _all_gather_raw(g.contiguous(), ctx.group), None, None
 
 
 class GatherBatchRows(torch.autograd.Function):
@@ -353,9 +395,16 @@ class ShardedMMSSL(nn.Module):
     replicated  image_trans.{weight,bias}, text_trans.{weight,bias}, w_self_attention_cat
     sharded     user_id_embedding [per_u, d], item_id_embedding [per_i, d]."""
 
-    def __init__(self, backend, cfg, ush, ish, state, image_feats, text_feats, group=None):
+    def __init__(self, backend, cfg, ush, ish, state, image_feats, text_feats, group=None, scheme="gather-both", chunks=0):
+        """scheme: which local graphs forward() receives as (ui, iu) and how the propagation communicates:
+             "gather-both"  ui = A_ui[U_r, :], iu = A_iu[I_r, :] (shard_graph): all-gather of the item table before
+                            A_ui . X_i and of the user table before A_iu . X_u
+             "item-side"    ui = A_ui[U_r, :], iu = A_iu[:, U_r] (shard_graph_cols): only this rank's users' edges; every
+                            collective is of item-table size (_ShardedItemSide)
+           chunks: column chunks per collective of the item-side node (0 = by size, see n_chunks)."""
         super().__init__()
         self.bk, self.cfg, self.ush, self.ish, self.group = backend, cfg, ush, ish, group
+        self.scheme, self.chunks = scheme, int(chunks)
         self.img_w = nn.Parameter(state["image_trans.weight"].clone())
         self.img_b = nn.Parameter(state["image_trans.bias"].clone())
         self.txt_w = nn.Parameter(state["text_trans.weight"].clone())
@@ -393,15 +442,36 @@ class ShardedMMSSL(nn.Module):
             u = bk.l2norm_rows(self._fusion(img_uid, txt_uid), self.E_u, c.id_cat_rate)
             i = bk.l2norm_rows(self._fusion(img_iid, txt_iid), self.E_i, c.id_cat_rate)
         d = c.embed_size
-        u_g, i_g, ss, MI, MU = _ShardedHotForward.apply(
-            2, scale, keep, ui, iu, c.n_ui_layers, c.model_cat_rate, bk, self.group, u, i,
-            self.image_feats, self.text_feats, self.img_w, self.txt_w, self.img_b, self.txt_b)
+        if getattr(self, "scheme", "gather-both") == "item-side" and not _solo(self.group):
+            u_g, i_g, ss, MI, MU = _ShardedItemSide.apply(
+                2, scale, keep, ui, iu, c.n_ui_layers, c.model_cat_rate, bk, self.group, self.n_chunks(2), u, i,
+                self.image_feats, self.text_feats, self.img_w, self.txt_w, self.img_b, self.txt_b)
+        else:       # (one rank without forced collectives: both schemes are the same computation)
+            u_g, i_g, ss, MI, MU = _ShardedHotForward.apply(
+                2, scale, keep, ui, iu, c.n_ui_layers, c.model_cat_rate, bk, self.group, u, i,
+                self.image_feats, self.text_feats, self.img_w, self.txt_w, self.img_b, self.txt_b)
         self._feat_ss_local = ss
         img_item, txt_item, img_user, txt_user = MI[:, :d], MI[:, d:], MU[:, :d], MU[:, d:]
         return (u_g, i_g, img_item, txt_item, img_user, txt_user, u_g, i_g, img_uid, txt_uid, img_iid, txt_iid)
 
     def replicated_parameters(self):
         return [self.img_w, self.img_b, self.txt_w, self.txt_b, self.w_cat]
+
+    CHUNK_BYTES = 64 << 20
+
+    def n_chunks(self, nm):
+        """Column chunks per collective of the item-side node. Explicit (`chunks` > 0) or by size: collectives below
+        CHUNK_BYTES (the whole gathered item table at width d) are latency-bound and stay whole - every chunk is one more
+        RCCL launch - larger ones are cut in two (chunk 0's product runs under chunk 1's transfer; 2 x 64-wide at
+        configs[4]'s d = 128 keeps the SpMM on its 256-byte-row flavour)."""
+        d = self.cfg.embed_size
+        ok = getattr(self.bk, "chunk_ok", lambda w, n: w % n == 0)
+        nc = int(getattr(self, "chunks", 0))
+        if nc <= 0:
+            nc = 2 if self.ish.n_pad * d * 4 >= self.CHUNK_BYTES else 1
+        while nc > 1 and not (ok(d, nc) and ok(nm * d, nc)):
+            nc -= 1
+        return max(nc, 1)
 
     def _gather(self, x):
         return AllGatherRows.apply(x, self.group)
@@ -437,12 +507,21 @@ class ShardedMMSSL(nn.Module):
         x_txt = bk.linear(self.text_feats, self.txt_w, self.txt_b, km_t, scale)
         # one gather for both modalities (columns concatenated): halves the collective count
         d = c.embed_size
+        item_side = getattr(self, "scheme", "gather-both") == "item-side"
+        if item_side:        # A_iu . X_u = reduce_scatter(A_iu[:, U_r] . X_u_r): `iu` is the column block of A_iu
+            to_items = lambda x, epi=bk.EPI_NONE: ReduceScatterRows.apply(bk.spmm(iu, x), self.ish.per, self.group)   # noqa: E731
+        else:
+            to_items = lambda x, epi=bk.EPI_NONE: bk.spmm(iu, self._gather(x), epi)                                   # noqa: E731
         x_both = self._gather(torch.cat((x_img, x_txt), 1))
         img_user = bk.spmm(ui, x_both[:, :d].contiguous())
         txt_user = bk.spmm(ui, x_both[:, d:].contiguous())
-        u_both = self._gather(torch.cat((img_user, txt_user), 1))
-        img_item = bk.spmm(iu, u_both[:, :d].contiguous())
-        txt_item = bk.spmm(iu, u_both[:, d:].contiguous())
+        if item_side:
+            both = to_items(torch.cat((img_user, txt_user), 1))
+            img_item, txt_item = both[:, :d], both[:, d:]
+        else:
+            u_both = self._gather(torch.cat((img_user, txt_user), 1))
+            img_item = bk.spmm(iu, u_both[:, :d].contiguous())
+            txt_item = bk.spmm(iu, u_both[:, d:].contiguous())
         if modal_empty:
             # empty modal graphs (the reference's steady state): the id views are exact zeros
             zu = torch.zeros_like(self.E_u)
@@ -461,7 +540,9 @@ class ShardedMMSSL(nn.Module):
         for layer in range(c.n_ui_layers):
             epi = bk.EPI_SOFTMAX if layer == c.n_ui_layers - 1 else bk.EPI_NONE
             u = bk.spmm(ui, self._gather(i), epi)
-            i = bk.spmm(iu, self._gather(u), epi)
+            i = to_items(u, epi)
+            if item_side and epi == bk.EPI_SOFTMAX:
+                i = bk.softmax_rows(i)           # whole rows exist only after the reduce-scatter
             u_sum = u_sum + u
             i_sum = i_sum + i
         inv = 1.0 / (c.n_ui_layers + 1)
@@ -676,6 +757,7 @@ class _ShardedHotForward(torch.autograd.Function):
             # from here on the gradient of u_0 exists; a step object may update the (sharded, never all-reduced) embedding
             # tables on the side stream as soon as the GCN chain there has produced the gradient of i_0
             bk.after_fuse_bwd = st.main.record_event()
+            bk.tables_stream = st.side
             g_u0.record_stream(st.side)
             for t in (uG, iG, Gu, Gi):
                 t.record_stream(st.side)
@@ -742,7 +824,273 @@ class _ShardedHotForward(torch.autograd.Function):
         if st.side is not None:
             gi.record_stream(st.main)
         grads_b = [(gb[k] if (gb is not None and has_b[k]) else None) for k in range(nm)]
+        bk.table_grads = (g_u0, gi)
         return (None,) * 9 + (g_u0, gi) + (None,) * nm + tuple(gW) + tuple(grads_b)
+
+
+def _reduce_scatter_raw(full, per, group):
+    _log_comm("reduce_scatter", full)
+    return _reduce_scatter_sum(full, per, group)
+
+
+class _Lanes:
+    """Column-chunk lanes. A d-wide propagation is nc independent d/nc-wide ones (LightGCN layers have no cross-column
+    term, Models.py:201-211): lane c's whole chain - collective, product, product, collective, ... - is issued on stream c.
+    RCCL runs the collectives of one process group on its own stream in ISSUE order, so while lane c's product runs, lane
+    c+1's collective is on the links. Lanes meet only where a row is needed whole (the last layer's softmax) and at the
+    end. On CPU (gloo tests) and for nc == 1 the lanes are plain loops."""
+
+    def __init__(self, bk, ref, n, base=0, first_is_current=False):
+        self.n = int(n)
+        self.cuda = bool(ref.is_cuda and hasattr(bk, "lane_streams"))
+        self.main, self.streams = None, [None] * self.n
+        if self.cuda:
+            self.main = torch.cuda.current_stream(ref.device)
+            pool = bk.lane_streams(ref.device, base + self.n)
+            self.streams = [self.main if (first_is_current and c == 0) else pool[base + c] for c in range(self.n)]
+
+    def on(self, c):
+        import contextlib
+        return torch.cuda.stream(self.streams[c]) if self.cuda else contextlib.nullcontext()
+
+    def fork(self):
+        if self.cuda:
+            for st in self.streams:
+                if st is not self.main:
+                    st.wait_stream(self.main)
+
+    def join(self):
+        if self.cuda:
+            for st in self.streams:
+                if st is not self.main:
+                    self.main.wait_stream(st)
+
+    def meet(self):
+        """Lane 0 waits for all lanes (then runs the whole-row kernel); `part` lets the others continue behind it."""
+        if self.cuda:
+            for st in self.streams[1:]:
+                self.streams[0].wait_stream(st)
+
+    def part(self):
+        if self.cuda:
+            for st in self.streams[1:]:
+                st.wait_stream(self.streams[0])
+
+    def uses(self, t, lanes=None):
+        """`t` (allocated on the current stream) is read / written on the lanes: tell the caching allocator."""
+        if self.cuda and t is not None and t.is_cuda:
+            for st in (self.streams if lanes is None else [self.streams[c] for c in lanes]):
+                if st is not self.main:
+                    t.record_stream(st)
+
+
+def _chunks_of(t, nc):
+    """Column chunks of a row-major [rows, w] tensor as views (row pitch w)."""
+    w = t.shape[1] // nc
+    return [t[:, c * w:(c + 1) * w] for c in range(nc)] if nc > 1 else [t]
+
+
+def _contig_chunks(t, nc):
+    return [x.contiguous() for x in _chunks_of(t, nc)]
+
+
+class _ShardedItemSide(torch.autograd.Function):
+    """The packed hot node over USER-ROW BLOCKS ONLY ("item-side" scheme). Rank r holds the edges of its users twice:
+    `ui` = A_ui[U_r, :] ([per_u, I_pad], global item columns) and `iuT` = A_iu[:, U_r] ([I_pad, per_u]). Then
+
+        u_r   = A_ui[U_r, :] . all_gather(i_r)                  gather of item-table size (north_star's all-gather
+                                                                  before every propagation layer)
+        i_r   = reduce_scatter( A_iu[:, U_r] . u_r )             local partial products over ALL items, summed across ranks
+        backward: g(u_r) = A_iu[:, U_r]^T . all_gather(g(i_r)),  g(i_r) = reduce_scatter( A_ui[U_r, :]^T . g(u_r) )
+
+    every collective moves ITEM-table bytes (the user table, twice as large for every shape of BASELINE.json, never
+    travels): -33 % bytes per step against gathering both tables. The packed modal chain X -> MU -> MI goes the same way.
+
+    Column chunks (`nc`): every collective and the products on either side of it are cut into nc column chunks on nc
+    lanes (see _Lanes). User-side tables stay row-major [per_u, w]; a lane's products read / write its column chunk in
+    place (row-pitched operands, mmssl_spmm_ld_f32). Item-side chunks are contiguous [per_i, w / nc] buffers - what a
+    reduce-scatter delivers and an all-gather takes - and are put side by side once per layer for the fuse kernel.
+    The last layer's softmax needs whole rows: a launch of its own where the lanes meet (same arithmetic as the SpMM's
+    fused epilogue)."""
+
+    @staticmethod
+    def forward(ctx, nm, scale, keep, ui, iuT, n_layers, r, bk, group, nc, u0, i0, *flat):
+        Fs, Ws, bs = flat[:nm], flat[nm:2 * nm], flat[2 * nm:3 * nm]
+        draw_p, ext_tick = 0.0, False
+        if isinstance(keep, tuple):                  # ("draw", p, external_tick): fresh masks from the device generator
+            _, draw_p, ext_tick = keep
+            keep = None
+        g = group
+        world = dist.get_world_size(g)
+        per_u, per_i, d = u0.shape[0], i0.shape[0], u0.shape[1]
+        wm = nm * d
+        twin = (lambda p, k: p.twin(k)) if hasattr(ui, "twin") else (lambda p, k: p)
+        new = lambda rows, w: torch.empty((rows, w), dtype=torch.float32, device=u0.device)      # noqa: E731
+        G = _Lanes(bk, u0, nc)                                    # GCN chain: nc side lanes
+        M = _Lanes(bk, u0, nc, base=nc, first_is_current=True)    # modal chain: the current stream + nc - 1 lanes
+        G.fork()
+        X, keep = bk.proj_forward(list(Fs), list(Ws), list(bs), keep, scale, draw_p, ext_tick)      # [per_i, nm d], current stream
+        MU, MI_c = new(per_u, wm), [None] * nc
+        us, its = [u0], [i0]
+        i_c = [i0]
+        if nc > 1:                                # a lane's chunk copy runs on the lane (i0 exists before the fork)
+            i_c = []
+            for c, v in enumerate(_chunks_of(i0, nc)):
+                with G.on(c):
+                    i_c.append(v.contiguous())
+        # the modal chain's collectives are issued behind the GCN layers modal_at (RCCL runs collectives in issue order: a
+        # gather that waits for the projection GEMM must not sit in front of the first GCN layers' collectives)
+        modal_at = (max(0, n_layers - 2), n_layers - 1)
+
+        def modal_gather():
+            M.fork()
+            M.uses(MU)
+            M.uses(X)
+            for c, v in enumerate(_chunks_of(X, nc)):
+                with M.on(c):
+                    X_full = _all_gather_raw(v.contiguous() if nc > 1 else v, g)
+                    bk.spmm_raw(twin(ui, 10 + c), False, X_full, bk.EPI_NONE, out=_chunks_of(MU, nc)[c])
+
+        def modal_scatter():
+            for c in range(nc):
+                with M.on(c):
+                    PM = bk.spmm_raw(twin(iuT, 10 + c), False, _chunks_of(MU, nc)[c], bk.EPI_NONE)
+                    MI_c[c] = _reduce_scatter_raw(PM, per_i, g)
+
+        for l in range(n_layers):
+            last = l == n_layers - 1
+            u = new(per_u, d)
+            G.uses(u)
+            u_v = _chunks_of(u, nc)
+            for c in range(nc):                 # item rows -> user rows: gather, product into the lane's column chunk
+                with G.on(c):
+                    i_full = _all_gather_raw(i_c[c], g)
+                    bk.spmm_raw(twin(ui, 2 + c), False, i_full, bk.EPI_NONE, out=u_v[c])
+            if last:
+                G.meet()
+                with G.on(0):
+                    bk.softmax_rows_(u)
+                G.part()
+            i_n = [None] * nc
+            for c in range(nc):                 # user rows -> ALL item rows (partial), summed into the owners' rows
+                with G.on(c):
+                    P = bk.spmm_raw(twin(iuT, 2 + c), False, u_v[c], bk.EPI_NONE)
+                    i_n[c] = _reduce_scatter_raw(P, per_i, g)
+            if nc > 1 or last:
+                G.meet()
+            with G.on(0):
+                i = torch.cat(i_n, 1) if nc > 1 else i_n[0]
+                if last:
+                    bk.softmax_rows_(i)
+            i_c = i_n
+            us.append(u)
+            its.append(i)
+            if l == modal_at[0]:
+                modal_gather()
+            if l == modal_at[1]:
+                modal_scatter()
+        M.meet()
+        MI = torch.cat(MI_c, 1) if nc > 1 else MI_c[0]
+        M.join()
+        G.join()
+        if G.cuda:
+            for t_ in us[1:] + its[1:]:
+                t_.record_stream(G.main)
+        inv = 1.0 / (n_layers + 1)
+        u_g, i_g, ss = bk.fuse_fwd(us, MU, its, MI, inv, nm, r)
+        ctx.save_for_backward(MU, MI, us[-1], its[-1], keep, *Fs)
+        ctx.cfg = (nm, float(scale), ui, iuT, n_layers, float(r), inv, bk, g, [b is not None for b in bs], nc)
+        ctx.set_materialize_grads(False)
+        return u_g, i_g, ss, MI, MU
+
+    @staticmethod
+    def backward(ctx, Gu, Gi, g_ss, G_MI, G_MU):
+        MU, MI, uG, iG, keep = ctx.saved_tensors[:5]
+        Fs = ctx.saved_tensors[5:]
+        nm, scale, ui, iuT, n_layers, r, inv, bk, g, has_b, nc = ctx.cfg
+        per_u, per_i, d = MU.shape[0], MI.shape[0], uG.shape[1]
+        wm = nm * d
+        Gu = Gu.contiguous() if Gu is not None else torch.zeros_like(uG)
+        Gi = Gi.contiguous() if Gi is not None else torch.zeros_like(iG)
+        g_ss = g_ss.contiguous().to(torch.float32) if g_ss is not None else None
+        G_MI = G_MI.contiguous() if G_MI is not None else None
+        G_MU = G_MU.contiguous() if G_MU is not None else None
+        twin = (lambda p, k: p.twin(k)) if hasattr(ui, "twin") else (lambda p, k: p)
+        new = lambda rows, w: torch.empty((rows, w), dtype=torch.float32, device=Gu.device)      # noqa: E731
+        G = _Lanes(bk, Gu, nc)
+        M = _Lanes(bk, Gu, nc, base=nc, first_is_current=True)
+        G.fork()
+        gMU, g_u0, gMI = bk.fuse_bwd(MU, Gu, G_MU, MI, Gi, G_MI, nm, r, inv, g_ss)         # current stream
+        if G.cuda:
+            # from here on the gradient of u_0 exists; the gradient of i_0 completes on GCN lane 0: a step object may
+            # update the (sharded, never all-reduced) embedding tables there while the weight gradient still runs
+            bk.after_fuse_bwd = G.main.record_event()
+            bk.tables_stream = G.streams[0]
+            for t_ in (uG, iG, Gu, Gi, g_u0):
+                G.uses(t_)
+        M.fork()
+        # ---- modal chain, first half: t = gMU + A_iu[:, U_r]^T . all_gather(gMI)
+        t = new(per_u, wm)
+        for t_ in (t, gMU, gMI):
+            M.uses(t_)
+        for c, v in enumerate(_chunks_of(gMI, nc)):
+            with M.on(c):
+                gPM = _all_gather_raw(v.contiguous() if nc > 1 else v, g)
+                bk.spmm_raw(twin(iuT, 10 + c), True, gPM, bk.EPI_AXPY, _chunks_of(gMU, nc)[c], 1.0, out=_chunks_of(t, nc)[c])
+        # ---- GCN chain, last layer
+        with G.on(0):
+            gi = bk.softmax_rows_bwd(iG, Gi, inv)                   # g before the item-side softmax, [per_i, d]
+            gi_c = _contig_chunks(gi, nc) if nc > 1 else [gi]
+        for c in range(1, nc):
+            G.uses(gi_c[c], [c])
+        G.part()
+        gX_c = [None] * nc
+        for l in range(n_layers, 0, -1):
+            last = l == n_layers
+            gu = new(per_u, d)
+            G.uses(gu)
+            gu_v, Gu_v = _chunks_of(gu, nc), _chunks_of(Gu, nc)
+            for c in range(nc):                 # g(u_l) = inv Gu + A_iu[:, U_r]^T . all_gather(g(i_l))
+                with G.on(c):
+                    gP = _all_gather_raw(gi_c[c], g)
+                    bk.spmm_raw(twin(iuT, 2 + c), True, gP, bk.EPI_AXPY, Gu_v[c], inv, out=gu_v[c])
+            if last:
+                G.meet()
+                with G.on(0):
+                    gu = bk.softmax_rows_bwd(uG, gu, 1.0)
+                    gu_v = _chunks_of(gu, nc)
+                G.uses(gu)
+                G.part()
+            if l == n_layers:
+                # ---- modal chain, second half, issued behind the GCN chain's first gathers:
+                # gX = dropout-backward( reduce_scatter( A_ui[U_r, :]^T . t ) )
+                for c in range(nc):
+                    with M.on(c):
+                        part = bk.spmm_raw(twin(ui, 10 + c), True, _chunks_of(t, nc)[c], bk.EPI_NONE)
+                        gX_c[c] = _reduce_scatter_raw(part, per_i, g)
+            gi_n = [None] * nc
+            Gi_v = _chunks_of(Gi, nc)
+            for c in range(nc):                 # g(i_{l-1}) = inv Gi + reduce_scatter( A_ui[U_r, :]^T . g(u_l) )
+                with G.on(c):
+                    part = bk.spmm_raw(twin(ui, 2 + c), True, gu_v[c], bk.EPI_NONE)
+                    gi_n[c] = _reduce_scatter_raw(part, per_i, g).add_(Gi_v[c], alpha=inv)
+            gi_c = gi_n
+        # ---- the weight gradient (current stream) next to the rest of the GCN chain
+        M.meet()
+        gX = torch.cat(gX_c, 1) if nc > 1 else gX_c[0]
+        if keep is not None:
+            gX = bk.mask_packed(gX, keep, d, scale)
+        gW, gb = bk.proj_wgrad(gX, list(Fs), any(has_b))
+        G.meet()
+        with G.on(0):
+            gi0 = torch.cat(gi_c, 1) if nc > 1 else gi_c[0]
+        M.join()
+        G.join()
+        if G.cuda:
+            gi0.record_stream(G.main)
+        grads_b = [(gb[k] if (gb is not None and has_b[k]) else None) for k in range(nm)]
+        bk.table_grads = (g_u0, gi0)
+        return (None,) * 10 + (g_u0, gi0) + (None,) * nm + tuple(gW) + tuple(grads_b)
 
 
 class ShardedHotPathStep:
@@ -845,14 +1193,19 @@ class ShardedHotPathStep:
         for p in self.model.parameters():
             p.grad = None
         torch.autograd.backward(roots, grads)
-        side = getattr(self, "_tables_early", None)
+        side = getattr(self.model.bk, "tables_stream", None) if getattr(self, "_tables_early", False) else None
         if side is not None and self.optimizer is not None and self.model.bk.after_fuse_bwd is not None:
             m = self.model
             main = torch.cuda.current_stream(self.loss.device)
             side.wait_event(m.bk.after_fuse_bwd)
+            # only ahead of the current stream if the tables' .grad ARE the node's buffers (see hotpath.HotPathStep._step)
+            tg = getattr(m.bk, "table_grads", None)
+            if tg is None or any(p.grad is None or p.grad.data_ptr() != g.data_ptr() for p, g in zip((m.E_u, m.E_i), tg)):
+                side.wait_event(main.record_event())
             with torch.cuda.stream(side):
                 self.optimizer.step(external_tick=True, exclude=m.replicated_parameters())
             self._tables_join = (main, side)
+            self._tables_joined = True
         # replicated dense parameters: partial (local-row) gradients -> ONE all-reduce of a persistent flat bucket that also
         # carries this rank's regulariser share in its last slot (no second collective for one scalar); the gradients are
         # packed by one multi-tensor copy and afterwards ARE views of the bucket (no copy back)
@@ -903,13 +1256,15 @@ class ShardedHotPathStep:
         # the gradient bucket's all-reduce are still under way; only the replicated tensors are updated behind the
         # all-reduce on the step's own stream (same rule, same counter: the loss tail ticked it once for the step).
         bk = m.bk
-        side = bk.side_streams(self.loss.device)[2] if (own_ticks and self.modal_empty and hasattr(bk, "side_streams")) else None
-        self._tables_early = side
+        early = bool(own_ticks and self.modal_empty and hasattr(bk, "side_streams"))
+        self._tables_early = early
+        bk.after_fuse_bwd, bk.table_grads, bk.tables_stream = None, None, None
+        self._tables_joined = False
         try:
             total = self.backward()
             if self.optimizer is not None:
                 if own_ticks:
-                    self.optimizer.step(external_tick=True, exclude=[m.E_u, m.E_i] if side is not None else None)
+                    self.optimizer.step(external_tick=True, exclude=[m.E_u, m.E_i] if self._tables_joined else None)
                 else:
                     self.optimizer.step()
             tj, self._tables_join = getattr(self, "_tables_join", None), None
@@ -917,7 +1272,7 @@ class ShardedHotPathStep:
                 tj[0].wait_stream(tj[1])
         finally:
             self._ticks = None
-            self._tables_early = None
+            self._tables_early = False
             self.model._external_ticks = False
         return total
 

@@ -42,6 +42,9 @@ class HotCtx:
         #                               small launches that must precede the loss section but not the projection)
         self.after_fuse_bwd = None    # event on the current stream after the backward's fuse kernel: from there on the
         #                               gradient of u_0 exists (the GCN chain's side stream holds the one of i_0)
+        self.table_grads = None       # (g_u0, g_i0) as the node's backward returned them: a step object that updates the
+        #                               tables on the side stream checks that autograd STOLE these buffers as .grad
+        #                               (a cloned gradient would be written by a copy on the current stream)
         self.batch_rows = None        # (user rows [B], item rows [2B]) int64 device tensors: the ONLY rows of the fused
         #                               tables the caller will read (a training step's loss). The forward then computes
         #                               just those rows (the other rows of u_g / i_g stay UNDEFINED); the regulariser's
@@ -231,6 +234,7 @@ class _HotNode(torch.autograd.Function):
             main.wait_stream(sC)
             gi.record_stream(main)
         grads_b = [(gb[k] if (gb is not None and has_b[k]) else None) for k in range(nm)]
+        hot.table_grads = (g_u0, gi)
         return (None,) * 9 + (g_u0, gi) + (None,) * nm + tuple(gW) + tuple(grads_b)
 
 

@@ -55,18 +55,30 @@ class HotPathStep:
         self.parts = {}
         self._graph = None
         self.eager_loss = bool(eager_loss)
-        self.fuse_adam = bool(fuse_adam)
-        self.batch_rows = bool(batch_rows)
+        # Only the PACKED hot node (hotnode._HotNode: two modalities, a modal width the SpMM has, feature widths the
+        # grouped projection takes) consumes the step's hand-offs: the fused AdamW slots of the projection weights, the
+        # step-owned RNG tick of its mask draw, the batch-rows fuse. A model that MMSSL.forward routes through
+        # _forward_multi (a third modality, d = 128, a 20-wide feature ...) gets none of them: every parameter is
+        # updated by the optimiser launch and ops.dropout_masks ticks the generator itself.
+        from .hotnode import packed_supported
+        self._packed = (not getattr(model, "extra_names", None)
+                        and packed_supported([model.image_feats.shape[1], model.text_feats.shape[1]], model.n_items,
+                                             args.embed_size))
+        self.fuse_adam = bool(fuse_adam) and self._packed
+        self.batch_rows = bool(batch_rows) and self._packed
         self.hot = HotCtx(dev, overlap=overlap)
         self._proj = [model.image_trans, model.text_trans]
         # tables first: with empty modal graphs their gradients are complete as soon as the GCN chain is
-        self._modal_empty = (not getattr(model, "extra_names", None)
+        self._modal_empty = (self._packed
                              and all(getattr(g, "nnz", 1) == 0 and not hasattr(g, "_pair") for g in self.graphs[2:6]))
         self._tables_early = self.fuse_adam and self.hot.overlap and self._modal_empty
         # parity runs inject fixed uint8 dropout keep-masks (img, txt), each [n_items, d]; None = drawn inside the
         # projection's epilogue (fresh masks on every replay)
         self.keep_masks = None
         self._ring = None
+        # completed steps as a uint64 (the batch ring's slot index; the optimiser's own counter is an fp32 that stops
+        # counting at 2^24): advanced by the loss tail's tick list together with the RNG launch counter
+        self._steps_done = torch.zeros(1, dtype=torch.int64, device=dev)
         # ONE stream for everything this object launches (eager steps, capture, replays): autograd
         # binds each parameter's AccumulateGrad node to the stream of its first backward, and a
         # later capture on a different stream would have to synchronise across streams.
@@ -98,7 +110,7 @@ class HotPathStep:
     def _select_batch(self):
         dev = self.loss.device
         rc = ops._lib.lib().mmssl_select_slot_i64(self._ring.data_ptr(), self._ring.shape[0], 3 * self.batch_size,
-                                                  self.optimizer.step_counter(0, dev).data_ptr(), self.batch.data_ptr(),
+                                                  self._steps_done.data_ptr(), self.batch.data_ptr(),
                                                   ops._lib.stream_ptr())
         ops._lib.check(rc, "mmssl_select_slot_i64")
 
@@ -130,7 +142,7 @@ class HotPathStep:
         # batch-rows form: the forward fuses the batch's rows only and sums |.|^2 on the side stream (see __init__).
         # Otherwise it leaves its regulariser sum unreduced and the loss tail reduces it (one launch less in front of the
         # loss chain) - only valid because the very next consumer of `ss` IS that tail, which checks it.
-        rows_mode = self.batch_rows and not getattr(m, "extra_names", None)
+        rows_mode = self.batch_rows
         hot.defer_ss, hot.ss_parts, hot.prefill_buf = (not rows_mode), None, None
         hot.reg_parts, hot.reg_target = None, None
         hot.batch_rows = (self.users, self.batch[1:3].reshape(-1)) if rows_mode else None
@@ -159,7 +171,33 @@ class HotPathStep:
         with torch.cuda.stream(self.stream):
             return self._step()
 
+    def _step_multi(self):
+        """The step of a model with further modalities (MMSSL(extra_feats=...), BASELINE configs[1]'s V/A/T): the loss over
+        EVERY modality (one InfoNCE term and two regulariser tables per modality: oracle generator_loss_multi) out of the
+        differentiable HIP ops, ordinary autograd, one AdamW launch over all parameters. None of the packed node's
+        hand-offs apply here."""
+        m = self.model
+        self.optimizer.zero_grad(set_to_none=True)
+        out = m(*self.graphs, keep_masks=self.keep_masks, extra_graphs=getattr(self, "extra_graphs", None))
+        n_extra = (len(out) - 12) // 4
+        mf, emb = ops.bpr_gather(out[0], out[1], self.users, self.pos, self.neg, self.decay, self.batch_size)
+        feats = [2, 3, 4, 5] + [12 + 4 * k + j for k in range(n_extra) for j in (0, 1)]
+        views = [8, 9] + [14 + 4 * k for k in range(n_extra)]
+        ss = ops.sumsq(out[feats[0]])
+        for k in feats[1:]:
+            ss = ss + ops.sumsq(out[k])
+        cl = ops.infonce(out[views[0]], out[0], args.tau, idx=self.users)
+        for k in views[1:]:
+            cl = cl + ops.infonce(out[k], out[0], args.tau, idx=self.users)
+        total = mf + emb + (args.feat_reg_decay * 0.5 / m.n_items) * ss + args.cl_rate * cl
+        total.backward()
+        self.optimizer.step()
+        self.loss.copy_(total.detach())
+        return self.loss
+
     def _step(self):
+        if getattr(self.model, "extra_names", None):
+            return self._step_multi()
         self.optimizer.zero_grad(set_to_none=True)
         # the step owns its counters: the projection's mask draw and the AdamW launch run without their one-thread tick
         # kernels, the loss section's last launch (between them in stream order) advances the RNG launch counter and
@@ -167,7 +205,7 @@ class HotPathStep:
         dev = self.loss.device
         hot = self.hot
         counters = [self.optimizer.step_counter(gi, dev).data_ptr() for gi in range(len(self.optimizer.param_groups))]
-        ticks = (counters, [ops._rng_state(dev).data_ptr() + 8])
+        ticks = (counters, [self._steps_done.data_ptr()] + ([ops._rng_state(dev).data_ptr() + 8] if self._packed else []))
         hot.external_ticks, hot.lazy_anchors = True, True
         hot.side_prologue = self._select_batch if self._ring is not None else None
         fused = []
@@ -187,6 +225,14 @@ class HotPathStep:
                 main = torch.cuda.current_stream(dev)
                 sC = hot.streams()[1]
                 sC.wait_event(hot.after_fuse_bwd)
+                # the side stream may only run ahead of the current one if the tables' .grad ARE the node's buffers
+                # (AccumulateGrad stole them); a cloned / accumulated gradient was written by a launch on the current
+                # stream, which the update then has to wait for. Decided at capture time for a replayed graph.
+                tg = hot.table_grads
+                m = self.model
+                if tg is None or any(p.grad is None or p.grad.data_ptr() != g.data_ptr()
+                                     for p, g in zip((m.user_id_embedding.weight, m.item_id_embedding.weight), tg)):
+                    sC.wait_event(main.record_event())
                 with torch.cuda.stream(sC):
                     self.optimizer.step(external_tick=True, exclude=fused)
                 main.wait_stream(sC)
@@ -194,7 +240,7 @@ class HotPathStep:
                 self.optimizer.step(external_tick=True, exclude=fused)
         finally:
             hot.external_ticks, hot.lazy_anchors = False, False
-            hot.anchored, hot.adam, hot.after_fuse_bwd, hot.side_prologue = [], None, None, None
+            hot.anchored, hot.adam, hot.after_fuse_bwd, hot.side_prologue, hot.table_grads = [], None, None, None, None
         return self.loss
 
     # ---- hipGraph capture ---------------------------------------------------------------------

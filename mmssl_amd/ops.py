@@ -26,7 +26,9 @@ STATS = {"enabled": False, "spmm_launches": 0, "edge_layers": 0, "spmm_bytes": 0
 
 def _count_spmm(plan, rows, d):
     STATS["spmm_launches"] += 1
-    STATS["edge_layers"] += plan.nnz * (max(1, d // STATS["unit_d"]) if STATS["unit_d"] else 1)
+    # a launch over a column CHUNK (width d < unit_d: the sharded step's chunked propagation) counts its fraction
+    # (a float sum of exact binary fractions; readers round it)
+    STATS["edge_layers"] += plan.nnz * ((d / STATS["unit_d"]) if STATS["unit_d"] else 1)
     STATS["spmm_bytes"] += plan.nnz * (8 + 4 * d) + rows * 4 * d + (rows + 1) * 4
 _NORM_EPS = 1e-12        # F.normalize default eps
 
@@ -46,7 +48,9 @@ def _ptr(t):
 # ---------------------------------------------------------------------------------------
 # SpMM                                    Models.py:69-73 (mm), :177-186, :201-211
 # ---------------------------------------------------------------------------------------
-def _spmm_raw(plan, transpose, X, epilogue, Z=None, alpha=0.0, S=None):
+def _spmm_raw(plan, transpose, X, epilogue, Z=None, alpha=0.0, S=None, out=None):
+    """Y = op(A) . X with a store epilogue. X, Z and `out` may be COLUMN CHUNKS of wider row-major tables (views with
+    stride(1) == 1 and a row pitch > their width: mmssl_spmm_ld_f32, plain product or AXPY; Z must have out's pitch)."""
     rows = plan.shape[1] if transpose else plan.shape[0]
     cols = plan.shape[0] if transpose else plan.shape[1]
     if X.dim() != 2 or X.shape[0] != cols:
@@ -54,7 +58,23 @@ def _spmm_raw(plan, transpose, X, epilogue, Z=None, alpha=0.0, S=None):
     d = X.shape[1]
     if STATS["enabled"]:
         _count_spmm(plan, rows, d)
-    Y = torch.empty((rows, d), dtype=torch.float32, device=X.device)
+    if out is not None and (tuple(out.shape) != (rows, d) or out.dtype != torch.float32 or out.device != X.device):
+        raise _lib.MmsslError("spmm: `out` must be a [%d, %d] fp32 tensor on X's device" % (rows, d))
+    pitched = [t for t in (X, out, Z) if t is not None and t.shape[0] > 1 and t.stride(0) != t.shape[1]]
+    if pitched:
+        if epilogue not in (EPI_NONE, EPI_AXPY) or S is not None or any(t.stride(1) != 1 for t in pitched):
+            raise _lib.MmsslError("spmm: column-chunk operands take the plain product or the AXPY epilogue only")
+        Y = out if out is not None else torch.empty((rows, d), dtype=torch.float32, device=X.device)
+        ldx = X.stride(0) if X.shape[0] > 1 else d
+        ldy = Y.stride(0) if rows > 1 else d
+        if Z is not None and rows > 1 and Z.stride(0) != ldy:
+            raise _lib.MmsslError("spmm: Z must have the row pitch of the output")
+        ws = plan.workspace(transpose, d)
+        rc = _lib.lib().mmssl_spmm_ld_f32(plan.handle, int(transpose), _ptr(X), ldx, d, _ptr(Y), ldy, epilogue, _ptr(Z),
+                                          float(alpha), _ptr(ws), ws.numel() * 4, _lib.stream_ptr())
+        _lib.check(rc, "mmssl_spmm_ld_f32")
+        return Y
+    Y = out if out is not None else torch.empty((rows, d), dtype=torch.float32, device=X.device)
     ws = plan.workspace(transpose, d)
     rc = _lib.lib().mmssl_spmm_ex_f32(plan.handle, int(transpose), _ptr(X), d, _ptr(Y), epilogue, _ptr(Z),
                                       float(alpha), _ptr(S), _ptr(ws), ws.numel() * 4, _lib.stream_ptr())
@@ -92,6 +112,33 @@ def spmm(plan, X, epilogue=EPI_NONE, transpose=False):
 # ---------------------------------------------------------------------------------------
 # row kernels            F.normalize Models.py:196-197,217-218; main.py:212-213
 # ---------------------------------------------------------------------------------------
+def softmax_rows(X, out=None):
+    """softmax over the features of every row (the MMSSL_EPI_SOFTMAX store epilogue as a launch of its own; in place with
+    out=X)."""
+    Y = torch.empty_like(X) if out is None else out
+    rc = _lib.lib().mmssl_softmax_rows_f32(_ptr(X), X.shape[0], X.shape[1], _ptr(Y), _lib.stream_ptr())
+    _lib.check(rc, "mmssl_softmax_rows_f32")
+    return Y
+
+
+class _SoftmaxRows(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, X):
+        Y = softmax_rows(_chk(X, "X"))
+        ctx.save_for_backward(Y)
+        return Y
+
+    @staticmethod
+    def backward(ctx, gY):
+        (Y,) = ctx.saved_tensors
+        return softmax_rows_bwd(Y, _chk(gY, "gY"))
+
+
+def softmax_rows_fn(X):
+    """Differentiable row softmax (torch.softmax(X, -1), Models.py:203-204) on the row kernels."""
+    return _SoftmaxRows.apply(X)
+
+
 def softmax_rows_bwd(Y, gY, scale=1.0):
     gX = torch.empty_like(Y)
     rc = _lib.lib().mmssl_softmax_rows_bwd_f32(_ptr(Y), _ptr(gY), float(scale), Y.shape[0], Y.shape[1], _ptr(gX),
@@ -562,6 +609,10 @@ def topk_rows(X, k, values=False):
     # equal blocks of at most TOPK_MAX_COLS columns, each a multiple of 4 wide (16-byte aligned starts)
     nblk = -(-n // TOPK_MAX_COLS)
     width = (-(-n // nblk) + 3) // 4 * 4
+    # every block is at least n / nblk - 4 nblk > TOPK_MAX_K columns wide, so no block pads its winners with (-inf, -1)
+    # slots that could tie with a later block's real -inf columns (the where() below only guards that invariant)
+    if n - (nblk - 1) * width < k:
+        raise _lib.MmsslError("topk_rows: column block narrower than k")
     cand_i, cand_v = [], []
     for c0 in range(0, n, width):
         i, v = _topk_launch(X[:, c0:min(n, c0 + width)], k, True)

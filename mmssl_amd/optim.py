@@ -62,6 +62,7 @@ class FusedAdamW(torch.optim.Optimizer):
                 "beta2": float(b2), "eps": float(group["eps"]), "weight_decay": float(group["weight_decay"]),
                 "pre_ticked": bool(pre_ticked)}
 
+    @torch.no_grad()
     def step(self, closure=None, groups=None, sliced=None, external_tick=False, exclude=None):
         """`groups`: optional iterable of param-group indices to update (each group has its own device step
         counter, so groups may be stepped at different points of one iteration).

@@ -41,14 +41,9 @@ def _rel(a, b):
     return float((a - b).abs().max() / (b.abs().max() + 1e-30))
 
 
-def _row_rel(a, b, floor=1e-3):
-    """max over rows of |a_r - b_r|_inf / max(|b_r|_inf, floor * |b|_inf): rows with small gradients are checked
-    against their own scale, not against the largest row of the table."""
-    a, b = a.detach().cpu().double(), b.detach().cpu().double()
-    if a.dim() == 1:
-        a, b = a[None], b[None]
-    den = torch.clamp(b.abs().amax(1), min=floor * float(b.abs().max()) + 1e-30)
-    return float(((a - b).abs().amax(1) / den).max())
+import helpers as H   # noqa: E402  (tests/ is on sys.path above)
+
+_row_rel = H.row_rel
 
 
 def _comm_kinds(md, fn):

@@ -76,3 +76,27 @@ def rel_err(a, b):
     a = np.asarray(a, np.float64)
     b = np.asarray(b, np.float64)
     return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
+
+
+def row_rel(a, b, floor=1e-3):
+    """max over rows of |a_r - b_r|_inf / max(|b_r|_inf, floor * |b|_inf): a row with a small gradient is checked against
+    its OWN scale (down to `floor` of the table's largest entry), not against the largest row of the table."""
+    a = torch.as_tensor(np.asarray(a.detach().cpu() if torch.is_tensor(a) else a)).double()
+    b = torch.as_tensor(np.asarray(b.detach().cpu() if torch.is_tensor(b) else b)).double()
+    if a.dim() == 1:
+        a, b = a[None], b[None]
+    den = torch.clamp(b.abs().amax(1), min=floor * float(b.abs().max()) + 1e-30)
+    return float(((a - b).abs().amax(1) / den).max())
+
+
+def check_grad(got, want, tol, what, row_tol=5e-3, floor=1e-3):
+    """A gradient against its reference: max-abs / max-abs over the whole tensor below `tol` AND - for the embedding-table
+    shaped ones ([rows, d] with many rows: user / item tables and their per-row relatives) - every row within `row_tol`
+    of its own scale."""
+    e = rel_err(got.detach().cpu() if torch.is_tensor(got) else got, want.detach().cpu() if torch.is_tensor(want) else want)
+    assert e < tol, (what, e)
+    w = np.asarray(want.detach().cpu() if torch.is_tensor(want) else want)
+    if w.ndim == 2 and w.shape[0] >= 64 and w.shape[0] > 4 * w.shape[1]:
+        er = row_rel(got, want, floor)
+        assert er < row_tol, (what, "row-wise", er)
+    return e

@@ -67,7 +67,7 @@ class OracleBackend:
 
     # ---- non-autograd ("raw") ops used by the fused sharded node ------------------------------------
     @staticmethod
-    def spmm_raw(plan, transpose, X, epilogue, Z=None, alpha=0.0, S=None):
+    def spmm_raw(plan, transpose, X, epilogue, Z=None, alpha=0.0, S=None, out=None):
         with torch.no_grad():
             Y = O.spmm(plan.AT if transpose else plan.A, X)
             if epilogue == 1:
@@ -76,7 +76,19 @@ class OracleBackend:
                 Y = Y + alpha * Z
                 if epilogue == 3:
                     Y = S * (Y - (Y * S).sum(1, keepdim=True))
+            if out is not None:              # a column chunk of a wider table (the item-side node's lanes)
+                out.copy_(Y)
+                return out
             return Y
+
+    @staticmethod
+    def softmax_rows(X):
+        return torch.softmax(X, -1)
+
+    @staticmethod
+    def softmax_rows_(X):
+        with torch.no_grad():
+            return X.copy_(torch.softmax(X, -1))
 
     # ---- the packed node (dist._ShardedHotForward): modalities side by side, 64-wide each ---------------------------
     EPI_AXPY, EPI_AXPY_SOFTMAX_BWD = 2, 3

@@ -57,7 +57,15 @@ def _global_masks(I, d=64):
     return [(torch.rand(I, d, generator=g) >= 0.2) for _ in range(2)]
 
 
-def _worker(rank, world, port, modal, out_dir, fused=True):
+def _local_pair(md, bk, O, m, ush, ish, scheme="gather-both"):
+    """(A_ui[U_r, :], A_iu[I_r, :]) - or, scheme item-side, (A_ui[U_r, :], A_iu[:, U_r]) - of the raw interactions m."""
+    ui, iu = O.csr_norm(m, True), O.csr_norm(m.T, True)
+    if scheme == "item-side":
+        return bk.make_graph(md.shard_graph(ui, ush, ish)), bk.make_graph(md.shard_graph_cols(iu, ish, ush))
+    return bk.make_graph(md.shard_graph(ui, ush, ish)), bk.make_graph(md.shard_graph(iu, ish, ush))
+
+
+def _worker(rank, world, port, modal, out_dir, fused=True, scheme="gather-both", chunks=0):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -75,12 +83,14 @@ def _worker(rank, world, port, modal, out_dir, fused=True):
     def local_pair(m):
         ui, iu = O.csr_norm(m, True), O.csr_norm(m.T, True)
         return bk.make_graph(md.shard_graph(ui, ush, ish)), bk.make_graph(md.shard_graph(iu, ish, ush))
-    ui, iu = local_pair(raw)
-    a, b = local_pair(img_raw)
+    ui, iu = _local_pair(md, bk, O, raw, ush, ish, scheme)       # the interaction graph in the scheme's form
+    a, b = local_pair(img_raw)                                   # (the modal id graphs always as row blocks)
     c, e = local_pair(txt_raw)
-    model = md.ShardedMMSSL(bk, cfg, ush, ish, state, d["image_feat"], d["text_feat"]).train()
+    model = md.ShardedMMSSL(bk, cfg, ush, ish, state, d["image_feat"], d["text_feat"], scheme=scheme, chunks=chunks).train()
     step = md.ShardedHotPathStep(model, (ui, iu, a, b, c, e), 48, I, modal_empty=(modal == "empty_shortcut"),
                                  optimizer=False, fused=fused)
+    if scheme == "item-side" and fused and world > 1:
+        assert model.n_chunks(2) == max(chunks, 1)
     step.set_batch(users, pos, neg)
     if drop:
         step.keep_masks = tuple(ish.slice_rows(k.to(torch.uint8)) for k in _global_masks(I))
@@ -112,14 +122,21 @@ def _reference(modal):
     return float(loss), P
 
 
-@pytest.mark.parametrize("world,modal,fused", [(2, "full", True), (3, "full", True), (2, "empty", True),
-                                               (2, "empty_shortcut", True), (2, "full", False), (3, "full", False),
-                                               (3, "full_drop", True)])
-def test_sharded_step_equals_single_process(tmp_path, world, modal, fused):
+@pytest.mark.parametrize("world,modal,fused,scheme,chunks", [
+    (2, "full", True, "gather-both", 0), (3, "full", True, "gather-both", 0), (2, "empty", True, "gather-both", 0),
+    (2, "empty_shortcut", True, "gather-both", 0), (2, "full", False, "gather-both", 0), (3, "full", False, "gather-both", 0),
+    (3, "full_drop", True, "gather-both", 0),
+    # item-side scheme (user-row blocks only; every collective of item-table size), whole and in column chunks; uneven
+    # last blocks at world 3 (300 users / 200 items are not multiples of 3) and world 8
+    (2, "full", True, "item-side", 1), (3, "full", True, "item-side", 2), (3, "full_drop", True, "item-side", 2),
+    (2, "empty_shortcut", True, "item-side", 2), (3, "empty", True, "item-side", 1), (3, "full", False, "item-side", 0),
+    (8, "full_drop", True, "item-side", 2)])
+def test_sharded_step_equals_single_process(tmp_path, world, modal, fused, scheme, chunks):
     port = _free_port()
-    mp.spawn(_worker, args=(world, port, modal, str(tmp_path), fused), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, modal, str(tmp_path), fused, scheme, chunks), nprocs=world, join=True)
     ref_loss, P = _reference(modal)
     outs = [torch.load(os.path.join(str(tmp_path), "r%d.pt" % r)) for r in range(world)]
+    import helpers as H
     for o in outs:
         assert abs(o["loss"] - ref_loss) <= 2e-5 * abs(ref_loss), (o["loss"], ref_loss)
 
@@ -139,12 +156,16 @@ def test_sharded_step_equals_single_process(tmp_path, world, modal, fused):
             lo, hi, n = sh
             k = max(0, min(hi, n) - lo)
             g = P[key].grad[lo:lo + k]
-            assert rel(o["g"][name][:k], g) < 1e-4, name
+            if k > 0:
+                assert rel(o["g"][name][:k], g) < 1e-4, name
+                # every owned row against its own scale (floor: 1e-3 of the GLOBAL table's largest entry)
+                den = torch.clamp(g.abs().amax(1), min=1e-3 * float(P[key].grad.abs().max()))
+                assert float(((o["g"][name][:k] - g).abs().amax(1) / den).max()) < 5e-3, (name, "row-wise")
             if k < hi - lo:      # padded rows never receive gradient
                 assert float(o["g"][name][k:].abs().max()) == 0.0
 
 
-def _traj_worker(rank, world, port, out_dir, steps):
+def _traj_worker(rank, world, port, out_dir, steps, scheme="gather-both", chunks=0):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -160,8 +181,8 @@ def _traj_worker(rank, world, port, out_dir, steps):
     def local_pair(m):
         ui, iu = O.csr_norm(m, True), O.csr_norm(m.T, True)
         return bk.make_graph(md.shard_graph(ui, ush, ish)), bk.make_graph(md.shard_graph(iu, ish, ush))
-    graphs = local_pair(raw) + local_pair(img_raw) + local_pair(txt_raw)
-    model = md.ShardedMMSSL(bk, cfg, ush, ish, state, d["image_feat"], d["text_feat"]).train()
+    graphs = _local_pair(md, bk, O, raw, ush, ish, scheme) + local_pair(img_raw) + local_pair(txt_raw)
+    model = md.ShardedMMSSL(bk, cfg, ush, ish, state, d["image_feat"], d["text_feat"], scheme=scheme, chunks=chunks).train()
     step = md.ShardedHotPathStep(model, graphs, 48, I, lr=1e-2)          # CPU: torch.optim.AdamW on the local tensors
     losses = []
     g = torch.Generator().manual_seed(5)
@@ -175,15 +196,15 @@ def _traj_worker(rank, world, port, out_dir, steps):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_sharded_trajectory_equals_single_process_adamw(tmp_path, world):
+@pytest.mark.parametrize("world,scheme,chunks", [(2, "gather-both", 0), (3, "gather-both", 0), (3, "item-side", 2)])
+def test_sharded_trajectory_equals_single_process_adamw(tmp_path, world, scheme, chunks):
     """Four sharded steps WITH the optimiser (gloo, world 2 / 3): every rank's losses, its rows of the embedding tables and
     the replicated tensors follow the single-process oracle stepped by torch.optim.AdamW on the global problem - the
     persistent gradient bucket (gradients = views of it, the regulariser share in its last slot) across several steps."""
     import mmssl_oracle as O
     steps = 4
     port = _free_port()
-    mp.spawn(_traj_worker, args=(world, port, str(tmp_path), steps), nprocs=world, join=True)
+    mp.spawn(_traj_worker, args=(world, port, str(tmp_path), steps, scheme, chunks), nprocs=world, join=True)
     fx, d, raw, U, I, state, users, pos, neg, img_raw, txt_raw = _global_problem("full")
     names = ("image_trans.weight", "image_trans.bias", "text_trans.weight", "text_trans.bias", "user_id_embedding.weight",
              "item_id_embedding.weight", "weight_dict.w_self_attention_cat")
@@ -234,6 +255,14 @@ def test_row_shard_and_graph_slicing():
     assert np.array_equal(full[:10, :7], m.toarray()) and not full[10:].any() and not full[:, 7:].any()
     t = torch.arange(20.).view(10, 2)
     assert torch.equal(md.RowShard(10, 3, 2).slice_rows(t), torch.cat([t[8:], torch.zeros(2, 2)]))
+    # the item-side scheme's second graph: column blocks over ALL (padded) rows; side by side they are the matrix again
+    cols = []
+    for r in range(3):
+        g = md.shard_graph_cols(m, md.RowShard(10, 3, r), md.RowShard(7, 3, r))
+        assert g.shape == (12, 3)
+        cols.append(g)
+    full = sp.hstack(cols).toarray()
+    assert np.array_equal(full[:10, :7], m.toarray()) and not full[10:].any() and not full[:, 7:].any()
 
 
 @pytest.mark.parametrize("mode", ["ok", "fail"])

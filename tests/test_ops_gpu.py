@@ -677,6 +677,11 @@ def test_topk_rows_is_heapq_nlargest_including_ties(n, k):
     X[1] = 0.25                                # a constant row: the first k ids win
     X[2, : n // 2] = float("-inf")             # masked half
     X[3, 5] = X[3].max() + 1.0
+    # mostly -inf rows (evaluation masks a user's train items to -inf): fewer than k finite scores, so the winners' tail
+    # consists of REAL -inf columns in ascending column order - never a padded slot (-1) of a column block
+    X[4] = float("-inf")
+    X[4, [n - 3, 7, n // 2]] = torch.tensor([1.0, 2.0, 3.0])
+    X[5] = float("-inf")
     idx, val = ops.topk_rows(X.to(DEV), k, values=True)
     idx, val = idx.cpu(), val.cpu()
     ke = min(k, n)

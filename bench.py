@@ -230,6 +230,58 @@ def projection_record(step, iters=600):
     return out
 
 
+def spmm_hbm_record(iters=20):
+    """The CSR SpMM on an HBM-RESIDENT working set: one rank's share of configs[4] (A_ui[U_r, :]: 250 000 user rows x
+    1 000 000 item columns, 12.5 M edges, d = 128; the gathered item table is 512 MB = 2x the 256 MiB Infinity Cache) and
+    its transpose (the backward's partial product: 512 MB written). HIP events on the launch stream. Fractions: of the 8 TB/s
+    HBM peak by algorithmic bytes (gather-per-edge, no cache credit), and the kernel's fabric bytes (FETCH_SIZE x 2 +
+    WRITE_SIZE of the committed PMC pass) / time against the 4.3-4.5 TB/s a purely random 512-byte-row gather reaches on
+    this chip (profiles/r03_fetch_calibration.json)."""
+    from mmssl_amd import ops, synth
+    from mmssl_amd.graph import GraphPlan
+    d, U_r, I = 128, 250_000, 1_000_000
+    raw = synth.interaction_matrix(U_r, I, 12_500_000, seed=11)
+    ui_r = synth.normalised_rows(raw)
+    P = GraphPlan(ui_r)
+    X = torch.randn(I, d, device="cuda")
+    G = torch.randn(U_r, d, device="cuda")
+    pmc = None
+    pp = os.path.join(ROOT, "profiles", "r04_spmm_hbm_pmc.json")
+    if os.path.exists(pp):
+        try:
+            pmc = json.load(open(pp))
+        except Exception:
+            pmc = None
+    out = {"what": "configs[4] rank shape, d=128: A_ui[U_r,:] 250000 x 1000000, 12.5M edges; gathered table 512 MB (HBM resident)",
+           "random_gather_ceiling_GBps": 4400.0}
+    with torch.no_grad():
+        for name, tr, Xin, m in (("forward", False, X, ui_r), ("transpose", True, G, ui_r.T.tocsr())):
+            for _ in range(3):
+                ops.spmm(P, Xin, transpose=tr)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(iters):
+                ops.spmm(P, Xin, transpose=tr)
+            e1.record()
+            torch.cuda.synchronize()
+            us = e0.elapsed_time(e1) * 1e3 / iters
+            by = synth.spmm_bytes(m, d)
+            rec = {"us": round(us, 1), "algorithmic_bytes": int(by), "algorithmic_GBps": round(by / us * 1e-3, 1),
+                   "frac_hbm_algorithmic": round(by / us * 1e-3 / HBM_PEAK_GBPS, 4),
+                   "edge_layers_per_s": round(m.nnz / us * 1e6, 1)}
+            t = (pmc or {}).get(name)
+            if t and t.get("fabric_bytes"):
+                rec["traffic"] = int(t["fabric_bytes"])
+                rec["fabric_GBps"] = round(t["fabric_bytes"] / us * 1e-3, 1)
+                rec["fabric_frac_of_8TBps"] = round(rec["fabric_GBps"] / HBM_PEAK_GBPS, 4)
+                rec["fabric_over_random_gather_ceiling"] = round(rec["fabric_GBps"] / 4400.0, 3)
+            out[name] = rec
+    del P, X, G
+    torch.cuda.empty_cache()
+    return out
+
+
 def first_step_loss(a, step, raw, batch):
     """HIP side of the loss check: the loss of ONE hot-path forward on the bench model's initial parameters with
     injected dropout masks. Returns (loss, snapshot of the inputs) — cpu_baseline() evaluates the CPU oracle on the
@@ -438,6 +490,7 @@ def main():
                     help="launcher dry run (no GPU needed): rendezvous of --gpus ranks on --backend, one all-reduce, one "
                          "JSON line from rank 0")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl", help="process-group backend (gloo: --launch-check only)")
+    ap.add_argument("--no-hbm", action="store_true", dest="no_hbm", help="skip the HBM-resident SpMM record (`spmm_hbm`)")
     ap.add_argument("--no-stress", action="store_true", dest="no_stress",
                     help="N>1: skip the `scaling_stress` record (configs[4]'s per-rank share x N after the timed region)")
     ap.add_argument("--scheme", choices=["item-side", "gather-both"], default="item-side",
@@ -475,112 +528,73 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=dev)
 
-    n_users = n_items = n_edges = None
-    comm = None
-    if not sharded:
-        step, raw, mats, plans = build_single_gpu(a, dev)
-        stats = count_edge_layers(step, a.d)
-        if a.graph_probe:            # child process: does whole-step hipGraph capture + replay work here?
-            ok = step.capture()
-            if ok:
-                step.run()
-                torch.cuda.synchronize()
-            sys.exit(0 if ok else 3)
-        first = None
-        if rank == 0 and a.only == "all" and not a.no_cpu_baseline:
-            first = first_step_loss(a, step, raw, make_batches(raw, 1, a.batch, seed=5)[0])
-        batches = [(torch.stack([torch.from_numpy(x).to(dev) for x in b]),)      # packed [3, B]
-                   for b in make_batches(raw, 8, a.batch, seed=2022)]
-        # the eight batches stay resident as a ring: every step picks slot (optimiser step mod 8) by a launch of its own
-        # (HotPathStep.set_batch_ring; BEFORE the capture: that launch is part of the step), so two replays are not
-        # separated by a host-issued copy
-        step.set_batch_ring(torch.stack([b[0] for b in batches]))
-        captured = (not a.no_graph) and graph_capture_works(a) and step.capture()
-        edge_layers_total = stats["edge_layers"]
-        parallelism = "single"
-        n_users, n_items, n_edges = int(raw.shape[0]), int(raw.shape[1]), int(raw.nnz)
-        scaling = "weak"
-    else:
-        from mmssl_amd import dist as mdist
-        scaling = "weak" if a.workload == "synth" else a.scaling
-        if a.dist_graph_probe:       # child of one rank: sharded capture + replay on a small shape
-            step, _, _, _ = mdist.build_bench_step(a, rank, world, dev, scaling)
-            ok = step.capture()
-            if ok:
-                for _ in range(3):
-                    step.run()
-                torch.cuda.synchronize()
-                ok = bool(torch.isfinite(step.loss).item())
-            dist.barrier()
-            dist.destroy_process_group()
-            sys.exit(0 if ok else 3)
-        want = a.dist_graph != "off" and not a.no_graph
-        if want and a.dist_graph == "auto":
-            # A failed capture with RCCL inside can abort or hang the process: try it first in one child
-            # per rank (own rendezvous on MASTER_PORT+1), then agree on the outcome across ranks.
-            cmd = [sys.executable, os.path.abspath(__file__), "--dist-graph-probe", "--gpus", str(a.gpus),
-                   "--workload", "tiktok", "--d", str(a.d), "--gcn-layers", str(a.gcn_layers), "--batch", str(a.batch),
-                   "--scaling", "strong"]
-            if a.force_dist:
-                cmd.append("--force-dist")
-            flag = torch.tensor([1 if mdist.spawn_rank_probe(cmd) else 0], device=dev, dtype=torch.int32)
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            want = bool(flag.item())
-        step, mats, plans, stats = mdist.build_bench_step(a, rank, world, dev, scaling)
-        captured = want and step.capture()
-        edge_layers_total = stats["edge_layers_global"]
-        parallelism = "row-shard x%d (RCCL all-gather / reduce-scatter, 3 interleaved chains)" % world
-        n_users, n_items, n_edges = stats["n_users"], stats["n_items"], stats["n_edges"]
-        # communication of one step: what was issued, and how long those collectives take on their own
-        log = stats["comm_log"]
-        comm = {"collectives_per_step": len(log),
-                "bytes_per_step": int(sum(b for _, _, b in log)),
-                "by_kind": {k: [sum(1 for x in log if x[0] == k), int(sum(x[2] for x in log if x[0] == k))]
-                            for k in ("all_gather", "reduce_scatter", "all_reduce")},
-                "note": "bytes = size of the full (gathered / to-be-scattered / reduced) fp32 buffer of every collective "
-                        "of one step on one rank; comm_only_ms = the same collectives replayed alone, back to back"}
-        with torch.cuda.stream(step.stream):
-            comm["comm_only_ms"] = round(mdist.comm_replay_ms(log, None, dev), 4)
-        rngb = np.random.default_rng(2022)          # identical batches on every rank (global ids)
-        batches = [(torch.stack([torch.from_numpy(x).to(dev) for x in (                   # packed [3, B]: one copy per step
-            rngb.choice(n_users, a.batch, replace=a.batch > n_users).astype(np.int64),
-            rngb.integers(0, n_items, a.batch).astype(np.int64), rngb.integers(0, n_items, a.batch).astype(np.int64))]),)
-            for _ in range(8)]
+    if sharded:
+        run_sharded_main(a, rank, world, dev)
+        return
+    step, raw, mats, plans = build_single_gpu(a, dev)
+    stats = count_edge_layers(step, a.d)
+    if a.graph_probe:            # child process: does whole-step hipGraph capture + replay work here?
+        ok = step.capture()
+        if ok:
+            step.run()
+            torch.cuda.synchronize()
+        sys.exit(0 if ok else 3)
+    first = None
+    if a.only == "all" and not a.no_cpu_baseline:
+        first = first_step_loss(a, step, raw, make_batches(raw, 1, a.batch, seed=5)[0])
+    batches = [torch.stack([torch.from_numpy(x).to(dev) for x in b])      # packed [3, B]
+               for b in make_batches(raw, 8, a.batch, seed=2022)]
+    # the eight batches stay resident as a ring: every step picks slot (completed steps mod 8) by a launch of its own
+    # (HotPathStep.set_batch_ring; BEFORE the capture: that launch is part of the step), so two replays are not
+    # separated by a host-issued copy
+    step.set_batch_ring(torch.stack(batches))
+    captured = (not a.no_graph) and graph_capture_works(a) and step.capture()
+    edge_layers_total = stats["edge_layers"]
 
     def run_steps(n):
-        for i in range(n):
-            if sharded:
-                step.set_batch(*batches[i % len(batches)])
+        for _ in range(n):
             step.run()
 
     if a.only == "roofline":
         a.warmup, a.steps = 1, 1
     # the isolated-kernel records first (they also bring the clocks up before the short timed region)
     extra = {}
-    if rank == 0 and not sharded and a.only != "steps":
+    if a.only != "steps":
         extra["roofline"] = spmm_roofline(plans, mats, a.d)
         extra["gcn_forward"] = gcn_forward_record(plans, mats, a.d, a.gcn_layers)
         extra["projection"] = projection_record(step)
+        if a.only == "all" and not a.no_hbm:
+            extra["spmm_hbm"] = spmm_hbm_record()
     run_steps(a.warmup)
-    if sharded:
-        dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     run_steps(a.steps)
     torch.cuda.synchronize()
-    if sharded:
-        dist.barrier()
-    torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    if sharded:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    loss = float(step.loss)
     ms = elapsed * 1e3 / a.steps
+    out = result_line(a, 1, "weak", ms, edge_layers_total, stats, captured, float(step.loss), "single",
+                      int(raw.shape[0]), int(raw.shape[1]), int(raw.nnz))
+    if a.only != "steps":
+        rf = extra["roofline"]
+        # the same byte model over the WHOLE step: every SpMM launch's algorithmic bytes / step time. The
+        # step is not SpMM-bound (projection GEMMs and the loss section share it), so this is far lower.
+        rf["step_spmm_GBps"] = round(stats["spmm_bytes"] / (ms * 1e-3) * 1e-9, 1)
+        rf["step_frac"] = round(rf["step_spmm_GBps"] / HBM_PEAK_GBPS, 4)
+        out["roofline"] = rf
+        out["gcn_forward"] = extra["gcn_forward"]
+        out["projection"] = extra["projection"]
+        if "spmm_hbm" in extra:
+            out["spmm_hbm"] = extra["spmm_hbm"]
+    if not a.no_cpu_baseline and a.only == "all":
+        out["cpu_baseline"] = cpu_baseline(a, raw, mats, first=first)
+        out["loss_check"] = out["cpu_baseline"].pop("loss_check")
+    print(json.dumps(out))
+
+
+def result_line(a, world, scaling, ms, edge_layers_total, stats, captured, loss, parallelism, n_users, n_items, n_edges):
     shape_note = "" if world == 1 else (" x%d (weak: per-rank share fixed)" % world if scaling == "weak"
                                         else " cut %d ways (strong)" % world)
-    out = {
+    return {
         "metric": "edge.layers/s (d-wide multiply-adds per nonzero over every SpMM launch of a hot-path step / step time)",
         "value": round(edge_layers_total / (ms * 1e-3), 1), "unit": "edge.layers/s", "n_gpus": world,
         "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 4), "higher_is_better": True,
@@ -592,27 +606,134 @@ def main():
                    "launch": "hipGraph replay" if captured else "eager", "parallelism": parallelism,
                    "final_loss": round(loss, 6)},
     }
-    if rank == 0:
-        if not sharded:
-            if a.only != "steps":
-                rf = extra["roofline"]
-                # the same byte model over the WHOLE step: every SpMM launch's algorithmic bytes / step time. The
-                # step is not SpMM-bound (projection GEMMs and the loss section share it), so this is far lower.
-                rf["step_spmm_GBps"] = round(stats["spmm_bytes"] / (ms * 1e-3) * 1e-9, 1)
-                rf["step_frac"] = round(rf["step_spmm_GBps"] / HBM_PEAK_GBPS, 4)
-                out["roofline"] = rf
-                out["gcn_forward"] = extra["gcn_forward"]
-                out["projection"] = extra["projection"]
-            if not a.no_cpu_baseline and a.only == "all":
-                out["cpu_baseline"] = cpu_baseline(a, raw, mats, first=first)
-                out["loss_check"] = out["cpu_baseline"].pop("loss_check")
-        else:
-            out["roofline"] = spmm_roofline(plans, mats, a.d, traffic=False)   # rank 0's shard
-            out["comm"] = comm
-        print(json.dumps(out))
-    if sharded:
+
+
+def timed_sharded(a, rank, world, dev, scaling, want_graph):
+    """Build the row-sharded step for workload `a`, W warm-up steps, then EXACTLY K timed steps between barrier +
+    synchronize on both sides, max over ranks. Returns a dict (ms, stats, comm, ...)."""
+    import torch.distributed as dist
+    from mmssl_amd import dist as mdist
+    step, mats, plans, stats = mdist.build_bench_step(a, rank, world, dev, scaling)
+    captured = bool(want_graph and step.capture())
+    n_users, n_items = stats["n_users"], stats["n_items"]
+    # communication of one step: what was issued, and how long those collectives take on their own
+    log = stats["comm_log"]
+    comm = {"scheme": stats["scheme"], "column_chunks": stats["chunks"], "collectives_per_step": len(log),
+            "bytes_per_step": int(sum(b for _, _, b in log)),
+            "by_kind": {k: [sum(1 for x in log if x[0] == k), int(sum(x[2] for x in log if x[0] == k))]
+                        for k in ("all_gather", "reduce_scatter", "all_reduce")},
+            "note": "bytes = size of the full (gathered / to-be-scattered / reduced) fp32 buffer of every collective "
+                    "of one step on one rank; comm_only_ms = the same collectives replayed alone, back to back"}
+    with torch.cuda.stream(step.stream):
+        comm["comm_only_ms"] = round(mdist.comm_replay_ms(log, None, dev), 4)
+    rngb = np.random.default_rng(2022)          # identical batches on every rank (global ids)
+    batches = [torch.stack([torch.from_numpy(x).to(dev) for x in (                   # packed [3, B]: one copy per step
+        rngb.choice(n_users, a.batch, replace=a.batch > n_users).astype(np.int64),
+        rngb.integers(0, n_items, a.batch).astype(np.int64), rngb.integers(0, n_items, a.batch).astype(np.int64))])
+        for _ in range(8)]
+
+    def run_steps(n):
+        for i in range(n):
+            step.set_batch(batches[i % len(batches)])
+            step.run()
+    run_steps(a.warmup)
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run_steps(a.steps)
+    torch.cuda.synchronize()
+    dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    ms = float(t.item()) * 1e3 / a.steps
+    return {"ms": ms, "stats": stats, "comm": comm, "captured": captured, "loss": float(step.loss), "plans": plans,
+            "mats": mats, "step": step}
+
+
+def committed_rank_figure():
+    """ms/step and edge.layers/s of configs[4]'s per-rank share on ONE rank (no link crossed), from the committed run."""
+    for name in ("r04_bench_synth_w1.json", "r03_bench_synth_w1.json"):
+        p = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(p):
+            try:
+                with open(p) as f:
+                    d = json.loads([ln for ln in f.read().splitlines() if ln.startswith("{")][0])
+                return {"file": "profiles/" + name, "ms_per_step": d["ms_per_step"], "edge_layers_per_s": d["value"]}
+            except Exception:
+                pass
+    return None
+
+
+def run_sharded_main(a, rank, world, dev):
+    import copy
+    import gc
+    import torch.distributed as dist
+    from mmssl_amd import dist as mdist
+    scaling = "weak" if a.workload == "synth" else a.scaling
+    if a.dist_graph_probe:       # child of one rank: sharded capture + replay on a small shape
+        step, _, _, _ = mdist.build_bench_step(a, rank, world, dev, scaling)
+        ok = step.capture()
+        if ok:
+            for _ in range(3):
+                step.run()
+            torch.cuda.synchronize()
+            ok = bool(torch.isfinite(step.loss).item())
         dist.barrier()
         dist.destroy_process_group()
+        sys.exit(0 if ok else 3)
+    want = a.dist_graph != "off" and not a.no_graph
+    if want and a.dist_graph == "auto":
+        # A failed capture with RCCL inside can abort or hang the process: try it first in one child
+        # per rank (own rendezvous on MASTER_PORT+1), then agree on the outcome across ranks.
+        cmd = [sys.executable, os.path.abspath(__file__), "--dist-graph-probe", "--gpus", str(a.gpus),
+               "--workload", "tiktok", "--d", str(a.d), "--gcn-layers", str(a.gcn_layers), "--batch", str(a.batch),
+               "--scaling", "strong", "--scheme", a.scheme, "--chunks", str(max(a.chunks, 2) if world > 1 else a.chunks)]
+        if a.force_dist:
+            cmd.append("--force-dist")
+        flag = torch.tensor([1 if mdist.spawn_rank_probe(cmd) else 0], device=dev, dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        want = bool(flag.item())
+    r = timed_sharded(a, rank, world, dev, scaling, want)
+    stats = r["stats"]
+    out = result_line(a, world, scaling, r["ms"], stats["edge_layers_global"], stats, r["captured"], r["loss"],
+                      "row-shard x%d, %s scheme, %d column chunk(s) per collective (RCCL all-gather / reduce-scatter)" % (
+                          world, stats["scheme"], stats["chunks"]),
+                      stats["n_users"], stats["n_items"], stats["n_edges"])
+    if rank == 0:
+        out["roofline"] = spmm_roofline(r["plans"], r["mats"], a.d, traffic=False)   # rank 0's shard
+        out["comm"] = r["comm"]
+    # N > 1: the shape on which north_star's >= 6x is arithmetically possible, in the same run - configs[4]'s per-rank
+    # share x N (250 K users x 125 K items x 12.5 M edges per rank, d = 128), a few steps, next to the committed one-rank
+    # figure of the same share (its ratio = the weak-scaling efficiency on that shape)
+    if world > 1 and a.workload != "synth" and not a.no_stress:
+        del r
+        gc.collect()
+        torch.cuda.empty_cache()
+        a2 = copy.copy(a)
+        a2.workload, a2.d, a2.steps, a2.warmup = "synth", 128, min(a.steps, 10), min(a.warmup, 3)
+        try:
+            r2 = timed_sharded(a2, rank, world, dev, "weak", want)
+            st2 = r2["stats"]
+            rec = {"what": "configs[4]: per-rank share 250K users x 125K items x 12.5M edges, d=128, x %d ranks" % world,
+                   "ms_per_step": round(r2["ms"], 4), "steps": a2.steps, "warmup": a2.warmup,
+                   "edge_layers_per_s": round(st2["edge_layers_global"] / (r2["ms"] * 1e-3), 1),
+                   "launch": "hipGraph replay" if r2["captured"] else "eager", "comm": r2["comm"],
+                   "final_loss": round(r2["loss"], 6)}
+            ref = committed_rank_figure()
+            if ref:
+                rec["one_rank"] = ref
+                rec["per_rank_ratio"] = round(rec["edge_layers_per_s"] / world / ref["edge_layers_per_s"], 4)
+                rec["speedup_vs_one_rank"] = round(rec["edge_layers_per_s"] / ref["edge_layers_per_s"], 3)
+        except Exception as e:       # the headline line must survive a failing stress run
+            rec = {"error": repr(e)[:400]}
+        if rank == 0:
+            out["scaling_stress"] = rec
+    if rank == 0:
+        print(json.dumps(out))
+    dist.barrier()
+    dist.destroy_process_group()
 
 
 if __name__ == "__main__":

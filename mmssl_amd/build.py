@@ -49,16 +49,23 @@ def build(force=False, verbose=True):
     with ThreadPoolExecutor(max_workers=8) as ex:
         res = list(ex.map(lambda s: _compile(s, force, hdr_m), _sources()))
     objs = [o for o, _ in res]
+    build.last = {"compiled": [os.path.basename(o) for o, c in res if c],
+                  "reused": [os.path.basename(o) for o, c in res if not c], "linked": False}
     if force or any(c for _, c in res) or not os.path.exists(LIB):
         cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("link failed:\n%s\n%s" % (r.stdout, r.stderr))
+        build.last["linked"] = True
         if verbose:
-            print("built", LIB)
+            print("built %s: %d unit(s) compiled for gfx950, %d object(s) reused" % (
+                LIB, len(build.last["compiled"]), len(build.last["reused"])))
     elif verbose:
-        print("up to date:", LIB)
+        print("up to date: %s (%d objects newer than their sources and headers; --force recompiles)" % (LIB, len(objs)))
     return LIB
+
+
+build.last = None
 
 
 if __name__ == "__main__":

@@ -865,6 +865,11 @@ class _Lanes:
                 if st is not self.main:
                     self.main.wait_stream(st)
 
+    def wait(self, c, other):
+        """This lane c waits for lane c of another lane set (two chains meeting at a grouped collective)."""
+        if self.cuda and self.streams[c] is not other.streams[c]:
+            self.streams[c].wait_stream(other.streams[c])
+
     def meet(self):
         """Lane 0 waits for all lanes (then runs the whole-row kernel); `part` lets the others continue behind it."""
         if self.cuda:
@@ -904,7 +909,9 @@ class _ShardedItemSide(torch.autograd.Function):
         backward: g(u_r) = A_iu[:, U_r]^T . all_gather(g(i_r)),  g(i_r) = reduce_scatter( A_ui[U_r, :]^T . g(u_r) )
 
     every collective moves ITEM-table bytes (the user table, twice as large for every shape of BASELINE.json, never
-    travels): -33 % bytes per step against gathering both tables. The packed modal chain X -> MU -> MI goes the same way.
+    travels): -33 % bytes per step against gathering both tables. The packed modal chain X -> MU -> MI goes the same way;
+    its four collectives ride on GCN collectives of the same kind as grouped pairs (one RCCL launch each):
+    4 L + 2 launches per step like the gather-both node.
 
     Column chunks (`nc`): every collective and the products on either side of it are cut into nc column chunks on nc
     lanes (see _Lanes). User-side tables stay row-major [per_u, w]; a lane's products read / write its column chunk in
@@ -921,7 +928,6 @@ class _ShardedItemSide(torch.autograd.Function):
             _, draw_p, ext_tick = keep
             keep = None
         g = group
-        world = dist.get_world_size(g)
         per_u, per_i, d = u0.shape[0], i0.shape[0], u0.shape[1]
         wm = nm * d
         twin = (lambda p, k: p.twin(k)) if hasattr(ui, "twin") else (lambda p, k: p)
@@ -930,7 +936,12 @@ class _ShardedItemSide(torch.autograd.Function):
         M = _Lanes(bk, u0, nc, base=nc, first_is_current=True)    # modal chain: the current stream + nc - 1 lanes
         G.fork()
         X, keep = bk.proj_forward(list(Fs), list(Ws), list(bs), keep, scale, draw_p, ext_tick)      # [per_i, nm d], current stream
-        MU, MI_c = new(per_u, wm), [None] * nc
+        M.fork()
+        MU = new(per_u, wm)
+        for t_ in (MU, X):
+            M.uses(t_)
+            G.uses(t_)
+        MU_v, X_v, MI_c = _chunks_of(MU, nc), _chunks_of(X, nc), [None] * nc
         us, its = [u0], [i0]
         i_c = [i0]
         if nc > 1:                                # a lane's chunk copy runs on the lane (i0 exists before the fork)
@@ -938,34 +949,29 @@ class _ShardedItemSide(torch.autograd.Function):
             for c, v in enumerate(_chunks_of(i0, nc)):
                 with G.on(c):
                     i_c.append(v.contiguous())
-        # the modal chain's collectives are issued behind the GCN layers modal_at (RCCL runs collectives in issue order: a
-        # gather that waits for the projection GEMM must not sit in front of the first GCN layers' collectives)
-        modal_at = (max(0, n_layers - 2), n_layers - 1)
-
-        def modal_gather():
-            M.fork()
-            M.uses(MU)
-            M.uses(X)
-            for c, v in enumerate(_chunks_of(X, nc)):
-                with M.on(c):
-                    X_full = _all_gather_raw(v.contiguous() if nc > 1 else v, g)
-                    bk.spmm_raw(twin(ui, 10 + c), False, X_full, bk.EPI_NONE, out=_chunks_of(MU, nc)[c])
-
-        def modal_scatter():
-            for c in range(nc):
-                with M.on(c):
-                    PM = bk.spmm_raw(twin(iuT, 10 + c), False, _chunks_of(MU, nc)[c], bk.EPI_NONE)
-                    MI_c[c] = _reduce_scatter_raw(PM, per_i, g)
-
+        # the modal chain's gather rides on the GCN gather of layer pair_at[0], its reduce-scatter on the GCN
+        # reduce-scatter of layer pair_at[1]: late, because RCCL runs a group's collectives in issue order and a gather that
+        # waits for the projection GEMM must not sit in front of the first GCN layers' collectives
+        pair_at = (max(0, n_layers - 2), n_layers - 1)
         for l in range(n_layers):
             last = l == n_layers - 1
             u = new(per_u, d)
             G.uses(u)
             u_v = _chunks_of(u, nc)
             for c in range(nc):                 # item rows -> user rows: gather, product into the lane's column chunk
-                with G.on(c):
-                    i_full = _all_gather_raw(i_c[c], g)
-                    bk.spmm_raw(twin(ui, 2 + c), False, i_full, bk.EPI_NONE, out=u_v[c])
+                if l == pair_at[0]:
+                    G.wait(c, M)
+                    with G.on(c):
+                        i_full, X_full = _all_gather_pair(i_c[c], X_v[c].contiguous() if nc > 1 else X, g)
+                        bk.spmm_raw(twin(ui, 2 + c), False, i_full, bk.EPI_NONE, out=u_v[c])
+                    M.wait(c, G)
+                    with M.on(c):
+                        M.uses(X_full, [c])
+                        bk.spmm_raw(twin(ui, 10 + c), False, X_full, bk.EPI_NONE, out=MU_v[c])
+                else:
+                    with G.on(c):
+                        i_full = _all_gather_raw(i_c[c], g)
+                        bk.spmm_raw(twin(ui, 2 + c), False, i_full, bk.EPI_NONE, out=u_v[c])
             if last:
                 G.meet()
                 with G.on(0):
@@ -973,9 +979,21 @@ class _ShardedItemSide(torch.autograd.Function):
                 G.part()
             i_n = [None] * nc
             for c in range(nc):                 # user rows -> ALL item rows (partial), summed into the owners' rows
-                with G.on(c):
-                    P = bk.spmm_raw(twin(iuT, 2 + c), False, u_v[c], bk.EPI_NONE)
-                    i_n[c] = _reduce_scatter_raw(P, per_i, g)
+                if l == pair_at[1]:
+                    with M.on(c):
+                        PM = bk.spmm_raw(twin(iuT, 10 + c), False, MU_v[c], bk.EPI_NONE)
+                    with G.on(c):
+                        P = bk.spmm_raw(twin(iuT, 2 + c), False, u_v[c], bk.EPI_NONE)
+                    G.wait(c, M)
+                    with G.on(c):
+                        G.uses(PM, [c])
+                        i_n[c], MI_c[c] = _reduce_scatter_pair(P, PM, per_i, g)
+                    M.wait(c, G)
+                    M.uses(MI_c[c], [c])
+                else:
+                    with G.on(c):
+                        P = bk.spmm_raw(twin(iuT, 2 + c), False, u_v[c], bk.EPI_NONE)
+                        i_n[c] = _reduce_scatter_raw(P, per_i, g)
             if nc > 1 or last:
                 G.meet()
             with G.on(0):
@@ -985,16 +1003,12 @@ class _ShardedItemSide(torch.autograd.Function):
             i_c = i_n
             us.append(u)
             its.append(i)
-            if l == modal_at[0]:
-                modal_gather()
-            if l == modal_at[1]:
-                modal_scatter()
         M.meet()
         MI = torch.cat(MI_c, 1) if nc > 1 else MI_c[0]
         M.join()
         G.join()
         if G.cuda:
-            for t_ in us[1:] + its[1:]:
+            for t_ in us[1:] + its[1:] + [MI]:
                 t_.record_stream(G.main)
         inv = 1.0 / (n_layers + 1)
         u_g, i_g, ss = bk.fuse_fwd(us, MU, its, MI, inv, nm, r)
@@ -1029,15 +1043,11 @@ class _ShardedItemSide(torch.autograd.Function):
             for t_ in (uG, iG, Gu, Gi, g_u0):
                 G.uses(t_)
         M.fork()
-        # ---- modal chain, first half: t = gMU + A_iu[:, U_r]^T . all_gather(gMI)
         t = new(per_u, wm)
         for t_ in (t, gMU, gMI):
             M.uses(t_)
-        for c, v in enumerate(_chunks_of(gMI, nc)):
-            with M.on(c):
-                gPM = _all_gather_raw(v.contiguous() if nc > 1 else v, g)
-                bk.spmm_raw(twin(iuT, 10 + c), True, gPM, bk.EPI_AXPY, _chunks_of(gMU, nc)[c], 1.0, out=_chunks_of(t, nc)[c])
-        # ---- GCN chain, last layer
+            G.uses(t_)
+        t_v, gMU_v, gMI_v = _chunks_of(t, nc), _chunks_of(gMU, nc), _chunks_of(gMI, nc)
         with G.on(0):
             gi = bk.softmax_rows_bwd(iG, Gi, inv)                   # g before the item-side softmax, [per_i, d]
             gi_c = _contig_chunks(gi, nc) if nc > 1 else [gi]
@@ -1046,41 +1056,58 @@ class _ShardedItemSide(torch.autograd.Function):
         G.part()
         gX_c = [None] * nc
         for l in range(n_layers, 0, -1):
-            last = l == n_layers
+            first = l == n_layers               # the last layer comes first; the modal chain's collectives ride on its pair
             gu = new(per_u, d)
             G.uses(gu)
             gu_v, Gu_v = _chunks_of(gu, nc), _chunks_of(Gu, nc)
             for c in range(nc):                 # g(u_l) = inv Gu + A_iu[:, U_r]^T . all_gather(g(i_l))
-                with G.on(c):
-                    gP = _all_gather_raw(gi_c[c], g)
-                    bk.spmm_raw(twin(iuT, 2 + c), True, gP, bk.EPI_AXPY, Gu_v[c], inv, out=gu_v[c])
-            if last:
+                if first:
+                    G.wait(c, M)
+                    with G.on(c):
+                        gP, gPM = _all_gather_pair(gi_c[c], gMI_v[c].contiguous() if nc > 1 else gMI, g)
+                        bk.spmm_raw(twin(iuT, 2 + c), True, gP, bk.EPI_AXPY, Gu_v[c], inv, out=gu_v[c])
+                    M.wait(c, G)
+                    with M.on(c):           # t = g(MU) = own branch + A_iu[:, U_r]^T . all_gather(g(MI))
+                        M.uses(gPM, [c])
+                        bk.spmm_raw(twin(iuT, 10 + c), True, gPM, bk.EPI_AXPY, gMU_v[c], 1.0, out=t_v[c])
+                else:
+                    with G.on(c):
+                        gP = _all_gather_raw(gi_c[c], g)
+                        bk.spmm_raw(twin(iuT, 2 + c), True, gP, bk.EPI_AXPY, Gu_v[c], inv, out=gu_v[c])
+            if first:
                 G.meet()
                 with G.on(0):
                     gu = bk.softmax_rows_bwd(uG, gu, 1.0)
                     gu_v = _chunks_of(gu, nc)
                 G.uses(gu)
                 G.part()
-            if l == n_layers:
-                # ---- modal chain, second half, issued behind the GCN chain's first gathers:
-                # gX = dropout-backward( reduce_scatter( A_ui[U_r, :]^T . t ) )
-                for c in range(nc):
-                    with M.on(c):
-                        part = bk.spmm_raw(twin(ui, 10 + c), True, _chunks_of(t, nc)[c], bk.EPI_NONE)
-                        gX_c[c] = _reduce_scatter_raw(part, per_i, g)
             gi_n = [None] * nc
             Gi_v = _chunks_of(Gi, nc)
             for c in range(nc):                 # g(i_{l-1}) = inv Gi + reduce_scatter( A_ui[U_r, :]^T . g(u_l) )
-                with G.on(c):
-                    part = bk.spmm_raw(twin(ui, 2 + c), True, gu_v[c], bk.EPI_NONE)
-                    gi_n[c] = _reduce_scatter_raw(part, per_i, g).add_(Gi_v[c], alpha=inv)
+                if first:
+                    with M.on(c):           # g(X) = dropout-backward( reduce_scatter( A_ui[U_r, :]^T . t ) )
+                        part_m = bk.spmm_raw(twin(ui, 10 + c), True, t_v[c], bk.EPI_NONE)
+                    with G.on(c):
+                        part_g = bk.spmm_raw(twin(ui, 2 + c), True, gu_v[c], bk.EPI_NONE)
+                    G.wait(c, M)
+                    with G.on(c):
+                        G.uses(part_m, [c])
+                        rg, gX_c[c] = _reduce_scatter_pair(part_g, part_m, per_i, g)
+                        gi_n[c] = rg.add_(Gi_v[c], alpha=inv)
+                    M.wait(c, G)
+                    M.uses(gX_c[c], [c])
+                else:
+                    with G.on(c):
+                        part_g = bk.spmm_raw(twin(ui, 2 + c), True, gu_v[c], bk.EPI_NONE)
+                        gi_n[c] = _reduce_scatter_raw(part_g, per_i, g).add_(Gi_v[c], alpha=inv)
             gi_c = gi_n
-        # ---- the weight gradient (current stream) next to the rest of the GCN chain
-        M.meet()
-        gX = torch.cat(gX_c, 1) if nc > 1 else gX_c[0]
-        if keep is not None:
-            gX = bk.mask_packed(gX, keep, d, scale)
-        gW, gb = bk.proj_wgrad(gX, list(Fs), any(has_b))
+            if first:
+                # ---- the weight gradient (current stream) next to the rest of the GCN chain
+                M.meet()
+                gX = torch.cat(gX_c, 1) if nc > 1 else gX_c[0]
+                if keep is not None:
+                    gX = bk.mask_packed(gX, keep, d, scale)
+                gW, gb = bk.proj_wgrad(gX, list(Fs), any(has_b))
         G.meet()
         with G.on(0):
             gi0 = torch.cat(gi_c, 1) if nc > 1 else gi_c[0]
@@ -1385,15 +1412,18 @@ def _exchange_edges_to_item_owners(users_g, items, ish, world, rank, dev):
     return recv[:, 0], recv[:, 1]
 
 
-def build_sharded_graph(a, rank, world, dev, scaling):
-    """The job's graph as this rank's two CSR row blocks (A_ui[U_r, :], A_iu[I_r, :], global columns).
+def build_sharded_graph(a, rank, world, dev, scaling, scheme="gather-both"):
+    """The job's graph as this rank's two local matrices (global column / row ids):
+        scheme gather-both : A_ui[U_r, :], A_iu[I_r, :]   (CSR row blocks of both directions)
+        scheme item-side   : A_ui[U_r, :], A_iu[:, U_r]   (this rank's users' edges only, seen from both sides)
 
     strong : the `a.workload` shape itself (configs[3]: Amazon-Baby sharded N-way). The global graph is small
-             (0.2 s to generate), so every rank generates it from the same seed and keeps its rows.
-    weak   : the shape x world. Each rank generates ONLY the interactions of its own user block (per-rank seed)
-             and the (user, item) pairs are routed to the item owners by one all-to-all: no rank ever holds the
-             global edge list. `synth` (configs[4]) is defined for the whole 8-GPU job, so its per-rank share is
-             2M/8 users x 1M/8 items x 100M/8 edges whatever N is.
+             (0.2 s to generate), so every rank generates it from the same seed and keeps its part.
+    weak   : the shape x world. Each rank generates ONLY the interactions of its own user block (per-rank seed).
+             gather-both: the (user, item) pairs are routed to the item owners by one all-to-all; item-side: no edge leaves
+             its rank - only the items' global degrees (A_iu's 1/sqrt(deg) values) are summed by one all-reduce. No rank
+             ever holds the global edge list. `synth` (configs[4]) is defined for the whole 8-GPU job, so its per-rank
+             share is 2M/8 users x 1M/8 items x 100M/8 edges whatever N is.
     Returns (ui_local, iu_local, ush, ish, U, I, E_global, dv, dt)."""
     from . import synth
     U, I, E, dv, dt = synth.SHAPES[a.workload]
@@ -1404,13 +1434,25 @@ def build_sharded_graph(a, rank, world, dev, scaling):
         raw = synth.interaction_matrix(U, I, E, seed=1)
         ui, iu = synth.normalised_pair(raw)
         ush, ish = RowShard(U, world, rank), RowShard(I, world, rank)
-        return shard_graph(ui, ush, ish), shard_graph(iu, ish, ush), ush, ish, U, I, int(raw.nnz), dv, dt
+        iu_l = shard_graph_cols(iu, ish, ush) if scheme == "item-side" else shard_graph(iu, ish, ush)
+        return shard_graph(ui, ush, ish), iu_l, ush, ish, U, I, int(raw.nnz), dv, dt
     Ug, Ig = U * world, I * world
     ush, ish = RowShard(Ug, world, rank), RowShard(Ig, world, rank)
     # my users' interactions with ALL items (item popularity shared by all ranks through the seed of `p`)
     raw_u = synth.interaction_matrix(U, Ig, E, seed=1000 + rank, item_seed=77)
     ui_l = synth.normalised_rows(raw_u)                               # [U, Ig] rows of A_ui
     ui_l.resize((ush.per, ish.n_pad))
+    t = torch.tensor([raw_u.nnz], dtype=torch.int64, device=dev)
+    if world > 1:
+        dist.all_reduce(t)
+    if scheme == "item-side":
+        deg = torch.from_numpy(np.asarray(raw_u.sum(0)).ravel().astype(np.int64)).to(dev)      # my users' share of every item's degree
+        if world > 1:
+            dist.all_reduce(deg)
+        sc = np.power(deg.cpu().numpy().astype(np.float64) + 1e-8, -0.5)
+        iu_l = (sp.diags(sc) @ raw_u.T.tocsr().astype(np.float32)).tocsr().astype(np.float32)  # A_iu[:, U_r]: [Ig, U]
+        iu_l.resize((ish.n_pad, ush.per))
+        return ui_l, iu_l, ush, ish, Ug, Ig, int(t.item()), dv, dt
     coo = raw_u.tocoo()
     if world > 1:
         ug, it = _exchange_edges_to_item_owners(coo.row.astype(np.int64) + ush.lo, coo.col.astype(np.int64), ish,
@@ -1419,9 +1461,6 @@ def build_sharded_graph(a, rank, world, dev, scaling):
         ug, it = coo.row.astype(np.int64), coo.col.astype(np.int64)
     raw_i = sp.csr_matrix((np.ones(ug.shape[0], np.float32), (it - ish.lo, ug)), shape=(ish.per, ush.n_pad))
     iu_l = synth.normalised_rows(raw_i)                               # [I_per, Ug] rows of A_iu
-    t = torch.tensor([raw_u.nnz], dtype=torch.int64, device=dev)
-    if world > 1:
-        dist.all_reduce(t)
     return ui_l, iu_l, ush, ish, Ug, Ig, int(t.item()), dv, dt
 
 
@@ -1430,7 +1469,8 @@ def build_bench_step(a, rank, world, dev, scaling="weak"):
     from . import synth
     from .config import configure, HotCfg
     configure([], embed_size=a.d, weight_size=str([a.d] * a.gcn_layers), batch_size=a.batch, drop_rate=0.2)
-    ui_l, iu_l, ush, ish, U, I, E_global, dv, dt = build_sharded_graph(a, rank, world, dev, scaling)
+    scheme = getattr(a, "scheme", "item-side")
+    ui_l, iu_l, ush, ish, U, I, E_global, dv, dt = build_sharded_graph(a, rank, world, dev, scaling, scheme)
     bk = HipBackend()
     with torch.cuda.device(dev):
         plans = [bk.make_graph(ui_l), bk.make_graph(iu_l)]
@@ -1452,6 +1492,7 @@ def build_bench_step(a, rank, world, dev, scaling="weak"):
     model = ShardedMMSSL.__new__(ShardedMMSSL)
     nn.Module.__init__(model)
     model.bk, model.cfg, model.ush, model.ish, model.group = bk, cfg, ush, ish, None
+    model.scheme, model.chunks = scheme, int(getattr(a, "chunks", 0))
     model.img_w = nn.Parameter(xavier(a.d, dv))
     model.img_b = nn.Parameter(torch.zeros(a.d))
     model.txt_w = nn.Parameter(xavier(a.d, dt))
@@ -1471,11 +1512,13 @@ def build_bench_step(a, rank, world, dev, scaling="weak"):
     ops.STATS["enabled"] = False
     stats = dict(ops.STATS)
     stats["comm_log"], COMM["log"] = COMM["log"], None
-    t = torch.tensor([stats["edge_layers"]], dtype=torch.int64, device=dev)
+    t = torch.tensor([int(round(stats["edge_layers"]))], dtype=torch.int64, device=dev)
     with torch.cuda.stream(step.stream):
         dist.all_reduce(t)
     torch.cuda.synchronize()
     stats["edge_layers_global"] = int(t.item())
+    stats["edge_layers"] = int(round(stats["edge_layers"]))
     stats.update(n_users=U, n_items=I, n_edges=E_global, local_users=ush.per, local_items=ish.per,
-                 local_edges=int(ui_l.nnz))
+                 local_edges=int(ui_l.nnz), scheme=scheme,
+                 chunks=(model.n_chunks(2) if (scheme == "item-side" and not _solo(None)) else 1))
     return step, (ui_l, iu_l), plans, stats

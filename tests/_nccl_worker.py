@@ -44,6 +44,13 @@ def _rel(a, b):
 import helpers as H   # noqa: E402  (tests/ is on sys.path above)
 
 _row_rel = H.row_rel
+# which sharding scheme / how many column chunks the cases run (the parent sets them per test)
+SCHEME = os.environ.get("MMSSL_TEST_SCHEME", "gather-both")
+CHUNKS = int(os.environ.get("MMSSL_TEST_CHUNKS", "0"))
+
+
+def _iu_local(md, iu, ish, ush):
+    return md.shard_graph_cols(iu, ish, ush) if SCHEME == "item-side" else md.shard_graph(iu, ish, ush)
 
 
 def _comm_kinds(md, fn):
@@ -68,9 +75,10 @@ def case_g8(out):
         def local_pair(m):
             ui, iu = O.csr_norm(m, True), O.csr_norm(m.T, True)
             return bk.make_graph(md.shard_graph(ui, ush, ish)), bk.make_graph(md.shard_graph(iu, ish, ush))
-        graphs = local_pair(raw) + local_pair(img_raw) + local_pair(txt_raw)
+        graphs = T._local_pair(md, bk, O, raw, ush, ish, SCHEME) + local_pair(img_raw) + local_pair(txt_raw)
         d, state, k_txt = T._pad_text_to_slices(d, state)      # whole 32-deep slices: the packed node runs
-        model = md.ShardedMMSSL(bk, cfg, ush, ish, state, d["image_feat"], d["text_feat"]).to(dev).train()
+        model = md.ShardedMMSSL(bk, cfg, ush, ish, state, d["image_feat"], d["text_feat"], scheme=SCHEME,
+                                chunks=CHUNKS).to(dev).train()
         step = md.ShardedHotPathStep(model, graphs, 48, I, modal_empty=(modal == "empty_shortcut"), optimizer=False)
         step.set_batch(torch.stack([users, pos, neg]).to(dev))
         ref_loss, P = T._reference(modal)
@@ -109,11 +117,13 @@ def case_g8(out):
         bk = md.HipBackend()
         cfg = O.Cfg(drop_rate=0.0, batch_size=48, n_ui_layers=2)
         graphs = ()
-        for m in (raw, img_raw, txt_raw):
+        for k, m in enumerate((raw, img_raw, txt_raw)):
             ui, iu = O.csr_norm(m, True), O.csr_norm(m.T, True)
-            graphs += (bk.make_graph(md.shard_graph(ui, ush, ish)), bk.make_graph(md.shard_graph(iu, ish, ush)))
+            graphs += (bk.make_graph(md.shard_graph(ui, ush, ish)),
+                       bk.make_graph(_iu_local(md, iu, ish, ush) if k == 0 else md.shard_graph(iu, ish, ush)))
         d2, st2, _ = T._pad_text_to_slices(d, state)
-        model = md.ShardedMMSSL(bk, cfg, ush, ish, st2, d2["image_feat"], d2["text_feat"]).to(dev).train()
+        model = md.ShardedMMSSL(bk, cfg, ush, ish, st2, d2["image_feat"], d2["text_feat"], scheme=SCHEME,
+                                chunks=CHUNKS).to(dev).train()
         step = md.ShardedHotPathStep(model, graphs, 48, I, lr=1e-2)
         step.set_batch(torch.stack([users, pos, neg]).to(dev))
         snap = [p.detach().clone() for p in model.parameters()]
@@ -139,7 +149,7 @@ def _baby_problem(dev):
     U, I, E, dv, dt = synth.SHAPES["baby"]
     config.configure([], drop_rate=0.2, batch_size=1024, weight_size=str([64] * 3), debug=True)
     a = types.SimpleNamespace(workload="baby")
-    ui_l, iu_l, ush, ish, U, I, E, dv, dt = md.build_sharded_graph(a, 0, 1, dev, "strong")
+    ui_l, iu_l, ush, ish, U, I, E, dv, dt = md.build_sharded_graph(a, 0, 1, dev, "strong", SCHEME)
     g = torch.Generator().manual_seed(0)
     img, txt = torch.randn(I, dv, generator=g), torch.randn(I, dt, generator=g)
     torch.manual_seed(4)
@@ -175,8 +185,10 @@ def case_baby(out):
     bk = md.HipBackend()
     plans = (bk.make_graph(pb["ui"]), bk.make_graph(pb["iu"]), bk.make_graph(pb["e_ui"]), bk.make_graph(pb["e_iu"]))
     graphs = (plans[0], plans[1], plans[2], plans[3], plans[2], plans[3])
-    model = md.ShardedMMSSL(bk, pb["cfg"], pb["ush"], pb["ish"], pb["state"], pb["img"].numpy(), pb["txt"].numpy())
+    model = md.ShardedMMSSL(bk, pb["cfg"], pb["ush"], pb["ish"], pb["state"], pb["img"].numpy(), pb["txt"].numpy(),
+                            scheme=SCHEME, chunks=CHUNKS)
     model = model.to(dev).train()
+    out["baby/chunks"] = model.n_chunks(2) if SCHEME == "item-side" else 1
     step = md.ShardedHotPathStep(model, graphs, 1024, pb["I"], modal_empty=True, optimizer=False)
     step.keep_masks = tuple(k.to(torch.uint8).to(dev) for k in pb["km"])
     step.set_batch(pb["batch"].to(dev))
@@ -213,8 +225,9 @@ def case_synth_rank(out):
     import mmssl_oracle as O
     from mmssl_amd import dist as md, ops
     dev = torch.device("cuda", 0)
-    a = types.SimpleNamespace(workload="synth", d=128, gcn_layers=3, batch=1024)
+    a = types.SimpleNamespace(workload="synth", d=128, gcn_layers=3, batch=1024, scheme=SCHEME, chunks=CHUNKS)
     step, (ui_l, iu_l), plans, stats = md.build_bench_step(a, 0, 1, dev, "weak")
+    out["synth/scheme"] = [stats["scheme"], stats["chunks"]]
     out["synth/shape"] = {k: stats[k] for k in ("local_users", "local_items", "local_edges", "spmm_launches")}
     g = torch.Generator().manual_seed(0)
     for name, plan, mat in (("ui", plans[0], ui_l), ("iu", plans[1], iu_l)):

@@ -283,32 +283,40 @@ def test_spawn_rank_probe(mode):
     assert r.returncode == 0, r.stderr[-2000:]
 
 
-def _graph_worker(rank, world, port, scaling, out_dir, workload="tiny"):
+def _graph_worker(rank, world, port, scaling, out_dir, workload="tiny", scheme="gather-both"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import types
     from mmssl_amd import dist as md
     a = types.SimpleNamespace(workload=workload)
-    ui_l, iu_l, ush, ish, U, I, E, dv, dt = md.build_sharded_graph(a, rank, world, torch.device("cpu"), scaling)
+    ui_l, iu_l, ush, ish, U, I, E, dv, dt = md.build_sharded_graph(a, rank, world, torch.device("cpu"), scaling, scheme)
     torch.save({"ui": ui_l, "iu": iu_l, "U": U, "I": I, "E": E, "per": (ush.per, ish.per)},
                os.path.join(out_dir, "g%d.pt" % rank))
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,scaling", [(2, "weak"), (3, "weak"), (2, "strong")])
-def test_sharded_graph_generation_is_one_consistent_global_graph(tmp_path, world, scaling):
+@pytest.mark.parametrize("world,scaling,scheme", [(2, "weak", "gather-both"), (3, "weak", "gather-both"),
+                                                  (2, "strong", "gather-both"), (3, "weak", "item-side"),
+                                                  (2, "strong", "item-side")])
+def test_sharded_graph_generation_is_one_consistent_global_graph(tmp_path, world, scaling, scheme):
     """bench.py's N>1 workloads: in weak mode every rank generates only its users' interactions and the edges
     reach the item owners through an all-to-all; the row blocks must assemble to ONE graph whose A_iu is the
     row-normalised transpose of the same interactions as A_ui (main.py:65-67), with nothing lost or duplicated."""
     import scipy.sparse as sp
     port = _free_port()
-    mp.spawn(_graph_worker, args=(world, port, scaling, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_graph_worker, args=(world, port, scaling, str(tmp_path), "tiny", scheme), nprocs=world, join=True)
     outs = [torch.load(os.path.join(str(tmp_path), "g%d.pt" % r), weights_only=False) for r in range(world)]
     U, I, E = outs[0]["U"], outs[0]["I"], outs[0]["E"]
     A_ui = sp.vstack([o["ui"] for o in outs]).tocsr()[:U, :I]
-    A_iu = sp.vstack([o["iu"] for o in outs]).tocsr()[:I, :U]
+    if scheme == "item-side":        # column blocks A_iu[:, U_r]: no edge left its rank, only the item degrees were summed
+        for o in outs:
+            assert o["iu"].shape == (o["per"][1] * world, o["per"][0])
+            assert ((o["iu"] != 0).astype(np.int8) != (o["ui"] != 0).astype(np.int8).T).nnz == 0      # the rank's own edges
+        A_iu = sp.hstack([o["iu"] for o in outs]).tocsr()[:I, :U]
+    else:
+        A_iu = sp.vstack([o["iu"] for o in outs]).tocsr()[:I, :U]
     assert A_ui.nnz == E == A_iu.nnz
     pat = (A_ui != 0).astype(np.float32)
     assert ((A_iu != 0).astype(np.float32) != pat.T).nnz == 0            # same interactions, transposed

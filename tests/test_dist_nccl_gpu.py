@@ -14,10 +14,14 @@ pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-def _run(case, tmp_path, timeout):
+SCHEMES = [("gather-both", 0), ("item-side", 1), ("item-side", 2)]
+
+
+def _run(case, tmp_path, timeout, scheme="gather-both", chunks=0):
     out = os.path.join(str(tmp_path), case + ".json")
     env = dict(os.environ)
     env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    env["MMSSL_TEST_SCHEME"], env["MMSSL_TEST_CHUNKS"] = scheme, str(chunks)
     for attempt in range(2):
         r = subprocess.run([sys.executable, os.path.join(HERE, "_nccl_worker.py"), case, out], env=env,
                            capture_output=True, text=True, timeout=timeout)
@@ -31,19 +35,22 @@ def _run(case, tmp_path, timeout):
     keep = os.environ.get("MMSSL_TEST_KEEP")          # optional: copy the records somewhere (profiles/ evidence)
     if keep:
         os.makedirs(keep, exist_ok=True)
-        json.dump(rec, open(os.path.join(keep, "nccl_%s.json" % case), "w"), indent=1)
+        json.dump(rec, open(os.path.join(keep, "nccl_%s_%s_c%d.json" % (case, scheme, chunks)), "w"), indent=1)
     return rec
 
 
-def test_g8_sharded_step_with_real_rccl_collectives_eager_and_captured(tmp_path):
-    rec = _run("g8", tmp_path, 600)
+@pytest.mark.parametrize("scheme,chunks", SCHEMES)
+def test_g8_sharded_step_with_real_rccl_collectives_eager_and_captured(tmp_path, scheme, chunks):
+    rec = _run("g8", tmp_path, 600, scheme, chunks)
+    nc = max(chunks, 1)
     for modal in ("full", "empty_shortcut"):
         kinds = rec["g8/%s/collectives" % modal]
-        # 2 GCN layers: 4 gathers / 4 reduce-scatters (the packed modal chain's ride along as grouped pairs), the batch-row
-        # all-reduce and the flat gradient bucket (which carries the regulariser share); the non-empty modal graphs add
-        # the two table gathers of the id views and their two reduce-scatters
+        # 2 GCN layers: 4 gathers / 4 reduce-scatters (the packed modal chain's ride along as grouped pairs; the item-side
+        # node issues every one of them once per column chunk), the batch-row all-reduce and the flat gradient bucket (which
+        # carries the regulariser share); the non-empty modal graphs add the two table gathers of the id views and their
+        # two reduce-scatters
         extra = 2 if modal == "full" else 0
-        assert kinds == {"all_gather": 4 + extra, "reduce_scatter": 4 + extra, "all_reduce": 2}, kinds
+        assert kinds == {"all_gather": 4 * nc + extra, "reduce_scatter": 4 * nc + extra, "all_reduce": 2}, kinds
         assert rec["g8/%s/captured" % modal], rec.get("g8/%s/capture_error" % modal)
         for tag in ("eager", "replay"):
             r = rec["g8/%s/%s" % (modal, tag)]
@@ -56,10 +63,13 @@ def test_g8_sharded_step_with_real_rccl_collectives_eager_and_captured(tmp_path)
     assert tr["eager"][-1] < tr["eager"][0]            # lr 1e-2: the loss moves
 
 
-def test_baby_strong_shape_sharded_step_with_real_rccl_matches_oracle(tmp_path):
-    rec = _run("baby", tmp_path, 900)
+@pytest.mark.parametrize("scheme,chunks", [("gather-both", 0), ("item-side", 2)])
+def test_baby_strong_shape_sharded_step_with_real_rccl_matches_oracle(tmp_path, scheme, chunks):
+    rec = _run("baby", tmp_path, 900, scheme, chunks)
     kinds = rec["baby/collectives"]
-    assert kinds == {"all_gather": 6, "reduce_scatter": 6, "all_reduce": 2}, kinds      # 14 launches per step
+    nc = max(chunks, 1)
+    assert rec["baby/chunks"] == nc
+    assert kinds == {"all_gather": 6 * nc, "reduce_scatter": 6 * nc, "all_reduce": 2}, kinds      # 14 launches per step whole
     assert rec["baby/captured"], rec.get("baby/capture_error")
     for tag in ("eager", "replay"):
         r = rec["baby/" + tag]
@@ -69,8 +79,10 @@ def test_baby_strong_shape_sharded_step_with_real_rccl_matches_oracle(tmp_path):
             assert r[k + "_rowwise"] < 5e-3, (tag, k, r[k + "_rowwise"])     # every row against its own scale
 
 
-def test_synth_rank_shape_spmm_and_sharded_step(tmp_path):
-    rec = _run("synth_rank", tmp_path, 900)
+@pytest.mark.parametrize("scheme,chunks", [("gather-both", 0), ("item-side", 2)])
+def test_synth_rank_shape_spmm_and_sharded_step(tmp_path, scheme, chunks):
+    rec = _run("synth_rank", tmp_path, 900, scheme, chunks)
+    assert rec["synth/scheme"] == [scheme, max(chunks, 1)]
     assert rec["synth/shape"]["local_edges"] > 12_000_000 and rec["synth/shape"]["local_users"] == 250_000
     for name in ("ui", "iu"):
         r = rec["synth/spmm_" + name]

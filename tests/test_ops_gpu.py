@@ -38,6 +38,48 @@ def _rand_graph(rows, cols, nnz_per_row, seed, heavy=(), empty=()):
     return m
 
 
+@pytest.mark.parametrize("w,nc", [(64, 2), (128, 2), (128, 4), (256, 2), (256, 4)])
+def test_spmm_on_column_chunks_of_wider_tables_is_bitwise_the_whole_product(w, nc):
+    """mmssl_spmm_ld_f32: the product on column CHUNKS of row-major [rows, w] tables in place (row-pitched X / Y / Z; the
+    sharded step's column-chunk lanes) - every plan class, both directions, plain and AXPY - equals the w-wide launch bit
+    for bit (same per-column summation order); and the stand-alone row softmax equals the fused epilogue bit for bit."""
+    ops, graph = _ops()
+    m = _rand_graph(700, 900, 6, seed=w + nc, heavy=[(5, 33), (6, 128), (7, 129), (8, 700), (699, 400), (9, 850)],
+                    empty=[0, 3, 698])
+    plan = graph.GraphPlan(m)
+    g = torch.Generator().manual_seed(2)
+    dc = w // nc
+    for tr, n_in, n_out in ((False, 900, 700), (True, 700, 900)):
+        X = torch.randn(n_in, w, generator=g).to(DEV)
+        Z = torch.randn(n_out, w, generator=g).to(DEV)
+        whole = ops._spmm_raw(plan, tr, X, ops.EPI_NONE)
+        whole_axpy = ops._spmm_raw(plan, tr, X, ops.EPI_AXPY, Z, 0.25)
+        Y = torch.full((n_out, w), float("nan"), device=DEV)
+        Ya = torch.full((n_out, w), float("nan"), device=DEV)
+        for c in range(nc):
+            sl = slice(c * dc, (c + 1) * dc)
+            ops._spmm_raw(plan.twin(20 + c), tr, X[:, sl], ops.EPI_NONE, out=Y[:, sl])             # pitched in, pitched out
+            ops._spmm_raw(plan.twin(20 + c), tr, X[:, sl].contiguous(), ops.EPI_AXPY, Z[:, sl], 0.25, out=Ya[:, sl])
+        assert torch.equal(Y, whole) and torch.equal(Ya, whole_axpy), (tr, w, nc)
+        # contiguous chunk out of a pitched input (what a reduce-scatter takes)
+        P = ops._spmm_raw(plan, tr, X[:, :dc], ops.EPI_NONE)
+        assert P.is_contiguous() and torch.equal(P, whole[:, :dc])
+    X = torch.randn(900, w, generator=g).to(DEV)
+    fused = ops._spmm_raw(plan, False, X, ops.EPI_SOFTMAX)
+    raw = ops._spmm_raw(plan, False, X, ops.EPI_NONE)
+    assert torch.equal(ops.softmax_rows(raw), fused)
+    assert torch.equal(ops.softmax_rows(raw, out=raw), fused)                 # in place
+    y = raw.clone().requires_grad_(True)                                      # (raw is softmaxed by now: any input will do)
+    sm = ops.softmax_rows_fn(y)
+    gy = torch.randn(700, w, generator=g).to(DEV)
+    sm.backward(gy)
+    yc = y.detach().cpu().requires_grad_(True)
+    torch.softmax(yc, -1).backward(gy.cpu())
+    assert H.rel_err(y.grad.cpu(), yc.grad) < 1e-5
+    with pytest.raises(Exception):        # the softmax epilogues need whole rows: not on a chunk
+        ops._spmm_raw(plan, False, X[:, :dc], ops.EPI_SOFTMAX)
+
+
 @pytest.mark.parametrize("d", [32, 64, 128, 256])
 def test_spmm_forward_transpose_softmax(d):
     ops, graph = _ops()

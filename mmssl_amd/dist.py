@@ -824,7 +824,7 @@ class _ShardedHotForward(torch.autograd.Function):
         if st.side is not None:
             gi.record_stream(st.main)
         grads_b = [(gb[k] if (gb is not None and has_b[k]) else None) for k in range(nm)]
-        bk.table_grads = (g_u0, gi)
+        bk.table_grads = (g_u0.data_ptr(), gi.data_ptr())
         return (None,) * 9 + (g_u0, gi) + (None,) * nm + tuple(gW) + tuple(grads_b)
 
 
@@ -865,21 +865,44 @@ class _Lanes:
                 if st is not self.main:
                     self.main.wait_stream(st)
 
-    def wait(self, c, other):
-        """This lane c waits for lane c of another lane set (two chains meeting at a grouped collective)."""
-        if self.cuda and self.streams[c] is not other.streams[c]:
-            self.streams[c].wait_stream(other.streams[c])
+    def coll(self, c, fn):
+        """One plain collective of lane c, issued on the lane."""
+        with self.on(c):
+            return fn()
+
+    def to_main(self, c):
+        """The origin stream waits for lane c (a grouped collective is issued from the origin stream)."""
+        if self.cuda and self.streams[c] is not self.main:
+            self.main.wait_stream(self.streams[c])
+
+    def after(self, c, ev):
+        if self.cuda and ev is not None and self.streams[c] is not self.main:
+            self.streams[c].wait_event(ev)
+
+    def mark(self):
+        return self.main.record_event() if self.cuda else None
 
     def meet(self):
-        """Lane 0 waits for all lanes (then runs the whole-row kernel); `part` lets the others continue behind it."""
-        if self.cuda:
+        """Lane 0 waits for all lanes (then runs the whole-row kernel); `part` lets the others continue behind it. Side
+        lanes synchronise THROUGH the origin stream: a direct wait between two forked streams of a hipGraph capture
+        crashes hipStreamEndCapture (ROCm 7.2; bisected on the GPU, tools/README.md)."""
+        if not self.cuda or self.n == 1:
+            return
+        if self.streams[0] is self.main:
             for st in self.streams[1:]:
-                self.streams[0].wait_stream(st)
+                self.main.wait_stream(st)
+            return
+        for st in self.streams:
+            self.main.wait_stream(st)
+        self.streams[0].wait_stream(self.main)
 
     def part(self):
-        if self.cuda:
-            for st in self.streams[1:]:
-                st.wait_stream(self.streams[0])
+        if not self.cuda or self.n == 1:
+            return
+        if self.streams[0] is not self.main:
+            self.main.wait_stream(self.streams[0])
+        for st in self.streams[1:]:
+            st.wait_stream(self.main)
 
     def uses(self, t, lanes=None):
         """`t` (allocated on the current stream) is read / written on the lanes: tell the caching allocator."""
@@ -934,11 +957,16 @@ class _ShardedItemSide(torch.autograd.Function):
         new = lambda rows, w: torch.empty((rows, w), dtype=torch.float32, device=u0.device)      # noqa: E731
         G = _Lanes(bk, u0, nc)                                    # GCN chain: nc side lanes
         M = _Lanes(bk, u0, nc, base=nc, first_is_current=True)    # modal chain: the current stream + nc - 1 lanes
+        # Every table the LANES write is allocated here, on the origin stream BEFORE the fork: the caching allocator may hand
+        # out a block whose last user is an earlier kernel of the allocating stream, which is only safe for writers ordered
+        # behind that stream's work at allocation time - the lanes are, through the fork, and only then (a table allocated
+        # mid-way would land in memory a still-running origin-stream kernel uses: seen as a wrong weight gradient).
+        u_new = [new(per_u, d) for _ in range(n_layers)]
+        MU = new(per_u, wm)
         G.fork()
         X, keep = bk.proj_forward(list(Fs), list(Ws), list(bs), keep, scale, draw_p, ext_tick)      # [per_i, nm d], current stream
         M.fork()
-        MU = new(per_u, wm)
-        for t_ in (MU, X):
+        for t_ in [MU, X] + u_new:
             M.uses(t_)
             G.uses(t_)
         MU_v, X_v, MI_c = _chunks_of(MU, nc), _chunks_of(X, nc), [None] * nc
@@ -955,22 +983,31 @@ class _ShardedItemSide(torch.autograd.Function):
         pair_at = (max(0, n_layers - 2), n_layers - 1)
         for l in range(n_layers):
             last = l == n_layers - 1
-            u = new(per_u, d)
-            G.uses(u)
+            u = u_new[l]
             u_v = _chunks_of(u, nc)
-            for c in range(nc):                 # item rows -> user rows: gather, product into the lane's column chunk
-                if l == pair_at[0]:
-                    G.wait(c, M)
+            if l == pair_at[0]:
+                # grouped pairs are issued from the ORIGIN stream, all of them before the products they feed (a grouped
+                # launch recorded on a forked stream of a hipGraph capture crashes hipStreamEndCapture, ROCm 7.2): lane c's
+                # products wait for pair c only
+                fulls = []
+                for c in range(nc):
+                    G.to_main(c)
+                    M.to_main(c)
+                    fulls.append(_all_gather_pair(i_c[c], X_v[c].contiguous() if nc > 1 else X, g) + (G.mark(),))
+                for c, (i_full, X_full, ev) in enumerate(fulls):
+                    G.after(c, ev)
+                    M.after(c, ev)
                     with G.on(c):
-                        i_full, X_full = _all_gather_pair(i_c[c], X_v[c].contiguous() if nc > 1 else X, g)
+                        G.uses(i_full, [c])
                         bk.spmm_raw(twin(ui, 2 + c), False, i_full, bk.EPI_NONE, out=u_v[c])
-                    M.wait(c, G)
                     with M.on(c):
                         M.uses(X_full, [c])
                         bk.spmm_raw(twin(ui, 10 + c), False, X_full, bk.EPI_NONE, out=MU_v[c])
-                else:
+                del fulls
+            else:
+                for c in range(nc):             # item rows -> user rows: gather, product into the lane's column chunk
+                    i_full = G.coll(c, lambda: _all_gather_raw(i_c[c], g))
                     with G.on(c):
-                        i_full = _all_gather_raw(i_c[c], g)
                         bk.spmm_raw(twin(ui, 2 + c), False, i_full, bk.EPI_NONE, out=u_v[c])
             if last:
                 G.meet()
@@ -978,22 +1015,34 @@ class _ShardedItemSide(torch.autograd.Function):
                     bk.softmax_rows_(u)
                 G.part()
             i_n = [None] * nc
-            for c in range(nc):                 # user rows -> ALL item rows (partial), summed into the owners' rows
-                if l == pair_at[1]:
+            if l == pair_at[1]:                 # user rows -> ALL item rows (partial), summed into the owners' rows
+                parts = []
+                for c in range(nc):
                     with M.on(c):
                         PM = bk.spmm_raw(twin(iuT, 10 + c), False, MU_v[c], bk.EPI_NONE)
                     with G.on(c):
                         P = bk.spmm_raw(twin(iuT, 2 + c), False, u_v[c], bk.EPI_NONE)
-                    G.wait(c, M)
-                    with G.on(c):
-                        G.uses(PM, [c])
-                        i_n[c], MI_c[c] = _reduce_scatter_pair(P, PM, per_i, g)
-                    M.wait(c, G)
+                    parts.append((P, PM))
+                evs = []
+                for c, (P, PM) in enumerate(parts):
+                    G.to_main(c)
+                    M.to_main(c)
+                    i_n[c], MI_c[c] = _reduce_scatter_pair(P, PM, per_i, g)
+                    G.uses(i_n[c], [c])
                     M.uses(MI_c[c], [c])
-                else:
+                    for t_ in (P, PM):          # allocated on a lane, read by the collective issued from the origin stream
+                        if G.cuda:
+                            t_.record_stream(G.main)
+                    evs.append(G.mark())
+                for c, ev in enumerate(evs):
+                    G.after(c, ev)
+                    M.after(c, ev)
+                del parts
+            else:
+                for c in range(nc):
                     with G.on(c):
                         P = bk.spmm_raw(twin(iuT, 2 + c), False, u_v[c], bk.EPI_NONE)
-                        i_n[c] = _reduce_scatter_raw(P, per_i, g)
+                    i_n[c] = G.coll(c, lambda: _reduce_scatter_raw(P, per_i, g))
             if nc > 1 or last:
                 G.meet()
             with G.on(0):
@@ -1033,6 +1082,8 @@ class _ShardedItemSide(torch.autograd.Function):
         new = lambda rows, w: torch.empty((rows, w), dtype=torch.float32, device=Gu.device)      # noqa: E731
         G = _Lanes(bk, Gu, nc)
         M = _Lanes(bk, Gu, nc, base=nc, first_is_current=True)
+        gu_new = [new(per_u, d) for _ in range(n_layers)]          # allocated before the fork: see forward
+        t = new(per_u, wm)
         G.fork()
         gMU, g_u0, gMI = bk.fuse_bwd(MU, Gu, G_MU, MI, Gi, G_MI, nm, r, inv, g_ss)         # current stream
         if G.cuda:
@@ -1043,8 +1094,7 @@ class _ShardedItemSide(torch.autograd.Function):
             for t_ in (uG, iG, Gu, Gi, g_u0):
                 G.uses(t_)
         M.fork()
-        t = new(per_u, wm)
-        for t_ in (t, gMU, gMI):
+        for t_ in [t, gMU, gMI] + gu_new:
             M.uses(t_)
             G.uses(t_)
         t_v, gMU_v, gMI_v = _chunks_of(t, nc), _chunks_of(gMU, nc), _chunks_of(gMI, nc)
@@ -1057,22 +1107,28 @@ class _ShardedItemSide(torch.autograd.Function):
         gX_c = [None] * nc
         for l in range(n_layers, 0, -1):
             first = l == n_layers               # the last layer comes first; the modal chain's collectives ride on its pair
-            gu = new(per_u, d)
-            G.uses(gu)
+            gu = gu_new[l - 1]
             gu_v, Gu_v = _chunks_of(gu, nc), _chunks_of(Gu, nc)
-            for c in range(nc):                 # g(u_l) = inv Gu + A_iu[:, U_r]^T . all_gather(g(i_l))
-                if first:
-                    G.wait(c, M)
+            if first:                           # g(u_l) = inv Gu + A_iu[:, U_r]^T . all_gather(g(i_l))
+                fulls = []
+                for c in range(nc):             # (grouped pairs from the origin stream, see forward)
+                    G.to_main(c)
+                    M.to_main(c)
+                    fulls.append(_all_gather_pair(gi_c[c], gMI_v[c].contiguous() if nc > 1 else gMI, g) + (G.mark(),))
+                for c, (gP, gPM, ev) in enumerate(fulls):
+                    G.after(c, ev)
+                    M.after(c, ev)
                     with G.on(c):
-                        gP, gPM = _all_gather_pair(gi_c[c], gMI_v[c].contiguous() if nc > 1 else gMI, g)
+                        G.uses(gP, [c])
                         bk.spmm_raw(twin(iuT, 2 + c), True, gP, bk.EPI_AXPY, Gu_v[c], inv, out=gu_v[c])
-                    M.wait(c, G)
                     with M.on(c):           # t = g(MU) = own branch + A_iu[:, U_r]^T . all_gather(g(MI))
                         M.uses(gPM, [c])
                         bk.spmm_raw(twin(iuT, 10 + c), True, gPM, bk.EPI_AXPY, gMU_v[c], 1.0, out=t_v[c])
-                else:
+                del fulls
+            else:
+                for c in range(nc):
+                    gP = G.coll(c, lambda: _all_gather_raw(gi_c[c], g))
                     with G.on(c):
-                        gP = _all_gather_raw(gi_c[c], g)
                         bk.spmm_raw(twin(iuT, 2 + c), True, gP, bk.EPI_AXPY, Gu_v[c], inv, out=gu_v[c])
             if first:
                 G.meet()
@@ -1083,23 +1139,38 @@ class _ShardedItemSide(torch.autograd.Function):
                 G.part()
             gi_n = [None] * nc
             Gi_v = _chunks_of(Gi, nc)
-            for c in range(nc):                 # g(i_{l-1}) = inv Gi + reduce_scatter( A_ui[U_r, :]^T . g(u_l) )
-                if first:
+            if first:                           # g(i_{l-1}) = inv Gi + reduce_scatter( A_ui[U_r, :]^T . g(u_l) )
+                parts = []
+                for c in range(nc):
                     with M.on(c):           # g(X) = dropout-backward( reduce_scatter( A_ui[U_r, :]^T . t ) )
                         part_m = bk.spmm_raw(twin(ui, 10 + c), True, t_v[c], bk.EPI_NONE)
                     with G.on(c):
                         part_g = bk.spmm_raw(twin(ui, 2 + c), True, gu_v[c], bk.EPI_NONE)
-                    G.wait(c, M)
-                    with G.on(c):
-                        G.uses(part_m, [c])
-                        rg, gX_c[c] = _reduce_scatter_pair(part_g, part_m, per_i, g)
-                        gi_n[c] = rg.add_(Gi_v[c], alpha=inv)
-                    M.wait(c, G)
+                    parts.append((part_g, part_m))
+                rgs = []
+                for c, (part_g, part_m) in enumerate(parts):
+                    G.to_main(c)
+                    M.to_main(c)
+                    rg, gX_c[c] = _reduce_scatter_pair(part_g, part_m, per_i, g)
+                    G.uses(rg, [c])
                     M.uses(gX_c[c], [c])
-                else:
+                    for t_ in (part_g, part_m):
+                        if G.cuda:
+                            t_.record_stream(G.main)
+                    rgs.append((rg, G.mark()))
+                for c, (rg, ev) in enumerate(rgs):
+                    G.after(c, ev)
+                    M.after(c, ev)
+                    with G.on(c):
+                        gi_n[c] = rg.add_(Gi_v[c], alpha=inv)
+                del parts, rgs
+            else:
+                for c in range(nc):
                     with G.on(c):
                         part_g = bk.spmm_raw(twin(ui, 2 + c), True, gu_v[c], bk.EPI_NONE)
-                        gi_n[c] = _reduce_scatter_raw(part_g, per_i, g).add_(Gi_v[c], alpha=inv)
+                    rs = G.coll(c, lambda: _reduce_scatter_raw(part_g, per_i, g))
+                    with G.on(c):
+                        gi_n[c] = rs.add_(Gi_v[c], alpha=inv)
             gi_c = gi_n
             if first:
                 # ---- the weight gradient (current stream) next to the rest of the GCN chain
@@ -1116,7 +1187,7 @@ class _ShardedItemSide(torch.autograd.Function):
         if G.cuda:
             gi0.record_stream(G.main)
         grads_b = [(gb[k] if (gb is not None and has_b[k]) else None) for k in range(nm)]
-        bk.table_grads = (g_u0, gi0)
+        bk.table_grads = (g_u0.data_ptr(), gi0.data_ptr())
         return (None,) * 10 + (g_u0, gi0) + (None,) * nm + tuple(gW) + tuple(grads_b)
 
 
@@ -1227,7 +1298,7 @@ class ShardedHotPathStep:
             side.wait_event(m.bk.after_fuse_bwd)
             # only ahead of the current stream if the tables' .grad ARE the node's buffers (see hotpath.HotPathStep._step)
             tg = getattr(m.bk, "table_grads", None)
-            if tg is None or any(p.grad is None or p.grad.data_ptr() != g.data_ptr() for p, g in zip((m.E_u, m.E_i), tg)):
+            if tg is None or any(p.grad is None or p.grad.data_ptr() != g for p, g in zip((m.E_u, m.E_i), tg)):
                 side.wait_event(main.record_event())
             with torch.cuda.stream(side):
                 self.optimizer.step(external_tick=True, exclude=m.replicated_parameters())
@@ -1285,7 +1356,6 @@ class ShardedHotPathStep:
         bk = m.bk
         early = bool(own_ticks and self.modal_empty and hasattr(bk, "side_streams"))
         self._tables_early = early
-        bk.after_fuse_bwd, bk.table_grads, bk.tables_stream = None, None, None
         self._tables_joined = False
         try:
             total = self.backward()
@@ -1301,6 +1371,9 @@ class ShardedHotPathStep:
             self._ticks = None
             self._tables_early = False
             self.model._external_ticks = False
+            # dropped HERE, not at the start of the next step: a tensor of this step released inside the next step's
+            # capture region ends in a segfault inside hipStreamEndCapture (ROCm 7.2)
+            bk.after_fuse_bwd, bk.table_grads, bk.tables_stream = None, None, None
         return total
 
     def step(self):

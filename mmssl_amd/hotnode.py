@@ -234,7 +234,7 @@ class _HotNode(torch.autograd.Function):
             main.wait_stream(sC)
             gi.record_stream(main)
         grads_b = [(gb[k] if (gb is not None and has_b[k]) else None) for k in range(nm)]
-        hot.table_grads = (g_u0, gi)
+        hot.table_grads = (g_u0.data_ptr(), gi.data_ptr())     # addresses only: a reference would keep AccumulateGrad from stealing the buffers
         return (None,) * 9 + (g_u0, gi) + (None,) * nm + tuple(gW) + tuple(grads_b)
 
 

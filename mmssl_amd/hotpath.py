@@ -230,7 +230,7 @@ class HotPathStep:
                 # stream, which the update then has to wait for. Decided at capture time for a replayed graph.
                 tg = hot.table_grads
                 m = self.model
-                if tg is None or any(p.grad is None or p.grad.data_ptr() != g.data_ptr()
+                if tg is None or any(p.grad is None or p.grad.data_ptr() != g
                                      for p, g in zip((m.user_id_embedding.weight, m.item_id_embedding.weight), tg)):
                     sC.wait_event(main.record_event())
                 with torch.cuda.stream(sC):

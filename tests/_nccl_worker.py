@@ -268,6 +268,8 @@ def case_synth_rank(out):
 
 
 def main():
+    import faulthandler
+    faulthandler.enable()
     case, path = sys.argv[1], sys.argv[2]
     dist = _init()
     out = {"case": case, "backend": dist.get_backend()}

@@ -39,10 +39,13 @@ def _rand_graph(rows, cols, nnz_per_row, seed, heavy=(), empty=()):
 
 
 @pytest.mark.parametrize("w,nc", [(64, 2), (128, 2), (128, 4), (256, 2), (256, 4)])
-def test_spmm_on_column_chunks_of_wider_tables_is_bitwise_the_whole_product(w, nc):
+def test_spmm_on_column_chunks_of_wider_tables_equals_the_whole_product(w, nc):
     """mmssl_spmm_ld_f32: the product on column CHUNKS of row-major [rows, w] tables in place (row-pitched X / Y / Z; the
-    sharded step's column-chunk lanes) - every plan class, both directions, plain and AXPY - equals the w-wide launch bit
-    for bit (same per-column summation order); and the stand-alone row softmax equals the fused epilogue bit for bit."""
+    sharded step's column-chunk lanes) - every plan class, both directions, plain and AXPY - against the w-wide launch:
+    bit-equal on rows of at most 32 nonzeros (one lane group walks the row in edge order whatever the width), to fp32
+    rounding on longer rows (their edge tiles are dealt to 64 / (width / 4) lane groups, so the summation order depends on
+    the width); pitched and contiguous launches of the SAME width agree bit for bit; the stand-alone row softmax equals
+    the fused epilogue bit for bit."""
     ops, graph = _ops()
     m = _rand_graph(700, 900, 6, seed=w + nc, heavy=[(5, 33), (6, 128), (7, 129), (8, 700), (699, 400), (9, 850)],
                     empty=[0, 3, 698])
@@ -60,10 +63,15 @@ def test_spmm_on_column_chunks_of_wider_tables_is_bitwise_the_whole_product(w, n
             sl = slice(c * dc, (c + 1) * dc)
             ops._spmm_raw(plan.twin(20 + c), tr, X[:, sl], ops.EPI_NONE, out=Y[:, sl])             # pitched in, pitched out
             ops._spmm_raw(plan.twin(20 + c), tr, X[:, sl].contiguous(), ops.EPI_AXPY, Z[:, sl], 0.25, out=Ya[:, sl])
-        assert torch.equal(Y, whole) and torch.equal(Ya, whole_axpy), (tr, w, nc)
-        # contiguous chunk out of a pitched input (what a reduce-scatter takes)
+        assert not torch.isnan(Y).any() and not torch.isnan(Ya).any()          # every row of every chunk written
+        assert H.rel_err(Y.cpu(), whole.cpu()) < 2e-6 and H.rel_err(Ya.cpu(), whole_axpy.cpu()) < 2e-6, (tr, w, nc)
+        deg = np.diff((m.T.tocsr() if tr else m).indptr)
+        short = torch.from_numpy(np.nonzero(deg <= 32)[0]).to(DEV)
+        assert torch.equal(Y[short], whole[short]) and torch.equal(Ya[short], whole_axpy[short])
+        # contiguous chunk out of a pitched input (what a reduce-scatter takes) == the same chunk launched all-contiguous
         P = ops._spmm_raw(plan, tr, X[:, :dc], ops.EPI_NONE)
-        assert P.is_contiguous() and torch.equal(P, whole[:, :dc])
+        assert P.is_contiguous() and torch.equal(P, Y[:, :dc])
+        assert torch.equal(P, ops._spmm_raw(plan, tr, X[:, :dc].contiguous(), ops.EPI_NONE))
     X = torch.randn(900, w, generator=g).to(DEV)
     fused = ops._spmm_raw(plan, False, X, ops.EPI_SOFTMAX)
     raw = ops._spmm_raw(plan, False, X, ops.EPI_NONE)

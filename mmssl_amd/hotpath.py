@@ -82,7 +82,10 @@ class HotPathStep:
         # ONE stream for everything this object launches (eager steps, capture, replays): autograd
         # binds each parameter's AccumulateGrad node to the stream of its first backward, and a
         # later capture on a different stream would have to synchronise across streams.
-        self.stream = torch.cuda.Stream(device=dev)
+        # The step's own stream - the critical projection / modal / loss chain - runs at high priority: its workgroups are
+        # dispatched ahead of the GCN chain's (side streams, default priority) wherever both are ready (measured: 0.481-0.485
+        # against 0.487-0.490 ms per step, two alternating pairs on one box).
+        self.stream = torch.cuda.Stream(device=dev, priority=-1)
         self.stream.wait_stream(torch.cuda.current_stream(dev))
 
     def set_batch(self, users, pos=None, neg=None):

@@ -59,9 +59,19 @@ typedef struct mmssl_graph mmssl_graph;
 int mmssl_graph_create(const int32_t* rowptr, const int32_t* col, const float* val,
                        int32_t rows, int32_t cols, int64_t nnz, void* stream,
                        mmssl_graph** out);
+/* The same with the XCD banding of the work list stated explicitly. xcd_bands: 0 = automatic (what mmssl_graph_create
+ * does: a direction's short rows are banded when >= 50 % of its edges fall into their row's dominant column band and the
+ * bands are balanced - a graph with community / locality structure whose rows and columns are numbered accordingly),
+ * 1 = always, -1 = never. Banding
+ * changes which block processes which row, never the arithmetic: results are bit-identical either way. */
+int mmssl_graph_create_ex(const int32_t* rowptr, const int32_t* col, const float* val,
+                          int32_t rows, int32_t cols, int64_t nnz, int xcd_bands, void* stream,
+                          mmssl_graph** out);
 int mmssl_graph_destroy(mmssl_graph* g);
 /* info[0..7] = rows, cols, nnz, group_items, wave_items, multi_rows, partial_slots,
- *              same five for the transpose in info[8..12] (info has 16 slots). */
+ *              same four for the transpose in info[8..11]; info[12..14] = work-list shaping constants;
+ *              info[15] = XCD banding: bit 0 / 1 = forward / transposed direction banded, bits 8..23 / 24..39 = the
+ *              directions' locality scores in 1/1000. */
 int mmssl_graph_info(const mmssl_graph* g, int64_t info[16]);
 /* Copy the device-resident transposed CSR back to host buffers (tests / debugging). */
 int mmssl_graph_export_transpose(const mmssl_graph* g, int32_t* t_rowptr, int32_t* t_col,
@@ -94,6 +104,14 @@ int mmssl_csr_validate_host(const int32_t* rowptr, const int32_t* col, int32_t r
 int mmssl_csr_transpose_host(const int32_t* rowptr, const int32_t* col, const float* val,
                              int32_t rows, int32_t cols, int64_t nnz, int32_t* t_rowptr,
                              int32_t* t_col, float* t_val);
+/* XCD banding of a plan's group items (no reference counterpart: an MI355X placement matter). The columns are cut into
+ * n_bands equal ranges; band_of_row[r] = the band most of row r's edges fall into, *score = the fraction of all edges that
+ * fall into their row's band (1 / n_bands for uniformly random columns). mmssl_plan_band_group_items_host reorders the
+ * degree-sorted group items band-major (stable) and returns the band boundaries. */
+int mmssl_plan_band_host(const int32_t* rowptr, const int32_t* col, int32_t rows, int32_t cols, int32_t n_bands,
+                         int32_t* band_of_row, double* score);
+int mmssl_plan_band_group_items_host(int32_t* group_items, int64_t n_g, const int32_t* band_of_row, int32_t n_bands,
+                                     int32_t* band_start);
 /* counts[0..3] = group_items, wave_items (incl. padding), multi_rows, partial_slots */
 int mmssl_plan_count_host(const int32_t* rowptr, int32_t rows, int64_t counts[4]);
 /* items are int32 quadruples {row, edge_begin, edge_end, code}:

@@ -18,7 +18,16 @@ struct DirPlan {
   // device-built plans: the real item counts {n_g, n_w, n_multi, n_slots, nnz} live HERE (device int32[8]); the host
   // fields above then are CAPACITIES (launch grids and workspaces are sized by them)
   int32_t* dyn = nullptr;
+  // XCD-banded group items (host-built plans whose rows mostly reference ONE of kBands column bands): gitems is laid out
+  // band-major, bands[x] .. bands[x + 1] are the items of band x (device int32[kBands + 1]); block b takes its items from
+  // band b % 8 - the XCD it is observed to run on - so that an XCD's L2 holds one band of the gathered table instead of
+  // all of it. band_max = the longest band (sizes the grid). nullptr: the flat degree-sorted list.
+  int32_t* bands = nullptr;
+  int64_t band_max = 0;
+  double band_score = 0.0;      // fraction of the edges that fall into their row's dominant band
 };
+
+constexpr int kBands = 8;
 
 
 void free_dir(DirPlan& p);

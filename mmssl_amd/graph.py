@@ -20,7 +20,10 @@ class GraphPlan:
     COO tensor (the reference's handle type). The current CUDA device owns the plan.
     """
 
-    def __init__(self, mat, device=None):
+    def __init__(self, mat, device=None, xcd_bands=0):
+        """xcd_bands: 0 = the short rows' work list is XCD-banded when the graph has column locality (>= 50 % of a
+        direction's edges in their row's dominant column band, balanced bands), 1 = always, -1 = never (see mmssl_graph_create_ex; results
+        are bit-identical, only the block -> row assignment changes)."""
         if isinstance(mat, torch.Tensor):
             mat = _coo_tensor_to_scipy(mat)
         csr = sp.csr_matrix(mat, dtype=np.float32)
@@ -35,11 +38,11 @@ class GraphPlan:
         self._handle = ctypes.c_void_p()
         self._ws = {}
         with torch.cuda.device(self.device):
-            rc = _lib.lib().mmssl_graph_create(
+            rc = _lib.lib().mmssl_graph_create_ex(
                 rowptr.ctypes.data, col.ctypes.data if self.nnz else None,
-                val.ctypes.data if self.nnz else None, self.shape[0], self.shape[1], self.nnz,
+                val.ctypes.data if self.nnz else None, self.shape[0], self.shape[1], self.nnz, int(xcd_bands),
                 _lib.stream_ptr(), ctypes.byref(self._handle))
-        _lib.check(rc, "mmssl_graph_create")
+        _lib.check(rc, "mmssl_graph_create_ex")
 
     # -- reference-handle compatibility -------------------------------------------------
     def _nnz(self):
@@ -64,7 +67,11 @@ class GraphPlan:
         keys = ["rows", "cols", "nnz", "group_items", "wave_items", "multi_rows", "partial_slots", "_",
                 "t_group_items", "t_wave_items", "t_multi_rows", "t_partial_slots", "short_max",
                 "task_nnz", "sorted"]
-        return {k: int(v) for k, v in zip(keys, buf) if k != "_"}
+        out = {k: int(v) for k, v in zip(keys, buf) if k != "_"}
+        b = int(buf[15])
+        out.update(banded=bool(b & 1), t_banded=bool(b & 2), band_score=((b >> 8) & 0xffff) / 1000.0,
+                   t_band_score=((b >> 24) & 0xffff) / 1000.0)
+        return out
 
     def workspace(self, transpose, d, lane=0):
         """Scratch of one SpMM launch (partial sums of the rows that span several blocks + their arrival

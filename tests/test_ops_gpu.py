@@ -88,6 +88,37 @@ def test_spmm_on_column_chunks_of_wider_tables_equals_the_whole_product(w, nc):
         ops._spmm_raw(plan, False, X[:, :dc], ops.EPI_SOFTMAX)
 
 
+@pytest.mark.parametrize("d", [32, 64, 128])
+def test_xcd_banded_plan_is_bitwise_the_flat_plan(d):
+    """GraphPlan(xcd_bands=...): the short rows' work list laid out band-major (block b takes rows of column band b % 8,
+    the XCD it runs on) changes which block computes which row, nothing else: forward, transpose and every epilogue equal
+    the flat plan bit for bit - on a community-structured graph (banded automatically) and on a graph without locality
+    (banded only when forced, unbalanced bands included)."""
+    ops, graph = _ops()
+    from mmssl_amd import synth
+    g = torch.Generator().manual_seed(d)
+    for kind, raw in (("communities", synth.interaction_matrix_communities(3000, 1900, 24000, seed=2)),
+                      ("uniform", synth.interaction_matrix(3000, 1900, 24000, seed=2))):
+        ui = synth.normalised_rows(raw)
+        flat, auto, forced = graph.GraphPlan(ui, xcd_bands=-1), graph.GraphPlan(ui), graph.GraphPlan(ui, xcd_bands=1)
+        assert not flat.info()["banded"] and forced.info()["banded"] and forced.info()["t_banded"]
+        assert auto.info()["banded"] == (kind == "communities"), (kind, auto.info())
+        assert (auto.info()["band_score"] > 0.8) == (kind == "communities")
+        X, G = torch.randn(1900, d, generator=g).to(DEV), torch.randn(3000, d, generator=g).to(DEV)
+        Z = torch.randn(3000, d, generator=g).to(DEV)
+        for plan in (auto, forced):
+            assert torch.equal(ops._spmm_raw(plan, False, X, ops.EPI_NONE), ops._spmm_raw(flat, False, X, ops.EPI_NONE))
+            assert torch.equal(ops._spmm_raw(plan, True, G, ops.EPI_NONE), ops._spmm_raw(flat, True, G, ops.EPI_NONE))
+            assert torch.equal(ops._spmm_raw(plan, False, X, ops.EPI_SOFTMAX), ops._spmm_raw(flat, False, X, ops.EPI_SOFTMAX))
+            assert torch.equal(ops._spmm_raw(plan, False, X, ops.EPI_AXPY, Z, 0.5), ops._spmm_raw(flat, False, X, ops.EPI_AXPY, Z, 0.5))
+            Y = torch.full((3000, d), float("nan"), device=DEV)
+            ops._spmm_raw(plan, False, X[:, :d], ops.EPI_NONE, out=Y)
+            assert not torch.isnan(Y).any()                  # every row written exactly once, idle band blocks included
+    # empty and tiny graphs: nothing to band, nothing breaks
+    e = graph.GraphPlan(sp.csr_matrix((50, 40), dtype=np.float32), xcd_bands=1)
+    assert float(ops._spmm_raw(e, False, torch.randn(40, d).to(DEV), ops.EPI_NONE).abs().max()) == 0.0
+
+
 @pytest.mark.parametrize("d", [32, 64, 128, 256])
 def test_spmm_forward_transpose_softmax(d):
     ops, graph = _ops()

@@ -112,6 +112,11 @@ int mmssl_plan_band_host(const int32_t* rowptr, const int32_t* col, int32_t rows
                          int32_t* band_of_row, double* score);
 int mmssl_plan_band_group_items_host(int32_t* group_items, int64_t n_g, const int32_t* band_of_row, int32_t n_bands,
                                      int32_t* band_start);
+/* The wave items' side of the banding: the light section is reordered band-major in place and wmap[b] (ceil(n_w / 4)
+ * entries, a permutation) names the wave block - 4 consecutive wave items - that hardware block b processes: one of band
+ * b % n_bands while that band has any, heaviest first. */
+int mmssl_plan_band_wave_blocks_host(int32_t* wave_items, int64_t n_w, const int32_t* band_of_row, int32_t n_bands,
+                                     int32_t* wmap);
 /* counts[0..3] = group_items, wave_items (incl. padding), multi_rows, partial_slots */
 int mmssl_plan_count_host(const int32_t* rowptr, int32_t rows, int64_t counts[4]);
 /* items are int32 quadruples {row, edge_begin, edge_end, code}:

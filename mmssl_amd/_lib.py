@@ -42,6 +42,7 @@ SIGNATURES = {
                                       POINTER(c_void_p)]),
     "mmssl_plan_band_host": (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
     "mmssl_plan_band_group_items_host": (c_int, [c_void_p, c_int64, c_void_p, c_int32, c_void_p]),
+    "mmssl_plan_band_wave_blocks_host": (c_int, [c_void_p, c_int64, c_void_p, c_int32, c_void_p]),
     "mmssl_plan_count_host": (c_int, [c_void_p, c_int32, _i64p]),
     "mmssl_plan_fill_host": (c_int, [c_void_p, c_int32, c_void_p, c_void_p, c_void_p]),
     "mmssl_graph_rows_mask_normalize_f32": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_float, c_void_p,

@@ -42,6 +42,7 @@ namespace mmssl {
 void free_dir(DirPlan& p) {
   if (p.dyn) (void)hipFree(p.dyn);
   if (p.bands) (void)hipFree(p.bands);
+  if (p.wmap) (void)hipFree(p.wmap);
   if (p.rowptr) (void)hipFree(p.rowptr);
   if (p.edges) (void)hipFree(p.edges);
   if (p.gitems) (void)hipFree(p.gitems);
@@ -98,6 +99,12 @@ int build_dir(DirPlan& p, const int32_t* rowptr, const int32_t* col, const float
         g.swap(banded);
         p.band_max = longest;
         if ((rc = upload(&p.bands, start, (size_t)kBands + 1))) return rc;
+        if (p.n_w > 0) {
+          std::vector<int32_t> wmap((size_t)((p.n_w + 3) / 4));
+          rc = mmssl_plan_band_wave_blocks_host(w.data(), p.n_w, band.data(), kBands, wmap.data());
+          if (rc) return rc;
+          if ((rc = upload(&p.wmap, wmap.data(), wmap.size()))) return rc;
+        }
       }
     }
   }
@@ -302,6 +309,50 @@ extern "C" int mmssl_plan_band_group_items_host(int32_t* group_items, int64_t n_
   return 0;
 }
 
+// Wave blocks (consecutive groups of 4 wave items): the light section (whole rows, code -1, behind the heavy section) is
+// reordered band-major in place, then every hardware block b gets a wave block of band b % n_bands while that band has
+// any (in list order: heaviest first), else one of the band with the most blocks left. wmap[b] = the wave block b runs.
+extern "C" int mmssl_plan_band_wave_blocks_host(int32_t* wave_items, int64_t n_w, const int32_t* band_of_row,
+                                                int32_t n_bands, int32_t* wmap) {
+  if (n_w < 0 || (n_w > 0 && (!wave_items || !band_of_row || !wmap)) || n_bands < 1 || n_bands > 64) return MMSSL_E_BADARG;
+  const int64_t nb = (n_w + 3) / 4;
+  int64_t light0 = n_w;                                   // first light item: a real row with code -1
+  for (int64_t k = 0; k < n_w; ++k)
+    if (wave_items[k * 4 + 3] == -1 && wave_items[k * 4] >= 0) { light0 = k; break; }
+  if (light0 % 4) return MMSSL_E_BADARG;                  // the heavy section is padded to whole blocks
+  {
+    std::vector<int32_t> tmp((size_t)(n_w - light0) * 4);
+    int64_t dst = 0;
+    for (int b = 0; b < n_bands; ++b)
+      for (int64_t k = light0; k < n_w; ++k)
+        if (band_of_row[wave_items[k * 4]] == b) {
+          std::memcpy(&tmp[(size_t)dst * 4], &wave_items[k * 4], 4 * sizeof(int32_t));
+          ++dst;
+        }
+    if (dst != n_w - light0) return MMSSL_E_BADARG;
+    if (!tmp.empty()) std::memcpy(&wave_items[light0 * 4], tmp.data(), tmp.size() * sizeof(int32_t));
+  }
+  std::vector<std::vector<int32_t>> q((size_t)n_bands);
+  for (int64_t vb = 0; vb < nb; ++vb) {
+    const int32_t row = wave_items[vb * 16];              // first item of the block: never padding
+    if (row < 0) return MMSSL_E_BADARG;
+    q[(size_t)band_of_row[row]].push_back((int32_t)vb);
+  }
+  std::vector<size_t> head((size_t)n_bands, 0);
+  for (int64_t b = 0; b < nb; ++b) {
+    int x = (int)(b % n_bands);
+    if (head[(size_t)x] >= q[(size_t)x].size()) {         // this band is done: help the fullest one
+      size_t best = 0;
+      for (int y = 0; y < n_bands; ++y) {
+        const size_t left = q[(size_t)y].size() - head[(size_t)y];
+        if (left > best) { best = left; x = y; }
+      }
+    }
+    wmap[b] = q[(size_t)x][head[(size_t)x]++];
+  }
+  return 0;
+}
+
 // ======================================================================================
 // graph object
 // ======================================================================================
@@ -498,7 +549,8 @@ __global__ __launch_bounds__(kBlock) void spmm_kernel(const int4* __restrict__ g
                                                       const int32_t* __restrict__ slot2multi,
                                                       int32_t* __restrict__ arrivals,
                                                       const int32_t* __restrict__ dyn,
-                                                      const int32_t* __restrict__ bands) {
+                                                      const int32_t* __restrict__ bands,
+                                                      const int32_t* __restrict__ wmap) {
   // device-built plans (csrc/graphdev.hip): the item counts live in device memory and the grid is an upper bound
   if (dyn) {
     n_g = dyn[0];
@@ -529,8 +581,9 @@ __global__ __launch_bounds__(kBlock) void spmm_kernel(const int4* __restrict__ g
     Y[(size_t)it.x * py + lig] = acc;
   } else {
     const int wave = (int)threadIdx.x >> 6;
-    const int wi = (int)blockIdx.x * 4 + wave;
-    const int code0 = witems[(int)blockIdx.x * 4].w;       // block-uniform: light (-1) or heavy block
+    const int vb = wmap ? wmap[blockIdx.x] : (int)blockIdx.x;    // XCD-banded plan: the wave block chosen for this block
+    const int wi = vb * 4 + wave;
+    const int code0 = witems[vb * 4].w;                    // block-uniform: light (-1) or heavy block
     if (code0 == -1) {                                      // four unrelated whole rows
       if (wi >= n_w) return;
       const int4 it = witems[wi];
@@ -557,7 +610,7 @@ __global__ __launch_bounds__(kBlock) void spmm_kernel(const int4* __restrict__ g
     if (lane < LPR) red[wave][lig] = acc;
     __syncthreads();
     if (wave != 0) return;
-    const int row = witems[(int)blockIdx.x * 4].x;          // the first slice of a block is never padding
+    const int row = witems[vb * 4].x;                       // the first slice of a block is never padding
     if (lane < LPR) {
       const float4 b1 = red[1][lig], b2 = red[2][lig], b3 = red[3][lig];
       acc.x = ((acc.x + b1.x) + b2.x) + b3.x;
@@ -649,7 +702,7 @@ int launch_spmm(const DirPlan& p, const float* X, float* Y, float* partials, con
                        p.gitems, (int)p.n_g, p.witems, (int)p.n_w, n_wblocks, p.edges,
                        reinterpret_cast<const float4*>(X), reinterpret_cast<float4*>(Y),
                        reinterpret_cast<float4*>(partials), epi, p.multi, p.slot2multi,
-                       arrivals, p.dyn, p.bands);
+                       arrivals, p.dyn, p.bands, p.wmap);
     MMSSL_LAUNCH_CHECK();
   }
   return 0;

@@ -24,6 +24,10 @@ struct DirPlan {
   // all of it. band_max = the longest band (sizes the grid). nullptr: the flat degree-sorted list.
   int32_t* bands = nullptr;
   int64_t band_max = 0;
+  // ... and wave blocks (4 wave items each: the slices of one heavy row, or four light rows): hardware block b processes
+  // wave block wmap[b], chosen at plan time from the blocks of band b % 8 (heaviest first; an exhausted band takes over
+  // blocks of the fullest one). nullptr: block b processes wave block b.
+  int32_t* wmap = nullptr;
   double band_score = 0.0;      // fraction of the edges that fall into their row's dominant band
 };
 

@@ -182,3 +182,42 @@ def test_xcd_band_host_helpers():
         assert (band[seg[:, 0]] == x).all()
         want = before[band[before[:, 0]] == x]
         assert np.array_equal(seg, want)                                             # stable: degree order kept
+
+
+def test_xcd_band_wave_block_map_is_a_permutation_that_follows_the_bands():
+    import ctypes
+    import scipy.sparse as sp
+    from mmssl_amd import _lib, synth
+    L = _lib.lib()
+    m = sp.csr_matrix(synth.interaction_matrix_communities(6000, 1600, 90000, n_comm=8, cross=0.1, seed=5).T)   # item rows: many long ones
+    m.sort_indices()
+    rows = m.shape[0]
+    rp = np.ascontiguousarray(m.indptr, dtype=np.int32)
+    col = np.ascontiguousarray(m.indices, dtype=np.int32)
+    band = np.empty(rows, np.int32)
+    assert L.mmssl_plan_band_host(rp.ctypes.data, col.ctypes.data, rows, m.shape[1], 8, band.ctypes.data, None) == 0
+    counts = (ctypes.c_int64 * 4)()
+    assert L.mmssl_plan_count_host(rp.ctypes.data, rows, counts) == 0
+    n_g, n_w, n_m = counts[0], counts[1], counts[2]
+    assert n_w > 200 and n_m > 0
+    gi, wi, mi = (np.zeros(max(4 * n, 4), np.int32) for n in (n_g, n_w, n_m))
+    assert L.mmssl_plan_fill_host(rp.ctypes.data, rows, gi.ctypes.data, wi.ctypes.data, mi.ctypes.data) == 0
+    before = wi.reshape(-1, 4)[:n_w].copy()
+    nb = (n_w + 3) // 4
+    wmap = np.full(nb, -1, np.int32)
+    assert L.mmssl_plan_band_wave_blocks_host(wi.ctypes.data, n_w, band.ctypes.data, 8, wmap.ctypes.data) == 0
+    after = wi.reshape(-1, 4)[:n_w]
+    assert sorted(wmap.tolist()) == list(range(nb))                                  # every wave block exactly once
+    light = (before[:, 3] == -1) & (before[:, 0] >= 0)
+    l0 = int(np.argmax(light))
+    assert np.array_equal(before[:l0], after[:l0])                                   # heavy section untouched
+    assert sorted(map(tuple, before[l0:])) == sorted(map(tuple, after[l0:]))         # light rows: same set, band-major
+    assert (np.diff(band[after[l0:, 0]]) >= 0).all()
+    # the block a hardware block gets belongs to its band while that band has blocks left
+    blk_band = band[after[::4, 0]]
+    left = np.bincount(blk_band, minlength=8)
+    for b in range(nb):
+        x = b % 8
+        if left[x] > 0:
+            assert blk_band[wmap[b]] == x
+        left[blk_band[wmap[b]]] -= 1

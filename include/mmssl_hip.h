@@ -292,6 +292,13 @@ int mmssl_fuse_fwd_f32(int sides, const float* const* const* layers, int n_layer
 int mmssl_fuse_fwd_rows_f32(int sides, const float* const* const* layers, int n_layers, float inv,
                             const float* const* Mod, int nm, float r, const int64_t* const* idx, const int64_t* n_idx,
                             int d, float eps, float* const* out, void* stream);
+/* The same on a ROW-SHARDED table (mmssl_amd/dist.py; no reference counterpart): idx[k] holds GLOBAL row ids, this rank owns
+ * rows [lo[k], lo[k] + n_local[k]) of side k as local rows 0 .. n_local[k] - 1 and computes only the listed rows it owns
+ * (the batch rows of the other ranks are theirs to compute; mmssl_gather_owned_rows_f32 zero-fills them). */
+int mmssl_fuse_fwd_owned_rows_f32(int sides, const float* const* const* layers, int n_layers, float inv,
+                                  const float* const* Mod, int nm, float r, const int64_t* const* idx,
+                                  const int64_t* n_idx, const int64_t* lo, const int64_t* n_local, int d, float eps,
+                                  float* const* out, void* stream);
 int mmssl_loss_add_partials_f32(const float* part, int64_t n, float c, float* total, float* sum_out, void* stream);
 int mmssl_fuse_bwd_f32(int sides, const float* const* Mod, int nm, const float* const* G, const float* const* Gx,
                        float r, float inv, const float* c_dev, float c_scale, const int64_t* rows, int d, float eps,

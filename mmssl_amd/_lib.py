@@ -90,6 +90,8 @@ SIGNATURES = {
     "mmssl_sum_partials_f32": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
     "mmssl_fuse_fwd_rows_f32": (c_int, [c_int, c_void_p, c_int, c_float, c_void_p, c_int, c_float, c_void_p, c_void_p, c_int,
                                         c_float, c_void_p, c_void_p]),
+    "mmssl_fuse_fwd_owned_rows_f32": (c_int, [c_int, c_void_p, c_int, c_float, c_void_p, c_int, c_float, c_void_p, c_void_p,
+                                              c_void_p, c_void_p, c_int, c_float, c_void_p, c_void_p]),
     "mmssl_loss_add_partials_f32": (c_int, [c_void_p, c_int64, c_float, c_void_p, c_void_p, c_void_p]),
     "mmssl_sumsq_workspace_bytes": (c_size_t, [c_int64]),
     "mmssl_sumsq_f32": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_size_t, c_void_p]),

@@ -179,6 +179,8 @@ struct FuseSide {
   float4* gL;           // backward only, may be NULL
   float* part;          // may be NULL: per-block sums of |Mod|^2 (both directions see every row of Mod)
   const int64_t* idx;   // forward only, may be NULL: the rows to compute (then `rows` = their number)
+  int64_t lo, n_local;  // with idx: entries are GLOBAL row ids of a row-sharded table; this rank holds rows [lo, lo + n_local)
+  //                       as local rows 0.. and skips the others (lo = 0, n_local = max: plain row lists)
   int64_t rows;
   int n_layers;
   int blocks;
@@ -197,7 +199,8 @@ __global__ __launch_bounds__(kBlock) void fuse_fwd_kernel(FuseSide S0, FuseSide 
   const int64_t stride = (int64_t)S.blocks * GPB;
   float ss = 0.f;
   for (int64_t it = (int64_t)blk * GPB + threadIdx.x / GL; it < S.rows; it += stride) {
-    const int64_t row = S.idx ? S.idx[it] : it;
+    const int64_t row = S.idx ? S.idx[it] - S.lo : it;
+    if (S.idx && (row < 0 || row >= S.n_local)) continue;      // a row another rank owns (uniform over the row's lanes)
     const int64_t o = row * LPR + lig;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int k = m; k < S.n_layers; k += NM) {
@@ -487,8 +490,17 @@ extern "C" int mmssl_fuse_blocks(int64_t rows, int d, int nm) {
 extern "C" int mmssl_fuse_fwd_rows_f32(int sides, const float* const* const* layers, int n_layers, float inv,
                                        const float* const* Mod, int nm, float r, const int64_t* const* idx,
                                        const int64_t* n_idx, int d, float eps, float* const* out, void* stream) {
+  return mmssl_fuse_fwd_owned_rows_f32(sides, layers, n_layers, inv, Mod, nm, r, idx, n_idx, nullptr, nullptr, d, eps, out,
+                                       stream);
+}
+
+extern "C" int mmssl_fuse_fwd_owned_rows_f32(int sides, const float* const* const* layers, int n_layers, float inv,
+                                             const float* const* Mod, int nm, float r, const int64_t* const* idx,
+                                             const int64_t* n_idx, const int64_t* lo, const int64_t* n_local, int d,
+                                             float eps, float* const* out, void* stream) {
   if (sides < 1 || sides > 2 || n_layers < 1 || n_layers > kMaxLayers || !layers || !Mod || !idx || !n_idx || !out)
     return MMSSL_E_BADARG;
+  if ((lo == nullptr) != (n_local == nullptr)) return MMSSL_E_BADARG;
   if (!fuse_shape_ok(d, nm)) return MMSSL_E_UNSUPP;
   FuseSide S[2] = {};
   int total = 0;
@@ -503,6 +515,9 @@ extern "C" int mmssl_fuse_fwd_rows_f32(int sides, const float* const* const* lay
     S[k].out = reinterpret_cast<float4*>(out[k]);
     S[k].part = nullptr;
     S[k].idx = idx[k];
+    S[k].lo = lo ? lo[k] : 0;
+    S[k].n_local = n_local ? n_local[k] : INT64_MAX;
+    if (S[k].n_local < 0) return MMSSL_E_BADARG;
     S[k].rows = n_idx[k];
     S[k].n_layers = n_layers;
     S[k].blocks = fuse_grid(n_idx[k], (d / 4) * nm);

@@ -58,6 +58,11 @@ class HipBackend:
         self.tables_stream = None       # the stream on which that backward completes the gradient of i_0
         self.table_grads = None
         self.defer_ss, self.ss_parts = False, None      # hand-off of the regulariser partials to a step's loss tail
+        # batch-rows form (set by a step object for one forward + backward): (global user rows [B], global item rows [2B],
+        # lo_u, lo_i) - the ONLY rows of the fused tables the step's loss reads. The forward fuses the owned ones of those
+        # rows only; the regulariser's |Mod|^2 sums then come out of the backward's fuse kernel (reg_parts = the partials,
+        # reg_ss = the 0-dim tensor that receives their sum when the step adds c * sum to its loss)
+        self.batch_rows, self.reg_parts, self.reg_ss = None, None, None
 
     def gather_owned(self, table, idx, lo, out):
         from . import _lib
@@ -162,6 +167,12 @@ class HipBackend:
         from . import _lib
         ops = self.ops
         d = us[0].shape[1]
+        if self.batch_rows is not None:
+            ru, ri, lo_u, lo_i = self.batch_rows
+            u_g, i_g = ops.fuse_fwd_rows([(us, MU, ru), (its, MI, ri)], inv, nm, r, lo=(lo_u, lo_i))
+            ss = torch.empty((), dtype=torch.float32, device=MU.device)
+            self.reg_ss, self.reg_parts = ss, None          # the backward's fuse kernel owes the |Mod|^2 partials
+            return u_g, i_g, ss
         nbu, nbi = ops.fuse_blocks(us[0].shape[0], d, nm), ops.fuse_blocks(its[0].shape[0], d, nm)
         part = torch.empty(nbu + nbi, dtype=torch.float32, device=MU.device)
         u_g, i_g = ops.fuse_fwd([(us, MU, part[:nbu]), (its, MI, part[nbu:])], inv, nm, r)
@@ -175,7 +186,15 @@ class HipBackend:
 
     def fuse_bwd(self, MU, Gu, G_MU, MI, Gi, G_MI, nm, r, inv, g_ss):
         """(gMU, g_u0, gMI): normalise backward + regulariser gradient of both sides in one launch."""
-        (gMU, g_u0), (gMI, _) = self.ops.fuse_bwd([(MU, Gu, G_MU, True), (MI, Gi, G_MI, False)], nm, r, inv, g_ss, 2.0)
+        part = None
+        if self.reg_ss is not None and self.reg_parts is None:      # a batch-rows forward: leave the regulariser's partials
+            ops = self.ops
+            d = Gu.shape[1]
+            nbu, nbi = ops.fuse_blocks(MU.shape[0], d, nm), ops.fuse_blocks(MI.shape[0], d, nm)
+            part = torch.empty(nbu + nbi, dtype=torch.float32, device=MU.device)
+            self.reg_parts = part
+        (gMU, g_u0), (gMI, _) = self.ops.fuse_bwd([(MU, Gu, G_MU, True), (MI, Gi, G_MI, False)], nm, r, inv, g_ss, 2.0,
+                                                  sumsq_part=None if part is None else [part[:nbu], part[nbu:]])
         return gMU, g_u0, gMI
 
     def spmm_mask(self, plan, X, keep, dm, scale):
@@ -359,6 +378,9 @@ class GatherBatchRowsMulti(torch.autograd.Function):
             live = [g for g in gs if g is not None]
             if not live:
                 return (None, None, None) + (None,) * (3 * len(ctx.meta))
+            # (zero-filled HERE, right in front of the scatter-adds: filled ahead of time - during the forward, on an idle
+            # stream - the lines have left the L2s by now and the fp32 atomics run against memory: 27 - 51 us per launch
+            # instead of 4 - 5, measured)
             buf = torch.zeros((rows, live[0].shape[1]), dtype=live[0].dtype, device=live[0].device)
             for k, (g, m) in enumerate(zip(gs, ctx.meta)):
                 if g is None:
@@ -1196,8 +1218,12 @@ class ShardedHotPathStep:
     gradients -> AdamW, over row shards (the N-rank counterpart of hotpath.HotPathStep)."""
 
     def __init__(self, model, graphs, batch_size, n_items, group=None, lr=5.5e-4, modal_empty=False,
-                 optimizer=True, fused=True):
+                 optimizer=True, fused=True, batch_rows=True):
+        """batch_rows (product backend, empty modal graphs): the fused tables are computed at the batch's rows only in
+        front of the loss section - all it reads - like hotpath.HotPathStep(batch_rows=True); the regulariser's sums come
+        out of the backward's fuse kernel. False: the dense two-sided fuse launch."""
         self.fused = fused
+        self.batch_rows = bool(batch_rows)
         self.model, self.graphs, self.group = model, tuple(graphs), group
         self.batch_size, self.n_items, self.modal_empty = int(batch_size), int(n_items), modal_empty
         dev = model.E_u.device
@@ -1238,13 +1264,19 @@ class ShardedHotPathStep:
         local_total = replicated loss terms + THIS rank's share of the regulariser."""
         m, bk, c, g = self.model, self.model.bk, self.model.cfg, self.group
         eager = self.fused and hasattr(bk, "ops")
+        rows_mode = bool(eager and self.batch_rows and self.modal_empty)
         if eager:
             bk.defer_ss, bk.ss_parts = True, None
+            bk.reg_parts, bk.reg_ss = None, None
+            # batch-rows form: the loss reads the fused tables at the batch's rows only (global ids; the kernel keeps the
+            # owned ones), see HipBackend.batch_rows
+            bk.batch_rows = (self.users, self.batch[1:3].reshape(-1), m.ush.lo, m.ish.lo) if rows_mode else None
         try:
             o = m(self.graphs, keep_masks=keep_masks, modal_empty=self.modal_empty, fused=self.fused)
         finally:
             if eager:
-                bk.defer_ss = False
+                bk.defer_ss, bk.batch_rows = False, None
+        rows_mode = rows_mode and m.last_fused and bk.reg_ss is not None
         fused = self.fused and m.last_fused
         items = self.batch[1:3].reshape(-1)           # positive then negative items: one [2B] index list, one piece
         if self.modal_empty:       # the id views are exact zeros: nothing to gather for them
@@ -1271,8 +1303,10 @@ class ShardedHotPathStep:
                 holder = types.SimpleNamespace(ss_parts=bk.ss_parts, prefill_buf=None)      # the node's unreduced |.|^2
                 bk.ss_parts = None
                 terms = bk.batch_losses_rows(u, ia, z_img, z_txt, c.decay, self.batch_size, c.tau, eager_w=self._loss_w,
-                                             tail=(ss.detach(), feat_c, self.loss, getattr(self, "_ticks", None)),
-                                             hot=holder)
+                                             tail=(None if rows_mode else ss.detach(), feat_c, self.loss,
+                                                   getattr(self, "_ticks", None)), hot=holder)
+                if rows_mode:       # the regulariser joins the loss after the backward (its sums come out of the fuse backward)
+                    return [terms, ss], [self._loss_w, self._feat_c], self.loss, None
                 return [terms, ss], [self._loss_w, self._feat_c], self.loss, (feat_c * ss).detach()
             terms = bk.batch_losses_rows(u, ia, z_img, z_txt, c.decay, self.batch_size, c.tau)
             total_local = bk.loss_assemble(terms, self._loss_w, ss, feat_c)
@@ -1291,6 +1325,13 @@ class ShardedHotPathStep:
         for p in self.model.parameters():
             p.grad = None
         torch.autograd.backward(roots, grads)
+        if feat_local is None:
+            # batch-rows form: loss += c * sum |Mod|^2 (this rank's rows) from the backward fuse kernel's partials
+            bk_, c_ = self.model.bk, self.model.cfg
+            feat_c = c_.feat_reg_decay * 0.5 / self.n_items
+            bk_.ops.loss_add_partials(bk_.reg_parts, feat_c, self.loss, bk_.reg_ss)
+            feat_local = None if _solo(self.group) else feat_c * bk_.reg_ss
+            bk_.reg_parts, bk_.reg_ss = None, None
         side = getattr(self.model.bk, "tables_stream", None) if getattr(self, "_tables_early", False) else None
         if side is not None and self.optimizer is not None and self.model.bk.after_fuse_bwd is not None:
             m = self.model

@@ -1059,9 +1059,11 @@ def fuse_fwd(sides, inv, nm, r):
     return outs
 
 
-def fuse_fwd_rows(sides, inv, nm, r):
+def fuse_fwd_rows(sides, inv, nm, r, lo=None):
     """fuse_fwd for a LIST of rows per side: sides = [(layers, Mod [rows, nm * d], idx int64 [n]), ...]. Returns full-size
-    output tables of which ONLY the listed rows are defined (bit for bit fuse_fwd's values there)."""
+    output tables of which ONLY the listed rows are defined (bit for bit fuse_fwd's values there). `lo` (one int per
+    side): the lists hold GLOBAL row ids of row-sharded tables whose local rows start at lo[k]; rows of other ranks are
+    skipped (mmssl_fuse_fwd_owned_rows_f32)."""
     n = len(sides)
     outs = [torch.empty_like(sd[0][0]) for sd in sides]
     d = outs[0].shape[1]
@@ -1074,6 +1076,13 @@ def fuse_fwd_rows(sides, inv, nm, r):
     for sd in sides:
         if sd[2].dtype != torch.int64 or not sd[2].is_contiguous():
             raise _lib.MmsslError("fuse_fwd_rows: contiguous int64 row lists expected")
+    if lo is not None:
+        los = (_ct.c_int64 * n)(*[int(x) for x in lo])
+        nloc = (_ct.c_int64 * n)(*[sd[0][0].shape[0] for sd in sides])
+        rc = _lib.lib().mmssl_fuse_fwd_owned_rows_f32(n, lay_arr, len(sides[0][0]), float(inv), mods, int(nm), float(r), idxs,
+                                                      nidx, los, nloc, d, _NORM_EPS, oarr, _lib.stream_ptr())
+        _lib.check(rc, "mmssl_fuse_fwd_owned_rows_f32")
+        return outs
     rc = _lib.lib().mmssl_fuse_fwd_rows_f32(n, lay_arr, len(sides[0][0]), float(inv), mods, int(nm), float(r), idxs, nidx, d,
                                             _NORM_EPS, oarr, _lib.stream_ptr())
     _lib.check(rc, "mmssl_fuse_fwd_rows_f32")

@@ -70,9 +70,12 @@ def build_single_gpu(a, dev):
     U, I, E, dv, dt = synth.SHAPES[a.workload]
     config.configure([], embed_size=a.d, weight_size=str([a.d] * a.gcn_layers), batch_size=a.batch,
                      drop_rate=0.2, layers=1)
-    raw = synth.interaction_matrix(U, I, E, seed=1)
+    if a.graph == "communities":     # the same shape with column locality (8 communities, 10 % global edges): XCD-banded plans
+        raw = synth.interaction_matrix_communities(U, I, E, seed=1)
+    else:
+        raw = synth.interaction_matrix(U, I, E, seed=1)
     ui, iu = synth.normalised_pair(raw)
-    plans = [GraphPlan(ui), GraphPlan(iu)]
+    plans = [GraphPlan(ui, xcd_bands=a.xcd_bands), GraphPlan(iu, xcd_bands=a.xcd_bands)]
     # steady state of the reference loop: modal graphs are empty from the third batch on
     e_ui = GraphPlan(sp.csr_matrix((U, I), dtype=np.float32))
     e_iu = GraphPlan(sp.csr_matrix((I, U), dtype=np.float32))
@@ -97,6 +100,7 @@ def count_edge_layers(step, d):
 
 
 def spmm_roofline(plans, mats, d, iters=200, traffic=True):
+    # (the committed PMC pass behind `traffic` was taken on the uniform graph with the flat work list)
     """Average duration of the dominant kernel (the CSR SpMM, all four launch flavours of the
     step: A_ui, A_iu and their transposes) from HIP events on the launch stream, against the
     algorithmic bytes per launch (nnz*(8+4d) + rows*4d + (rows+1)*4)."""
@@ -306,12 +310,13 @@ def first_step_loss(a, step, raw, batch):
 
 def load_traffic():
     """HBM bytes per SpMM launch from the committed rocprofv3 PMC pass (profiles/*_pmc.json), if any."""
-    p = os.path.join(ROOT, "profiles", "r03_spmm_pmc.json")
-    if os.path.exists(p):
-        try:
-            return json.load(open(p)).get("hbm_bytes_per_launch")
-        except Exception:
-            return None
+    for name in ("r04_spmm_pmc.json", "r03_spmm_pmc.json"):
+        p = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(p):
+            try:
+                return json.load(open(p)).get("hbm_bytes_per_launch")
+            except Exception:
+                continue
     return None
 
 
@@ -490,6 +495,12 @@ def main():
                     help="launcher dry run (no GPU needed): rendezvous of --gpus ranks on --backend, one all-reduce, one "
                          "JSON line from rank 0")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl", help="process-group backend (gloo: --launch-check only)")
+    ap.add_argument("--graph", choices=["uniform", "communities"], default="uniform",
+                    help="N=1: uniform = the SURVEY 8d generator (no column locality; the metric's workload); communities = "
+                         "the same shape as 8 user / item communities with 10 %% global edges (what the XCD-banded SpMM work "
+                         "list is for)")
+    ap.add_argument("--xcd-bands", type=int, default=0, dest="xcd_bands", choices=[-1, 0, 1],
+                    help="GraphPlan XCD banding: 0 = automatic (on when the graph has column locality), 1 = always, -1 = never")
     ap.add_argument("--no-hbm", action="store_true", dest="no_hbm", help="skip the HBM-resident SpMM record (`spmm_hbm`)")
     ap.add_argument("--no-stress", action="store_true", dest="no_stress",
                     help="N>1: skip the `scaling_stress` record (configs[4]'s per-rank share x N after the timed region)")
@@ -572,6 +583,9 @@ def main():
     ms = elapsed * 1e3 / a.steps
     out = result_line(a, 1, "weak", ms, edge_layers_total, stats, captured, float(step.loss), "single",
                       int(raw.shape[0]), int(raw.shape[1]), int(raw.nnz))
+    info = plans[0].info()
+    out["config"]["graph"] = "%s; XCD-banded work list: %s (locality score %.2f / %.2f)" % (
+        a.graph, "on" if info["banded"] else "off", info["band_score"], plans[1].info()["band_score"])
     if a.only != "steps":
         rf = extra["roofline"]
         # the same byte model over the WHOLE step: every SpMM launch's algorithmic bytes / step time. The

@@ -484,13 +484,15 @@ class ShardedMMSSL(nn.Module):
     def n_chunks(self, nm):
         """Column chunks per collective of the item-side node. Explicit (`chunks` > 0) or by size: collectives below
         CHUNK_BYTES (the whole gathered item table at width d) are latency-bound and stay whole - every chunk is one more
-        RCCL launch - larger ones are cut in two (chunk 0's product runs under chunk 1's transfer; 2 x 64-wide at
-        configs[4]'s d = 128 keeps the SpMM on its 256-byte-row flavour)."""
+        RCCL launch - larger ones are cut in two, from 4 x CHUNK_BYTES on (configs[4]: a 512 MB table per collective) in four:
+        only the first chunk's transfer and the last chunk's product stay exposed per collective (tools/shard_bytes.py:
+        4 chunks are what brings configs[4]'s link-bound step from 3.8x to 5.9x one GPU at 70 GB/s per link)."""
         d = self.cfg.embed_size
         ok = getattr(self.bk, "chunk_ok", lambda w, n: w % n == 0)
         nc = int(getattr(self, "chunks", 0))
         if nc <= 0:
-            nc = 2 if self.ish.n_pad * d * 4 >= self.CHUNK_BYTES else 1
+            full = self.ish.n_pad * d * 4
+            nc = 4 if full >= 4 * self.CHUNK_BYTES else (2 if full >= self.CHUNK_BYTES else 1)
         while nc > 1 and not (ok(d, nc) and ok(nm * d, nc)):
             nc -= 1
         return max(nc, 1)

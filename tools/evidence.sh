@@ -44,7 +44,9 @@ if has dist; then
   S="python bench.py --gpus 1 --workload synth --steps 10 --warmup 2 --no-cpu-baseline"
   timeout 600 $S > $O/bench_synth_w1.json 2>> $O/bench.err; line $O/bench_synth_w1.json
   MMSSL_DIST_FORCE_COLLECTIVES=1 timeout 600 $S --scheme item-side --chunks 2 > $O/bench_synth_w1_rccl_itemside_c2.json 2>> $O/bench.err; line $O/bench_synth_w1_rccl_itemside_c2.json
+  MMSSL_DIST_FORCE_COLLECTIVES=1 timeout 600 $S --scheme item-side --chunks 4 > $O/bench_synth_w1_rccl_itemside_c4.json 2>> $O/bench.err; line $O/bench_synth_w1_rccl_itemside_c4.json
   MMSSL_DIST_FORCE_COLLECTIVES=1 timeout 600 $S --scheme gather-both > $O/bench_synth_w1_rccl_gatherboth.json 2>> $O/bench.err; line $O/bench_synth_w1_rccl_gatherboth.json
+  timeout 600 python bench.py --gpus 1 --steps 500 --warmup 100 --no-cpu-baseline --no-hbm --graph communities > $O/bench_communities.json 2>> $O/bench.err; line $O/bench_communities.json
 fi
 if has prof; then
   cd /tmp

@@ -2,13 +2,16 @@
 behind DESIGN.md section 6 (runs anywhere: python tools/shard_bytes.py). Three schemes for the 2L GCN products and the
 packed modal chain of one step (forward gathers + backward reduce-scatters move the same bytes):
 
-  gather-both      (built: mmssl_amd/dist.py) all-gather the item table before A_ui . X_i AND the user table before
-                   A_iu . X_u; the adjoints are reduce-scatters of the same sizes
-  item-collectives every rank keeps only its user-row block of the graph; A_iu . X_u becomes local partial products over
-                   ALL items + a reduce-scatter of item-table size (its adjoint a gather of item-table size): every
-                   collective moves item-table bytes
-  2-D (R x C)      ranks in an R x C grid, A cut in both directions: a gather inside a column group and a reduce-scatter
-                   inside a row group per product
+  gather-both      (built, round 3: mmssl_amd/dist.py _ShardedHotForward, bench.py --scheme gather-both) all-gather the item
+                   table before A_ui . X_i AND the user table before A_iu . X_u; the adjoints are reduce-scatters of the
+                   same sizes
+  item-collectives (built, round 4, the default: _ShardedItemSide, --scheme item-side) every rank keeps only its user-row
+                   block of the graph; A_iu . X_u becomes local partial products over ALL items + a reduce-scatter of
+                   item-table size (its adjoint a gather of item-table size): every collective moves item-table bytes; with
+                   --chunks c every collective and the products around it are cut into c column chunks on c lanes, so
+                   that a chunk's product runs under the next chunk's transfer
+  2-D (R x C)      (not built) ranks in an R x C grid, A cut in both directions: a gather inside a column group and a
+                   reduce-scatter inside a row group per product
 
 Per-link time assumes one xGMI link per peer (full mesh, 8 GPUs) at `--link-gbs` per direction and that a rank's traffic
 spreads evenly over its N - 1 peers."""
@@ -54,3 +57,12 @@ for name, s in SHAPES.items():
             line.append("%s %.0f MB/rank = %.0f MB/link = %.2f ms" % (nm, b / 1e6, per_link / 1e6, ms))
         comp = s["ms"] if s["weak"] else s["ms"] * 8 / N
         print("  N=%d  compute %.2f ms |  %s" % (N, comp, "  |  ".join(line)))
+        # what the built item-side scheme can reach: no overlap (links idle while the SpMMs run) .. perfect overlap with c
+        # column chunks (only the first chunk's transfer and the last chunk's product are exposed per collective)
+        link = schemes["item-collectives"] / (N - 1) / (a.link_gbs * 1e9) * 1e3
+        one = s["ms"] if s["weak"] else s["ms"] * 8
+        for c in (1, 2, 4):
+            t = max(comp, link) + (min(comp, link) / c if c > 1 else min(comp, link))
+            print("         item-side, %d chunk(s): %.2f ms per step -> %.1fx one GPU%s" % (
+                c, t, (one / t) if not s["weak"] else N * one / t / 1.0,
+                "" if c > 1 else "  (no overlap)"))

@@ -1431,6 +1431,15 @@ class ShardedHotPathStep:
                 for _ in range(warmup):
                     self._step()
             torch.cuda.synchronize()
+            if dist.is_initialized() and dist.get_backend(self.group) == "nccl":
+                # The process group's watchdog thread polls the completion events of the collectives issued so far (every
+                # ~100 ms) until it has seen them complete. A poll that lands inside the capture fails on ROCm 7.2 with
+                # hipErrorCapturedEvent ("event last recorded in a capturing stream") for a work issued on this stream
+                # just before - and the exception in that thread terminates the process (seen on the 12.5 M-edge shape,
+                # where a capture takes long enough to meet a poll). Everything is complete here: give the watchdog two of
+                # its cycles to retire its list before the capture begins.
+                import time
+                time.sleep(0.3)
             g = torch.cuda.CUDAGraph()
             # thread_local: the process group's watchdog thread keeps querying the events of earlier collectives
             # while this thread captures; in the default (global) mode that query is an illegal call during capture

@@ -27,7 +27,7 @@ except Exception as e:
 PY
 }
 if has tests; then
-  timeout 2400 python -m pytest tests -m gpu -q -x 2>&1 | tail -15 | tee $O/gpu_tests.log
+  MMSSL_TEST_KEEP=$R/$O/nccl timeout 2400 python -m pytest tests -m gpu -q -x 2>&1 | tail -15 | tee $O/gpu_tests.log
   python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2 | tee -a $O/gpu_tests.log
 fi
 if has bench; then

@@ -67,6 +67,13 @@ int mmssl_graph_create(const int32_t* rowptr, const int32_t* col, const float* v
 int mmssl_graph_create_ex(const int32_t* rowptr, const int32_t* col, const float* val,
                           int32_t rows, int32_t cols, int64_t nnz, int xcd_bands, void* stream,
                           mmssl_graph** out);
+/* ... and with the band of every row (row_band[rows]: which XCD's blocks process the row in Y = A.X) and of every column
+ * (col_band[cols]: the same for the transposed product) GIVEN, entries in [0, 8): for graphs whose communities are not
+ * contiguous in the numbering - the caller clusters rows and columns together (mmssl_amd/graph.py co-clusters them at plan
+ * time) so that a row mostly references columns of its own band. Both NULL = mmssl_graph_create_ex. */
+int mmssl_graph_create_banded(const int32_t* rowptr, const int32_t* col, const float* val,
+                              int32_t rows, int32_t cols, int64_t nnz, int xcd_bands, const int32_t* row_band,
+                              const int32_t* col_band, void* stream, mmssl_graph** out);
 int mmssl_graph_destroy(mmssl_graph* g);
 /* info[0..7] = rows, cols, nnz, group_items, wave_items, multi_rows, partial_slots,
  *              same four for the transpose in info[8..11]; info[12..14] = work-list shaping constants;

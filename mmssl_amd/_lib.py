@@ -40,6 +40,8 @@ SIGNATURES = {
                                          c_void_p, c_void_p, c_void_p]),
     "mmssl_graph_create_ex": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int64, c_int, c_void_p,
                                       POINTER(c_void_p)]),
+    "mmssl_graph_create_banded": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int64, c_int, c_void_p, c_void_p,
+                                          c_void_p, POINTER(c_void_p)]),
     "mmssl_plan_band_host": (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
     "mmssl_plan_band_group_items_host": (c_int, [c_void_p, c_int64, c_void_p, c_int32, c_void_p]),
     "mmssl_plan_band_wave_blocks_host": (c_int, [c_void_p, c_int64, c_void_p, c_int32, c_void_p]),

@@ -71,7 +71,7 @@ constexpr double kBandAuto = 0.50;
 constexpr double kBandImbalance = 1.5;  // longest band / mean band: beyond this the idle blocks cost more than the locality buys
 
 int build_dir(DirPlan& p, const int32_t* rowptr, const int32_t* col, const float* val, int32_t rows,
-              int32_t cols, int64_t nnz, int xcd_bands) {
+              int32_t cols, int64_t nnz, int xcd_bands, const int32_t* band_given = nullptr) {
   p.rows = rows;
   p.cols = cols;
   p.nnz = nnz;
@@ -82,11 +82,19 @@ int build_dir(DirPlan& p, const int32_t* rowptr, const int32_t* col, const float
   std::vector<int32_t> g((size_t)p.n_g * 4), w((size_t)p.n_w * 4), m((size_t)p.n_multi * 4);
   rc = mmssl_plan_fill_host(rowptr, rows, g.data(), w.data(), m.data());
   if (rc) return rc;
-  if (xcd_bands >= 0 && p.n_g > 0 && nnz > 0) {
+  if ((xcd_bands >= 0 || band_given) && p.n_g > 0 && nnz > 0) {
     std::vector<int32_t> band((size_t)rows);
     double score = 0.0;
-    rc = mmssl_plan_band_host(rowptr, col, rows, cols, kBands, band.data(), &score);
-    if (rc) return rc;
+    if (band_given) {              // the caller clustered the graph (GraphPlan: co-clustering of rows and columns)
+      for (int32_t r = 0; r < rows; ++r) {
+        if (band_given[r] < 0 || band_given[r] >= kBands) return MMSSL_E_BADARG;
+        band[(size_t)r] = band_given[r];
+      }
+      xcd_bands = 1;
+    } else {
+      rc = mmssl_plan_band_host(rowptr, col, rows, cols, kBands, band.data(), &score);
+      if (rc) return rc;
+    }
     p.band_score = score;
     if (xcd_bands > 0 || score >= kBandAuto) {
       std::vector<int32_t> banded(g);
@@ -365,7 +373,14 @@ extern "C" int mmssl_graph_create(const int32_t* rowptr, const int32_t* col, con
 extern "C" int mmssl_graph_create_ex(const int32_t* rowptr, const int32_t* col, const float* val,
                                      int32_t rows, int32_t cols, int64_t nnz, int xcd_bands, void* stream,
                                      mmssl_graph** out) {
-  (void)stream;  // set-up is synchronous (hipMemcpy); the handle is usable on any stream afterwards
+  return mmssl_graph_create_banded(rowptr, col, val, rows, cols, nnz, xcd_bands, nullptr, nullptr, stream, out);
+}
+
+extern "C" int mmssl_graph_create_banded(const int32_t* rowptr, const int32_t* col, const float* val,
+                                         int32_t rows, int32_t cols, int64_t nnz, int xcd_bands, const int32_t* row_band,
+                                         const int32_t* col_band, void* stream, mmssl_graph** out) {
+  (void)stream;
+  if ((row_band == nullptr) != (col_band == nullptr)) return MMSSL_E_BADARG;  // set-up is synchronous (hipMemcpy); the handle is usable on any stream afterwards
   if (!out) return MMSSL_E_BADARG;
   *out = nullptr;
   int rc = mmssl_csr_validate_host(rowptr, col, rows, cols, nnz);
@@ -378,8 +393,8 @@ extern "C" int mmssl_graph_create_ex(const int32_t* rowptr, const int32_t* col, 
   if (rc) return rc;
   mmssl_graph* g = new (std::nothrow) mmssl_graph();
   if (!g) return (int)hipErrorOutOfMemory;
-  rc = build_dir(g->fwd, rowptr, col, val, rows, cols, nnz, xcd_bands);
-  if (!rc) rc = build_dir(g->bwd, t_rowptr.data(), t_col.data(), t_val.data(), cols, rows, nnz, xcd_bands);
+  rc = build_dir(g->fwd, rowptr, col, val, rows, cols, nnz, xcd_bands, row_band);
+  if (!rc) rc = build_dir(g->bwd, t_rowptr.data(), t_col.data(), t_val.data(), cols, rows, nnz, xcd_bands, col_band);
   if (rc) {
     free_dir(g->fwd);
     free_dir(g->bwd);

@@ -114,6 +114,15 @@ def test_xcd_banded_plan_is_bitwise_the_flat_plan(d):
             Y = torch.full((3000, d), float("nan"), device=DEV)
             ops._spmm_raw(plan, False, X[:, :d], ops.EPI_NONE, out=Y)
             assert not torch.isnan(Y).any()                  # every row written exactly once, idle band blocks included
+    # communities hidden by a random renumbering of rows and columns: found by the plan-time co-clustering
+    rng = np.random.default_rng(0)
+    raw = synth.interaction_matrix_communities(3000, 1900, 24000, seed=2)
+    ui = synth.normalised_rows(sp.csr_matrix(raw[rng.permutation(3000)][:, rng.permutation(1900)]))
+    flat, auto = graph.GraphPlan(ui, xcd_bands=-1), graph.GraphPlan(ui)
+    assert auto.info()["banded"] and auto.info()["t_banded"] and auto.info()["cluster_score"] > 0.6, auto.info()
+    X, G = torch.randn(1900, d, generator=g).to(DEV), torch.randn(3000, d, generator=g).to(DEV)
+    assert torch.equal(ops._spmm_raw(auto, False, X, ops.EPI_SOFTMAX), ops._spmm_raw(flat, False, X, ops.EPI_SOFTMAX))
+    assert torch.equal(ops._spmm_raw(auto, True, G, ops.EPI_NONE), ops._spmm_raw(flat, True, G, ops.EPI_NONE))
     # empty and tiny graphs: nothing to band, nothing breaks
     e = graph.GraphPlan(sp.csr_matrix((50, 40), dtype=np.float32), xcd_bands=1)
     assert float(ops._spmm_raw(e, False, torch.randn(40, d).to(DEV), ops.EPI_NONE).abs().max()) == 0.0

@@ -17,15 +17,21 @@ from mmssl_amd import graph, ops, synth  # noqa: E402
 U, I, E, _, _ = synth.SHAPES["baby"]
 mode = os.environ.get("MODE", "time")
 out = {}
+import numpy as np  # noqa: E402
+import scipy.sparse as sp  # noqa: E402
+_com = synth.interaction_matrix_communities(U, I, E, seed=1)
+_rng = np.random.default_rng(5)
+_perm = sp.csr_matrix(_com[_rng.permutation(U)][:, _rng.permutation(I)])      # the same graph, randomly renumbered
 for kind, raw in (("uniform", synth.interaction_matrix(U, I, E, seed=1)),
-                  ("communities", synth.interaction_matrix_communities(U, I, E, seed=1))):
+                  ("communities", _com), ("communities_renumbered", _perm)):
     ui, iu = synth.normalised_pair(raw)
     for d in ((64,) if mode == "pmc" else (64, 128)):
         Xi, Xu = torch.randn(I, d, device="cuda"), torch.randn(U, d, device="cuda")
-        for name, bands in (("flat", -1), ("banded", 1)):
+        for name, bands in (("flat", -1), ("banded", 2 if kind == "communities_renumbered" else 1)):
             P = (graph.GraphPlan(ui, xcd_bands=bands), graph.GraphPlan(iu, xcd_bands=bands))
             launches = [(P[0], False, Xi, ui), (P[1], False, Xu, iu), (P[0], True, Xu, ui.T.tocsr()), (P[1], True, Xi, iu.T.tocsr())]
-            rec = {"score": [P[0].info()["band_score"], P[1].info()["band_score"]]}
+            rec = {"score": [P[0].info()["band_score"] or P[0].info()["cluster_score"],
+                             P[1].info()["band_score"] or P[1].info()["cluster_score"]]}
             with torch.no_grad():
                 if mode == "pmc":
                     for (p, t, X, m) in launches:

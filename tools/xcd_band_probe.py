@@ -27,7 +27,10 @@ for kind, raw in (("uniform", synth.interaction_matrix(U, I, E, seed=1)),
     ui, iu = synth.normalised_pair(raw)
     for d in ((64,) if mode == "pmc" else (64, 128)):
         Xi, Xu = torch.randn(I, d, device="cuda"), torch.randn(U, d, device="cuda")
-        for name, bands in (("flat", -1), ("banded", 2 if kind == "communities_renumbered" else 1)):
+        variants = [("flat", -1), ("banded", 2 if kind == "communities_renumbered" else 1)]
+        if kind == "uniform" and mode != "pmc":
+            variants.append(("coclustered", 2))          # forced co-clustering where the automatic rule says no (score 0.41)
+        for name, bands in variants:
             P = (graph.GraphPlan(ui, xcd_bands=bands), graph.GraphPlan(iu, xcd_bands=bands))
             launches = [(P[0], False, Xi, ui), (P[1], False, Xu, iu), (P[0], True, Xu, ui.T.tocsr()), (P[1], True, Xi, iu.T.tocsr())]
             rec = {"score": [P[0].info()["band_score"] or P[0].info()["cluster_score"],

@@ -260,6 +260,21 @@ def _all_reduce(t, group):
     return t
 
 
+def _all_gather_into(out, x, group):
+    """all_gather_into_tensor; device tensors on a gloo group (tests: several ranks sharing ONE GPU) go through gloo's device
+    all-reduce of a zero-padded buffer - gloo has no device all-gather - which is the same data movement seen from the
+    step."""
+    if x.is_cuda and dist.get_backend(group) == "gloo":
+        per = x.shape[0]
+        r = dist.get_rank(group)
+        out.zero_()
+        out[r * per:(r + 1) * per].copy_(x)
+        dist.all_reduce(out, group=group)
+        return out
+    dist.all_gather_into_tensor(out, x.contiguous(), group=group)
+    return out
+
+
 def _reduce_scatter_sum(full, per, group):
     if _solo(group):
         return full
@@ -281,7 +296,7 @@ class AllGatherRows(torch.autograd.Function):
         ctx.group, ctx.per = group, x.shape[0]
         world = dist.get_world_size(group)
         out = torch.empty((world * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
-        dist.all_gather_into_tensor(out, x.contiguous(), group=group)
+        _all_gather_into(out, x.contiguous(), group)
         _log_comm("all_gather", out)
         return out
 
@@ -593,7 +608,7 @@ def _all_gather_raw(x, group):
         _log_comm("all_gather", x)
         return x
     out = torch.empty((world * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
-    dist.all_gather_into_tensor(out, x.contiguous(), group=group)
+    _all_gather_into(out, x.contiguous(), group)
     _log_comm("all_gather", out)
     return out
 
@@ -618,7 +633,7 @@ def _all_gather_pair(xa, xb, group):
     cm, grouped = _coalesced(group, xa.device)
     with cm:
         for o, x in zip(outs, (xa, xb)):
-            dist.all_gather_into_tensor(o, x.contiguous(), group=group)
+            _all_gather_into(o, x.contiguous(), group)
     if COMM["log"] is not None:
         if grouped:
             COMM["log"].append(("all_gather", tuple(tuple(o.shape) for o in outs), 4 * sum(o.numel() for o in outs)))

@@ -1,0 +1,61 @@
+"""Child rank of tests/test_dist_gpu.py::test_hip_backend_at_world_2_and_3_on_one_gpu: the row-sharded hot path on the
+PRODUCT backend (dist.HipBackend: HIP kernels, lanes on real streams, row-pitched column-chunk SpMMs) at world size > 1 with
+every rank on the SAME GPU. RCCL refuses two ranks on one device, so the ranks talk through a gloo group (device tensors:
+gloo's device all-reduce; all-gather as an all-reduce of a zero-padded buffer) - different transport, the same shards, the
+same per-rank partial products, uneven last blocks and all.
+
+    python tests/_hip_world_worker.py RANK WORLD PORT MODAL SCHEME CHUNKS OUT_DIR"""
+import os
+import sys
+
+import torch
+import torch.distributed as dist
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+for p in (ROOT, os.path.join(ROOT, "oracle"), HERE):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def main():
+    rank, world, port = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
+    modal, scheme, chunks, out_dir = sys.argv[4], sys.argv[5], int(sys.argv[6]), sys.argv[7]
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import mmssl_oracle as O
+    import test_dist_cpu as T
+    from mmssl_amd import dist as md
+    dev = torch.device("cuda", 0)
+    fx, d, raw, U, I, state, users, pos, neg, img_raw, txt_raw = T._global_problem(modal)
+    ush, ish = md.RowShard(U, world, rank), md.RowShard(I, world, rank)
+    bk = md.HipBackend()
+    drop = modal.endswith("_drop")
+    cfg = O.Cfg(drop_rate=0.2 if drop else 0.0, batch_size=48, n_ui_layers=2)
+    d, state, k_txt = T._pad_text_to_slices(d, state)            # whole 32-deep slices: the packed node runs
+
+    def row_pair(m):
+        ui, iu = O.csr_norm(m, True), O.csr_norm(m.T, True)
+        return bk.make_graph(md.shard_graph(ui, ush, ish)), bk.make_graph(md.shard_graph(iu, ish, ush))
+    graphs = T._local_pair(md, bk, O, raw, ush, ish, scheme) + row_pair(img_raw) + row_pair(txt_raw)
+    model = md.ShardedMMSSL(bk, cfg, ush, ish, state, d["image_feat"], d["text_feat"], scheme=scheme, chunks=chunks).to(dev).train()
+    step = md.ShardedHotPathStep(model, graphs, 48, I, modal_empty=(modal.replace("_drop", "") == "empty_shortcut"),
+                                 optimizer=False)
+    step.set_batch(torch.stack([users, pos, neg]).to(dev))
+    if drop:
+        step.keep_masks = tuple(ish.slice_rows(k.to(torch.uint8)).to(dev) for k in T._global_masks(I))
+    total = step.backward()
+    torch.cuda.synchronize()
+    assert model.last_fused
+    g = {n: (p.grad.detach().cpu().clone() if p.grad is not None else None) for n, p in model.named_parameters()}
+    assert float(g["txt_w"][:, k_txt:].abs().max()) == 0.0
+    g["txt_w"] = g["txt_w"][:, :k_txt]
+    torch.save({"loss": float(total), "ush": (ush.lo, ush.hi, ush.n), "ish": (ish.lo, ish.hi, ish.n), "g": g,
+                "chunks": model.n_chunks(2) if scheme == "item-side" else 1}, os.path.join(out_dir, "r%d.pt" % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,4 +1,4 @@
-"""Child rank of tests/test_dist_gpu.py::test_hip_backend_at_world_2_and_3_on_one_gpu: the row-sharded hot path on the
+"""Child rank of tests/test_dist_gpu.py::test_hip_backend_at_world_2_3_8_on_one_gpu: the row-sharded hot path on the
 PRODUCT backend (dist.HipBackend: HIP kernels, lanes on real streams, row-pitched column-chunk SpMMs) at world size > 1 with
 every rank on the SAME GPU. RCCL refuses two ranks on one device, so the ranks talk through a gloo group (device tensors:
 gloo's device all-reduce; all-gather as an all-reduce of a zero-padded buffer) - different transport, the same shards, the
@@ -28,6 +28,8 @@ def main():
     import test_dist_cpu as T
     from mmssl_amd import dist as md
     dev = torch.device("cuda", 0)
+    if modal == "baby":
+        return baby(rank, world, scheme, chunks, out_dir, md, dev)
     fx, d, raw, U, I, state, users, pos, neg, img_raw, txt_raw = T._global_problem(modal)
     ush, ish = md.RowShard(U, world, rank), md.RowShard(I, world, rank)
     bk = md.HipBackend()
@@ -51,6 +53,36 @@ def main():
     g = {n: (p.grad.detach().cpu().clone() if p.grad is not None else None) for n, p in model.named_parameters()}
     assert float(g["txt_w"][:, k_txt:].abs().max()) == 0.0
     g["txt_w"] = g["txt_w"][:, :k_txt]
+    torch.save({"loss": float(total), "ush": (ush.lo, ush.hi, ush.n), "ish": (ish.lo, ish.hi, ish.n), "g": g,
+                "chunks": model.n_chunks(2) if scheme == "item-side" else 1}, os.path.join(out_dir, "r%d.pt" % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def baby(rank, world, scheme, chunks, out_dir, md, dev):
+    """BASELINE configs[3]: the Amazon-Baby graph cut `world` ways (35598 users / 18357 items: uneven last blocks), one
+    sharded step with injected dropout masks; the parent holds the oracle's loss and gradients."""
+    import scipy.sparse as sp
+    import numpy as np
+    import _nccl_worker as W
+    pb = W._baby_problem(torch.device("cpu"), ref=False)
+    U, I = pb["U"], pb["I"]
+    ush, ish = md.RowShard(U, world, rank), md.RowShard(I, world, rank)
+    bk = md.HipBackend()
+    ui_l = md.shard_graph(pb["ui"], ush, ish)
+    iu_l = md.shard_graph_cols(pb["iu"], ish, ush) if scheme == "item-side" else md.shard_graph(pb["iu"], ish, ush)
+    e_ui = bk.make_graph(sp.csr_matrix((ush.per, ish.n_pad), dtype=np.float32))
+    e_iu = bk.make_graph(sp.csr_matrix((ish.per, ush.n_pad), dtype=np.float32))
+    graphs = (bk.make_graph(ui_l), bk.make_graph(iu_l), e_ui, e_iu, e_ui, e_iu)
+    model = md.ShardedMMSSL(bk, pb["cfg"], ush, ish, pb["state"], pb["img"].numpy(), pb["txt"].numpy(), scheme=scheme,
+                            chunks=chunks).to(dev).train()
+    step = md.ShardedHotPathStep(model, graphs, 1024, I, modal_empty=True, optimizer=False)
+    step.keep_masks = tuple(ish.slice_rows(k.to(torch.uint8)).to(dev) for k in pb["km"])
+    step.set_batch(pb["batch"].to(dev))
+    total = step.backward()
+    torch.cuda.synchronize()
+    assert model.last_fused
+    g = {n: (p.grad.detach().cpu().clone() if p.grad is not None else None) for n, p in model.named_parameters()}
     torch.save({"loss": float(total), "ush": (ush.lo, ush.hi, ush.n), "ish": (ish.lo, ish.hi, ish.n), "g": g,
                 "chunks": model.n_chunks(2) if scheme == "item-side" else 1}, os.path.join(out_dir, "r%d.pt" % rank))
     dist.barrier()

@@ -142,7 +142,8 @@ def case_g8(out):
     out["g8/trajectory"] = losses
 
 
-def _baby_problem(dev):
+def _baby_problem(dev, ref=True):
+    """`ref=False`: inputs only (no oracle forward / backward)."""
     import mmssl_oracle as O
     from mmssl_amd import config, synth, dist as md
     from mmssl_amd.Models import MMSSL
@@ -167,13 +168,16 @@ def _baby_problem(dev):
     A = [O.to_torch_sparse(x) for x in (ui_l[:U, :I], iu_l[:I, :U], e_ui, e_iu, e_ui, e_iu)]
     P = {k: v.clone().requires_grad_(v.dtype.is_floating_point) for k, v in state.items()}
     cfg = O.Cfg(drop_rate=0.2, n_ui_layers=3, batch_size=1024)
-    o = O.forward(P, img, txt, A, cfg, training=True, keep_masks=[k.float() for k in km])
-    mf, emb, _ = O.bpr(o[0][users], o[1][pos], o[1][neg], 1e-5, 1024)
-    ref = mf + emb + O.feat_reg(o[2], o[3], o[4], o[5], I, 1e-5) + 0.03 * (
-        O.infonce(o[8][users], o[6][users], 0.5) + O.infonce(o[9][users], o[6][users], 0.5))
-    ref.backward()
+    loss = float("nan")
+    if ref:
+        o = O.forward(P, img, txt, A, cfg, training=True, keep_masks=[k.float() for k in km])
+        mf, emb, _ = O.bpr(o[0][users], o[1][pos], o[1][neg], 1e-5, 1024)
+        tot = mf + emb + O.feat_reg(o[2], o[3], o[4], o[5], I, 1e-5) + 0.03 * (
+            O.infonce(o[8][users], o[6][users], 0.5) + O.infonce(o[9][users], o[6][users], 0.5))
+        tot.backward()
+        loss = float(tot)
     return dict(U=U, I=I, ui=ui_l, iu=iu_l, ush=ush, ish=ish, state=state, img=img, txt=txt, km=km,
-                batch=torch.stack([users, pos, neg]), ref=float(ref), P=P, e_ui=e_ui, e_iu=e_iu, cfg=cfg)
+                batch=torch.stack([users, pos, neg]), ref=loss, P=P, e_ui=e_ui, e_iu=e_iu, cfg=cfg)
 
 
 def case_baby(out):

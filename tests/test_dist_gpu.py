@@ -133,37 +133,45 @@ def test_sharded_packed_node_at_d128_per_modality_projection_equals_oracle(solo_
 
 
 @pytest.mark.parametrize("world,modal,scheme,chunks", [(2, "full", "item-side", 2), (3, "full_drop", "item-side", 2),
-                                                       (3, "empty_shortcut", "item-side", 1), (3, "full", "gather-both", 0)])
-def test_hip_backend_at_world_2_and_3_on_one_gpu(tmp_path, world, modal, scheme, chunks):
+                                                       (3, "empty_shortcut", "item-side", 1), (3, "full", "gather-both", 0),
+                                                       (3, "baby", "item-side", 2), (8, "baby", "item-side", 1),
+                                                       (8, "baby", "gather-both", 0)])
+def test_hip_backend_at_world_2_3_8_on_one_gpu(tmp_path, world, modal, scheme, chunks):
     """dist.HipBackend at world size > 1: `world` processes share GPU 0 (their group is gloo - RCCL refuses two ranks on one
     device - moving DEVICE tensors), each runs its shard of the sharded step on the HIP kernels: real per-rank partial
     products, uneven last blocks (300 users / 200 items over 3 ranks), lanes on real streams with row-pitched column-chunk
     SpMMs, the batch-rows fuse on owned rows only. Loss and every gradient against the single-process oracle, the sharded
-    tables row by row."""
+    tables row by row. The (8, "baby", ...) cases are BASELINE configs[3]'s partition itself: the Amazon-Baby graph, item and
+    user rows sharded 8 ways (4450 / 2295 rows per rank, the last blocks short), both schemes."""
     import subprocess
     import test_dist_cpu as T
     port = T._free_port()
     procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "_hip_world_worker.py"), str(r), str(world), str(port), modal,
                                scheme, str(chunks), str(tmp_path)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
              for r in range(world)]
-    outs = [p.communicate(timeout=600)[0] for p in procs]
+    outs = [p.communicate(timeout=900)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), "\n".join(o[-1500:] for o in outs)
-    ref_loss, P = T._reference(modal)
+    if modal == "baby":            # configs[3]: the Baby graph cut 3 ways; reference = the oracle's step (north_star: loss 1e-4)
+        import _nccl_worker as W
+        pb = W._baby_problem(torch.device("cpu"), ref=True)
+        ref_loss, P, tol_l, tol_g = pb["ref"], pb["P"], 1e-4, 5e-4
+    else:
+        (ref_loss, P), tol_l, tol_g = T._reference(modal), 2e-5, 1e-4
     recs = [torch.load(os.path.join(str(tmp_path), "r%d.pt" % r)) for r in range(world)]
     for o in recs:
-        assert abs(o["loss"] - ref_loss) <= 2e-5 * abs(ref_loss), (o["loss"], ref_loss)
+        assert abs(o["loss"] - ref_loss) <= tol_l * abs(ref_loss), (o["loss"], ref_loss)
         assert o["chunks"] == max(chunks, 1)
         for name, key in (("img_w", "image_trans.weight"), ("img_b", "image_trans.bias"), ("txt_w", "text_trans.weight"),
                           ("txt_b", "text_trans.bias")):
-            H.check_grad(o["g"][name], P[key].grad, 1e-4, name)
+            H.check_grad(o["g"][name], P[key].grad, tol_g, name)
         if modal.startswith("full"):
-            H.check_grad(o["g"]["w_cat"], P["weight_dict.w_self_attention_cat"].grad, 1e-4, "w_cat")
+            H.check_grad(o["g"]["w_cat"], P["weight_dict.w_self_attention_cat"].grad, tol_g, "w_cat")
         for name, key, sh in (("E_u", "user_id_embedding.weight", o["ush"]), ("E_i", "item_id_embedding.weight", o["ish"])):
             lo, hi, n = sh
             k = max(0, min(hi, n) - lo)
             if k > 0:
                 ref = P[key].grad[lo:lo + k]
-                assert H.rel_err(o["g"][name][:k], ref) < 1e-4, name
+                assert H.rel_err(o["g"][name][:k], ref) < tol_g, name
                 den = torch.clamp(ref.abs().amax(1), min=1e-3 * float(P[key].grad.abs().max()))
                 assert float(((o["g"][name][:k] - ref).abs().amax(1) / den).max()) < 5e-3, (name, "row-wise")
             if k < hi - lo:

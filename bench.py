@@ -502,6 +502,9 @@ def main():
     ap.add_argument("--xcd-bands", type=int, default=0, dest="xcd_bands", choices=[-1, 0, 1],
                     help="GraphPlan XCD banding: 0 = automatic (on when the graph has column locality), 1 = always, -1 = never")
     ap.add_argument("--no-hbm", action="store_true", dest="no_hbm", help="skip the HBM-resident SpMM record (`spmm_hbm`)")
+    ap.add_argument("--share-gpu", action="store_true", dest="share_gpu",
+                    help="test aid: every rank on GPU 0, process group on gloo moving device tensors (RCCL refuses two ranks on "
+                         "one device) - runs the whole N > 1 flow on a one-GPU box; eager steps, timings mean nothing")
     ap.add_argument("--no-stress", action="store_true", dest="no_stress",
                     help="N>1: skip the `scaling_stress` record (configs[4]'s per-rank share x N after the timed region)")
     ap.add_argument("--scheme", choices=["item-side", "gather-both"], default="item-side",
@@ -524,6 +527,9 @@ def main():
     if a.launch_check:
         launch_check(a, rank, world, local_rank)
         return
+    if a.share_gpu:
+        local_rank = 0
+        a.dist_graph, a.backend = "off", "gloo"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     sharded = world > 1 or a.force_dist or a.workload == "synth" or a.dist_graph_probe
@@ -536,6 +542,8 @@ def main():
             os.environ.setdefault("RANK", "0")
             os.environ.setdefault("WORLD_SIZE", "1")
             dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        elif a.share_gpu:
+            dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=dev)
 

@@ -1520,9 +1520,12 @@ def comm_replay_ms(log, group, dev, iters=10):
             with cm:
                 for full, part in members:
                     if kind == "all_gather":
-                        dist.all_gather_into_tensor(full, part, group=group)
+                        _all_gather_into(full, part, group)
                     elif kind == "reduce_scatter":
-                        dist.reduce_scatter_tensor(part, full, group=group)
+                        if dist.get_backend(group) == "gloo":
+                            dist.all_reduce(full, group=group)
+                        else:
+                            dist.reduce_scatter_tensor(part, full, group=group)
                     else:
                         dist.all_reduce(full, group=group)
     once()

@@ -58,3 +58,26 @@ def test_bench_sharded_path_one_rank_reports_comm():
     assert c["by_kind"]["all_gather"][0] == 6 and c["by_kind"]["reduce_scatter"][0] == 6 and c["by_kind"]["all_reduce"][0] == 2
     assert c["collectives_per_step"] == 14
     assert c["comm_only_ms"] > 0 and c["bytes_per_step"] > 0
+
+
+def test_bench_n_ranks_flow_on_one_gpu_including_scaling_stress():
+    """The N > 1 bench flow end to end on a one-GPU box (`--share-gpu`: every rank on GPU 0, gloo moving device tensors):
+    self-launch of the ranks, per-rank generation of the weak-scaling graph (item degrees summed across ranks), the item-side
+    sharded step, barrier + max-over-ranks timing, ONE JSON line with `comm` and the `scaling_stress` record (configs[4]'s
+    share x N). Timings mean nothing here; the contract fields and the record's arithmetic are checked."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--workload", "tiktok", "--share-gpu"], capture_output=True, text=True, timeout=1500, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["steps"] == 3 and d["value"] > 0
+    assert d["config"]["n_users"] == 2 * 9319 and d["config"]["launch"] == "eager"
+    c = d["comm"]
+    assert c["scheme"] == "item-side" and c["collectives_per_step"] >= 14 and c["bytes_per_step"] > 0
+    st = d["scaling_stress"]
+    assert "error" not in st, st
+    assert st["ms_per_step"] > 0 and st["comm"]["scheme"] == "item-side" and st["comm"]["column_chunks"] >= 1
+    assert abs(st["edge_layers_per_s"] - 2 * 250_000_000 / (st["ms_per_step"] * 1e-3)) <= 1e-3 * st["edge_layers_per_s"]
+    assert st["one_rank"]["edge_layers_per_s"] > 0 and abs(st["per_rank_ratio"] - st["edge_layers_per_s"] / 2 / st["one_rank"]["edge_layers_per_s"]) < 1e-3

@@ -15,6 +15,7 @@ from . import _lib
 
 N_BANDS = 8                 # XCDs of an MI355X
 CLUSTER_SCORE = 0.6         # co-clustering is used when >= this fraction of the edges stays inside its row's cluster
+CLUSTER_AUTO_NNZ = 20_000_000   # automatic mode tries it up to this many entries (~0.4 s per million on the host); 2 = always
 
 
 def _balanced_argmax(C, cap, rng):
@@ -113,7 +114,7 @@ class GraphPlan:
                 _lib.check(_lib.lib().mmssl_plan_band_host(rowptr.ctypes.data, col.ctypes.data, self.shape[0], self.shape[1],
                                                            N_BANDS, band.ctypes.data, ctypes.byref(sc)), "mmssl_plan_band_host")
                 contiguous = sc.value >= 0.5
-            if not contiguous:
+            if not contiguous and (xcd_bands == 2 or self.nnz <= CLUSTER_AUTO_NNZ):
                 rl, cl, score = cocluster(csr)
                 self.cluster_score = score
                 if xcd_bands == 2 or score >= CLUSTER_SCORE:

@@ -82,10 +82,10 @@ class HotPathStep:
         # ONE stream for everything this object launches (eager steps, capture, replays): autograd
         # binds each parameter's AccumulateGrad node to the stream of its first backward, and a
         # later capture on a different stream would have to synchronise across streams.
-        # The step's own stream - the critical projection / modal / loss chain - runs at high priority: its workgroups are
-        # dispatched ahead of the GCN chain's (side streams, default priority) wherever both are ready (measured: 0.481-0.485
-        # against 0.487-0.490 ms per step, two alternating pairs on one box).
-        self.stream = torch.cuda.Stream(device=dev, priority=-1)
+        # (Default priority. A high-priority step stream measured 5 us faster per step when it worked - and in about one run of
+        # three the replayed graph then executed its branches one after the other: 0.76-0.83 ms per step, the sum of the
+        # kernel times. profiles/r04/experiments_rejected.txt)
+        self.stream = torch.cuda.Stream(device=dev)
         self.stream.wait_stream(torch.cuda.current_stream(dev))
 
     def set_batch(self, users, pos=None, neg=None):

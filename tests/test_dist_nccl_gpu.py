@@ -79,7 +79,7 @@ def test_baby_strong_shape_sharded_step_with_real_rccl_matches_oracle(tmp_path, 
             assert r[k + "_rowwise"] < 5e-3, (tag, k, r[k + "_rowwise"])     # every row against its own scale
 
 
-@pytest.mark.parametrize("scheme,chunks", [("gather-both", 0), ("item-side", 2)])
+@pytest.mark.parametrize("scheme,chunks", [("gather-both", 0), ("item-side", 2), ("item-side", 4)])
 def test_synth_rank_shape_spmm_and_sharded_step(tmp_path, scheme, chunks):
     rec = _run("synth_rank", tmp_path, 900, scheme, chunks)
     assert rec["synth/scheme"] == [scheme, max(chunks, 1)]

@@ -507,9 +507,10 @@ def main():
                          "one device) - runs the whole N > 1 flow on a one-GPU box; eager steps, timings mean nothing")
     ap.add_argument("--no-stress", action="store_true", dest="no_stress",
                     help="N>1: skip the `scaling_stress` record (configs[4]'s per-rank share x N after the timed region)")
-    ap.add_argument("--scheme", choices=["item-side", "gather-both"], default="item-side",
+    ap.add_argument("--scheme", choices=["item-side", "gather-both", "halo"], default="item-side",
                     help="sharded step: item-side = user-row blocks only, every collective of item-table size; "
-                         "gather-both = user AND item row blocks, all-gather of both tables (round-3 scheme)")
+                         "gather-both = user AND item row blocks, all-gather of both tables (round-3 scheme); halo = item-side "
+                         "exchanging only the item rows a rank's edges reference (all-to-all of row lists)")
     ap.add_argument("--chunks", type=int, default=0,
                     help="sharded step: column chunks per collective (chunk c's SpMM runs under chunk c+1's collective); "
                          "0 = by size (1 below 64 MB per collective, else 2-4)")
@@ -643,11 +644,14 @@ def timed_sharded(a, rank, world, dev, scaling, want_graph):
     comm = {"scheme": stats["scheme"], "column_chunks": stats["chunks"], "collectives_per_step": len(log),
             "bytes_per_step": int(sum(b for _, _, b in log)),
             "by_kind": {k: [sum(1 for x in log if x[0] == k), int(sum(x[2] for x in log if x[0] == k))]
-                        for k in ("all_gather", "reduce_scatter", "all_reduce")},
+                        for k in ("all_gather", "reduce_scatter", "all_reduce", "halo_gather", "halo_reduce")
+                        if k in ("all_gather", "reduce_scatter", "all_reduce") or any(x[0] == k for x in log)},
             "note": "bytes = size of the full (gathered / to-be-scattered / reduced) fp32 buffer of every collective "
                     "of one step on one rank; comm_only_ms = the same collectives replayed alone, back to back"}
     with torch.cuda.stream(step.stream):
-        comm["comm_only_ms"] = round(mdist.comm_replay_ms(log, None, dev), 4)
+        comm["comm_only_ms"] = round(mdist.comm_replay_ms(log, None, dev, halo=stats.get("halo")), 4)
+    if stats.get("halo_rows_fraction") is not None:
+        comm["halo_rows_fraction"] = stats["halo_rows_fraction"]      # referenced item rows / item table (this rank)
     rngb = np.random.default_rng(2022)          # identical batches on every rank (global ids)
     batches = [torch.stack([torch.from_numpy(x).to(dev) for x in (                   # packed [3, B]: one copy per step
         rngb.choice(n_users, a.batch, replace=a.batch > n_users).astype(np.int64),

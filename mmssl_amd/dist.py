@@ -70,6 +70,13 @@ class HipBackend:
                                                     idx.shape[0], int(lo), out.data_ptr(), _lib.stream_ptr())
         _lib.check(rc, "mmssl_gather_owned_rows_f32")
 
+    def pack_rows(self, table, idx):
+        """table[idx] (idx int64 device rows of `table`): the halo exchange's send buffer, one gather launch."""
+        out = torch.empty((idx.shape[0], table.shape[1]), dtype=table.dtype, device=table.device)
+        if idx.shape[0]:
+            self.gather_owned(table.contiguous(), idx, 0, out)
+        return out
+
     def scatter_owned(self, g, idx, lo, gtable):
         from . import _lib
         rc = _lib.lib().mmssl_scatter_owned_rows_f32(g.data_ptr(), idx.data_ptr(), idx.shape[0], int(lo), gtable.shape[0],
@@ -243,6 +250,17 @@ def shard_graph_cols(mat, row_shard, col_shard):
     m = sp.csr_matrix(mat, dtype=np.float32).copy()
     m.resize((row_shard.n_pad, col_shard.n_pad))
     return m.tocsc()[:, col_shard.lo:col_shard.hi].tocsr()
+
+
+def halo_graphs(ui_local, iu_cols_local):
+    """The item-side pair (A_ui[U_r, :] [per_u, I_pad], A_iu[:, U_r] [I_pad, per_u]) on COMPACT item ids: returns
+    (need, A_ui[U_r, need] [per_u, n_need], A_iu[need, U_r] [n_need, per_u]) with need = the sorted global ids of the items
+    this rank's edges reference (scheme "halo")."""
+    ui_local = sp.csr_matrix(ui_local)
+    need = np.unique(ui_local.indices).astype(np.int64)
+    if need.shape[0] == 0:
+        need = np.zeros(1, np.int64)
+    return need, ui_local[:, need].tocsr(), sp.csr_matrix(iu_cols_local)[need, :].tocsr()
 
 
 # ---------------------------------------------------------------------------------------------
@@ -438,6 +456,8 @@ class ShardedMMSSL(nn.Module):
                             A_ui . X_i and of the user table before A_iu . X_u
              "item-side"    ui = A_ui[U_r, :], iu = A_iu[:, U_r] (shard_graph_cols): only this rank's users' edges; every
                             collective is of item-table size (_ShardedItemSide)
+             "halo"         the item-side graphs with COMPACT item columns (halo_graphs) + `model.halo` = their HaloPlan:
+                            only the item rows this rank's edges reference travel (all-to-all of row lists)
            chunks: column chunks per collective of the item-side node (0 = by size, see n_chunks)."""
         super().__init__()
         self.bk, self.cfg, self.ush, self.ish, self.group = backend, cfg, ush, ish, group
@@ -479,9 +499,12 @@ class ShardedMMSSL(nn.Module):
             u = bk.l2norm_rows(self._fusion(img_uid, txt_uid), self.E_u, c.id_cat_rate)
             i = bk.l2norm_rows(self._fusion(img_iid, txt_iid), self.E_i, c.id_cat_rate)
         d = c.embed_size
-        if getattr(self, "scheme", "gather-both") == "item-side" and not _solo(self.group):
+        if getattr(self, "scheme", "gather-both") in ("item-side", "halo") and not _solo(self.group):
+            xch = getattr(self, "halo", None) if self.scheme == "halo" else None
+            if self.scheme == "halo" and xch is None:
+                raise RuntimeError("ShardedMMSSL(scheme='halo') needs model.halo = HaloPlan(...) (see halo_graphs)")
             u_g, i_g, ss, MI, MU = _ShardedItemSide.apply(
-                2, scale, keep, ui, iu, c.n_ui_layers, c.model_cat_rate, bk, self.group, self.n_chunks(2), u, i,
+                2, scale, keep, ui, iu, c.n_ui_layers, c.model_cat_rate, bk, self.group, self.n_chunks(2), xch, u, i,
                 self.image_feats, self.text_feats, self.img_w, self.txt_w, self.img_b, self.txt_b)
         else:       # (one rank without forced collectives: both schemes are the same computation)
             u_g, i_g, ss, MI, MU = _ShardedHotForward.apply(
@@ -506,7 +529,8 @@ class ShardedMMSSL(nn.Module):
         ok = getattr(self.bk, "chunk_ok", lambda w, n: w % n == 0)
         nc = int(getattr(self, "chunks", 0))
         if nc <= 0:
-            full = self.ish.n_pad * d * 4
+            rows = self.halo.n_need if (getattr(self, "scheme", "") == "halo" and getattr(self, "halo", None)) else self.ish.n_pad
+            full = rows * d * 4
             nc = 4 if full >= 4 * self.CHUNK_BYTES else (2 if full >= self.CHUNK_BYTES else 1)
         while nc > 1 and not (ok(d, nc) and ok(nm * d, nc)):
             nc -= 1
@@ -961,6 +985,99 @@ def _contig_chunks(t, nc):
     return [x.contiguous() for x in _chunks_of(t, nc)]
 
 
+
+class _TableExchange:
+    """How the item-side node moves item-table rows between ranks: the WHOLE table by RCCL all-gather / reduce-scatter
+    (scheme "item-side"). gather: this rank's rows [per_i, w] -> what the local products gather from ([I_pad, w]);
+    reduce: local partial products over that row space -> this rank's rows of their sum over all ranks."""
+
+    def __init__(self, group, per_i):
+        self.group, self.per_i = group, per_i
+
+    def gather(self, x):
+        return _all_gather_raw(x, self.group)
+
+    def reduce(self, P):
+        return _reduce_scatter_raw(P, self.per_i, self.group)
+
+    def gather_pair(self, a, b):
+        return _all_gather_pair(a, b, self.group)
+
+    def reduce_pair(self, fa, fb):
+        return _reduce_scatter_pair(fa, fb, self.per_i, self.group)
+
+
+def _all_to_all_rows(out, inp, out_rows, in_rows, group):
+    """Variable all-to-all of row blocks (rank q gets inp's block q, sends its blocks likewise). Device tensors on a gloo
+    group (tests: ranks sharing one GPU) are staged through the host."""
+    if inp.is_cuda and dist.get_backend(group) == "gloo":
+        o = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_to_all_single(o, inp.cpu(), output_split_sizes=out_rows, input_split_sizes=in_rows, group=group)
+        out.copy_(o)
+        return out
+    dist.all_to_all_single(out, inp.contiguous(), output_split_sizes=out_rows, input_split_sizes=in_rows, group=group)
+    return out
+
+
+class HaloPlan:
+    """Scheme "halo": a rank exchanges only the item rows its own users' edges REFERENCE. Built once per graph on the host:
+      need        sorted global ids of the items this rank's edges touch (n_need of them: 55 % of the table for the
+                  Baby-shaped weak-scaling graph at N = 8, 98 % for configs[4], a few % for a community-partitioned graph)
+      the local graphs use COMPACT columns 0 .. n_need - 1 (A_ui[U_r, need], A_iu[need, U_r])
+      send_idx    for every peer q, the local rows of MY item block that q needs (owners send exactly those rows)
+      sel         [per_i, n_send] 0/1 selection matrix as a graph plan: summing the partial-product rows that came back for
+                  my items is one deterministic SpMM (a row's contributions in rank order)
+    gather = pack (row gather kernel) + all-to-all;  reduce = all-to-all + selection SpMM; each the other's adjoint."""
+
+    def __init__(self, need, ish, group, bk, device):
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+        need = np.ascontiguousarray(need, dtype=np.int64)
+        lists = [None] * world
+        dist.all_gather_object(lists, need, group=group)           # host, once per graph
+        owner_cut = np.searchsorted(need, np.arange(world + 1) * ish.per)
+        self.recv_rows = [int(owner_cut[q + 1] - owner_cut[q]) for q in range(world)]      # what I get from owner q
+        send = []
+        for q in range(world):                                       # rows of MY block that rank q needs, as local ids
+            nq = lists[q]
+            a, b = np.searchsorted(nq, ish.lo), np.searchsorted(nq, ish.lo + ish.per)
+            send.append(nq[a:b] - ish.lo)
+        self.send_rows = [int(x.shape[0]) for x in send]
+        flat = np.concatenate(send) if send else np.zeros(0, np.int64)
+        self.n_need, self.n_send, self.per_i = int(need.shape[0]), int(flat.shape[0]), ish.per
+        self.group, self.bk = group, bk
+        self.send_idx = torch.from_numpy(flat.astype(np.int64)).to(device)
+        sel = sp.csr_matrix((np.ones(flat.shape[0], np.float32), (flat, np.arange(flat.shape[0]))),
+                            shape=(ish.per, max(flat.shape[0], 1)))
+        self.sel = bk.make_graph(sel)
+        self.bytes_fraction = self.n_need / float(ish.n_pad)
+
+    def _pack(self, x):
+        if hasattr(self.bk, "pack_rows"):
+            return self.bk.pack_rows(x, self.send_idx)
+        return x[self.send_idx]
+
+    def gather(self, x):
+        send = self._pack(x)
+        out = torch.empty((self.n_need, x.shape[1]), dtype=x.dtype, device=x.device)
+        _all_to_all_rows(out, send, self.recv_rows, self.send_rows, self.group)
+        _log_comm("halo_gather", out)
+        return out
+
+    def reduce(self, P):
+        recv = torch.empty((max(self.n_send, 1), P.shape[1]), dtype=P.dtype, device=P.device)
+        if self.n_send == 0:
+            recv.zero_()
+        _all_to_all_rows(recv[:self.n_send], P, self.send_rows, self.recv_rows, self.group)
+        _log_comm("halo_reduce", P)
+        return self.bk.spmm_raw(self.sel, False, recv, self.bk.EPI_NONE)
+
+    def gather_pair(self, a, b):       # (no grouped form: two launches)
+        return self.gather(a), self.gather(b)
+
+    def reduce_pair(self, fa, fb):
+        return self.reduce(fa), self.reduce(fb)
+
+
 class _ShardedItemSide(torch.autograd.Function):
     """The packed hot node over USER-ROW BLOCKS ONLY ("item-side" scheme). Rank r holds the edges of its users twice:
     `ui` = A_ui[U_r, :] ([per_u, I_pad], global item columns) and `iuT` = A_iu[:, U_r] ([I_pad, per_u]). Then
@@ -983,7 +1100,7 @@ class _ShardedItemSide(torch.autograd.Function):
     fused epilogue)."""
 
     @staticmethod
-    def forward(ctx, nm, scale, keep, ui, iuT, n_layers, r, bk, group, nc, u0, i0, *flat):
+    def forward(ctx, nm, scale, keep, ui, iuT, n_layers, r, bk, group, nc, xch, u0, i0, *flat):
         Fs, Ws, bs = flat[:nm], flat[nm:2 * nm], flat[2 * nm:3 * nm]
         draw_p, ext_tick = 0.0, False
         if isinstance(keep, tuple):                  # ("draw", p, external_tick): fresh masks from the device generator
@@ -992,6 +1109,8 @@ class _ShardedItemSide(torch.autograd.Function):
         g = group
         per_u, per_i, d = u0.shape[0], i0.shape[0], u0.shape[1]
         wm = nm * d
+        if xch is None:
+            xch = _TableExchange(g, per_i)
         twin = (lambda p, k: p.twin(k)) if hasattr(ui, "twin") else (lambda p, k: p)
         new = lambda rows, w: torch.empty((rows, w), dtype=torch.float32, device=u0.device)      # noqa: E731
         G = _Lanes(bk, u0, nc)                                    # GCN chain: nc side lanes
@@ -1032,7 +1151,7 @@ class _ShardedItemSide(torch.autograd.Function):
                 for c in range(nc):
                     G.to_main(c)
                     M.to_main(c)
-                    fulls.append(_all_gather_pair(i_c[c], X_v[c].contiguous() if nc > 1 else X, g) + (G.mark(),))
+                    fulls.append(tuple(xch.gather_pair(i_c[c], X_v[c].contiguous() if nc > 1 else X)) + (G.mark(),))
                 for c, (i_full, X_full, ev) in enumerate(fulls):
                     G.after(c, ev)
                     M.after(c, ev)
@@ -1045,7 +1164,7 @@ class _ShardedItemSide(torch.autograd.Function):
                 del fulls
             else:
                 for c in range(nc):             # item rows -> user rows: gather, product into the lane's column chunk
-                    i_full = G.coll(c, lambda: _all_gather_raw(i_c[c], g))
+                    i_full = G.coll(c, lambda: xch.gather(i_c[c]))
                     with G.on(c):
                         bk.spmm_raw(twin(ui, 2 + c), False, i_full, bk.EPI_NONE, out=u_v[c])
             if last:
@@ -1066,7 +1185,7 @@ class _ShardedItemSide(torch.autograd.Function):
                 for c, (P, PM) in enumerate(parts):
                     G.to_main(c)
                     M.to_main(c)
-                    i_n[c], MI_c[c] = _reduce_scatter_pair(P, PM, per_i, g)
+                    i_n[c], MI_c[c] = xch.reduce_pair(P, PM)
                     G.uses(i_n[c], [c])
                     M.uses(MI_c[c], [c])
                     for t_ in (P, PM):          # allocated on a lane, read by the collective issued from the origin stream
@@ -1081,7 +1200,7 @@ class _ShardedItemSide(torch.autograd.Function):
                 for c in range(nc):
                     with G.on(c):
                         P = bk.spmm_raw(twin(iuT, 2 + c), False, u_v[c], bk.EPI_NONE)
-                    i_n[c] = G.coll(c, lambda: _reduce_scatter_raw(P, per_i, g))
+                    i_n[c] = G.coll(c, lambda: xch.reduce(P))
             if nc > 1 or last:
                 G.meet()
             with G.on(0):
@@ -1101,7 +1220,7 @@ class _ShardedItemSide(torch.autograd.Function):
         inv = 1.0 / (n_layers + 1)
         u_g, i_g, ss = bk.fuse_fwd(us, MU, its, MI, inv, nm, r)
         ctx.save_for_backward(MU, MI, us[-1], its[-1], keep, *Fs)
-        ctx.cfg = (nm, float(scale), ui, iuT, n_layers, float(r), inv, bk, g, [b is not None for b in bs], nc)
+        ctx.cfg = (nm, float(scale), ui, iuT, n_layers, float(r), inv, bk, g, [b is not None for b in bs], nc, xch)
         ctx.set_materialize_grads(False)
         return u_g, i_g, ss, MI, MU
 
@@ -1109,7 +1228,7 @@ class _ShardedItemSide(torch.autograd.Function):
     def backward(ctx, Gu, Gi, g_ss, G_MI, G_MU):
         MU, MI, uG, iG, keep = ctx.saved_tensors[:5]
         Fs = ctx.saved_tensors[5:]
-        nm, scale, ui, iuT, n_layers, r, inv, bk, g, has_b, nc = ctx.cfg
+        nm, scale, ui, iuT, n_layers, r, inv, bk, g, has_b, nc, xch = ctx.cfg
         per_u, per_i, d = MU.shape[0], MI.shape[0], uG.shape[1]
         wm = nm * d
         Gu = Gu.contiguous() if Gu is not None else torch.zeros_like(uG)
@@ -1153,7 +1272,7 @@ class _ShardedItemSide(torch.autograd.Function):
                 for c in range(nc):             # (grouped pairs from the origin stream, see forward)
                     G.to_main(c)
                     M.to_main(c)
-                    fulls.append(_all_gather_pair(gi_c[c], gMI_v[c].contiguous() if nc > 1 else gMI, g) + (G.mark(),))
+                    fulls.append(tuple(xch.gather_pair(gi_c[c], gMI_v[c].contiguous() if nc > 1 else gMI)) + (G.mark(),))
                 for c, (gP, gPM, ev) in enumerate(fulls):
                     G.after(c, ev)
                     M.after(c, ev)
@@ -1166,7 +1285,7 @@ class _ShardedItemSide(torch.autograd.Function):
                 del fulls
             else:
                 for c in range(nc):
-                    gP = G.coll(c, lambda: _all_gather_raw(gi_c[c], g))
+                    gP = G.coll(c, lambda: xch.gather(gi_c[c]))
                     with G.on(c):
                         bk.spmm_raw(twin(iuT, 2 + c), True, gP, bk.EPI_AXPY, Gu_v[c], inv, out=gu_v[c])
             if first:
@@ -1190,7 +1309,7 @@ class _ShardedItemSide(torch.autograd.Function):
                 for c, (part_g, part_m) in enumerate(parts):
                     G.to_main(c)
                     M.to_main(c)
-                    rg, gX_c[c] = _reduce_scatter_pair(part_g, part_m, per_i, g)
+                    rg, gX_c[c] = xch.reduce_pair(part_g, part_m)
                     G.uses(rg, [c])
                     M.uses(gX_c[c], [c])
                     for t_ in (part_g, part_m):
@@ -1207,7 +1326,7 @@ class _ShardedItemSide(torch.autograd.Function):
                 for c in range(nc):
                     with G.on(c):
                         part_g = bk.spmm_raw(twin(ui, 2 + c), True, gu_v[c], bk.EPI_NONE)
-                    rs = G.coll(c, lambda: _reduce_scatter_raw(part_g, per_i, g))
+                    rs = G.coll(c, lambda: xch.reduce(part_g))
                     with G.on(c):
                         gi_n[c] = rs.add_(Gi_v[c], alpha=inv)
             gi_c = gi_n
@@ -1227,7 +1346,7 @@ class _ShardedItemSide(torch.autograd.Function):
             gi0.record_stream(G.main)
         grads_b = [(gb[k] if (gb is not None and has_b[k]) else None) for k in range(nm)]
         bk.table_grads = (g_u0.data_ptr(), gi0.data_ptr())
-        return (None,) * 10 + (g_u0, gi0) + (None,) * nm + tuple(gW) + tuple(grads_b)
+        return (None,) * 11 + (g_u0, gi0) + (None,) * nm + tuple(gW) + tuple(grads_b)
 
 
 class ShardedHotPathStep:
@@ -1441,6 +1560,13 @@ class ShardedHotPathStep:
     def capture(self, warmup=3):
         """OPT-IN: capture the whole sharded step, RCCL collectives included, into a hipGraph (all on
         this object's stream). Returns False and stays eager if the runtime refuses."""
+        if getattr(self.model, "scheme", "") == "halo" and not _solo(self.group):
+            # the halo exchanges are all-to-alls (grouped send / recv) issued on the forked lane streams: capturing them
+            # ends in a crash inside hipStreamEndCapture on ROCm 7.2 for the 3-layer step (not for the 2-layer one; the
+            # grouped pairs of the item-side scheme had the same problem and moved to the origin stream, which here would
+            # put every exchange behind the projection GEMM). The halo step runs eagerly.
+            self._graph, self.capture_error = None, "halo scheme: eager only (all-to-all on forked streams is not capturable)"
+            return False
         try:
             with torch.cuda.stream(self.stream):
                 for _ in range(warmup):
@@ -1499,12 +1625,17 @@ def spawn_rank_probe(argv, port_offset=1, timeout=180):
         return False
 
 
-def comm_replay_ms(log, group, dev, iters=10):
+def comm_replay_ms(log, group, dev, iters=10, halo=None):
     """Time the collectives of one step ALONE (same kinds and sizes, dummy buffers, back to back on one stream):
-    the per-step communication time if nothing overlapped. HIP events on the issuing stream."""
+    the per-step communication time if nothing overlapped. HIP events on the issuing stream. Halo exchanges are replayed
+    through their plan (pack + all-to-all / all-to-all + selection SpMM)."""
     world = dist.get_world_size(group)
     bufs = []
     for kind, shape, _ in log:
+        if kind in ("halo_gather", "halo_reduce"):
+            rows = halo.per_i if kind == "halo_gather" else halo.n_need
+            bufs.append((kind, [(torch.zeros((rows, shape[1]), dtype=torch.float32, device=dev), None)]))
+            continue
         shapes = shape if (len(shape) and isinstance(shape[0], tuple)) else (shape,)      # grouped pair: several tensors
         members = []
         for sh in shapes:
@@ -1519,7 +1650,11 @@ def comm_replay_ms(log, group, dev, iters=10):
             cm = _coalesced(group, dev)[0] if len(members) > 1 else contextlib.nullcontext()
             with cm:
                 for full, part in members:
-                    if kind == "all_gather":
+                    if kind == "halo_gather":
+                        halo.gather(full)
+                    elif kind == "halo_reduce":
+                        halo.reduce(full)
+                    elif kind == "all_gather":
                         _all_gather_into(full, part, group)
                     elif kind == "reduce_scatter":
                         if dist.get_backend(group) == "gloo":
@@ -1613,8 +1748,12 @@ def build_bench_step(a, rank, world, dev, scaling="weak"):
     from .config import configure, HotCfg
     configure([], embed_size=a.d, weight_size=str([a.d] * a.gcn_layers), batch_size=a.batch, drop_rate=0.2)
     scheme = getattr(a, "scheme", "item-side")
-    ui_l, iu_l, ush, ish, U, I, E_global, dv, dt = build_sharded_graph(a, rank, world, dev, scaling, scheme)
+    ui_l, iu_l, ush, ish, U, I, E_global, dv, dt = build_sharded_graph(a, rank, world, dev, scaling,
+                                                                     "item-side" if scheme == "halo" else scheme)
     bk = HipBackend()
+    need = None
+    if scheme == "halo":            # the item-side pair on the item ids this rank's edges reference
+        need, ui_l, iu_l = halo_graphs(ui_l, iu_l)
     with torch.cuda.device(dev):
         plans = [bk.make_graph(ui_l), bk.make_graph(iu_l)]
         e_ui = bk.make_graph(sp.csr_matrix((ush.per, ish.n_pad), dtype=np.float32))
@@ -1636,6 +1775,8 @@ def build_bench_step(a, rank, world, dev, scaling="weak"):
     nn.Module.__init__(model)
     model.bk, model.cfg, model.ush, model.ish, model.group = bk, cfg, ush, ish, None
     model.scheme, model.chunks = scheme, int(getattr(a, "chunks", 0))
+    if scheme == "halo":
+        model.halo = HaloPlan(need, ish, None, bk, dev)
     model.img_w = nn.Parameter(xavier(a.d, dv))
     model.img_b = nn.Parameter(torch.zeros(a.d))
     model.txt_w = nn.Parameter(xavier(a.d, dt))
@@ -1663,5 +1804,7 @@ def build_bench_step(a, rank, world, dev, scaling="weak"):
     stats["edge_layers"] = int(round(stats["edge_layers"]))
     stats.update(n_users=U, n_items=I, n_edges=E_global, local_users=ush.per, local_items=ish.per,
                  local_edges=int(ui_l.nnz), scheme=scheme,
-                 chunks=(model.n_chunks(2) if (scheme == "item-side" and not _solo(None)) else 1))
+                 chunks=(model.n_chunks(2) if (scheme in ("item-side", "halo") and not _solo(None)) else 1),
+                 halo=(model.halo if scheme == "halo" else None),
+                 halo_rows_fraction=(round(model.halo.bytes_fraction, 4) if scheme == "halo" else None))
     return step, (ui_l, iu_l), plans, stats

@@ -40,8 +40,11 @@ def main():
     def row_pair(m):
         ui, iu = O.csr_norm(m, True), O.csr_norm(m.T, True)
         return bk.make_graph(md.shard_graph(ui, ush, ish)), bk.make_graph(md.shard_graph(iu, ish, ush))
-    graphs = T._local_pair(md, bk, O, raw, ush, ish, scheme) + row_pair(img_raw) + row_pair(txt_raw)
+    need = []
+    graphs = T._local_pair(md, bk, O, raw, ush, ish, scheme, need) + row_pair(img_raw) + row_pair(txt_raw)
     model = md.ShardedMMSSL(bk, cfg, ush, ish, state, d["image_feat"], d["text_feat"], scheme=scheme, chunks=chunks).to(dev).train()
+    if scheme == "halo":
+        model.halo = md.HaloPlan(need[0], ish, None, bk, dev)
     step = md.ShardedHotPathStep(model, graphs, 48, I, modal_empty=(modal.replace("_drop", "") == "empty_shortcut"),
                                  optimizer=False)
     step.set_batch(torch.stack([users, pos, neg]).to(dev))
@@ -54,7 +57,7 @@ def main():
     assert float(g["txt_w"][:, k_txt:].abs().max()) == 0.0
     g["txt_w"] = g["txt_w"][:, :k_txt]
     torch.save({"loss": float(total), "ush": (ush.lo, ush.hi, ush.n), "ish": (ish.lo, ish.hi, ish.n), "g": g,
-                "chunks": model.n_chunks(2) if scheme == "item-side" else 1}, os.path.join(out_dir, "r%d.pt" % rank))
+                "chunks": model.n_chunks(2) if scheme in ("item-side", "halo") else 1}, os.path.join(out_dir, "r%d.pt" % rank))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -70,12 +73,17 @@ def baby(rank, world, scheme, chunks, out_dir, md, dev):
     ush, ish = md.RowShard(U, world, rank), md.RowShard(I, world, rank)
     bk = md.HipBackend()
     ui_l = md.shard_graph(pb["ui"], ush, ish)
-    iu_l = md.shard_graph_cols(pb["iu"], ish, ush) if scheme == "item-side" else md.shard_graph(pb["iu"], ish, ush)
+    iu_l = md.shard_graph_cols(pb["iu"], ish, ush) if scheme in ("item-side", "halo") else md.shard_graph(pb["iu"], ish, ush)
+    need = None
+    if scheme == "halo":
+        need, ui_l, iu_l = md.halo_graphs(ui_l, iu_l)
     e_ui = bk.make_graph(sp.csr_matrix((ush.per, ish.n_pad), dtype=np.float32))
     e_iu = bk.make_graph(sp.csr_matrix((ish.per, ush.n_pad), dtype=np.float32))
     graphs = (bk.make_graph(ui_l), bk.make_graph(iu_l), e_ui, e_iu, e_ui, e_iu)
     model = md.ShardedMMSSL(bk, pb["cfg"], ush, ish, pb["state"], pb["img"].numpy(), pb["txt"].numpy(), scheme=scheme,
                             chunks=chunks).to(dev).train()
+    if scheme == "halo":
+        model.halo = md.HaloPlan(need, ish, None, bk, dev)
     step = md.ShardedHotPathStep(model, graphs, 1024, I, modal_empty=True, optimizer=False)
     step.keep_masks = tuple(ish.slice_rows(k.to(torch.uint8)).to(dev) for k in pb["km"])
     step.set_batch(pb["batch"].to(dev))
@@ -84,7 +92,8 @@ def baby(rank, world, scheme, chunks, out_dir, md, dev):
     assert model.last_fused
     g = {n: (p.grad.detach().cpu().clone() if p.grad is not None else None) for n, p in model.named_parameters()}
     torch.save({"loss": float(total), "ush": (ush.lo, ush.hi, ush.n), "ish": (ish.lo, ish.hi, ish.n), "g": g,
-                "chunks": model.n_chunks(2) if scheme == "item-side" else 1}, os.path.join(out_dir, "r%d.pt" % rank))
+                "chunks": model.n_chunks(2) if scheme in ("item-side", "halo") else 1,
+                "halo_fraction": (model.halo.bytes_fraction if scheme == "halo" else None)}, os.path.join(out_dir, "r%d.pt" % rank))
     dist.barrier()
     dist.destroy_process_group()
 

@@ -50,7 +50,12 @@ CHUNKS = int(os.environ.get("MMSSL_TEST_CHUNKS", "0"))
 
 
 def _iu_local(md, iu, ish, ush):
-    return md.shard_graph_cols(iu, ish, ush) if SCHEME == "item-side" else md.shard_graph(iu, ish, ush)
+    return md.shard_graph_cols(iu, ish, ush) if SCHEME in ("item-side", "halo") else md.shard_graph(iu, ish, ush)
+
+
+def _halo(md, model, need, ish, bk, dev):
+    if SCHEME == "halo":
+        model.halo = md.HaloPlan(need, ish, None, bk, dev)
 
 
 def _comm_kinds(md, fn):
@@ -75,10 +80,12 @@ def case_g8(out):
         def local_pair(m):
             ui, iu = O.csr_norm(m, True), O.csr_norm(m.T, True)
             return bk.make_graph(md.shard_graph(ui, ush, ish)), bk.make_graph(md.shard_graph(iu, ish, ush))
-        graphs = T._local_pair(md, bk, O, raw, ush, ish, SCHEME) + local_pair(img_raw) + local_pair(txt_raw)
+        need = []
+        graphs = T._local_pair(md, bk, O, raw, ush, ish, SCHEME, need) + local_pair(img_raw) + local_pair(txt_raw)
         d, state, k_txt = T._pad_text_to_slices(d, state)      # whole 32-deep slices: the packed node runs
         model = md.ShardedMMSSL(bk, cfg, ush, ish, state, d["image_feat"], d["text_feat"], scheme=SCHEME,
                                 chunks=CHUNKS).to(dev).train()
+        _halo(md, model, need[0] if need else None, ish, bk, dev)
         step = md.ShardedHotPathStep(model, graphs, 48, I, modal_empty=(modal == "empty_shortcut"), optimizer=False)
         step.set_batch(torch.stack([users, pos, neg]).to(dev))
         ref_loss, P = T._reference(modal)
@@ -116,18 +123,19 @@ def case_g8(out):
         ush, ish = md.RowShard(U, 1, 0), md.RowShard(I, 1, 0)
         bk = md.HipBackend()
         cfg = O.Cfg(drop_rate=0.0, batch_size=48, n_ui_layers=2)
-        graphs = ()
-        for k, m in enumerate((raw, img_raw, txt_raw)):
+        need = []
+        graphs = T._local_pair(md, bk, O, raw, ush, ish, SCHEME, need)
+        for m in (img_raw, txt_raw):
             ui, iu = O.csr_norm(m, True), O.csr_norm(m.T, True)
-            graphs += (bk.make_graph(md.shard_graph(ui, ush, ish)),
-                       bk.make_graph(_iu_local(md, iu, ish, ush) if k == 0 else md.shard_graph(iu, ish, ush)))
+            graphs += (bk.make_graph(md.shard_graph(ui, ush, ish)), bk.make_graph(md.shard_graph(iu, ish, ush)))
         d2, st2, _ = T._pad_text_to_slices(d, state)
         model = md.ShardedMMSSL(bk, cfg, ush, ish, st2, d2["image_feat"], d2["text_feat"], scheme=SCHEME,
                                 chunks=CHUNKS).to(dev).train()
+        _halo(md, model, need[0] if need else None, ish, bk, dev)
         step = md.ShardedHotPathStep(model, graphs, 48, I, lr=1e-2)
         step.set_batch(torch.stack([users, pos, neg]).to(dev))
         snap = [p.detach().clone() for p in model.parameters()]
-        if mode == "graph":
+        if mode == "graph" and SCHEME != "halo":          # (halo: eager only - the second pass repeats the eager trajectory)
             assert step.capture(warmup=2), getattr(step, "capture_error", "")
             with torch.no_grad():
                 for p, q in zip(model.parameters(), snap):
@@ -150,7 +158,7 @@ def _baby_problem(dev, ref=True):
     U, I, E, dv, dt = synth.SHAPES["baby"]
     config.configure([], drop_rate=0.2, batch_size=1024, weight_size=str([64] * 3), debug=True)
     a = types.SimpleNamespace(workload="baby")
-    ui_l, iu_l, ush, ish, U, I, E, dv, dt = md.build_sharded_graph(a, 0, 1, dev, "strong", SCHEME)
+    ui_l, iu_l, ush, ish, U, I, E, dv, dt = md.build_sharded_graph(a, 0, 1, dev, "strong", "item-side" if SCHEME == "halo" else SCHEME)
     g = torch.Generator().manual_seed(0)
     img, txt = torch.randn(I, dv, generator=g), torch.randn(I, dt, generator=g)
     torch.manual_seed(4)
@@ -187,12 +195,16 @@ def case_baby(out):
     dev = torch.device("cuda", 0)
     pb = _baby_problem(dev)
     bk = md.HipBackend()
-    plans = (bk.make_graph(pb["ui"]), bk.make_graph(pb["iu"]), bk.make_graph(pb["e_ui"]), bk.make_graph(pb["e_iu"]))
+    ui_l, iu_l, need = pb["ui"], pb["iu"], None
+    if SCHEME == "halo":
+        need, ui_l, iu_l = md.halo_graphs(ui_l, iu_l)
+    plans = (bk.make_graph(ui_l), bk.make_graph(iu_l), bk.make_graph(pb["e_ui"]), bk.make_graph(pb["e_iu"]))
     graphs = (plans[0], plans[1], plans[2], plans[3], plans[2], plans[3])
     model = md.ShardedMMSSL(bk, pb["cfg"], pb["ush"], pb["ish"], pb["state"], pb["img"].numpy(), pb["txt"].numpy(),
                             scheme=SCHEME, chunks=CHUNKS)
     model = model.to(dev).train()
-    out["baby/chunks"] = model.n_chunks(2) if SCHEME == "item-side" else 1
+    _halo(md, model, need, pb["ish"], bk, dev)
+    out["baby/chunks"] = model.n_chunks(2) if SCHEME in ("item-side", "halo") else 1
     step = md.ShardedHotPathStep(model, graphs, 1024, pb["I"], modal_empty=True, optimizer=False)
     step.keep_masks = tuple(k.to(torch.uint8).to(dev) for k in pb["km"])
     step.set_batch(pb["batch"].to(dev))

@@ -57,11 +57,16 @@ def _global_masks(I, d=64):
     return [(torch.rand(I, d, generator=g) >= 0.2) for _ in range(2)]
 
 
-def _local_pair(md, bk, O, m, ush, ish, scheme="gather-both"):
-    """(A_ui[U_r, :], A_iu[I_r, :]) - or, scheme item-side, (A_ui[U_r, :], A_iu[:, U_r]) - of the raw interactions m."""
+def _local_pair(md, bk, O, m, ush, ish, scheme="gather-both", need_out=None):
+    """(A_ui[U_r, :], A_iu[I_r, :]) - or, scheme item-side, (A_ui[U_r, :], A_iu[:, U_r]); scheme halo: the item-side pair on
+    compact item columns (the referenced item ids are appended to `need_out`) - of the raw interactions m."""
     ui, iu = O.csr_norm(m, True), O.csr_norm(m.T, True)
-    if scheme == "item-side":
-        return bk.make_graph(md.shard_graph(ui, ush, ish)), bk.make_graph(md.shard_graph_cols(iu, ish, ush))
+    if scheme in ("item-side", "halo"):
+        ui_l, iu_l = md.shard_graph(ui, ush, ish), md.shard_graph_cols(iu, ish, ush)
+        if scheme == "halo":
+            need, ui_l, iu_l = md.halo_graphs(ui_l, iu_l)
+            need_out.append(need)
+        return bk.make_graph(ui_l), bk.make_graph(iu_l)
     return bk.make_graph(md.shard_graph(ui, ush, ish)), bk.make_graph(md.shard_graph(iu, ish, ush))
 
 
@@ -83,13 +88,17 @@ def _worker(rank, world, port, modal, out_dir, fused=True, scheme="gather-both",
     def local_pair(m):
         ui, iu = O.csr_norm(m, True), O.csr_norm(m.T, True)
         return bk.make_graph(md.shard_graph(ui, ush, ish)), bk.make_graph(md.shard_graph(iu, ish, ush))
-    ui, iu = _local_pair(md, bk, O, raw, ush, ish, scheme)       # the interaction graph in the scheme's form
+    need = []
+    ui, iu = _local_pair(md, bk, O, raw, ush, ish, scheme, need)   # the interaction graph in the scheme's form
     a, b = local_pair(img_raw)                                   # (the modal id graphs always as row blocks)
     c, e = local_pair(txt_raw)
     model = md.ShardedMMSSL(bk, cfg, ush, ish, state, d["image_feat"], d["text_feat"], scheme=scheme, chunks=chunks).train()
+    if scheme == "halo":
+        model.halo = md.HaloPlan(need[0], ish, None, bk, torch.device("cpu"))
+        assert model.halo.n_need <= ish.n_pad and sum(model.halo.recv_rows) == model.halo.n_need
     step = md.ShardedHotPathStep(model, (ui, iu, a, b, c, e), 48, I, modal_empty=(modal == "empty_shortcut"),
                                  optimizer=False, fused=fused)
-    if scheme == "item-side" and fused and world > 1:
+    if scheme in ("item-side", "halo") and fused and world > 1:
         assert model.n_chunks(2) == max(chunks, 1)
     step.set_batch(users, pos, neg)
     if drop:
@@ -130,7 +139,10 @@ def _reference(modal):
     # last blocks at world 3 (300 users / 200 items are not multiples of 3) and world 8
     (2, "full", True, "item-side", 1), (3, "full", True, "item-side", 2), (3, "full_drop", True, "item-side", 2),
     (2, "empty_shortcut", True, "item-side", 2), (3, "empty", True, "item-side", 1), (3, "full", False, "item-side", 0),
-    (8, "full_drop", True, "item-side", 2)])
+    (8, "full_drop", True, "item-side", 2),
+    # halo scheme: only the item rows a rank's edges reference travel (all-to-all of row lists + selection SpMM)
+    (2, "full", True, "halo", 1), (3, "full_drop", True, "halo", 2), (3, "empty_shortcut", True, "halo", 1),
+    (8, "full_drop", True, "halo", 2)])
 def test_sharded_step_equals_single_process(tmp_path, world, modal, fused, scheme, chunks):
     port = _free_port()
     mp.spawn(_worker, args=(world, port, modal, str(tmp_path), fused, scheme, chunks), nprocs=world, join=True)
@@ -181,8 +193,11 @@ def _traj_worker(rank, world, port, out_dir, steps, scheme="gather-both", chunks
     def local_pair(m):
         ui, iu = O.csr_norm(m, True), O.csr_norm(m.T, True)
         return bk.make_graph(md.shard_graph(ui, ush, ish)), bk.make_graph(md.shard_graph(iu, ish, ush))
-    graphs = _local_pair(md, bk, O, raw, ush, ish, scheme) + local_pair(img_raw) + local_pair(txt_raw)
+    need = []
+    graphs = _local_pair(md, bk, O, raw, ush, ish, scheme, need) + local_pair(img_raw) + local_pair(txt_raw)
     model = md.ShardedMMSSL(bk, cfg, ush, ish, state, d["image_feat"], d["text_feat"], scheme=scheme, chunks=chunks).train()
+    if scheme == "halo":
+        model.halo = md.HaloPlan(need[0], ish, None, bk, torch.device("cpu"))
     step = md.ShardedHotPathStep(model, graphs, 48, I, lr=1e-2)          # CPU: torch.optim.AdamW on the local tensors
     losses = []
     g = torch.Generator().manual_seed(5)
@@ -196,7 +211,8 @@ def _traj_worker(rank, world, port, out_dir, steps, scheme="gather-both", chunks
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,scheme,chunks", [(2, "gather-both", 0), (3, "gather-both", 0), (3, "item-side", 2)])
+@pytest.mark.parametrize("world,scheme,chunks", [(2, "gather-both", 0), (3, "gather-both", 0), (3, "item-side", 2),
+                                                 (3, "halo", 2)])
 def test_sharded_trajectory_equals_single_process_adamw(tmp_path, world, scheme, chunks):
     """Four sharded steps WITH the optimiser (gloo, world 2 / 3): every rank's losses, its rows of the embedding tables and
     the replicated tensors follow the single-process oracle stepped by torch.optim.AdamW on the global problem - the

@@ -707,6 +707,11 @@ def run_sharded_main(a, rank, world, dev):
             torch.cuda.synchronize()
             ok = bool(torch.isfinite(step.loss).item())
         dist.barrier()
+        # the captured graph goes first: destroying the process group while a live hipGraph still holds its all-to-all
+        # (send / recv) nodes hangs inside RCCL (seen with the halo scheme)
+        del step
+        gc.collect()
+        torch.cuda.synchronize()
         dist.destroy_process_group()
         sys.exit(0 if ok else 3)
     want = a.dist_graph != "off" and not a.no_graph
@@ -733,8 +738,9 @@ def run_sharded_main(a, rank, world, dev):
     # N > 1: the shape on which north_star's >= 6x is arithmetically possible, in the same run - configs[4]'s per-rank
     # share x N (250 K users x 125 K items x 12.5 M edges per rank, d = 128), a few steps, next to the committed one-rank
     # figure of the same share (its ratio = the weak-scaling efficiency on that shape)
+    r2 = None
     if world > 1 and a.workload != "synth" and not a.no_stress:
-        del r
+        r = None
         gc.collect()
         torch.cuda.empty_cache()
         a2 = copy.copy(a)
@@ -757,8 +763,11 @@ def run_sharded_main(a, rank, world, dev):
         if rank == 0:
             out["scaling_stress"] = rec
     if rank == 0:
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     dist.barrier()
+    r = r2 = None                     # (captured graphs before the process group: see the probe branch)
+    gc.collect()
+    torch.cuda.synchronize()
     dist.destroy_process_group()
 
 

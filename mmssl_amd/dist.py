@@ -507,6 +507,8 @@ class ShardedMMSSL(nn.Module):
                 2, scale, keep, ui, iu, c.n_ui_layers, c.model_cat_rate, bk, self.group, self.n_chunks(2), xch, u, i,
                 self.image_feats, self.text_feats, self.img_w, self.txt_w, self.img_b, self.txt_b)
         else:       # (one rank without forced collectives: both schemes are the same computation)
+            if getattr(self, "scheme", "") == "halo" and ui.shape[1] != self.ish.n_pad:
+                raise RuntimeError("scheme 'halo' on one rank without collectives: pass the item-side graphs (full item columns)")
             u_g, i_g, ss, MI, MU = _ShardedHotForward.apply(
                 2, scale, keep, ui, iu, c.n_ui_layers, c.model_cat_rate, bk, self.group, u, i,
                 self.image_feats, self.text_feats, self.img_w, self.txt_w, self.img_b, self.txt_b)
@@ -903,14 +905,18 @@ class _Lanes:
     c+1's collective is on the links. Lanes meet only where a row is needed whole (the last layer's softmax) and at the
     end. On CPU (gloo tests) and for nc == 1 the lanes are plain loops."""
 
-    def __init__(self, bk, ref, n, base=0, first_is_current=False):
+    def __init__(self, bk, ref, n, base=0, first_is_current=False, one_stream=False, via_main=False):
+        """one_stream: all n lanes share ONE forked stream (chunks run one after the other there). via_main: a lane's plain
+        collectives are issued from the origin stream (see coll)."""
         self.n = int(n)
         self.cuda = bool(ref.is_cuda and hasattr(bk, "lane_streams"))
         self.main, self.streams = None, [None] * self.n
+        self.via_main = bool(via_main)
         if self.cuda:
             self.main = torch.cuda.current_stream(ref.device)
             pool = bk.lane_streams(ref.device, base + self.n)
-            self.streams = [self.main if (first_is_current and c == 0) else pool[base + c] for c in range(self.n)]
+            self.streams = [self.main if (first_is_current and c == 0) else pool[base + (0 if one_stream else c)]
+                            for c in range(self.n)]
 
     def on(self, c):
         import contextlib
@@ -928,8 +934,17 @@ class _Lanes:
                 if st is not self.main:
                     self.main.wait_stream(st)
 
-    def coll(self, c, fn):
-        """One plain collective of lane c, issued on the lane."""
+    def coll(self, c, fn, reads=()):
+        """One plain collective of lane c (`reads`: lane-allocated tensors it consumes): issued on the lane, or - via_main -
+        from the origin stream with the lane waiting for ITS event (exchanges that cannot be captured on a forked stream)."""
+        if self.cuda and self.via_main and self.streams[c] is not self.main:
+            self.to_main(c)
+            for t in reads:
+                t.record_stream(self.main)
+            out = fn()
+            self.after(c, self.mark())
+            self.uses(out, [c])
+            return out
         with self.on(c):
             return fn()
 
@@ -949,7 +964,7 @@ class _Lanes:
         """Lane 0 waits for all lanes (then runs the whole-row kernel); `part` lets the others continue behind it. Side
         lanes synchronise THROUGH the origin stream: a direct wait between two forked streams of a hipGraph capture
         crashes hipStreamEndCapture (ROCm 7.2; bisected on the GPU, tools/README.md)."""
-        if not self.cuda or self.n == 1:
+        if not self.cuda or self.n == 1 or all(st is self.streams[0] for st in self.streams):
             return
         if self.streams[0] is self.main:
             for st in self.streams[1:]:
@@ -960,7 +975,7 @@ class _Lanes:
         self.streams[0].wait_stream(self.main)
 
     def part(self):
-        if not self.cuda or self.n == 1:
+        if not self.cuda or self.n == 1 or all(st is self.streams[0] for st in self.streams):
             return
         if self.streams[0] is not self.main:
             self.main.wait_stream(self.streams[0])
@@ -1113,8 +1128,12 @@ class _ShardedItemSide(torch.autograd.Function):
             xch = _TableExchange(g, per_i)
         twin = (lambda p, k: p.twin(k)) if hasattr(ui, "twin") else (lambda p, k: p)
         new = lambda rows, w: torch.empty((rows, w), dtype=torch.float32, device=u0.device)      # noqa: E731
-        G = _Lanes(bk, u0, nc)                                    # GCN chain: nc side lanes
-        M = _Lanes(bk, u0, nc, base=nc, first_is_current=True)    # modal chain: the current stream + nc - 1 lanes
+        # item-side: the projection / modal chain (the critical one) on the current stream + nc - 1 lanes, the GCN chain on nc
+        # side lanes. halo: its exchanges are all-to-alls, which a capture only takes from the ORIGIN stream - so there the
+        # GCN chain (lane 0) and every exchange live on the current stream and the modal chain on ONE forked stream.
+        swap = isinstance(xch, HaloPlan)
+        G = _Lanes(bk, u0, nc, first_is_current=swap, via_main=swap)
+        M = _Lanes(bk, u0, nc, base=nc, first_is_current=not swap, one_stream=swap)
         # Every table the LANES write is allocated here, on the origin stream BEFORE the fork: the caching allocator may hand
         # out a block whose last user is an earlier kernel of the allocating stream, which is only safe for writers ordered
         # behind that stream's work at allocation time - the lanes are, through the fork, and only then (a table allocated
@@ -1122,8 +1141,14 @@ class _ShardedItemSide(torch.autograd.Function):
         u_new = [new(per_u, d) for _ in range(n_layers)]
         MU = new(per_u, wm)
         G.fork()
-        X, keep = bk.proj_forward(list(Fs), list(Ws), list(bs), keep, scale, draw_p, ext_tick)      # [per_i, nm d], current stream
-        M.fork()
+        if swap:
+            M.fork()
+        with M.on(0):
+            X, keep = bk.proj_forward(list(Fs), list(Ws), list(bs), keep, scale, draw_p, ext_tick)      # [per_i, nm d]
+        if not swap:
+            M.fork()
+        elif G.cuda:
+            X.record_stream(G.main)
         for t_ in [MU, X] + u_new:
             M.uses(t_)
             G.uses(t_)
@@ -1164,7 +1189,7 @@ class _ShardedItemSide(torch.autograd.Function):
                 del fulls
             else:
                 for c in range(nc):             # item rows -> user rows: gather, product into the lane's column chunk
-                    i_full = G.coll(c, lambda: xch.gather(i_c[c]))
+                    i_full = G.coll(c, lambda: xch.gather(i_c[c]), reads=(i_c[c],))
                     with G.on(c):
                         bk.spmm_raw(twin(ui, 2 + c), False, i_full, bk.EPI_NONE, out=u_v[c])
             if last:
@@ -1200,7 +1225,7 @@ class _ShardedItemSide(torch.autograd.Function):
                 for c in range(nc):
                     with G.on(c):
                         P = bk.spmm_raw(twin(iuT, 2 + c), False, u_v[c], bk.EPI_NONE)
-                    i_n[c] = G.coll(c, lambda: xch.reduce(P))
+                    i_n[c] = G.coll(c, lambda: xch.reduce(P), reads=(P,))
             if nc > 1 or last:
                 G.meet()
             with G.on(0):
@@ -1211,7 +1236,8 @@ class _ShardedItemSide(torch.autograd.Function):
             us.append(u)
             its.append(i)
         M.meet()
-        MI = torch.cat(MI_c, 1) if nc > 1 else MI_c[0]
+        with M.on(0):
+            MI = torch.cat(MI_c, 1) if nc > 1 else MI_c[0]
         M.join()
         G.join()
         if G.cuda:
@@ -1238,8 +1264,9 @@ class _ShardedItemSide(torch.autograd.Function):
         G_MU = G_MU.contiguous() if G_MU is not None else None
         twin = (lambda p, k: p.twin(k)) if hasattr(ui, "twin") else (lambda p, k: p)
         new = lambda rows, w: torch.empty((rows, w), dtype=torch.float32, device=Gu.device)      # noqa: E731
-        G = _Lanes(bk, Gu, nc)
-        M = _Lanes(bk, Gu, nc, base=nc, first_is_current=True)
+        swap = isinstance(xch, HaloPlan)           # (see forward)
+        G = _Lanes(bk, Gu, nc, first_is_current=swap, via_main=swap)
+        M = _Lanes(bk, Gu, nc, base=nc, first_is_current=not swap, one_stream=swap)
         gu_new = [new(per_u, d) for _ in range(n_layers)]          # allocated before the fork: see forward
         t = new(per_u, wm)
         G.fork()
@@ -1285,7 +1312,7 @@ class _ShardedItemSide(torch.autograd.Function):
                 del fulls
             else:
                 for c in range(nc):
-                    gP = G.coll(c, lambda: xch.gather(gi_c[c]))
+                    gP = G.coll(c, lambda: xch.gather(gi_c[c]), reads=(gi_c[c],))
                     with G.on(c):
                         bk.spmm_raw(twin(iuT, 2 + c), True, gP, bk.EPI_AXPY, Gu_v[c], inv, out=gu_v[c])
             if first:
@@ -1326,17 +1353,21 @@ class _ShardedItemSide(torch.autograd.Function):
                 for c in range(nc):
                     with G.on(c):
                         part_g = bk.spmm_raw(twin(ui, 2 + c), True, gu_v[c], bk.EPI_NONE)
-                    rs = G.coll(c, lambda: xch.reduce(part_g))
+                    rs = G.coll(c, lambda: xch.reduce(part_g), reads=(part_g,))
                     with G.on(c):
                         gi_n[c] = rs.add_(Gi_v[c], alpha=inv)
             gi_c = gi_n
             if first:
-                # ---- the weight gradient (current stream) next to the rest of the GCN chain
+                # ---- the weight gradient (the modal chain's stream) next to the rest of the GCN chain
                 M.meet()
-                gX = torch.cat(gX_c, 1) if nc > 1 else gX_c[0]
-                if keep is not None:
-                    gX = bk.mask_packed(gX, keep, d, scale)
-                gW, gb = bk.proj_wgrad(gX, list(Fs), any(has_b))
+                with M.on(0):
+                    gX = torch.cat(gX_c, 1) if nc > 1 else gX_c[0]
+                    if keep is not None:
+                        gX = bk.mask_packed(gX, keep, d, scale)
+                    gW, gb = bk.proj_wgrad(gX, list(Fs), any(has_b))
+                if swap and G.cuda:
+                    for t_ in list(gW) + [x for x in (gb or []) if x is not None]:
+                        t_.record_stream(G.main)
         G.meet()
         with G.on(0):
             gi0 = torch.cat(gi_c, 1) if nc > 1 else gi_c[0]
@@ -1560,13 +1591,6 @@ class ShardedHotPathStep:
     def capture(self, warmup=3):
         """OPT-IN: capture the whole sharded step, RCCL collectives included, into a hipGraph (all on
         this object's stream). Returns False and stays eager if the runtime refuses."""
-        if getattr(self.model, "scheme", "") == "halo" and not _solo(self.group):
-            # the halo exchanges are all-to-alls (grouped send / recv) issued on the forked lane streams: capturing them
-            # ends in a crash inside hipStreamEndCapture on ROCm 7.2 for the 3-layer step (not for the 2-layer one; the
-            # grouped pairs of the item-side scheme had the same problem and moved to the origin stream, which here would
-            # put every exchange behind the projection GEMM). The halo step runs eagerly.
-            self._graph, self.capture_error = None, "halo scheme: eager only (all-to-all on forked streams is not capturable)"
-            return False
         try:
             with torch.cuda.stream(self.stream):
                 for _ in range(warmup):
@@ -1748,6 +1772,8 @@ def build_bench_step(a, rank, world, dev, scaling="weak"):
     from .config import configure, HotCfg
     configure([], embed_size=a.d, weight_size=str([a.d] * a.gcn_layers), batch_size=a.batch, drop_rate=0.2)
     scheme = getattr(a, "scheme", "item-side")
+    if scheme == "halo" and _solo(None):
+        scheme = "item-side"        # one rank, nothing exchanged: the compact item columns would only renumber the table
     ui_l, iu_l, ush, ish, U, I, E_global, dv, dt = build_sharded_graph(a, rank, world, dev, scaling,
                                                                      "item-side" if scheme == "halo" else scheme)
     bk = HipBackend()

@@ -135,7 +135,7 @@ def case_g8(out):
         step = md.ShardedHotPathStep(model, graphs, 48, I, lr=1e-2)
         step.set_batch(torch.stack([users, pos, neg]).to(dev))
         snap = [p.detach().clone() for p in model.parameters()]
-        if mode == "graph" and SCHEME != "halo":          # (halo: eager only - the second pass repeats the eager trajectory)
+        if mode == "graph":
             assert step.capture(warmup=2), getattr(step, "capture_error", "")
             with torch.no_grad():
                 for p, q in zip(model.parameters(), snap):

@@ -54,8 +54,8 @@ def test_g8_sharded_step_with_real_rccl_collectives_eager_and_captured(tmp_path,
             assert kinds == {"all_gather": extra, "reduce_scatter": extra, "all_reduce": 2}, kinds
         else:
             assert kinds == {"all_gather": 4 * nc + extra, "reduce_scatter": 4 * nc + extra, "all_reduce": 2}, kinds
-        assert rec["g8/%s/captured" % modal] == (scheme != "halo"), rec.get("g8/%s/capture_error" % modal)     # halo: eager only
-        for tag in (("eager", "replay") if scheme != "halo" else ("eager",)):
+        assert rec["g8/%s/captured" % modal], rec.get("g8/%s/capture_error" % modal)
+        for tag in ("eager", "replay"):
             r = rec["g8/%s/%s" % (modal, tag)]
             assert r.pop("loss_rel") <= 2e-5, (modal, tag)
             for k, v in r.items():
@@ -76,8 +76,8 @@ def test_baby_strong_shape_sharded_step_with_real_rccl_matches_oracle(tmp_path, 
         assert kinds == {"all_gather": 0, "reduce_scatter": 0, "all_reduce": 2}, kinds
     else:
         assert kinds == {"all_gather": 6 * nc, "reduce_scatter": 6 * nc, "all_reduce": 2}, kinds      # 14 launches per step whole
-    assert rec["baby/captured"] == (scheme != "halo"), rec.get("baby/capture_error")
-    for tag in (("eager", "replay") if scheme != "halo" else ("eager",)):
+    assert rec["baby/captured"], rec.get("baby/capture_error")
+    for tag in ("eager", "replay"):
         r = rec["baby/" + tag]
         assert r["loss_rel"] <= 1e-4, (tag, r)                               # north_star bar
         for k in ("img_w", "img_b", "txt_w", "txt_b", "E_u", "E_i"):

@@ -10,7 +10,7 @@ packed modal chain of one step (forward gathers + backward reduce-scatters move 
                    item-table size (its adjoint a gather of item-table size): every collective moves item-table bytes; with
                    --chunks c every collective and the products around it are cut into c column chunks on c lanes, so
                    that a chunk's product runs under the next chunk's transfer
-  halo             (built, round 4: --scheme halo, eager only) item-collectives moving only the item rows a rank's edges
+  halo             (built, round 4: --scheme halo) item-collectives moving only the item rows a rank's edges
                    reference: x 0.92 / 0.76 / 0.56 of the bytes for the Baby-shaped weak-scaling graph at N = 2 / 4 / 8 (measured
                    fractions of referenced rows), x 0.98 for configs[4]
   2-D (R x C)      (not built) ranks in an R x C grid, A cut in both directions: a gather inside a column group and a

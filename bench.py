@@ -474,6 +474,8 @@ def main():
     ap.add_argument("--gcn-layers", type=int, default=3, dest="gcn_layers")
     ap.add_argument("--batch", type=int, default=1024)
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
+    ap.add_argument("--stress-timeout", type=int, default=300,
+                    help="N > 1: seconds the scaling_stress run may take before the line is printed without it")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="N>1: weak = shape x N (per-rank work fixed); strong = the shape itself cut N ways")
@@ -692,6 +694,24 @@ def committed_rank_figure():
     return None
 
 
+def stress_watchdog(limit_s, out, rank):
+    """The N > 1 line must survive a scaling_stress run that HANGS (a collective some rank never joins cannot be caught
+    as an exception): after `limit_s` seconds rank 0 prints the headline line with the time-out noted and every rank
+    leaves with rc 0. Returns the started timer; cancel() it when the stress run is over."""
+    import threading
+
+    def fire():
+        if rank == 0:
+            out["scaling_stress"] = {"error": "timed out after %d s (run abandoned; the headline figures above were "
+                                              "complete before it started)" % limit_s}
+            print(json.dumps(out), flush=True)
+        os._exit(0)
+    t = threading.Timer(limit_s, fire)
+    t.daemon = True
+    t.start()
+    return t
+
+
 def run_sharded_main(a, rank, world, dev):
     import copy
     import gc
@@ -745,6 +765,7 @@ def run_sharded_main(a, rank, world, dev):
         torch.cuda.empty_cache()
         a2 = copy.copy(a)
         a2.workload, a2.d, a2.steps, a2.warmup = "synth", 128, min(a.steps, 10), min(a.warmup, 3)
+        dog = stress_watchdog(a.stress_timeout, out, rank)
         try:
             r2 = timed_sharded(a2, rank, world, dev, "weak", want)
             st2 = r2["stats"]
@@ -760,6 +781,7 @@ def run_sharded_main(a, rank, world, dev):
                 rec["speedup_vs_one_rank"] = round(rec["edge_layers_per_s"] / ref["edge_layers_per_s"], 3)
         except Exception as e:       # the headline line must survive a failing stress run
             rec = {"error": repr(e)[:400]}
+        dog.cancel()
         if rank == 0:
             out["scaling_stress"] = rec
     if rank == 0:

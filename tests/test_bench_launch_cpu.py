@@ -42,3 +42,25 @@ def test_bench_under_the_drivers_launcher_and_world_mismatch():
     r = subprocess.run(base + ["--gpus", "4", "--launch-check", "--backend", "gloo"], capture_output=True, text=True,
                        timeout=300, cwd=ROOT)
     assert r.returncode != 0 and not _json_lines(r.stdout)
+
+
+def test_stress_watchdog_prints_the_headline_line_and_leaves_cleanly():
+    """A scaling_stress run that hangs (a collective one rank never joins) must not cost the N > 1 line: after the limit rank
+    0 prints the headline with the time-out recorded and every rank exits 0."""
+    code = ("import sys, time; sys.path.insert(0, %r); import bench\n"
+            "out = {'metric': 'm', 'value': 1.0}\n"
+            "bench.stress_watchdog(1, out, int(sys.argv[1]))\n"
+            "time.sleep(60)\nprint('not reached'); sys.exit(5)\n" % ROOT)
+    for rank in (0, 1):
+        r = subprocess.run([sys.executable, "-c", code, str(rank)], capture_output=True, text=True, timeout=120, cwd=ROOT)
+        assert r.returncode == 0 and "not reached" not in r.stdout, (r.returncode, r.stdout, r.stderr[-500:])
+        recs = _json_lines(r.stdout)
+        if rank == 0:
+            assert len(recs) == 1 and recs[0]["value"] == 1.0 and "timed out" in recs[0]["scaling_stress"]["error"]
+        else:
+            assert recs == []
+    # cancelled in time: nothing happens
+    code2 = ("import sys, time; sys.path.insert(0, %r); import bench\n"
+             "t = bench.stress_watchdog(1, {}, 0); t.cancel(); time.sleep(2); print('alive')\n" % ROOT)
+    r = subprocess.run([sys.executable, "-c", code2], capture_output=True, text=True, timeout=120, cwd=ROOT)
+    assert r.returncode == 0 and r.stdout.strip() == "alive"

@@ -139,7 +139,9 @@ def spmm_roofline(plans, mats, d, iters=200, traffic=True):
     rec = {"bound": "hbm", "kernel": "spmm_kernel<16> (CSR SpMM d=%d)" % d, "achieved": round(achieved, 1),
            "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
            "avg_launch_us": round(avg_us, 2), "algorithmic_bytes_per_launch": int(avg_bytes),
-           "traffic": load_traffic() if traffic else None}
+           "traffic": load_traffic() if traffic else None,
+           "traffic_source": ("profiles/%s (rocprofv3 --pmc pass, FETCH_SIZE x 2 + WRITE_SIZE, gfx950-calibrated; a committed "
+                              "constant, not measured in this run)" % TRAFFIC_FILE[0]) if traffic and TRAFFIC_FILE[0] else None}
     if rec["frac"] > 1.0:
         rec["note"] = ("algorithmic bytes count every gathered row once per edge; here the gathered table fits the 256 MB "
                        "Infinity Cache, so most of those bytes never reach HBM and the ratio to the HBM peak exceeds 1")
@@ -257,12 +259,21 @@ def spmm_hbm_record(iters=20):
         except Exception:
             pmc = None
     out = {"what": "configs[4] rank shape, d=128: A_ui[U_r,:] 250000 x 1000000, 12.5M edges; gathered table 512 MB (HBM resident)",
-           "random_gather_ceiling_GBps": 4400.0}
+           "random_gather_ceiling_GBps": 4400.0,
+           "traffic_source": "profiles/r04_spmm_hbm_pmc.json (rocprofv3 --pmc pass of tools/spmm_hbm_pmc.py; not measured in this run)"
+                             if pmc else None}
+    rng = np.random.default_rng(0)
     with torch.no_grad():
         for name, tr, Xin, m in (("forward", False, X, ui_r), ("transpose", True, G, ui_r.T.tocsr())):
             for _ in range(3):
-                ops.spmm(P, Xin, transpose=tr)
+                Yd = ops.spmm(P, Xin, transpose=tr)
             torch.cuda.synchronize()
+            # the launch that is timed below, checked: 2048 sampled output rows (+ the 8 longest) against a float64 CPU product
+            rows = np.unique(np.concatenate([rng.choice(m.shape[0], 2048, replace=False), np.argsort(np.diff(m.indptr))[-8:]]))
+            ref = np.asarray(m[rows].astype(np.float64) @ Xin.double().cpu().numpy())
+            got = Yd[torch.from_numpy(rows).cuda()].double().cpu().numpy()
+            rows_err = float(np.abs(got - ref).max() / np.abs(ref).max())
+            del Yd
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(iters):
@@ -271,9 +282,14 @@ def spmm_hbm_record(iters=20):
             torch.cuda.synchronize()
             us = e0.elapsed_time(e1) * 1e3 / iters
             by = synth.spmm_bytes(m, d)
-            rec = {"us": round(us, 1), "algorithmic_bytes": int(by), "algorithmic_GBps": round(by / us * 1e-3, 1),
-                   "frac_hbm_algorithmic": round(by / us * 1e-3 / HBM_PEAK_GBPS, 4),
+            # (algorithmic bytes count a gathered row once per EDGE: with the table partly cached their rate can exceed the
+            # HBM peak - `algorithmic_over_peak` is a ratio of the byte model, not a roofline fraction; the fabric figures are)
+            rec = {"us": round(us, 1), "rows_vs_cpu": float("%.3g" % rows_err), "rows_checked": int(rows.shape[0]),
+                   "algorithmic_bytes": int(by), "algorithmic_GBps": round(by / us * 1e-3, 1),
+                   "algorithmic_over_peak": round(by / us * 1e-3 / HBM_PEAK_GBPS, 4),
                    "edge_layers_per_s": round(m.nnz / us * 1e6, 1)}
+            if rows_err > 5e-6:
+                rec["rows_check_failed"] = True
             t = (pmc or {}).get(name)
             if t and t.get("fabric_bytes"):
                 rec["traffic"] = int(t["fabric_bytes"])
@@ -308,13 +324,18 @@ def first_step_loss(a, step, raw, batch):
                  "batch": (users, pos, neg)}
 
 
+TRAFFIC_FILE = [None]
+
+
 def load_traffic():
     """HBM bytes per SpMM launch from the committed rocprofv3 PMC pass (profiles/*_pmc.json), if any."""
-    for name in ("r04_spmm_pmc.json", "r03_spmm_pmc.json"):
+    for name in ("r05_spmm_pmc.json", "r04_spmm_pmc.json", "r03_spmm_pmc.json"):
         p = os.path.join(ROOT, "profiles", name)
         if os.path.exists(p):
             try:
-                return json.load(open(p)).get("hbm_bytes_per_launch")
+                v = json.load(open(p)).get("hbm_bytes_per_launch")
+                TRAFFIC_FILE[0] = name
+                return v
             except Exception:
                 continue
     return None
@@ -517,7 +538,7 @@ def main():
                     help="sharded step: column chunks per collective (chunk c's SpMM runs under chunk c+1's collective); "
                          "0 = by size (1 below 64 MB per collective, else 2-4)")
     a = ap.parse_args()
-    if a.workload == "synth" and a.d == 64:
+    if a.workload in ("synth", "synth-full") and a.d == 64:
         a.d = 128                      # configs[4] is defined at d=128
     if "WORLD_SIZE" not in os.environ and a.gpus > 1:
         sys.exit(self_launch(a.gpus))
@@ -535,7 +556,7 @@ def main():
         a.dist_graph, a.backend = "off", "gloo"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    sharded = world > 1 or a.force_dist or a.workload == "synth" or a.dist_graph_probe
+    sharded = world > 1 or a.force_dist or a.workload in ("synth", "synth-full") or a.dist_graph_probe
     if sharded:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if world == 1:
@@ -694,6 +715,18 @@ def committed_rank_figure():
     return None
 
 
+def committed_full_n1_figure():
+    """ms/step of configs[4] WHOLE (2M x 1M x 100M edges, d = 128) on ONE GPU (`--workload synth-full`), from the committed
+    run: the denominator of north_star's ">= 6x 1 -> 8" on the shape where that is arithmetically possible."""
+    p = os.path.join(ROOT, "profiles", "r05_bench_synth_full_n1.json")
+    try:
+        with open(p) as f:
+            d = json.loads([ln for ln in f.read().splitlines() if ln.startswith("{")][0])
+        return {"file": "profiles/r05_bench_synth_full_n1.json", "ms_per_step": d["ms_per_step"], "edge_layers_per_s": d["value"]}
+    except Exception:
+        return None
+
+
 def stress_watchdog(limit_s, out, rank):
     """The N > 1 line must survive a scaling_stress run that HANGS (a collective some rank never joins cannot be caught
     as an exception): after `limit_s` seconds rank 0 prints the headline line with the time-out noted and every rank
@@ -717,7 +750,7 @@ def run_sharded_main(a, rank, world, dev):
     import gc
     import torch.distributed as dist
     from mmssl_amd import dist as mdist
-    scaling = "weak" if a.workload == "synth" else a.scaling
+    scaling = "weak" if a.workload in ("synth", "synth-full") else a.scaling
     if a.dist_graph_probe:       # child of one rank: sharded capture + replay on a small shape
         step, _, _, _ = mdist.build_bench_step(a, rank, world, dev, scaling)
         ok = step.capture()
@@ -755,11 +788,15 @@ def run_sharded_main(a, rank, world, dev):
     if rank == 0:
         out["roofline"] = spmm_roofline(r["plans"], r["mats"], a.d, traffic=False)   # rank 0's shard
         out["comm"] = r["comm"]
+        full = committed_full_n1_figure()
+        if a.workload == "synth" and world == 8 and full:      # this job IS configs[4]: strong ratio to the same graph on one GPU
+            out["full_n1"] = full
+            out["strong_vs_full_n1"] = round(full["ms_per_step"] / r["ms"], 3)
     # N > 1: the shape on which north_star's >= 6x is arithmetically possible, in the same run - configs[4]'s per-rank
     # share x N (250 K users x 125 K items x 12.5 M edges per rank, d = 128), a few steps, next to the committed one-rank
     # figure of the same share (its ratio = the weak-scaling efficiency on that shape)
     r2 = None
-    if world > 1 and a.workload != "synth" and not a.no_stress:
+    if world > 1 and a.workload not in ("synth", "synth-full") and not a.no_stress:
         r = None
         gc.collect()
         torch.cuda.empty_cache()
@@ -775,10 +812,14 @@ def run_sharded_main(a, rank, world, dev):
                    "launch": "hipGraph replay" if r2["captured"] else "eager", "comm": r2["comm"],
                    "final_loss": round(r2["loss"], 6)}
             ref = committed_rank_figure()
-            if ref:
+            if ref:           # WEAK: one rank's share alone (its item table 1/8 of the job's) vs the same share inside the job
                 rec["one_rank"] = ref
                 rec["per_rank_ratio"] = round(rec["edge_layers_per_s"] / world / ref["edge_layers_per_s"], 4)
                 rec["speedup_vs_one_rank"] = round(rec["edge_layers_per_s"] / ref["edge_layers_per_s"], 3)
+            full = committed_full_n1_figure()
+            if full and world == 8:   # STRONG: the 8-rank job IS configs[4]; the same 2M x 1M x 100M graph on ONE GPU
+                rec["full_n1"] = full
+                rec["strong_vs_full_n1"] = round(full["ms_per_step"] / rec["ms_per_step"], 3)
         except Exception as e:       # the headline line must survive a failing stress run
             rec = {"error": repr(e)[:400]}
         dog.cancel()

@@ -373,6 +373,37 @@ int mmssl_proj_wgrad_adamw_f32(int n_prob, const float* G, int64_t ldg, const fl
                                float* const* vW, float* const* b, float* const* mb, float* const* vb,
                                const float* state, float lr, float beta1, float beta2, float eps, float weight_decay,
                                int pre_ticked, void* workspace, size_t workspace_bytes, void* stream);
+/* ------------------------------------------------------------------------------------
+ * The same grouped projection in SPLIT PRECISION on the bf16 matrix pipe (csrc/projection.hip, "projx"): every fp32 operand
+ * value is cut exactly into three bf16 pieces and a product is evaluated as its six partial products of weight >= 2^-16
+ * (v_mfma_f32_32x32x16_bf16, fp32 accumulation): per product the dropped terms are <= 2^-23 relative - one fp32 rounding -
+ * so the results are fp32-accurate (tests pin the error against float64 at or below the fp32-MFMA kernels' and torch's fp32
+ * GEMM), at 6/16 of the fp32-MFMA issue time: the launch is bound by the feature stream (HBM) instead of the matrix pipe.
+ * Same call sites as above (Models.py:28-29, 54, 173-174), same epilogues, same determinism. Differences at the boundary:
+ *   - the constant feature matrices (Models.py:46-47) are passed as TILE-MAJOR IMAGES made once by mmssl_projx_pack_f32:
+ *     `Fimg[g]` = image of F_g [M, K_g] for the forward, `FTimg[g]` = image of F_g^T [K_g, M] (transpose = 1) for the weight
+ *     gradient; an image holds mmssl_projx_image_floats(rows, red) floats (rows x red zero-padded to 256 x 32 blocks, each
+ *     block contiguous and laid out as the kernel's LDS stage, so every LDS-DMA instruction streams one contiguous KB);
+ *   - K_g % 4 == 0 both ways (zero padding replaces the forward's K_g % 32 requirement);
+ *   - workspace: mmssl_projx_workspace_bytes (256-byte aligned pointer): partial slots + the per-launch bf16 operand planes
+ *     of W (forward) or of G^T (weight gradient, which also yields the bias-gradient sums).
+ * ---------------------------------------------------------------------------------- */
+int mmssl_projx_supported(int n_prob, const int* K, int64_t M, int N);
+size_t mmssl_projx_image_floats(int64_t rows, int64_t red);
+int mmssl_projx_pack_f32(const float* F, int64_t M, int64_t K, int64_t ldf, int transpose, float* out, void* stream);
+size_t mmssl_projx_workspace_bytes(int n_prob, const int* K, int64_t M, int N, int wgrad);
+int mmssl_projx_fwd_f32(int n_prob, const float* const* Fimg, const float* const* W, const float* const* bias,
+                        const int* K, int64_t M, int N, const uint8_t* keep, uint8_t* keep_out,
+                        const uint64_t* rng_state, float p_drop, float scale, float* Y, int64_t ldy,
+                        void* workspace, size_t workspace_bytes, void* stream);
+int mmssl_projx_wgrad_f32(int n_prob, const float* G, int64_t ldg, const float* const* FTimg, const int* K, int64_t M,
+                          int N, float* const* gW, float* const* gb, void* workspace, size_t workspace_bytes,
+                          void* stream);
+int mmssl_projx_wgrad_adamw_f32(int n_prob, const float* G, int64_t ldg, const float* const* FTimg, const int* K, int64_t M,
+                                int N, float* const* gW, float* const* gb, float* const* W, float* const* mW,
+                                float* const* vW, float* const* b, float* const* mb, float* const* vb,
+                                const float* state, float lr, float beta1, float beta2, float eps, float weight_decay,
+                                int pre_ticked, void* workspace, size_t workspace_bytes, void* stream);
 size_t mmssl_linear_wgrad_workspace_bytes(int64_t M, int K, int N);
 /* 1 when mmssl_linear_wgrad_f32 will run this shape on the register-direct kernel, which applies keep/scale and
  * sums the bias gradient on the fragments it loads (pass `keep`; no separate dropout-backward pass is needed);

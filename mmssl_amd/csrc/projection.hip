@@ -652,6 +652,323 @@ __global__ __launch_bounds__(kThreads) void proj_wgrad_reduce_kernel(Group P, in
 }
 
 // =====================================================================================================================
+// SPLIT-PRECISION grouped projection ("projx"): the same stream-K launch structure on the bf16 matrix pipe
+// =====================================================================================================================
+// fp32 MFMA runs at the fp32 VECTOR rate (157 TFLOP/s, 1/16 of the bf16 pipe): at 12 GFLOP per direction the kernels above
+// are matrix-pipe bound (88 us of MFMA issue alone) with a 387 MB feature stream (62-80 us) that only partly hides under it.
+// Here every fp32 operand value is cut EXACTLY into three bf16 pieces (a = hi + mid + lo: three truncations of 8 significant
+// bits each cover fp32's 24) and a product a.b is evaluated as the six partial products of weight >= 2^-16
+//     hi.hi + (hi.mid + mid.hi) + (hi.lo + lo.hi + mid.mid)
+// on v_mfma_f32_32x32x16_bf16 with fp32 accumulation: each partial product is exact in fp32 (8 x 8 significant bits), the
+// three dropped ones (mid.lo, lo.mid, lo.lo) are <= 2^-23 of |a.b| - the size of ONE fp32 rounding of that product, which
+// the fp32 kernels above commit as well. tests/test_proj_gpu.py pins it: against a float64 product the error of this path
+// is not above that of the fp32-MFMA kernels (nor of torch's fp32 GEMM). Six bf16 MFMAs cost 6/16 of one fp32 MFMA per
+// flop, so the matrix pipe is ~35 % busy and the launch is bound by the feature stream: HBM, where it belongs
+// (SURVEY 7.2-8 allows exactly this: "no bf16 in the projection unless split-precision").
+//
+// Operands:
+//   long operand  A [rows, red] fp32 in a TILE-MAJOR image made once (the features are constants, Models.py:46-47;
+//                 mmssl_projx_pack_f32): the 256 x 32 slice (tile t, slice s) is one contiguous 32 KB block that IS the LDS
+//                 stage image (row r = 128 B, 16-byte chunk c stored at position c ^ ((r >> 1) & 7)), so every LDS-DMA
+//                 instruction of a wave streams one contiguous KB. Forward: A = F_g [M, K_g]; weight gradient: A = F_g^T
+//                 [K_g, M] (a second packed copy: +1 x the feature bytes of HBM, irrelevant on 288 GB) - ONE kernel serves
+//                 both directions. Zero-padded to whole tiles / slices.
+//   short operand B [64, red] as three bf16 planes in the same slice-major form (12 KB per slice: plane p, row j = 64 B,
+//                 8-value chunk c at position c ^ ((j >> 2) & 3)), produced per launch by a small kernel: the weights W_g
+//                 (forward: projx_wsplit_kernel) or the transposed masked output gradient G^T (weight gradient:
+//                 projx_gprep_kernel, which also leaves the bias-gradient column sums).
+// The A values are cut into their three planes in registers (12 integer / fp32 VALU operations per pair of values, on the
+// vector pipe beside the MFMAs); a wave reads exactly the 32 rows it DMAs.
+typedef unsigned uintx4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int kXAFloats = PT * PBK;                    // 8192 floats = 32 KB: one A slice
+constexpr int kXBBytes = 3 * PJ * PBK * 2;             // 12288 B: the three bf16 planes of one B slice
+constexpr int kXStageBytes = kXAFloats * 4 + kXBBytes; // 44 KB
+constexpr int kXLdsBytes = PST * kXStageBytes;         // 132 KB
+constexpr int kXPieces = 6;                            // DMA instructions per wave per slice: 4 of A + 2 of B
+constexpr int kXGRows = 128;                           // reduction rows per block of the G preparation kernel
+
+__device__ __forceinline__ unsigned f2u(float x) { return __builtin_bit_cast(unsigned, x); }
+__device__ __forceinline__ float u2f(unsigned x) { return __builtin_bit_cast(float, x); }
+
+// a = hi + mid + lo exactly, each piece a bf16 (the top 16 bits of an fp32): the bit patterns of the three pieces
+__device__ __forceinline__ void cut3(float a, unsigned& hi, unsigned& mid, unsigned& lo) {
+  hi = f2u(a) & 0xffff0000u;
+  const float r = a - u2f(hi);            // exact: the low 16 significand bits
+  mid = f2u(r) & 0xffff0000u;
+  lo = f2u(r - u2f(mid));                 // <= 8 significant bits left: its top half is the whole value
+}
+// eight consecutive reduction values -> three packed bf16x8 operands (element e in bits 16 (e & 1) of dword e >> 1)
+__device__ __forceinline__ void cut8(const float4& v0, const float4& v1, uintx4& H, uintx4& Mi, uintx4& L) {
+  const float x[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    unsigned h0, m0, l0, h1, m1, l1;
+    cut3(x[2 * i], h0, m0, l0);
+    cut3(x[2 * i + 1], h1, m1, l1);
+    H[i] = h1 | (h0 >> 16);
+    Mi[i] = m1 | (m0 >> 16);
+    L[i] = (l1 & 0xffff0000u) | (l0 >> 16);
+  }
+}
+
+struct FragX {
+  uintx4 a[3][2];          // [plane][k-step]: this lane's row, reduction values 16 step + 8 h .. + 7
+  uintx4 b[3][2][2];       // [plane][k-step][column half]: channel 32 half + (lane & 31), same reduction values
+};
+
+__global__ __launch_bounds__(kThreads) void projx_sk_kernel(Group P, int upb, int64_t total, int max_segs,
+                                                            float* __restrict__ partials) {
+  extern __shared__ __attribute__((aligned(16))) float ring[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int h = lane >> 5, lr = lane & 31;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  const unsigned ring_lds = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)ring);
+  const int64_t u_begin = (int64_t)blockIdx.x * upb;
+  const int64_t u_end = min(total, u_begin + upb);
+  // the wave's two B pieces of a slice: KB wave and KB 8 + wave of the 12 (waves 4-7 repeat KB 0-3: the same bytes to the
+  // same place, so that every wave has the same number of DMA instructions in flight - the wait counts are immediates)
+  const int be0 = wave_u, be1 = (8 + wave_u) % 12;
+  int64_t u = u_begin;
+  int seg = 0;
+  while (u < u_end) {
+    const Segment sg = segment_at(P, u, u_end);
+    const int nk = sg.nk;
+    const float* pa = P.A[sg.g] + ((int64_t)sg.tip * P.S[sg.g] + sg.s0) * kXAFloats + (32 * wave) * PBK + 4 * lane;
+    const char* pb = reinterpret_cast<const char*>(P.B[sg.g]) + (int64_t)sg.s0 * kXBBytes + 16 * lane;
+    auto issue_piece = [&](int kt, int e) {
+      const unsigned st = ring_lds + (unsigned)(kt % PST) * kXStageBytes;
+      if (e < 4) {
+        glds16_nt(pa + (int64_t)kt * kXAFloats + e * (8 * PBK), st + (unsigned)((32 * wave_u + 8 * e) * PBK * 4));
+      } else {
+        const int kb = e == 4 ? be0 : be1;
+        glds16(reinterpret_cast<const float*>(pb + (int64_t)kt * kXBBytes + kb * 1024),
+               st + (unsigned)(kXAFloats * 4 + kb * 1024));
+      }
+    };
+    auto issue = [&](int kt) {
+#pragma unroll
+      for (int e = 0; e < kXPieces; ++e) issue_piece(kt, e);
+    };
+    // the operands of k-step s of slice kt: two 16-byte reads of my A row (cut into planes here), six of the B planes
+    auto read_half = [&](int kt, int s, FragX& f) {
+      const char* st = reinterpret_cast<const char*>(ring) + (kt % PST) * kXStageBytes;
+      const int swa = (lr >> 1) & 7;
+      const char* arow = st + (32 * wave + lr) * (PBK * 4);
+      const float4 v0 = *reinterpret_cast<const float4*>(arow + (((4 * s + 2 * h) ^ swa) << 4));
+      const float4 v1 = *reinterpret_cast<const float4*>(arow + (((4 * s + 2 * h + 1) ^ swa) << 4));
+#pragma unroll
+      for (int p = 0; p < 3; ++p)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int n = 32 * j + lr;
+          f.b[p][s][j] = *reinterpret_cast<const uintx4*>(st + kXAFloats * 4 + p * (PJ * PBK * 2) + n * (PBK * 2) +
+                                                          (((2 * s + h) ^ ((n >> 2) & 3)) << 4));
+        }
+      cut8(v0, v1, f.a[0][s], f.a[1][s], f.a[2][s]);
+    };
+    floatx16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+    // k-step s: the six partial products of both column halves, smallest first, the two accumulators alternating
+    auto mfma_half = [&](int s, const FragX& f) {
+      constexpr int pa_[6] = {0, 2, 1, 0, 1, 0};
+      constexpr int pb_[6] = {2, 0, 1, 1, 0, 0};
+#pragma unroll
+      for (int t = 0; t < 6; ++t) {
+        const bf16x8 av = __builtin_bit_cast(bf16x8, f.a[pa_[t]][s]);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, __builtin_bit_cast(bf16x8, f.b[pb_[t]][s][0]), acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, __builtin_bit_cast(bf16x8, f.b[pb_[t]][s][1]), acc1, 0, 0, 0);
+      }
+    };
+    // One pipeline step = slice kt's 24 MFMAs; per k-step: half of slice kt+3's DMA, the 12 MFMAs, then slice kt+1's
+    // operands INTO THE REGISTERS THOSE MFMAs JUST READ (one operand set, refilled in place)
+    auto step = [&](int kt, FragX& f, bool more1, bool more3, int sync_out) {
+      if (sync_out >= 0) step_sync<kXPieces>(sync_out);
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        if (more3) {
+#pragma unroll
+          for (int e = 3 * s; e < 3 * s + 3; ++e) issue_piece(kt + PST, e);
+        }
+        mfma_half(s, f);
+        if (more1) read_half(kt + 1, s, f);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    };
+    // the previous segment's slot stores and operand reads must be done before the ring is refilled
+    vm_wait_n<0>();
+    lgkm_wait0();
+    bare_barrier();
+#pragma unroll
+    for (int j = 0; j < PST; ++j)
+      if (j < nk) issue(j);
+    wait_outstanding<kXPieces>(min(nk, PST) - 1);          // slice 0 has landed
+    bare_barrier();
+    FragX f;
+    read_half(0, 0, f);
+    read_half(0, 1, f);
+    int kt = 0;
+    for (; kt + PST < nk; ++kt) step(kt, f, true, true, PST - 2);
+    for (; kt < nk; ++kt) step(kt, f, kt + 1 < nk, false, kt + 1 < nk ? min(nk - kt - 2, PST - 2) : -1);
+    // accumulator image -> partial slot, in the forward kernel's plane order (the 32x32 C layout is dtype-independent)
+    float4* Pq = reinterpret_cast<float4*>(partials + ((size_t)blockIdx.x * max_segs + seg) * kSlotFloats);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      Pq[q * kThreads + tid] = make_float4(acc0[4 * q], acc0[4 * q + 1], acc0[4 * q + 2], acc0[4 * q + 3]);
+      Pq[(4 + q) * kThreads + tid] = make_float4(acc1[4 * q], acc1[4 * q + 1], acc1[4 * q + 2], acc1[4 * q + 3]);
+    }
+    u += nk;
+    ++seg;
+  }
+}
+
+// one 16-byte chunk of each plane: the eight values x[0..7] of row j, chunk c of slice-image `img`
+__device__ __forceinline__ void store_planes(char* img, int j, int c, const float* x) {
+  uintx4 H, Mi, L;
+  cut8(make_float4(x[0], x[1], x[2], x[3]), make_float4(x[4], x[5], x[6], x[7]), H, Mi, L);
+  char* at = img + j * (PBK * 2) + ((c ^ ((j >> 2) & 3)) << 4);
+  *reinterpret_cast<uintx4*>(at) = H;
+  *reinterpret_cast<uintx4*>(at + PJ * PBK * 2) = Mi;
+  *reinterpret_cast<uintx4*>(at + 2 * PJ * PBK * 2) = L;
+}
+
+// forward: W_g [64, K] fp32 -> the B image of problem g (ceil(K / 32) slices, zeros past K). One thread = one chunk.
+struct XSplit {
+  const float* W[kMaxProb];
+  char* img[kMaxProb];
+  int K[kMaxProb];
+  int unit0[kMaxProb + 1];      // first (slice, row, chunk) unit of problem g
+  int n;
+};
+__global__ __launch_bounds__(256) void projx_wsplit_kernel(XSplit X) {
+  const int uidx = blockIdx.x * 256 + threadIdx.x;
+  if (uidx >= X.unit0[X.n]) return;
+  int g = 0;
+  while (g + 1 < X.n && uidx >= X.unit0[g + 1]) ++g;
+  const int r = uidx - X.unit0[g];
+  const int c = r & 3, j = (r >> 2) & 63, s = r >> 8;
+  const int K = X.K[g], k0 = 32 * s + 8 * c;
+  float x[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) x[e] = (k0 + e < K) ? X.W[g][(int64_t)j * K + k0 + e] : 0.f;
+  store_planes(X.img[g] + (int64_t)s * kXBBytes, j, c, x);
+}
+
+// weight gradient: G [M, ldg] fp32 (problem g = columns 64 g .. 64 g + 63) -> the B image of G_g^T (ceil(M / 32) slices,
+// zeros past M) + this block's column sums. grid = (ceil(M / 128), n_prob).
+__global__ __launch_bounds__(256) void projx_gprep_kernel(const float* __restrict__ G, int64_t ldg, int64_t M, int n_slices,
+                                                          char* __restrict__ img0, int64_t img_stride,
+                                                          float* __restrict__ bpart) {
+  __shared__ float tile[kXGRows][PJ + 1];
+  const int tid = threadIdx.x, g = blockIdx.y;
+  const int64_t m0 = (int64_t)blockIdx.x * kXGRows;
+  for (int i = tid; i < kXGRows * (PJ / 4); i += 256) {
+    const int r = i >> 4, c4 = i & 15;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (m0 + r < M) v = *reinterpret_cast<const float4*>(G + (m0 + r) * ldg + (int64_t)g * PJ + 4 * c4);
+    tile[r][4 * c4] = v.x; tile[r][4 * c4 + 1] = v.y; tile[r][4 * c4 + 2] = v.z; tile[r][4 * c4 + 3] = v.w;
+  }
+  __syncthreads();
+  char* img = img0 + (int64_t)g * img_stride;
+  for (int uidx = tid; uidx < (kXGRows / PBK) * PJ * 4; uidx += 256) {
+    const int c = uidx & 3, j = (uidx >> 2) & 63, sl = uidx >> 8;
+    const int64_t s = m0 / PBK + sl;
+    if (s >= n_slices) break;
+    float x[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) x[e] = tile[32 * sl + 8 * c + e][j];
+    store_planes(img + s * kXBBytes, j, c, x);
+  }
+  if (bpart && tid < PJ) {
+    float sum = 0.f;
+    for (int r = 0; r < kXGRows; ++r) sum += tile[r][tid];
+    bpart[((size_t)blockIdx.x * gridDim.y + g) * PJ + tid] = sum;
+  }
+}
+
+// the tile-major image of A = F (transpose 0: rows = M, reduction = K) or A = F^T (transpose 1): one thread per 16 bytes
+__global__ __launch_bounds__(256) void projx_pack_kernel(const float* __restrict__ F, int64_t M, int64_t K, int64_t ldf,
+                                                         int transpose, int64_t n_slices, int64_t n_chunks,
+                                                         float* __restrict__ out) {
+  const int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (o >= n_chunks) return;
+  const int pos = (int)(o & 7), r = (int)((o >> 3) & 255);
+  const int64_t ts = o >> 11, s = ts % n_slices, t = ts / n_slices;
+  const int c = pos ^ ((r >> 1) & 7);
+  const int64_t row = t * PT + r, col = s * PBK + 4 * c;
+  const int64_t rows = transpose ? K : M, red = transpose ? M : K;
+  float v[4] = {0.f, 0.f, 0.f, 0.f};
+  if (row < rows) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (col + e < red) v[e] = transpose ? F[(col + e) * ldf + row] : F[row * ldf + col + e];
+  }
+  reinterpret_cast<float4*>(out)[o] = make_float4(v[0], v[1], v[2], v[3]);
+}
+
+// weight-gradient epilogue on the forward-shaped slots: the tile is C[i = feature column][j = channel];
+// gW[j][i .. i + 3] is one float4; bias gradient = the G preparation kernel's block sums in block order
+__global__ __launch_bounds__(kThreads) void projx_wgrad_reduce_kernel(Group P, int upb, int max_segs,
+                                                                      const float* __restrict__ partials,
+                                                                      const float* __restrict__ bpart, int n_gblocks,
+                                                                      WgradPtrs ptrs, AdamSlots ad) {
+  __shared__ float sh[2];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int t = (int)blockIdx.x >> 3, q = (int)blockIdx.x & 7;
+  const int g = prob_of_tile(P, t), tip = t - P.tile0[g];
+  if (ad.state) {
+    if (tid == 0) {
+      const float step = ad.pre_ticked ? fmaxf(ad.state[0], 1.0f) : ad.state[0] + 1.0f;
+      sh[0] = ad.lr / (1.0f - __builtin_amdgcn_exp2f(step * ad.log2_beta1));
+      sh[1] = sqrtf(1.0f - __builtin_amdgcn_exp2f(step * ad.log2_beta2));
+    }
+    __syncthreads();
+  }
+  const float decay = 1.0f - ad.lr * ad.wd;
+  const float4 v = sum_slots(P, t, g, tip, q, upb, max_segs, partials, tid);
+  const int col = 32 * (q >> 2) + (lane & 31);
+  const int64_t i = (int64_t)tip * PT + 32 * wave + 8 * (q & 3) + 4 * (lane >> 5);
+  const int64_t K = P.I[g];
+  if (i < K) {
+    const int64_t o = (int64_t)col * K + i;
+    if (ptrs.gW[g]) *reinterpret_cast<float4*>(ptrs.gW[g] + o) = v;
+    if (ad.state && ad.W[g]) {
+      float4 pp = *reinterpret_cast<float4*>(ad.W[g] + o);
+      float4 mm = *reinterpret_cast<float4*>(ad.mW[g] + o);
+      float4 vv = *reinterpret_cast<float4*>(ad.vW[g] + o);
+      adamw_update(pp.x, v.x, mm.x, vv.x, sh[0], sh[1], decay, ad.beta1, ad.beta2, ad.eps);
+      adamw_update(pp.y, v.y, mm.y, vv.y, sh[0], sh[1], decay, ad.beta1, ad.beta2, ad.eps);
+      adamw_update(pp.z, v.z, mm.z, vv.z, sh[0], sh[1], decay, ad.beta1, ad.beta2, ad.eps);
+      adamw_update(pp.w, v.w, mm.w, vv.w, sh[0], sh[1], decay, ad.beta1, ad.beta2, ad.eps);
+      *reinterpret_cast<float4*>(ad.W[g] + o) = pp;
+      *reinterpret_cast<float4*>(ad.mW[g] + o) = mm;
+      *reinterpret_cast<float4*>(ad.vW[g] + o) = vv;
+    }
+  }
+  if (tip == 0 && q == 0 && tid < PJ && bpart && (ptrs.gb[g] || (ad.state && ad.b[g]))) {
+    float s = 0.f;
+    for (int b0 = 0; b0 < n_gblocks; b0 += 8) {
+      float pv[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) pv[k] = bpart[((size_t)min(b0 + k, n_gblocks - 1) * P.n + g) * PJ + tid];
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        if (b0 + k < n_gblocks) s += pv[k];
+    }
+    if (ptrs.gb[g]) ptrs.gb[g][tid] = s;
+    if (ad.state && ad.b[g]) {
+      float pp = ad.b[g][tid], mm = ad.mb[g][tid], vv = ad.vb[g][tid];
+      adamw_update(pp, s, mm, vv, sh[0], sh[1], decay, ad.beta1, ad.beta2, ad.eps);
+      ad.b[g][tid] = pp;
+      ad.mb[g][tid] = mm;
+      ad.vb[g][tid] = vv;
+    }
+  }
+}
+
+// =====================================================================================================================
 // host side
 // =====================================================================================================================
 struct Plan {
@@ -875,4 +1192,202 @@ static int wgrad_impl(int n_prob, const float* G, int64_t ldg, const float* cons
                      pl.max_segs, (const float*)part, (const float*)bpart, ptrs, ad);
   MMSSL_LAUNCH_CHECK();
   return 0;
+}
+
+// =====================================================================================================================
+// split-precision path: host side
+// =====================================================================================================================
+namespace {
+
+int64_t x_slices(int64_t red) { return (red + PBK - 1) / PBK; }
+int64_t x_tiles(int64_t rows) { return (rows + PT - 1) / PT; }
+size_t x_align(size_t b) { return (b + 255) & ~(size_t)255; }
+size_t x_slot_bytes(const Plan& pl) { return x_align((size_t)pl.blocks * pl.max_segs * kSlotFloats * sizeof(float)); }
+
+bool x_shape_ok(int n_prob, const int* K, int64_t M, int N) {
+  if (n_prob < 1 || n_prob > kMaxProb || N != PJ || M <= 0 || M > (1ll << 31)) return false;
+  for (int g = 0; g < n_prob; ++g)
+    if (K[g] < 4 || K[g] % 4 != 0) return false;
+  return true;
+}
+
+int x_lds_ready() {
+  static const int rc = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(projx_sk_kernel),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, kXLdsBytes);
+  return rc;
+}
+
+bool x_plan(int n_prob, const int* K, int64_t M, int wgrad, Plan& pl) {
+  int64_t I[kMaxProb], R[kMaxProb];
+  for (int g = 0; g < n_prob; ++g) {
+    I[g] = wgrad ? K[g] : M;
+    R[g] = wgrad ? M : K[g];
+  }
+  return make_plan(n_prob, I, R, pl);
+}
+
+int x_wgrad_impl(int n_prob, const float* G, int64_t ldg, const float* const* FTimg, const int* K, int64_t M, int N,
+                 float* const* gW, float* const* gb, const AdamSlots& ad, void* workspace, size_t workspace_bytes,
+                 void* stream) {
+  if (!G || !FTimg || !K || !workspace || (!gW && !ad.state)) return MMSSL_E_BADARG;
+  if (!x_shape_ok(n_prob, K, M, N)) return MMSSL_E_UNSUPP;
+  if (ldg < (int64_t)n_prob * N || (ldg & 3) || ((uintptr_t)G & 15) || ((uintptr_t)workspace & 255)) return MMSSL_E_BADARG;
+  Plan pl;
+  if (!x_plan(n_prob, K, M, 1, pl)) return MMSSL_E_UNSUPP;
+  if (workspace_bytes < mmssl_projx_workspace_bytes(n_prob, K, M, N, 1)) return MMSSL_E_WORKSPACE;
+  if (x_lds_ready() != 0) return MMSSL_E_UNSUPP;
+  const int64_t S = x_slices(M);
+  const int gblocks = (int)((M + kXGRows - 1) / kXGRows);
+  char* base = reinterpret_cast<char*>(workspace);
+  float* part = reinterpret_cast<float*>(base);
+  char* gimg = base + x_slot_bytes(pl);
+  const int64_t img_stride = S * kXBBytes;
+  float* bpart = reinterpret_cast<float*>(gimg + x_align((size_t)n_prob * img_stride));
+  WgradPtrs ptrs;
+  bool any_b = false;
+  for (int g = 0; g < kMaxProb; ++g) {
+    ptrs.gW[g] = (g < n_prob && gW) ? gW[g] : nullptr;
+    ptrs.gb[g] = (g < n_prob && gb) ? gb[g] : nullptr;
+    any_b = any_b || ptrs.gb[g] != nullptr || (ad.state && g < n_prob && ad.b[g] != nullptr);
+    if (g < n_prob) {
+      float* gw = gW ? gW[g] : nullptr;
+      if (!FTimg[g] || (!gw && !ad.state) || (((uintptr_t)FTimg[g] | (uintptr_t)gw) & 15)) return MMSSL_E_BADARG;
+      pl.P.A[g] = FTimg[g];
+      pl.P.B[g] = reinterpret_cast<const float*>(gimg + (int64_t)g * img_stride);
+      pl.P.lda[g] = pl.P.ldb[g] = 0;
+    }
+  }
+  hipStream_t s = as_stream(stream);
+  hipLaunchKernelGGL(projx_gprep_kernel, dim3((unsigned)gblocks, (unsigned)n_prob), dim3(256), 0, s, G, ldg, M, (int)S, gimg,
+                     img_stride, any_b ? bpart : (float*)nullptr);
+  MMSSL_LAUNCH_CHECK();
+  hipLaunchKernelGGL(projx_sk_kernel, dim3((unsigned)pl.blocks), dim3(kThreads), kXLdsBytes, s, pl.P, pl.upb, pl.total,
+                     pl.max_segs, part);
+  MMSSL_LAUNCH_CHECK();
+  hipLaunchKernelGGL(projx_wgrad_reduce_kernel, dim3((unsigned)pl.tiles * 8), dim3(kThreads), 0, s, pl.P, pl.upb, pl.max_segs,
+                     (const float*)part, any_b ? (const float*)bpart : (const float*)nullptr, gblocks, ptrs, ad);
+  MMSSL_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int mmssl_projx_supported(int n_prob, const int* K, int64_t M, int N) {
+  return (K && x_shape_ok(n_prob, K, M, N)) ? 1 : 0;
+}
+
+extern "C" size_t mmssl_projx_image_floats(int64_t rows, int64_t red) {
+  if (rows <= 0 || red <= 0) return 0;
+  return (size_t)(x_tiles(rows) * x_slices(red)) * kXAFloats;
+}
+
+extern "C" int mmssl_projx_pack_f32(const float* F, int64_t M, int64_t K, int64_t ldf, int transpose, float* out,
+                                    void* stream) {
+  if (!F || !out || M <= 0 || K <= 0 || ldf < K || ((uintptr_t)out & 15)) return MMSSL_E_BADARG;
+  const int64_t rows = transpose ? K : M, red = transpose ? M : K;
+  const int64_t S = x_slices(red), chunks = x_tiles(rows) * S * (kXAFloats / 4);
+  hipLaunchKernelGGL(projx_pack_kernel, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, as_stream(stream), F, M, K, ldf,
+                     transpose ? 1 : 0, S, chunks, out);
+  MMSSL_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" size_t mmssl_projx_workspace_bytes(int n_prob, const int* K, int64_t M, int N, int wgrad) {
+  if (!K || !x_shape_ok(n_prob, K, M, N)) return 0;
+  Plan pl;
+  if (!x_plan(n_prob, K, M, wgrad, pl)) return 0;
+  size_t b = x_slot_bytes(pl);
+  if (wgrad) {
+    b += x_align((size_t)n_prob * x_slices(M) * kXBBytes);
+    b += x_align((size_t)((M + kXGRows - 1) / kXGRows) * n_prob * PJ * sizeof(float));
+  } else {
+    for (int g = 0; g < n_prob; ++g) b += x_align((size_t)x_slices(K[g]) * kXBBytes);
+  }
+  return b + 256;
+}
+
+extern "C" int mmssl_projx_fwd_f32(int n_prob, const float* const* Fimg, const float* const* W, const float* const* bias,
+                                   const int* K, int64_t M, int N, const uint8_t* keep, uint8_t* keep_out,
+                                   const uint64_t* rng_state, float p_drop, float scale, float* Y, int64_t ldy,
+                                   void* workspace, size_t workspace_bytes, void* stream) {
+  if (!Fimg || !W || !K || !Y || !workspace) return MMSSL_E_BADARG;
+  if (!x_shape_ok(n_prob, K, M, N)) return MMSSL_E_UNSUPP;
+  if (ldy < (int64_t)n_prob * N || (ldy & 3) || ((uintptr_t)Y & 15) || ((uintptr_t)workspace & 255)) return MMSSL_E_BADARG;
+  if (keep && keep_out) return MMSSL_E_BADARG;
+  if (keep_out && (!rng_state || !(p_drop >= 0.f && p_drop < 1.f))) return MMSSL_E_BADARG;
+  Plan pl;
+  if (!x_plan(n_prob, K, M, 0, pl)) return MMSSL_E_UNSUPP;
+  if (workspace_bytes < mmssl_projx_workspace_bytes(n_prob, K, M, N, 0)) return MMSSL_E_WORKSPACE;
+  if (x_lds_ready() != 0) return MMSSL_E_UNSUPP;
+  char* base = reinterpret_cast<char*>(workspace);
+  float* part = reinterpret_cast<float*>(base);
+  char* wimg = base + x_slot_bytes(pl);
+  XSplit X;
+  X.n = n_prob;
+  int units = 0;
+  for (int g = 0; g < kMaxProb; ++g) {
+    X.unit0[g] = units;
+    X.W[g] = nullptr; X.img[g] = nullptr; X.K[g] = 0;
+    if (g < n_prob) {
+      if (!Fimg[g] || !W[g] || (((uintptr_t)Fimg[g] | (uintptr_t)W[g]) & 15)) return MMSSL_E_BADARG;
+      X.W[g] = W[g];
+      X.img[g] = wimg;
+      X.K[g] = K[g];
+      pl.P.A[g] = Fimg[g];
+      pl.P.B[g] = reinterpret_cast<const float*>(wimg);
+      pl.P.lda[g] = pl.P.ldb[g] = 0;
+      units += (int)x_slices(K[g]) * PJ * 4;
+      wimg += x_align((size_t)x_slices(K[g]) * kXBBytes);
+    }
+  }
+  X.unit0[kMaxProb] = units;
+  for (int g = n_prob; g <= kMaxProb; ++g) X.unit0[g] = units;
+  hipStream_t s = as_stream(stream);
+  FwdPtrs ptrs;
+  for (int g = 0; g < kMaxProb; ++g) ptrs.bias[g] = (bias && g < n_prob) ? bias[g] : nullptr;
+  hipLaunchKernelGGL(projx_wsplit_kernel, dim3((unsigned)((units + 255) / 256)), dim3(256), 0, s, X);
+  MMSSL_LAUNCH_CHECK();
+  hipLaunchKernelGGL(projx_sk_kernel, dim3((unsigned)pl.blocks), dim3(kThreads), kXLdsBytes, s, pl.P, pl.upb, pl.total,
+                     pl.max_segs, part);
+  MMSSL_LAUNCH_CHECK();
+  hipLaunchKernelGGL(proj_fwd_reduce_kernel, dim3((unsigned)pl.tiles * 8), dim3(kFThreads), 0, s, pl.P, pl.upb, pl.max_segs,
+                     (const float*)part, M, Y, ldy, ptrs, keep, keep_out, rng_state, p_drop, scale);
+  MMSSL_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int mmssl_projx_wgrad_f32(int n_prob, const float* G, int64_t ldg, const float* const* FTimg, const int* K,
+                                     int64_t M, int N, float* const* gW, float* const* gb, void* workspace,
+                                     size_t workspace_bytes, void* stream) {
+  AdamSlots ad = {};
+  return x_wgrad_impl(n_prob, G, ldg, FTimg, K, M, N, gW, gb, ad, workspace, workspace_bytes, stream);
+}
+
+extern "C" int mmssl_projx_wgrad_adamw_f32(int n_prob, const float* G, int64_t ldg, const float* const* FTimg, const int* K,
+                                           int64_t M, int N, float* const* gW, float* const* gb, float* const* W,
+                                           float* const* mW, float* const* vW, float* const* b, float* const* mb,
+                                           float* const* vb, const float* state, float lr, float beta1, float beta2,
+                                           float eps, float weight_decay, int pre_ticked, void* workspace,
+                                           size_t workspace_bytes, void* stream) {
+  if (!state || !W || !mW || !vW || n_prob < 1 || n_prob > kMaxProb) return MMSSL_E_BADARG;
+  AdamSlots ad = {};
+  for (int g = 0; g < n_prob; ++g) {
+    if (!W[g] || !mW[g] || !vW[g]) return MMSSL_E_BADARG;
+    if (((uintptr_t)W[g] | (uintptr_t)mW[g] | (uintptr_t)vW[g]) & 15) return MMSSL_E_BADARG;
+    ad.W[g] = W[g];
+    ad.mW[g] = mW[g];
+    ad.vW[g] = vW[g];
+    if (b && b[g]) {
+      if (!mb || !vb || !mb[g] || !vb[g]) return MMSSL_E_BADARG;
+      ad.b[g] = b[g];
+      ad.mb[g] = mb[g];
+      ad.vb[g] = vb[g];
+    }
+  }
+  ad.state = state;
+  ad.lr = lr; ad.beta1 = beta1; ad.beta2 = beta2; ad.eps = eps; ad.wd = weight_decay;
+  ad.log2_beta1 = (float)std::log2((double)beta1);
+  ad.log2_beta2 = (float)std::log2((double)beta2);
+  ad.pre_ticked = pre_ticked ? 1 : 0;
+  return x_wgrad_impl(n_prob, G, ldg, FTimg, K, M, N, gW, gb, ad, workspace, workspace_bytes, stream);
 }

@@ -177,6 +177,8 @@ class HipBackend:
         if self.batch_rows is not None:
             ru, ri, lo_u, lo_i = self.batch_rows
             u_g, i_g = ops.fuse_fwd_rows([(us, MU, ru), (its, MI, ri)], inv, nm, r, lo=(lo_u, lo_i))
+            # UNDEFINED until the step has summed the backward fuse kernel's partials into it (ShardedHotPathStep.backward
+            # raises if they never came); not pre-filled: that would be one more launch in every step
             ss = torch.empty((), dtype=torch.float32, device=MU.device)
             self.reg_ss, self.reg_parts = ss, None          # the backward's fuse kernel owes the |Mod|^2 partials
             return u_g, i_g, ss
@@ -531,7 +533,9 @@ class ShardedMMSSL(nn.Module):
         ok = getattr(self.bk, "chunk_ok", lambda w, n: w % n == 0)
         nc = int(getattr(self, "chunks", 0))
         if nc <= 0:
-            rows = self.halo.n_need if (getattr(self, "scheme", "") == "halo" and getattr(self, "halo", None)) else self.ish.n_pad
+            # (halo: the JOB's largest referenced-row count, identical on every rank - n_need itself is per rank, and two
+            # ranks either side of a threshold would issue different numbers of exchanges of different widths)
+            rows = self.halo.n_need_max if (getattr(self, "scheme", "") == "halo" and getattr(self, "halo", None)) else self.ish.n_pad
             full = rows * d * 4
             nc = 4 if full >= 4 * self.CHUNK_BYTES else (2 if full >= self.CHUNK_BYTES else 1)
         while nc > 1 and not (ok(d, nc) and ok(nm * d, nc)):
@@ -557,6 +561,10 @@ class ShardedMMSSL(nn.Module):
         if self.last_fused:
             return self._forward_fused(graphs, keep_masks, modal_empty)
         # (feature widths the grouped projection does not take: the composed form below runs them)
+        if getattr(self, "scheme", "gather-both") == "halo":
+            raise RuntimeError("ShardedMMSSL(scheme='halo') runs on the packed node only (feature widths %s, d = %d are not "
+                               "packable): use scheme='item-side' for this model" % (
+                                   [self.image_feats.shape[1], self.text_feats.shape[1]], c.embed_size))
         ui, iu, img_ui, img_iu, txt_ui, txt_iu = graphs
         scale = 1.0
         km_i = km_t = None
@@ -1059,6 +1067,9 @@ class HaloPlan:
         self.send_rows = [int(x.shape[0]) for x in send]
         flat = np.concatenate(send) if send else np.zeros(0, np.int64)
         self.n_need, self.n_send, self.per_i = int(need.shape[0]), int(flat.shape[0]), ish.per
+        # the job-wide maximum of n_need (every rank has all the lists): what rank-agreed decisions are sized from
+        # (ShardedMMSSL.n_chunks: the chunk count fixes the number AND the width of every rank's exchanges)
+        self.n_need_max = max(int(x.shape[0]) for x in lists)
         self.group, self.bk = group, bk
         self.send_idx = torch.from_numpy(flat.astype(np.int64)).to(device)
         sel = sp.csr_matrix((np.ones(flat.shape[0], np.float32), (flat, np.arange(flat.shape[0]))),
@@ -1496,6 +1507,9 @@ class ShardedHotPathStep:
             # batch-rows form: loss += c * sum |Mod|^2 (this rank's rows) from the backward fuse kernel's partials
             bk_, c_ = self.model.bk, self.model.cfg
             feat_c = c_.feat_reg_decay * 0.5 / self.n_items
+            if bk_.reg_parts is None:
+                raise RuntimeError("batch-rows step: the node's backward did not leave the regulariser partials (was the "
+                                   "forward of another node run on this backend between losses() and backward()?)")
             bk_.ops.loss_add_partials(bk_.reg_parts, feat_c, self.loss, bk_.reg_ss)
             feat_local = None if _solo(self.group) else feat_c * bk_.reg_ss
             bk_.reg_parts, bk_.reg_ss = None, None
@@ -1729,6 +1743,14 @@ def build_sharded_graph(a, rank, world, dev, scaling, scheme="gather-both"):
     Returns (ui_local, iu_local, ush, ish, U, I, E_global, dv, dt)."""
     from . import synth
     U, I, E, dv, dt = synth.SHAPES[a.workload]
+    if a.workload == "synth-full":
+        # configs[4] WHOLE on one rank: the vertical stack of the 8 user blocks the 8-rank `synth` job generates (same seeds),
+        # i.e. the very graph that job trains on - the N = 1 denominator of its speed-up
+        if world != 1:
+            raise ValueError("workload 'synth-full' is the one-GPU form of configs[4]; with N ranks use --workload synth")
+        raw = sp.vstack(synth.stress_blocks(8)).tocsr()
+        ui, iu = synth.normalised_pair(raw)
+        return ui, iu, RowShard(U, 1, 0), RowShard(I, 1, 0), U, I, int(raw.nnz), dv, dt
     if a.workload == "synth":
         U, I, E, dv, dt = U // 8, I // 8, E // 8, 128, 128
         scaling = "weak"

@@ -106,6 +106,7 @@ class GraphPlan:
         self._ws = {}
         rb = cb = None
         self.cluster_score = 0.0
+        contiguous_tried = False
         if xcd_bands in (0, 2) and self.nnz >= 4096 and min(self.shape) >= 64 * N_BANDS:
             contiguous = False
             if xcd_bands == 0:          # contiguous column bands first (cheap): both directions must qualify
@@ -113,20 +114,33 @@ class GraphPlan:
                 band = np.empty(self.shape[0], np.int32)
                 _lib.check(_lib.lib().mmssl_plan_band_host(rowptr.ctypes.data, col.ctypes.data, self.shape[0], self.shape[1],
                                                            N_BANDS, band.ctypes.data, ctypes.byref(sc)), "mmssl_plan_band_host")
-                contiguous = sc.value >= 0.5
+                contiguous = contiguous_tried = sc.value >= 0.5
             if not contiguous and (xcd_bands == 2 or self.nnz <= CLUSTER_AUTO_NNZ):
                 rl, cl, score = cocluster(csr)
                 self.cluster_score = score
                 if xcd_bands == 2 or score >= CLUSTER_SCORE:
                     rb, cb = np.ascontiguousarray(rl), np.ascontiguousarray(cl)
-        with torch.cuda.device(self.device):
-            rc = _lib.lib().mmssl_graph_create_banded(
-                rowptr.ctypes.data, col.ctypes.data if self.nnz else None,
-                val.ctypes.data if self.nnz else None, self.shape[0], self.shape[1], self.nnz,
-                int(xcd_bands) if xcd_bands in (-1, 0, 1) else 0,
-                None if rb is None else rb.ctypes.data, None if cb is None else cb.ctypes.data,
-                _lib.stream_ptr(), ctypes.byref(self._handle))
-        _lib.check(rc, "mmssl_graph_create_banded")
+        def create(rb, cb):
+            with torch.cuda.device(self.device):
+                rc = _lib.lib().mmssl_graph_create_banded(
+                    rowptr.ctypes.data, col.ctypes.data if self.nnz else None,
+                    val.ctypes.data if self.nnz else None, self.shape[0], self.shape[1], self.nnz,
+                    int(xcd_bands) if xcd_bands in (-1, 0, 1) else 0,
+                    None if rb is None else rb.ctypes.data, None if cb is None else cb.ctypes.data,
+                    _lib.stream_ptr(), ctypes.byref(self._handle))
+            _lib.check(rc, "mmssl_graph_create_banded")
+        create(rb, cb)
+        if xcd_bands == 0 and contiguous_tried and rb is None and self.nnz <= CLUSTER_AUTO_NNZ:
+            # the cheap pre-check saw contiguous column bands in the forward direction, but the plan builder (both directions,
+            # band balance) banded NEITHER: co-clustering has not been tried yet for this graph - do so now
+            i = self.info()
+            if not (i["banded"] or i["t_banded"]):
+                rl, cl, score = cocluster(csr)
+                self.cluster_score = score
+                if score >= CLUSTER_SCORE:
+                    self.destroy()
+                    self._handle = ctypes.c_void_p()
+                    create(np.ascontiguousarray(rl), np.ascontiguousarray(cl))
 
     # -- reference-handle compatibility -------------------------------------------------
     def _nnz(self):

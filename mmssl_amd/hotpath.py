@@ -181,6 +181,8 @@ class HotPathStep:
         hand-offs apply here."""
         m = self.model
         self.optimizer.zero_grad(set_to_none=True)
+        if self._ring is not None:          # no hot node to hang the slot pick on: select it in front of the forward
+            self._select_batch()
         out = m(*self.graphs, keep_masks=self.keep_masks, extra_graphs=getattr(self, "extra_graphs", None))
         n_extra = (len(out) - 12) // 4
         mf, emb = ops.bpr_gather(out[0], out[1], self.users, self.pos, self.neg, self.decay, self.batch_size)
@@ -196,6 +198,7 @@ class HotPathStep:
         total.backward()
         self.optimizer.step()
         self.loss.copy_(total.detach())
+        self._steps_done.add_(1)             # the batch ring's slot index (the packed path's loss tail ticks it)
         return self.loss
 
     def _step(self):

@@ -343,9 +343,57 @@ def _c_ptr_arr(tensors):
     return (_ct.c_void_p * len(tensors))(*[None if t is None else t.data_ptr() for t in tensors])
 
 
+# The grouped projection runs in SPLIT PRECISION by default (csrc/projection.hip "projx": exact 3-way bf16 cut of every fp32
+# value, six partial products on the bf16 matrix pipe, fp32 accumulation - fp32-accurate, bound by the feature stream instead
+# of the fp32 MFMA rate). False = the fp32-MFMA kernels (A/B runs: bench.py --proj f32).
+PROJ_SPLIT = True
+_PROJ_IMAGES = {}          # (data_ptr, shape, stride, device) -> [F (kept alive: its address cannot be reused), version, img, imgT]
+_PROJ_IMAGES_MAX = 8
+
+
+def projx_supported(Ks, M, N):
+    return len(Ks) >= 1 and _lib.lib().mmssl_projx_supported(len(Ks), _c_int_arr(Ks), int(M), int(N)) == 1
+
+
+def proj_images(F, transposed=False):
+    """The tile-major image of the constant feature matrix F [M, K] (reference Models.py:46-47) that the split-precision
+    projection streams: of F itself (forward) or of F^T (weight gradient). Built once per matrix by mmssl_projx_pack_f32 and
+    cached; the cache entry keeps F alive, and an in-place change of F (its version counter) rebuilds the images."""
+    key = (F.data_ptr(), tuple(F.shape), tuple(F.stride()), F.device.index)
+    e = _PROJ_IMAGES.get(key)
+    if e is None or e[1] != F._version:
+        while len(_PROJ_IMAGES) >= _PROJ_IMAGES_MAX:
+            _PROJ_IMAGES.pop(next(iter(_PROJ_IMAGES)))
+        e = _PROJ_IMAGES[key] = [F, F._version, None, None]
+    k = 3 if transposed else 2
+    if e[k] is None:
+        M, K = F.shape
+        rows, red = (K, M) if transposed else (M, K)
+        n = _lib.lib().mmssl_projx_image_floats(rows, red)
+        img = torch.empty(n, dtype=torch.float32, device=F.device)
+        rc = _lib.lib().mmssl_projx_pack_f32(_ptr(F), M, K, F.stride(0), 1 if transposed else 0, _ptr(img), _lib.stream_ptr())
+        _lib.check(rc, "mmssl_projx_pack_f32")
+        e[k] = img
+    return e[k]
+
+
+def _projx_ws(n, Ks, M, N, wgrad, dev):
+    nb = _lib.lib().mmssl_projx_workspace_bytes(n, _c_int_arr(Ks), M, N, int(wgrad))
+    if nb == 0:
+        raise _lib.MmsslError("split-precision projection: unsupported modality list K=%s M=%d N=%d" % (Ks, M, N))
+    ws = torch.empty(nb // 4 + 64, dtype=torch.float32, device=dev)
+    off = (-ws.data_ptr() % 256) // 4             # the entry points want a 256-byte aligned workspace
+    return ws[off:], nb
+
+
 def proj_supported(Ks, M, N, wgrad=False):
-    """True when mmssl_proj_fwd_f32 / mmssl_proj_wgrad_f32 run this modality list (N == 64, K % 32 == 0 forward)."""
-    return len(Ks) >= 1 and _lib.lib().mmssl_proj_supported(len(Ks), _c_int_arr(Ks), int(M), int(N), int(bool(wgrad))) == 1
+    """True when the grouped projection runs this modality list: N == 64 and, split precision (default), K % 4 == 0; on the
+    fp32-MFMA kernels K % 32 == 0 forward, K % 4 == 0 weight gradient."""
+    if len(Ks) < 1:
+        return False
+    if PROJ_SPLIT and projx_supported(Ks, M, N):
+        return True
+    return _lib.lib().mmssl_proj_supported(len(Ks), _c_int_arr(Ks), int(M), int(N), int(bool(wgrad))) == 1
 
 
 def proj_forward(Fs, Ws, bs, keep=None, draw=None, scale=1.0):
@@ -358,10 +406,15 @@ def proj_forward(Fs, Ws, bs, keep=None, draw=None, scale=1.0):
     Ks = [f.shape[1] for f in Fs]
     dev = Fs[0].device
     Y = torch.empty((M, N * n), dtype=torch.float32, device=dev)
-    nb = _lib.lib().mmssl_proj_workspace_bytes(n, _c_int_arr(Ks), M, N, 0)
-    if nb == 0:
-        raise _lib.MmsslError("proj_forward: unsupported modality list K=%s M=%d N=%d" % (Ks, M, N))
-    ws = torch.empty(nb // 4 + 4, dtype=torch.float32, device=dev)
+    split = PROJ_SPLIT and projx_supported(Ks, M, N)
+    if split:
+        imgs = [proj_images(f) for f in Fs]
+        ws, nb = _projx_ws(n, Ks, M, N, 0, dev)
+    else:
+        nb = _lib.lib().mmssl_proj_workspace_bytes(n, _c_int_arr(Ks), M, N, 0)
+        if nb == 0:
+            raise _lib.MmsslError("proj_forward: unsupported modality list K=%s M=%d N=%d" % (Ks, M, N))
+        ws = torch.empty(nb // 4 + 4, dtype=torch.float32, device=dev)
     keep_out, rng, p = None, None, 0.0
     if draw is not None:
         p, rng = float(draw[0]), draw[1]
@@ -369,6 +422,12 @@ def proj_forward(Fs, Ws, bs, keep=None, draw=None, scale=1.0):
     elif keep is not None:
         if keep.dtype != torch.uint8 or tuple(keep.shape) != (n, M, N) or not keep.is_contiguous():
             raise _lib.MmsslError("proj_forward: keep must be a contiguous uint8 [n, M, 64] tensor")
+    if split:
+        rc = _lib.lib().mmssl_projx_fwd_f32(n, _c_ptr_arr(imgs), _c_ptr_arr(Ws), _c_ptr_arr(bs), _c_int_arr(Ks), M, N,
+                                            _ptr(keep), _ptr(keep_out), _ptr(rng), p, float(scale), _ptr(Y), N * n, _ptr(ws),
+                                            nb, _lib.stream_ptr())
+        _lib.check(rc, "mmssl_projx_fwd_f32")
+        return Y, (keep_out if draw is not None else keep)
     rc = _lib.lib().mmssl_proj_fwd_f32(n, _c_ptr_arr(Fs), _c_ptr_arr(Ws), _c_ptr_arr(bs), _c_int_arr(Ks), M, N, _ptr(keep),
                                        _ptr(keep_out), _ptr(rng), p, float(scale), _ptr(Y), N * n, _ptr(ws),
                                        ws.numel() * 4, _lib.stream_ptr())
@@ -387,6 +446,25 @@ def proj_wgrad(G, Fs, want_bias=True, adam=None):
     dev = G.device
     gW = [torch.empty((N, k), dtype=torch.float32, device=dev) for k in Ks]
     gb = [torch.empty(N, dtype=torch.float32, device=dev) for _ in Ks] if want_bias else None
+    if PROJ_SPLIT and projx_supported(Ks, M, N):
+        imgs = [proj_images(f, transposed=True) for f in Fs]
+        ws, nb = _projx_ws(n, Ks, M, N, 1, dev)
+        if adam is None:
+            rc = _lib.lib().mmssl_projx_wgrad_f32(n, _ptr(G), G.stride(0), _c_ptr_arr(imgs), _c_int_arr(Ks), M, N,
+                                                  _c_ptr_arr(gW), _c_ptr_arr(gb) if gb else None, _ptr(ws), nb,
+                                                  _lib.stream_ptr())
+            _lib.check(rc, "mmssl_projx_wgrad_f32")
+            return gW, gb
+        a = adam
+        bias = a["b"] if any(t is not None for t in a["b"]) else None
+        rc = _lib.lib().mmssl_projx_wgrad_adamw_f32(
+            n, _ptr(G), G.stride(0), _c_ptr_arr(imgs), _c_int_arr(Ks), M, N, _c_ptr_arr(gW), _c_ptr_arr(gb) if gb else None,
+            _c_ptr_arr(a["W"]), _c_ptr_arr(a["mW"]), _c_ptr_arr(a["vW"]), _c_ptr_arr(a["b"]) if bias else None,
+            _c_ptr_arr(a["mb"]) if bias else None, _c_ptr_arr(a["vb"]) if bias else None, _ptr(a["state"]), a["lr"],
+            a["beta1"], a["beta2"], a["eps"], a["weight_decay"], 1 if a["pre_ticked"] else 0, _ptr(ws), nb,
+            _lib.stream_ptr())
+        _lib.check(rc, "mmssl_projx_wgrad_adamw_f32")
+        return gW, gb
     nb = _lib.lib().mmssl_proj_workspace_bytes(n, _c_int_arr(Ks), M, N, 1)
     if nb == 0:
         raise _lib.MmsslError("proj_wgrad: unsupported modality list K=%s M=%d N=%d" % (Ks, M, N))

@@ -30,6 +30,8 @@ def main():
     dev = torch.device("cuda", 0)
     if modal == "baby":
         return baby(rank, world, scheme, chunks, out_dir, md, dev)
+    if modal == "synth_full":
+        return synth_full(rank, world, scheme, chunks, out_dir, md, dev)
     fx, d, raw, U, I, state, users, pos, neg, img_raw, txt_raw = T._global_problem(modal)
     ush, ish = md.RowShard(U, world, rank), md.RowShard(I, world, rank)
     bk = md.HipBackend()
@@ -94,6 +96,48 @@ def baby(rank, world, scheme, chunks, out_dir, md, dev):
     torch.save({"loss": float(total), "ush": (ush.lo, ush.hi, ush.n), "ish": (ish.lo, ish.hi, ish.n), "g": g,
                 "chunks": model.n_chunks(2) if scheme in ("item-side", "halo") else 1,
                 "halo_fraction": (model.halo.bytes_fraction if scheme == "halo" else None)}, os.path.join(out_dir, "r%d.pt" % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def synth_full(rank, world, scheme, chunks, out_dir, md, dev):
+    """BASELINE configs[4] at its real size over `world` = 8 ranks: this rank generates ONLY its own 250 000 users' edges
+    (dist.build_sharded_graph: the items' degrees are summed over the group), takes its rows of the seeded inputs
+    (synth.stress_inputs) and runs one sharded step with the injected dropout masks. Saved: the job's loss, the small
+    parameters' gradients, and this rank's table-gradient rows at the golden file's sampled row ids."""
+    import types
+    import numpy as np
+    import scipy.sparse as sp
+    import mmssl_oracle as O
+    import helpers as H
+    from mmssl_amd import synth
+    a = types.SimpleNamespace(workload="synth", d=128, gcn_layers=3, batch=1024, scheme=scheme, chunks=chunks)
+    ui_l, iu_l, ush, ish, U, I, E_global, _, _ = md.build_sharded_graph(a, rank, world, dev, "weak", scheme)
+    assert (U, I) == (2_000_000, 1_000_000)
+    bk = md.HipBackend()
+    graphs = [bk.make_graph(ui_l), bk.make_graph(iu_l)]
+    del ui_l, iu_l
+    e_ui = bk.make_graph(sp.csr_matrix((ush.per, ish.n_pad), dtype=np.float32))
+    e_iu = bk.make_graph(sp.csr_matrix((ish.per, ush.n_pad), dtype=np.float32))
+    pb = synth.stress_inputs(U, I)
+    cfg = O.Cfg(embed_size=128, n_ui_layers=3, drop_rate=0.2, batch_size=1024)
+    model = md.ShardedMMSSL(bk, cfg, ush, ish, pb["state"], pb["img"].numpy(), pb["txt"].numpy(), scheme=scheme,
+                            chunks=chunks).to(dev).train()
+    step = md.ShardedHotPathStep(model, tuple(graphs) + (e_ui, e_iu, e_ui, e_iu), 1024, I, modal_empty=True, optimizer=False)
+    step.keep_masks = tuple(ish.slice_rows(k).to(dev) for k in pb["keep"])
+    step.set_batch(pb["batch"].to(dev))
+    del pb
+    total = step.backward()
+    torch.cuda.synchronize()
+    assert model.last_fused
+    z = H.load("synth_full_n1.npz")
+    g = {n: p.grad.detach().cpu().clone() for n, p in model.named_parameters() if n not in ("E_u", "E_i") and p.grad is not None}
+    for n, rows_k, sh in (("E_u", "rows_u", ush), ("E_i", "rows_i", ish)):
+        rows = z[rows_k]
+        loc = rows[(rows >= sh.lo) & (rows < sh.hi)] - sh.lo
+        g[n] = dict(model.named_parameters())[n].grad[torch.from_numpy(loc).to(dev)].cpu()
+    torch.save({"loss": float(total), "ush": (ush.lo, ush.hi, ush.n), "ish": (ish.lo, ish.hi, ish.n), "g": g,
+                "edges_global": int(E_global), "chunks": model.n_chunks(2)}, os.path.join(out_dir, "r%d.pt" % rank))
     dist.barrier()
     dist.destroy_process_group()
 

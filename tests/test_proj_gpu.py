@@ -11,6 +11,15 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda"
 
 
+@pytest.fixture(params=["split", "f32"], autouse=True)
+def precision(request, monkeypatch):
+    """Every test of this file runs twice: on the split-precision kernels (the default: exact 3-way bf16 cut, six partial
+    products on the bf16 matrix pipe) and on the fp32-MFMA kernels (ops.PROJ_SPLIT = False)."""
+    from mmssl_amd import ops
+    monkeypatch.setattr(ops, "PROJ_SPLIT", request.param == "split")
+    return request.param
+
+
 def _problem(M, Ks, seed):
     g = torch.Generator().manual_seed(seed)
     Fs = [torch.randn(M, k, generator=g) for k in Ks]
@@ -89,11 +98,75 @@ def test_proj_wgrad_matches_torch(M, Ks):
     assert all(torch.equal(a, b) for a, b in zip(gW, gW3))
 
 
-def test_proj_rejects_what_it_cannot_run():
+def test_proj_rejects_what_it_cannot_run(precision):
     from mmssl_amd import ops, _lib
-    assert not ops.proj_supported((100,), 1000, 64)               # forward: K % 32
+    bad_k = 102 if precision == "split" else 100                 # split: K % 4; fp32-MFMA forward: K % 32
+    assert not ops.proj_supported((bad_k,), 1000, 64)
     assert not ops.proj_supported((128,), 1000, 32)               # N != 64
     assert ops.proj_supported((100,), 1000, 64, wgrad=True)
-    F_ = torch.randn(100, 100, device=DEV)
+    assert ops.proj_supported((100,), 1000, 64) == (precision == "split")
+    F_ = torch.randn(100, bad_k, device=DEV)
     with pytest.raises(_lib.MmsslError):
-        ops.proj_forward([F_], [torch.randn(64, 100, device=DEV)], [None])
+        ops.proj_forward([F_], [torch.randn(64, bad_k, device=DEV)], [None])
+
+
+@pytest.mark.parametrize("M,Ks", [(18357, (4096, 1024)), (3000, (20, 260))])
+def test_split_precision_is_fp32_accurate_against_float64(M, Ks, precision):
+    """The claim behind the split-precision kernels: cutting every fp32 value exactly into three bf16 pieces and keeping
+    the six partial products of weight >= 2^-16 loses at most ~2^-23 of a product - one fp32 rounding. Measured against a
+    float64 product, element by element (normalised by |F| . |W|, the scale of a dot product's rounding error), the error
+    of this path must not exceed that of fp32 arithmetic itself: 1.25 x the fp32-MFMA kernels' (same sequential fp32
+    accumulation; a three-product bf16x3 scheme would sit at 3 x), within 4 x torch's blocked fp32 GEMM on the CPU. Forward and weight gradient; K = 20 exercises the zero padding of
+    a slice, M = 18357 the ragged last tile and reduction slice."""
+    if precision != "split":
+        pytest.skip("the fp32-MFMA kernels are the yardstick here")
+    from mmssl_amd import ops
+    Fs, Ws, bs, _ = _problem(M, Ks, 11)
+    Fd, Wd = [f.to(DEV) for f in Fs], [w.to(DEV) for w in Ws]
+    Y, _ = ops.proj_forward(Fd, Wd, [None] * len(Ks), scale=1.0)
+    ops.PROJ_SPLIT = False
+    try:
+        Yf = ops.proj_forward(Fd, Wd, [None] * len(Ks), scale=1.0)[0] if all(k % 32 == 0 for k in Ks) else None
+    finally:
+        ops.PROJ_SPLIT = True
+    g = torch.Generator().manual_seed(5)
+    G = torch.randn(M, 64 * len(Ks), generator=g)
+    gW, _ = ops.proj_wgrad(G.to(DEV), Fd)
+    for k in range(len(Ks)):
+        F64, W64 = Fs[k].double(), Ws[k].double()
+        ref = F64 @ W64.t()
+        scale = F64.abs() @ W64.abs().t()                          # sum |a| |b|: what a dot product's rounding scales with
+        e_split = float(((Y[:, 64 * k:64 * k + 64].cpu().double() - ref).abs() / scale).max())
+        e_torch = float((((Fs[k] @ Ws[k].t()).double() - ref).abs() / scale).max())
+        assert e_split <= 4.0 * e_torch + 1e-9 and e_split < 1e-6, (Ks[k], e_split, e_torch)
+        if Yf is not None:
+            e_mfma = float(((Yf[:, 64 * k:64 * k + 64].cpu().double() - ref).abs() / scale).max())
+            assert e_split <= 1.25 * e_mfma + 1e-9, (Ks[k], e_split, e_mfma)
+        Gk = G[:, 64 * k:64 * k + 64].double()
+        refw = Gk.t() @ F64
+        scw = Gk.abs().t() @ F64.abs()
+        e_w = float(((gW[k].cpu().double() - refw).abs() / scw).max())
+        e_wt = float((((G[:, 64 * k:64 * k + 64].t() @ Fs[k]).double() - refw).abs() / scw).max())
+        assert e_w <= 4.0 * e_wt + 1e-9 and e_w < 1e-6, (Ks[k], e_w, e_wt)
+
+
+def test_split_precision_images_follow_the_feature_matrix(precision):
+    """The packed images are cached per feature matrix: a second matrix of the same shape gets its own images (the cache
+    keeps the first alive, so its address cannot be recycled), an in-place change rebuilds them."""
+    if precision != "split":
+        pytest.skip("fp32-MFMA kernels read the matrices themselves")
+    from mmssl_amd import ops
+    M, K = 700, 96
+    W = [torch.randn(64, K, device=DEV) * 0.1]
+    F1 = torch.randn(M, K, device=DEV)
+    Y1, _ = ops.proj_forward([F1], W, [None])
+    F2 = torch.randn(M, K, device=DEV)
+    Y2, _ = ops.proj_forward([F2], W, [None])
+    assert H.rel_err(Y1.cpu(), (F1 @ W[0].t()).cpu()) < 2e-5 and H.rel_err(Y2.cpu(), (F2 @ W[0].t()).cpu()) < 2e-5
+    F1.mul_(2.0)
+    Y3, _ = ops.proj_forward([F1], W, [None])
+    assert H.rel_err(Y3.cpu(), 2 * Y1.cpu()) < 1e-6
+    for _ in range(12):                                            # more matrices than cache entries: evictions
+        Fn = torch.randn(M, K, device=DEV)
+        Yn, _ = ops.proj_forward([Fn], W, [None])
+        assert H.rel_err(Yn.cpu(), (Fn @ W[0].t()).cpu()) < 2e-5

@@ -1,0 +1,218 @@
+"""BASELINE configs[4] AT ITS REAL SIZE (synthetic 2M users x 1M items, 100M edges, d = 128, 3-layer GCN) - the one config
+no reference run can cover (the reference allocates dense U x I matrices, MMSSL/main.py:59-60 of the reference tree):
+
+  (a) the item-side scheme's true per-rank operand, A_ui[U_r, :] = 250 000 x 1 000 000 with 12.5 M edges gathering from a
+      512 MB item table: SpMM forward and transpose on sampled rows against a CPU product, adjointness, determinism;
+  (b) the WHOLE graph unsharded on one GPU (the int32 / size_t overflow test and the N = 1 denominator of north_star's
+      ">= 6x 1 -> 8"): plan build, SpMM both directions on sampled rows, the forward's output rows, one step's loss and
+      gradients against tests/golden/synth_full_n1.npz - the CPU oracle's step on the same seeded problem, generated in the
+      build container by oracle/gen_golden_synth_full.py - and the captured step against the eager one;
+  (c) the 8-rank flow at that size: 8 processes sharing this GPU (gloo group moving device tensors), every rank generating
+      only its own user block - loss and sampled gradient rows against the same golden file.
+"""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import torch
+import torch.distributed as dist
+
+import helpers as H
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _cpu_rows(mat, rows, X):
+    """(mat[rows] @ X) on the CPU in float64 (scipy)."""
+    return torch.from_numpy(np.asarray(sp.csr_matrix(mat[rows]).astype(np.float64) @ X.double().numpy()))
+
+
+def spmm_checks(plan, mat, d, n_rows=2048, seed=0):
+    """Forward and transposed SpMM of `plan` (built from scipy CSR `mat`) on sampled rows / columns (the longest ones
+    included: the multi-block path) against float64 CPU products; adjointness; bitwise determinism."""
+    from mmssl_amd import ops
+    g = torch.Generator().manual_seed(seed)
+    X = torch.randn(mat.shape[1], d, generator=g)
+    Yv = torch.randn(mat.shape[0], d, generator=g)
+    Xd, Yd = X.to(DEV), Yv.to(DEV)
+    Y = ops.spmm(plan, Xd)
+    rng = np.random.default_rng(seed + 3)
+    deg = np.diff(mat.indptr)
+    rows = np.unique(np.concatenate([rng.choice(mat.shape[0], n_rows, replace=False), np.argsort(deg)[-8:]]))
+    rec = {"rows": H.rel_err(Y[torch.from_numpy(rows).to(DEV)].cpu(), _cpu_rows(mat, rows, X)), "max_row_nnz": int(deg.max())}
+    YT = ops.spmm(plan, Yd, transpose=True)
+    lhs = float((Y.double() * Yd.double()).sum())
+    rhs = float((Xd.double() * YT.double()).sum())
+    rec["adjoint"] = abs(lhs - rhs) / abs(lhs)
+    rec["deterministic"] = bool(torch.equal(Y, ops.spmm(plan, Xd)) and torch.equal(YT, ops.spmm(plan, Yd, transpose=True)))
+    matT = mat.T.tocsr()
+    cdeg = np.diff(matT.indptr)
+    cols = np.unique(np.concatenate([rng.choice(mat.shape[1], n_rows, replace=False), np.argsort(cdeg)[-8:]]))
+    rec["transpose_rows"] = H.rel_err(YT[torch.from_numpy(cols).to(DEV)].cpu(), _cpu_rows(matT, cols, Yv))
+    rec["max_col_nnz"] = int(cdeg.max())
+    return rec
+
+
+def test_item_side_rank_operand_250k_by_1m_spmm_matches_cpu_rows():
+    """(a) rank 0's block of the 8-rank job: [250 000, 1 000 000], 12.5 M edges, d = 128 (gathered table 512 MB)."""
+    from mmssl_amd import synth
+    from mmssl_amd.graph import GraphPlan
+    raw = synth.stress_blocks(1)[0]
+    assert raw.shape == (250_000, 1_000_000) and raw.nnz == 12_500_000
+    ui_r = synth.normalised_rows(raw)
+    rec = spmm_checks(GraphPlan(ui_r), ui_r, 128)
+    assert rec["rows"] < 5e-6 and rec["transpose_rows"] < 5e-6, rec
+    assert rec["adjoint"] < 1e-5 and rec["deterministic"], rec
+
+
+@pytest.fixture(scope="module")
+def golden():
+    z = H.load("synth_full_n1.npz")
+    assert int(z["scale"]) == 1
+    return z
+
+
+@pytest.fixture(scope="module")
+def solo_group():
+    import test_dist_cpu as T
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(T._free_port())
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("gloo", rank=0, world_size=1)
+    yield
+    if created:
+        dist.destroy_process_group()
+
+
+def _cfg():
+    import mmssl_oracle as O
+    return O.Cfg(embed_size=128, n_ui_layers=3, drop_rate=0.2, batch_size=1024)
+
+
+def owned_sample(z, name, lo=0, hi=None):
+    """The golden's sampled rows of table `name` ("E_u" / "E_i") that fall into the row block [lo, hi): (mask over the
+    golden's row list, local row ids)."""
+    rows = z["rows_u" if name == "E_u" else "rows_i"]
+    sel = (rows >= lo) & (rows < (hi if hi is not None else 1 << 62))
+    return sel, rows[sel] - lo
+
+
+def _check_against_golden(z, loss, grads, table_rows, tol_l=1e-4):
+    """loss within north_star's 1e-4; small parameters' gradients whole; the table gradients on the golden's sampled rows
+    (`table_rows[name]` = (mask over the golden's row list, gradient rows in that order)), every row against its own scale."""
+    ref = float(z["loss"][0])
+    assert abs(loss - ref) <= tol_l * abs(ref), (loss, ref)
+    for name, key in (("img_w", "image_trans.weight"), ("img_b", "image_trans.bias"), ("txt_w", "text_trans.weight"),
+                      ("txt_b", "text_trans.bias")):
+        H.check_grad(grads[name], torch.from_numpy(z["g_" + key]), 5e-4, name)
+    for name, g_k, amax_k in (("E_u", "g_Eu_rows", "g_Eu_absmax"), ("E_i", "g_Ei_rows", "g_Ei_absmax")):
+        sel, got = table_rows[name]
+        assert sel.sum() > 16, (name, int(sel.sum()))
+        got = got.double().cpu()
+        want = torch.from_numpy(z[g_k][sel]).double()
+        amax = float(z[amax_k])
+        assert float((got - want).abs().max()) < 5e-4 * amax, (name, float((got - want).abs().max()), amax)
+        den = torch.clamp(want.abs().amax(1), min=1e-3 * amax)
+        assert float(((got - want).abs().amax(1) / den).max()) < 5e-3, (name, "row-wise")
+
+
+def test_full_graph_2m_by_1m_100m_edges_on_one_gpu_matches_cpu_oracle_golden(solo_group, golden):
+    """(b)"""
+    from mmssl_amd import dist as md, synth
+    z = golden
+    raw = sp.vstack(synth.stress_blocks(8)).tocsr()
+    U, I = raw.shape
+    assert (U, I, raw.nnz) == (2_000_000, 1_000_000, 100_000_000) and tuple(z["shape"]) == (U, I, raw.nnz)
+    ui, iu = synth.normalised_pair(raw)
+    del raw
+    bk = md.HipBackend()
+    dev = torch.device("cuda")
+    plans = [bk.make_graph(ui), bk.make_graph(iu)]
+    for plan, mat in zip(plans, (ui, iu)):
+        rec = spmm_checks(plan, mat, 128, seed=7)
+        assert rec["rows"] < 5e-6 and rec["transpose_rows"] < 5e-6, rec
+        assert rec["adjoint"] < 1e-5 and rec["deterministic"], rec
+    del ui, iu
+    pb = synth.stress_inputs(U, I)
+    ush, ish = md.RowShard(U, 1, 0), md.RowShard(I, 1, 0)
+    e_ui = bk.make_graph(sp.csr_matrix((U, I), dtype=np.float32))
+    e_iu = bk.make_graph(sp.csr_matrix((I, U), dtype=np.float32))
+    graphs = (plans[0], plans[1], e_ui, e_iu, e_ui, e_iu)
+    keep = tuple(k.to(dev) for k in pb["keep"])
+
+    def make(optimizer):
+        model = md.ShardedMMSSL(bk, _cfg(), ush, ish, pb["state"], pb["img"].numpy(), pb["txt"].numpy(),
+                                scheme="item-side").to(dev).train()
+        step = md.ShardedHotPathStep(model, graphs, 1024, I, modal_empty=True, optimizer=optimizer, lr=1e-3)
+        step.set_batch(pb["batch"].to(dev))
+        step.keep_masks = keep
+        return model, step
+    # forward: the output tables on the golden's sampled rows
+    model, step = make(False)
+    with torch.no_grad():
+        o = model(graphs, keep_masks=keep, modal_empty=True)
+    assert model.last_fused
+    for k, rows_k, ref_k in ((0, "rows_u", "ua_rows"), (1, "rows_i", "ia_rows")):
+        got = o[k][torch.from_numpy(z[rows_k]).to(dev)].cpu()
+        assert H.rel_err(got, z[ref_k]) < 2e-5, (k, H.rel_err(got, z[ref_k]))
+        assert H.row_rel(got, z[ref_k]) < 1e-3, (k, "row-wise")
+    del o
+    # one eager step's loss and gradients
+    total = step.backward()
+    torch.cuda.synchronize()
+    grads = {n: p.grad for n, p in model.named_parameters()}
+    picks = {}
+    for n in ("E_u", "E_i"):
+        sel, loc = owned_sample(z, n)
+        picks[n] = (sel, grads[n][torch.from_numpy(loc).to(dev)])
+    _check_against_golden(z, float(total), grads, picks)
+    for n in ("E_u", "E_i"):        # whole-table invariants: nothing lost or duplicated beyond the sampled rows
+        ss = float((grads[n].double() ** 2).sum())
+        ref = float(z["g_Eu_sumsq" if n == "E_u" else "g_Ei_sumsq"])
+        assert abs(ss - ref) <= 1e-3 * ref, (n, ss, ref)
+        assert abs(float(grads[n].abs().max()) - float(z["g_Eu_absmax" if n == "E_u" else "g_Ei_absmax"])) <= 1e-3 * float(
+            z["g_Eu_absmax" if n == "E_u" else "g_Ei_absmax"])
+    del model, step, grads
+    # eager trajectory vs warm-up + hipGraph replays of a second model (same batch, same masks)
+    _, ea = make(True)
+    la = []
+    for _ in range(5):
+        ea.step()
+        torch.cuda.synchronize()
+        la.append(float(ea.loss))
+    assert abs(la[0] - float(z["loss"][0])) <= 1e-4 * abs(la[0])
+    assert all(np.isfinite(la)) and la[-1] != la[0]
+    del ea
+    _, cb = make(True)
+    assert cb.capture(warmup=3), getattr(cb, "capture_error", None)
+    lb = []
+    for _ in range(2):
+        cb.run()
+        torch.cuda.synchronize()
+        lb.append(float(cb.loss))
+    for a, b in zip(la[3:], lb):
+        assert abs(a - b) <= 2e-5 * abs(a), (la, lb)
+
+
+def test_eight_ranks_sharing_the_gpu_run_configs4_at_full_size(tmp_path, golden):
+    """(c) 8 processes, every rank on GPU 0 over gloo, each generating only its own 250 000-user block (item-side scheme,
+    automatic column chunks): the job's loss equals the one-GPU golden within 1e-4 on every rank, the sampled gradient
+    rows of each rank's table blocks match."""
+    import test_dist_cpu as T
+    world, port = 8, T._free_port()
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "_hip_world_worker.py"), str(r), str(world), str(port),
+                               "synth_full", "item-side", "0", str(tmp_path)], stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT, text=True) for r in range(world)]
+    outs = [p.communicate(timeout=1500)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(o[-1500:] for o in outs)
+    for r in range(world):
+        o = torch.load(os.path.join(str(tmp_path), "r%d.pt" % r))
+        assert o["edges_global"] == 100_000_000 and o["chunks"] == 4
+        picks = {n: (owned_sample(golden, n, *o[sh][:2])[0], o["g"][n]) for n, sh in (("E_u", "ush"), ("E_i", "ish"))}
+        _check_against_golden(golden, o["loss"], o["g"], picks)

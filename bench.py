@@ -205,10 +205,17 @@ def projection_record(step, iters=600):
     M = Fs[0].shape[0]
     dev = Fs[0].device
     flops = sum(2.0 * M * f.shape[1] * 64 for f in Fs)
+    nbytes = sum(4.0 * (M * f.shape[1] + 64 * f.shape[1] + M * 64) for f in Fs)       # F + W + Y, fp32
+    split = bool(ops.PROJ_SPLIT and ops.projx_supported([f.shape[1] for f in Fs], M, 64))
     st = ops._rng_state(dev).clone()
     G = torch.randn(M, 128, device=dev) * (torch.rand(M, 128, device=dev) >= 0.2)      # like the step's masked gradient
     out = {"what": "grouped projection of both modalities, one stream-K launch + epilogue each way", "GFLOP": round(flops * 1e-9, 3),
-           "peak_TFLOPs": 157.3}
+           "peak_TFLOPs": 157.3, "algorithmic_MB": round(nbytes * 1e-6, 1),
+           "arithmetic": ("split precision: every fp32 value cut exactly into 3 bf16 pieces, 6 partial products per product on "
+                          "v_mfma_f32_32x32x16_bf16, fp32 accumulate (error vs float64 <= the fp32-MFMA kernels': "
+                          "tests/test_proj_gpu.py); bound = the feature stream (HBM); frac_mfma = fp32-equivalent rate over the "
+                          "fp32 MFMA peak, can exceed 1") if split else "fp32 MFMA (v_mfma_f32_32x32x2_f32 / 16x16x4_f32)",
+           "bound": "hbm" if split else "mfma"}
     with torch.no_grad():
         for name, fn in (("forward", lambda: ops.proj_forward(Fs, Ws, bs, draw=(0.2, st), scale=1.25)),
                          ("weight_gradient", lambda: ops.proj_wgrad(G, Fs))):
@@ -232,7 +239,8 @@ def projection_record(step, iters=600):
                 e1.record()
             torch.cuda.synchronize()
             us = e0.elapsed_time(e1) * 1e3 / (iters * 5)
-            out[name] = {"us": round(us, 1), "TFLOPs": round(flops / us * 1e-6, 1), "frac_mfma": round(flops / us * 1e-6 / 157.3, 3)}
+            out[name] = {"us": round(us, 1), "TFLOPs": round(flops / us * 1e-6, 1), "frac_mfma": round(flops / us * 1e-6 / 157.3, 3),
+                         "GBps": round(nbytes / us * 1e-3, 1), "frac_hbm": round(nbytes / us * 1e-3 / HBM_PEAK_GBPS, 3)}
     return out
 
 
@@ -524,6 +532,9 @@ def main():
                          "list is for)")
     ap.add_argument("--xcd-bands", type=int, default=0, dest="xcd_bands", choices=[-1, 0, 1],
                     help="GraphPlan XCD banding: 0 = automatic (on when the graph has column locality), 1 = always, -1 = never")
+    ap.add_argument("--proj", choices=["split", "f32"], default="split",
+                    help="grouped projection kernels: split = exact 3-way bf16 cut, six partial products on the bf16 matrix pipe "
+                         "(fp32-accurate, default); f32 = the fp32-MFMA kernels (A/B)")
     ap.add_argument("--no-hbm", action="store_true", dest="no_hbm", help="skip the HBM-resident SpMM record (`spmm_hbm`)")
     ap.add_argument("--share-gpu", action="store_true", dest="share_gpu",
                     help="test aid: every rank on GPU 0, process group on gloo moving device tensors (RCCL refuses two ranks on "
@@ -538,6 +549,9 @@ def main():
                     help="sharded step: column chunks per collective (chunk c's SpMM runs under chunk c+1's collective); "
                          "0 = by size (1 below 64 MB per collective, else 2-4)")
     a = ap.parse_args()
+    if a.proj == "f32":
+        from mmssl_amd import ops as _ops
+        _ops.PROJ_SPLIT = False
     if a.workload in ("synth", "synth-full") and a.d == 64:
         a.d = 128                      # configs[4] is defined at d=128
     if "WORLD_SIZE" not in os.environ and a.gpus > 1:

@@ -113,10 +113,11 @@ class Trainer(object):
             return left * csr_mat
         return left * csr_mat * inv_sqrt(csr_mat.sum(0))
 
-    def matrix_to_tensor(self, cur_matrix, xcd_bands=0):
-        """scipy matrix -> device graph handle (the reference returns a torch COO tensor here). xcd_bands = -1 for graphs that
-        are rebuilt while training (the modal graphs): no plan-time clustering for a plan that lives one batch."""
-        return GraphPlan(cur_matrix, xcd_bands=xcd_bands)
+    def matrix_to_tensor(self, cur_matrix):
+        """scipy matrix -> device graph handle (the reference returns a torch COO tensor here; same one-argument
+        signature). While the modal graphs are rebuilt (`_plan_xcd_bands` = -1) the plan skips its XCD-band / co-clustering
+        pass: not worth it for a plan that lives one batch."""
+        return GraphPlan(cur_matrix, xcd_bands=getattr(self, "_plan_xcd_bands", 0))
 
     def sparse_mx_to_torch_sparse_tensor(self, sparse_mx):
         return GraphPlan(sparse_mx)
@@ -290,8 +291,12 @@ class Trainer(object):
                     self._set_empty_modal(name)
                     continue
                 tmp = sp.csr_matrix((np.ones(len(store["x"]), np.float32), (store["x"], store["y"])), shape=shape)
-                setattr(self, name + "_ui_graph", self.matrix_to_tensor(self.csr_norm(tmp, mean_flag=True), xcd_bands=-1))
-                setattr(self, name + "_iu_graph", self.matrix_to_tensor(self.csr_norm(tmp.T, mean_flag=True), xcd_bands=-1))
+                self._plan_xcd_bands = -1
+                try:
+                    setattr(self, name + "_ui_graph", self.matrix_to_tensor(self.csr_norm(tmp, mean_flag=True)))
+                    setattr(self, name + "_iu_graph", self.matrix_to_tensor(self.csr_norm(tmp.T, mean_flag=True)))
+                finally:
+                    self._plan_xcd_bands = 0
             self.image_ui_index = {"x": [], "y": []}
             self.text_ui_index = {"x": [], "y": []}
         else:

@@ -10,9 +10,14 @@ box and compare the HIP step - one GPU, and 8 ranks sharing it - against these r
 The reference itself cannot run this size at all (it allocates dense U x I matrices, /root/reference/MMSSL/main.py:59-60),
 so the pinned oracle (tests/test_oracle_golden.py) is the only possible witness.
 
-The oracle's functions are used unchanged except for ONE memory measure: modality_attention materialises a
-[heads, 2, 2, rows, d] tensor (16 GB for 2M users), so it is applied to row blocks of 2^16 rows under
-torch.utils.checkpoint - it is row-independent, the values are those of the whole-table call.
+The oracle's functions are used unchanged except for two measures this size forces:
+  * memory: modality_attention materialises a [heads, 2, 2, rows, d] tensor (16 GB for 2M users), so it is applied to row
+    blocks of 2^16 rows under torch.utils.checkpoint - it is row-independent, the values are those of the whole-table call;
+  * the SpMM sums are ACCUMULATED IN FLOAT64 and rounded once to fp32 (forward and the autograd transpose product). A hub
+    item of this graph has ~10^6 edges; torch's fp32 COO product adds them one after the other, and a 10^6-term fp32
+    running sum is itself only good to ~1e-3 - 1e-4 (first attempt: fp32 oracle vs HIP 4e-4 on the output rows, the HIP
+    kernel's 128-edge partial sums being the MORE accurate side). With exactly rounded sums the golden measures the HIP
+    path's own error instead of the witness's. Everything else (projection, softmax, normalise, losses) stays fp32.
 """
 import argparse
 import os
@@ -41,6 +46,36 @@ def sample_rows(batch, n_users, n_items, n=1024):
     return u.astype(np.int64), i.astype(np.int64)
 
 
+class _Graph64:
+    """A sparse matrix held as float64 CSR together with its transpose (the autograd product)."""
+
+    def __init__(self, mat):
+        def csr64(m):
+            m = sp.csr_matrix(m).astype(np.float64)
+            m.sort_indices()
+            return torch.sparse_csr_tensor(torch.from_numpy(m.indptr.astype(np.int64)), torch.from_numpy(m.indices.astype(np.int64)),
+                                           torch.from_numpy(m.data), size=m.shape)
+        self.A, self.AT = csr64(mat), csr64(mat.T.tocsr())
+
+
+def _mm64(A, X, cols=32):
+    out = torch.empty((A.shape[0], X.shape[1]), dtype=torch.float32)
+    for c in range(0, X.shape[1], cols):
+        out[:, c:c + cols] = torch.sparse.mm(A, X[:, c:c + cols].double()).float()
+    return out
+
+
+class _Spmm64(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, X, G):
+        ctx.G = G
+        return _mm64(G.A, X)
+
+    @staticmethod
+    def backward(ctx, g):
+        return _mm64(ctx.G.AT, g.contiguous()), None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--scale", type=int, default=1)
@@ -57,7 +92,10 @@ def main():
     d = 128
     pb = synth.stress_inputs(U, I, d)
     cfg = O.Cfg(embed_size=d, n_ui_layers=3, drop_rate=0.2, batch_size=pb["batch"].shape[1])
-    A_ui, A_iu = O.to_torch_sparse(ui).coalesce(), O.to_torch_sparse(iu).coalesce()
+    nnz = int(ui.nnz)
+    A_ui, A_iu = _Graph64(ui), _Graph64(iu)
+    plain = O.spmm
+    O.spmm = lambda A, X: _Spmm64.apply(X, A) if isinstance(A, _Graph64) else plain(A, X)
     e_ui = O.to_torch_sparse(sp.csr_matrix((U, I), dtype=np.float32))
     e_iu = O.to_torch_sparse(sp.csr_matrix((I, U), dtype=np.float32))
     del ui, iu, raw
@@ -85,7 +123,7 @@ def main():
     print("backward %.0f s   loss %.7f" % (time.time() - t0, float(total)), flush=True)
     ru, ri = sample_rows(pb["batch"], U, I)
     gu, gi = P["user_id_embedding.weight"].grad, P["item_id_embedding.weight"].grad
-    rec = {"scale": np.int64(a.scale), "shape": np.array([U, I, int(A_ui._nnz())], np.int64),
+    rec = {"scale": np.int64(a.scale), "shape": np.array([U, I, nnz], np.int64),
            "loss": np.array([float(x) for x in (total, mf, emb, feat, cl_i, cl_t)], np.float64),
            "rows_u": ru, "rows_i": ri,
            "ua_rows": o[0].detach()[ru].numpy(), "ia_rows": o[1].detach()[ri].numpy(),

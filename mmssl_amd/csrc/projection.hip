@@ -41,6 +41,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
+#include <type_traits>
 
 #include "lds_dma.hpp"
 
@@ -668,9 +669,9 @@ __global__ __launch_bounds__(kThreads) void proj_wgrad_reduce_kernel(Group P, in
 //
 // Operands:
 //   long operand  A [rows, red] fp32 in a TILE-MAJOR image made once (the features are constants, Models.py:46-47;
-//                 mmssl_projx_pack_f32): the 256 x 32 slice (tile t, slice s) is one contiguous 32 KB block that IS the LDS
-//                 stage image (row r = 128 B, 16-byte chunk c stored at position c ^ ((r >> 1) & 7)), so every LDS-DMA
-//                 instruction of a wave streams one contiguous KB. Forward: A = F_g [M, K_g]; weight gradient: A = F_g^T
+//                 mmssl_projx_pack_f32): the 256 x 32 slice (tile t, slice s) is one contiguous 32 KB block in the order
+//                 the kernel's lanes consume it (see projx_pack_kernel), so every load instruction of a wave streams one
+//                 contiguous KB straight into registers. Forward: A = F_g [M, K_g]; weight gradient: A = F_g^T
 //                 [K_g, M] (a second packed copy: +1 x the feature bytes of HBM, irrelevant on 288 GB) - ONE kernel serves
 //                 both directions. Zero-padded to whole tiles / slices.
 //   short operand B [64, red] as three bf16 planes in the same slice-major form (12 KB per slice: plane p, row j = 64 B,
@@ -678,15 +679,13 @@ __global__ __launch_bounds__(kThreads) void proj_wgrad_reduce_kernel(Group P, in
 //                 (forward: projx_wsplit_kernel) or the transposed masked output gradient G^T (weight gradient:
 //                 projx_gprep_kernel, which also leaves the bias-gradient column sums).
 // The A values are cut into their three planes in registers (12 integer / fp32 VALU operations per pair of values, on the
-// vector pipe beside the MFMAs); a wave reads exactly the 32 rows it DMAs.
+// vector pipe beside the MFMAs); a wave loads exactly the 32 rows its MFMAs read.
 typedef unsigned uintx4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int kXAFloats = PT * PBK;                    // 8192 floats = 32 KB: one A slice
 constexpr int kXBBytes = 3 * PJ * PBK * 2;             // 12288 B: the three bf16 planes of one B slice
-constexpr int kXStageBytes = kXAFloats * 4 + kXBBytes; // 44 KB
-constexpr int kXLdsBytes = PST * kXStageBytes;         // 132 KB
-constexpr int kXPieces = 6;                            // DMA instructions per wave per slice: 4 of A + 2 of B
+constexpr int kXPieces = 6;                            // memory instructions per wave per slice: 4 loads of A + 2 DMA pieces of B
 constexpr int kXGRows = 128;                           // reduction rows per block of the G preparation kernel
 
 __device__ __forceinline__ unsigned f2u(float x) { return __builtin_bit_cast(unsigned, x); }
@@ -718,6 +717,26 @@ struct FragX {
   uintx4 b[3][2][2];       // [plane][k-step][column half]: channel 32 half + (lane & 31), same reduction values
 };
 
+// 16 bytes global -> VGPRs, non-temporal, as an asm the compiler cannot wait for by itself: the kernel keeps kXDepth
+// slices of its A operand in flight in registers and counts vmcnt by hand (the LDS-DMA pieces of B share that counter).
+template <int OFF>
+__device__ __forceinline__ void gload16_nt(floatx4& dst, const float* p) {
+  asm volatile("global_load_dwordx4 %0, %1, off offset:%2 nt" : "=v"(dst) : "v"(p), "n"(OFF) : "memory");
+}
+// "these four registers are valid from here on": ties their readers behind the wait that precedes this statement
+__device__ __forceinline__ void tie4(floatx4& a, floatx4& b, floatx4& c, floatx4& d) {
+  asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d)::"memory");
+}
+
+constexpr int kXDepth = 4;                             // slices in flight per wave: A in registers, B in the LDS ring
+constexpr int kXLdsBytes = kXDepth * kXBBytes;         // 48 KB: only the short operand passes through LDS
+
+// The long operand never touches LDS: a wave's MFMA rows are read by that wave alone, so each lane loads the 16 values of
+// its row straight into registers - four fully coalesced 1 KB loads per wave and slice out of an image laid out for
+// exactly that (projx_pack_kernel) - kXDepth slices ahead (64 KB per CU in flight beside the B ring's DMA; the LDS-staged
+// form of this kernel measured 92 us for the 387 MB stream: every byte paid the LDS-DMA path's ~6.4 TB/s chip-wide
+// ceiling TOGETHER with the L2-resident B planes, +37 % bytes). LDS carries the three bf16 planes of the short operand
+// only (12 KB per slice, kXDepth stages, one barrier per slice).
 __global__ __launch_bounds__(kThreads) void projx_sk_kernel(Group P, int upb, int64_t total, int max_segs,
                                                             float* __restrict__ partials) {
   extern __shared__ __attribute__((aligned(16))) float ring[];
@@ -728,45 +747,42 @@ __global__ __launch_bounds__(kThreads) void projx_sk_kernel(Group P, int upb, in
   const int64_t u_begin = (int64_t)blockIdx.x * upb;
   const int64_t u_end = min(total, u_begin + upb);
   // the wave's two B pieces of a slice: KB wave and KB 8 + wave of the 12 (waves 4-7 repeat KB 0-3: the same bytes to the
-  // same place, so that every wave has the same number of DMA instructions in flight - the wait counts are immediates)
+  // same place, so that every wave has the same number of memory instructions in flight - the wait counts are immediates)
   const int be0 = wave_u, be1 = (8 + wave_u) % 12;
   int64_t u = u_begin;
   int seg = 0;
   while (u < u_end) {
     const Segment sg = segment_at(P, u, u_end);
     const int nk = sg.nk;
-    const float* pa = P.A[sg.g] + ((int64_t)sg.tip * P.S[sg.g] + sg.s0) * kXAFloats + (32 * wave) * PBK + 4 * lane;
+    const float* pa = P.A[sg.g] + ((int64_t)sg.tip * P.S[sg.g] + sg.s0) * kXAFloats + wave * 1024 + 4 * lane;
     const char* pb = reinterpret_cast<const char*>(P.B[sg.g]) + (int64_t)sg.s0 * kXBBytes + 16 * lane;
-    auto issue_piece = [&](int kt, int e) {
-      const unsigned st = ring_lds + (unsigned)(kt % PST) * kXStageBytes;
-      if (e < 4) {
-        glds16_nt(pa + (int64_t)kt * kXAFloats + e * (8 * PBK), st + (unsigned)((32 * wave_u + 8 * e) * PBK * 4));
-      } else {
-        const int kb = e == 4 ? be0 : be1;
-        glds16(reinterpret_cast<const float*>(pb + (int64_t)kt * kXBBytes + kb * 1024),
-               st + (unsigned)(kXAFloats * 4 + kb * 1024));
-      }
+    floatx4 raw[kXDepth][4];
+    // slice kt's memory instructions of this wave: 4 loads of A into register set J, 2 DMA pieces of B into stage kt % depth
+    auto issue = [&](auto J, int kt) {
+      const float* p = pa + (int64_t)kt * kXAFloats;
+      gload16_nt<0>(raw[J.value][0], p);
+      gload16_nt<1024>(raw[J.value][1], p);
+      gload16_nt<2048>(raw[J.value][2], p);
+      gload16_nt<3072>(raw[J.value][3], p);
+      const unsigned st = ring_lds + (unsigned)(kt % kXDepth) * kXBBytes;
+      const char* q = pb + (int64_t)kt * kXBBytes;
+      glds16(reinterpret_cast<const float*>(q + be0 * 1024), st + (unsigned)(be0 * 1024));
+      glds16(reinterpret_cast<const float*>(q + be1 * 1024), st + (unsigned)(be1 * 1024));
     };
-    auto issue = [&](int kt) {
-#pragma unroll
-      for (int e = 0; e < kXPieces; ++e) issue_piece(kt, e);
-    };
-    // the operands of k-step s of slice kt: two 16-byte reads of my A row (cut into planes here), six of the B planes
-    auto read_half = [&](int kt, int s, FragX& f) {
-      const char* st = reinterpret_cast<const char*>(ring) + (kt % PST) * kXStageBytes;
-      const int swa = (lr >> 1) & 7;
-      const char* arow = st + (32 * wave + lr) * (PBK * 4);
-      const float4 v0 = *reinterpret_cast<const float4*>(arow + (((4 * s + 2 * h) ^ swa) << 4));
-      const float4 v1 = *reinterpret_cast<const float4*>(arow + (((4 * s + 2 * h + 1) ^ swa) << 4));
+    // the operands of k-step s of slice kt: my A values from register set J (cut into planes here), six reads of B planes
+    auto take_half = [&](auto J, int kt, int s, FragX& f) {
+      const char* st = reinterpret_cast<const char*>(ring) + (kt % kXDepth) * kXBBytes;
 #pragma unroll
       for (int p = 0; p < 3; ++p)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           const int n = 32 * j + lr;
-          f.b[p][s][j] = *reinterpret_cast<const uintx4*>(st + kXAFloats * 4 + p * (PJ * PBK * 2) + n * (PBK * 2) +
+          f.b[p][s][j] = *reinterpret_cast<const uintx4*>(st + p * (PJ * PBK * 2) + n * (PBK * 2) +
                                                           (((2 * s + h) ^ ((n >> 2) & 3)) << 4));
         }
-      cut8(v0, v1, f.a[0][s], f.a[1][s], f.a[2][s]);
+      const floatx4 v0 = raw[J.value][2 * s], v1 = raw[J.value][2 * s + 1];
+      cut8(make_float4(v0[0], v0[1], v0[2], v0[3]), make_float4(v1[0], v1[1], v1[2], v1[3]), f.a[0][s], f.a[1][s],
+           f.a[2][s]);
     };
     floatx16 acc0, acc1;
 #pragma unroll
@@ -782,36 +798,46 @@ __global__ __launch_bounds__(kThreads) void projx_sk_kernel(Group P, int upb, in
         acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, __builtin_bit_cast(bf16x8, f.b[pb_[t]][s][1]), acc1, 0, 0, 0);
       }
     };
-    // One pipeline step = slice kt's 24 MFMAs; per k-step: half of slice kt+3's DMA, the 12 MFMAs, then slice kt+1's
-    // operands INTO THE REGISTERS THOSE MFMAs JUST READ (one operand set, refilled in place)
-    auto step = [&](int kt, FragX& f, bool more1, bool more3, int sync_out) {
-      if (sync_out >= 0) step_sync<kXPieces>(sync_out);
+    // One pipeline step = slice kt's 24 MFMAs (operand set f). Before them: slice kt + 1 has landed (mine: vmcnt;
+    // everyone's B: barrier). Slice kt + depth is issued into the register set / stage slice kt has just left; after each
+    // k-step's MFMAs slice kt + 1's operands replace the ones those MFMAs read.
+    auto step = [&](auto J, int kt, FragX& f) {
+      constexpr int JN = (J.value + 1) % kXDepth;
+      const bool more1 = kt + 1 < nk, more = kt + kXDepth < nk;
+      if (more1) {
+        wait_outstanding<kXPieces>(min(nk - kt - 2, kXDepth - 2));
+        tie4(raw[JN][0], raw[JN][1], raw[JN][2], raw[JN][3]);
+        lgkm_wait0();
+        bare_barrier();
+      }
+      if (more) issue(J, kt + kXDepth);
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
-        if (more3) {
-#pragma unroll
-          for (int e = 3 * s; e < 3 * s + 3; ++e) issue_piece(kt + PST, e);
-        }
         mfma_half(s, f);
-        if (more1) read_half(kt + 1, s, f);
+        if (more1) take_half(std::integral_constant<int, JN>{}, kt + 1, s, f);
         __builtin_amdgcn_sched_barrier(0);
       }
     };
-    // the previous segment's slot stores and operand reads must be done before the ring is refilled
+    // the previous segment's slot stores and operand reads must be done before registers and ring are refilled
     vm_wait_n<0>();
     lgkm_wait0();
     bare_barrier();
-#pragma unroll
-    for (int j = 0; j < PST; ++j)
-      if (j < nk) issue(j);
-    wait_outstanding<kXPieces>(min(nk, PST) - 1);          // slice 0 has landed
+    issue(std::integral_constant<int, 0>{}, 0);
+    if (nk > 1) issue(std::integral_constant<int, 1>{}, 1);
+    if (nk > 2) issue(std::integral_constant<int, 2>{}, 2);
+    if (nk > 3) issue(std::integral_constant<int, 3>{}, 3);
+    wait_outstanding<kXPieces>(min(nk, kXDepth) - 1);          // slice 0 has landed
+    tie4(raw[0][0], raw[0][1], raw[0][2], raw[0][3]);
     bare_barrier();
     FragX f;
-    read_half(0, 0, f);
-    read_half(0, 1, f);
-    int kt = 0;
-    for (; kt + PST < nk; ++kt) step(kt, f, true, true, PST - 2);
-    for (; kt < nk; ++kt) step(kt, f, kt + 1 < nk, false, kt + 1 < nk ? min(nk - kt - 2, PST - 2) : -1);
+    take_half(std::integral_constant<int, 0>{}, 0, 0, f);
+    take_half(std::integral_constant<int, 0>{}, 0, 1, f);
+    for (int kt = 0; kt < nk; kt += kXDepth) {
+      step(std::integral_constant<int, 0>{}, kt, f);
+      if (kt + 1 < nk) step(std::integral_constant<int, 1>{}, kt + 1, f);
+      if (kt + 2 < nk) step(std::integral_constant<int, 2>{}, kt + 2, f);
+      if (kt + 3 < nk) step(std::integral_constant<int, 3>{}, kt + 3, f);
+    }
     // accumulator image -> partial slot, in the forward kernel's plane order (the 32x32 C layout is dtype-independent)
     float4* Pq = reinterpret_cast<float4*>(partials + ((size_t)blockIdx.x * max_segs + seg) * kSlotFloats);
 #pragma unroll
@@ -888,16 +914,17 @@ __global__ __launch_bounds__(256) void projx_gprep_kernel(const float* __restric
   }
 }
 
-// the tile-major image of A = F (transpose 0: rows = M, reduction = K) or A = F^T (transpose 1): one thread per 16 bytes
+// the tile-major image of A = F (transpose 0: rows = M, reduction = K) or A = F^T (transpose 1): one thread per 16 bytes.
+// Block (tile t, slice s) = 2048 float4: wave w's KB q (0..3) holds, at lane l, the float4 of row 256 t + 32 w + (l & 31),
+// reduction values 32 s + 16 (q >> 1) + 8 (l >> 5) + 4 (q & 1) .. + 3 - what projx_sk_kernel's lane l feeds the MFMA.
 __global__ __launch_bounds__(256) void projx_pack_kernel(const float* __restrict__ F, int64_t M, int64_t K, int64_t ldf,
                                                          int transpose, int64_t n_slices, int64_t n_chunks,
                                                          float* __restrict__ out) {
   const int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (o >= n_chunks) return;
-  const int pos = (int)(o & 7), r = (int)((o >> 3) & 255);
+  const int l = (int)(o & 63), q = (int)((o >> 6) & 3), w = (int)((o >> 8) & 7);
   const int64_t ts = o >> 11, s = ts % n_slices, t = ts / n_slices;
-  const int c = pos ^ ((r >> 1) & 7);
-  const int64_t row = t * PT + r, col = s * PBK + 4 * c;
+  const int64_t row = t * PT + 32 * w + (l & 31), col = s * PBK + 16 * (q >> 1) + 8 * (l >> 5) + 4 * (q & 1);
   const int64_t rows = transpose ? K : M, red = transpose ? M : K;
   float v[4] = {0.f, 0.f, 0.f, 0.f};
   if (row < rows) {

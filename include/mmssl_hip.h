@@ -386,24 +386,28 @@ int mmssl_proj_wgrad_adamw_f32(int n_prob, const float* G, int64_t ldg, const fl
  *     block contiguous and laid out as the kernel's LDS stage, so every LDS-DMA instruction streams one contiguous KB);
  *   - K_g % 4 == 0 both ways (zero padding replaces the forward's K_g % 32 requirement);
  *   - workspace: mmssl_projx_workspace_bytes (256-byte aligned pointer): partial slots + the per-launch bf16 operand planes
- *     of W (forward) or of G^T (weight gradient, which also yields the bias-gradient sums).
+ *     of W (forward) or of G^T (weight gradient, which also yields the bias-gradient sums);
+ *   - n_blocks: the launch's block count = equal ranges the work is cut into (0 = one per CU). The launch is bound by the
+ *     feature stream, which fewer CUs still saturate: a caller that runs other kernels beside it (the step's GCN chain on a
+ *     side stream) passes ~13/16 of the CU count so that those kernels are not starved. Same value for the size query.
+ *     Results are bit-identical for a given n_blocks (fixed-order partial sums), not across different ones.
  * ---------------------------------------------------------------------------------- */
 int mmssl_projx_supported(int n_prob, const int* K, int64_t M, int N);
 size_t mmssl_projx_image_floats(int64_t rows, int64_t red);
 int mmssl_projx_pack_f32(const float* F, int64_t M, int64_t K, int64_t ldf, int transpose, float* out, void* stream);
-size_t mmssl_projx_workspace_bytes(int n_prob, const int* K, int64_t M, int N, int wgrad);
+size_t mmssl_projx_workspace_bytes(int n_prob, const int* K, int64_t M, int N, int wgrad, int n_blocks);
 int mmssl_projx_fwd_f32(int n_prob, const float* const* Fimg, const float* const* W, const float* const* bias,
                         const int* K, int64_t M, int N, const uint8_t* keep, uint8_t* keep_out,
                         const uint64_t* rng_state, float p_drop, float scale, float* Y, int64_t ldy,
-                        void* workspace, size_t workspace_bytes, void* stream);
+                        int n_blocks, void* workspace, size_t workspace_bytes, void* stream);
 int mmssl_projx_wgrad_f32(int n_prob, const float* G, int64_t ldg, const float* const* FTimg, const int* K, int64_t M,
-                          int N, float* const* gW, float* const* gb, void* workspace, size_t workspace_bytes,
-                          void* stream);
+                          int N, float* const* gW, float* const* gb, int n_blocks, void* workspace,
+                          size_t workspace_bytes, void* stream);
 int mmssl_projx_wgrad_adamw_f32(int n_prob, const float* G, int64_t ldg, const float* const* FTimg, const int* K, int64_t M,
                                 int N, float* const* gW, float* const* gb, float* const* W, float* const* mW,
                                 float* const* vW, float* const* b, float* const* mb, float* const* vb,
                                 const float* state, float lr, float beta1, float beta2, float eps, float weight_decay,
-                                int pre_ticked, void* workspace, size_t workspace_bytes, void* stream);
+                                int pre_ticked, int n_blocks, void* workspace, size_t workspace_bytes, void* stream);
 size_t mmssl_linear_wgrad_workspace_bytes(int64_t M, int K, int N);
 /* 1 when mmssl_linear_wgrad_f32 will run this shape on the register-direct kernel, which applies keep/scale and
  * sums the bias gradient on the fragments it loads (pass `keep`; no separate dropout-backward pass is needed);

@@ -1015,7 +1015,7 @@ int n_cus() {
 }
 
 // tile axis extents I[g], reduction lengths R[g]; tile height pt, `per_cu` unit ranges per CU
-bool make_plan(int n_prob, const int64_t* I, const int64_t* R, Plan& pl, int pt = PT, int per_cu = 1) {
+bool make_plan(int n_prob, const int64_t* I, const int64_t* R, Plan& pl, int pt = PT, int per_cu = 1, int n_blocks = 0) {
   if (n_prob < 1 || n_prob > kMaxProb) return false;
   Group& P = pl.P;
   P.n = n_prob;
@@ -1043,7 +1043,7 @@ bool make_plan(int n_prob, const int64_t* I, const int64_t* R, Plan& pl, int pt 
     P.S[g] = 1;
   }
   if (units > (1ll << 40) || tiles > (1 << 20)) return false;
-  const int64_t slots_ = (int64_t)n_cus() * per_cu;
+  const int64_t slots_ = n_blocks > 0 ? n_blocks : (int64_t)n_cus() * per_cu;
   int64_t upb = (units + slots_ - 1) / slots_;
   const int64_t floor_ = std::min<int64_t>(min_s, 8);       // a range is at least 8 slices deep (or one whole tile)
   if (upb < floor_) upb = floor_;
@@ -1244,24 +1244,29 @@ int x_lds_ready() {
   return rc;
 }
 
-bool x_plan(int n_prob, const int* K, int64_t M, int wgrad, Plan& pl) {
+// n_blocks: unit ranges = blocks of the launch (0 = one per CU). A step that runs other kernels beside the projection
+// (hotpath.HotPathStep: the GCN chain on a side stream) asks for fewer - 13/16 of the CUs measured best there
+// (profiles/r05/projx_blocks.txt): the launch is bound by the feature stream, which 13/16 of the CUs still saturate, and the
+// kernels beside it stop starving (a side-stream SpMM under a full-width launch: 63 us instead of 11).
+bool x_plan(int n_prob, const int* K, int64_t M, int wgrad, int n_blocks, Plan& pl) {
   int64_t I[kMaxProb], R[kMaxProb];
   for (int g = 0; g < n_prob; ++g) {
     I[g] = wgrad ? K[g] : M;
     R[g] = wgrad ? M : K[g];
   }
-  return make_plan(n_prob, I, R, pl);
+  if (n_blocks < 0 || n_blocks > 4096) return false;
+  return make_plan(n_prob, I, R, pl, PT, 1, n_blocks);
 }
 
 int x_wgrad_impl(int n_prob, const float* G, int64_t ldg, const float* const* FTimg, const int* K, int64_t M, int N,
-                 float* const* gW, float* const* gb, const AdamSlots& ad, void* workspace, size_t workspace_bytes,
-                 void* stream) {
+                 float* const* gW, float* const* gb, const AdamSlots& ad, int n_blocks, void* workspace,
+                 size_t workspace_bytes, void* stream) {
   if (!G || !FTimg || !K || !workspace || (!gW && !ad.state)) return MMSSL_E_BADARG;
   if (!x_shape_ok(n_prob, K, M, N)) return MMSSL_E_UNSUPP;
   if (ldg < (int64_t)n_prob * N || (ldg & 3) || ((uintptr_t)G & 15) || ((uintptr_t)workspace & 255)) return MMSSL_E_BADARG;
   Plan pl;
-  if (!x_plan(n_prob, K, M, 1, pl)) return MMSSL_E_UNSUPP;
-  if (workspace_bytes < mmssl_projx_workspace_bytes(n_prob, K, M, N, 1)) return MMSSL_E_WORKSPACE;
+  if (!x_plan(n_prob, K, M, 1, n_blocks, pl)) return MMSSL_E_UNSUPP;
+  if (workspace_bytes < mmssl_projx_workspace_bytes(n_prob, K, M, N, 1, n_blocks)) return MMSSL_E_WORKSPACE;
   if (x_lds_ready() != 0) return MMSSL_E_UNSUPP;
   const int64_t S = x_slices(M);
   const int gblocks = (int)((M + kXGRows - 1) / kXGRows);
@@ -1319,10 +1324,10 @@ extern "C" int mmssl_projx_pack_f32(const float* F, int64_t M, int64_t K, int64_
   return 0;
 }
 
-extern "C" size_t mmssl_projx_workspace_bytes(int n_prob, const int* K, int64_t M, int N, int wgrad) {
+extern "C" size_t mmssl_projx_workspace_bytes(int n_prob, const int* K, int64_t M, int N, int wgrad, int n_blocks) {
   if (!K || !x_shape_ok(n_prob, K, M, N)) return 0;
   Plan pl;
-  if (!x_plan(n_prob, K, M, wgrad, pl)) return 0;
+  if (!x_plan(n_prob, K, M, wgrad, n_blocks, pl)) return 0;
   size_t b = x_slot_bytes(pl);
   if (wgrad) {
     b += x_align((size_t)n_prob * x_slices(M) * kXBBytes);
@@ -1336,15 +1341,15 @@ extern "C" size_t mmssl_projx_workspace_bytes(int n_prob, const int* K, int64_t 
 extern "C" int mmssl_projx_fwd_f32(int n_prob, const float* const* Fimg, const float* const* W, const float* const* bias,
                                    const int* K, int64_t M, int N, const uint8_t* keep, uint8_t* keep_out,
                                    const uint64_t* rng_state, float p_drop, float scale, float* Y, int64_t ldy,
-                                   void* workspace, size_t workspace_bytes, void* stream) {
+                                   int n_blocks, void* workspace, size_t workspace_bytes, void* stream) {
   if (!Fimg || !W || !K || !Y || !workspace) return MMSSL_E_BADARG;
   if (!x_shape_ok(n_prob, K, M, N)) return MMSSL_E_UNSUPP;
   if (ldy < (int64_t)n_prob * N || (ldy & 3) || ((uintptr_t)Y & 15) || ((uintptr_t)workspace & 255)) return MMSSL_E_BADARG;
   if (keep && keep_out) return MMSSL_E_BADARG;
   if (keep_out && (!rng_state || !(p_drop >= 0.f && p_drop < 1.f))) return MMSSL_E_BADARG;
   Plan pl;
-  if (!x_plan(n_prob, K, M, 0, pl)) return MMSSL_E_UNSUPP;
-  if (workspace_bytes < mmssl_projx_workspace_bytes(n_prob, K, M, N, 0)) return MMSSL_E_WORKSPACE;
+  if (!x_plan(n_prob, K, M, 0, n_blocks, pl)) return MMSSL_E_UNSUPP;
+  if (workspace_bytes < mmssl_projx_workspace_bytes(n_prob, K, M, N, 0, n_blocks)) return MMSSL_E_WORKSPACE;
   if (x_lds_ready() != 0) return MMSSL_E_UNSUPP;
   char* base = reinterpret_cast<char*>(workspace);
   float* part = reinterpret_cast<float*>(base);
@@ -1384,17 +1389,17 @@ extern "C" int mmssl_projx_fwd_f32(int n_prob, const float* const* Fimg, const f
 }
 
 extern "C" int mmssl_projx_wgrad_f32(int n_prob, const float* G, int64_t ldg, const float* const* FTimg, const int* K,
-                                     int64_t M, int N, float* const* gW, float* const* gb, void* workspace,
+                                     int64_t M, int N, float* const* gW, float* const* gb, int n_blocks, void* workspace,
                                      size_t workspace_bytes, void* stream) {
   AdamSlots ad = {};
-  return x_wgrad_impl(n_prob, G, ldg, FTimg, K, M, N, gW, gb, ad, workspace, workspace_bytes, stream);
+  return x_wgrad_impl(n_prob, G, ldg, FTimg, K, M, N, gW, gb, ad, n_blocks, workspace, workspace_bytes, stream);
 }
 
 extern "C" int mmssl_projx_wgrad_adamw_f32(int n_prob, const float* G, int64_t ldg, const float* const* FTimg, const int* K,
                                            int64_t M, int N, float* const* gW, float* const* gb, float* const* W,
                                            float* const* mW, float* const* vW, float* const* b, float* const* mb,
                                            float* const* vb, const float* state, float lr, float beta1, float beta2,
-                                           float eps, float weight_decay, int pre_ticked, void* workspace,
+                                           float eps, float weight_decay, int pre_ticked, int n_blocks, void* workspace,
                                            size_t workspace_bytes, void* stream) {
   if (!state || !W || !mW || !vW || n_prob < 1 || n_prob > kMaxProb) return MMSSL_E_BADARG;
   AdamSlots ad = {};
@@ -1416,5 +1421,5 @@ extern "C" int mmssl_projx_wgrad_adamw_f32(int n_prob, const float* G, int64_t l
   ad.log2_beta1 = (float)std::log2((double)beta1);
   ad.log2_beta2 = (float)std::log2((double)beta2);
   ad.pre_ticked = pre_ticked ? 1 : 0;
-  return x_wgrad_impl(n_prob, G, ldg, FTimg, K, M, N, gW, gb, ad, workspace, workspace_bytes, stream);
+  return x_wgrad_impl(n_prob, G, ldg, FTimg, K, M, N, gW, gb, ad, n_blocks, workspace, workspace_bytes, stream);
 }

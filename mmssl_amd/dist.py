@@ -142,11 +142,12 @@ class HipBackend:
         dev = Fs[0].device
         if self._grouped([f.shape[1] for f in Fs], M, d):
             if keep is None and draw_p > 0.0:
-                X, keep = ops.proj_forward(Fs, Ws, bs, draw=(draw_p, ops._rng_state(dev)), scale=scale)
+                X, keep = ops.proj_forward(Fs, Ws, bs, draw=(draw_p, ops._rng_state(dev)), scale=scale,
+                                           blocks=ops.proj_step_blocks(dev))
                 if not external_tick:
                     ops.tick_rng(dev)
                 return X, keep
-            return ops.proj_forward(Fs, Ws, bs, keep=keep, scale=scale)[0], keep
+            return ops.proj_forward(Fs, Ws, bs, keep=keep, scale=scale, blocks=ops.proj_step_blocks(Fs[0].device))[0], keep
         if keep is None and draw_p > 0.0:
             keep = ops.dropout_masks(len(Fs), M, d, draw_p, dev, **({"external_tick": True} if external_tick else {}))
         cols = [ops._linear_raw(F_, W, b, None if keep is None else keep[m], scale)
@@ -159,7 +160,7 @@ class HipBackend:
         nm = len(Fs)
         M, d = Fs[0].shape[0], G.shape[1] // nm
         if self._grouped([f.shape[1] for f in Fs], M, d):
-            return ops.proj_wgrad(G, Fs, want_bias=want_bias)
+            return ops.proj_wgrad(G, Fs, want_bias=want_bias, blocks=ops.proj_step_blocks(G.device))
         gWs, gbs = [], []
         for m, F_ in enumerate(Fs):
             Gm = G[:, m * d:(m + 1) * d].contiguous()

@@ -108,7 +108,9 @@ class _HotNode(torch.autograd.Function):
         draw = None
         if keep is None and p_drop > 0.0:
             draw = (p_drop, ops._rng_state(dev))
-        X, keep_used = ops.proj_forward(Fs, Ws, bs, keep=keep, draw=draw, scale=scale)
+        # with the GCN chain forked beside it the projection asks for 13/16 of the CUs (ops.proj_step_blocks)
+        pblocks = ops.proj_step_blocks(dev) if hot.overlap else 0
+        X, keep_used = ops.proj_forward(Fs, Ws, bs, keep=keep, draw=draw, scale=scale, blocks=pblocks)
         if draw is not None and not hot.external_ticks:
             ops.tick_rng(dev)
         if hot.overlap:
@@ -227,7 +229,8 @@ class _HotNode(torch.autograd.Function):
             gX = ops.spmm_mask_raw(ui, True, t, keep, d, scale)
         else:
             gX = ops._spmm_raw(ui, True, t, ops.EPI_NONE)
-        gW, gb = ops.proj_wgrad(gX, Fs, want_bias=any(has_b), adam=hot.adam)
+        gW, gb = ops.proj_wgrad(gX, Fs, want_bias=any(has_b), adam=hot.adam,
+                                blocks=ops.proj_step_blocks(gX.device) if hot.overlap else 0)
         if hot.overlap:
             # the embedding-table gradient (GCN chain) is complete before anything downstream of this node runs: the
             # chain ends long before the weight gradient above does, so the join never waits

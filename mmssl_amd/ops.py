@@ -377,8 +377,22 @@ def proj_images(F, transposed=False):
     return e[k]
 
 
-def _projx_ws(n, Ks, M, N, wgrad, dev):
-    nb = _lib.lib().mmssl_projx_workspace_bytes(n, _c_int_arr(Ks), M, N, int(wgrad))
+_CU_COUNT = {}
+
+
+def proj_step_blocks(dev):
+    """Block count for a projection launch that runs BESIDE other kernels (the step's GCN chain on a side stream): 13/16 of
+    the CUs. The split-precision launch is bound by the feature stream, which that many CUs still saturate; under a
+    full-width launch a side-stream SpMM took 63 us instead of 11 (profiles/r05/projx_blocks.txt)."""
+    key = torch.device(dev).index
+    n = _CU_COUNT.get(key)
+    if n is None:
+        n = _CU_COUNT[key] = torch.cuda.get_device_properties(dev).multi_processor_count
+    return max(1, (13 * n) // 16)
+
+
+def _projx_ws(n, Ks, M, N, wgrad, dev, blocks=0):
+    nb = _lib.lib().mmssl_projx_workspace_bytes(n, _c_int_arr(Ks), M, N, int(wgrad), int(blocks))
     if nb == 0:
         raise _lib.MmsslError("split-precision projection: unsupported modality list K=%s M=%d N=%d" % (Ks, M, N))
     ws = torch.empty(nb // 4 + 64, dtype=torch.float32, device=dev)
@@ -396,9 +410,9 @@ def proj_supported(Ks, M, N, wgrad=False):
     return _lib.lib().mmssl_proj_supported(len(Ks), _c_int_arr(Ks), int(M), int(N), int(bool(wgrad))) == 1
 
 
-def proj_forward(Fs, Ws, bs, keep=None, draw=None, scale=1.0):
+def proj_forward(Fs, Ws, bs, keep=None, draw=None, scale=1.0, blocks=0):
     """Y [M, 64 * n] = the projections dropout(F_g W_g^T + b_g) of all modalities side by side, one launch + one
-    epilogue launch. `keep`: uint8 [n, M, 64] given masks; `draw` = (p, device rng state tensor): the masks are drawn in
+    epilogue launch. `blocks` (split precision only): the launch's block count, 0 = one per CU (see proj_step_blocks). `keep`: uint8 [n, M, 64] given masks; `draw` = (p, device rng state tensor): the masks are drawn in
     the epilogue (same bytes as ops.dropout_masks(n, M, 64, p) at the same generator state) and returned; the caller
     advances the generator (dropout_masks's external-tick contract). Returns (Y, keep or None)."""
     n = len(Fs)
@@ -409,7 +423,7 @@ def proj_forward(Fs, Ws, bs, keep=None, draw=None, scale=1.0):
     split = PROJ_SPLIT and projx_supported(Ks, M, N)
     if split:
         imgs = [proj_images(f) for f in Fs]
-        ws, nb = _projx_ws(n, Ks, M, N, 0, dev)
+        ws, nb = _projx_ws(n, Ks, M, N, 0, dev, blocks)
     else:
         nb = _lib.lib().mmssl_proj_workspace_bytes(n, _c_int_arr(Ks), M, N, 0)
         if nb == 0:
@@ -424,8 +438,8 @@ def proj_forward(Fs, Ws, bs, keep=None, draw=None, scale=1.0):
             raise _lib.MmsslError("proj_forward: keep must be a contiguous uint8 [n, M, 64] tensor")
     if split:
         rc = _lib.lib().mmssl_projx_fwd_f32(n, _c_ptr_arr(imgs), _c_ptr_arr(Ws), _c_ptr_arr(bs), _c_int_arr(Ks), M, N,
-                                            _ptr(keep), _ptr(keep_out), _ptr(rng), p, float(scale), _ptr(Y), N * n, _ptr(ws),
-                                            nb, _lib.stream_ptr())
+                                            _ptr(keep), _ptr(keep_out), _ptr(rng), p, float(scale), _ptr(Y), N * n, int(blocks),
+                                            _ptr(ws), nb, _lib.stream_ptr())
         _lib.check(rc, "mmssl_projx_fwd_f32")
         return Y, (keep_out if draw is not None else keep)
     rc = _lib.lib().mmssl_proj_fwd_f32(n, _c_ptr_arr(Fs), _c_ptr_arr(Ws), _c_ptr_arr(bs), _c_int_arr(Ks), M, N, _ptr(keep),
@@ -435,7 +449,7 @@ def proj_forward(Fs, Ws, bs, keep=None, draw=None, scale=1.0):
     return Y, (keep_out if draw is not None else keep)
 
 
-def proj_wgrad(G, Fs, want_bias=True, adam=None):
+def proj_wgrad(G, Fs, want_bias=True, adam=None, blocks=0):
     """([gW_g [64, K_g]], [gb_g [64]]) from the ALREADY masked output gradient G [M, 64 * n] (modalities side by side)
     and the feature matrices, one launch + one epilogue launch. `adam` (optim.FusedAdamW.fused_slots): the epilogue also
     applies the AdamW update of the projection weights / biases to the gradient it has just summed."""
@@ -448,10 +462,10 @@ def proj_wgrad(G, Fs, want_bias=True, adam=None):
     gb = [torch.empty(N, dtype=torch.float32, device=dev) for _ in Ks] if want_bias else None
     if PROJ_SPLIT and projx_supported(Ks, M, N):
         imgs = [proj_images(f, transposed=True) for f in Fs]
-        ws, nb = _projx_ws(n, Ks, M, N, 1, dev)
+        ws, nb = _projx_ws(n, Ks, M, N, 1, dev, blocks)
         if adam is None:
             rc = _lib.lib().mmssl_projx_wgrad_f32(n, _ptr(G), G.stride(0), _c_ptr_arr(imgs), _c_int_arr(Ks), M, N,
-                                                  _c_ptr_arr(gW), _c_ptr_arr(gb) if gb else None, _ptr(ws), nb,
+                                                  _c_ptr_arr(gW), _c_ptr_arr(gb) if gb else None, int(blocks), _ptr(ws), nb,
                                                   _lib.stream_ptr())
             _lib.check(rc, "mmssl_projx_wgrad_f32")
             return gW, gb
@@ -461,7 +475,7 @@ def proj_wgrad(G, Fs, want_bias=True, adam=None):
             n, _ptr(G), G.stride(0), _c_ptr_arr(imgs), _c_int_arr(Ks), M, N, _c_ptr_arr(gW), _c_ptr_arr(gb) if gb else None,
             _c_ptr_arr(a["W"]), _c_ptr_arr(a["mW"]), _c_ptr_arr(a["vW"]), _c_ptr_arr(a["b"]) if bias else None,
             _c_ptr_arr(a["mb"]) if bias else None, _c_ptr_arr(a["vb"]) if bias else None, _ptr(a["state"]), a["lr"],
-            a["beta1"], a["beta2"], a["eps"], a["weight_decay"], 1 if a["pre_ticked"] else 0, _ptr(ws), nb,
+            a["beta1"], a["beta2"], a["eps"], a["weight_decay"], 1 if a["pre_ticked"] else 0, int(blocks), _ptr(ws), nb,
             _lib.stream_ptr())
         _lib.check(rc, "mmssl_projx_wgrad_adamw_f32")
         return gW, gb

@@ -14,7 +14,7 @@ def main(path, which=12):
             rows.append((r["Kernel_Name"], int(r["Start_Timestamp"]), int(r["End_Timestamp"]),
                          r.get("Queue_Id", r.get("Stream_Id", "?"))))
     rows.sort(key=lambda r: r[1])
-    marker = ([a.split("=", 1)[1] for a in sys.argv if a.startswith("--marker=")] or ["prep_kernel"])[0]
+    marker = ([a.split("=", 1)[1] for a in sys.argv if a.startswith("--marker=")] or ["::prep_kernel("])[0]
     idx = [i for i, r in enumerate(rows) if marker in r[0]]
     which = min(which, len(idx) - 2)
     step = rows[idx[which]:idx[which + 1]]

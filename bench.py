@@ -310,6 +310,77 @@ def spmm_hbm_record(iters=20):
     return out
 
 
+def _time_us(fn, iters, warm=3):
+    """HIP events on the current stream around `iters` eager calls of fn() (after `warm` untimed ones)."""
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / iters
+
+
+def f_rows_record(a, step, raw, plans):
+    """SURVEY 8f rows on the bench shape, each on its own (HIP events, eager launches, inputs resident):
+      u_sim    Trainer.u_sim_calculation (main.py:283-298): [B, d] . [d, I] with the train-row mask and the row L2
+               normalisation fused (ops.usim forward) - 5 calls per reference batch. HBM-bound on the [B, I] score write
+               (+ its re-read by the scale pass): bytes = 2 * 4 B I + 4 (B + I) d.
+      eval     one evaluation block of utility/batch_test.py:112-169 for 1024 users: scores with the training items at
+               -inf + top-max(Ks)=50 per row + hit membership (ops.sim_rows / topk_rows / rows_membership).
+      rebuild  the device-side modal-graph rebuild (main.py:378-405) from B * k (user, item) pairs: CSR + transpose + plans
+               of both directions (graph.DeviceGraphPair.rebuild), k = int(I * m_topk_rate) as the reference computes it
+               (1 for this shape), and the top-k selection that feeds it."""
+    from mmssl_amd import ops
+    from mmssl_amd.graph import DeviceGraphPair
+    m = step.model
+    U, I = raw.shape
+    d = a.d
+    B = a.batch
+    dev = m.user_id_embedding.weight.device
+    g = torch.Generator().manual_seed(11)
+    ua = torch.randn(U, d, generator=g).to(dev)
+    ia = torch.randn(I, d, generator=g).to(dev)
+    users = torch.randperm(U, generator=g)[:B].to(dev)
+    out = {}
+    with torch.no_grad():
+        us = _time_us(lambda: ops.usim(users, ua, ia, plans[0]), 200)
+        by = 2 * 4.0 * B * I + 4.0 * (B + I) * d
+        out["u_sim"] = {"what": "[%d, %d] masked, row-normalised scores (ops.usim forward)" % (B, I), "us": round(us, 1),
+                        "algorithmic_MB": round(by * 1e-6, 1), "GBps": round(by / us * 1e-3, 1),
+                        "frac_hbm": round(by / us * 1e-3 / HBM_PEAK_GBPS, 3)}
+        # evaluation block: the train CSR as the mask (int32 rowptr / sorted cols on the device), positives = the train rows too
+        rp = torch.from_numpy(raw.indptr.astype(np.int32)).to(dev)
+        cols = torch.from_numpy(raw.indices.astype(np.int32)).to(dev)
+
+        def eval_block():
+            rate, _ = ops.sim_rows(ua, ia, qidx=users, mask=(rp, cols), mask_value=float("-inf"))
+            order = ops.topk_rows(rate, 50)
+            return ops.rows_membership(rp, cols, users, order)
+        us = _time_us(eval_block, 50)
+        out["eval"] = {"what": "score + mask + top-50 + hit membership for %d users x %d items" % (B, I), "us": round(us, 1),
+                       "ms_per_1k_users": round(us * 1e-3 * 1000.0 / B, 3), "users_per_s": round(B / us * 1e6, 1)}
+        k = max(1, int(I * 0.0001))
+        S = torch.randn(B, I, generator=g).to(dev)
+        pair = DeviceGraphPair(U, I, DeviceGraphPair.MAX_PAIRS)
+
+        def rebuild():
+            ids = ops.topk_rows(S, k)
+            pair.rebuild(users.repeat(k), ids.reshape(-1))
+        us_all = _time_us(rebuild, 100)
+        ids = ops.topk_rows(S, k)
+        uu, ii = users.repeat(k), ids.reshape(-1)
+        us_rb = _time_us(lambda: pair.rebuild(uu, ii), 100)
+        out["modal_graph_rebuild"] = {"what": "top-%d of [%d, %d] scores, then CSR + transpose + plans of both directions from "
+                                              "%d pairs, all on the device" % (k, B, I, B * k),
+                                      "pairs": B * k, "us_topk_plus_rebuild": round(us_all, 1), "us_rebuild": round(us_rb, 1)}
+        pair.destroy()
+    return out
+
+
 def first_step_loss(a, step, raw, batch):
     """HIP side of the loss check: the loss of ONE hot-path forward on the bench model's initial parameters with
     injected dropout masks. Returns (loss, snapshot of the inputs) — cpu_baseline() evaluates the CPU oracle on the
@@ -428,7 +499,23 @@ def cpu_baseline(a, raw, mats, budget_s=20.0, first=None):
                     k += 1
                 gcn["%s_%dthr" % (fmt, threads)] = round(2 * a.gcn_layers * raw.nnz / ((time.time() - t0) / k), 1)
     torch.set_num_threads(min(32, os.cpu_count() or 1))
+    # the evaluation's CPU form (batch_test.py:21-36, 112-169: score GEMM, then per user a heap selection over the
+    # non-training items + the metric formulas; the reference forks a Pool over cores // 5 workers): 128 users, one process
+    eval_cpu = None
+    try:
+        gq = torch.Generator().manual_seed(11)
+        ua_c, ia_c = torch.randn(U, d, generator=gq), torch.randn(I, d, generator=gq)
+        us_c = torch.randperm(U, generator=gq)[:128].tolist()
+        tr_items = {u: raw.indices[raw.indptr[u]:raw.indptr[u + 1]].tolist() for u in us_c}
+        t0 = time.time()
+        O.evaluate(ua_c, ia_c, us_c, tr_items, {u: set(tr_items[u][:1]) for u in us_c}, [10, 20, 50])
+        el = time.time() - t0
+        eval_cpu = {"ms_per_1k_users": round(el * 1e3 * 1000.0 / len(us_c), 1), "users": len(us_c), "processes": 1,
+                    "kind": "port (oracle.evaluate: torch-CPU scores + per-user stable ranking)"}
+    except Exception as e:       # never lose the line over the side record
+        eval_cpu = {"error": repr(e)[:200]}
     return {"value": round(n_spmm * raw.nnz / dt_s, 1), "unit": "edge.layers/s", "cores": torch.get_num_threads(),
+            "eval_cpu": eval_cpu,
             "host_cores": os.cpu_count(), "gcn_forward_edge_layers_per_s": gcn, "loss_check": check,
             "kind": "port", "ms_per_step": round(dt_s * 1e3, 1),
             "sample": "%d steps of the same %s-shape step (fwd+losses+bwd+AdamW) by oracle/mmssl_oracle.py "
@@ -535,6 +622,8 @@ def main():
     ap.add_argument("--proj", choices=["split", "f32"], default="split",
                     help="grouped projection kernels: split = exact 3-way bf16 cut, six partial products on the bf16 matrix pipe "
                          "(fp32-accurate, default); f32 = the fp32-MFMA kernels (A/B)")
+    ap.add_argument("--no-frows", action="store_true", dest="no_frows", help="skip the `f_rows` record (u_sim / evaluation / "
+                    "modal-graph rebuild timings)")
     ap.add_argument("--no-hbm", action="store_true", dest="no_hbm", help="skip the HBM-resident SpMM record (`spmm_hbm`)")
     ap.add_argument("--share-gpu", action="store_true", dest="share_gpu",
                     help="test aid: every rank on GPU 0, process group on gloo moving device tensors (RCCL refuses two ranks on "
@@ -545,6 +634,10 @@ def main():
                     help="sharded step: item-side = user-row blocks only, every collective of item-table size; "
                          "gather-both = user AND item row blocks, all-gather of both tables (round-3 scheme); halo = item-side "
                          "exchanging only the item rows a rank's edges reference (all-to-all of row lists)")
+    ap.add_argument("--replicate-feats", choices=["auto", "on", "off"], default="auto", dest="replicate_feats",
+                    help="item-side scheme: keep the whole constant feature matrices on every rank and project all items "
+                         "locally, so the projected features never travel (auto: by dist.choose_replicate_feats - on for "
+                         "configs[4]'s narrow features, off for the Baby shape)")
     ap.add_argument("--chunks", type=int, default=0,
                     help="sharded step: column chunks per collective (chunk c's SpMM runs under chunk c+1's collective); "
                          "0 = by size (1 below 64 MB per collective, else 2-4)")
@@ -645,9 +738,14 @@ def main():
             # AFTER the timed region: building the 12.5 M-edge graph takes seconds of host time, during which the GPU
             # clocks fall back - in front of the short timed region that cost the driver's 20-step command 5-10 %
             out["spmm_hbm"] = spmm_hbm_record()
+    if a.only == "all" and not a.no_frows:
+        out["f_rows"] = f_rows_record(a, step, raw, plans)
     if not a.no_cpu_baseline and a.only == "all":
         out["cpu_baseline"] = cpu_baseline(a, raw, mats, first=first)
         out["loss_check"] = out["cpu_baseline"].pop("loss_check")
+        ev = out["cpu_baseline"].pop("eval_cpu", None)
+        if ev and "f_rows" in out:
+            out["f_rows"]["eval"]["cpu"] = ev
     print(json.dumps(out))
 
 
@@ -678,7 +776,8 @@ def timed_sharded(a, rank, world, dev, scaling, want_graph):
     n_users, n_items = stats["n_users"], stats["n_items"]
     # communication of one step: what was issued, and how long those collectives take on their own
     log = stats["comm_log"]
-    comm = {"scheme": stats["scheme"], "column_chunks": stats["chunks"], "collectives_per_step": len(log),
+    comm = {"scheme": stats["scheme"], "replicate_feats": stats.get("replicate_feats", False), "column_chunks": stats["chunks"],
+            "collectives_per_step": len(log),
             "bytes_per_step": int(sum(b for _, _, b in log)),
             "by_kind": {k: [sum(1 for x in log if x[0] == k), int(sum(x[2] for x in log if x[0] == k))]
                         for k in ("all_gather", "reduce_scatter", "all_reduce", "halo_gather", "halo_reduce")

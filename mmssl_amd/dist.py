@@ -448,12 +448,36 @@ class GatherBatchRowsMulti(torch.autograd.Function):
 # ---------------------------------------------------------------------------------------------
 # sharded model + step
 # ---------------------------------------------------------------------------------------------
+def _pad_rows(t, n_pad):
+    """All rows of a global [n, ...] tensor, zero-padded to n_pad rows."""
+    if t.shape[0] == n_pad:
+        return t.clone()
+    out = torch.zeros((n_pad,) + tuple(t.shape[1:]), dtype=t.dtype)
+    out[:t.shape[0]] = t
+    return out
+
+
+def choose_replicate_feats(n_items_pad, feat_dims, d, world, link_gbs=60.0, tflops=90.0):
+    """Should the item-side scheme replicate the feature matrices (ShardedMMSSL(replicate_feats=True))? Compares, per step
+    and rank, the link time of the two collectives it removes - (N-1)/N of [I, nm d] fp32 each, spread over N-1 links -
+    with the time of the extra projection flops (forward + weight gradient over all items instead of 1/N of them).
+    configs[4] (two 128-wide features, d = 128, N = 8): 4.3 ms of link time against 1.3 ms of flops -> True; the Baby
+    shape x 8 (4096 + 1024 wide): 0.3 ms against 1.9 ms -> False."""
+    if world <= 1:
+        return False
+    nm = len(feat_dims)
+    saved_s = 2.0 * n_items_pad * nm * d * 4.0 / world / (link_gbs * 1e9)           # per link: (N-1)/N * bytes / (N-1)
+    extra_s = 2.0 * 2.0 * (world - 1.0) / world * n_items_pad * float(sum(feat_dims)) * d / (tflops * 1e12)
+    return saved_s > 1.5 * extra_s
+
+
 class ShardedMMSSL(nn.Module):
     """MMSSL.forward (reference Models.py:171-220) over row shards. Parameters:
     replicated  image_trans.{weight,bias}, text_trans.{weight,bias}, w_self_attention_cat
     sharded     user_id_embedding [per_u, d], item_id_embedding [per_i, d]."""
 
-    def __init__(self, backend, cfg, ush, ish, state, image_feats, text_feats, group=None, scheme="gather-both", chunks=0):
+    def __init__(self, backend, cfg, ush, ish, state, image_feats, text_feats, group=None, scheme="gather-both", chunks=0,
+                 replicate_feats=False):
         """scheme: which local graphs forward() receives as (ui, iu) and how the propagation communicates:
              "gather-both"  ui = A_ui[U_r, :], iu = A_iu[I_r, :] (shard_graph): all-gather of the item table before
                             A_ui . X_i and of the user table before A_iu . X_u
@@ -461,10 +485,21 @@ class ShardedMMSSL(nn.Module):
                             collective is of item-table size (_ShardedItemSide)
              "halo"         the item-side graphs with COMPACT item columns (halo_graphs) + `model.halo` = their HaloPlan:
                             only the item rows this rank's edges reference travel (all-to-all of row lists)
-           chunks: column chunks per collective of the item-side node (0 = by size, see n_chunks)."""
+           chunks: column chunks per collective of the item-side node (0 = by size, see n_chunks).
+           replicate_feats (item-side scheme): every rank keeps the WHOLE constant feature matrices (Models.py:46-47) and
+                            projects all items itself, so the projected features never travel: the modal chain's all-gather
+                            of X [I, nm d] and its adjoint reduce-scatter disappear (its other two collectives stay) - 20 % of
+                            a step's bytes for configs[4] - for N times the projection flops per rank (the weight gradient
+                            each rank then forms from its users' partial g(X) is summed by the all-reduce the replicated
+                            parameters' gradients take anyway). Worth it when the features are narrow
+                            (choose_replicate_feats); injected / drawn dropout masks then cover ALL item rows and must be
+                            the same on every rank."""
         super().__init__()
         self.bk, self.cfg, self.ush, self.ish, self.group = backend, cfg, ush, ish, group
         self.scheme, self.chunks = scheme, int(chunks)
+        self.replicate_feats = bool(replicate_feats)
+        if self.replicate_feats and scheme != "item-side":
+            raise ValueError("replicate_feats needs scheme='item-side'")
         self.img_w = nn.Parameter(state["image_trans.weight"].clone())
         self.img_b = nn.Parameter(state["image_trans.bias"].clone())
         self.txt_w = nn.Parameter(state["text_trans.weight"].clone())
@@ -472,8 +507,9 @@ class ShardedMMSSL(nn.Module):
         self.w_cat = nn.Parameter(state["weight_dict.w_self_attention_cat"].clone())
         self.E_u = nn.Parameter(ush.slice_rows(state["user_id_embedding.weight"]))
         self.E_i = nn.Parameter(ish.slice_rows(state["item_id_embedding.weight"]))
-        self.register_buffer("image_feats", ish.slice_rows(torch.as_tensor(image_feats)), persistent=False)
-        self.register_buffer("text_feats", ish.slice_rows(torch.as_tensor(text_feats)), persistent=False)
+        rows = (lambda t: _pad_rows(torch.as_tensor(t), ish.n_pad)) if self.replicate_feats else ish.slice_rows
+        self.register_buffer("image_feats", rows(torch.as_tensor(image_feats)), persistent=False)
+        self.register_buffer("text_feats", rows(torch.as_tensor(text_feats)), persistent=False)
 
     def _forward_fused(self, graphs, keep_masks, modal_empty):
         bk, c = self.bk, self.cfg
@@ -507,9 +543,12 @@ class ShardedMMSSL(nn.Module):
             if self.scheme == "halo" and xch is None:
                 raise RuntimeError("ShardedMMSSL(scheme='halo') needs model.halo = HaloPlan(...) (see halo_graphs)")
             u_g, i_g, ss, MI, MU = _ShardedItemSide.apply(
-                2, scale, keep, ui, iu, c.n_ui_layers, c.model_cat_rate, bk, self.group, self.n_chunks(2), xch, u, i,
+                2, scale, keep, ui, iu, c.n_ui_layers, c.model_cat_rate, bk, self.group, self.n_chunks(2), xch,
+                bool(getattr(self, "replicate_feats", False)), u, i,
                 self.image_feats, self.text_feats, self.img_w, self.txt_w, self.img_b, self.txt_b)
         else:       # (one rank without forced collectives: both schemes are the same computation)
+            if getattr(self, "replicate_feats", False) and self.image_feats.shape[0] != self.E_i.shape[0]:
+                raise RuntimeError("replicate_feats on one rank: the features must have the rank's (= all) item rows")
             if getattr(self, "scheme", "") == "halo" and ui.shape[1] != self.ish.n_pad:
                 raise RuntimeError("scheme 'halo' on one rank without collectives: pass the item-side graphs (full item columns)")
             u_g, i_g, ss, MI, MU = _ShardedHotForward.apply(
@@ -562,6 +601,9 @@ class ShardedMMSSL(nn.Module):
         if self.last_fused:
             return self._forward_fused(graphs, keep_masks, modal_empty)
         # (feature widths the grouped projection does not take: the composed form below runs them)
+        if getattr(self, "replicate_feats", False):
+            raise RuntimeError("replicate_feats runs on the packed node only (feature widths %s, d = %d are not packable)" % (
+                [self.image_feats.shape[1], self.text_feats.shape[1]], c.embed_size))
         if getattr(self, "scheme", "gather-both") == "halo":
             raise RuntimeError("ShardedMMSSL(scheme='halo') runs on the packed node only (feature widths %s, d = %d are not "
                                "packable): use scheme='item-side' for this model" % (
@@ -1127,7 +1169,9 @@ class _ShardedItemSide(torch.autograd.Function):
     fused epilogue)."""
 
     @staticmethod
-    def forward(ctx, nm, scale, keep, ui, iuT, n_layers, r, bk, group, nc, xch, u0, i0, *flat):
+    def forward(ctx, nm, scale, keep, ui, iuT, n_layers, r, bk, group, nc, xch, repl, u0, i0, *flat):
+        # repl: the features are replicated - Fs hold ALL item rows, X is whole on every rank and never travels (see
+        # ShardedMMSSL.__init__); `keep` then covers all item rows too
         Fs, Ws, bs = flat[:nm], flat[nm:2 * nm], flat[2 * nm:3 * nm]
         draw_p, ext_tick = 0.0, False
         if isinstance(keep, tuple):                  # ("draw", p, external_tick): fresh masks from the device generator
@@ -1144,6 +1188,8 @@ class _ShardedItemSide(torch.autograd.Function):
         # side lanes. halo: its exchanges are all-to-alls, which a capture only takes from the ORIGIN stream - so there the
         # GCN chain (lane 0) and every exchange live on the current stream and the modal chain on ONE forked stream.
         swap = isinstance(xch, HaloPlan)
+        if repl and swap:
+            raise RuntimeError("replicate_feats runs with the whole-table exchange (scheme 'item-side'), not the halo plan")
         G = _Lanes(bk, u0, nc, first_is_current=swap, via_main=swap)
         M = _Lanes(bk, u0, nc, base=nc, first_is_current=not swap, one_stream=swap)
         # Every table the LANES write is allocated here, on the origin stream BEFORE the fork: the caching allocator may hand
@@ -1188,7 +1234,10 @@ class _ShardedItemSide(torch.autograd.Function):
                 for c in range(nc):
                     G.to_main(c)
                     M.to_main(c)
-                    fulls.append(tuple(xch.gather_pair(i_c[c], X_v[c].contiguous() if nc > 1 else X)) + (G.mark(),))
+                    if repl:        # X is whole here already: only the GCN table travels (X_v[c]: a column-chunk view)
+                        fulls.append((xch.gather(i_c[c]), X_v[c], G.mark()))
+                    else:
+                        fulls.append(tuple(xch.gather_pair(i_c[c], X_v[c].contiguous() if nc > 1 else X)) + (G.mark(),))
                 for c, (i_full, X_full, ev) in enumerate(fulls):
                     G.after(c, ev)
                     M.after(c, ev)
@@ -1258,7 +1307,7 @@ class _ShardedItemSide(torch.autograd.Function):
         inv = 1.0 / (n_layers + 1)
         u_g, i_g, ss = bk.fuse_fwd(us, MU, its, MI, inv, nm, r)
         ctx.save_for_backward(MU, MI, us[-1], its[-1], keep, *Fs)
-        ctx.cfg = (nm, float(scale), ui, iuT, n_layers, float(r), inv, bk, g, [b is not None for b in bs], nc, xch)
+        ctx.cfg = (nm, float(scale), ui, iuT, n_layers, float(r), inv, bk, g, [b is not None for b in bs], nc, xch, bool(repl))
         ctx.set_materialize_grads(False)
         return u_g, i_g, ss, MI, MU
 
@@ -1266,7 +1315,7 @@ class _ShardedItemSide(torch.autograd.Function):
     def backward(ctx, Gu, Gi, g_ss, G_MI, G_MU):
         MU, MI, uG, iG, keep = ctx.saved_tensors[:5]
         Fs = ctx.saved_tensors[5:]
-        nm, scale, ui, iuT, n_layers, r, inv, bk, g, has_b, nc, xch = ctx.cfg
+        nm, scale, ui, iuT, n_layers, r, inv, bk, g, has_b, nc, xch, repl = ctx.cfg
         per_u, per_i, d = MU.shape[0], MI.shape[0], uG.shape[1]
         wm = nm * d
         Gu = Gu.contiguous() if Gu is not None else torch.zeros_like(uG)
@@ -1348,7 +1397,10 @@ class _ShardedItemSide(torch.autograd.Function):
                 for c, (part_g, part_m) in enumerate(parts):
                     G.to_main(c)
                     M.to_main(c)
-                    rg, gX_c[c] = xch.reduce_pair(part_g, part_m)
+                    if repl:        # g(X) stays a PARTIAL over this rank's users, whole rows: the weight gradient formed from
+                        rg, gX_c[c] = xch.reduce(part_g), part_m      # it is summed by the replicated parameters' all-reduce
+                    else:
+                        rg, gX_c[c] = xch.reduce_pair(part_g, part_m)
                     G.uses(rg, [c])
                     M.uses(gX_c[c], [c])
                     for t_ in (part_g, part_m):
@@ -1389,7 +1441,7 @@ class _ShardedItemSide(torch.autograd.Function):
             gi0.record_stream(G.main)
         grads_b = [(gb[k] if (gb is not None and has_b[k]) else None) for k in range(nm)]
         bk.table_grads = (g_u0.data_ptr(), gi0.data_ptr())
-        return (None,) * 11 + (g_u0, gi0) + (None,) * nm + tuple(gW) + tuple(grads_b)
+        return (None,) * 12 + (g_u0, gi0) + (None,) * nm + tuple(gW) + tuple(grads_b)
 
 
 class ShardedHotPathStep:
@@ -1809,21 +1861,33 @@ def build_bench_step(a, rank, world, dev, scaling="weak"):
         e_iu = bk.make_graph(sp.csr_matrix((ish.per, ush.n_pad), dtype=np.float32))
     cfg = HotCfg()
     from . import ops as _ops
-    _ops.seed_dropout(2022 + rank, dev)            # independent masks per row shard
+    # item-side: replicate the constant features when that is cheaper than moving the projected ones (narrow features:
+    # configs[4]); `--replicate-feats on|off` overrides
+    rf = getattr(a, "replicate_feats", "auto")
+    repl = (scheme == "item-side" and world > 1
+            and (rf == "on" or (rf == "auto" and choose_replicate_feats(ish.n_pad, [dv, dt], a.d, world))))
+    _ops.seed_dropout(2022 if repl else 2022 + rank, dev)    # independent masks per row shard; replicated features: ONE mask set
     g = torch.Generator().manual_seed(2022)
 
     def xavier(rows, cols):
         bound = (6.0 / (rows + cols)) ** 0.5
         return (torch.rand(rows, cols, generator=g) * 2 - 1) * bound
     # features / embeddings are generated per shard (rank-dependent seeds); replicated weights from a shared seed
-    gi = torch.Generator().manual_seed(7 + 1000 * rank)
-    img_l = torch.randn(ish.per, dv, generator=gi)
-    txt_l = torch.randn(ish.per, dt, generator=gi)
+    def feat_block(q):
+        gq = torch.Generator().manual_seed(7 + 1000 * q)
+        return torch.randn(ish.per, dv, generator=gq), torch.randn(ish.per, dt, generator=gq)
+    if repl:                                      # every rank's block, on every rank
+        blocks = [feat_block(q) for q in range(world)]
+        img_l, txt_l = torch.cat([b[0] for b in blocks]), torch.cat([b[1] for b in blocks])
+        del blocks
+    else:
+        img_l, txt_l = feat_block(rank)
     ge = torch.Generator().manual_seed(99 + rank)
     model = ShardedMMSSL.__new__(ShardedMMSSL)
     nn.Module.__init__(model)
     model.bk, model.cfg, model.ush, model.ish, model.group = bk, cfg, ush, ish, None
     model.scheme, model.chunks = scheme, int(getattr(a, "chunks", 0))
+    model.replicate_feats = repl
     if scheme == "halo":
         model.halo = HaloPlan(need, ish, None, bk, dev)
     model.img_w = nn.Parameter(xavier(a.d, dv))
@@ -1852,7 +1916,7 @@ def build_bench_step(a, rank, world, dev, scaling="weak"):
     stats["edge_layers_global"] = int(t.item())
     stats["edge_layers"] = int(round(stats["edge_layers"]))
     stats.update(n_users=U, n_items=I, n_edges=E_global, local_users=ush.per, local_items=ish.per,
-                 local_edges=int(ui_l.nnz), scheme=scheme,
+                 local_edges=int(ui_l.nnz), scheme=scheme, replicate_feats=bool(repl),
                  chunks=(model.n_chunks(2) if (scheme in ("item-side", "halo") and not _solo(None)) else 1),
                  halo=(model.halo if scheme == "halo" else None),
                  halo_rows_fraction=(round(model.halo.bytes_fraction, 4) if scheme == "halo" else None))

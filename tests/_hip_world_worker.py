@@ -21,6 +21,8 @@ for p in (ROOT, os.path.join(ROOT, "oracle"), HERE):
 def main():
     rank, world, port = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
     modal, scheme, chunks, out_dir = sys.argv[4], sys.argv[5], int(sys.argv[6]), sys.argv[7]
+    repl = scheme.endswith("-repl")              # item-side with the constant feature matrices on every rank
+    scheme = scheme.replace("-repl", "")
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -29,7 +31,7 @@ def main():
     from mmssl_amd import dist as md
     dev = torch.device("cuda", 0)
     if modal == "baby":
-        return baby(rank, world, scheme, chunks, out_dir, md, dev)
+        return baby(rank, world, scheme, chunks, out_dir, md, dev, repl)
     if modal == "synth_full":
         return synth_full(rank, world, scheme, chunks, out_dir, md, dev)
     fx, d, raw, U, I, state, users, pos, neg, img_raw, txt_raw = T._global_problem(modal)
@@ -44,14 +46,16 @@ def main():
         return bk.make_graph(md.shard_graph(ui, ush, ish)), bk.make_graph(md.shard_graph(iu, ish, ush))
     need = []
     graphs = T._local_pair(md, bk, O, raw, ush, ish, scheme, need) + row_pair(img_raw) + row_pair(txt_raw)
-    model = md.ShardedMMSSL(bk, cfg, ush, ish, state, d["image_feat"], d["text_feat"], scheme=scheme, chunks=chunks).to(dev).train()
+    model = md.ShardedMMSSL(bk, cfg, ush, ish, state, d["image_feat"], d["text_feat"], scheme=scheme, chunks=chunks,
+                            replicate_feats=repl).to(dev).train()
     if scheme == "halo":
         model.halo = md.HaloPlan(need[0], ish, None, bk, dev)
     step = md.ShardedHotPathStep(model, graphs, 48, I, modal_empty=(modal.replace("_drop", "") == "empty_shortcut"),
                                  optimizer=False)
     step.set_batch(torch.stack([users, pos, neg]).to(dev))
     if drop:
-        step.keep_masks = tuple(ish.slice_rows(k.to(torch.uint8)).to(dev) for k in T._global_masks(I))
+        rows = (lambda k: md._pad_rows(k, ish.n_pad)) if repl else ish.slice_rows
+        step.keep_masks = tuple(rows(k.to(torch.uint8)).to(dev) for k in T._global_masks(I))
     total = step.backward()
     torch.cuda.synchronize()
     assert model.last_fused
@@ -64,7 +68,7 @@ def main():
     dist.destroy_process_group()
 
 
-def baby(rank, world, scheme, chunks, out_dir, md, dev):
+def baby(rank, world, scheme, chunks, out_dir, md, dev, repl=False):
     """BASELINE configs[3]: the Amazon-Baby graph cut `world` ways (35598 users / 18357 items: uneven last blocks), one
     sharded step with injected dropout masks; the parent holds the oracle's loss and gradients."""
     import scipy.sparse as sp
@@ -83,11 +87,12 @@ def baby(rank, world, scheme, chunks, out_dir, md, dev):
     e_iu = bk.make_graph(sp.csr_matrix((ish.per, ush.n_pad), dtype=np.float32))
     graphs = (bk.make_graph(ui_l), bk.make_graph(iu_l), e_ui, e_iu, e_ui, e_iu)
     model = md.ShardedMMSSL(bk, pb["cfg"], ush, ish, pb["state"], pb["img"].numpy(), pb["txt"].numpy(), scheme=scheme,
-                            chunks=chunks).to(dev).train()
+                            chunks=chunks, replicate_feats=repl).to(dev).train()
     if scheme == "halo":
         model.halo = md.HaloPlan(need, ish, None, bk, dev)
     step = md.ShardedHotPathStep(model, graphs, 1024, I, modal_empty=True, optimizer=False)
-    step.keep_masks = tuple(ish.slice_rows(k.to(torch.uint8)).to(dev) for k in pb["km"])
+    rows = (lambda k: md._pad_rows(k, ish.n_pad)) if repl else ish.slice_rows
+    step.keep_masks = tuple(rows(k.to(torch.uint8)).to(dev) for k in pb["km"])
     step.set_batch(pb["batch"].to(dev))
     total = step.backward()
     torch.cuda.synchronize()
@@ -121,10 +126,11 @@ def synth_full(rank, world, scheme, chunks, out_dir, md, dev):
     e_iu = bk.make_graph(sp.csr_matrix((ish.per, ush.n_pad), dtype=np.float32))
     pb = synth.stress_inputs(U, I)
     cfg = O.Cfg(embed_size=128, n_ui_layers=3, drop_rate=0.2, batch_size=1024)
+    repl = md.choose_replicate_feats(ish.n_pad, [pb["img"].shape[1], pb["txt"].shape[1]], 128, world)     # narrow features: True
     model = md.ShardedMMSSL(bk, cfg, ush, ish, pb["state"], pb["img"].numpy(), pb["txt"].numpy(), scheme=scheme,
-                            chunks=chunks).to(dev).train()
+                            chunks=chunks, replicate_feats=repl).to(dev).train()
     step = md.ShardedHotPathStep(model, tuple(graphs) + (e_ui, e_iu, e_ui, e_iu), 1024, I, modal_empty=True, optimizer=False)
-    step.keep_masks = tuple(ish.slice_rows(k).to(dev) for k in pb["keep"])
+    step.keep_masks = tuple((k if repl else ish.slice_rows(k)).to(dev) for k in pb["keep"])
     step.set_batch(pb["batch"].to(dev))
     del pb
     total = step.backward()
@@ -137,7 +143,8 @@ def synth_full(rank, world, scheme, chunks, out_dir, md, dev):
         loc = rows[(rows >= sh.lo) & (rows < sh.hi)] - sh.lo
         g[n] = dict(model.named_parameters())[n].grad[torch.from_numpy(loc).to(dev)].cpu()
     torch.save({"loss": float(total), "ush": (ush.lo, ush.hi, ush.n), "ish": (ish.lo, ish.hi, ish.n), "g": g,
-                "edges_global": int(E_global), "chunks": model.n_chunks(2)}, os.path.join(out_dir, "r%d.pt" % rank))
+                "edges_global": int(E_global), "chunks": model.n_chunks(2), "replicate_feats": bool(repl)},
+               os.path.join(out_dir, "r%d.pt" % rank))
     dist.barrier()
     dist.destroy_process_group()
 

@@ -84,6 +84,8 @@ def _worker(rank, world, port, modal, out_dir, fused=True, scheme="gather-both",
     drop = modal.endswith("_drop")           # injected dropout masks: the packed keep layout and its backward
     modal = modal.replace("_drop", "")
     cfg = O.Cfg(drop_rate=0.2 if drop else 0.0, batch_size=48, n_ui_layers=2)
+    repl = scheme.endswith("-repl")          # item-side with the feature matrices replicated on every rank
+    scheme = scheme.replace("-repl", "")
 
     def local_pair(m):
         ui, iu = O.csr_norm(m, True), O.csr_norm(m.T, True)
@@ -92,7 +94,8 @@ def _worker(rank, world, port, modal, out_dir, fused=True, scheme="gather-both",
     ui, iu = _local_pair(md, bk, O, raw, ush, ish, scheme, need)   # the interaction graph in the scheme's form
     a, b = local_pair(img_raw)                                   # (the modal id graphs always as row blocks)
     c, e = local_pair(txt_raw)
-    model = md.ShardedMMSSL(bk, cfg, ush, ish, state, d["image_feat"], d["text_feat"], scheme=scheme, chunks=chunks).train()
+    model = md.ShardedMMSSL(bk, cfg, ush, ish, state, d["image_feat"], d["text_feat"], scheme=scheme, chunks=chunks,
+                            replicate_feats=repl).train()
     if scheme == "halo":
         model.halo = md.HaloPlan(need[0], ish, None, bk, torch.device("cpu"))
         assert model.halo.n_need <= ish.n_pad and sum(model.halo.recv_rows) == model.halo.n_need
@@ -101,9 +104,18 @@ def _worker(rank, world, port, modal, out_dir, fused=True, scheme="gather-both",
     if scheme in ("item-side", "halo") and fused and world > 1:
         assert model.n_chunks(2) == max(chunks, 1)
     step.set_batch(users, pos, neg)
-    if drop:
-        step.keep_masks = tuple(ish.slice_rows(k.to(torch.uint8)) for k in _global_masks(I))
+    if drop:       # (replicated features: the masks cover ALL item rows on every rank)
+        rows = (lambda k: md._pad_rows(k, ish.n_pad)) if repl else ish.slice_rows
+        step.keep_masks = tuple(rows(k.to(torch.uint8)) for k in _global_masks(I))
+    md.COMM["log"] = []
     total = step.backward()
+    kinds = [k for k, _, _ in md.COMM["log"]]
+    md.COMM["log"] = None
+    if repl and world > 1 and fused:      # the modal chain's X never travels: 2 of its 4 table-sized collectives are gone
+        L, nc = cfg.n_ui_layers, max(chunks, 1)
+        extra = 0 if modal == "empty_shortcut" else 2          # the modal id graphs' own table gathers (and their adjoints)
+        want = (2 * L) * nc + nc + extra                         # (without replication: (2 L) nc + 2 nc + extra)
+        assert kinds.count("all_gather") == want and kinds.count("reduce_scatter") == want, kinds
     torch.save({"loss": float(total), "ush": (ush.lo, ush.hi, ush.n), "ish": (ish.lo, ish.hi, ish.n),
                 "g": {n: p.grad.clone() if p.grad is not None else None for n, p in model.named_parameters()}},
                os.path.join(out_dir, "r%d.pt" % rank))
@@ -140,6 +152,9 @@ def _reference(modal):
     (2, "full", True, "item-side", 1), (3, "full", True, "item-side", 2), (3, "full_drop", True, "item-side", 2),
     (2, "empty_shortcut", True, "item-side", 2), (3, "empty", True, "item-side", 1), (3, "full", False, "item-side", 0),
     (8, "full_drop", True, "item-side", 2),
+    # item-side with the constant feature matrices replicated: the projected features never travel
+    (2, "full", True, "item-side-repl", 1), (3, "full_drop", True, "item-side-repl", 2), (3, "empty_shortcut", True, "item-side-repl", 1),
+    (8, "full_drop", True, "item-side-repl", 2),
     # halo scheme: only the item rows a rank's edges reference travel (all-to-all of row lists + selection SpMM)
     (2, "full", True, "halo", 1), (3, "full_drop", True, "halo", 2), (3, "empty_shortcut", True, "halo", 1),
     (8, "full_drop", True, "halo", 2)])

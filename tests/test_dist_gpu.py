@@ -136,7 +136,8 @@ def test_sharded_packed_node_at_d128_per_modality_projection_equals_oracle(solo_
                                                        (3, "empty_shortcut", "item-side", 1), (3, "full", "gather-both", 0),
                                                        (3, "baby", "item-side", 2), (8, "baby", "item-side", 1),
                                                        (8, "baby", "gather-both", 0), (3, "full_drop", "halo", 2),
-                                                       (8, "baby", "halo", 1)])
+                                                       (8, "baby", "halo", 1), (3, "full_drop", "item-side-repl", 2),
+                                                       (8, "baby", "item-side-repl", 1)])
 def test_hip_backend_at_world_2_3_8_on_one_gpu(tmp_path, world, modal, scheme, chunks):
     """dist.HipBackend at world size > 1: `world` processes share GPU 0 (their group is gloo - RCCL refuses two ranks on one
     device - moving DEVICE tensors), each runs its shard of the sharded step on the HIP kernels: real per-rank partial

@@ -203,7 +203,8 @@ def test_full_graph_2m_by_1m_100m_edges_on_one_gpu_matches_cpu_oracle_golden(sol
 
 def test_eight_ranks_sharing_the_gpu_run_configs4_at_full_size(tmp_path, golden):
     """(c) 8 processes, every rank on GPU 0 over gloo, each generating only its own 250 000-user block (item-side scheme,
-    automatic column chunks): the job's loss equals the one-GPU golden within 1e-4 on every rank, the sampled gradient
+    automatic column chunks, the narrow constant features replicated so that the projected ones never travel - what
+    dist.choose_replicate_feats picks for this shape): the job's loss equals the one-GPU golden within 1e-4 on every rank, the sampled gradient
     rows of each rank's table blocks match."""
     import test_dist_cpu as T
     world, port = 8, T._free_port()
@@ -214,6 +215,6 @@ def test_eight_ranks_sharing_the_gpu_run_configs4_at_full_size(tmp_path, golden)
     assert all(p.returncode == 0 for p in procs), "\n".join(o[-1500:] for o in outs)
     for r in range(world):
         o = torch.load(os.path.join(str(tmp_path), "r%d.pt" % r))
-        assert o["edges_global"] == 100_000_000 and o["chunks"] == 4
+        assert o["edges_global"] == 100_000_000 and o["chunks"] == 4 and o["replicate_feats"]
         picks = {n: (owned_sample(golden, n, *o[sh][:2])[0], o["g"][n]) for n, sh in (("E_u", "ush"), ("E_i", "ish"))}
         _check_against_golden(golden, o["loss"], o["g"], picks)

@@ -1,71 +1,92 @@
-"""Bytes a rank receives per hot-path step under row sharding, per xGMI link, against its compute time - the arithmetic
-behind DESIGN.md section 6 (runs anywhere: python tools/shard_bytes.py). Three schemes for the 2L GCN products and the
-packed modal chain of one step (forward gathers + backward reduce-scatters move the same bytes):
+"""Bytes a rank moves per hot-path step under row sharding, per xGMI link, against its compute time and the collectives'
+launch latency - the arithmetic behind DESIGN.md section 6 (runs anywhere: python tools/shard_bytes.py [--link-gbs ...]).
 
-  gather-both      (built, round 3: mmssl_amd/dist.py _ShardedHotForward, bench.py --scheme gather-both) all-gather the item
-                   table before A_ui . X_i AND the user table before A_iu . X_u; the adjoints are reduce-scatters of the
-                   same sizes
-  item-collectives (built, round 4, the default: _ShardedItemSide, --scheme item-side) every rank keeps only its user-row
-                   block of the graph; A_iu . X_u becomes local partial products over ALL items + a reduce-scatter of
-                   item-table size (its adjoint a gather of item-table size): every collective moves item-table bytes; with
-                   --chunks c every collective and the products around it are cut into c column chunks on c lanes, so
-                   that a chunk's product runs under the next chunk's transfer
-  halo             (built, round 4: --scheme halo) item-collectives moving only the item rows a rank's edges
-                   reference: x 0.92 / 0.76 / 0.56 of the bytes for the Baby-shaped weak-scaling graph at N = 2 / 4 / 8 (measured
-                   fractions of referenced rows), x 0.98 for configs[4]
-  2-D (R x C)      (not built) ranks in an R x C grid, A cut in both directions: a gather inside a column group and a
-                   reduce-scatter inside a row group per product
+Schemes for the 2 L GCN products and the packed modal chain of one step (every forward collective has an adjoint of the same
+size in the backward):
 
-Per-link time assumes one xGMI link per peer (full mesh, 8 GPUs) at `--link-gbs` per direction and that a rank's traffic
-spreads evenly over its N - 1 peers."""
+  gather-both       (built, round 3; kept for A/B) all-gather the item table before A_ui . X_i AND the user table before
+                    A_iu . X_u; adjoints = reduce-scatters of the same sizes
+  item-side         (built, round 4, the default: dist._ShardedItemSide) a rank keeps only its users' edges; A_iu . X_u is a
+                    local partial product over ALL items + a reduce-scatter of item-table size: every collective moves
+                    item-table bytes. Per step: 2 L GCN-table passes (width d) + 2 modal passes (width nm d), twice
+                    (forward + backward) = (4 L d + 4 nm d) x I x 4 bytes of full buffers
+  item-side + repl  (built, round 5: ShardedMMSSL(replicate_feats=True)) the constant feature matrices live on every rank,
+                    every rank projects ALL items: the projected features X never travel and their gradient is consumed as a
+                    per-rank partial (the weight gradient is summed by the all-reduce the replicated parameters take
+                    anyway): 2 of the 4 modal passes disappear, for (N - 1) x the projection flops per rank
+  halo              (built, round 4) item-side moving only the item rows a rank's edges reference: x 0.98 of the bytes for
+                    configs[4] (every rank touches nearly every item), x 0.56 for the Baby-shaped weak-scaling graph at N = 8
+  2-D (R x C)       (not built) ranks in an R x C grid, A cut both ways: a gather inside a column group + a reduce-scatter
+                    inside a row group per product
+
+Model of a step at N ranks:  t = max(compute, link) + min(compute, link) / chunks + launches x latency
+  compute  = measured one-GPU time of the rank's share (+ the replicated projection's extra flops)
+  link     = bytes one rank receives / (N - 1) links / --link-gbs      (full mesh: one xGMI link per peer, traffic even)
+  chunks   = column chunks per collective (chunk c's product under chunk c+1's transfer: only 1 / chunks of the shorter side
+             stays exposed); launches x latency = collective launches per step x per-launch cost (RCCL on one rank, measured
+             round 4: ~20 us; a hand-written peer-to-peer store + flag would be ~3 us)
+Speed-up = one-GPU time of the WHOLE problem / t. For configs[4] that denominator is measured: 142.2 ms per step for the whole
+2M x 1M x 100M graph on one MI355X (profiles/r05_bench_synth_full_n1.json) - 8.0 x the 17.8 ms a rank's share costs."""
 import argparse
 
 ap = argparse.ArgumentParser()
-ap.add_argument("--link-gbs", type=float, default=70.0, help="achievable GB/s per xGMI link and direction")
+ap.add_argument("--link-gbs", type=float, nargs="*", default=[45.0, 50.0, 60.0, 70.0, 75.0],
+                help="achievable GB/s per xGMI link and direction (swept)")
 ap.add_argument("--layers", type=int, default=3)
+ap.add_argument("--latency-us", type=float, default=20.0, help="cost of one collective launch")
+ap.add_argument("--tflops", type=float, default=90.0, help="fp32 projection rate for the replicated-features extra work")
 a = ap.parse_args()
 
-SHAPES = {   # users, items, d, modal width, per-rank compute ms of one step (measured on one MI355X), weak: rows grow with N
-    "baby x N (weak)": dict(U=35598, I=18357, d=64, dm=128, ms=0.54, weak=True),
-    "configs[4] 2M x 1M (fixed, N = 8 is the config)": dict(U=2_000_000, I=1_000_000, d=128, dm=256, ms=16.4, weak=False),
-}
+N = 8
 
 
-def passes(U, I, d, dm, L):
-    """(bytes of item-table-sized passes, bytes of user-table-sized passes) per step, forward + backward."""
-    item = 2 * (L * I * d + I * dm) * 4        # gathers of items (fwd) + their reduce-scatters (bwd)
-    user = 2 * (L * U * d + U * dm) * 4
-    return item, user
+def step_ms(compute, link, chunks, launches):
+    return max(compute, link) + min(compute, link) / chunks + launches * a.latency_us * 1e-3
 
 
-for name, s in SHAPES.items():
+def table(name, I, U, d, nm, feat_dims, one_gpu_ms, rank_ms, weak):
     print(name)
-    for N in (2, 4, 8):
-        k = N if s["weak"] else 1
-        U, I = s["U"] * k, s["I"] * k
-        item, user = passes(U, I, s["d"], s["dm"], a.layers)
-        frac = (N - 1) / N
-        schemes = {"gather-both": (item + user) * frac, "item-collectives": 2 * item * frac}
-        if N == 8:
-            R, C = 2, 4                       # rows of A cut R ways (user side), columns C ways (item side)
-            # A_ui product: gather X_i inside a column group (R ranks share a column band), reduce-scatter partial user rows
-            # across the C ranks of a row group; A_iu product symmetric
-            per = lambda rows_g, rows_rs: ((R - 1) / R * rows_g / C + (C - 1) / C * rows_rs / R)       # noqa: E731
-            rows = lambda w: (per(I, U) + per(U, I)) * w * 4                                         # noqa: E731
-            schemes["2-D 2x4"] = 2 * (a.layers * rows(s["d"]) + rows(s["dm"]))
-        line = []
-        for nm, b in schemes.items():
-            per_link = b / (N - 1)
-            ms = per_link / (a.link_gbs * 1e9) * 1e3
-            line.append("%s %.0f MB/rank = %.0f MB/link = %.2f ms" % (nm, b / 1e6, per_link / 1e6, ms))
-        comp = s["ms"] if s["weak"] else s["ms"] * 8 / N
-        print("  N=%d  compute %.2f ms |  %s" % (N, comp, "  |  ".join(line)))
-        # what the built item-side scheme can reach: no overlap (links idle while the SpMMs run) .. perfect overlap with c
-        # column chunks (only the first chunk's transfer and the last chunk's product are exposed per collective)
-        link = schemes["item-collectives"] / (N - 1) / (a.link_gbs * 1e9) * 1e3
-        one = s["ms"] if s["weak"] else s["ms"] * 8
-        for c in (1, 2, 4):
-            t = max(comp, link) + (min(comp, link) / c if c > 1 else min(comp, link))
-            print("         item-side, %d chunk(s): %.2f ms per step -> %.1fx one GPU%s" % (
-                c, t, (one / t) if not s["weak"] else N * one / t / 1.0,
-                "" if c > 1 else "  (no overlap)"))
+    L = a.layers
+    frac = (N - 1) / N
+    full = {   # bytes of the full (gathered / to-be-scattered) buffers of one step on one rank
+        "gather-both": (2 * L * (I + U) * d + 2 * (I + U) * nm * d) * 4.0,
+        "item-side": (4 * L * I * d + 4 * I * nm * d) * 4.0,
+        "item-side + repl": (4 * L * I * d + 2 * I * nm * d) * 4.0,
+    }
+    R, C = 2, 4
+    per = lambda rows_g, rows_rs: ((R - 1) / R * rows_g / C + (C - 1) / C * rows_rs / R)       # noqa: E731
+    rows = lambda w: (per(I, U) + per(U, I)) * w * 4.0                                       # noqa: E731
+    recv2d = 2 * (L * rows(d) + rows(nm * d))
+    extra_ms = 2.0 * 2.0 * frac * I * sum(feat_dims) * d / (a.tflops * 1e12) * 1e3            # fwd + wgrad over all items
+    print("  one GPU, whole problem: %.1f ms;  one rank's share alone: %.2f ms;  replicated projection: +%.2f ms per rank" % (
+        one_gpu_ms, rank_ms, extra_ms))
+    for scheme, by in full.items():
+        recv = by * frac
+        print("  %-17s full buffers %6.2f GB / step, received %6.2f GB / rank, %5.0f MB / link" % (
+            scheme, by / 1e9, recv / 1e9, recv / (N - 1) / 1e6))
+    print("  %-17s (not built)                     received %6.2f GB / rank, %5.0f MB / link" % (
+        "2-D 2x4", recv2d / 1e9, recv2d / (N - 1) / 1e6))
+    print("  speed-up over one GPU at N = 8 (%s), 4 column chunks, launch latency %.0f us | 3 us:" % (
+        "weak: 8 x the rows" if weak else "strong: the same problem", a.latency_us))
+    print("    %-9s" % "GB/s/link" + "".join("%22s" % s for s in ("item-side", "item-side + repl", "2-D 2x4 (not built)")))
+    for gbs in a.link_gbs:
+        cells = []
+        for scheme, recv, comp, launches in (("item-side", full["item-side"] * frac, rank_ms, 14 * 4),
+                                             ("item-side + repl", full["item-side + repl"] * frac, rank_ms + extra_ms, 12 * 4),
+                                             ("2-D", recv2d, rank_ms, 28 * 4)):
+            link = recv / (N - 1) / (gbs * 1e9) * 1e3
+            t = step_ms(comp, link, 4, launches)
+            lat = launches * a.latency_us * 1e-3
+            t3 = t - lat + launches * 3e-3
+            tot = one_gpu_ms * (N if weak else 1)
+            cells.append("%5.1fx | %4.1fx (%4.1f ms)" % (tot / t, tot / t3, t))
+        print("    %-9.0f" % gbs + "".join("%22s" % c for c in cells))
+    print()
+
+
+# configs[4]: one-GPU whole-problem step and the per-rank share (1/8 of it: the SpMM time is linear in the edges)
+table("configs[4]: 2M users x 1M items, 100M edges, d = 128, two 128-wide features (strong scaling, N = 8 is the config)",
+      I=1_000_000, U=2_000_000, d=128, nm=2, feat_dims=(128, 128), one_gpu_ms=142.2, rank_ms=142.2 / 8, weak=False)
+# Baby x 8 (weak scaling: the driver's --gpus 8 default): a 0.49 ms step against >= 14 collective launches
+table("Amazon-Baby shape x 8 (weak scaling: every rank one Baby-sized share), d = 64, 4096 + 1024 wide features",
+      I=18357 * 8, U=35598 * 8, d=64, nm=2, feat_dims=(4096, 1024), one_gpu_ms=0.49, rank_ms=0.49, weak=True)

@@ -62,6 +62,31 @@ def main():
             n += 1
     out = {k: round(v / n * 1e3, 2) for k, v in acc.items()}
     out["phases_sum_ms"] = round(sum(acc.values()) / n * 1e3, 2)
+    # The D step split into its IN-SCOPE part (the model forward that feeds it and the three u_sim_calculation
+    # calls, rows a-5 and f-1) and the OUT-OF-SCOPE GAN arithmetic around them (Discriminator MLP forward / backward,
+    # Gumbel noise, gradient penalty, D's optimiser: SURVEY 2 rows 3 and 7), each piece timed on its own, synchronised
+    users, pos, neg = dg.sample()
+    tr._batch_idx(users, pos, neg)
+
+    def timed(fn, reps=5):
+        fn()
+        sync()
+        t = time.perf_counter()
+        for _ in range(reps):
+            r = fn()
+        sync()
+        return (time.perf_counter() - t) / reps * 1e3, r
+    with torch.no_grad():
+        t_fwd, outs = timed(lambda: tr.model(*tr._graphs()))
+        ua, ia, img_item, txt_item, img_user, txt_user = outs[:6]
+        t_usim, _ = timed(lambda: (tr.u_sim_calculation(users, ua, ia), tr.u_sim_calculation(users, img_user, img_item),
+                                   tr.u_sim_calculation(users, txt_user, txt_item)))
+    t_d, _ = timed(lambda: tr._discriminator_step(users))
+    out["d_step_parts_ms"] = {"model_forward_in_scope": round(t_fwd, 3), "u_sim_x3_in_scope": round(t_usim, 3),
+                              "gan_ops_out_of_scope": round(max(t_d - t_fwd - t_usim, 0.0), 3), "d_step_total": round(t_d, 3)}
+    t_g, _ = timed(lambda: tr._generator_step(a.batches + 50, users, pos, neg))
+    out["g_step_total_ms"] = round(t_g, 3)
+    out["in_scope_share_of_d_step"] = round((t_fwd + t_usim) / max(t_d, 1e-9), 4)
     # ... and the loop exactly as Trainer.train() runs it (next batch sampled while the device works)
     # (Trainer.train_batch: op by op with MMSSL_TRAINER_GRAPH=0, then on the two captured hot-path segments)
     base = a.batches

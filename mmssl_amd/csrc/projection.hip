@@ -176,7 +176,11 @@ __device__ __forceinline__ void wait_outstanding(int slices) {
   if (slices <= 0) vm_wait_n<0>();
   else if (slices == 1) vm_wait_n<PCS>();
   else if (slices == 2) vm_wait_n<2 * PCS>();
-  else vm_wait_n<3 * PCS>();
+  else if (slices == 3 || 4 * PCS > 63) vm_wait_n<3 * PCS>();
+  else if (slices == 4 || 5 * PCS > 63) vm_wait_n<(4 * PCS > 63 ? 63 : 4 * PCS)>();
+  else if (slices == 5 || 6 * PCS > 63) vm_wait_n<(5 * PCS > 63 ? 63 : 5 * PCS)>();
+  else if (slices == 6 || 7 * PCS > 63) vm_wait_n<(6 * PCS > 63 ? 63 : 6 * PCS)>();
+  else vm_wait_n<(7 * PCS > 63 ? 63 : 7 * PCS)>();
 }
 template <int PCS = kPieces>
 __device__ __forceinline__ void step_sync(int outstanding) {
@@ -686,7 +690,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 constexpr int kXAFloats = PT * PBK;                    // 8192 floats = 32 KB: one A slice
 constexpr int kXBBytes = 3 * PJ * PBK * 2;             // 12288 B: the three bf16 planes of one B slice
 constexpr int kXPieces = 6;                            // memory instructions per wave per slice: 4 loads of A + 2 DMA pieces of B
-constexpr int kXGRows = 128;                           // reduction rows per block of the G preparation kernel
+constexpr int kXGRows = 64;                            // reduction rows per block of the G preparation kernel
 
 __device__ __forceinline__ unsigned f2u(float x) { return __builtin_bit_cast(unsigned, x); }
 __device__ __forceinline__ float u2f(unsigned x) { return __builtin_bit_cast(float, x); }
@@ -728,8 +732,8 @@ __device__ __forceinline__ void tie4(floatx4& a, floatx4& b, floatx4& c, floatx4
   asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d)::"memory");
 }
 
-constexpr int kXDepth = 4;                             // slices in flight per wave: A in registers, B in the LDS ring
-constexpr int kXLdsBytes = kXDepth * kXBBytes;         // 48 KB: only the short operand passes through LDS
+// slices in flight per wave (template parameter of the kernel): A in registers, B in the LDS ring of that many stages
+constexpr int x_lds_bytes(int depth) { return depth * kXBBytes; }        // only the short operand passes through LDS
 
 // The long operand never touches LDS: a wave's MFMA rows are read by that wave alone, so each lane loads the 16 values of
 // its row straight into registers - four fully coalesced 1 KB loads per wave and slice out of an image laid out for
@@ -737,6 +741,7 @@ constexpr int kXLdsBytes = kXDepth * kXBBytes;         // 48 KB: only the short 
 // form of this kernel measured 92 us for the 387 MB stream: every byte paid the LDS-DMA path's ~6.4 TB/s chip-wide
 // ceiling TOGETHER with the L2-resident B planes, +37 % bytes). LDS carries the three bf16 planes of the short operand
 // only (12 KB per slice, kXDepth stages, one barrier per slice).
+template <int kXDepth>
 __global__ __launch_bounds__(kThreads) void projx_sk_kernel(Group P, int upb, int64_t total, int max_segs,
                                                             float* __restrict__ partials) {
   extern __shared__ __attribute__((aligned(16))) float ring[];
@@ -826,6 +831,10 @@ __global__ __launch_bounds__(kThreads) void projx_sk_kernel(Group P, int upb, in
     if (nk > 1) issue(std::integral_constant<int, 1>{}, 1);
     if (nk > 2) issue(std::integral_constant<int, 2>{}, 2);
     if (nk > 3) issue(std::integral_constant<int, 3>{}, 3);
+    if constexpr (kXDepth > 4) { if (nk > 4) issue(std::integral_constant<int, 4 % kXDepth>{}, 4); }
+    if constexpr (kXDepth > 5) { if (nk > 5) issue(std::integral_constant<int, 5 % kXDepth>{}, 5); }
+    if constexpr (kXDepth > 6) { if (nk > 6) issue(std::integral_constant<int, 6 % kXDepth>{}, 6); }
+    if constexpr (kXDepth > 7) { if (nk > 7) issue(std::integral_constant<int, 7 % kXDepth>{}, 7); }
     wait_outstanding<kXPieces>(min(nk, kXDepth) - 1);          // slice 0 has landed
     tie4(raw[0][0], raw[0][1], raw[0][2], raw[0][3]);
     bare_barrier();
@@ -837,6 +846,10 @@ __global__ __launch_bounds__(kThreads) void projx_sk_kernel(Group P, int upb, in
       if (kt + 1 < nk) step(std::integral_constant<int, 1>{}, kt + 1, f);
       if (kt + 2 < nk) step(std::integral_constant<int, 2>{}, kt + 2, f);
       if (kt + 3 < nk) step(std::integral_constant<int, 3>{}, kt + 3, f);
+      if constexpr (kXDepth > 4) { if (kt + 4 < nk) step(std::integral_constant<int, 4 % kXDepth>{}, kt + 4, f); }
+      if constexpr (kXDepth > 5) { if (kt + 5 < nk) step(std::integral_constant<int, 5 % kXDepth>{}, kt + 5, f); }
+      if constexpr (kXDepth > 6) { if (kt + 6 < nk) step(std::integral_constant<int, 6 % kXDepth>{}, kt + 6, f); }
+      if constexpr (kXDepth > 7) { if (kt + 7 < nk) step(std::integral_constant<int, 7 % kXDepth>{}, kt + 7, f); }
     }
     // accumulator image -> partial slot, in the forward kernel's plane order (the 32x32 C layout is dtype-independent)
     float4* Pq = reinterpret_cast<float4*>(partials + ((size_t)blockIdx.x * max_segs + seg) * kSlotFloats);
@@ -1238,10 +1251,32 @@ bool x_shape_ok(int n_prob, const int* K, int64_t M, int N) {
   return true;
 }
 
+// EXPERIMENT (tools/r05_call10.sh): prefetch depth from the environment, 4 / 6 / 8 slices
+int x_depth() {
+  static const int d = [] { const char* e = std::getenv("MMSSL_PROJX_DEPTH"); const int v = e ? std::atoi(e) : 4;
+                            return (v == 6 || v == 8) ? v : 4; }();
+  return d;
+}
 int x_lds_ready() {
-  static const int rc = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(projx_sk_kernel),
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, kXLdsBytes);
+  static const int rc = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(projx_sk_kernel<4>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, x_lds_bytes(4)) |
+                        (int)hipFuncSetAttribute(reinterpret_cast<const void*>(projx_sk_kernel<6>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, x_lds_bytes(6)) |
+                        (int)hipFuncSetAttribute(reinterpret_cast<const void*>(projx_sk_kernel<8>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, x_lds_bytes(8));
   return rc;
+}
+void x_launch_main(const Plan& pl, float* part, hipStream_t s) {
+  const int d = x_depth();
+  if (d == 8)
+    hipLaunchKernelGGL(projx_sk_kernel<8>, dim3((unsigned)pl.blocks), dim3(kThreads), x_lds_bytes(8), s, pl.P, pl.upb, pl.total,
+                       pl.max_segs, part);
+  else if (d == 6)
+    hipLaunchKernelGGL(projx_sk_kernel<6>, dim3((unsigned)pl.blocks), dim3(kThreads), x_lds_bytes(6), s, pl.P, pl.upb, pl.total,
+                       pl.max_segs, part);
+  else
+    hipLaunchKernelGGL(projx_sk_kernel<4>, dim3((unsigned)pl.blocks), dim3(kThreads), x_lds_bytes(4), s, pl.P, pl.upb, pl.total,
+                       pl.max_segs, part);
 }
 
 // n_blocks: unit ranges = blocks of the launch (0 = one per CU). A step that runs other kernels beside the projection
@@ -1293,8 +1328,7 @@ int x_wgrad_impl(int n_prob, const float* G, int64_t ldg, const float* const* FT
   hipLaunchKernelGGL(projx_gprep_kernel, dim3((unsigned)gblocks, (unsigned)n_prob), dim3(256), 0, s, G, ldg, M, (int)S, gimg,
                      img_stride, any_b ? bpart : (float*)nullptr);
   MMSSL_LAUNCH_CHECK();
-  hipLaunchKernelGGL(projx_sk_kernel, dim3((unsigned)pl.blocks), dim3(kThreads), kXLdsBytes, s, pl.P, pl.upb, pl.total,
-                     pl.max_segs, part);
+  x_launch_main(pl, part, s);
   MMSSL_LAUNCH_CHECK();
   hipLaunchKernelGGL(projx_wgrad_reduce_kernel, dim3((unsigned)pl.tiles * 8), dim3(kThreads), 0, s, pl.P, pl.upb, pl.max_segs,
                      (const float*)part, any_b ? (const float*)bpart : (const float*)nullptr, gblocks, ptrs, ad);
@@ -1379,8 +1413,7 @@ extern "C" int mmssl_projx_fwd_f32(int n_prob, const float* const* Fimg, const f
   for (int g = 0; g < kMaxProb; ++g) ptrs.bias[g] = (bias && g < n_prob) ? bias[g] : nullptr;
   hipLaunchKernelGGL(projx_wsplit_kernel, dim3((unsigned)((units + 255) / 256)), dim3(256), 0, s, X);
   MMSSL_LAUNCH_CHECK();
-  hipLaunchKernelGGL(projx_sk_kernel, dim3((unsigned)pl.blocks), dim3(kThreads), kXLdsBytes, s, pl.P, pl.upb, pl.total,
-                     pl.max_segs, part);
+  x_launch_main(pl, part, s);
   MMSSL_LAUNCH_CHECK();
   hipLaunchKernelGGL(proj_fwd_reduce_kernel, dim3((unsigned)pl.tiles * 8), dim3(kFThreads), 0, s, pl.P, pl.upb, pl.max_segs,
                      (const float*)part, M, Y, ldy, ptrs, keep, keep_out, rng_state, p_drop, scale);

@@ -1251,32 +1251,18 @@ bool x_shape_ok(int n_prob, const int* K, int64_t M, int N) {
   return true;
 }
 
-// EXPERIMENT (tools/r05_call10.sh): prefetch depth from the environment, 4 / 6 / 8 slices
-int x_depth() {
-  static const int d = [] { const char* e = std::getenv("MMSSL_PROJX_DEPTH"); const int v = e ? std::atoi(e) : 4;
-                            return (v == 6 || v == 8) ? v : 4; }();
-  return d;
-}
+// Prefetch depth: 4 slices per wave (16 KB of A in registers per wave, 48 KB of B planes in LDS). Measured on the Baby shape
+// (profiles/r05/projx_depth.txt): depth 4 109 / 113 us forward / weight gradient with their epilogues, depth 6 112 / 117
+// (230 VGPRs), depth 8 127 / 133 (256 VGPRs + scratch): the stream is not short of bytes in flight.
+constexpr int kXDepthUsed = 4;
 int x_lds_ready() {
-  static const int rc = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(projx_sk_kernel<4>),
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, x_lds_bytes(4)) |
-                        (int)hipFuncSetAttribute(reinterpret_cast<const void*>(projx_sk_kernel<6>),
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, x_lds_bytes(6)) |
-                        (int)hipFuncSetAttribute(reinterpret_cast<const void*>(projx_sk_kernel<8>),
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, x_lds_bytes(8));
+  static const int rc = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(projx_sk_kernel<kXDepthUsed>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, x_lds_bytes(kXDepthUsed));
   return rc;
 }
 void x_launch_main(const Plan& pl, float* part, hipStream_t s) {
-  const int d = x_depth();
-  if (d == 8)
-    hipLaunchKernelGGL(projx_sk_kernel<8>, dim3((unsigned)pl.blocks), dim3(kThreads), x_lds_bytes(8), s, pl.P, pl.upb, pl.total,
-                       pl.max_segs, part);
-  else if (d == 6)
-    hipLaunchKernelGGL(projx_sk_kernel<6>, dim3((unsigned)pl.blocks), dim3(kThreads), x_lds_bytes(6), s, pl.P, pl.upb, pl.total,
-                       pl.max_segs, part);
-  else
-    hipLaunchKernelGGL(projx_sk_kernel<4>, dim3((unsigned)pl.blocks), dim3(kThreads), x_lds_bytes(4), s, pl.P, pl.upb, pl.total,
-                       pl.max_segs, part);
+  hipLaunchKernelGGL(projx_sk_kernel<kXDepthUsed>, dim3((unsigned)pl.blocks), dim3(kThreads), x_lds_bytes(kXDepthUsed), s, pl.P,
+                     pl.upb, pl.total, pl.max_segs, part);
 }
 
 // n_blocks: unit ranges = blocks of the launch (0 = one per CU). A step that runs other kernels beside the projection

@@ -259,16 +259,18 @@ def spmm_hbm_record(iters=20):
     P = GraphPlan(ui_r)
     X = torch.randn(I, d, device="cuda")
     G = torch.randn(U_r, d, device="cuda")
-    pmc = None
-    pp = os.path.join(ROOT, "profiles", "r04_spmm_hbm_pmc.json")
-    if os.path.exists(pp):
-        try:
-            pmc = json.load(open(pp))
-        except Exception:
-            pmc = None
+    pmc, pmc_file = None, None
+    for name in ("r05_spmm_hbm_pmc.json", "r04_spmm_hbm_pmc.json"):
+        pp = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(pp):
+            try:
+                pmc, pmc_file = json.load(open(pp)), name
+                break
+            except Exception:
+                pmc = None
     out = {"what": "configs[4] rank shape, d=128: A_ui[U_r,:] 250000 x 1000000, 12.5M edges; gathered table 512 MB (HBM resident)",
            "random_gather_ceiling_GBps": 4400.0,
-           "traffic_source": "profiles/r04_spmm_hbm_pmc.json (rocprofv3 --pmc pass of tools/spmm_hbm_pmc.py; not measured in this run)"
+           "traffic_source": ("profiles/%s (rocprofv3 --pmc pass of tools/spmm_hbm_pmc.py; not measured in this run)" % pmc_file)
                              if pmc else None}
     rng = np.random.default_rng(0)
     with torch.no_grad():

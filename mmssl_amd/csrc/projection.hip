@@ -689,7 +689,6 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int kXAFloats = PT * PBK;                    // 8192 floats = 32 KB: one A slice
 constexpr int kXBBytes = 3 * PJ * PBK * 2;             // 12288 B: the three bf16 planes of one B slice
-constexpr int kXPieces = 6;                            // memory instructions per wave per slice: 4 loads of A + 2 DMA pieces of B
 constexpr int kXGRows = 64;                            // reduction rows per block of the G preparation kernel
 
 __device__ __forceinline__ unsigned f2u(float x) { return __builtin_bit_cast(unsigned, x); }
@@ -741,6 +740,11 @@ constexpr int x_lds_bytes(int depth) { return depth * kXBBytes; }        // only
 // form of this kernel measured 92 us for the 387 MB stream: every byte paid the LDS-DMA path's ~6.4 TB/s chip-wide
 // ceiling TOGETHER with the L2-resident B planes, +37 % bytes). LDS carries the three bf16 planes of the short operand
 // only (12 KB per slice, kXDepth stages, one barrier per slice).
+// Decomposition builds for tools/projx_ablate.sh (never set in the product build): bit 0 = no A loads in the steady loop,
+// bit 1 = no MFMAs, bit 2 = no cut of A into planes, bit 3 = no B DMA in the steady loop.
+#ifndef MMSSL_PROJX_DBG
+#define MMSSL_PROJX_DBG 0
+#endif
 template <int kXDepth>
 __global__ __launch_bounds__(kThreads) void projx_sk_kernel(Group P, int upb, int64_t total, int max_segs,
                                                             float* __restrict__ partials) {
@@ -751,115 +755,166 @@ __global__ __launch_bounds__(kThreads) void projx_sk_kernel(Group P, int upb, in
   const unsigned ring_lds = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)ring);
   const int64_t u_begin = (int64_t)blockIdx.x * upb;
   const int64_t u_end = min(total, u_begin + upb);
+  const int n = (int)(u_end - u_begin);          // slices of this block's range
+  if (n <= 0) return;
   // the wave's two B pieces of a slice: KB wave and KB 8 + wave of the 12 (waves 4-7 repeat KB 0-3: the same bytes to the
   // same place, so that every wave has the same number of memory instructions in flight - the wait counts are immediates)
   const int be0 = wave_u, be1 = (8 + wave_u) % 12;
-  int64_t u = u_begin;
-  int seg = 0;
-  while (u < u_end) {
-    const Segment sg = segment_at(P, u, u_end);
-    const int nk = sg.nk;
-    const float* pa = P.A[sg.g] + ((int64_t)sg.tip * P.S[sg.g] + sg.s0) * kXAFloats + wave * 1024 + 4 * lane;
-    const char* pb = reinterpret_cast<const char*>(P.B[sg.g]) + (int64_t)sg.s0 * kXBBytes + 16 * lane;
-    floatx4 raw[kXDepth][4];
-    // slice kt's memory instructions of this wave: 4 loads of A into register set J, 2 DMA pieces of B into stage kt % depth
-    auto issue = [&](auto J, int kt) {
-      const float* p = pa + (int64_t)kt * kXAFloats;
-      gload16_nt<0>(raw[J.value][0], p);
-      gload16_nt<1024>(raw[J.value][1], p);
-      gload16_nt<2048>(raw[J.value][2], p);
-      gload16_nt<3072>(raw[J.value][3], p);
-      const unsigned st = ring_lds + (unsigned)(kt % kXDepth) * kXBBytes;
-      const char* q = pb + (int64_t)kt * kXBBytes;
-      glds16(reinterpret_cast<const float*>(q + be0 * 1024), st + (unsigned)(be0 * 1024));
-      glds16(reinterpret_cast<const float*>(q + be1 * 1024), st + (unsigned)(be1 * 1024));
-    };
-    // the operands of k-step s of slice kt: my A values from register set J (cut into planes here), six reads of B planes
-    auto take_half = [&](auto J, int kt, int s, FragX& f) {
-      const char* st = reinterpret_cast<const char*>(ring) + (kt % kXDepth) * kXBBytes;
+  // The block's whole range is ONE pipeline: the loads run kXDepth slices ahead of the MFMAs ACROSS segment boundaries (a
+  // segment = the slices of one output tile; 2.5 per block on the Baby shape). Draining and refilling at every boundary,
+  // as the fp32 kernels above do, cost ~5 us each with four slices in flight. Two cursors walk the range: the issue cursor
+  // (source pointers of the next slice to load) and the compute cursor (slices left in the tile being accumulated).
+  const float* pa = nullptr;       // issue cursor: this lane's source of the next slice's A values / B pieces
+  const char* pb = nullptr;
+  int i_left = 0;                  // slices left in the issue cursor's segment
+  int64_t i_u = u_begin;
+  floatx4 raw[kXDepth][4];
+  // The issue cursor's next slice: `issue_B` sends its two DMA pieces of B into LDS stage k % depth, `issue_A` its four
+  // loads of A into register set J and advances the cursor. B runs THREE slices ahead of the MFMAs, A four: a stage is
+  // then refilled a whole step after its last operand read was issued, so the step's barrier only needs the reads
+  // issued before the latest six (lgkmcnt(6)) - the reads of the slice's second half no longer stall the barrier.
+  auto open_segment = [&]() {
+    if (i_left == 0) {
+      const Segment sg = segment_at(P, i_u, u_end);
+      pa = P.A[sg.g] + ((int64_t)sg.tip * P.S[sg.g] + sg.s0) * kXAFloats + wave * 1024 + 4 * lane;
+      pb = reinterpret_cast<const char*>(P.B[sg.g]) + (int64_t)sg.s0 * kXBBytes + 16 * lane;
+      i_left = sg.nk;
+    }
+  };
+  // B of slice k where k = (slices A has issued so far) - 1 + ... : called right BEFORE issue_A of the slice after it
+  const char* pb_next = nullptr;       // source of the next B slice to issue (B lags A by one slice)
+  auto issue_B = [&](int k) {
+    const unsigned st = ring_lds + (unsigned)(k % kXDepth) * kXBBytes;
+    if (!(MMSSL_PROJX_DBG & 8) || k < kXDepth) {
+      glds16(reinterpret_cast<const float*>(pb_next + be0 * 1024), st + (unsigned)(be0 * 1024));
+      glds16(reinterpret_cast<const float*>(pb_next + be1 * 1024), st + (unsigned)(be1 * 1024));
+    }
+  };
+  auto issue_A = [&](auto J, int k) {
+    open_segment();
+    if (!(MMSSL_PROJX_DBG & 1) || k < kXDepth) {
+      gload16_nt<0>(raw[J.value][0], pa);
+      gload16_nt<1024>(raw[J.value][1], pa);
+      gload16_nt<2048>(raw[J.value][2], pa);
+      gload16_nt<3072>(raw[J.value][3], pa);
+    }
+    pb_next = pb;                      // this slice's B goes out with the NEXT issue (one step later)
+    pa += kXAFloats;
+    pb += kXBBytes;
+    --i_left;
+    ++i_u;
+  };
+  // the operands of k-step s of slice k: my A values from register set J (cut into planes here), six reads of B planes
+  auto take_half = [&](auto J, int k, int s, FragX& f) {
+    const char* st = reinterpret_cast<const char*>(ring) + (k % kXDepth) * kXBBytes;
 #pragma unroll
-      for (int p = 0; p < 3; ++p)
+    for (int p = 0; p < 3; ++p)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          const int n = 32 * j + lr;
-          f.b[p][s][j] = *reinterpret_cast<const uintx4*>(st + p * (PJ * PBK * 2) + n * (PBK * 2) +
-                                                          (((2 * s + h) ^ ((n >> 2) & 3)) << 4));
-        }
-      const floatx4 v0 = raw[J.value][2 * s], v1 = raw[J.value][2 * s + 1];
+      for (int j = 0; j < 2; ++j) {
+        const int nn = 32 * j + lr;
+        f.b[p][s][j] = *reinterpret_cast<const uintx4*>(st + p * (PJ * PBK * 2) + nn * (PBK * 2) +
+                                                        (((2 * s + h) ^ ((nn >> 2) & 3)) << 4));
+      }
+    const floatx4 v0 = raw[J.value][2 * s], v1 = raw[J.value][2 * s + 1];
+    if (MMSSL_PROJX_DBG & 4) {         // decomposition build: the raw bits as "planes" (wrong numbers, same data flow)
+      f.a[0][s] = __builtin_bit_cast(uintx4, v0);
+      f.a[1][s] = __builtin_bit_cast(uintx4, v1);
+      f.a[2][s] = __builtin_bit_cast(uintx4, v0);
+    } else {
       cut8(make_float4(v0[0], v0[1], v0[2], v0[3]), make_float4(v1[0], v1[1], v1[2], v1[3]), f.a[0][s], f.a[1][s],
            f.a[2][s]);
-    };
-    floatx16 acc0, acc1;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
-    // k-step s: the six partial products of both column halves, smallest first, the two accumulators alternating
-    auto mfma_half = [&](int s, const FragX& f) {
-      constexpr int pa_[6] = {0, 2, 1, 0, 1, 0};
-      constexpr int pb_[6] = {2, 0, 1, 1, 0, 0};
-#pragma unroll
-      for (int t = 0; t < 6; ++t) {
-        const bf16x8 av = __builtin_bit_cast(bf16x8, f.a[pa_[t]][s]);
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, __builtin_bit_cast(bf16x8, f.b[pb_[t]][s][0]), acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, __builtin_bit_cast(bf16x8, f.b[pb_[t]][s][1]), acc1, 0, 0, 0);
-      }
-    };
-    // One pipeline step = slice kt's 24 MFMAs (operand set f). Before them: slice kt + 1 has landed (mine: vmcnt;
-    // everyone's B: barrier). Slice kt + depth is issued into the register set / stage slice kt has just left; after each
-    // k-step's MFMAs slice kt + 1's operands replace the ones those MFMAs read.
-    auto step = [&](auto J, int kt, FragX& f) {
-      constexpr int JN = (J.value + 1) % kXDepth;
-      const bool more1 = kt + 1 < nk, more = kt + kXDepth < nk;
-      if (more1) {
-        wait_outstanding<kXPieces>(min(nk - kt - 2, kXDepth - 2));
-        tie4(raw[JN][0], raw[JN][1], raw[JN][2], raw[JN][3]);
-        lgkm_wait0();
-        bare_barrier();
-      }
-      if (more) issue(J, kt + kXDepth);
-#pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        mfma_half(s, f);
-        if (more1) take_half(std::integral_constant<int, JN>{}, kt + 1, s, f);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    };
-    // the previous segment's slot stores and operand reads must be done before registers and ring are refilled
-    vm_wait_n<0>();
-    lgkm_wait0();
-    bare_barrier();
-    issue(std::integral_constant<int, 0>{}, 0);
-    if (nk > 1) issue(std::integral_constant<int, 1>{}, 1);
-    if (nk > 2) issue(std::integral_constant<int, 2>{}, 2);
-    if (nk > 3) issue(std::integral_constant<int, 3>{}, 3);
-    if constexpr (kXDepth > 4) { if (nk > 4) issue(std::integral_constant<int, 4 % kXDepth>{}, 4); }
-    if constexpr (kXDepth > 5) { if (nk > 5) issue(std::integral_constant<int, 5 % kXDepth>{}, 5); }
-    if constexpr (kXDepth > 6) { if (nk > 6) issue(std::integral_constant<int, 6 % kXDepth>{}, 6); }
-    if constexpr (kXDepth > 7) { if (nk > 7) issue(std::integral_constant<int, 7 % kXDepth>{}, 7); }
-    wait_outstanding<kXPieces>(min(nk, kXDepth) - 1);          // slice 0 has landed
-    tie4(raw[0][0], raw[0][1], raw[0][2], raw[0][3]);
-    bare_barrier();
-    FragX f;
-    take_half(std::integral_constant<int, 0>{}, 0, 0, f);
-    take_half(std::integral_constant<int, 0>{}, 0, 1, f);
-    for (int kt = 0; kt < nk; kt += kXDepth) {
-      step(std::integral_constant<int, 0>{}, kt, f);
-      if (kt + 1 < nk) step(std::integral_constant<int, 1>{}, kt + 1, f);
-      if (kt + 2 < nk) step(std::integral_constant<int, 2>{}, kt + 2, f);
-      if (kt + 3 < nk) step(std::integral_constant<int, 3>{}, kt + 3, f);
-      if constexpr (kXDepth > 4) { if (kt + 4 < nk) step(std::integral_constant<int, 4 % kXDepth>{}, kt + 4, f); }
-      if constexpr (kXDepth > 5) { if (kt + 5 < nk) step(std::integral_constant<int, 5 % kXDepth>{}, kt + 5, f); }
-      if constexpr (kXDepth > 6) { if (kt + 6 < nk) step(std::integral_constant<int, 6 % kXDepth>{}, kt + 6, f); }
-      if constexpr (kXDepth > 7) { if (kt + 7 < nk) step(std::integral_constant<int, 7 % kXDepth>{}, kt + 7, f); }
     }
-    // accumulator image -> partial slot, in the forward kernel's plane order (the 32x32 C layout is dtype-independent)
-    float4* Pq = reinterpret_cast<float4*>(partials + ((size_t)blockIdx.x * max_segs + seg) * kSlotFloats);
+  };
+  floatx16 acc0, acc1;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      Pq[q * kThreads + tid] = make_float4(acc0[4 * q], acc0[4 * q + 1], acc0[4 * q + 2], acc0[4 * q + 3]);
-      Pq[(4 + q) * kThreads + tid] = make_float4(acc1[4 * q], acc1[4 * q + 1], acc1[4 * q + 2], acc1[4 * q + 3]);
+  for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+  // k-step s: the six partial products of both column halves, smallest first, the two accumulators alternating
+  auto mfma_half = [&](int s, const FragX& f) {
+    constexpr int pa_[6] = {0, 2, 1, 0, 1, 0};
+    constexpr int pb_[6] = {2, 0, 1, 1, 0, 0};
+#pragma unroll
+    for (int t = 0; t < 6; ++t) {
+      if (MMSSL_PROJX_DBG & 2) {         // decomposition build: keep the operands alive without the matrix pipe
+        acc0[t] += u2f(f.a[pa_[t]][s][0] ^ f.b[pb_[t]][s][0][1]);
+        acc1[t] += u2f(f.a[pa_[t]][s][2] ^ f.b[pb_[t]][s][1][3]);
+        continue;
+      }
+      const bf16x8 av = __builtin_bit_cast(bf16x8, f.a[pa_[t]][s]);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, __builtin_bit_cast(bf16x8, f.b[pb_[t]][s][0]), acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, __builtin_bit_cast(bf16x8, f.b[pb_[t]][s][1]), acc1, 0, 0, 0);
     }
-    u += nk;
-    ++seg;
+  };
+  int c_left = segment_at(P, u_begin, u_end).nk;       // compute cursor: slices left in the tile being accumulated
+  int64_t c_u = u_begin;
+  int seg = 0;
+  // One pipeline step = slice k's 24 MFMAs (operand set f). Before them: slice k + 1 has landed (mine: vmcnt; everyone's
+  // B: barrier). B of slice k + 3 and A of slice k + 4 are issued into the stage / register set their predecessors have
+  // left; after each k-step's MFMAs slice k + 1's operands replace the ones those MFMAs read. A tile's last slice then leaves the accumulator image in
+  // the range's next partial slot (the forward kernel's plane order: the 32x32 C layout is dtype-independent).
+  auto step = [&](auto J, int k, FragX& f) {
+    constexpr int JN = (J.value + 1) % kXDepth;
+    const bool more1 = k + 1 < n;
+    if (more1) {
+      // memory instructions younger than B(k + 1) in issue order: A(k + 2), B(k + 2), A(k + 3) - as far as they exist
+      const int young = (k + 2 < n ? 6 : 0) + (k + 3 < n ? 4 : 0);
+      if (young >= 10) vm_wait_n<10>();
+      else if (young >= 6) vm_wait_n<6>();
+      else vm_wait_n<0>();
+      tie4(raw[JN][0], raw[JN][1], raw[JN][2], raw[JN][3]);
+      __builtin_amdgcn_s_waitcnt(0xC07F | (6 << 8));          // lgkmcnt(6): all operand reads but the latest six
+      asm volatile("" ::: "memory");
+      bare_barrier();
+    }
+    if (k + kXDepth - 1 < n) issue_B(k + kXDepth - 1);
+    if (k + kXDepth < n) issue_A(J, k + kXDepth);
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      mfma_half(s, f);
+      if (more1) take_half(std::integral_constant<int, JN>{}, k + 1, s, f);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    ++c_u;
+    if (--c_left == 0) {
+      float4* Pq = reinterpret_cast<float4*>(partials + ((size_t)blockIdx.x * max_segs + seg) * kSlotFloats);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        Pq[q * kThreads + tid] = make_float4(acc0[4 * q], acc0[4 * q + 1], acc0[4 * q + 2], acc0[4 * q + 3]);
+        Pq[(4 + q) * kThreads + tid] = make_float4(acc1[4 * q], acc1[4 * q + 1], acc1[4 * q + 2], acc1[4 * q + 3]);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+      ++seg;
+      if (more1) c_left = segment_at(P, c_u, u_end).nk;
+    }
+  };
+  // prologue, in the steady order (B of a slice goes out right before A of the next one): A0 | B0 A1 | B1 A2 | B2 A3
+  static_assert(kXDepth == 4, "the prologue and the wait counts below are written for four slices in flight");
+  issue_A(std::integral_constant<int, 0>{}, 0);
+  issue_B(0);
+  if (n > 1) { issue_A(std::integral_constant<int, 1>{}, 1); issue_B(1); }
+  if (n > 2) { issue_A(std::integral_constant<int, 2>{}, 2); issue_B(2); }
+  if (n > 3) issue_A(std::integral_constant<int, 3>{}, 3);
+  {     // A(0) and B(0) have landed: younger than B(0) are A1 B1 A2 B2 A3, as far as they exist
+    const int young = (n > 1 ? 6 : 0) + (n > 2 ? 6 : 0) + (n > 3 ? 4 : 0);
+    if (young >= 16) vm_wait_n<16>();
+    else if (young >= 12) vm_wait_n<12>();
+    else if (young >= 6) vm_wait_n<6>();
+    else vm_wait_n<0>();
+  }
+  tie4(raw[0][0], raw[0][1], raw[0][2], raw[0][3]);
+  bare_barrier();
+  FragX f;
+  take_half(std::integral_constant<int, 0>{}, 0, 0, f);
+  take_half(std::integral_constant<int, 0>{}, 0, 1, f);
+  for (int k = 0; k < n; k += kXDepth) {
+    step(std::integral_constant<int, 0>{}, k, f);
+    if (k + 1 < n) step(std::integral_constant<int, 1>{}, k + 1, f);
+    if (k + 2 < n) step(std::integral_constant<int, 2>{}, k + 2, f);
+    if (k + 3 < n) step(std::integral_constant<int, 3>{}, k + 3, f);
+    if constexpr (kXDepth > 4) { if (k + 4 < n) step(std::integral_constant<int, 4 % kXDepth>{}, k + 4, f); }
+    if constexpr (kXDepth > 5) { if (k + 5 < n) step(std::integral_constant<int, 5 % kXDepth>{}, k + 5, f); }
+    if constexpr (kXDepth > 6) { if (k + 6 < n) step(std::integral_constant<int, 6 % kXDepth>{}, k + 6, f); }
+    if constexpr (kXDepth > 7) { if (k + 7 < n) step(std::integral_constant<int, 7 % kXDepth>{}, k + 7, f); }
   }
 }
 

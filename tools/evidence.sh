@@ -47,6 +47,9 @@ if has dist; then
   MMSSL_DIST_FORCE_COLLECTIVES=1 timeout 600 $S --scheme item-side --chunks 4 > $O/bench_synth_w1_rccl_itemside_c4.json 2>> $O/bench.err; line $O/bench_synth_w1_rccl_itemside_c4.json
   MMSSL_DIST_FORCE_COLLECTIVES=1 timeout 600 $S --scheme gather-both > $O/bench_synth_w1_rccl_gatherboth.json 2>> $O/bench.err; line $O/bench_synth_w1_rccl_gatherboth.json
   timeout 600 python bench.py --gpus 1 --steps 500 --warmup 100 --no-cpu-baseline --no-hbm --graph communities > $O/bench_communities.json 2>> $O/bench.err; line $O/bench_communities.json
+  # configs[4] WHOLE on one GPU (2M x 1M x 100M edges, d = 128): the N = 1 denominator of the 8-rank job's speed-up
+  timeout 900 python bench.py --workload synth-full --steps 10 --warmup 3 --no-cpu-baseline > $O/bench_synth_full_n1.json 2>> $O/bench.err; line $O/bench_synth_full_n1.json
+  timeout 300 $B --proj f32 > $O/bench_steps_proj_f32.json 2>> $O/bench.err; line $O/bench_steps_proj_f32.json
 fi
 if has prof; then
   cd /tmp
@@ -72,7 +75,7 @@ if has pmc; then
   {
     echo "# rocprofv3 --pmc passes over tools/proj_pmc.py: the grouped projection kernels of the hot step, averages over the launches after the first"
     for p in proj_sq proj_FETCH_SIZE proj_WRITE_SIZE; do
-      echo "## pass $p"; python tools/pmc_split.py $(find $O/$p -name "*counter_collection.csv") 8 proj_
+      echo "## pass $p"; python tools/pmc_split.py $(find $O/$p -name "*counter_collection.csv") 8 proj
     done
   } > $O/${ROUND}_proj_pmc.txt 2>&1
 fi

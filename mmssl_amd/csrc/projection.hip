@@ -1005,16 +1005,22 @@ __global__ __launch_bounds__(256) void projx_pack_kernel(const float* __restrict
 
 // weight-gradient epilogue on the forward-shaped slots: the tile is C[i = feature column][j = channel];
 // gW[j][i .. i + 3] is one float4; bias gradient = the G preparation kernel's block sums in block order
-__global__ __launch_bounds__(kThreads) void projx_wgrad_reduce_kernel(Group P, int upb, int max_segs,
-                                                                      const float* __restrict__ partials,
-                                                                      const float* __restrict__ bpart, int n_gblocks,
-                                                                      WgradPtrs ptrs, AdamSlots ad) {
+// grid = tiles x 8 planes x kXRParts: a weight-gradient problem has few tiles (20 for the Baby shape) with ~13 slots each, so
+// a plane is cut into kXRParts blocks of 128 threads - 640 blocks instead of 160 hide the slot loads' latency (the launch sits
+// on the step's critical chain and runs beside the tables' AdamW launch there: 39 us as 160 blocks)
+constexpr int kXRParts = 4;
+constexpr int kXRThreads = kThreads / kXRParts;
+__global__ __launch_bounds__(kXRThreads) void projx_wgrad_reduce_kernel(Group P, int upb, int max_segs,
+                                                                        const float* __restrict__ partials,
+                                                                        const float* __restrict__ bpart, int n_gblocks,
+                                                                        WgradPtrs ptrs, AdamSlots ad) {
   __shared__ float sh[2];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int t = (int)blockIdx.x >> 3, q = (int)blockIdx.x & 7;
+  const int part = (int)blockIdx.x % kXRParts, bq = (int)blockIdx.x / kXRParts;
+  const int tid = part * kXRThreads + (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;      // position inside the plane
+  const int t = bq >> 3, q = bq & 7;
   const int g = prob_of_tile(P, t), tip = t - P.tile0[g];
   if (ad.state) {
-    if (tid == 0) {
+    if (threadIdx.x == 0) {
       const float step = ad.pre_ticked ? fmaxf(ad.state[0], 1.0f) : ad.state[0] + 1.0f;
       sh[0] = ad.lr / (1.0f - __builtin_amdgcn_exp2f(step * ad.log2_beta1));
       sh[1] = sqrtf(1.0f - __builtin_amdgcn_exp2f(step * ad.log2_beta2));
@@ -1371,7 +1377,8 @@ int x_wgrad_impl(int n_prob, const float* G, int64_t ldg, const float* const* FT
   MMSSL_LAUNCH_CHECK();
   x_launch_main(pl, part, s);
   MMSSL_LAUNCH_CHECK();
-  hipLaunchKernelGGL(projx_wgrad_reduce_kernel, dim3((unsigned)pl.tiles * 8), dim3(kThreads), 0, s, pl.P, pl.upb, pl.max_segs,
+  hipLaunchKernelGGL(projx_wgrad_reduce_kernel, dim3((unsigned)pl.tiles * 8 * kXRParts), dim3(kXRThreads), 0, s, pl.P, pl.upb,
+                     pl.max_segs,
                      (const float*)part, any_b ? (const float*)bpart : (const float*)nullptr, gblocks, ptrs, ad);
   MMSSL_LAUNCH_CHECK();
   return 0;

@@ -11,9 +11,9 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda"
 
 
-@pytest.fixture(params=["split", "f32"], autouse=True)
+@pytest.fixture(params=["split", "f32"])
 def precision(request, monkeypatch):
-    """Every test of this file runs twice: on the split-precision kernels (the default: exact 3-way bf16 cut, six partial
+    """A test that asks for this fixture runs twice: on the split-precision kernels (the default: exact 3-way bf16 cut, six partial
     products on the bf16 matrix pipe) and on the fp32-MFMA kernels (ops.PROJ_SPLIT = False)."""
     from mmssl_amd import ops
     monkeypatch.setattr(ops, "PROJ_SPLIT", request.param == "split")
@@ -31,7 +31,7 @@ def _problem(M, Ks, seed):
 
 @pytest.mark.parametrize("M,Ks", [(18357, (4096, 1024)), (6710, (128, 768, 128)), (1000, (64,)), (257, (32, 96)),
                                   (256, (4096,))])
-def test_proj_forward_matches_torch(M, Ks):
+def test_proj_forward_matches_torch(M, Ks, precision):
     from mmssl_amd import ops
     assert ops.proj_supported(Ks, M, 64)
     Fs, Ws, bs, keep = _problem(M, Ks, 1)
@@ -52,7 +52,7 @@ def test_proj_forward_matches_torch(M, Ks):
         assert H.rel_err(Y[:, 64 * g:64 * g + 64].cpu(), one.cpu()) < 2e-5
 
 
-def test_proj_forward_draws_the_masks_of_dropout_masks():
+def test_proj_forward_draws_the_masks_of_dropout_masks(precision):
     """draw=(p, state): the epilogue's inline generator reproduces ops.dropout_masks at the same generator state, the
     output is the given-mask result for those masks, and the state itself is left to the caller (external tick)."""
     from mmssl_amd import ops
@@ -76,7 +76,7 @@ def test_proj_forward_draws_the_masks_of_dropout_masks():
 
 @pytest.mark.parametrize("M,Ks", [(18357, (4096, 1024)), (6710, (128, 768, 128)), (1000, (64,)), (257, (32, 96)),
                                   (33, (260,))])
-def test_proj_wgrad_matches_torch(M, Ks):
+def test_proj_wgrad_matches_torch(M, Ks, precision):
     from mmssl_amd import ops
     assert ops.proj_supported(Ks, M, 64, wgrad=True)
     Fs, _, _, _ = _problem(M, Ks, 3)
@@ -111,16 +111,15 @@ def test_proj_rejects_what_it_cannot_run(precision):
 
 
 @pytest.mark.parametrize("M,Ks", [(18357, (4096, 1024)), (3000, (20, 260))])
-def test_split_precision_is_fp32_accurate_against_float64(M, Ks, precision):
+def test_split_precision_is_fp32_accurate_against_float64(M, Ks):
     """The claim behind the split-precision kernels: cutting every fp32 value exactly into three bf16 pieces and keeping
     the six partial products of weight >= 2^-16 loses at most ~2^-23 of a product - one fp32 rounding. Measured against a
     float64 product, element by element (normalised by |F| . |W|, the scale of a dot product's rounding error), the error
     of this path must not exceed that of fp32 arithmetic itself: 1.25 x the fp32-MFMA kernels' (same sequential fp32
     accumulation; a three-product bf16x3 scheme would sit at 3 x), within 4 x torch's blocked fp32 GEMM on the CPU. Forward and weight gradient; K = 20 exercises the zero padding of
     a slice, M = 18357 the ragged last tile and reduction slice."""
-    if precision != "split":
-        pytest.skip("the fp32-MFMA kernels are the yardstick here")
     from mmssl_amd import ops
+    assert ops.PROJ_SPLIT
     Fs, Ws, bs, _ = _problem(M, Ks, 11)
     Fd, Wd = [f.to(DEV) for f in Fs], [w.to(DEV) for w in Ws]
     Y, _ = ops.proj_forward(Fd, Wd, [None] * len(Ks), scale=1.0)
@@ -150,12 +149,11 @@ def test_split_precision_is_fp32_accurate_against_float64(M, Ks, precision):
         assert e_w <= 4.0 * e_wt + 1e-9 and e_w < 1e-6, (Ks[k], e_w, e_wt)
 
 
-def test_split_precision_images_follow_the_feature_matrix(precision):
+def test_split_precision_images_follow_the_feature_matrix():
     """The packed images are cached per feature matrix: a second matrix of the same shape gets its own images (the cache
     keeps the first alive, so its address cannot be recycled), an in-place change rebuilds them."""
-    if precision != "split":
-        pytest.skip("fp32-MFMA kernels read the matrices themselves")
     from mmssl_amd import ops
+    assert ops.PROJ_SPLIT
     M, K = 700, 96
     W = [torch.randn(64, K, device=DEV) * 0.1]
     F1 = torch.randn(M, K, device=DEV)

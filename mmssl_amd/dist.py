@@ -277,8 +277,24 @@ def _solo(group):
 
 def _all_reduce(t, group):
     if not _solo(group):
+        fence = t.is_cuda and dist.get_backend(group) == "gloo"        # (test transport: see _gloo_device_fence)
+        if fence:
+            torch.cuda.synchronize(t.device)
         dist.all_reduce(t, group=group)
+        if fence:
+            torch.cuda.synchronize(t.device)
     return t
+
+
+def _gloo_device_fence(t):
+    """TEST TRANSPORT ONLY (ranks sharing one GPU talk through gloo, which stages device tensors through the host on its
+    own streams): a device-wide synchronisation on both sides of the collective. With >= 4 ranks on one GPU and the item-side
+    node's column-chunk lanes (collectives issued from 4 - 8 forked streams) torch's gloo path hands stale or half-written
+    buffers to the consumers - repeated steps on unchanged inputs disagree, garbage in gradients, once a loss of 6e5 - while
+    the same lanes are bit-stable over RCCL's stream-ordered collectives (world 1, forced launches, 1 / 2 / 4 chunks) and over
+    gloo with this fence (world 4 / 8): profiles/NOTEBOOK.md round 5, tools/repeat_probe_synth.py. RCCL needs no fence."""
+    if t.is_cuda:
+        torch.cuda.synchronize(t.device)
 
 
 def _all_gather_into(out, x, group):
@@ -290,7 +306,9 @@ def _all_gather_into(out, x, group):
         r = dist.get_rank(group)
         out.zero_()
         out[r * per:(r + 1) * per].copy_(x)
+        _gloo_device_fence(out)
         dist.all_reduce(out, group=group)
+        _gloo_device_fence(out)
         return out
     dist.all_gather_into_tensor(out, x.contiguous(), group=group)
     return out
@@ -301,7 +319,9 @@ def _reduce_scatter_sum(full, per, group):
         return full
     if dist.get_backend(group) == "gloo":      # gloo has no reduce_scatter: all-reduce + slice
         full = full.contiguous()
+        _gloo_device_fence(full)
         dist.all_reduce(full, group=group)
+        _gloo_device_fence(full)
         r = dist.get_rank(group)
         return full[r * per:(r + 1) * per].clone()
     out = torch.empty((per,) + tuple(full.shape[1:]), dtype=full.dtype, device=full.device)
@@ -352,7 +372,7 @@ class GatherBatchRows(torch.autograd.Function):
         mine = ((idx >= lo) & (idx < lo + per))
         local = (idx - lo).clamp(0, per - 1)
         rows = table[local] * mine.unsqueeze(1).to(table.dtype)
-        dist.all_reduce(rows, group=group)
+        _all_reduce(rows, group) if not _solo(group) else dist.all_reduce(rows, group=group)
         ctx.save_for_backward(local, mine)
         ctx.per = per
         return rows

@@ -222,10 +222,7 @@ def test_eight_ranks_sharing_the_gpu_run_configs4_at_full_size(tmp_path, golden)
         o = torch.load(os.path.join(str(tmp_path), "r%d.pt" % r))
         assert o["edges_global"] == 100_000_000 and o["chunks"] == 4 and o["replicate_feats"]
         picks = {n: (owned_sample(golden, n, *o[sh][:2])[0], o["g"][n]) for n, sh in (("E_u", "ush"), ("E_i", "ish"))}
-        # Row-wise bound 2e-2 with a floor of 1e-2 of the table's largest entry (one GPU: 5e-3 / 1e-3). This graph amplifies:
-        # a hub item's rows carry ~sqrt(degree) ~ 10^3 x the typical magnitude (csr_norm scales an edge by 1/sqrt(deg(row))
-        # only), every user reads them in the next hop, and at N ranks a hub row is an N-way fp32 sum whose order belongs to
-        # the transport - measured over repeated runs: the small-gradient rows move by up to 1e-4 of the table's largest entry
-        # between two 8-rank runs of the SAME inputs (bit-identical forward, tools/spmm_stress.py: the SpMM's multi-block
-        # combine is bit-stable under 8 processes), the large rows and the loss do not. The table-wide bound (5e-4) stays.
-        _check_against_golden(golden, o["loss"], o["g"], picks, row_tol=2e-2, floor=1e-2)
+        # (the first version of this test saw small-gradient rows move by up to 10 % between runs: torch's gloo path for
+        # device tensors, not arithmetic - dist._gloo_device_fence; with the fence the 8-rank step is bit-stable)
+        _check_against_golden(golden, o["loss"], o["g"], picks, row_tol=float(os.environ.get("MMSSL_TEST_ROWTOL", "5e-3")),
+                              floor=float(os.environ.get("MMSSL_TEST_FLOOR", "1e-3")))

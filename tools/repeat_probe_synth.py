@@ -15,7 +15,11 @@ import torch.multiprocessing as mp
 def worker(rank, world, port, chunks, repl):
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     torch.cuda.set_device(0)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    if os.environ.get("PROBE_BACKEND") == "nccl":       # one rank, real RCCL launches of the self-collectives (stream-ordered)
+        os.environ["MMSSL_DIST_FORCE_COLLECTIVES"] = "1"
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     from mmssl_amd import dist as md
     dev = torch.device("cuda", 0)
     a = types.SimpleNamespace(workload="synth", d=128, gcn_layers=3, batch=1024, scheme="item-side", chunks=chunks,
@@ -29,6 +33,11 @@ def worker(rank, world, port, chunks, repl):
     b = torch.stack([torch.randperm(stats["n_users"], generator=g)[:1024], torch.randint(0, stats["n_items"], (1024,), generator=g),
                      torch.randint(0, stats["n_items"], (1024,), generator=g)])
     step.set_batch(b.to(dev))
+    if os.environ.get("PRE_FWD"):        # two forwards without autograd first (an evaluation before training, say)
+        with torch.no_grad():
+            for _ in range(2):
+                model(step.graphs, keep_masks=torch.stack(step.keep_masks), modal_empty=True)
+        torch.cuda.synchronize()
     snap = {n: p.detach().clone() for n, p in model.named_parameters()}
     g0 = None
     for k in range(4):

@@ -23,10 +23,11 @@ Model of a step at N ranks:  t = max(compute, link) + min(compute, link) / chunk
   compute  = measured one-GPU time of the rank's share (+ the replicated projection's extra flops)
   link     = bytes one rank receives / (N - 1) links / --link-gbs      (full mesh: one xGMI link per peer, traffic even)
   chunks   = column chunks per collective (chunk c's product under chunk c+1's transfer: only 1 / chunks of the shorter side
-             stays exposed); launches x latency = collective launches per step x per-launch cost (RCCL on one rank, measured
-             round 4: ~20 us; a hand-written peer-to-peer store + flag would be ~3 us)
-Speed-up = one-GPU time of the WHOLE problem / t. For configs[4] that denominator is measured: 142.2 ms per step for the whole
-2M x 1M x 100M graph on one MI355X (profiles/r05_bench_synth_full_n1.json) - 8.0 x the 17.8 ms a rank's share costs."""
+             stays exposed). Automatic: 1 below 64 MB per collective, 2 - 4 above (configs[4]: 4); the table prints one lane
+             (no overlap) and four. launches x latency = collective launches per
+             step x per-launch cost (RCCL on one rank, measured round 4: ~20 us; a peer-to-peer store + flag would be ~3 us)
+Speed-up = one-GPU time of the WHOLE problem / t. For configs[4] that denominator is measured: 138.3 ms per step for the whole
+2M x 1M x 100M graph on one MI355X (profiles/r05_bench_synth_full_n1.json) - 8.0 x the 17.3 ms a rank's share costs."""
 import argparse
 
 ap = argparse.ArgumentParser()
@@ -66,27 +67,29 @@ def table(name, I, U, d, nm, feat_dims, one_gpu_ms, rank_ms, weak):
             scheme, by / 1e9, recv / 1e9, recv / (N - 1) / 1e6))
     print("  %-17s (not built)                     received %6.2f GB / rank, %5.0f MB / link" % (
         "2-D 2x4", recv2d / 1e9, recv2d / (N - 1) / 1e6))
-    print("  speed-up over one GPU at N = 8 (%s), 4 column chunks, launch latency %.0f us | 3 us:" % (
-        "weak: 8 x the rows" if weak else "strong: the same problem", a.latency_us))
-    print("    %-9s" % "GB/s/link" + "".join("%22s" % s for s in ("item-side", "item-side + repl", "2-D 2x4 (not built)")))
-    for gbs in a.link_gbs:
-        cells = []
-        for scheme, recv, comp, launches in (("item-side", full["item-side"] * frac, rank_ms, 14 * 4),
-                                             ("item-side + repl", full["item-side + repl"] * frac, rank_ms + extra_ms, 12 * 4),
-                                             ("2-D", recv2d, rank_ms, 28 * 4)):
-            link = recv / (N - 1) / (gbs * 1e9) * 1e3
-            t = step_ms(comp, link, 4, launches)
-            lat = launches * a.latency_us * 1e-3
-            t3 = t - lat + launches * 3e-3
-            tot = one_gpu_ms * (N if weak else 1)
-            cells.append("%5.1fx | %4.1fx (%4.1f ms)" % (tot / t, tot / t3, t))
-        print("    %-9.0f" % gbs + "".join("%22s" % c for c in cells))
+    for nc, label in ((1, "ONE lane (--chunks 1: transfers and products one after the other)"),
+                      (4, "4 column-chunk lanes (what the automatic rule picks for 512 MB tables)")):
+        print("  speed-up over one GPU at N = 8 (%s), %s, launch latency %.0f us | 3 us:" % (
+            "weak: 8 x the rows" if weak else "strong: the same problem", label, a.latency_us))
+        print("    %-9s" % "GB/s/link" + "".join("%22s" % s for s in ("item-side", "item-side + repl", "2-D 2x4 (not built)")))
+        for gbs in a.link_gbs:
+            cells = []
+            for scheme, recv, comp, launches in (("item-side", full["item-side"] * frac, rank_ms, 14 * nc),
+                                                 ("item-side + repl", full["item-side + repl"] * frac, rank_ms + extra_ms, 12 * nc),
+                                                 ("2-D", recv2d, rank_ms, 28 * nc)):
+                link = recv / (N - 1) / (gbs * 1e9) * 1e3
+                t = (comp + link if nc == 1 else max(comp, link) + min(comp, link) / nc) + launches * a.latency_us * 1e-3
+                lat = launches * a.latency_us * 1e-3
+                t3 = t - lat + launches * 3e-3
+                tot = one_gpu_ms * (N if weak else 1)
+                cells.append("%5.1fx | %4.1fx (%4.1f ms)" % (tot / t, tot / t3, t))
+            print("    %-9.0f" % gbs + "".join("%22s" % c for c in cells))
     print()
 
 
 # configs[4]: one-GPU whole-problem step and the per-rank share (1/8 of it: the SpMM time is linear in the edges)
 table("configs[4]: 2M users x 1M items, 100M edges, d = 128, two 128-wide features (strong scaling, N = 8 is the config)",
-      I=1_000_000, U=2_000_000, d=128, nm=2, feat_dims=(128, 128), one_gpu_ms=142.2, rank_ms=142.2 / 8, weak=False)
+      I=1_000_000, U=2_000_000, d=128, nm=2, feat_dims=(128, 128), one_gpu_ms=138.3, rank_ms=138.3 / 8, weak=False)
 # Baby x 8 (weak scaling: the driver's --gpus 8 default): a 0.49 ms step against >= 14 collective launches
 table("Amazon-Baby shape x 8 (weak scaling: every rank one Baby-sized share), d = 64, 4096 + 1024 wide features",
       I=18357 * 8, U=35598 * 8, d=64, nm=2, feat_dims=(4096, 1024), one_gpu_ms=0.49, rank_ms=0.49, weak=True)

@@ -26,8 +26,8 @@ Model of a step at N ranks:  t = max(compute, link) + min(compute, link) / chunk
              stays exposed). Automatic: 1 below 64 MB per collective, 2 - 4 above (configs[4]: 4); the table prints one lane
              (no overlap) and four. launches x latency = collective launches per
              step x per-launch cost (RCCL on one rank, measured round 4: ~20 us; a peer-to-peer store + flag would be ~3 us)
-Speed-up = one-GPU time of the WHOLE problem / t. For configs[4] that denominator is measured: 138.3 ms per step for the whole
-2M x 1M x 100M graph on one MI355X (profiles/r05_bench_synth_full_n1.json) - 8.0 x the 17.3 ms a rank's share costs."""
+Speed-up = one-GPU time of the WHOLE problem / t. For configs[4] that denominator is measured: 139.7 ms per step for the whole
+2M x 1M x 100M graph on one MI355X (profiles/r05_bench_synth_full_n1.json) - 8.0 x the 17.5 ms a rank's share costs."""
 import argparse
 
 ap = argparse.ArgumentParser()
@@ -89,7 +89,7 @@ def table(name, I, U, d, nm, feat_dims, one_gpu_ms, rank_ms, weak):
 
 # configs[4]: one-GPU whole-problem step and the per-rank share (1/8 of it: the SpMM time is linear in the edges)
 table("configs[4]: 2M users x 1M items, 100M edges, d = 128, two 128-wide features (strong scaling, N = 8 is the config)",
-      I=1_000_000, U=2_000_000, d=128, nm=2, feat_dims=(128, 128), one_gpu_ms=138.3, rank_ms=138.3 / 8, weak=False)
+      I=1_000_000, U=2_000_000, d=128, nm=2, feat_dims=(128, 128), one_gpu_ms=139.7, rank_ms=139.7 / 8, weak=False)
 # Baby x 8 (weak scaling: the driver's --gpus 8 default): a 0.49 ms step against >= 14 collective launches
 table("Amazon-Baby shape x 8 (weak scaling: every rank one Baby-sized share), d = 64, 4096 + 1024 wide features",
       I=18357 * 8, U=35598 * 8, d=64, nm=2, feat_dims=(4096, 1024), one_gpu_ms=0.49, rank_ms=0.49, weak=True)

@@ -380,3 +380,20 @@ def test_baby_strong_scaling_partition_world8(tmp_path):
     assert A_ui[U:].nnz == 0 and A_ui[:, I:].nnz == 0 and A_iu[I:].nnz == 0 and A_iu[:, U:].nnz == 0     # padding is empty
     assert (A_ui[:U, :I] != ref_ui).nnz == 0 and (A_iu[:I, :U] != ref_iu).nnz == 0                          # bit-identical values
     assert outs[0]["E"] == raw.nnz == sum(o["ui"].nnz for o in outs) == sum(o["iu"].nnz for o in outs)
+
+
+def test_replicate_feats_choice_and_row_padding():
+    """dist.choose_replicate_feats: narrow features on many items (configs[4]) -> replicate; wide features (the Baby shape
+    x 8) -> ship the projected ones; never at world 1. dist._pad_rows keeps the rows and zero-fills the padding."""
+    from mmssl_amd import dist as md
+    assert md.choose_replicate_feats(1_000_000, [128, 128], 128, 8)
+    assert md.choose_replicate_feats(250_000, [128, 128], 128, 2)
+    assert not md.choose_replicate_feats(18357 * 8, [4096, 1024], 64, 8)
+    assert not md.choose_replicate_feats(1_000_000, [128, 128], 128, 1)
+    t = torch.arange(12.0).reshape(4, 3)
+    p = md._pad_rows(t, 6)
+    assert p.shape == (6, 3) and torch.equal(p[:4], t) and float(p[4:].abs().max()) == 0.0
+    assert md._pad_rows(t, 4).data_ptr() != t.data_ptr()
+    with pytest.raises(ValueError):
+        md.ShardedMMSSL(object(), None, md.RowShard(4, 1, 0), md.RowShard(4, 1, 0), {}, t, t, scheme="gather-both",
+                        replicate_feats=True)

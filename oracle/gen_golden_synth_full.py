@@ -5,6 +5,8 @@ gradients of every small parameter, and SAMPLED ROWS of the two output tables an
 
     python oracle/gen_golden_synth_full.py [--scale 8] [--out tests/golden/synth_full_n1.npz]
 
+Re-running it reproduces the committed file bit for bit (checked in the build container, 8 threads: ~4 min, ~30 GB).
+
 TEST INFRASTRUCTURE. The GPU tests (tests/test_synth_full_gpu.py) rebuild the same inputs from the same seeds on the GPU
 box and compare the HIP step - one GPU, and 8 ranks sharing it - against these rows; nothing of the oracle runs there.
 The reference itself cannot run this size at all (it allocates dense U x I matrices, /root/reference/MMSSL/main.py:59-60),

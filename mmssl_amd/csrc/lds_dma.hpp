@@ -24,6 +24,15 @@ __device__ __forceinline__ void glds16_nt(const float* gsrc, unsigned lds_dst) {
       : "v"(gsrc), "s"(lds_dst)
       : "memory");
 }
+// the same from a wave-uniform base (SGPR pair) + a 32-bit per-lane byte offset: no 64-bit per-lane pointer to carry
+__device__ __forceinline__ void glds16_s(const char* sbase, unsigned voff, unsigned lds_dst) {
+  unsigned keep_m0;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep_m0)
+      : "v"(voff), "s"(sbase), "s"(lds_dst)
+      : "memory");
+}
 template <int N>
 __device__ __forceinline__ void vm_wait_n() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");

@@ -432,9 +432,20 @@ __global__ __launch_bounds__(kBlock, WG_D <= 8 ? 2 : 1) void wgrad10_kernel(cons
 #pragma unroll
     for (int b = 0; b < 4; ++b) acc[a][b] = floatx4{0.f, 0.f, 0.f, 0.f};
   float bs[4] = {0.f, 0.f, 0.f, 0.f};
-  // Register ring of WG_D steps. The loads are inline asm so that neither the IR passes nor the machine scheduler can
-  // sink them next to their use (both did, which serialised load latency and MFMAs); the matching waits therefore are
-  // explicit: when slot d is consumed, exactly WG_D - 1 younger steps of loads are outstanding.
+  // Register ring of WG_D steps, loads and waits left to the compiler. History: the loads used to be inline asm with
+  // hand-counted `s_waitcnt vmcnt` (plain loads were sunk next to their use). To the compiler the destination of such a
+  // load is a value that exists once the asm has executed, so the allocator could COPY it before the hand-written wait:
+  // a `v_mov_b64` of slot 0's gradient fragment at the loop back-edge read a register whose load was still in flight,
+  // and the epilogue's lane index was written into a register a dead tail prefetch could still overwrite. Alone the
+  // loads had landed by then (7 steps of MFMAs); beside the GCN chain's SpMMs, at configs[4]'s size, one run in three or
+  // four was 6e-3 off (round 5; tools/vmcnt_check.py finds both in the old ISA and guards the remaining hand-counted
+  // kernel). What kept plain loads from staying where they are written was not the scheduler alone: the loads of a
+  // `const __restrict__` KERNEL ARGUMENT count as constant memory, are chained to the DAG's entry node and float freely
+  // inside the block. Through a laundered base pointer they are ordinary loads, ordered against side effects, and
+  // sched_barrier(0) is one: each step's loads stay between its two barriers, SIInsertWaitcnts counts vmcnt itself.
+  typedef const __attribute__((address_space(1))) char* gptr;        // still known to be global memory (not flat)
+  gptr Fq = (gptr)(uintptr_t)F, Gq = (gptr)(uintptr_t)gY, Kq = (gptr)(uintptr_t)keep;
+  asm volatile("" : "+s"(Fq), "+s"(Gq), "+s"(Kq));
   floatx4 fv[WG_D], gv[WG_D];
   uint32_t kv[WG_D];
   const int64_t m_mine = m_lo + 4 * wave + g;
@@ -445,21 +456,21 @@ __global__ __launch_bounds__(kBlock, WG_D <= 8 ? 2 : 1) void wgrad10_kernel(cons
   const uint32_t oF = (uint32_t)((m_base * K + c0 + 4 * j) * 4), oG = (uint32_t)((m_base * N + n0 + 4 * j) * 4);
   const uint32_t oK = (uint32_t)(m_base * N + n0 + 4 * j);
   const uint32_t sF = 64u * (uint32_t)K, sG = 64u * (uint32_t)N, sK = 16u * (uint32_t)N;
-  constexpr int kYounger = (KEEP ? 3 : 2) * (WG_D - 1);
   auto load = [&](int slot, int t) {
     const uint32_t tc = (uint32_t)min(t, t_last);
     const uint32_t a = oF + __umul24(tc, sF), b = oG + __umul24(tc, sG);
-    if (NT) asm volatile("global_load_dwordx4 %0, %1, %2 nt" : "=v"(fv[slot]) : "v"(a), "s"(F) : "memory");
-    else asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(fv[slot]) : "v"(a), "s"(F) : "memory");
-    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(gv[slot]) : "v"(b), "s"(gY) : "memory");
-    if (KEEP) {
-      const uint32_t c = oK + __umul24(tc, sK);
-      asm volatile("global_load_dword %0, %1, %2" : "=v"(kv[slot]) : "v"(c), "s"(keep) : "memory");
-    }
+    typedef const __attribute__((address_space(1))) floatx4* gvec;
+    typedef const __attribute__((address_space(1))) uint32_t* gword;
+    if (NT) fv[slot] = __builtin_nontemporal_load((gvec)(Fq + a));
+    else fv[slot] = *(gvec)(Fq + a);
+    gv[slot] = *(gvec)(Gq + b);
+    if (KEEP) kv[slot] = *(gword)(Kq + (oK + __umul24(tc, sK)));
   };
   auto consume = [&](int slot, int t) {
-    if (KEEP) asm volatile("s_waitcnt vmcnt(%3)" : "+v"(fv[slot]), "+v"(gv[slot]), "+v"(kv[slot]) : "n"(kYounger));
-    else asm volatile("s_waitcnt vmcnt(%2)" : "+v"(fv[slot]), "+v"(gv[slot]) : "n"(kYounger));
+    // the slot's readers start HERE (a side-effecting statement, ordered with the barriers): without it the scaling
+    // multiplies of all eight slots are hoisted to the top of the iteration and drain the ring there
+    if (KEEP) asm volatile("" : "+v"(fv[slot]), "+v"(gv[slot]), "+v"(kv[slot]));
+    else asm volatile("" : "+v"(fv[slot]), "+v"(gv[slot]));
     const float s1 = t <= t_valid ? sc : 0.f;
     float a[4];
     if (KEEP) {
@@ -480,14 +491,17 @@ __global__ __launch_bounds__(kBlock, WG_D <= 8 ? 2 : 1) void wgrad10_kernel(cons
     for (int rb = 0; rb < 4; ++rb)
 #pragma unroll
       for (int cb = 0; cb < 4; ++cb) acc[rb][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rb], f[cb], acc[rb][cb], 0, 0, 0);
-    // pin: the MFMAs of this step are issued HERE (left alone, the DAG scheduler defers them past the next loads)
+    // pin: the MFMAs of this step are issued HERE (they have no side effect: left alone they all sink below the loads)
 #pragma unroll
     for (int rb = 0; rb < 4; rb += 2)
       asm volatile("" : "+v"(acc[rb][0]), "+v"(acc[rb][1]), "+v"(acc[rb][2]), "+v"(acc[rb][3]), "+v"(acc[rb + 1][0]),
                         "+v"(acc[rb + 1][1]), "+v"(acc[rb + 1][2]), "+v"(acc[rb + 1][3]));
   };
 #pragma unroll
-  for (int d = 0; d < WG_D; ++d) load(d, d);
+  for (int d = 0; d < WG_D; ++d) {
+    load(d, d);
+    __builtin_amdgcn_sched_barrier(0);
+  }
   for (int t0 = 0; t0 < nsteps; t0 += WG_D) {
 #pragma unroll
     for (int d = 0; d < WG_D; ++d) {
@@ -497,7 +511,6 @@ __global__ __launch_bounds__(kBlock, WG_D <= 8 ? 2 : 1) void wgrad10_kernel(cons
       __builtin_amdgcn_sched_barrier(0);
     }
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the ring's last prefetches still target live registers
   float4* mine = red + wave * 1024;
 #pragma unroll
   for (int rb = 0; rb < 4; ++rb)

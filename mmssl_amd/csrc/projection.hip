@@ -720,19 +720,37 @@ struct FragX {
   uintx4 b[3][2][2];       // [plane][k-step][column half]: channel 32 half + (lane & 31), same reduction values
 };
 
-// 16 bytes global -> VGPRs, non-temporal, as an asm the compiler cannot wait for by itself: the kernel keeps kXDepth
-// slices of its A operand in flight in registers and counts vmcnt by hand (the LDS-DMA pieces of B share that counter).
-template <int OFF>
-__device__ __forceinline__ void gload16_nt(floatx4& dst, const float* p) {
-  asm volatile("global_load_dwordx4 %0, %1, off offset:%2 nt" : "=v"(dst) : "v"(p), "n"(OFF) : "memory");
+// 16 bytes global -> VGPRs, non-temporal. A PLAIN load: the kernel keeps kXDepth slices of its A operand in flight in
+// registers, and the wait for them is the compiler's (SIInsertWaitcnts puts the vmcnt in front of the first reader, and in
+// front of any copy the register allocator makes of such a register). Until round 6 these loads were inline asm waited for
+// with the hand-counted vmcnt that B's LDS-DMA pieces need anyway: to the compiler the destination of an asm load is a
+// value that exists as soon as the statement has executed, so it may copy it, or reuse a dead prefetch's register, before
+// the hand-written wait - the cause of the round-5 intermittent weight gradient in linear.hip's wgrad10_kernel. The DMA
+// pieces (asm, invisible to the compiler) sit between the A loads in the memory queue, so the compiler's count for A is
+// never too lenient: it waits for at most two loads more than the hand count did.
+typedef const __attribute__((address_space(1))) floatx4* gvec4;
+typedef const __attribute__((address_space(1))) char* gbytes;
+// a pointer every lane holds the same value of, as the SGPR pair the saddr forms want (the divergence analysis does not
+// see through the segment lookup's VALU divisions)
+__device__ __forceinline__ const char* uniform_ptr(const void* p) {
+  const uint64_t v = reinterpret_cast<uint64_t>(p);
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+  return reinterpret_cast<const char*>(((uint64_t)hi << 32) | lo);
 }
-// "these four registers are valid from here on": ties their readers behind the wait that precedes this statement
+// wave-uniform base + 32-bit per-lane byte offset (+ immediate): the saddr form of global_load
+template <int OFF>
+__device__ __forceinline__ void gload16_nt(floatx4& dst, const char* sbase, unsigned voff) {
+  dst = __builtin_nontemporal_load((gvec4)((gbytes)(uintptr_t)sbase + voff + OFF));
+}
+// "the readers of these four registers start here": a side-effecting statement (ordered with the barriers and the DMA
+// issues) that the cut of the slice into bf16 planes cannot be hoisted across; the compiler's vmcnt lands in front of it
 __device__ __forceinline__ void tie4(floatx4& a, floatx4& b, floatx4& c, floatx4& d) {
   asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d)::"memory");
 }
 
 // slices in flight per wave (template parameter of the kernel): A in registers, B in the LDS ring of that many stages
-constexpr int x_lds_bytes(int depth) { return depth * kXBBytes; }        // only the short operand passes through LDS
+// only the short operand passes through LDS; one stage more = the dump the issues past a range's end write into
+constexpr int x_lds_bytes(int depth) { return (depth + 1) * kXBBytes; }
 
 // The long operand never touches LDS: a wave's MFMA rows are read by that wave alone, so each lane loads the 16 values of
 // its row straight into registers - four fully coalesced 1 KB loads per wave and slice out of an image laid out for
@@ -764,45 +782,64 @@ __global__ __launch_bounds__(kThreads) void projx_sk_kernel(Group P, int upb, in
   // segment = the slices of one output tile; 2.5 per block on the Baby shape). Draining and refilling at every boundary,
   // as the fp32 kernels above do, cost ~5 us each with four slices in flight. Two cursors walk the range: the issue cursor
   // (source pointers of the next slice to load) and the compute cursor (slices left in the tile being accumulated).
-  const float* pa = nullptr;       // issue cursor: this lane's source of the next slice's A values / B pieces
+  //
+  // EVERY step issues the same memory instructions, on every path: past the end of the range the issues still go out,
+  // from one lane-uniform line of the first image (a single 64-byte request) into registers nobody reads and into the
+  // LDS dump stage. The memory queue then has ONE shape: the hand-counted waits for the DMA pieces are constants (no
+  // ladder over "how many slices are left"), and the compiler's own vmcnt for the register loads is exact - a pass that
+  // merges control-flow paths can only keep the smallest count, so with conditional issues it drained the ring
+  // (vmcnt(0)) in every step. tools/vmcnt_check.py walks the same graph and needs the same property.
+  // issue cursor: wave-uniform sources of the next slice's A values / B pieces (+ this lane's constant byte offsets)
+  const char* pa = nullptr;
   const char* pb = nullptr;
+  const unsigned la = (unsigned)(wave * 1024 + 4 * lane) * 4u, lb = 16u * (unsigned)lane;
   int i_left = 0;                  // slices left in the issue cursor's segment
-  int64_t i_u = u_begin;
+  int i_k = 0;                     // slices issued so far (32-bit: `i_k < n` is a scalar compare, the select stays in SGPRs)
   floatx4 raw[kXDepth][4];
+  const unsigned dump_lds = ring_lds + (unsigned)kXDepth * kXBBytes;
   // The issue cursor's next slice: `issue_B` sends its two DMA pieces of B into LDS stage k % depth, `issue_A` its four
   // loads of A into register set J and advances the cursor. B runs THREE slices ahead of the MFMAs, A four: a stage is
   // then refilled a whole step after its last operand read was issued, so the step's barrier only needs the reads
   // issued before the latest six (lgkmcnt(6)) - the reads of the slice's second half no longer stall the barrier.
+  // Slices k >= n do not exist: their issues re-read the first line of the range's LAST slice (every lane the same 16
+  // bytes) - no second pointer to carry, and the address is one this block has just read.
   auto open_segment = [&]() {
     if (i_left == 0) {
-      const Segment sg = segment_at(P, i_u, u_end);
-      pa = P.A[sg.g] + ((int64_t)sg.tip * P.S[sg.g] + sg.s0) * kXAFloats + wave * 1024 + 4 * lane;
-      pb = reinterpret_cast<const char*>(P.B[sg.g]) + (int64_t)sg.s0 * kXBBytes + 16 * lane;
+      const Segment sg = segment_at(P, u_begin + i_k, u_end);
+      pa = uniform_ptr(P.A[sg.g] + ((int64_t)sg.tip * P.S[sg.g] + sg.s0) * kXAFloats);
+      pb = uniform_ptr(reinterpret_cast<const char*>(P.B[sg.g]) + (int64_t)sg.s0 * kXBBytes);
       i_left = sg.nk;
     }
   };
-  // B of slice k where k = (slices A has issued so far) - 1 + ... : called right BEFORE issue_A of the slice after it
-  const char* pb_next = nullptr;       // source of the next B slice to issue (B lags A by one slice)
+  // B of slice k: called right BEFORE issue_A of the slice after it (B lags A by one slice), i.e. when `pb` has been
+  // advanced past slice k (or past the last slice, for k >= n) and the next segment has not been opened yet
   auto issue_B = [&](int k) {
-    const unsigned st = ring_lds + (unsigned)(k % kXDepth) * kXBBytes;
+    const bool real = k < n;
+    const unsigned st = real ? ring_lds + (unsigned)(k % kXDepth) * kXBBytes : dump_lds;
+    const unsigned off = real ? lb : 0u;
+    const char* src = pb - kXBBytes;
     if (!(MMSSL_PROJX_DBG & 8) || k < kXDepth) {
-      glds16(reinterpret_cast<const float*>(pb_next + be0 * 1024), st + (unsigned)(be0 * 1024));
-      glds16(reinterpret_cast<const float*>(pb_next + be1 * 1024), st + (unsigned)(be1 * 1024));
+      glds16_s(src + be0 * 1024, off, st + (unsigned)(be0 * 1024));
+      glds16_s(src + be1 * 1024, off, st + (unsigned)(be1 * 1024));
     }
   };
   auto issue_A = [&](auto J, int k) {
-    open_segment();
+    const bool real = k < n;
+    if (real) open_segment();
+    const char* src = real ? pa : pa - kXAFloats * 4;
+    const unsigned off = real ? la : 0u;
     if (!(MMSSL_PROJX_DBG & 1) || k < kXDepth) {
-      gload16_nt<0>(raw[J.value][0], pa);
-      gload16_nt<1024>(raw[J.value][1], pa);
-      gload16_nt<2048>(raw[J.value][2], pa);
-      gload16_nt<3072>(raw[J.value][3], pa);
+      gload16_nt<0>(raw[J.value][0], src, off);
+      gload16_nt<1024>(raw[J.value][1], src, off);
+      gload16_nt<2048>(raw[J.value][2], src, off);
+      gload16_nt<3072>(raw[J.value][3], src, off);
     }
-    pb_next = pb;                      // this slice's B goes out with the NEXT issue (one step later)
-    pa += kXAFloats;
-    pb += kXBBytes;
-    --i_left;
-    ++i_u;
+    if (real) {
+      pa += kXAFloats * 4;
+      pb += kXBBytes;
+      --i_left;
+      ++i_k;
+    }
   };
   // the operands of k-step s of slice k: my A values from register set J (cut into planes here), six reads of B planes
   auto take_half = [&](auto J, int k, int s, FragX& f) {
@@ -851,22 +888,21 @@ __global__ __launch_bounds__(kThreads) void projx_sk_kernel(Group P, int upb, in
   // B: barrier). B of slice k + 3 and A of slice k + 4 are issued into the stage / register set their predecessors have
   // left; after each k-step's MFMAs slice k + 1's operands replace the ones those MFMAs read. A tile's last slice then leaves the accumulator image in
   // the range's next partial slot (the forward kernel's plane order: the 32x32 C layout is dtype-independent).
+  // Steps k >= n (the loop below runs whole groups of kXDepth) only issue: see the note on the memory queue above.
   auto step = [&](auto J, int k, FragX& f) {
     constexpr int JN = (J.value + 1) % kXDepth;
     const bool more1 = k + 1 < n;
-    if (more1) {
-      // memory instructions younger than B(k + 1) in issue order: A(k + 2), B(k + 2), A(k + 3) - as far as they exist
-      const int young = (k + 2 < n ? 6 : 0) + (k + 3 < n ? 4 : 0);
-      if (young >= 10) vm_wait_n<10>();
-      else if (young >= 6) vm_wait_n<6>();
-      else vm_wait_n<0>();
-      tie4(raw[JN][0], raw[JN][1], raw[JN][2], raw[JN][3]);
-      __builtin_amdgcn_s_waitcnt(0xC07F | (6 << 8));          // lgkmcnt(6): all operand reads but the latest six
-      asm volatile("" ::: "memory");
-      bare_barrier();
-    }
-    if (k + kXDepth - 1 < n) issue_B(k + kXDepth - 1);
-    if (k + kXDepth < n) issue_A(J, k + kXDepth);
+    // memory instructions younger than B(k + 1) in issue order: A(k + 2), B(k + 2), A(k + 3) = 4 + 2 + 4, always.
+    // Unconditional (also in the steps past the end, where nothing reads what landed): a wait that only some paths
+    // take leaves, for the compiler, loads in flight into registers it reuses - it then waits again, conservatively.
+    vm_wait_n<10>();
+    tie4(raw[JN][0], raw[JN][1], raw[JN][2], raw[JN][3]);
+    __builtin_amdgcn_s_waitcnt(0xC07F | (6 << 8));          // lgkmcnt(6): all operand reads but the latest six
+    asm volatile("" ::: "memory");
+    bare_barrier();
+    issue_B(k + kXDepth - 1);
+    issue_A(J, k + kXDepth);
+    if (k >= n) return;
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       mfma_half(s, f);
@@ -888,19 +924,15 @@ __global__ __launch_bounds__(kThreads) void projx_sk_kernel(Group P, int upb, in
     }
   };
   // prologue, in the steady order (B of a slice goes out right before A of the next one): A0 | B0 A1 | B1 A2 | B2 A3
-  static_assert(kXDepth == 4, "the prologue and the wait counts below are written for four slices in flight");
+  static_assert(kXDepth == 4, "the prologue and the wait counts are written for four slices in flight");
   issue_A(std::integral_constant<int, 0>{}, 0);
   issue_B(0);
-  if (n > 1) { issue_A(std::integral_constant<int, 1>{}, 1); issue_B(1); }
-  if (n > 2) { issue_A(std::integral_constant<int, 2>{}, 2); issue_B(2); }
-  if (n > 3) issue_A(std::integral_constant<int, 3>{}, 3);
-  {     // A(0) and B(0) have landed: younger than B(0) are A1 B1 A2 B2 A3, as far as they exist
-    const int young = (n > 1 ? 6 : 0) + (n > 2 ? 6 : 0) + (n > 3 ? 4 : 0);
-    if (young >= 16) vm_wait_n<16>();
-    else if (young >= 12) vm_wait_n<12>();
-    else if (young >= 6) vm_wait_n<6>();
-    else vm_wait_n<0>();
-  }
+  issue_A(std::integral_constant<int, 1>{}, 1);
+  issue_B(1);
+  issue_A(std::integral_constant<int, 2>{}, 2);
+  issue_B(2);
+  issue_A(std::integral_constant<int, 3>{}, 3);
+  vm_wait_n<16>();     // A(0) and B(0) have landed: younger than B(0) are A1 B1 A2 B2 A3 = 4 + 2 + 4 + 2 + 4
   tie4(raw[0][0], raw[0][1], raw[0][2], raw[0][3]);
   bare_barrier();
   FragX f;
@@ -908,14 +940,12 @@ __global__ __launch_bounds__(kThreads) void projx_sk_kernel(Group P, int upb, in
   take_half(std::integral_constant<int, 0>{}, 0, 1, f);
   for (int k = 0; k < n; k += kXDepth) {
     step(std::integral_constant<int, 0>{}, k, f);
-    if (k + 1 < n) step(std::integral_constant<int, 1>{}, k + 1, f);
-    if (k + 2 < n) step(std::integral_constant<int, 2>{}, k + 2, f);
-    if (k + 3 < n) step(std::integral_constant<int, 3>{}, k + 3, f);
-    if constexpr (kXDepth > 4) { if (k + 4 < n) step(std::integral_constant<int, 4 % kXDepth>{}, k + 4, f); }
-    if constexpr (kXDepth > 5) { if (k + 5 < n) step(std::integral_constant<int, 5 % kXDepth>{}, k + 5, f); }
-    if constexpr (kXDepth > 6) { if (k + 6 < n) step(std::integral_constant<int, 6 % kXDepth>{}, k + 6, f); }
-    if constexpr (kXDepth > 7) { if (k + 7 < n) step(std::integral_constant<int, 7 % kXDepth>{}, k + 7, f); }
+    step(std::integral_constant<int, 1>{}, k + 1, f);
+    step(std::integral_constant<int, 2>{}, k + 2, f);
+    step(std::integral_constant<int, 3>{}, k + 3, f);
   }
+  // the issues past the end are still in flight: their DMA pieces must not land in LDS the next block already owns
+  vm_wait_n<0>();
 }
 
 // one 16-byte chunk of each plane: the eight values x[0..7] of row j, chunk c of slice-image `img`

@@ -951,14 +951,9 @@ class _ShardedHotForward(torch.autograd.Function):
             with st.gcn():
                 gi = rg.add_(Gi, alpha=inv)
         # ---- the weight gradient (current stream) next to the rest of the GCN chain (side stream)
-        if hasattr(bk, "_grouped") and not bk._grouped([f.shape[1] for f in Fs], Fs[0].shape[0], d):
-            # Per-modality weight-gradient kernels (shapes the grouped projection does not take, e.g. configs[4]'s d = 128):
-            # NOT beside the GCN chain. At the full configs[4] size one run in three or four gave a text-projection weight
-            # gradient 6e-3 off the golden when these launches overlapped the side stream's SpMMs; every kernel involved is
-            # bit-stable on its own and pairwise (tools/wgrad_stress.py), the cause is not found; with the chains joined
-            # here 5 of 5 runs are right (profiles/NOTEBOOK.md, round 5). Costs the overlap of ~2 x 1.3 ms at that size.
-            st.join()
-            st.fork()
+        # (Round 5 joined the chains here for the per-modality kernels: one run in three or four at configs[4]'s size had a
+        # text-projection weight gradient 6e-3 off. Root cause, round 6: csrc/linear.hip's wgrad10_kernel copied a register
+        # whose load was still in flight - see the note in that kernel and tools/vmcnt_check.py. The overlap is back.)
         gW, gb = bk.proj_wgrad(gX, list(Fs), any(has_b))
         with st.gcn():
             for _ in range(n_layers - 1):

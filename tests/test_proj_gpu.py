@@ -168,3 +168,91 @@ def test_split_precision_images_follow_the_feature_matrix():
         Fn = torch.randn(M, K, device=DEV)
         Yn, _ = ops.proj_forward([Fn], W, [None])
         assert H.rel_err(Yn.cpu(), (Fn @ W[0].t()).cpu()) < 2e-5
+
+
+def test_per_modality_weight_gradient_is_bit_stable_beside_memory_bound_streams():
+    """csrc/linear.hip wgrad10_kernel at configs[4]'s shape ([1M, 128]^T x [1M, 128], with and without the fused dropout
+    backward) while three other streams saturate the memory system with HBM-resident transposed SpMMs and a fourth with
+    device copies: 30 launches of each kind, every result the same bits as on the idle device. The round-5 kernel
+    (registers copied while their loads were in flight) fails this when its loads are late enough:
+    tools/wgrad_race_repro.py is the A/B of the two builds, profiles/r06/wgrad_race_repro.txt its record."""
+    from mmssl_amd import ops, synth
+    from mmssl_amd.graph import GraphPlan
+    dev = torch.device("cuda")
+    raw = synth.interaction_matrix(250_000, 1_000_000, 12_500_000, seed=1000, item_seed=77)
+    plan = GraphPlan(synth.normalised_rows(raw), xcd_bands=-1)
+    g = torch.Generator().manual_seed(0)
+    rows = 1_000_000
+    G = torch.randn(rows, 128, generator=g).to(dev)
+    F_ = torch.randn(rows, 128, generator=g).to(dev)
+    keep = (torch.rand(rows, 128, generator=g) >= 0.2).to(torch.uint8).to(dev)
+    W = torch.empty(128, 128, device=dev)
+    Gu = [torch.randn(250_000, 128, generator=g).to(dev) for _ in range(3)]
+    big = [torch.empty(256 << 20, dtype=torch.uint8, device=dev) for _ in range(2)]
+    torch.cuda.synchronize()
+    ref = {"plain": ops._linear_wgrad_raw(G, None, 1.0, F_, W)[1].clone(),
+           "masked": ops._linear_wgrad_raw(G, keep, 1.25, F_, W)[1].clone()}
+    # against float64 on a slice of the reduction (the whole product on the CPU would take a minute)
+    sub = slice(0, 200_000)
+    want = (G[sub].double().t() @ F_[sub].double()).float()
+    got = ops._linear_wgrad_raw(G[sub].contiguous(), None, 1.0, F_[sub].contiguous(), W)[1]
+    assert float((got - want).abs().max()) <= 2e-5 * float(want.abs().max())
+    main_s, copy_s = torch.cuda.Stream(), torch.cuda.Stream()
+    hog_s = [torch.cuda.Stream() for _ in range(3)]
+    for it in range(10):
+        for h, st in enumerate(hog_s):
+            with torch.cuda.stream(st):
+                for _ in range(6):
+                    ops._spmm_raw(plan.twin(h + 1), True, Gu[h], ops.EPI_NONE)
+        with torch.cuda.stream(copy_s):
+            for _ in range(8):
+                big[1].copy_(big[0])
+        with torch.cuda.stream(main_s):
+            outs = {"plain": [ops._linear_wgrad_raw(G, None, 1.0, F_, W)[1] for _ in range(3)],
+                    "masked": [ops._linear_wgrad_raw(G, keep, 1.25, F_, W)[1] for _ in range(3)]}
+        torch.cuda.synchronize()
+        for k, lst in outs.items():
+            for o in lst:
+                assert torch.equal(o, ref[k]), (it, k, float((o - ref[k]).abs().max()), float(ref[k].abs().max()))
+
+
+def test_grouped_projection_is_bit_stable_beside_memory_bound_streams():
+    """The same question for the hot path's split-precision projection at the Baby shape (csrc/projection.hip
+    projx_sk_kernel keeps four slices of its long operand in flight in registers): forward and weight gradient, 30
+    launches each under the same load, the bits of the idle device every time."""
+    from mmssl_amd import ops, synth
+    from mmssl_amd.graph import GraphPlan
+    dev = torch.device("cuda")
+    raw = synth.interaction_matrix(250_000, 1_000_000, 12_500_000, seed=1000, item_seed=77)
+    plan = GraphPlan(synth.normalised_rows(raw), xcd_bands=-1)
+    M, Ks = 18357, (4096, 1024)
+    Fs, Ws, bs, keep = _problem(M, Ks, 11)
+    Fd, Wd, bd, keep = [f.to(dev) for f in Fs], [w.to(dev) for w in Ws], [b.to(dev) for b in bs], keep.to(dev)
+    g = torch.Generator().manual_seed(1)
+    Gd = torch.randn(M, 64 * len(Ks), generator=g).to(dev)
+    Gu = [torch.randn(250_000, 128, generator=g).to(dev) for _ in range(3)]
+    big = [torch.empty(256 << 20, dtype=torch.uint8, device=dev) for _ in range(2)]
+    torch.cuda.synchronize()
+    Y0 = ops.proj_forward(Fd, Wd, bd, keep=keep, scale=1.25)[0].clone()
+    gW0, gb0 = ops.proj_wgrad(Gd, Fd)
+    gW0, gb0 = [t.clone() for t in gW0], [t.clone() for t in gb0]
+    torch.cuda.synchronize()
+    main_s, copy_s = torch.cuda.Stream(), torch.cuda.Stream()
+    hog_s = [torch.cuda.Stream() for _ in range(3)]
+    for it in range(10):
+        for h, st in enumerate(hog_s):
+            with torch.cuda.stream(st):
+                for _ in range(3):
+                    ops._spmm_raw(plan.twin(h + 1), True, Gu[h], ops.EPI_NONE)
+        with torch.cuda.stream(copy_s):
+            for _ in range(4):
+                big[1].copy_(big[0])
+        with torch.cuda.stream(main_s):
+            Ys = [ops.proj_forward(Fd, Wd, bd, keep=keep, scale=1.25)[0] for _ in range(3)]
+            gs = [ops.proj_wgrad(Gd, Fd) for _ in range(3)]
+        torch.cuda.synchronize()
+        for Y in Ys:
+            assert torch.equal(Y, Y0), (it, "forward", float((Y - Y0).abs().max()))
+        for gW, gb in gs:
+            for a, b in zip(list(gW) + list(gb), gW0 + gb0):
+                assert torch.equal(a, b), (it, "wgrad", float((a - b).abs().max()), float(b.abs().max()))

@@ -635,6 +635,50 @@ int mmssl_ngcf_combine_bwd_f32(const float* G, const float* B, const uint8_t* ke
                                const float* g_ego, const float* g_norm, int64_t rows, int d, float eps, float* gG,
                                float* gB, void* stream);
 
+/* ------------------------------------------------------------------------------------
+ * Peer exchange (csrc/peer.hip): the row-sharded tables of mmssl_amd/dist.py move between the ranks of ONE node through
+ * IPC-mapped device windows and epoch flags written by kernels - no collective library in the data path. The reference
+ * has no multi-device path at all (MMSSL/main.py:529: one CUDA_VISIBLE_DEVICES); BASELINE.json's north_star asks for the
+ * all-gather of neighbour embeddings before each propagation layer (MMSSL/Models.py:201-211), which this replaces RCCL for.
+ *   context   one per process (= rank); `max_channels` epoch channels. Handles (mmssl_peer_handle_bytes() bytes each) travel
+ *             between the processes by any host mechanism (the Python layer: torch.distributed all_gather_object).
+ *   window    mmssl_peer_window_create allocates `bytes` of device memory (zeroed) and returns its IPC handle;
+ *             mmssl_peer_window_open takes ALL ranks' handles of the same window id ([world][handle_bytes], own slot
+ *             ignored) and maps the peers' buffers. Windows live until mmssl_peer_destroy.
+ *   channel   mmssl_peer_signal: epoch[ch] += 1 and a system-scope release store of it into slot [ch][rank] of every
+ *             rank's flags; mmssl_peer_wait: returns (in stream order) once every slot [ch][*] of THIS rank's flags has
+ *             reached epoch[ch] - i.e. every rank has signalled as often as this one. A wait that is not satisfied within
+ *             the timeout (default 20 s) sets the context's error word and returns: the device is never hung;
+ *             mmssl_peer_error copies the word to the host (blocking) - non-zero = some wait gave up, results invalid.
+ *   push      rows [0, rows) x `width` floats of `src` (row pitch src_pitch floats) -> rows [dst_row0, ...) of EVERY rank's
+ *             window `win_id` (row pitch dst_pitch), then signal(ch): the all-gather, pushed over every link at once.
+ *   pull-sum  out[r] = sum_{q = 0 .. world-1, in that order} window_q[row0 + r]: the reduce-scatter as a pull with a
+ *             fixed summation order (the same bits on every run and for every rank count's partition of the same sum
+ *             order); call after signal + wait on the channel that guards the window.
+ *   sum-slots out[j] = sum_{q = 0 .. n-1} slots[q * stride + j] (local): the second half of an all-reduce by push.
+ * All compute calls are asynchronous on `stream` and hipGraph-capturable (epochs live in device memory).
+ * widths, pitches: multiples of 4 floats; pointers 16-byte aligned; world <= 16.
+ * ---------------------------------------------------------------------------------- */
+typedef struct mmssl_peer mmssl_peer;
+int mmssl_peer_create(int world, int rank, int max_channels, mmssl_peer** out);
+int mmssl_peer_destroy(mmssl_peer* p);
+/* info[0..5] = world, rank, max_channels, flags in fine-grained memory (0/1), windows, window bytes */
+int mmssl_peer_info(const mmssl_peer* p, int64_t* info);
+int mmssl_peer_set_timeout_ms(mmssl_peer* p, int64_t ms);
+int mmssl_peer_handle_bytes(void);
+int mmssl_peer_flags_handle(mmssl_peer* p, void* handle_out);
+int mmssl_peer_open_flags(mmssl_peer* p, const void* handles);
+int mmssl_peer_window_create(mmssl_peer* p, int64_t bytes, int* win_id, void* handle_out, void** local_ptr);
+int mmssl_peer_window_open(mmssl_peer* p, int win_id, const void* handles);
+int mmssl_peer_push_rows_f32(mmssl_peer* p, int ch, int win_id, const float* src, int64_t src_pitch, int64_t rows, int width,
+                             int64_t dst_row0, int64_t dst_pitch, void* stream);
+int mmssl_peer_signal(mmssl_peer* p, int ch, void* stream);
+int mmssl_peer_wait(mmssl_peer* p, int ch, void* stream);
+int mmssl_peer_pull_sum_rows_f32(mmssl_peer* p, int win_id, int64_t row0, int64_t rows, int width, int64_t pitch, float* out,
+                                 int64_t out_pitch, void* stream);
+int mmssl_peer_sum_slots_f32(const float* slots, int n, int64_t stride, int64_t len, float* out, void* stream);
+int mmssl_peer_error(mmssl_peer* p, uint32_t* err);
+
 #ifdef __cplusplus
 }
 #endif

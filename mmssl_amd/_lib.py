@@ -138,6 +138,23 @@ SIGNATURES = {
                                        c_void_p]),
     "mmssl_ngcf_combine_bwd_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_int64,
                                            c_int, c_float, c_void_p, c_void_p, c_void_p]),
+    "mmssl_peer_create": (c_int, [c_int, c_int, c_int, POINTER(c_void_p)]),
+    "mmssl_peer_destroy": (c_int, [c_void_p]),
+    "mmssl_peer_info": (c_int, [c_void_p, _i64p]),
+    "mmssl_peer_set_timeout_ms": (c_int, [c_void_p, c_int64]),
+    "mmssl_peer_handle_bytes": (c_int, []),
+    "mmssl_peer_flags_handle": (c_int, [c_void_p, c_void_p]),
+    "mmssl_peer_open_flags": (c_int, [c_void_p, c_void_p]),
+    "mmssl_peer_window_create": (c_int, [c_void_p, c_int64, POINTER(c_int), c_void_p, POINTER(c_void_p)]),
+    "mmssl_peer_window_open": (c_int, [c_void_p, c_int, c_void_p]),
+    "mmssl_peer_push_rows_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int64, c_int64, c_int, c_int64, c_int64,
+                                         c_void_p]),
+    "mmssl_peer_signal": (c_int, [c_void_p, c_int, c_void_p]),
+    "mmssl_peer_wait": (c_int, [c_void_p, c_int, c_void_p]),
+    "mmssl_peer_pull_sum_rows_f32": (c_int, [c_void_p, c_int, c_int64, c_int64, c_int, c_int64, c_void_p, c_int64,
+                                             c_void_p]),
+    "mmssl_peer_sum_slots_f32": (c_int, [c_void_p, c_int, c_int64, c_int64, c_void_p, c_void_p]),
+    "mmssl_peer_error": (c_int, [c_void_p, POINTER(ctypes.c_uint32)]),
     "mmssl_mask_scale_f32": (c_int, [c_void_p, c_void_p, c_float, c_int64, c_void_p, c_void_p]),
     "mmssl_mask_packed_f32": (c_int, [c_void_p, c_void_p, c_float, c_int64, c_int, c_int, c_void_p, c_void_p]),
     "mmssl_dropout_mask_u8": (c_int, [c_void_p, c_float, c_int64, c_void_p, c_void_p]),

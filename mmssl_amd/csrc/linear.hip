@@ -796,7 +796,8 @@ inline bool wg10_usable(int64_t M, int K, int N) {
          K < (1 << 18) && N < (1 << 18);
 }
 inline WgPlan wg10_plan(int64_t M, int K, int N) {
-  constexpr int target = 512, max_sp = 8;
+  // (max_sp was 8 until round 6: configs[4]'s [1M, 128] x [1M, 128] then ran as 2 x 2 x 8 = 32 blocks on 256 CUs)
+  constexpr int target = 512, max_sp = 128;
   WgPlan p;
   p.tk = K / 64;
   p.tn = N / 64;

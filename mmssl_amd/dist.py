@@ -275,7 +275,40 @@ def _solo(group):
     return dist.get_world_size(group) == 1 and os.environ.get("MMSSL_DIST_FORCE_COLLECTIVES", "0") != "1"
 
 
+# ---- peer exchange (mmssl_amd/peer.py, csrc/peer.hip): the same exchanges without a collective library in the data path ----
+_PEER = {}
+
+
+def _gkey(group):
+    return group if group is not None else dist.group.WORLD
+
+
+def enable_peer_exchange(group=None, device=None, timeout_ms=20000):
+    """Route every exchange of `group` (all-gather / reduce-scatter of table rows, the small all-reduces) through
+    IPC-mapped peer windows written and read by kernels. A host-side collective (IPC handles travel over `group`); the
+    ranks must be processes of ONE node. Returns the PeerComm."""
+    from .peer import PeerComm
+    key = _gkey(group)
+    if key not in _PEER:
+        dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        _PEER[key] = PeerComm(key, dev, timeout_ms=timeout_ms)
+    return _PEER[key]
+
+
+def disable_peer_exchange(group=None):
+    pc = _PEER.pop(_gkey(group), None)
+    if pc is not None:
+        pc.close()
+
+
+def _peer(group):
+    return _PEER.get(_gkey(group)) if _PEER else None
+
+
 def _all_reduce(t, group):
+    pc = _peer(group)
+    if pc is not None and t.is_cuda and not _solo(group):
+        return pc.all_reduce_(t)
     if not _solo(group):
         fence = t.is_cuda and dist.get_backend(group) == "gloo"        # (test transport: see _gloo_device_fence)
         if fence:
@@ -301,6 +334,10 @@ def _all_gather_into(out, x, group):
     """all_gather_into_tensor; device tensors on a gloo group (tests: several ranks sharing ONE GPU) go through gloo's device
     all-reduce of a zero-padded buffer - gloo has no device all-gather - which is the same data movement seen from the
     step."""
+    pc = _peer(group)
+    if pc is not None and x.is_cuda:
+        out.copy_(pc.gather(x if x.dim() == 2 else x.reshape(x.shape[0], -1)).view_as(out))
+        return out
     if x.is_cuda and dist.get_backend(group) == "gloo":
         per = x.shape[0]
         r = dist.get_rank(group)
@@ -317,6 +354,10 @@ def _all_gather_into(out, x, group):
 def _reduce_scatter_sum(full, per, group):
     if _solo(group):
         return full
+    pc = _peer(group)
+    if pc is not None and full.is_cuda:
+        f2 = full if full.dim() == 2 else full.reshape(full.shape[0], -1)
+        return pc.reduce(f2, per).view((per,) + tuple(full.shape[1:]))
     if dist.get_backend(group) == "gloo":      # gloo has no reduce_scatter: all-reduce + slice
         full = full.contiguous()
         _gloo_device_fence(full)
@@ -616,6 +657,9 @@ class ShardedMMSSL(nn.Module):
         implementation (_ShardedHotForward); fused=False composes differentiable backend ops and
         AllGatherRows (the same math, kept as the cross-check)."""
         bk, c = self.bk, self.cfg
+        pc = _peer(self.group)
+        if pc is not None and self.E_i.is_cuda and not _solo(self.group):
+            pc.begin_step()          # every rank has finished the previous step: the exchange windows may be rewritten
         self.last_fused = bool(fused and bk.packed_supported([self.image_feats.shape[1], self.text_feats.shape[1]],
                                                              self.ish.per, c.embed_size))
         if self.last_fused:
@@ -704,6 +748,11 @@ def _all_gather_raw(x, group):
     if _solo(group):
         _log_comm("all_gather", x)
         return x
+    pc = _peer(group)
+    if pc is not None and x.is_cuda and x.dim() == 2 and x.stride(1) == 1:
+        out = pc.gather(x)                    # the window itself: no staging copy, row-pitched shards pushed as they are
+        _log_comm("peer_gather", out)
+        return out
     out = torch.empty((world * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
     _all_gather_into(out, x.contiguous(), group)
     _log_comm("all_gather", out)
@@ -725,6 +774,8 @@ def _all_gather_pair(xa, xb, group):
         if COMM["log"] is not None:
             COMM["log"].append(("all_gather", (tuple(xa.shape), tuple(xb.shape)), 4 * (xa.numel() + xb.numel())))
         return xa, xb
+    if _peer(group) is not None and xa.is_cuda:
+        return _all_gather_raw(xa, group), _all_gather_raw(xb, group)
     world = dist.get_world_size(group)
     outs = [torch.empty((world * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device) for x in (xa, xb)]
     cm, grouped = _coalesced(group, xa.device)
@@ -742,10 +793,13 @@ def _all_gather_pair(xa, xb, group):
 
 def _reduce_scatter_pair(fa, fb, per, group):
     """Full partial products fa, fb (same row count) -> this rank's rows of their sums, as ONE grouped launch."""
-    if _solo(group) or dist.get_backend(group) == "gloo":
+    if _solo(group) or dist.get_backend(group) == "gloo" or _peer(group) is not None:
         outs = (_reduce_scatter_sum(fa, per, group), _reduce_scatter_sum(fb, per, group))
         if COMM["log"] is not None:
-            if _solo(group):
+            if _peer(group) is not None and not _solo(group):
+                _log_comm("peer_reduce", fa)
+                _log_comm("peer_reduce", fb)
+            elif _solo(group):
                 COMM["log"].append(("reduce_scatter", (tuple(fa.shape), tuple(fb.shape)), 4 * (fa.numel() + fb.numel())))
             else:
                 _log_comm("reduce_scatter", fa)
@@ -968,7 +1022,7 @@ class _ShardedHotForward(torch.autograd.Function):
 
 
 def _reduce_scatter_raw(full, per, group):
-    _log_comm("reduce_scatter", full)
+    _log_comm("peer_reduce" if (_peer(group) is not None and not _solo(group)) else "reduce_scatter", full)
     return _reduce_scatter_sum(full, per, group)
 
 
@@ -1086,6 +1140,12 @@ class _TableExchange:
     def gather(self, x):
         return _all_gather_raw(x, self.group)
 
+    def partial(self, rows, width):
+        """Where the next [rows, width] partial product should be written (the peer exchange's window: the reduce then
+        pulls from it in place), or None = allocate as usual."""
+        pc = _peer(self.group)
+        return pc.partial(rows, width) if (pc is not None and not _solo(self.group)) else None
+
     def reduce(self, P):
         return _reduce_scatter_raw(P, self.per_i, self.group)
 
@@ -1099,6 +1159,8 @@ class _TableExchange:
 def _all_to_all_rows(out, inp, out_rows, in_rows, group):
     """Variable all-to-all of row blocks (rank q gets inp's block q, sends its blocks likewise). Device tensors on a gloo
     group (tests: ranks sharing one GPU) are staged through the host."""
+    if _peer(group) is not None and inp.is_cuda:
+        raise RuntimeError("the halo scheme's all-to-alls run over RCCL: use scheme 'item-side' with the peer exchange")
     if inp.is_cuda and dist.get_backend(group) == "gloo":
         o = torch.empty(out.shape, dtype=out.dtype)
         dist.all_to_all_single(o, inp.cpu(), output_split_sizes=out_rows, input_split_sizes=in_rows, group=group)
@@ -1162,6 +1224,9 @@ class HaloPlan:
         _all_to_all_rows(recv[:self.n_send], P, self.send_rows, self.recv_rows, self.group)
         _log_comm("halo_reduce", P)
         return self.bk.spmm_raw(self.sel, False, recv, self.bk.EPI_NONE)
+
+    def partial(self, rows, width):    # (the halo's partial products go through an all-to-all: no window)
+        return None
 
     def gather_pair(self, a, b):       # (no grouped form: two launches)
         return self.gather(a), self.gather(b)
@@ -1286,9 +1351,11 @@ class _ShardedItemSide(torch.autograd.Function):
                 parts = []
                 for c in range(nc):
                     with M.on(c):
-                        PM = bk.spmm_raw(twin(iuT, 10 + c), False, MU_v[c], bk.EPI_NONE)
+                        PM = bk.spmm_raw(twin(iuT, 10 + c), False, MU_v[c], bk.EPI_NONE,
+                                         out=xch.partial(iuT.shape[0], MU_v[c].shape[1]))
                     with G.on(c):
-                        P = bk.spmm_raw(twin(iuT, 2 + c), False, u_v[c], bk.EPI_NONE)
+                        P = bk.spmm_raw(twin(iuT, 2 + c), False, u_v[c], bk.EPI_NONE,
+                                        out=xch.partial(iuT.shape[0], u_v[c].shape[1]))
                     parts.append((P, PM))
                 evs = []
                 for c, (P, PM) in enumerate(parts):
@@ -1308,7 +1375,8 @@ class _ShardedItemSide(torch.autograd.Function):
             else:
                 for c in range(nc):
                     with G.on(c):
-                        P = bk.spmm_raw(twin(iuT, 2 + c), False, u_v[c], bk.EPI_NONE)
+                        P = bk.spmm_raw(twin(iuT, 2 + c), False, u_v[c], bk.EPI_NONE,
+                                        out=xch.partial(iuT.shape[0], u_v[c].shape[1]))
                     i_n[c] = G.coll(c, lambda: xch.reduce(P), reads=(P,))
             if nc > 1 or last:
                 G.meet()
@@ -1412,9 +1480,11 @@ class _ShardedItemSide(torch.autograd.Function):
                 parts = []
                 for c in range(nc):
                     with M.on(c):           # g(X) = dropout-backward( reduce_scatter( A_ui[U_r, :]^T . t ) )
-                        part_m = bk.spmm_raw(twin(ui, 10 + c), True, t_v[c], bk.EPI_NONE)
+                        part_m = bk.spmm_raw(twin(ui, 10 + c), True, t_v[c], bk.EPI_NONE,
+                                             out=xch.partial(ui.shape[1], t_v[c].shape[1]))
                     with G.on(c):
-                        part_g = bk.spmm_raw(twin(ui, 2 + c), True, gu_v[c], bk.EPI_NONE)
+                        part_g = bk.spmm_raw(twin(ui, 2 + c), True, gu_v[c], bk.EPI_NONE,
+                                             out=xch.partial(ui.shape[1], gu_v[c].shape[1]))
                     parts.append((part_g, part_m))
                 rgs = []
                 for c, (part_g, part_m) in enumerate(parts):
@@ -1439,7 +1509,8 @@ class _ShardedItemSide(torch.autograd.Function):
             else:
                 for c in range(nc):
                     with G.on(c):
-                        part_g = bk.spmm_raw(twin(ui, 2 + c), True, gu_v[c], bk.EPI_NONE)
+                        part_g = bk.spmm_raw(twin(ui, 2 + c), True, gu_v[c], bk.EPI_NONE,
+                                             out=xch.partial(ui.shape[1], gu_v[c].shape[1]))
                     rs = G.coll(c, lambda: xch.reduce(part_g), reads=(part_g,))
                     with G.on(c):
                         gi_n[c] = rs.add_(Gi_v[c], alpha=inv)

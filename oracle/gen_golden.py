@@ -14,6 +14,7 @@ Each fixture cites the reference call that produced it:
   G7  test_torch (Recall/NDCG/precision/hit @ Ks)       utility/batch_test.py:112-169
   G8  G-step loss assembly                              main.py:363-420
   G9  modal-graph maintenance inside Trainer.train()    main.py:378-405 (k = int(n_items*m_topk_rate) in {1, 2}, T in {1, 2})
+  G16 the same loop + evaluation at the Amazon-Baby SHAPE (python oracle/gen_golden.py g16; see gen_g16)
   G12 K-batch trajectory of Trainer.train() + evaluation  main.py:308-429 -> utility/batch_test.py:112-169
       (python oracle/gen_golden.py g12: own process, discriminator dropout off so that every random draw of the loop
        is one of the two recorded tensors)
@@ -485,6 +486,213 @@ def gen_g12(ref, dg, n_batches=8):
     print("G12: val recall", rec["val.recall"], "test recall", rec["test.recall"])
 
 
+# ---------------------------------------------------------------------------------------------------
+# G16: the reference loop at the AMAZON-BABY SHAPE (the configuration BASELINE.json's metric is quoted on)
+# ---------------------------------------------------------------------------------------------------
+BABY = dict(U=35598, I=18357, E=256308, DV=4096, DT=1024, B=1024)
+G16_SEED = 3
+
+
+def digest(t, n=32):
+    """(sum, sum of squares, n fixed entries) of a tensor: enough to tell 'the same tensor' without storing it."""
+    a = np.asarray(npy(t) if torch.is_tensor(t) else t, np.float64).ravel()
+    idx = (np.arange(n, dtype=np.int64) * 2654435761) % max(a.size, 1)
+    return np.concatenate([[a.sum(), (a * a).sum()], a[idx]])
+
+
+def boundary_gaps(ua, ia, users, train_items, Ks):
+    """For every tested user: the relative gap between the K-th and (K+1)-th score among non-training items - the margin
+    by which its top-K SET is decided. Returns {K: sorted gaps}. A product whose scores differ from the reference's by
+    less than a user's gap ranks the same top-K set for that user."""
+    out = {k: [] for k in Ks}
+    ia_t = ia.t().contiguous()
+    for lo in range(0, len(users), 1024):
+        ub = users[lo:lo + 1024]
+        sc = (ua[ub] @ ia_t).double()
+        for r, u in enumerate(ub):
+            sc[r, train_items[u]] = -float("inf")
+        top = torch.topk(sc, max(Ks) + 1, dim=1).values
+        scale = top[:, :1].abs().clamp_min(1e-30)
+        for k in Ks:
+            out[k].append(((top[:, k - 1] - top[:, k]) / scale[:, 0]).numpy())
+    return {k: np.sort(np.concatenate(v)) for k, v in out.items()}
+
+
+def gen_g16(ref, dg, n_batches=6):
+    """G16: the reference's own Trainer.train() for `n_batches` batches + Trainer.test() on EVERY validation and test user
+    of a Baby-shaped synthetic dataset (35 598 users x 18 357 items, 256 K interactions, 4096 / 1024-wide features,
+    d = 64, B = 1024; k = int(n_items * 1e-4) = 1, T = 1: batches 0-1 on the interaction graph, 2 on the top-1 graph,
+    3+ on empty modal graphs). The tensors of this size cannot be committed (the discriminator alone is 2 x 380 MB, one
+    batch's Gumbel uniforms 75 MB), so the fixture holds what lets the test REBUILD them and prove it did:
+      * the dataset is a pure function of (sizes, seed) (oracle/synth_data.py, numpy Generator);
+      * initial parameters and the loop's random tensors come from torch's CPU generator after set_seed(2022): the test
+        constructs the product Trainer with its discriminator kept on the CPU while it is initialised (what the shimmed
+        reference does here) and draws the noise in the recorded order; digests (sum, sum of squares, 32 entries) of every
+        initial tensor and of every noise tensor are stored and compared first;
+      * recorded in full: every sampled batch, the per-batch loss components, the final SMALL parameters, 512 sampled
+        rows of the final embedding tables / eval-mode embeddings (+ digests of the whole tensors), the metric dicts;
+      * the margin by which each tested user's top-K set is decided (relative gap between score K and K + 1)."""
+    args = ref.args
+    assert (dg.n_users, dg.n_items) == (BABY["U"], BABY["I"]) and args.batch_size == BABY["B"]
+    args.epoch = 1
+    ref.set_seed(2022)
+    tr = ref.Trainer(data_config={"n_users": dg.n_users, "n_items": dg.n_items})
+    skip = ("encoder.", "align.", "image_embedding", "text_embedding")
+    rec = {"n_batches": n_batches, "k": int(dg.n_items * args.m_topk_rate), "T": int(args.T),
+           "m_topk_rate": args.m_topk_rate, "lr": args.lr, "D_lr": args.D_lr, "G_rate": args.G_rate,
+           "cl_rate": args.cl_rate, "gp_rate": args.gp_rate, "shape": np.array([dg.n_users, dg.n_items, dg.n_train]),
+           "dataset_seed": G16_SEED, "torch_version": str(torch.__version__)}
+    assert rec["k"] == 1 and rec["T"] == 1
+    for k, v in tr.model.state_dict().items():
+        if not k.startswith(skip):
+            rec["m0d." + k] = digest(v)
+    for k, v in tr.D.state_dict().items():
+        if v.dtype.is_floating_point:
+            rec["D0d." + k] = digest(v)
+    st = {"fwd": 0, "D": 0, "cl": 0, "uni": 0, "alpha": 0, "sample": 0, "on": False}
+    o_fwd, o_D, o_bpr, o_cl = tr.model.forward, tr.D.forward, tr.bpr_loss, tr.batched_contrastive_loss
+    o_feat, o_gp, o_sample = tr.feat_reg_loss_calculation, tr.gradient_penalty, dg.sample
+    o_uniform, o_rand = torch.Tensor.uniform_, torch.rand
+    import time
+    t0 = time.time()
+
+    def fwd(*graphs):
+        c = st["fwd"]
+        st["fwd"] += 1
+        if st["on"] and c % 2 == 0:
+            print("G16: batch %d starts at %.0f s" % (c // 2, time.time() - t0), flush=True)
+        if st["on"] and c % 2 == 0 and c // 2 >= n_batches:
+            raise _StopTraining()
+        return o_fwd(*graphs)
+
+    def D_fwd(x):
+        out = o_D(x)
+        if st["on"]:
+            b, j = divmod(st["D"], 4)
+            st["D"] += 1
+            rec["b%d.D%d_mean" % (b, j)] = np.float32(out.detach().mean().item())
+        return out
+
+    def bpr(u, p, n):
+        mf, emb, reg = o_bpr(u, p, n)
+        b = st["fwd"] // 2 - 1
+        rec["b%d.mf" % b], rec["b%d.emb" % b] = np.float32(mf.item()), np.float32(emb.item())
+        return mf, emb, reg
+
+    def cl(z1, z2):
+        out = o_cl(z1, z2)
+        b, j = divmod(st["cl"], 2)
+        st["cl"] += 1
+        rec["b%d.cl%d" % (b, j + 1)] = np.float32(out.item())
+        return out
+
+    def feat(a, b_, c, d):
+        out = o_feat(a, b_, c, d)
+        rec["b%d.feat" % (st["fwd"] // 2 - 1)] = np.float32(out.item())
+        return out
+
+    def gp(D, xr, xf):
+        out = o_gp(D, xr, xf)
+        rec["b%d.gp" % (st["fwd"] // 2)] = np.float32(out.item())
+        return out
+
+    def sample():
+        out = o_sample()
+        b = st["sample"]
+        st["sample"] += 1
+        if b < n_batches:
+            rec["b%d.users" % b] = np.array(out[0], np.int32)
+            rec["b%d.pos" % b] = np.array(out[1], np.int32)
+            rec["b%d.neg" % b] = np.array(out[2], np.int32)
+        return out
+
+    def uniform_(self, *a, **k):
+        out = o_uniform(self, *a, **k)
+        if st["on"]:
+            rec["b%d.gumbel_d" % st["uni"]] = digest(out)
+            rec["b%d.gumbel_shape" % st["uni"]] = np.array(out.shape)
+            st["uni"] += 1
+        return out
+
+    def rand(*a, **k):
+        out = o_rand(*a, **k)
+        if st["on"]:
+            rec["b%d.gp_alpha_d" % st["alpha"]] = digest(out)
+            st["alpha"] += 1
+        return out
+
+    tr.model.forward, tr.D.forward, tr.bpr_loss, tr.batched_contrastive_loss = fwd, D_fwd, bpr, cl
+    tr.feat_reg_loss_calculation, tr.gradient_penalty, dg.sample = feat, gp, sample
+    torch.Tensor.uniform_, torch.rand = uniform_, rand
+    st["on"] = True
+    try:
+        tr.train()
+    except _StopTraining:
+        pass
+    finally:
+        st["on"] = False
+        torch.Tensor.uniform_, torch.rand = o_uniform, o_rand
+        dg.sample = o_sample
+        tr.model.forward, tr.D.forward = o_fwd, o_D
+    assert st["uni"] == n_batches and st["alpha"] == n_batches and st["D"] == 4 * n_batches, st
+    for b in range(n_batches):
+        G_lossf = -float(rec["b%d.D3_mean" % b])
+        rec["b%d.G_lossf" % b] = np.float32(G_lossf)
+        rec["b%d.loss_D" % b] = np.float32(-float(rec["b%d.D1_mean" % b]) + float(rec["b%d.D0_mean" % b])
+                                           + args.gp_rate * float(rec["b%d.gp" % b]))
+        rec["b%d.batch_loss" % b] = np.float32(
+            float(rec["b%d.mf" % b]) + float(rec["b%d.emb" % b]) + float(rec["b%d.feat" % b])
+            + args.cl_rate * (float(rec["b%d.cl1" % b]) + float(rec["b%d.cl2" % b])) + args.G_rate * G_lossf)
+    rng = np.random.default_rng(16)
+    rows_u = np.sort(rng.choice(dg.n_users, 512, replace=False))
+    rows_i = np.sort(rng.choice(dg.n_items, 512, replace=False))
+    rec["rows_u"], rec["rows_i"] = rows_u, rows_i
+    for k, v in tr.model.state_dict().items():
+        if k.startswith(skip):
+            continue
+        rec["m1d." + k] = digest(v)
+        a = npy(v)
+        if k == "user_id_embedding.weight":
+            rec["m1." + k] = a[rows_u]
+        elif k == "item_id_embedding.weight":
+            rec["m1." + k] = a[rows_i]
+        elif a.size <= 70000:
+            rec["m1." + k] = a
+        else:                                  # image_trans.weight [64, 4096]: every 8th column
+            rec["m1." + k] = a[:, ::8]
+    for nm, g in zip(("img_ui", "img_iu", "txt_ui", "txt_iu"),
+                     (tr.image_ui_graph, tr.image_iu_graph, tr.text_ui_graph, tr.text_iu_graph)):
+        rec["final.%s_nnz" % nm] = int(g._nnz())
+    tr.model.eval()
+    with torch.no_grad():
+        outs = tr.model(tr.ui_graph, tr.iu_graph, tr.image_ui_graph, tr.image_iu_graph, tr.text_ui_graph, tr.text_iu_graph)
+    ua, ia = outs[0].detach(), outs[1].detach()
+    rec["eval.ua"], rec["eval.ia"] = npy(ua)[rows_u], npy(ia)[rows_i]
+    rec["eval.ua_d"], rec["eval.ia_d"] = digest(ua), digest(ia)
+    Ks = eval(args.Ks)
+    for is_val, nm in ((True, "val"), (False, "test")):
+        users = [u for u, v in (dg.val_set if is_val else dg.test_set).items() if len(v) > 0]
+        print("G16: evaluating %d %s users at %.0f s" % (len(users), nm, time.time() - t0), flush=True)
+        res = tr.test(users, is_val)
+        for k in ("precision", "recall", "ndcg", "hit_ratio"):
+            rec["%s.%s" % (nm, k)] = np.asarray(res[k], np.float64)
+        rec["%s.n_users" % nm] = len(users)
+        rec["%s.users_d" % nm] = digest(np.array(users, np.float64))
+    # how firmly each tested user's top-K set is decided (test users; training items masked as test_one_user does)
+    users = [u for u, v in dg.test_set.items() if len(v) > 0]
+    gaps = boundary_gaps(ua, ia, users, dg.train_items, Ks)
+    for k in Ks:
+        rec["test.gap%d_smallest" % k] = gaps[k][:64]
+        rec["test.gap%d_below_1e-5" % k] = int((gaps[k] < 1e-5).sum())
+        rec["test.gap%d_below_1e-4" % k] = int((gaps[k] < 1e-4).sum())
+    np.savez_compressed(os.path.join(OUT, "g16_baby_trajectory.npz"), **rec)
+    print("G16: batch losses", [float(rec["b%d.batch_loss" % b]) for b in range(n_batches)])
+    print("G16: val recall", rec["val.recall"], "test recall", rec["test.recall"])
+    print("G16: users whose top-20 set is decided by < 1e-5 / 1e-4 of the top score:", rec["test.gap20_below_1e-5"],
+          rec["test.gap20_below_1e-4"], "of", len(users))
+    print("G16: %d bytes" % os.path.getsize(os.path.join(OUT, "g16_baby_trajectory.npz")))
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "g12":     # own process: discriminator dropout must be 0 at import time
         if os.path.isdir(TMP):
@@ -493,6 +701,13 @@ if __name__ == "__main__":
         _ref = ref_shim.load(TMP, "tiny", ["--batch_size", str(B), "--drop_rate", "0.0", "--G_drop1", "0.0",
                                            "--G_drop2", "0.0"])
         gen_g12(_ref, _ref.data_generator)
+    elif len(sys.argv) > 1 and sys.argv[1] == "g16":     # the Baby shape: ~15 min of CPU, ~12 GB
+        TMP16 = "/tmp/mmssl_golden_baby/"
+        if not os.path.isfile(TMP16 + "baby/text_feat.npy"):
+            synth_data.write_dataset(TMP16, "baby", BABY["U"], BABY["I"], BABY["E"], BABY["DV"], BABY["DT"], seed=G16_SEED)
+        _ref = ref_shim.load(TMP16, "baby", ["--batch_size", str(BABY["B"]), "--drop_rate", "0.0", "--G_drop1", "0.0",
+                                             "--G_drop2", "0.0"])
+        gen_g16(_ref, _ref.data_generator)
     elif len(sys.argv) > 1 and sys.argv[1] == "g9":      # only (re)generate G9; same data set, same seeds
         if os.path.isdir(TMP):
             shutil.rmtree(TMP)

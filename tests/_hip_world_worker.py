@@ -18,6 +18,43 @@ for p in (ROOT, os.path.join(ROOT, "oracle"), HERE):
         sys.path.insert(0, p)
 
 
+DEVICE_COLLECTIVES = {"n": 0}
+
+
+def _count_device_collectives():
+    for name in ("all_reduce", "all_gather_into_tensor", "reduce_scatter_tensor", "all_to_all_single", "all_gather",
+                 "broadcast"):
+        inner = getattr(dist, name)
+
+        def wrapped(*a, _inner=inner, **k):
+            if any(torch.is_tensor(x) and x.is_cuda for x in list(a) + list(k.values())):
+                DEVICE_COLLECTIVES["n"] += 1
+            return _inner(*a, **k)
+        setattr(dist, name, wrapped)
+
+
+def _finish_peer(md, step, total, model, rec):
+    """Peer transport only: a SECOND step on the same inputs (every window is reused: the begin-of-step barrier and the
+    epochs are what keep it right) must give the same result; no wait timed out; no collective carried a device tensor."""
+    pc = md._peer(None)
+    if pc is None:
+        return rec
+    g1 = {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
+    l1 = float(total)
+    sites = pc.stats()["call_sites"]
+    total2 = step.backward()
+    torch.cuda.synchronize()
+    pc.check()
+    assert abs(float(total2) - l1) <= 1e-6 * abs(l1), (float(total2), l1)
+    for n, p in model.named_parameters():
+        if p.grad is not None:        # (the batch rows' scatter uses fp32 atomics: equal up to their summation order)
+            assert float((p.grad - g1[n]).abs().max()) <= 2e-5 * float(g1[n].abs().max()) + 1e-30, n
+    st = pc.stats()
+    assert st["call_sites"] == sites and DEVICE_COLLECTIVES["n"] == 0, (st, sites, DEVICE_COLLECTIVES)
+    rec["peer"] = st
+    return rec
+
+
 def main():
     rank, world, port = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
     modal, scheme, chunks, out_dir = sys.argv[4], sys.argv[5], int(sys.argv[6]), sys.argv[7]
@@ -30,6 +67,11 @@ def main():
     import test_dist_cpu as T
     from mmssl_amd import dist as md
     dev = torch.device("cuda", 0)
+    if os.environ.get("MMSSL_TEST_TRANSPORT") == "peer":
+        # the exchanges go through IPC-mapped windows + epoch flags (csrc/peer.hip): from here on NO torch.distributed
+        # call may carry a device tensor - counted, and asserted to be zero when the rank is done
+        md.enable_peer_exchange(None, dev, timeout_ms=120000)
+        _count_device_collectives()
     if modal == "baby":
         return baby(rank, world, scheme, chunks, out_dir, md, dev, repl)
     if modal == "synth_full":
@@ -62,8 +104,9 @@ def main():
     g = {n: (p.grad.detach().cpu().clone() if p.grad is not None else None) for n, p in model.named_parameters()}
     assert float(g["txt_w"][:, k_txt:].abs().max()) == 0.0
     g["txt_w"] = g["txt_w"][:, :k_txt]
-    torch.save({"loss": float(total), "ush": (ush.lo, ush.hi, ush.n), "ish": (ish.lo, ish.hi, ish.n), "g": g,
-                "chunks": model.n_chunks(2) if scheme in ("item-side", "halo") else 1}, os.path.join(out_dir, "r%d.pt" % rank))
+    rec = {"loss": float(total), "ush": (ush.lo, ush.hi, ush.n), "ish": (ish.lo, ish.hi, ish.n), "g": g,
+           "chunks": model.n_chunks(2) if scheme in ("item-side", "halo") else 1}
+    torch.save(_finish_peer(md, step, total, model, rec), os.path.join(out_dir, "r%d.pt" % rank))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -98,9 +141,10 @@ def baby(rank, world, scheme, chunks, out_dir, md, dev, repl=False):
     torch.cuda.synchronize()
     assert model.last_fused
     g = {n: (p.grad.detach().cpu().clone() if p.grad is not None else None) for n, p in model.named_parameters()}
-    torch.save({"loss": float(total), "ush": (ush.lo, ush.hi, ush.n), "ish": (ish.lo, ish.hi, ish.n), "g": g,
-                "chunks": model.n_chunks(2) if scheme in ("item-side", "halo") else 1,
-                "halo_fraction": (model.halo.bytes_fraction if scheme == "halo" else None)}, os.path.join(out_dir, "r%d.pt" % rank))
+    rec = {"loss": float(total), "ush": (ush.lo, ush.hi, ush.n), "ish": (ish.lo, ish.hi, ish.n), "g": g,
+           "chunks": model.n_chunks(2) if scheme in ("item-side", "halo") else 1,
+           "halo_fraction": (model.halo.bytes_fraction if scheme == "halo" else None)}
+    torch.save(_finish_peer(md, step, total, model, rec), os.path.join(out_dir, "r%d.pt" % rank))
     dist.barrier()
     dist.destroy_process_group()
 

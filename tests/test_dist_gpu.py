@@ -139,6 +139,25 @@ def test_sharded_packed_node_at_d128_per_modality_projection_equals_oracle(solo_
                                                        (8, "baby", "halo", 1), (3, "full_drop", "item-side-repl", 2),
                                                        (8, "baby", "item-side-repl", 1)])
 def test_hip_backend_at_world_2_3_8_on_one_gpu(tmp_path, world, modal, scheme, chunks):
+    _world_on_one_gpu(tmp_path, world, modal, scheme, chunks, None)
+
+
+@pytest.mark.parametrize("world,modal,scheme,chunks", [(2, "full", "item-side", 2), (3, "full_drop", "item-side", 2),
+                                                       (3, "empty_shortcut", "item-side", 1), (3, "full", "gather-both", 0),
+                                                       (3, "baby", "item-side", 2), (8, "baby", "item-side", 1),
+                                                       (3, "full_drop", "item-side-repl", 2), (8, "baby", "item-side-repl", 1)])
+def test_peer_exchange_at_world_2_3_8_on_one_gpu(tmp_path, world, modal, scheme, chunks):
+    """The same sharded steps with the PEER EXCHANGE as the transport (csrc/peer.hip: every all-gather is a kernel that
+    pushes the rank's rows into all peers' IPC-mapped windows, every reduce-scatter a kernel that pulls the rank's rows out
+    of them in rank order, the small all-reduces likewise): no torch.distributed call carries a device tensor (counted in
+    the worker), no device-wide fence, the lanes' overlap intact. Loss and gradients against the single-process oracle as
+    above; a second step on the same inputs reproduces the first (windows reused behind the step barrier)."""
+    recs = _world_on_one_gpu(tmp_path, world, modal, scheme, chunks, "peer")
+    for o in recs:
+        assert o["peer"]["world"] == world and o["peer"]["call_sites"] >= 6 and o["peer"]["launches"] > 0, o["peer"]
+
+
+def _world_on_one_gpu(tmp_path, world, modal, scheme, chunks, transport):
     """dist.HipBackend at world size > 1: `world` processes share GPU 0 (their group is gloo - RCCL refuses two ranks on one
     device - moving DEVICE tensors), each runs its shard of the sharded step on the HIP kernels: real per-rank partial
     products, uneven last blocks (300 users / 200 items over 3 ranks), lanes on real streams with row-pitched column-chunk
@@ -148,8 +167,12 @@ def test_hip_backend_at_world_2_3_8_on_one_gpu(tmp_path, world, modal, scheme, c
     import subprocess
     import test_dist_cpu as T
     port = T._free_port()
+    env = dict(os.environ)
+    if transport:
+        env["MMSSL_TEST_TRANSPORT"] = transport
     procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "_hip_world_worker.py"), str(r), str(world), str(port), modal,
-                               scheme, str(chunks), str(tmp_path)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+                               scheme, str(chunks), str(tmp_path)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
+                              env=env)
              for r in range(world)]
     outs = [p.communicate(timeout=900)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), "\n".join(o[-1500:] for o in outs)
@@ -178,3 +201,4 @@ def test_hip_backend_at_world_2_3_8_on_one_gpu(tmp_path, world, modal, scheme, c
                 assert float(((o["g"][name][:k] - ref).abs().amax(1) / den).max()) < 5e-3, (name, "row-wise")
             if k < hi - lo:
                 assert float(o["g"][name][k:].abs().max()) == 0.0
+    return recs

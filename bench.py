@@ -632,6 +632,12 @@ def main():
                          "one device) - runs the whole N > 1 flow on a one-GPU box; eager steps, timings mean nothing")
     ap.add_argument("--no-stress", action="store_true", dest="no_stress",
                     help="N>1: skip the `scaling_stress` record (configs[4]'s per-rank share x N after the timed region)")
+    ap.add_argument("--transport", choices=["auto", "peer", "collective"], default="auto",
+                    help="N > 1: how table rows move between the ranks. peer = kernels writing / reading IPC-mapped peer "
+                         "windows (csrc/peer.hip, no collective library in the data path); collective = RCCL (gloo with "
+                         "--share-gpu); auto = peer if its start-up self-test passes on every rank, else collective")
+    ap.add_argument("--no-loss-check", action="store_true", dest="no_loss_check",
+                    help="N > 1: skip `loss_vs_n1` (the sharded job's first-step loss against the same job whole on rank 0)")
     ap.add_argument("--scheme", choices=["item-side", "gather-both", "halo"], default="item-side",
                     help="sharded step: item-side = user-row blocks only, every collective of item-table size; "
                          "gather-both = user AND item row blocks, all-gather of both tables (round-3 scheme); halo = item-side "
@@ -662,7 +668,7 @@ def main():
         return
     if a.share_gpu:
         local_rank = 0
-        a.dist_graph, a.backend = "off", "gloo"
+        a.backend = "gloo"          # (the gloo stand-in cannot be captured: run_sharded_main turns the graph off for it)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     sharded = world > 1 or a.force_dist or a.workload in ("synth", "synth-full") or a.dist_graph_probe
@@ -768,12 +774,12 @@ def result_line(a, world, scaling, ms, edge_layers_total, stats, captured, loss,
     }
 
 
-def timed_sharded(a, rank, world, dev, scaling, want_graph):
+def timed_sharded(a, rank, world, dev, scaling, want_graph, pre_step=None):
     """Build the row-sharded step for workload `a`, W warm-up steps, then EXACTLY K timed steps between barrier +
     synchronize on both sides, max over ranks. Returns a dict (ms, stats, comm, ...)."""
     import torch.distributed as dist
     from mmssl_amd import dist as mdist
-    step, mats, plans, stats = mdist.build_bench_step(a, rank, world, dev, scaling)
+    step, mats, plans, stats = mdist.build_bench_step(a, rank, world, dev, scaling, pre_step=pre_step)
     captured = bool(want_graph and step.capture())
     n_users, n_items = stats["n_users"], stats["n_items"]
     # communication of one step: what was issued, and how long those collectives take on their own
@@ -782,12 +788,31 @@ def timed_sharded(a, rank, world, dev, scaling, want_graph):
             "collectives_per_step": len(log),
             "bytes_per_step": int(sum(b for _, _, b in log)),
             "by_kind": {k: [sum(1 for x in log if x[0] == k), int(sum(x[2] for x in log if x[0] == k))]
-                        for k in ("all_gather", "reduce_scatter", "all_reduce", "halo_gather", "halo_reduce")
+                        for k in ("all_gather", "reduce_scatter", "all_reduce", "halo_gather", "halo_reduce", "peer_gather",
+                                  "peer_reduce")
                         if k in ("all_gather", "reduce_scatter", "all_reduce") or any(x[0] == k for x in log)},
             "note": "bytes = size of the full (gathered / to-be-scattered / reduced) fp32 buffer of every collective "
                     "of one step on one rank; comm_only_ms = the same collectives replayed alone, back to back"}
-    with torch.cuda.stream(step.stream):
-        comm["comm_only_ms"] = round(mdist.comm_replay_ms(log, None, dev, halo=stats.get("halo")), 4)
+    pc = mdist._peer(None)
+    if pc is None:
+        with torch.cuda.stream(step.stream):
+            comm["comm_only_ms"] = round(mdist.comm_replay_ms(log, None, dev, halo=stats.get("halo")), 4)
+    else:
+        comm["comm_only_ms"] = None
+    # what one step hands to torch.distributed in its data path (an eager step; the count is 0 over the peer exchange)
+    before = mdist.COMM["dist_calls"]
+    step.step()
+    torch.cuda.synchronize()
+    comm["torch_distributed_collectives_per_step"] = mdist.COMM["dist_calls"] - before
+    if pc is not None:
+        l0 = pc.t.launches
+        step.step()
+        torch.cuda.synchronize()
+        pc.check()
+        st = pc.stats()
+        comm["peer"] = {"exchange_call_sites_per_step": st["call_sites"], "exchange_launches_per_step": pc.t.launches - l0,
+                        "windows": st["windows"], "window_MB": round(st["window_bytes"] / 2 ** 20, 1),
+                        "flags_finegrained": st["flags_finegrained"]}
     if stats.get("halo_rows_fraction") is not None:
         comm["halo_rows_fraction"] = stats["halo_rows_fraction"]      # referenced item rows / item table (this rank)
     rngb = np.random.default_rng(2022)          # identical batches on every rank (global ids)
@@ -860,12 +885,155 @@ def stress_watchdog(limit_s, out, rank):
     return t
 
 
+def peer_selftest(pc, dev):
+    """One all-gather / reduce-scatter / all-reduce round trip through the peer windows on values every rank knows."""
+    w, r, per, width = pc.world, pc.rank, 64, 64
+    ramp = torch.arange(width, device=dev, dtype=torch.float32)
+    pc.begin_step()
+    want = torch.cat([torch.full((per, width), float(q + 1), device=dev) + ramp for q in range(w)])
+    full = pc.gather(want[r * per:(r + 1) * per].contiguous())
+    ok = bool(torch.equal(full, want))
+    P = pc.partial(w * per, width)
+    P.copy_(want * float(r + 1))
+    tot = float(sum(q + 1 for q in range(w)))
+    ok = ok and bool(torch.allclose(pc.reduce(P, per), want[r * per:(r + 1) * per] * tot, rtol=1e-6))
+    t = torch.arange(1001, device=dev, dtype=torch.float32) * float(r + 1)
+    pc.all_reduce_(t)
+    ok = ok and bool(torch.allclose(t, torch.arange(1001, device=dev, dtype=torch.float32) * tot, rtol=1e-6))
+    torch.cuda.synchronize()
+    pc.check()
+    return ok
+
+
+def choose_transport(a, rank, world, dev):
+    """(name, record). `auto`: the peer exchange if it can be set up and its self-test passes on EVERY rank."""
+    import torch.distributed as dist
+    from mmssl_amd import dist as mdist
+    if world == 1 and not a.force_dist:
+        return "none", {"transport": "none (one rank: every exchange is the identity)"}
+    if a.transport == "collective" or a.scheme == "halo" or (world == 1 and a.transport == "auto"):
+        return "collective", {"transport": "collective (%s)" % dist.get_backend()}
+    ok, err = 1, None
+    try:
+        pc = mdist.enable_peer_exchange(None, dev, timeout_ms=10000)
+        ok = 1 if peer_selftest(pc, dev) else 0
+        if not ok:
+            err = "self-test values differ"
+    except Exception as e:          # IPC export / open refused, a wait timed out, ...
+        ok, err = 0, repr(e)[:300]
+    flag = torch.tensor([ok], dtype=torch.int32, device=dev if dist.get_backend() == "nccl" else "cpu")
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    if int(flag.item()) == 1:
+        pc = mdist._peer(None)
+        info = pc.stats()
+        return "peer", {"transport": "peer (IPC-mapped windows + epoch flags, csrc/peer.hip)",
+                        "flags_finegrained": info["flags_finegrained"], "selftest": "passed on all %d ranks" % world}
+    if a.transport == "peer":
+        raise SystemExit("--transport peer: the peer exchange is not usable here (rank %d: %s)" % (rank, err))
+    try:
+        mdist.disable_peer_exchange(None)
+    except Exception:
+        pass
+    return "collective", {"transport": "collective (%s)" % dist.get_backend(),
+                          "peer_rejected": err or "another rank's self-test failed"}
+
+
+def rank_devices(world, dev):
+    """Which physical devices the job's ranks sit on: UUIDs gathered from every rank (a job whose ranks share a device, or
+    a launcher that started fewer processes than --gpus says, shows here)."""
+    import torch.distributed as dist
+    try:
+        uid = str(torch.cuda.get_device_properties(dev).uuid)
+    except Exception:
+        uid = "%s:%d" % (torch.cuda.get_device_name(dev), dev.index or 0)
+    got = [None] * world
+    dist.all_gather_object(got, uid)
+    return {"world_size": world, "backend": dist.get_backend(), "device_uuids": got, "distinct_devices": len(set(got))}
+
+
+def loss_vs_n1(a, step, rank, world, dev, scaling, group1):
+    """First-step loss of the sharded job (its own step object, injected dropout masks, batch 0) against the SAME job whole
+    on rank 0's GPU (dist.build_whole_bench_step: one rank, no exchange): north_star's 1e-4."""
+    import torch.distributed as dist
+    from mmssl_amd import dist as mdist
+    m = step.model
+    rngb = np.random.default_rng(4242)
+    n_users, n_items = m.ush.n, m.ish.n
+    batch = torch.stack([torch.from_numpy(x) for x in (
+        rngb.choice(n_users, a.batch, replace=a.batch > n_users).astype(np.int64),
+        rngb.integers(0, n_items, a.batch).astype(np.int64), rngb.integers(0, n_items, a.batch).astype(np.int64))])
+    if getattr(m, "replicate_feats", False):
+        km = [mdist.bench_check_masks(q, m.ish.per, a.d) for q in range(world)]
+        keep = tuple(torch.cat([k[i] for k in km]).to(dev) for i in range(2))
+    else:
+        keep = tuple(k.to(dev) for k in mdist.bench_check_masks(rank, m.ish.per, a.d))
+    old = step.keep_masks
+    step.keep_masks = keep
+    with torch.cuda.stream(step.stream):
+        step.set_batch(batch.to(dev))
+        ln = float(step.backward())
+    torch.cuda.synchronize()
+    step.keep_masks = old
+    rec = {"sharded": ln, "tolerance": 1e-4}
+    if rank == 0:
+        try:
+            whole = mdist.build_whole_bench_step(a, world, dev, scaling, group1)
+            with torch.cuda.stream(whole.stream):
+                whole.set_batch(batch.to(dev))
+                l1 = float(whole.backward())
+            torch.cuda.synchronize()
+            rec.update(n1=l1, rel_err=abs(ln - l1) / abs(l1), ok=bool(abs(ln - l1) <= 1e-4 * abs(l1)),
+                       what="loss of one step from the initial parameters, injected dropout masks: the job on %d rank(s) vs "
+                            "the same graph / tables / features whole on rank 0's GPU" % world)
+            del whole
+        except Exception as e:
+            rec["error"] = repr(e)[:300]
+    dist.barrier()
+    return rec
+
+
+def one_rank_ms(a, rank, dev, group1):
+    """ms/step of workload `a`'s per-rank share ALONE on rank 0 (a one-rank group: every exchange is the identity), timed in
+    this invocation like the job itself; the other ranks wait. Returned on every rank (broadcast as a python object)."""
+    import gc
+    import torch.distributed as dist
+    from mmssl_amd import dist as mdist
+    ms = None
+    if rank == 0:
+        saved = mdist._PEER.copy()
+        mdist._PEER.clear()                  # (keyed by group, but build_sharded_graph's helpers use the default group)
+        try:
+            step, _, _, _ = mdist.build_bench_step(a, 0, 1, dev, "weak", group=group1)
+            step.capture()
+            for _ in range(max(a.warmup, 2)):
+                step.run()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(a.steps):
+                step.run()
+            torch.cuda.synchronize()
+            ms = round((time.perf_counter() - t0) * 1e3 / a.steps, 4)
+            del step
+            gc.collect()
+        finally:
+            mdist._PEER.update(saved)
+    box = [ms]
+    dist.broadcast_object_list(box, src=0)
+    return box[0]
+
+
 def run_sharded_main(a, rank, world, dev):
     import copy
     import gc
     import torch.distributed as dist
     from mmssl_amd import dist as mdist
     scaling = "weak" if a.workload in ("synth", "synth-full") else a.scaling
+    group1 = dist.new_group([0]) if world > 1 else None          # (collective call: rank 0's one-rank group for loss_vs_n1)
+    tname, trec = choose_transport(a, rank, world, dev) if not a.dist_graph_probe else ("collective", {})
+    if tname == "peer":
+        a.dist_graph = "on" if a.dist_graph == "auto" else a.dist_graph     # plain kernels: nothing a capture could choke on
+    elif a.share_gpu:
+        a.dist_graph = "off"
     if a.dist_graph_probe:       # child of one rank: sharded capture + replay on a small shape
         step, _, _, _ = mdist.build_bench_step(a, rank, world, dev, scaling)
         ok = step.capture()
@@ -894,15 +1062,28 @@ def run_sharded_main(a, rank, world, dev):
         flag = torch.tensor([1 if mdist.spawn_rank_probe(cmd) else 0], device=dev, dtype=torch.int32)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         want = bool(flag.item())
-    r = timed_sharded(a, rank, world, dev, scaling, want)
+    lbox = {}
+    check = None
+    if world > 1 and not a.no_loss_check and a.workload != "synth":
+        check = lambda st: lbox.update(rec=loss_vs_n1(a, st, rank, world, dev, scaling, group1))      # noqa: E731
+    r = timed_sharded(a, rank, world, dev, scaling, want, pre_step=check)
     stats = r["stats"]
+    lrec = lbox.get("rec")
+    devs = rank_devices(world, dev) if world > 1 else None
     out = result_line(a, world, scaling, r["ms"], stats["edge_layers_global"], stats, r["captured"], r["loss"],
-                      "row-shard x%d, %s scheme, %d column chunk(s) per collective (RCCL all-gather / reduce-scatter)" % (
-                          world, stats["scheme"], stats["chunks"]),
+                      "row-shard x%d, %s scheme, %d column chunk(s) per exchange (%s)" % (
+                          world, stats["scheme"], stats["chunks"],
+                          "peer push all-gather / pull reduce-scatter over IPC-mapped windows" if tname == "peer"
+                          else "RCCL all-gather / reduce-scatter"),
                       stats["n_users"], stats["n_items"], stats["n_edges"])
     if rank == 0:
         out["roofline"] = spmm_roofline(r["plans"], r["mats"], a.d, traffic=False)   # rank 0's shard
         out["comm"] = r["comm"]
+        out["comm"].update(trec)
+        if devs is not None:
+            out["rccl_ranks"] = devs
+        if lrec is not None:
+            out["loss_vs_n1"] = lrec
         full = committed_full_n1_figure()
         if a.workload == "synth" and world == 8 and full:      # this job IS configs[4]: strong ratio to the same graph on one GPU
             out["full_n1"] = full
@@ -926,6 +1107,13 @@ def run_sharded_main(a, rank, world, dev):
                    "edge_layers_per_s": round(st2["edge_layers_global"] / (r2["ms"] * 1e-3), 1),
                    "launch": "hipGraph replay" if r2["captured"] else "eager", "comm": r2["comm"],
                    "final_loss": round(r2["loss"], 6)}
+            # the SAME share on ONE rank, measured in this invocation on rank 0 (no link crossed): the weak-scaling denominator
+            try:
+                rec["n1_ms"] = one_rank_ms(a2, rank, dev, group1)
+                if rec["n1_ms"]:
+                    rec["weak_efficiency_vs_n1_ms"] = round(rec["n1_ms"] / rec["ms_per_step"], 4)
+            except Exception as e:
+                rec["n1_ms_error"] = repr(e)[:300]
             ref = committed_rank_figure()
             if ref:           # WEAK: one rank's share alone (its item table 1/8 of the job's) vs the same share inside the job
                 rec["one_rank"] = ref

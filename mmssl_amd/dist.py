@@ -313,6 +313,7 @@ def _all_reduce(t, group):
         fence = t.is_cuda and dist.get_backend(group) == "gloo"        # (test transport: see _gloo_device_fence)
         if fence:
             torch.cuda.synchronize(t.device)
+        COMM["dist_calls"] += 1
         dist.all_reduce(t, group=group)
         if fence:
             torch.cuda.synchronize(t.device)
@@ -344,9 +345,11 @@ def _all_gather_into(out, x, group):
         out.zero_()
         out[r * per:(r + 1) * per].copy_(x)
         _gloo_device_fence(out)
+        COMM["dist_calls"] += 1
         dist.all_reduce(out, group=group)
         _gloo_device_fence(out)
         return out
+    COMM["dist_calls"] += 1
     dist.all_gather_into_tensor(out, x.contiguous(), group=group)
     return out
 
@@ -361,11 +364,13 @@ def _reduce_scatter_sum(full, per, group):
     if dist.get_backend(group) == "gloo":      # gloo has no reduce_scatter: all-reduce + slice
         full = full.contiguous()
         _gloo_device_fence(full)
+        COMM["dist_calls"] += 1
         dist.all_reduce(full, group=group)
         _gloo_device_fence(full)
         r = dist.get_rank(group)
         return full[r * per:(r + 1) * per].clone()
     out = torch.empty((per,) + tuple(full.shape[1:]), dtype=full.dtype, device=full.device)
+    COMM["dist_calls"] += 1
     dist.reduce_scatter_tensor(out, full.contiguous(), group=group)
     return out
 
@@ -735,7 +740,9 @@ class ShardedMMSSL(nn.Module):
 
 # launch accounting for bench.py: every collective of a counted step {kind, bytes of the full (gathered /
 # to-be-scattered / reduced) buffer}; COMM["log"] is None when not recording
-COMM = {"log": None}
+# log: per-step accounting of the exchanges; dist_calls: torch.distributed collectives that carried a tensor in the data
+# path (0 per step when the peer exchange is the transport)
+COMM = {"log": None, "dist_calls": 0}
 
 
 def _log_comm(kind, t):
@@ -809,6 +816,7 @@ def _reduce_scatter_pair(fa, fb, per, group):
     cm, grouped = _coalesced(group, fa.device)
     with cm:
         for o, f in zip(outs, (fa, fb)):
+            COMM["dist_calls"] += 1
             dist.reduce_scatter_tensor(o, f.contiguous(), group=group)
     if COMM["log"] is not None:
         if grouped:
@@ -1163,9 +1171,11 @@ def _all_to_all_rows(out, inp, out_rows, in_rows, group):
         raise RuntimeError("the halo scheme's all-to-alls run over RCCL: use scheme 'item-side' with the peer exchange")
     if inp.is_cuda and dist.get_backend(group) == "gloo":
         o = torch.empty(out.shape, dtype=out.dtype)
+        COMM["dist_calls"] += 1
         dist.all_to_all_single(o, inp.cpu(), output_split_sizes=out_rows, input_split_sizes=in_rows, group=group)
         out.copy_(o)
         return out
+    COMM["dist_calls"] += 1
     dist.all_to_all_single(out, inp.contiguous(), output_split_sizes=out_rows, input_split_sizes=in_rows, group=group)
     return out
 
@@ -1935,13 +1945,106 @@ def build_sharded_graph(a, rank, world, dev, scaling, scheme="gather-both"):
     return ui_l, iu_l, ush, ish, Ug, Ig, int(t.item()), dv, dt
 
 
-def build_bench_step(a, rank, world, dev, scaling="weak"):
-    """bench.py workload for the sharded path. Returns (step, local_mats, plans, stats)."""
+def _bench_shared_weights(a, dv, dt):
+    """The replicated parameters of the bench model (same on every rank): image / text projection, fusion weights."""
+    g = torch.Generator().manual_seed(2022)
+
+    def xavier(rows, cols):
+        bound = (6.0 / (rows + cols)) ** 0.5
+        return (torch.rand(rows, cols, generator=g) * 2 - 1) * bound
+    return xavier(a.d, dv), xavier(a.d, dt), xavier(4 * a.d, a.d)
+
+
+def _bench_feat_block(q, per_i, dv, dt):
+    gq = torch.Generator().manual_seed(7 + 1000 * q)
+    return torch.randn(per_i, dv, generator=gq), torch.randn(per_i, dt, generator=gq)
+
+
+def _bench_table_block(a, q, per_u, per_i, U, I):
+    ge = torch.Generator().manual_seed(99 + q)
+    e_u = (torch.rand(per_u, a.d, generator=ge) * 2 - 1) * (6.0 / (U + a.d)) ** 0.5
+    e_i = (torch.rand(per_i, a.d, generator=ge) * 2 - 1) * (6.0 / (I + a.d)) ** 0.5
+    return e_u, e_i
+
+
+def bench_check_masks(q, per_i, d, rows=None):
+    """Injected dropout keep-masks of item-row block q for the first-step loss check (bench.py `loss_vs_n1`): a pure
+    function of the block, so the sharded job and its one-GPU form drop the same entries."""
+    g = torch.Generator().manual_seed(555 + q)
+    return [(torch.rand(per_i if rows is None else rows, d, generator=g) >= 0.2).to(torch.uint8) for _ in range(2)]
+
+
+def _bench_model(a, bk, cfg, ush, ish, group, scheme, repl, need, dev, dv, dt, img_l, txt_l, e_u, e_i):
+    model = ShardedMMSSL.__new__(ShardedMMSSL)
+    nn.Module.__init__(model)
+    model.bk, model.cfg, model.ush, model.ish, model.group = bk, cfg, ush, ish, group
+    model.scheme, model.chunks = scheme, int(getattr(a, "chunks", 0))
+    model.replicate_feats = repl
+    if scheme == "halo":
+        model.halo = HaloPlan(need, ish, None, bk, dev)
+    img_w, txt_w, w_cat = _bench_shared_weights(a, dv, dt)
+    model.img_w = nn.Parameter(img_w)
+    model.img_b = nn.Parameter(torch.zeros(a.d))
+    model.txt_w = nn.Parameter(txt_w)
+    model.txt_b = nn.Parameter(torch.zeros(a.d))
+    model.w_cat = nn.Parameter(w_cat)
+    model.E_u = nn.Parameter(e_u)
+    model.E_i = nn.Parameter(e_i)
+    model.register_buffer("image_feats", img_l, persistent=False)
+    model.register_buffer("text_feats", txt_l, persistent=False)
+    return model.to(dev).train()
+
+
+def build_whole_bench_step(a, world, dev, scaling, group1):
+    """The SAME job build_bench_step(a, rank, world, ...) distributes over `world` ranks, whole in this process (a one-rank
+    `group1`: every exchange is the identity): the graph is the stack of the ranks' user blocks, tables and features the
+    concatenation of their blocks, the replicated weights the shared ones. bench.py's `loss_vs_n1` runs one step of it
+    on rank 0 beside the sharded job's first step (same batch, same injected dropout masks)."""
+    from . import synth
+    from .config import configure, HotCfg
+    configure([], embed_size=a.d, weight_size=str([a.d] * a.gcn_layers), batch_size=a.batch, drop_rate=0.2)
+    U, I, E, dv, dt = synth.SHAPES[a.workload]
+    if a.workload == "synth":
+        U, I, E, dv, dt, scaling = U // 8, I // 8, E // 8, 128, 128, "weak"
+    if scaling == "strong":
+        raw = synth.interaction_matrix(U, I, E, seed=1)
+        Ug, Ig = U, I
+        shards = [(RowShard(U, world, q), RowShard(I, world, q)) for q in range(world)]
+    else:
+        Ug, Ig = U * world, I * world
+        raw = sp.vstack([synth.interaction_matrix(U, Ig, E, seed=1000 + q, item_seed=77) for q in range(world)]).tocsr()
+        shards = [(RowShard(Ug, world, q), RowShard(Ig, world, q)) for q in range(world)]
+    ui, iu = synth.normalised_pair(raw)
+    ush, ish = RowShard(Ug, 1, 0), RowShard(Ig, 1, 0)
+    bk = HipBackend()
+    with torch.cuda.device(dev):
+        plans = [bk.make_graph(ui), bk.make_graph(iu)]
+        e_ui = bk.make_graph(sp.csr_matrix((Ug, Ig), dtype=np.float32))
+        e_iu = bk.make_graph(sp.csr_matrix((Ig, Ug), dtype=np.float32))
+    tabs = [_bench_table_block(a, q, us.per, is_.per, Ug, Ig) for q, (us, is_) in enumerate(shards)]
+    feats = [_bench_feat_block(q, is_.per, dv, dt) for q, (_, is_) in enumerate(shards)]
+    masks = [bench_check_masks(q, is_.per, a.d) for q, (_, is_) in enumerate(shards)]
+    e_u = torch.cat([t[0] for t in tabs])[:Ug]
+    e_i = torch.cat([t[1] for t in tabs])[:Ig]
+    img = torch.cat([f[0] for f in feats])[:Ig]
+    txt = torch.cat([f[1] for f in feats])[:Ig]
+    keep = tuple(torch.cat([m[k] for m in masks])[:Ig].to(dev) for k in range(2))
+    model = _bench_model(a, bk, HotCfg(), ush, ish, group1, "item-side", False, None, dev, dv, dt, img, txt, e_u, e_i)
+    step = ShardedHotPathStep(model, (plans[0], plans[1], e_ui, e_iu, e_ui, e_iu), a.batch, Ig, group=group1, modal_empty=True,
+                              optimizer=False)
+    step.keep_masks = keep
+    return step
+
+
+def build_bench_step(a, rank, world, dev, scaling="weak", group=None, pre_step=None):
+    """bench.py workload for the sharded path. Returns (step, local_mats, plans, stats). `group`: the process group of the
+    `world` ranks (None = the default one); `pre_step(step)`: called once on the freshly built step, before its first
+    optimiser step (bench.py's first-step loss check)."""
     from . import synth
     from .config import configure, HotCfg
     configure([], embed_size=a.d, weight_size=str([a.d] * a.gcn_layers), batch_size=a.batch, drop_rate=0.2)
     scheme = getattr(a, "scheme", "item-side")
-    if scheme == "halo" and _solo(None):
+    if scheme == "halo" and _solo(group):
         scheme = "item-side"        # one rank, nothing exchanged: the compact item columns would only renumber the table
     ui_l, iu_l, ush, ish, U, I, E_global, dv, dt = build_sharded_graph(a, rank, world, dev, scaling,
                                                                      "item-side" if scheme == "halo" else scheme)
@@ -1961,40 +2064,18 @@ def build_bench_step(a, rank, world, dev, scaling="weak"):
     repl = (scheme == "item-side" and world > 1
             and (rf == "on" or (rf == "auto" and choose_replicate_feats(ish.n_pad, [dv, dt], a.d, world))))
     _ops.seed_dropout(2022 if repl else 2022 + rank, dev)    # independent masks per row shard; replicated features: ONE mask set
-    g = torch.Generator().manual_seed(2022)
-
-    def xavier(rows, cols):
-        bound = (6.0 / (rows + cols)) ** 0.5
-        return (torch.rand(rows, cols, generator=g) * 2 - 1) * bound
     # features / embeddings are generated per shard (rank-dependent seeds); replicated weights from a shared seed
-    def feat_block(q):
-        gq = torch.Generator().manual_seed(7 + 1000 * q)
-        return torch.randn(ish.per, dv, generator=gq), torch.randn(ish.per, dt, generator=gq)
     if repl:                                      # every rank's block, on every rank
-        blocks = [feat_block(q) for q in range(world)]
+        blocks = [_bench_feat_block(q, ish.per, dv, dt) for q in range(world)]
         img_l, txt_l = torch.cat([b[0] for b in blocks]), torch.cat([b[1] for b in blocks])
         del blocks
     else:
-        img_l, txt_l = feat_block(rank)
-    ge = torch.Generator().manual_seed(99 + rank)
-    model = ShardedMMSSL.__new__(ShardedMMSSL)
-    nn.Module.__init__(model)
-    model.bk, model.cfg, model.ush, model.ish, model.group = bk, cfg, ush, ish, None
-    model.scheme, model.chunks = scheme, int(getattr(a, "chunks", 0))
-    model.replicate_feats = repl
-    if scheme == "halo":
-        model.halo = HaloPlan(need, ish, None, bk, dev)
-    model.img_w = nn.Parameter(xavier(a.d, dv))
-    model.img_b = nn.Parameter(torch.zeros(a.d))
-    model.txt_w = nn.Parameter(xavier(a.d, dt))
-    model.txt_b = nn.Parameter(torch.zeros(a.d))
-    model.w_cat = nn.Parameter(xavier(4 * a.d, a.d))
-    model.E_u = nn.Parameter((torch.rand(ush.per, a.d, generator=ge) * 2 - 1) * (6.0 / (U + a.d)) ** 0.5)
-    model.E_i = nn.Parameter((torch.rand(ish.per, a.d, generator=ge) * 2 - 1) * (6.0 / (I + a.d)) ** 0.5)
-    model.register_buffer("image_feats", img_l, persistent=False)
-    model.register_buffer("text_feats", txt_l, persistent=False)
-    model = model.to(dev).train()
-    step = ShardedHotPathStep(model, (plans[0], plans[1], e_ui, e_iu, e_ui, e_iu), a.batch, I, modal_empty=True)
+        img_l, txt_l = _bench_feat_block(rank, ish.per, dv, dt)
+    e_u, e_i = _bench_table_block(a, rank, ush.per, ish.per, U, I)
+    model = _bench_model(a, bk, cfg, ush, ish, group, scheme, repl, need, dev, dv, dt, img_l, txt_l, e_u, e_i)
+    step = ShardedHotPathStep(model, (plans[0], plans[1], e_ui, e_iu, e_ui, e_iu), a.batch, I, group=group, modal_empty=True)
+    if pre_step is not None:
+        pre_step(step)
     from . import ops
     ops.STATS.update(enabled=True, spmm_launches=0, edge_layers=0, spmm_bytes=0, unit_d=a.d)
     COMM["log"] = []
@@ -2004,14 +2085,15 @@ def build_bench_step(a, rank, world, dev, scaling="weak"):
     stats = dict(ops.STATS)
     stats["comm_log"], COMM["log"] = COMM["log"], None
     t = torch.tensor([int(round(stats["edge_layers"]))], dtype=torch.int64, device=dev)
-    with torch.cuda.stream(step.stream):
-        dist.all_reduce(t)
+    if world > 1:
+        with torch.cuda.stream(step.stream):
+            dist.all_reduce(t, group=group)
     torch.cuda.synchronize()
     stats["edge_layers_global"] = int(t.item())
     stats["edge_layers"] = int(round(stats["edge_layers"]))
     stats.update(n_users=U, n_items=I, n_edges=E_global, local_users=ush.per, local_items=ish.per,
                  local_edges=int(ui_l.nnz), scheme=scheme, replicate_feats=bool(repl),
-                 chunks=(model.n_chunks(2) if (scheme in ("item-side", "halo") and not _solo(None)) else 1),
+                 chunks=(model.n_chunks(2) if (scheme in ("item-side", "halo") and not _solo(group)) else 1),
                  halo=(model.halo if scheme == "halo" else None),
                  halo_rows_fraction=(round(model.halo.bytes_fraction, 4) if scheme == "halo" else None))
     return step, (ui_l, iu_l), plans, stats

@@ -60,24 +60,50 @@ def test_bench_sharded_path_one_rank_reports_comm():
     assert c["comm_only_ms"] > 0 and c["bytes_per_step"] > 0
 
 
-def test_bench_n_ranks_flow_on_one_gpu_including_scaling_stress():
-    """The N > 1 bench flow end to end on a one-GPU box (`--share-gpu`: every rank on GPU 0, gloo moving device tensors):
-    self-launch of the ranks, per-rank generation of the weak-scaling graph (item degrees summed across ranks), the item-side
-    sharded step, barrier + max-over-ranks timing, ONE JSON line with `comm` and the `scaling_stress` record (configs[4]'s
-    share x N). Timings mean nothing here; the contract fields and the record's arithmetic are checked."""
+def _n_rank_line(extra, timeout=1500):
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
-                        "--workload", "tiktok", "--share-gpu"], capture_output=True, text=True, timeout=1500, cwd=ROOT, env=env)
+                        "--workload", "tiktok", "--share-gpu"] + extra, capture_output=True, text=True, timeout=timeout,
+                       cwd=ROOT, env=env)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
-    d = json.loads(lines[0])
+    return json.loads(lines[0])
+
+
+def test_bench_n_ranks_flow_on_one_gpu_including_scaling_stress():
+    """The N > 1 bench flow end to end on a one-GPU box (`--share-gpu`: every rank on GPU 0): self-launch of the ranks,
+    per-rank generation of the weak-scaling graph (item degrees summed across ranks), the start-up self-test that selects
+    the PEER EXCHANGE (kernels over IPC-mapped windows), the item-side sharded step captured in a hipGraph, barrier +
+    max-over-ranks timing, ONE JSON line that proves itself: `rccl_ranks` (world size, backend, every rank's device UUID),
+    `loss_vs_n1` (the job's first-step loss against the same job whole on rank 0, 1e-4), `comm` (0 torch.distributed
+    collectives per step) and the `scaling_stress` record (configs[4]'s share x N next to the same share on one rank,
+    timed in this invocation). Timings mean nothing here; the fields and the records' arithmetic are checked."""
+    d = _n_rank_line([])
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["steps"] == 3 and d["value"] > 0
-    assert d["config"]["n_users"] == 2 * 9319 and d["config"]["launch"] == "eager"
+    assert d["config"]["n_users"] == 2 * 9319 and d["config"]["launch"] == "hipGraph replay"
     c = d["comm"]
     assert c["scheme"] == "item-side" and c["collectives_per_step"] >= 14 and c["bytes_per_step"] > 0
+    assert c["transport"].startswith("peer") and c["torch_distributed_collectives_per_step"] == 0, c
+    assert c["by_kind"]["peer_gather"][0] >= 6 and c["by_kind"]["peer_reduce"][0] >= 6 and c["by_kind"]["all_gather"][0] == 0
+    assert c["peer"]["exchange_launches_per_step"] > 0 and c["peer"]["windows"] >= c["peer"]["exchange_call_sites_per_step"]
+    rr = d["rccl_ranks"]
+    assert rr["world_size"] == 2 and len(rr["device_uuids"]) == 2 and rr["distinct_devices"] == 1      # --share-gpu
+    lv = d["loss_vs_n1"]
+    assert lv["ok"] and lv["rel_err"] <= lv["tolerance"] == 1e-4, lv
     st = d["scaling_stress"]
     assert "error" not in st, st
     assert st["ms_per_step"] > 0 and st["comm"]["scheme"] == "item-side" and st["comm"]["column_chunks"] >= 1
     assert abs(st["edge_layers_per_s"] - 2 * 250_000_000 / (st["ms_per_step"] * 1e-3)) <= 1e-3 * st["edge_layers_per_s"]
     assert st["one_rank"]["edge_layers_per_s"] > 0 and abs(st["per_rank_ratio"] - st["edge_layers_per_s"] / 2 / st["one_rank"]["edge_layers_per_s"]) < 1e-3
+    assert st["n1_ms"] > 0 and abs(st["weak_efficiency_vs_n1_ms"] - st["n1_ms"] / st["ms_per_step"]) < 1e-3
+
+
+def test_bench_n_ranks_flow_over_the_collective_transport():
+    """The same flow with `--transport collective` (the A/B: gloo moving device tensors on a shared GPU, RCCL on a real
+    node): eager launches, the exchanges counted as torch.distributed collectives, the same loss check."""
+    d = _n_rank_line(["--transport", "collective", "--no-stress"])
+    c = d["comm"]
+    assert d["config"]["launch"] == "eager" and c["transport"].startswith("collective")
+    assert c["torch_distributed_collectives_per_step"] >= 14 and c["by_kind"]["all_gather"][0] >= 6
+    assert d["loss_vs_n1"]["ok"], d["loss_vs_n1"]

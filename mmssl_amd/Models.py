@@ -76,6 +76,13 @@ class MMSSL(nn.Module):
             "w_self_attention_user": nn.Parameter(init(torch.empty([d, d]))),
             "w_self_attention_cat": nn.Parameter(init(torch.empty([args.head_num * d, d]))),
         })
+        # w_q: the reference's attention computes Q with it (Models.py:139-169), but K is a reshuffled Q and the softmax
+        # weights cancel, so its gradient is exactly zero on the CPU (~1e-9 noise on a GPU) - NOT None: torch.optim.AdamW
+        # therefore applies its decoupled weight decay to it every step (w_q <- w_q (1 - lr * 0.01); measured on G12: the
+        # trained w_q equals that to 1.2e-7), while w_k / w_v / ... receive no gradient at all and never move. The forward
+        # here does not read w_q (see _modality_fusion); the flag makes FusedAdamW hand it the same all-zero gradient, so a
+        # trained checkpoint's w_q matches the reference's.
+        self.weight_dict["w_q"].unused_grad_is_zero = True
         self.embedding_dict = {"user": {}, "item": {}}
         self.extra_names = []
         self.extra_feats = {}
@@ -127,8 +134,8 @@ class MMSSL(nn.Module):
         axis, the softmax weights sum to 1 and each head returns V itself, i.e.
             Z_b = V_b @ (sum of the head_num row blocks of w_self_attention_cat)
         (the oracle keeps the literal 5-D form and tests bound the gap, <= 4e-6).
-        w_q only ever receives ~1e-9 numerical-noise gradients in the reference and w_k none;
-        here both receive none."""
+        w_q only ever receives an all-zero (GPU: ~1e-9 numerical-noise) gradient in the reference and w_k none; here w_q
+        is handed the zero gradient by the optimiser (weight decay only, see __init__) and w_k none."""
         d = args.embed_size
         wcat = self.weight_dict["w_self_attention_cat"]
         fold = wcat.view(args.head_num, d, d).sum(0)               # [d, d]

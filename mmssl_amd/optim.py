@@ -23,6 +23,7 @@ class FusedAdamW(torch.optim.Optimizer):
             raise ValueError("FusedAdamW: invalid hyper-parameter")
         super().__init__(params, dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay))
         self._steps = {}        # per param group: device float[2] {completed steps, block counter}
+        self._zero_grads = {}   # parameter -> persistent all-zero gradient (parameters flagged `unused_grad_is_zero`)
 
     def _group_state(self, gi, device):
         st = self._steps.get(gi)
@@ -83,6 +84,13 @@ class FusedAdamW(torch.optim.Optimizer):
             todo = []
             for p in group["params"]:
                 sl = sliced.get(p) if sliced else None
+                if p.grad is None and sl is None and getattr(p, "unused_grad_is_zero", False) and id(p) not in skip:
+                    # a parameter the forward reads nowhere but the reference's autograd hands an all-zero gradient
+                    # (weight_dict.w_q, see Models.MMSSL.__init__): AdamW then applies its decoupled weight decay only
+                    z = self._zero_grads.get(p)
+                    if z is None:
+                        z = self._zero_grads[p] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                    p.grad = z
                 if (p.grad is None and sl is None) or id(p) in skip:
                     continue
                 if not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous()):

@@ -586,12 +586,16 @@ def test_g12_trainer_trajectory_and_recall_match_reference(tmp_path, graph_flag)
         assert not any(used)
     np.testing.assert_allclose(got[:, :4], want[:, :4], rtol=1e-4, atol=1e-7)
     np.testing.assert_allclose(got[:, 4], want[:, 4], rtol=1e-4, atol=1e-5)           # -mean(100 * sigmoid(.))
+    # weight_dict.w_q: an all-zero gradient in the reference, i.e. AdamW's weight decay only (8 x lr x 0.01 of its value);
+    # the product's optimiser hands it the same zero gradient (Models.MMSSL.__init__) - a trained checkpoint round-trips
     for k in ("image_trans.weight", "image_trans.bias", "text_trans.weight", "text_trans.bias", "user_id_embedding.weight",
-              "item_id_embedding.weight", "weight_dict.w_self_attention_cat"):
+              "item_id_embedding.weight", "weight_dict.w_self_attention_cat", "weight_dict.w_q"):
         e = H.rel_err(P[k], fx["m1." + k])
         assert e < 1e-4, (k, e)
         moved = H.rel_err(fx["m0." + k], fx["m1." + k])
         assert moved > 10 * e, (k, moved, e)                     # the comparison is not vacuous: training moved it
+    for k in ("weight_dict.w_k", "weight_dict.w_v"):             # no gradient at all on either side: untouched
+        assert np.array_equal(P[k].numpy(), fx["m1." + k]) and np.array_equal(fx["m0." + k], fx["m1." + k]), k
     assert H.rel_err(ua, fx["eval.ua"]) < 1e-4 and H.rel_err(ia, fx["eval.ia"]) < 1e-4
     for nm in ("val", "test"):
         for k in ("precision", "recall", "ndcg", "hit_ratio"):

@@ -140,8 +140,9 @@ def spmm_roofline(plans, mats, d, iters=200, traffic=True):
            "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
            "avg_launch_us": round(avg_us, 2), "algorithmic_bytes_per_launch": int(avg_bytes),
            "traffic": load_traffic() if traffic else None,
-           "traffic_source": ("profiles/%s (rocprofv3 --pmc pass, FETCH_SIZE x 2 + WRITE_SIZE, gfx950-calibrated; a committed "
-                              "constant, not measured in this run)" % TRAFFIC_FILE[0]) if traffic and TRAFFIC_FILE[0] else None}
+           "traffic_source": ("profiles/%s (rocprofv3 --pmc pass, FETCH_SIZE x 2 + WRITE_SIZE, gfx950-calibrated; taken by "
+                              "tools/evidence.sh in its own run - counters cannot be collected beside the timed region - and "
+                              "tied to the kernel sources by sha256)" % TRAFFIC_FILE[0]) if traffic and TRAFFIC_FILE[0] else None}
     if rec["frac"] > 1.0:
         rec["note"] = ("algorithmic bytes count every gathered row once per edge; here the gathered table fits the 256 MB "
                        "Infinity Cache, so most of those bytes never reach HBM and the ratio to the HBM peak exceeds 1")
@@ -259,19 +260,13 @@ def spmm_hbm_record(iters=20):
     P = GraphPlan(ui_r)
     X = torch.randn(I, d, device="cuda")
     G = torch.randn(U_r, d, device="cuda")
-    pmc, pmc_file = None, None
-    for name in ("r05_spmm_hbm_pmc.json", "r04_spmm_hbm_pmc.json"):
-        pp = os.path.join(ROOT, "profiles", name)
-        if os.path.exists(pp):
-            try:
-                pmc, pmc_file = json.load(open(pp)), name
-                break
-            except Exception:
-                pmc = None
+    pmc, pmc_file, stale, verified = pmc_record(("r06_spmm_hbm_pmc.json", "r05_spmm_hbm_pmc.json", "r04_spmm_hbm_pmc.json"))
+    if stale:
+        pmc, pmc_file = None, pmc_file + " [STALE: csrc/graph.hip changed since the pass]"
     out = {"what": "configs[4] rank shape, d=128: A_ui[U_r,:] 250000 x 1000000, 12.5M edges; gathered table 512 MB (HBM resident)",
            "random_gather_ceiling_GBps": 4400.0,
-           "traffic_source": ("profiles/%s (rocprofv3 --pmc pass of tools/spmm_hbm_pmc.py; not measured in this run)" % pmc_file)
-                             if pmc else None}
+           "traffic_source": ("profiles/%s (rocprofv3 --pmc pass of tools/spmm_hbm_pmc.py in its own run, tied to the kernel "
+                              "sources by sha256)" % pmc_file) if pmc_file else None}
     rng = np.random.default_rng(0)
     with torch.no_grad():
         for name, tr, Xin, m in (("forward", False, X, ui_r), ("transpose", True, G, ui_r.T.tocsr())):
@@ -406,20 +401,49 @@ def first_step_loss(a, step, raw, batch):
 
 
 TRAFFIC_FILE = [None]
+SPMM_SOURCES = ("mmssl_amd/csrc/graph.hip", "mmssl_amd/csrc/graph_internal.hpp", "mmssl_amd/csrc/common.hpp")
+
+
+def kernel_source_sha(files=SPMM_SOURCES):
+    """sha256 over the sources of a kernel: tools/pmc_summary.py records it next to the counters of a PMC pass, and a
+    `traffic` figure is only printed while the kernel it was measured on is still the kernel in the tree."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in files:
+        with open(os.path.join(ROOT, f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
+def pmc_record(names, key=None):
+    """(record, file name, stale?) of the newest committed PMC summary among `names`. A summary that carries a
+    `source_sha256` other than the current sources' is STALE (its numbers describe another kernel); summaries from before
+    round 6 carry none and count as unverified-but-usable only while no verified one exists."""
+    cur = kernel_source_sha()
+    for name in names:
+        p = os.path.join(ROOT, "profiles", name)
+        if not os.path.exists(p):
+            continue
+        try:
+            rec = json.load(open(p))
+        except Exception:
+            continue
+        sha = rec.get("source_sha256")
+        return rec, name, (sha is not None and sha != cur), sha is not None
+    return None, None, False, False
 
 
 def load_traffic():
-    """HBM bytes per SpMM launch from the committed rocprofv3 PMC pass (profiles/*_pmc.json), if any."""
-    for name in ("r05_spmm_pmc.json", "r04_spmm_pmc.json", "r03_spmm_pmc.json"):
-        p = os.path.join(ROOT, "profiles", name)
-        if os.path.exists(p):
-            try:
-                v = json.load(open(p)).get("hbm_bytes_per_launch")
-                TRAFFIC_FILE[0] = name
-                return v
-            except Exception:
-                continue
-    return None
+    """Fabric bytes per SpMM launch from the committed rocprofv3 PMC pass (profiles/*_spmm_pmc.json); None when the pass
+    was taken on other kernel sources than the tree's (re-run `bash tools/evidence.sh rNN pmc`)."""
+    rec, name, stale, verified = pmc_record(("r06_spmm_pmc.json", "r05_spmm_pmc.json", "r04_spmm_pmc.json"))
+    if rec is None:
+        return None
+    TRAFFIC_FILE[0] = name + ("" if verified else " [no source hash recorded]")
+    if stale:
+        TRAFFIC_FILE[0] = name + " [STALE: csrc/graph.hip changed since the pass - figure withheld]"
+        return None
+    return rec.get("hbm_bytes_per_launch")
 
 
 def cpu_baseline(a, raw, mats, budget_s=20.0, first=None):

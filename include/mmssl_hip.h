@@ -182,17 +182,39 @@ int mmssl_graph_rows_dense_f32(const mmssl_graph* g, const int64_t* rows, int64_
  *   sumsq_part (may be NULL): [B, mmssl_sim_rows_parts(n_items)] partial sums of squares of the unmasked scores;
  *   mmssl_rows_scale_parts_f32 turns them into the row factors 1/max(norm, eps), applies them in place and
  *   returns them (inv_out may be NULL). mmssl_graph_sim_rows_f32: the same with a graph plan's CSR as the mask.
+ * mmssl_usim_rows_f32 / mmssl_graph_usim_rows_f32: u_sim in ONE pass over the [B, n_items] matrix (d in {32, 64, 128}):
+ *   out = F.normalize(scores with the masked entries at 0, dim = 1) and inv_out[b] = 1 / max(|row b|, eps). The row norms
+ *   are known before the tile kernel runs - |S_b|^2 = q_b^T (T^T T) q_b - sum over the row's masked items of (q_b . t_j)^2,
+ *   Gram matrix on the fp32 matrix pipe with float64 block sums, quadratic form in float64 - so the matrix is written
+ *   once, already scaled; columns [n_items, ldo) of a pitched row are written as zeros. workspace:
+ *   mmssl_usim_workspace_bytes(d, n_items) bytes (0 = d not supported: use the two-launch form above).
  * mmssl_topk_rows_f32: idx_out[b, 0..K) = columns of the K largest entries of row b in DESCENDING value, ties by
  *   ASCENDING column (heapq.nlargest over an ascending-id dict); K <= 256, n_cols <= 36864 per launch (wider rows:
  *   one launch per column block, then one over the blocks' winners - ops.topk_rows does that); rows shorter than K
  *   are padded with -1. val_out (may be NULL) receives the values.
  * mmssl_rows_membership_u8: out[b, k] = 1 iff cand[b, k] is a column of CSR row rows[b] (sorted columns): the
  *   hit matrix of the evaluation without a dense [users, items] positives matrix.
+ * mmssl_eval_accumulate_f64: the metric formulas of utility/batch_test.py:38-80 / utility/metrics.py on the device:
+ *   acc[m * 8 + i] += sum over the B users of metric m (0 precision, 1 recall, 2 ndcg, 3 hit ratio) @ ks[i], float64,
+ *   from the ranked candidates cand [B, K] (the top-K kernel's output) and the users' positives (CSR rows rows[b], sorted
+ *   int32 columns). Fixed summation order (threads, waves, blocks). acc is [4][8] doubles, zeroed by the caller before
+ *   the first batch and read once after the last; n_ks <= 8, ks[i] <= K. workspace: mmssl_eval_workspace_bytes(B).
  * ---------------------------------------------------------------------------------- */
+size_t mmssl_eval_workspace_bytes(int64_t B);
+int mmssl_eval_accumulate_f64(const int32_t* pos_rowptr, const int32_t* pos_cols, const int64_t* rows, int64_t B, int K,
+                              const int64_t* cand, const int* ks, int n_ks, double* acc, void* workspace,
+                              size_t workspace_bytes, void* stream);
 int mmssl_sim_rows_parts(int64_t n_items);
 int mmssl_sim_rows_f32(const float* Q, const int64_t* qidx, int64_t B, const float* T, int64_t n_items, int d,
                        const int32_t* mask_rowptr, const int32_t* mask_cols, float mask_value, float* out,
                        int64_t ldo, float* sumsq_part, void* stream);
+size_t mmssl_usim_workspace_bytes(int d, int64_t n_items);
+int mmssl_usim_rows_f32(const float* Q, const int64_t* qidx, int64_t B, const float* T, int64_t n_items, int d,
+                        const int32_t* mask_rowptr, const int32_t* mask_cols, float eps, float* out, int64_t ldo,
+                        float* inv_out, void* workspace, size_t workspace_bytes, void* stream);
+int mmssl_graph_usim_rows_f32(const mmssl_graph* g, const float* Q, const int64_t* rows, int64_t n, const float* T, int d,
+                              float eps, float* out, int64_t ldo, float* inv_out, void* workspace, size_t workspace_bytes,
+                              void* stream);
 int mmssl_graph_sim_rows_f32(const mmssl_graph* g, const float* Q, const int64_t* rows, int64_t n, const float* T,
                              int d, float mask_value, float* out, int64_t ldo, float* sumsq_part, void* stream);
 int mmssl_rows_scale_parts_f32(float* X, int64_t B, int64_t n_items, int64_t ldo, const float* sumsq_part,

@@ -138,6 +138,14 @@ SIGNATURES = {
                                        c_void_p]),
     "mmssl_ngcf_combine_bwd_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_int64,
                                            c_int, c_float, c_void_p, c_void_p, c_void_p]),
+    "mmssl_eval_workspace_bytes": (c_size_t, [c_int64]),
+    "mmssl_eval_accumulate_f64": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p, POINTER(c_int), c_int,
+                                          c_void_p, c_void_p, c_size_t, c_void_p]),
+    "mmssl_usim_workspace_bytes": (c_size_t, [c_int, c_int64]),
+    "mmssl_usim_rows_f32": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_float,
+                                    c_void_p, c_int64, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "mmssl_graph_usim_rows_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int, c_float, c_void_p, c_int64,
+                                          c_void_p, c_void_p, c_size_t, c_void_p]),
     "mmssl_peer_create": (c_int, [c_int, c_int, c_int, POINTER(c_void_p)]),
     "mmssl_peer_destroy": (c_int, [c_void_p]),
     "mmssl_peer_info": (c_int, [c_void_p, _i64p]),

@@ -98,7 +98,12 @@ inline bool supported_d(int d) { return d == 32 || d == 64 || d == 128 || d == 2
 // csrc/simtopk.hip: batch similarity rows with a CSR mask given as (rowptr, column array with `m_stride` bytes
 // between consecutive columns)
 int sim_launch(const float* Q, const int64_t* qidx, int64_t B, const float* T, int64_t I, int d, const int32_t* m_rowptr,
-               const void* m_cols, int m_stride, float mask_value, float* out, int64_t ldo, float* sumsq_part,
-               hipStream_t s);
+               const void* m_cols, int m_stride, float mask_value, const float* row_scale, float* out, int64_t ldo,
+               float* sumsq_part, hipStream_t s);
+// the row factors 1 / max(|masked score row|, eps) without forming the rows (Gram matrix of T; workspace bytes below)
+size_t usim_norms_workspace(int d, int64_t n_items);
+int usim_norms_launch(const float* Q, const int64_t* qidx, int64_t B, const float* T, int64_t I, int d,
+                      const int32_t* m_rowptr, const void* m_cols, int m_stride, float eps, float* inv_out, void* ws,
+                      hipStream_t s);
 
 }  // namespace mmssl

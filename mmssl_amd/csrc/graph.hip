@@ -975,8 +975,26 @@ extern "C" int mmssl_graph_sim_rows_f32(const mmssl_graph* g, const float* Q, co
   if (!g || n < 0 || (n > 0 && (!rows || !Q || !T || !out)) || ldo < g->fwd.cols) return MMSSL_E_BADARG;
   if (n == 0 || g->fwd.cols == 0) return 0;
   if (((uintptr_t)Q | (uintptr_t)T) & 15) return MMSSL_E_BADARG;
-  return sim_launch(Q, rows, n, T, g->fwd.cols, d, g->fwd.rowptr, g->fwd.edges, (int)sizeof(Edge), mask_value, out, ldo,
-                    sumsq_part, as_stream(stream));
+  return sim_launch(Q, rows, n, T, g->fwd.cols, d, g->fwd.rowptr, g->fwd.edges, (int)sizeof(Edge), mask_value, nullptr, out,
+                    ldo, sumsq_part, as_stream(stream));
+}
+
+// Trainer.u_sim_calculation in ONE pass over the [n, n_items] matrix: out = normalize(scores . (1 - R[rows]), dim = 1);
+// the row factors come from the item table's Gram matrix before the tile kernel runs (csrc/simtopk.hip) and are returned
+extern "C" int mmssl_graph_usim_rows_f32(const mmssl_graph* g, const float* Q, const int64_t* rows, int64_t n,
+                                         const float* T, int d, float eps, float* out, int64_t ldo, float* inv_out,
+                                         void* workspace, size_t workspace_bytes, void* stream) {
+  if (!g || n < 0 || (n > 0 && (!rows || !Q || !T || !out || !inv_out)) || ldo < g->fwd.cols || !(eps > 0.f))
+    return MMSSL_E_BADARG;
+  if (n == 0 || g->fwd.cols == 0) return 0;
+  if (((uintptr_t)Q | (uintptr_t)T) & 15) return MMSSL_E_BADARG;
+  if (d != 32 && d != 64 && d != 128) return MMSSL_E_UNSUPP;
+  if (!workspace || workspace_bytes < usim_norms_workspace(d, g->fwd.cols)) return MMSSL_E_WORKSPACE;
+  int rc = usim_norms_launch(Q, rows, n, T, g->fwd.cols, d, g->fwd.rowptr, g->fwd.edges, (int)sizeof(Edge), eps, inv_out,
+                             workspace, as_stream(stream));
+  if (rc) return rc;
+  return sim_launch(Q, rows, n, T, g->fwd.cols, d, g->fwd.rowptr, g->fwd.edges, (int)sizeof(Edge), 0.f, inv_out, out, ldo,
+                    nullptr, as_stream(stream));
 }
 
 extern "C" int mmssl_graph_rows_dense_f32(const mmssl_graph* g, const int64_t* rows, int64_t n, float value,

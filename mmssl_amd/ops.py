@@ -633,6 +633,19 @@ def _pitch(n, mult=32):
     return (n + mult - 1) // mult * mult
 
 
+_USIM_WS = {}
+
+
+def _usim_ws(nbytes, dev):
+    """The Gram-matrix workspace of mmssl_usim_rows_f32 (block partials + the float64 matrix), one per stream: calls on
+    one stream are ordered, two streams must not share it."""
+    key = (str(dev), torch.cuda.current_stream(dev).cuda_stream, int(nbytes))
+    ws = _USIM_WS.get(key)
+    if ws is None:
+        ws = _USIM_WS[key] = torch.empty(int(nbytes) // 4 + 4, dtype=torch.float32, device=dev)
+    return ws
+
+
 def sim_rows(Q, T, qidx=None, mask=None, mask_value=0.0, normalize=False, eps=_NORM_EPS, pitch_mult=1):
     """S[b, j] = <Q[qidx[b]], T[j]> for every row j of T, on the fp32 matrix cores, with the entries of a CSR mask row
     replaced by `mask_value` and (optionally) the rows L2-normalised: the score product of
@@ -648,7 +661,28 @@ def sim_rows(Q, T, qidx=None, mask=None, mask_value=0.0, normalize=False, eps=_N
     B = Q.shape[0] if qidx is None else qidx.shape[0]
     n, d = T.shape
     ld = _pitch(n, pitch_mult)
-    out = (torch.zeros if ld != n else torch.empty)((B, ld), dtype=torch.float32, device=dev)
+    L = _lib.lib()
+    one_pass = normalize and float(mask_value) == 0.0 and L.mmssl_usim_workspace_bytes(d, n) > 0
+    if one_pass:
+        # u_sim: the row factors first (Gram matrix of T, float64 quadratic forms), then ONE pass that writes the scaled
+        # matrix, pad columns included - no zero fill, no partial sums, no second pass over [B, n]
+        out = torch.empty((B, ld), dtype=torch.float32, device=dev)
+        inv = torch.empty(B, dtype=torch.float32, device=dev)
+        nb = L.mmssl_usim_workspace_bytes(d, n)
+        ws = _usim_ws(nb, dev)
+        if mask is not None and hasattr(mask, "handle"):
+            if qidx is None:
+                raise _lib.MmsslError("sim_rows: a plan mask needs qidx (the plan rows of the batch)")
+            rc = L.mmssl_graph_usim_rows_f32(mask.handle, _ptr(Q), _ptr(qidx), B, _ptr(T), d, float(eps), _ptr(out), ld,
+                                             _ptr(inv), _ptr(ws), nb, _lib.stream_ptr())
+            _lib.check(rc, "mmssl_graph_usim_rows_f32")
+        else:
+            rp, cols = (None, None) if mask is None else mask
+            rc = L.mmssl_usim_rows_f32(_ptr(Q), _ptr(qidx), B, _ptr(T), n, d, _ptr(rp), _ptr(cols), float(eps), _ptr(out),
+                                       ld, _ptr(inv), _ptr(ws), nb, _lib.stream_ptr())
+            _lib.check(rc, "mmssl_usim_rows_f32")
+        return (out if ld == n else out[:, :n]), inv
+    out = torch.empty((B, ld), dtype=torch.float32, device=dev)       # (the tile kernel writes the pad columns as zeros)
     nparts = _lib.lib().mmssl_sim_rows_parts(n)
     part = torch.empty((B, max(nparts, 1)), dtype=torch.float32, device=dev) if normalize else None
     if mask is not None and hasattr(mask, "handle"):
@@ -728,6 +762,20 @@ def rows_membership(rowptr, cols, rows, cand):
                                              _lib.stream_ptr())
     _lib.check(rc, "mmssl_rows_membership_u8")
     return out
+
+
+def eval_accumulate(pos_rowptr, pos_cols, rows, cand, Ks, acc, ws=None):
+    """acc [4, 8] float64 (precision, recall, ndcg, hit ratio @ Ks) += the sums over the batch's users, on the device
+    (csrc/simtopk.hip eval_metrics_kernel; formulas of utility/batch_test.py:38-80). Returns the workspace for reuse."""
+    B, K = cand.shape
+    nb = _lib.lib().mmssl_eval_workspace_bytes(B)
+    if ws is None or ws.numel() * 8 < nb:
+        ws = torch.empty(nb // 8 + 2, dtype=torch.float64, device=cand.device)
+    ks = (_ct.c_int * len(Ks))(*[int(k) for k in Ks])
+    rc = _lib.lib().mmssl_eval_accumulate_f64(_ptr(pos_rowptr), _ptr(pos_cols), _ptr(rows), B, K, _ptr(cand.contiguous()), ks,
+                                              len(Ks), _ptr(acc), _ptr(ws), ws.numel() * 8, _lib.stream_ptr())
+    _lib.check(rc, "mmssl_eval_accumulate_f64")
+    return ws
 
 
 class _USim(torch.autograd.Function):

@@ -968,3 +968,76 @@ def test_fuse_rows_equals_dense_rows_and_bwd_partials_sum_the_squares():
     ops.loss_add_partials(part, 1e-3, total, ss)
     assert abs(float(ss) - want) <= 2e-6 * want
     assert abs(float(total) - (1.5 + 1e-3 * want)) <= 1e-6 * (1.5 + 1e-3 * want)
+
+
+@pytest.mark.parametrize("B,K,Ks", [(700, 50, (10, 20, 50)), (1, 20, (20,)), (2049, 64, (1, 5, 64))])
+def test_eval_metrics_on_the_device_equal_the_host_formulas(B, K, Ks):
+    """csrc/simtopk.hip eval_metrics_kernel against utility/batch_test._metric_sums (the reference's formulas,
+    batch_test.py:38-80 + metrics.py, vectorised in numpy float64): precision / recall / ndcg / hit ratio @ Ks summed
+    over the users, two batches accumulated into the same totals, users without positives, candidate lists padded
+    with -1; 1e-12 relative (float64 sums in another order)."""
+    from mmssl_amd import ops
+    from mmssl_amd.utility import batch_test
+    rng = np.random.RandomState(B + K)
+    U, I = 3000, 900
+    pos = sp.random(U, I, density=0.01, random_state=rng, format="csr", dtype=np.float32)
+    pos.sort_indices()
+    rp = torch.from_numpy(pos.indptr.astype(np.int32)).to(DEV)
+    cols = torch.from_numpy(pos.indices.astype(np.int32)).to(DEV)
+    acc = torch.zeros((4, 8), dtype=torch.float64, device=DEV)
+    want = {k: np.zeros(len(Ks)) for k in ("precision", "recall", "ndcg", "hit_ratio")}
+    ws = None
+    for rep in range(2):
+        users = rng.choice(U, size=B, replace=B > U)
+        cand = np.stack([rng.permutation(I)[:K] for _ in range(B)]).astype(np.int64)
+        cand[0, K // 2:] = -1                                   # a row shorter than K
+        for b in range(0, B, 7):                                # make sure there are hits at all ranks
+            mine = pos.indices[pos.indptr[users[b]]:pos.indptr[users[b] + 1]]
+            if len(mine):
+                cand[b, rng.randint(0, K)] = mine[0]
+                cand[b] = np.where(np.arange(K) == np.argmax(cand[b] == mine[0]), cand[b], np.where(cand[b] == mine[0], -1, cand[b]))
+        hits = np.zeros((B, K))
+        for b in range(B):
+            mine = set(pos.indices[pos.indptr[users[b]]:pos.indptr[users[b] + 1]].tolist())
+            hits[b] = [1.0 if (c >= 0 and int(c) in mine) else 0.0 for c in cand[b]]
+        n_pos = np.diff(pos.indptr)[users]
+        s = batch_test._metric_sums(hits, n_pos, list(Ks))
+        for k in want:
+            want[k] += s[k]
+        ws = ops.eval_accumulate(rp, cols, torch.from_numpy(users.astype(np.int64)).to(DEV), torch.from_numpy(cand).to(DEV),
+                                 list(Ks), acc, ws)
+    got = acc.cpu().numpy()
+    assert want["hit_ratio"].sum() > 0
+    for m, k in enumerate(("precision", "recall", "ndcg", "hit_ratio")):
+        np.testing.assert_allclose(got[m, :len(Ks)], want[k], rtol=1e-12, atol=1e-12, err_msg=k)
+    assert float(np.abs(got[:, len(Ks):]).max()) == 0.0
+
+
+@pytest.mark.parametrize("n,d,B", [(18357, 64, 1024), (4500, 32, 77), (2049, 128, 64)])
+def test_usim_one_pass_norms_come_from_the_gram_matrix(n, d, B):
+    """The one-pass u_sim (row factors from the item table's Gram matrix before the tile kernel, the [B, n] matrix written
+    once, pad columns zeroed by the kernel) against float64: scores, the returned factors, exact zeros at masked entries
+    and in the pad columns, and bit-identical results from two calls (fixed-order Gram sums)."""
+    from mmssl_amd import ops
+    gen = torch.Generator().manual_seed(n + d)
+    Q = 300
+    qt, tt = torch.randn(Q, d, generator=gen), torch.randn(n, d, generator=gen) * 0.3 + 0.1      # a common component
+    idx = torch.randint(0, Q, (B,), generator=gen)
+    rng = np.random.RandomState(n)
+    mask = sp.random(Q, n, density=0.01, random_state=rng, format="csr", dtype=np.float32)
+    mask.sort_indices()
+    rp = torch.from_numpy(mask.indptr.astype(np.int32)).to(DEV)
+    cols = torch.from_numpy(mask.indices.astype(np.int32)).to(DEV)
+    dense = torch.from_numpy(np.asarray(mask[idx.numpy()].todense()) != 0)
+    ref = (qt[idx].double() @ tt.double().t()).masked_fill(dense, 0.0)
+    nrm = ref.norm(dim=1)
+    Sn, inv = ops.sim_rows(qt.to(DEV), tt.to(DEV), qidx=idx.to(DEV), mask=(rp, cols), mask_value=0.0, normalize=True,
+                           pitch_mult=32)
+    full = Sn if Sn.stride(0) == Sn.shape[1] else torch.as_strided(Sn, (B, Sn.stride(0)), (Sn.stride(0), 1))
+    assert float(full[:, n:].abs().max()) == 0.0 if full.shape[1] > n else True
+    assert H.rel_err(Sn.cpu(), ref / nrm[:, None]) < 3e-6
+    assert float(((inv.cpu().double() * nrm) - 1.0).abs().max()) < 2e-6
+    assert float(Sn.cpu()[dense].abs().max()) == 0.0
+    Sn2, inv2 = ops.sim_rows(qt.to(DEV), tt.to(DEV), qidx=idx.to(DEV), mask=(rp, cols), mask_value=0.0, normalize=True,
+                             pitch_mult=32)
+    assert torch.equal(Sn, Sn2) and torch.equal(inv, inv2)

@@ -43,6 +43,11 @@ def main(fetch_csv, write_csv, out):
     res["note"] = ("tables and CSR of the Baby shape are Infinity-Cache resident: this fabric traffic is below the algorithmic "
                    "gather-per-edge bytes (74.7 MB/launch at d = 64) but above the compulsory once-through bytes (~16 MB) - "
                    "every XCD's L2 pulls its own copy of the gathered table")
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    res["source_sha256"] = bench.kernel_source_sha()      # bench.py withholds `traffic` when graph.hip has changed since
+    res["source_files"] = list(bench.SPMM_SOURCES)
     json.dump(res, open(out, "w"), indent=1)
     print(json.dumps(res, indent=1))
 

@@ -53,6 +53,9 @@ def summarise(fetch_csv, write_csv, out):
             continue
         fb, wb = 2 * 1024 * sum(ff) / len(ff), 1024 * sum(ww) / len(ww)
         res[name] = {"fetch_bytes_x2": int(fb), "write_bytes": int(wb), "fabric_bytes": int(fb + wb)}
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    res["source_sha256"] = bench.kernel_source_sha()      # bench.py withholds the figures when graph.hip has changed since
     json.dump(res, open(out, "w"), indent=1)
     print(json.dumps(res, indent=1))
 

@@ -24,163 +24,183 @@ namespace {
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 
-constexpr int kSimChunk = 512;           // items per block: 36 x 32 blocks for the Baby shape (4.5 per CU: no tail round)
+constexpr int kSimChunk = 256;           // items per block = one LDS stage: 72 x 32 short blocks for the Baby shape (no tail)
 constexpr int kSimTile = 32;
-constexpr int kSimGroup = 256;           // items staged in LDS and written out as whole 1 KB row segments
-constexpr int kStagePitch = kSimGroup + 4;
-static_assert(kSimChunk == 2 * kSimGroup, "a block stages its chunk as two groups, each in a buffer of its own");
+constexpr int kStagePitch = kSimChunk + 4;
 
 __device__ __forceinline__ int32_t mask_col(const void* cols, int stride, int64_t e) {
   return *reinterpret_cast<const int32_t*>(reinterpret_cast<const char*>(cols) + e * stride);
 }
 
 // DCH = d / 8: number of 8-deep k chunks (one float4 per lane half)
-// A block = 32 batch rows x 512 items: every wave computes four 32 x 32 MFMA tiles (item rows stream from L2 straight
-// into fragment layout, register double buffer), leaves them - masked, scaled by the row's factor - in an LDS stage
-// of 32 rows x 256 items, and the block then writes each staged row as ONE 1 KB segment (round 5 stored the MFMA
+// A block = 32 batch rows x 256 items: every wave computes two 32 x 32 MFMA tiles (both tiles' item rows are requested
+// from L2 before the first MFMA, straight into fragment layout), leaves them - scaled by the row's factor - in an LDS
+// stage of 32 rows x 256 items, and the block then writes each staged row as ONE 1 KB segment (round 5 stored the MFMA
 // fragments directly: 128-byte segments, 0.18 of the write roofline together with the separate scale pass).
 // row_scale != NULL: out = row_scale[b] * score (the factor of F.normalize, known BEFORE this launch: usim_norms_kernel),
 // so the [B, n_items] matrix is written exactly once. Columns [I, ldo) of a padded row are written as zeros.
-template <int DCH>
-__global__ __launch_bounds__(kBlock) void sim_tiles_kernel(const float* __restrict__ Q, const int64_t* __restrict__ qidx,
-                                                           int64_t B, const float* __restrict__ T, int64_t I,
-                                                           const int32_t* __restrict__ m_rowptr,
-                                                           const void* __restrict__ m_cols, int m_stride,
-                                                           float mask_value, const float* __restrict__ row_scale,
-                                                           float* __restrict__ out, int64_t ldo,
-                                                           float* __restrict__ sumsq_part, int nparts) {
+// INK (mask IN the Kernel): the CSR mask as a per-block bitmap + the fixed-order partial sums of squares of the unmasked
+// scores - the form the partial-sums API needs. The product's calls run INK = false: no bitmap, no binary searches in
+// front of the tiles, and mask_scatter_kernel overwrites the (few) masked entries afterwards.
+// decomposition builds for tools/frows_probe.py (never set in the product build): bit 0 = no MFMAs, bit 1 = no global
+// stores, bit 2 = no item-row loads
+#ifndef MMSSL_SIM_DBG
+#define MMSSL_SIM_DBG 0
+#endif
+// A block walks `cpb` consecutive chunks with ITS 32 batch rows (gathered once, kept in registers with their factors): the
+// fixed cost of a block - index load, row gather, factor loads: three dependent memory latencies - is paid once. Inside a
+// chunk a wave loads one tile's item rows, waits, runs its 32 MFMAs and stages the tile - no software pipeline: at four
+// waves per SIMD (<= 128 VGPRs) the waves of the resident blocks fall out of step after their first chunk (the matrix pipe
+// serves one of them at a time) and one wave's loads and stores run under another's MFMAs (three waves per SIMD at d <= 64). Measured decomposition of the
+// one-chunk-per-block form (profiles/r06/sim_tiles_ablate.txt): MFMAs 15 us + item-row loads 15 us (32 cache lines per
+// load instruction) + stores 12 us + skeleton 10 us, all in series = 52 us.
+template <int DCH, bool INK, bool VEC>
+__global__ __launch_bounds__(kBlock, DCH <= 8 ? 3 : 2) void sim_tiles_kernel(const float* __restrict__ Q, const int64_t* __restrict__ qidx,
+                                                              int64_t B, const float* __restrict__ T, int64_t I,
+                                                              const int32_t* __restrict__ m_rowptr,
+                                                              const void* __restrict__ m_cols, int m_stride,
+                                                              float mask_value, const float* __restrict__ row_scale,
+                                                              float* __restrict__ out, int64_t ldo,
+                                                              float* __restrict__ sumsq_part, int nparts, int cpb) {
   constexpr int d = DCH * 8;
-  __shared__ uint32_t bitmap[kSimChunk];
+  __shared__ uint32_t bitmap[INK ? kSimChunk : 1];
   __shared__ float red[4][32];
-  extern __shared__ __attribute__((aligned(16))) float stage_mem[];       // [2][32][kStagePitch]: 65 KB, dynamic
-  float(*stage)[32][kStagePitch] = reinterpret_cast<float(*)[32][kStagePitch]>(stage_mem);
+  __shared__ __attribute__((aligned(16))) float stage[32][kStagePitch];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n = lane & 31, kh = lane >> 5;
   const int64_t u0 = (int64_t)blockIdx.x * 32;
-  const int64_t c0 = (int64_t)blockIdx.y * kSimChunk;
-  const int64_t c1 = min(I, c0 + kSimChunk);
-  for (int i = tid; i < kSimChunk; i += kBlock) bitmap[i] = 0u;
-  __syncthreads();
-  if (m_rowptr) {                          // thread (user ui, part): the user's masked items inside [c0, c1)
-    const int ui = tid & 31, part = tid >> 5;
-    if (u0 + ui < B) {
-      const int64_t r = qidx ? qidx[u0 + ui] : (u0 + ui);
-      int lo = m_rowptr[r], hi = m_rowptr[r + 1];
-      const int end = hi;
-      while (lo < hi) {                    // lower bound of c0 in the sorted column list
-        const int mid = (lo + hi) >> 1;
-        if (mask_col(m_cols, m_stride, mid) < c0) lo = mid + 1;
-        else hi = mid;
-      }
-      for (int e = lo + part; e < end; e += 8) {
-        const int32_t c = mask_col(m_cols, m_stride, e);
-        if (c >= c1) break;
-        atomicOr(&bitmap[c - c0], 1u << ui);
-      }
-    }
-  }
+  const int ch_lo = (int)blockIdx.y * cpb, ch_hi = min(nparts, ch_lo + cpb);
   // A operand: my batch row (lane half kh holds k = 8q + 4kh .. +3 of every 8-chunk), zero past B
+  const int64_t ub_q = u0 + n;
+  const int64_t qrow_id = ub_q < B ? (qidx ? qidx[ub_q] : ub_q) : -1;
   float4 qf[DCH];
   {
-    const int64_t ub = u0 + n;
-    const float4* qrow = nullptr;
-    if (ub < B) qrow = reinterpret_cast<const float4*>(Q + (qidx ? qidx[ub] : ub) * d);
+    const float4* qrow = reinterpret_cast<const float4*>(Q + max(qrow_id, (int64_t)0) * d);
 #pragma unroll
-    for (int q = 0; q < DCH; ++q) qf[q] = qrow ? qrow[2 * q + kh] : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int q = 0; q < DCH; ++q) {
+      const float4 v = qrow[2 * q + kh];
+      qf[q] = qrow_id >= 0 ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
   }
   // the factors of the 16 batch rows this lane's accumulator entries belong to
   float sc[16];
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
-    const int64_t ub = u0 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-    sc[r] = (row_scale && ub < B) ? row_scale[ub] : 1.f;
+    const int64_t ub = min(u0 + (r & 3) + 8 * (r >> 2) + 4 * kh, B - 1);
+    sc[r] = row_scale ? row_scale[ub] : 1.f;
   }
-  __syncthreads();
-  float sq[16];
-#pragma unroll
-  for (int r = 0; r < 16; ++r) sq[r] = 0.f;
-  const int n_tiles = (int)((c1 - c0 + kSimTile - 1) / kSimTile);
-  auto load_items = [&](int tile, float4 (&tf)[DCH]) {
-    const int64_t j = min(c0 + (int64_t)tile * kSimTile + n, I - 1);
-    const float4* trow = reinterpret_cast<const float4*>(T + j * d);
+  float sq[INK ? 16 : 1];
+  auto tile = [&](int chunk, int t) {                      // one 32 x 32 tile of a chunk: load, MFMAs, stage
+    const int64_t j = (int64_t)chunk * kSimChunk + (int64_t)t * kSimTile + n;
+    const float4* trow = reinterpret_cast<const float4*>(T + ((MMSSL_SIM_DBG & 4) ? (int64_t)n : min(j, I - 1)) * d);
+    float4 tf[DCH];
 #pragma unroll
     for (int q = 0; q < DCH; ++q) tf[q] = trow[2 * q + kh];
-  };
-  float4 ta[DCH], tb[DCH];
-  auto do_tile = [&](int tile, const float4 (&tf)[DCH]) {
     floatx16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
     for (int q = 0; q < DCH; ++q) {
+      if (MMSSL_SIM_DBG & 1) {
+        acc[q & 15] += qf[q].x * tf[q].x + qf[q].y * tf[q].y + qf[q].z * tf[q].z + qf[q].w * tf[q].w;
+        continue;
+      }
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qf[q].x, tf[q].x, acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qf[q].y, tf[q].y, acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qf[q].z, tf[q].z, acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qf[q].w, tf[q].w, acc, 0, 0, 0);
     }
-    const int64_t j = c0 + (int64_t)tile * kSimTile + n;
-    const uint32_t word = bitmap[tile * kSimTile + n];
-    float(*st)[kStagePitch] = stage[tile >> 3];
-    const int col = (tile & 7) * kSimTile + n;
+    const uint32_t word = INK ? bitmap[t * kSimTile + n] : 0u;
+    const int col = t * kSimTile + n;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int m = (r & 3) + 8 * (r >> 2) + 4 * kh;
-      const bool masked = (word >> m) & 1u;
+      const bool masked = INK && ((word >> m) & 1u);
       const float v = masked ? mask_value : acc[r] * sc[r];
-      st[m][col] = j < I ? v : 0.f;                       // (columns past I: the zero padding of a pitched row)
-      if (!masked && u0 + m < B && j < I) sq[r] = fmaf(v, v, sq[r]);
+      stage[m][col] = j < I ? v : 0.f;                    // (columns past I: the zero padding of a pitched row)
+      if (INK && !masked && u0 + m < B && j < I) sq[INK ? r : 0] = fmaf(v, v, sq[INK ? r : 0]);
     }
   };
-  // tiles wave, wave + 4 (group 0) and wave + 8, wave + 12 (group 1): the loads run one tile ahead
-  if (wave < n_tiles) load_items(wave, ta);
-  if (wave + 4 < n_tiles) load_items(wave + 4, tb);
-  if (wave < n_tiles) do_tile(wave, ta);
-  if (wave + 8 < n_tiles) load_items(wave + 8, ta);
-  if (wave + 4 < n_tiles) do_tile(wave + 4, tb);
-  if (wave + 12 < n_tiles) load_items(wave + 12, tb);
-  // write-out of a group: wave w owns rows 8w .. 8w + 7, one row = one instruction per 256 items
-  const bool vec_ok = ((ldo & 3) == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
-  auto flush = [&](int g) {
-    const int64_t cg = c0 + (int64_t)g * kSimGroup;
-    if (cg >= ldo) return;
+  for (int chunk = ch_lo; chunk < ch_hi; ++chunk) {
+    const int64_t c0 = (int64_t)chunk * kSimChunk;
+    if (INK) {
+      const int64_t c1 = min(I, c0 + kSimChunk);
 #pragma unroll
-    for (int rr = 0; rr < 8; ++rr) {
-      const int m = 8 * wave + rr;
-      if (u0 + m >= B) continue;
-      float* __restrict__ orow = out + (u0 + m) * ldo + cg;
-      if (vec_ok) {
-        const int64_t c = cg + 4 * lane;
-        const float4 v = *reinterpret_cast<const float4*>(&stage[g][m][4 * lane]);
-        if (c + 3 < ldo) *reinterpret_cast<float4*>(orow + 4 * lane) = v;
-        else {
-          if (c < ldo) orow[4 * lane] = v.x;
-          if (c + 1 < ldo) orow[4 * lane + 1] = v.y;
-          if (c + 2 < ldo) orow[4 * lane + 2] = v.z;
+      for (int r = 0; r < 16; ++r) sq[INK ? r : 0] = 0.f;
+      for (int i = tid; i < kSimChunk; i += kBlock) bitmap[i] = 0u;
+      __syncthreads();
+      if (m_rowptr) {                      // thread (user ui, part): the user's masked items inside [c0, c1)
+        const int ui = tid & 31, part = tid >> 5;
+        if (u0 + ui < B) {
+          const int64_t r = qidx ? qidx[u0 + ui] : (u0 + ui);
+          int lo = m_rowptr[r], hi = m_rowptr[r + 1];
+          const int end = hi;
+          while (lo < hi) {                // lower bound of c0 in the sorted column list
+            const int mid = (lo + hi) >> 1;
+            if (mask_col(m_cols, m_stride, mid) < c0) lo = mid + 1;
+            else hi = mid;
+          }
+          for (int e = lo + part; e < end; e += 8) {
+            const int32_t c = mask_col(m_cols, m_stride, e);
+            if (c >= c1) break;
+            atomicOr(&bitmap[c - c0], 1u << ui);
+          }
         }
-      } else {
+      }
+      __syncthreads();
+    }
+    tile(chunk, wave);
+    tile(chunk, wave + 4);
+    __syncthreads();
+    // wave w writes rows 8w .. 8w + 7, one row = one instruction; a row past B or a column past ldo is stored as a duplicate
+    // of the last valid one (same data, read from the same clamped LDS slot): no branches around the stores
+    if (!(MMSSL_SIM_DBG & 2) || stage[0][0] == 12345.f) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
-          if (cg + lane + 64 * k < ldo) orow[lane + 64 * k] = stage[g][m][lane + 64 * k];
+      for (int rr = 0; rr < 8; ++rr) {
+        const int m = (int)(min(u0 + 8 * wave + rr, B - 1) - u0);
+        float* __restrict__ orow = out + (u0 + m) * ldo;
+        if (VEC) {                         // host-checked: ldo % 4 == 0, out 16-byte aligned
+          const int64_t c = min(c0 + 4 * lane, ldo - 4);
+          *reinterpret_cast<float4*>(orow + c) = *reinterpret_cast<const float4*>(&stage[m][c - c0]);
+        } else {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const int64_t c = min(c0 + lane + 64 * k, ldo - 1);
+            orow[c] = stage[m][c - c0];
+          }
+        }
       }
     }
-  };
-  __syncthreads();                         // group 0 is staged (tiles 0 .. 7; absent tiles left their slots untouched:
-  flush(0);                                // those columns are >= I rounded up to the tile, never inside ldo)
-  if (wave + 8 < n_tiles) do_tile(wave + 8, ta);
-  if (wave + 12 < n_tiles) do_tile(wave + 12, tb);
-  __syncthreads();
-  flush(1);
-  if (sumsq_part) {
+    if (INK && sumsq_part) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      float v = sq[r];
+      for (int r = 0; r < 16; ++r) {
+        float v = sq[INK ? r : 0];
 #pragma unroll
-      for (int mk = 1; mk < 32; mk <<= 1) v += __shfl_xor(v, mk, kWave);
-      if (n == 0) red[wave][(r & 3) + 8 * (r >> 2) + 4 * kh] = v;
+        for (int mk = 1; mk < 32; mk <<= 1) v += __shfl_xor(v, mk, kWave);
+        if (n == 0) red[wave][(r & 3) + 8 * (r >> 2) + 4 * kh] = v;
+      }
+      __syncthreads();
+      if (tid < 32 && u0 + tid < B)
+        sumsq_part[(u0 + tid) * nparts + chunk] = ((red[0][tid] + red[1][tid]) + red[2][tid]) + red[3][tid];
     }
-    __syncthreads();
-    if (tid < 32 && u0 + tid < B)
-      sumsq_part[(u0 + tid) * nparts + blockIdx.y] = ((red[0][tid] + red[1][tid]) + red[2][tid]) + red[3][tid];
+    __syncthreads();                       // the stage (and `red`) are free for the next chunk
+  }
+}
+
+// out[b, c] = value for every column c of CSR row qidx[b] of the mask: the masked entries of the score matrix, written
+// after the tile kernel (one wave per batch row, its lanes over the row's entries: a 2 000-item user takes 32 steps)
+__global__ __launch_bounds__(kBlock) void mask_scatter_kernel(const int64_t* __restrict__ qidx, int64_t B,
+                                                              const int32_t* __restrict__ m_rowptr,
+                                                              const void* __restrict__ m_cols, int m_stride, int64_t I,
+                                                              float value, float* __restrict__ out, int64_t ldo) {
+  const int lane = threadIdx.x & 63;
+  const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= B) return;
+  const int64_t r = qidx ? qidx[b] : b;
+  const int lo = m_rowptr[r], hi = m_rowptr[r + 1];
+  for (int e = lo + lane; e < hi; e += 64) {
+    const int32_t c = mask_col(m_cols, m_stride, e);
+    if (c >= 0 && c < I) out[b * ldo + c] = value;
   }
 }
 
@@ -192,20 +212,15 @@ __global__ __launch_bounds__(kBlock) void sim_tiles_kernel(const float* __restri
 // (main.py:297 F.normalize(dim=1): x / max(|x|, eps)).
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int kGramTileFloats = 12288;      // 48 KB of item rows per block: 192 rows at d = 64
-constexpr int kGramGroup = 8;               // blocks per first-level sum
 __host__ __device__ constexpr int gram_rows(int d) { return kGramTileFloats / d; }
 
 // Block b owns item rows [b * R, (b + 1) * R): staged in LDS with coalesced loads (one memory latency per block), then
 // every wave accumulates output tiles G[32 ti .. , 32 tj ..] += rows^T rows on v_mfma_f32_32x32x2_f32 (two rows per
-// instruction). The block partials are added in a FIXED order by whoever finishes last: per group of eight blocks into
-// a float64 group sum, then the group sums into G - two levels so that no block sums more than a few dozen images.
+// instruction) and leaves them as the block's fp32 partial image.
 template <int DT>                           // DT = d / 32 tiles per side
-__global__ __launch_bounds__(kBlock) void usim_gram_kernel(const float* __restrict__ T, int64_t I, float* __restrict__ part,
-                                                           double* __restrict__ part2, double* __restrict__ G,
-                                                           uint32_t* __restrict__ ticket) {
+__global__ __launch_bounds__(kBlock) void usim_gram_kernel(const float* __restrict__ T, int64_t I, float* __restrict__ part) {
   constexpr int d = DT * 32, R = gram_rows(d);
   __shared__ __attribute__((aligned(16))) float tile[kGramTileFloats];
-  __shared__ int last;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n = lane & 31, kh = lane >> 5;
   const int64_t r0 = (int64_t)blockIdx.x * R;
@@ -214,6 +229,7 @@ __global__ __launch_bounds__(kBlock) void usim_gram_kernel(const float* __restri
     const float4* src = reinterpret_cast<const float4*>(T + r0 * d);
     float4* dst = reinterpret_cast<float4*>(tile);
     const int n4 = rows * d / 4;
+#pragma unroll 4
     for (int i = tid; i < R * d / 4; i += kBlock) dst[i] = i < n4 ? src[i] : make_float4(0.f, 0.f, 0.f, 0.f);
   }
   __syncthreads();
@@ -233,79 +249,79 @@ __global__ __launch_bounds__(kBlock) void usim_gram_kernel(const float* __restri
       mine[(32 * ti + m) * d + 32 * tj + n] = acc[r];
     }
   }
-  const int nb = (int)gridDim.x, ng = (nb + kGramGroup - 1) / kGramGroup, g = (int)blockIdx.x / kGramGroup;
-  const int g_lo = g * kGramGroup, g_n = min(kGramGroup, nb - g_lo);
-  __threadfence();
-  __syncthreads();
-  if (tid == 0) last = (atomicAdd(ticket + 1 + g, 1u) == (unsigned)g_n - 1) ? 1 : 0;
-  __syncthreads();
-  if (!last) return;
-  __threadfence();
-  for (int e = tid; e < d * d; e += kBlock) {
-    double s = 0.0;
-    for (int k = 0; k < g_n; ++k) s += (double)__builtin_nontemporal_load(part + (size_t)(g_lo + k) * d * d + e);
-    part2[(size_t)g * d * d + e] = s;
-  }
-  __threadfence();
-  __syncthreads();
-  if (tid == 0) {
-    ticket[1 + g] = 0u;
-    last = (atomicAdd(ticket, 1u) == (unsigned)ng - 1) ? 1 : 0;
-  }
-  __syncthreads();
-  if (!last) return;
-  __threadfence();
-  for (int e = tid; e < d * d; e += kBlock) {
-    double s = 0.0;
-    for (int k = 0; k < ng; ++k) s += __builtin_nontemporal_load(part2 + (size_t)k * d * d + e);
-    G[e] = s;
-  }
-  if (tid == 0) ticket[0] = 0u;
 }
 
-// one wave per batch row: inv[b] = 1 / max(sqrt(q^T G q - masked part), eps)
-template <int DL>                           // DL = ceil(d / 64) columns per lane
+// G[e] = sum over the nb block images, in float64 and in a FIXED order: thread (e, p) adds images p, p + 4, ... (its loads
+// issued eight at a time), the four partial sums of an element meet in LDS in order p = 0 .. 3. 64 elements per block.
+__global__ __launch_bounds__(kBlock) void usim_gram_reduce_kernel(const float* __restrict__ part, int nb, int dd,
+                                                                  double* __restrict__ G) {
+  __shared__ double red[4][64];
+  const int el = threadIdx.x & 63, p = threadIdx.x >> 6;
+  const int e = (int)blockIdx.x * 64 + el;
+  double s = 0.0;
+  if (e < dd) {
+    int k = p;
+    for (; k + 28 < nb; k += 32) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = part[(size_t)(k + 4 * u) * dd + e];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += (double)v[u];
+    }
+    for (; k < nb; k += 4) s += (double)part[(size_t)k * dd + e];
+  }
+  red[p][el] = s;
+  __syncthreads();
+  if (p == 0 && e < dd) G[e] = ((red[0][el] + red[1][el]) + red[2][el]) + red[3][el];
+}
+
+// one BLOCK per batch row: inv[b] = 1 / max(sqrt(q^T G q - sum over the row's masked items of (q . t_j)^2), eps), float64.
+// Thread (c, p) forms the part of (G q)[c] over rows a = p, p + 4, ...; the masked items go one per thread, 256 at a time
+// (a user with 2 000 train items takes 8 steps, not 2 000).
 __global__ __launch_bounds__(kBlock) void usim_norms_kernel(const float* __restrict__ Q, const int64_t* __restrict__ qidx,
                                                             int64_t B, const float* __restrict__ T, int d,
                                                             const double* __restrict__ G,
                                                             const int32_t* __restrict__ m_rowptr,
                                                             const void* __restrict__ m_cols, int m_stride, float eps,
                                                             float* __restrict__ inv_out) {
-  __shared__ float qs[4][256];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int64_t b = (int64_t)blockIdx.x * 4 + wave;
-  if (b >= B) return;
+  __shared__ float qs[128];
+  __shared__ double red[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t b = blockIdx.x;
   const int64_t r = qidx ? qidx[b] : b;
   const float* __restrict__ q = Q + r * d;
-  for (int c = lane; c < d; c += 64) qs[wave][c] = q[c];
-  __builtin_amdgcn_wave_barrier();
+  if (tid < d) qs[tid] = q[tid];
+  __syncthreads();
   double s = 0.0;
-#pragma unroll
-  for (int k = 0; k < DL; ++k) {
-    const int c = lane + 64 * k;
-    if (c < d) {
-      double y = 0.0;
-      for (int a = 0; a < d; ++a) y += (double)qs[wave][a] * G[(size_t)a * d + c];
-      s += y * (double)qs[wave][c];
-    }
+  // q^T G q = sum_c q[c] * sum_a q[a] G[a][c]: thread (c = tid % d, p = tid / d) takes rows a = p, p + 256 / d, ...
+  {
+    const int c = tid % d, p = tid / d, step = kBlock / d;             // d in {32, 64, 128}: step 8 / 4 / 2
+    double y = 0.0;
+    for (int a = p; a < d; a += step) y += (double)qs[a] * G[(size_t)a * d + c];
+    s = y * (double)qs[c];
   }
   if (m_rowptr) {
-    for (int e = m_rowptr[r]; e < m_rowptr[r + 1]; ++e) {
-      const float* __restrict__ t = T + (int64_t)mask_col(m_cols, m_stride, e) * d;
-      float p = 0.f;
-#pragma unroll
-      for (int k = 0; k < DL; ++k) {
-        const int c = lane + 64 * k;
-        if (c < d) p = fmaf(qs[wave][c], t[c], p);
+    const int lo = m_rowptr[r], hi = m_rowptr[r + 1];
+    for (int e = lo + tid; e < hi; e += kBlock) {
+      const float4* __restrict__ t = reinterpret_cast<const float4*>(T + (int64_t)mask_col(m_cols, m_stride, e) * d);
+      float pa = 0.f, pb = 0.f;
+      for (int k = 0; k < d / 4; k += 2) {
+        const float4 x = t[k], y2 = t[k + 1];
+        pa = fmaf(qs[4 * k], x.x, fmaf(qs[4 * k + 1], x.y, fmaf(qs[4 * k + 2], x.z, fmaf(qs[4 * k + 3], x.w, pa))));
+        pb = fmaf(qs[4 * k + 4], y2.x, fmaf(qs[4 * k + 5], y2.y, fmaf(qs[4 * k + 6], y2.z, fmaf(qs[4 * k + 7], y2.w, pb))));
       }
-#pragma unroll
-      for (int mk = 1; mk < 64; mk <<= 1) p += __shfl_xor(p, mk, kWave);
-      if (lane == 0) s -= (double)p * (double)p;
+      const double pp = (double)(pa + pb);
+      s -= pp * pp;
     }
   }
 #pragma unroll
   for (int mk = 1; mk < 64; mk <<= 1) s += __shfl_xor(s, mk, kWave);
-  if (lane == 0) inv_out[b] = 1.f / fmaxf(sqrtf((float)fmax(s, 0.0)), eps);
+  if (lane == 0) red[wave] = s;
+  __syncthreads();
+  if (tid == 0) {
+    const double tot = (red[0] + red[1]) + (red[2] + red[3]);
+    inv_out[b] = 1.f / fmaxf(sqrtf((float)fmax(tot, 0.0)), eps);
+  }
 }
 
 // X[b, :] *= 1 / max(sqrt(sum of the row's partials), eps)   (F.normalize(dim=1), main.py:297); inv_out[b] gets the factor
@@ -359,70 +375,114 @@ __global__ __launch_bounds__(kBlock) void topk_rows_kernel(const float* __restri
   const int64_t b = blockIdx.x;
   const float* __restrict__ row = X + b * ldx;
   uint32_t key[CT];
+  // every load unconditional (a clamped address, the padding decided afterwards): a load under `if (j < I)` becomes a
+  // branch of its own with a full wait behind it - 72 memory latencies one after the other
+  float raw[CT];
 #pragma unroll
-  for (int i = 0; i < CT; ++i) {
-    const int64_t j = tid + (int64_t)kBlock * i;
-    key[i] = j < I ? order_key(row[j]) : 0u;               // 0 sorts below every real value (-inf included)
-  }
+  for (int i = 0; i < CT; ++i) raw[i] = row[min((int64_t)tid + (int64_t)kBlock * i, I - 1)];
+#pragma unroll
+  for (int i = 0; i < CT; ++i)
+    key[i] = (tid + (int64_t)kBlock * i) < I ? order_key(raw[i]) : 0u;      // 0 sorts below every real value (-inf included)
   if (tid < kTopkMaxK) { win_key[tid] = 0u; win_idx[tid] = 0x7fffffff; }
   if (tid == 0) slots = 0;
   const int Ke = (int)min((int64_t)K, I);
   int phase = 0;
-  auto block_count = [&](int c) {                          // every thread gets the block's total; one barrier per call
-#pragma unroll
-    for (int m = 1; m < 64; m <<= 1) c += __shfl_xor(c, m, kWave);
+  // block total of per-WAVE counts (every lane of a wave passes the same value): four LDS words and one barrier
+  auto block_total = [&](int c) {
     if (lane == 0) red[phase][wave] = c;
     __syncthreads();
     const int t = (red[phase][0] + red[phase][1]) + (red[phase][2] + red[phase][3]);
     phase ^= 1;
     return t;
   };
-  // K-th largest key: the largest t with #{keys >= t} >= Ke, one bit at a time
-  uint32_t tau = 0u;
+  // Candidates first. The Ke-th largest of the 256 THREAD MAXIMA is a lower bound of the row's Ke-th largest key (Ke
+  // different entries are at least that large), so every winner is >= t0 - and for scores without long runs of ties only
+  // a few more than Ke entries are (about Ke (1 + CT Ke / I)). Bisection over ONE value per thread is 32 x (compare,
+  // popcount, barrier); the full bisection below costs CT compares per step and is only run when more than 256 entries
+  // reach t0 (ties: rows that are mostly -inf, constant rows).
+  uint32_t kmax = 0u;
+#pragma unroll
+  for (int i = 0; i < CT; ++i) kmax = max(kmax, key[i]);
+  uint32_t t0 = 0u;
   for (int bit = 31; bit >= 0; --bit) {
-    const uint32_t cand = tau | (1u << bit);
-    int c = 0;
-#pragma unroll
-    for (int i = 0; i < CT; ++i) c += key[i] >= cand ? 1 : 0;
-    if (block_count(c) >= Ke) tau = cand;
+    const uint32_t cand = t0 | (1u << bit);
+    if (block_total(__builtin_popcountll(__ballot(kmax >= cand))) >= Ke) t0 = cand;
   }
-  int gt = 0, eq = 0;
+  int mine = 0;
 #pragma unroll
-  for (int i = 0; i < CT; ++i) {
-    gt += key[i] > tau ? 1 : 0;
-    eq += key[i] == tau ? 1 : 0;
-  }
-  const int n_gt = block_count(gt), n_eq = block_count(eq);
-  const int need_eq = Ke - n_gt;                           // >= 1 entries equal to tau are winners: those of smallest id
-  // the id below which an entry equal to tau is a winner (all of them unless the tie is cut: then the need_eq-th
-  // smallest id among them, found by the same bisection over the 16-bit ids)
-  int64_t id_cut = (int64_t)1 << 40;
-  if (n_eq > need_eq) {
-    uint32_t lim = 0u;                                     // largest L with #{eq entries with id < L} < need_eq ... as bits
-    for (int bit = 16; bit >= 0; --bit) {
-      const uint32_t cand = lim | (1u << bit);
-      int c = 0;
+  for (int i = 0; i < CT; ++i) mine += key[i] >= t0 ? 1 : 0;
 #pragma unroll
-      for (int i = 0; i < CT; ++i) c += (key[i] == tau && (uint32_t)(tid + kBlock * i) < cand) ? 1 : 0;
-      if (block_count(c) < need_eq) lim = cand;            // fewer than need_eq ids below cand: cand is still too small
-    }
-    id_cut = (int64_t)lim + 1;                             // ids <= lim: exactly need_eq entries
-  }
+  for (int m = 1; m < 64; m <<= 1) mine += __shfl_xor(mine, m, kWave);
+  const int n_cand = block_total(mine);
+  int n_win = Ke;                          // entries of win_key / win_idx to sort; the first Ke of the sorted list are the answer
+  if (n_cand <= kTopkMaxK) {
 #pragma unroll
-  for (int i = 0; i < CT; ++i) {
-    const int64_t j = tid + (int64_t)kBlock * i;
-    if (j < I && (key[i] > tau || (key[i] == tau && j < id_cut))) {
-      const int p = atomicAdd(&slots, 1);                  // (the winners are sorted below: their slot order is free)
-      if (p < kTopkMaxK) {
+    for (int i = 0; i < CT; ++i) {
+      const int64_t j = tid + (int64_t)kBlock * i;
+      if (j < I && key[i] >= t0) {
+        const int p = atomicAdd(&slots, 1);
         win_key[p] = key[i];
         win_idx[p] = (int32_t)j;
       }
     }
+    n_win = n_cand;
+  } else {
+    // K-th largest key: the largest t with #{keys >= t} >= Ke, one bit at a time
+    uint32_t tau = 0u;
+    for (int bit = 31; bit >= 0; --bit) {
+      const uint32_t cand = tau | (1u << bit);
+      int c = 0;
+#pragma unroll
+      for (int i = 0; i < CT; ++i) c += key[i] >= cand ? 1 : 0;
+#pragma unroll
+      for (int m = 1; m < 64; m <<= 1) c += __shfl_xor(c, m, kWave);
+      if (block_total(c) >= Ke) tau = cand;
+    }
+    int gt = 0, eq = 0;
+#pragma unroll
+    for (int i = 0; i < CT; ++i) {
+      gt += key[i] > tau ? 1 : 0;
+      eq += key[i] == tau ? 1 : 0;
+    }
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) {
+      gt += __shfl_xor(gt, m, kWave);
+      eq += __shfl_xor(eq, m, kWave);
+    }
+    const int n_gt = block_total(gt), n_eq = block_total(eq);
+    const int need_eq = Ke - n_gt;                         // >= 1 entries equal to tau are winners: those of smallest id
+    // the id below which an entry equal to tau is a winner (all of them unless the tie is cut: then the need_eq-th
+    // smallest id among them, found by the same bisection over the ids)
+    int64_t id_cut = (int64_t)1 << 40;
+    if (n_eq > need_eq) {
+      uint32_t lim = 0u;
+      for (int bit = 16; bit >= 0; --bit) {
+        const uint32_t cand = lim | (1u << bit);
+        int c = 0;
+#pragma unroll
+        for (int i = 0; i < CT; ++i) c += (key[i] == tau && (uint32_t)(tid + kBlock * i) < cand) ? 1 : 0;
+#pragma unroll
+        for (int m = 1; m < 64; m <<= 1) c += __shfl_xor(c, m, kWave);
+        if (block_total(c) < need_eq) lim = cand;          // fewer than need_eq ids below cand: cand is still too small
+      }
+      id_cut = (int64_t)lim + 1;                           // ids <= lim: exactly need_eq entries
+    }
+#pragma unroll
+    for (int i = 0; i < CT; ++i) {
+      const int64_t j = tid + (int64_t)kBlock * i;
+      if (j < I && (key[i] > tau || (key[i] == tau && j < id_cut))) {
+        const int p = atomicAdd(&slots, 1);                // (the winners are sorted below: their slot order is free)
+        if (p < kTopkMaxK) {
+          win_key[p] = key[i];
+          win_idx[p] = (int32_t)j;
+        }
+      }
+    }
   }
   __syncthreads();
-  if (K > 64) {                             // block-uniform: up to 256 winners, bitonic network through LDS
-    uint32_t k = tid < Ke ? win_key[tid] : 0u;
-    int32_t id = tid < Ke ? win_idx[tid] : 0x7fffffff;
+  if (n_win > 64) {                         // block-uniform: up to 256 candidates, bitonic network through LDS
+    uint32_t k = tid < n_win ? win_key[tid] : 0u;
+    int32_t id = tid < n_win ? win_idx[tid] : 0x7fffffff;
     for (int size = 2; size <= kBlock; size <<= 1) {
       for (int stride = size >> 1; stride > 0; stride >>= 1) {
         __syncthreads();
@@ -450,7 +510,7 @@ __global__ __launch_bounds__(kBlock) void topk_rows_kernel(const float* __restri
   if (tid < 64) {                           // one wave sorts the <= 64 winners: key descending, id ascending
     uint32_t k = win_key[tid];
     int32_t id = win_idx[tid];
-    const bool valid = tid < Ke;
+    const bool valid = tid < n_win;
     if (!valid) { k = 0u; id = 0x7fffffff; }
     // "a before b"  <=>  ka > kb or (ka == kb and ia < ib); bitonic network over 64 lanes
     for (int size = 2; size <= 64; size <<= 1) {
@@ -467,10 +527,11 @@ __global__ __launch_bounds__(kBlock) void topk_rows_kernel(const float* __restri
     if (tid < Ke) {
       idx_out[b * K + tid] = id;
       if (val_out) val_out[b * K + tid] = key_value(k);
-    } else if (tid < K) {
-      idx_out[b * K + tid] = -1;
-      if (val_out) val_out[b * K + tid] = 0.f;
     }
+  }
+  if (tid >= Ke && tid < K) {               // a row shorter than K: padding
+    idx_out[b * K + tid] = -1;
+    if (val_out) val_out[b * K + tid] = 0.f;
   }
 }
 
@@ -513,57 +574,75 @@ __global__ __launch_bounds__(kBlock) void eval_metrics_kernel(const int32_t* __r
                                                               const int64_t* __restrict__ cand, EvalKs ks,
                                                               double* __restrict__ part, double* __restrict__ acc,
                                                               uint32_t* __restrict__ ticket) {
+  // one WAVE per user: lane k looks candidate k (and k + 64, ...) up in the user's positives - 64 bisections side by
+  // side instead of K one after the other - and the per-K sums come from popcounts / in-order lane sums of the hit mask
   __shared__ double red[4][4 * kEvalMaxKs];
+  __shared__ double disc[kTopkMaxK + 1], cum[kTopkMaxK + 1];
   __shared__ int last;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int64_t b = (int64_t)blockIdx.x * kBlock + tid;
+  for (int k = tid; k <= K; k += kBlock) disc[k] = 1.0 / log2((double)(k + 2));
+  __syncthreads();
+  for (int k = tid; k <= K; k += kBlock) {               // cum[t] = ideal DCG of t hits = disc[0] + ... + disc[t - 1], in order
+    double c = 0.0;
+    for (int j = 0; j < k; ++j) c += disc[j];
+    cum[k] = c;
+  }
+  __syncthreads();
   double v[4 * kEvalMaxKs];
 #pragma unroll
   for (int i = 0; i < 4 * kEvalMaxKs; ++i) v[i] = 0.0;
-  if (b < B) {
+  // users of this wave: b = (4 blockIdx + wave) + 4 gridDim * t, in that order
+  for (int64_t b = (int64_t)blockIdx.x * 4 + wave; b < B; b += (int64_t)gridDim.x * 4) {
     const int64_t r = rows[b];
     const int lo0 = rowptr[r], hi0 = rowptr[r + 1];
     const double n_pos = (double)(hi0 - lo0);
-    int tot = 0;                                   // hits within K_max: the ideal list's ones (metrics.ndcg_at_k)
-    int s[kEvalMaxKs];
+    int tot = 0, s[kEvalMaxKs];
     double dcg[kEvalMaxKs];
 #pragma unroll
     for (int i = 0; i < kEvalMaxKs; ++i) { s[i] = 0; dcg[i] = 0.0; }
-    for (int k = 0; k < K; ++k) {
-      const int64_t c = cand[b * K + k];
-      int lo = lo0, hi = hi0;
-      while (lo < hi) {
-        const int mid = (lo + hi) >> 1;
-        if (cols[mid] < c) lo = mid + 1;
-        else hi = mid;
+    for (int k0 = 0; k0 < K; k0 += 64) {
+      const int k = k0 + lane;
+      bool hit = false;
+      if (k < K) {
+        const int64_t c = cand[b * K + k];
+        int lo = lo0, hi = hi0;
+        while (lo < hi) {
+          const int mid = (lo + hi) >> 1;
+          if (cols[mid] < c) lo = mid + 1;
+          else hi = mid;
+        }
+        hit = c >= 0 && lo < hi0 && cols[lo] == c;
       }
-      if (c >= 0 && lo < hi0 && cols[lo] == c) {
-        ++tot;
-        const double w = 1.0 / log2((double)(k + 2));
+      const uint64_t mask = __ballot(hit);
+      tot += __builtin_popcountll(mask);
 #pragma unroll
-        for (int i = 0; i < kEvalMaxKs; ++i)
-          if (i < ks.n && k < ks.k[i]) { ++s[i]; dcg[i] += w; }
+      for (int i = 0; i < kEvalMaxKs; ++i) {
+        if (i >= ks.n || ks.k[i] <= k0) continue;
+        const int upto = ks.k[i] - k0;                                 // ranks k0 .. k0 + upto - 1 count for this K
+        uint64_t m = upto >= 64 ? mask : (mask & ((1ull << upto) - 1ull));
+        s[i] += __builtin_popcountll(m);
+        while (m) {                                                    // ascending rank: a fixed order
+          const int j = __builtin_ctzll(m);
+          dcg[i] += disc[k0 + j];
+          m &= m - 1;
+        }
       }
     }
 #pragma unroll
     for (int i = 0; i < kEvalMaxKs; ++i) {
       if (i >= ks.n) continue;
       const int Kc = ks.k[i];
-      double best = 0.0;
-      for (int k = 0; k < min(tot, Kc); ++k) best += 1.0 / log2((double)(k + 2));
-      v[0 * kEvalMaxKs + i] = (double)s[i] / (double)Kc;
-      v[1 * kEvalMaxKs + i] = n_pos > 0.0 ? (double)s[i] / n_pos : 0.0;
-      v[2 * kEvalMaxKs + i] = best > 0.0 ? dcg[i] / best : 0.0;
-      v[3 * kEvalMaxKs + i] = s[i] > 0 ? 1.0 : 0.0;
+      const double best = cum[min(tot, Kc)];
+      v[0 * kEvalMaxKs + i] += (double)s[i] / (double)Kc;
+      v[1 * kEvalMaxKs + i] += n_pos > 0.0 ? (double)s[i] / n_pos : 0.0;
+      v[2 * kEvalMaxKs + i] += best > 0.0 ? dcg[i] / best : 0.0;
+      v[3 * kEvalMaxKs + i] += s[i] > 0 ? 1.0 : 0.0;
     }
   }
-  // thread order inside a wave (shuffle tree: fixed), wave order inside the block, block order across the launch
+  // every lane of a wave holds the same sums; wave order inside the block, block order across the launch
+  if (lane == 0) {
 #pragma unroll
-  for (int i = 0; i < 4 * kEvalMaxKs; ++i) {
-    double x = v[i];
-#pragma unroll
-    for (int m = 1; m < 64; m <<= 1) x += __shfl_xor(x, m, kWave);
-    if (lane == 0) red[wave][i] = x;
+    for (int i = 0; i < 4 * kEvalMaxKs; ++i) red[wave][i] = v[i];
   }
   __syncthreads();
   if (tid < 4 * kEvalMaxKs)
@@ -574,10 +653,19 @@ __global__ __launch_bounds__(kBlock) void eval_metrics_kernel(const int32_t* __r
   __syncthreads();
   if (!last) return;
   __threadfence();
-  if (tid < 4 * kEvalMaxKs) {
-    double x = acc[tid];
-    for (unsigned k = 0; k < gridDim.x; ++k) x += __builtin_nontemporal_load(part + (size_t)k * 4 * kEvalMaxKs + tid);
-    acc[tid] = x;
+  {   // the blocks' images in block order: thread (i, p) adds images p, p + 8, ..., the eight partial sums meet in order
+    __shared__ double fin[8][4 * kEvalMaxKs];
+    const int i = tid & 31, p = tid >> 5;
+    double x = 0.0;
+    for (unsigned k = p; k < gridDim.x; k += 8) x += __builtin_nontemporal_load(part + (size_t)k * 4 * kEvalMaxKs + i);
+    fin[p][i] = x;
+    __syncthreads();
+    if (tid < 4 * kEvalMaxKs) {
+      double t = acc[tid];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) t += fin[q][tid];
+      acc[tid] = t;
+    }
   }
   if (tid == 0) *ticket = 0u;
 }
@@ -681,15 +769,26 @@ int sim_launch(const float* Q, const int64_t* qidx, int64_t B, const float* T, i
                const void* m_cols, int m_stride, float mask_value, const float* row_scale, float* out, int64_t ldo,
                float* sumsq_part, hipStream_t s) {
   const int nparts = (int)((I + kSimChunk - 1) / kSimChunk);
-  const dim3 grid((unsigned)((B + 31) / 32), (unsigned)nparts);
-  constexpr size_t stage_bytes = 2 * 32 * kStagePitch * sizeof(float);
-#define SIM_CASE(DCH)                                                                                                   \
-  {                                                                                                                     \
-    static const int attr = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(sim_tiles_kernel<DCH>),              \
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)stage_bytes);     \
-    if (attr != 0) return MMSSL_E_UNSUPP;                                                                               \
-    hipLaunchKernelGGL((sim_tiles_kernel<DCH>), grid, dim3(kBlock), stage_bytes, s, Q, qidx, B, T, I, m_rowptr, m_cols, \
-                       m_stride, mask_value, row_scale, out, ldo, sumsq_part, nparts);                                   \
+  // chunks per block: about three resident blocks per CU in ONE round (768 on this part), each amortising its row gather
+  const int64_t ub = (B + 31) / 32;
+  int cpb = (int)((ub * nparts + 767) / 768);
+  cpb = cpb < 1 ? 1 : (cpb > nparts ? nparts : cpb);
+  const dim3 grid((unsigned)ub, (unsigned)((nparts + cpb - 1) / cpb));
+  const dim3 grid_wide((unsigned)ub, (unsigned)nparts);
+  // the partial-sums API needs the mask inside the tile kernel (sums over the UNMASKED scores); every other call runs the
+  // bitmap-free kernel and overwrites the masked entries afterwards
+  const bool ink = sumsq_part != nullptr && m_rowptr != nullptr;
+  const bool vec = ((ldo & 3) == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0) && ldo >= 4;
+#define SIM_LAUNCH(DCH, INK, VEC)                                                                                        \
+  hipLaunchKernelGGL((sim_tiles_kernel<DCH, INK, VEC>), grid, dim3(kBlock), 0, s, Q, qidx, B, T, I, m_rowptr, m_cols,    \
+                     m_stride, mask_value, row_scale, out, ldo, sumsq_part, nparts, cpb)
+#define SIM_CASE(DCH)                                                                                                    \
+  if (ink || sumsq_part) {                                                                                               \
+    if (vec) SIM_LAUNCH(DCH, true, true);                                                                                \
+    else SIM_LAUNCH(DCH, true, false);                                                                                   \
+  } else {                                                                                                               \
+    if (vec) SIM_LAUNCH(DCH, false, true);                                                                               \
+    else SIM_LAUNCH(DCH, false, false);                                                                                  \
   }
   switch (d) {
     case 32: SIM_CASE(4); break;
@@ -697,13 +796,19 @@ int sim_launch(const float* Q, const int64_t* qidx, int64_t B, const float* T, i
     case 128: SIM_CASE(16); break;
     case 256:
       if (row_scale) return MMSSL_E_UNSUPP;        // (d = 256 keeps the partial-sums + scale-pass form)
-      hipLaunchKernelGGL(sim_tiles_wide_kernel, grid, dim3(kBlock), 0, s, Q, qidx, B, T, I, m_rowptr, m_cols, m_stride,
+      hipLaunchKernelGGL(sim_tiles_wide_kernel, grid_wide, dim3(kBlock), 0, s, Q, qidx, B, T, I, m_rowptr, m_cols, m_stride,
                          mask_value, out, ldo, sumsq_part, nparts);
       break;
     default: return MMSSL_E_UNSUPP;
   }
 #undef SIM_CASE
+#undef SIM_LAUNCH
   MMSSL_LAUNCH_CHECK();
+  if (d != 256 && !sumsq_part && m_rowptr) {
+    hipLaunchKernelGGL(mask_scatter_kernel, dim3((unsigned)((B + 3) / 4)), dim3(kBlock), 0, s, qidx, B, m_rowptr, m_cols,
+                       m_stride, I, mask_value, out, ldo);
+    MMSSL_LAUNCH_CHECK();
+  }
   return 0;
 }
 
@@ -712,22 +817,16 @@ int sim_launch(const float* Q, const int64_t* qidx, int64_t B, const float* T, i
 namespace {
 struct GramWs {
   float* part;
-  double *part2, *G;
-  uint32_t* ticket;
-  int nb, ng;
+  double* G;
+  int nb;
   size_t bytes;
 };
 inline GramWs gram_ws(void* ws, int64_t I, int d) {
   GramWs w;
   w.nb = (int)((I + gram_rows(d) - 1) / gram_rows(d));
-  w.ng = (w.nb + kGramGroup - 1) / kGramGroup;
   char* p = reinterpret_cast<char*>(ws);
-  w.ticket = reinterpret_cast<uint32_t*>(p);
-  size_t o = ((size_t)(w.ng + 1) * 4 + 255) / 256 * 256;
-  w.G = reinterpret_cast<double*>(p + o);
-  o += (size_t)d * d * 8;
-  w.part2 = reinterpret_cast<double*>(p + o);
-  o += (size_t)w.ng * d * d * 8;
+  w.G = reinterpret_cast<double*>(p);
+  size_t o = (size_t)d * d * 8;
   w.part = reinterpret_cast<float*>(p + o);
   o += (size_t)w.nb * d * d * 4;
   w.bytes = o;
@@ -740,22 +839,17 @@ int usim_norms_launch(const float* Q, const int64_t* qidx, int64_t B, const floa
                       hipStream_t s) {
   if (d != 32 && d != 64 && d != 128) return MMSSL_E_UNSUPP;
   const GramWs w = gram_ws(ws, I, d);
-  MMSSL_HIP_TRY(hipMemsetAsync(w.ticket, 0, (size_t)(w.ng + 1) * 4, s));
-  float* part = w.part;
-  double* G = w.G;
   switch (d) {
-    case 32: hipLaunchKernelGGL((usim_gram_kernel<1>), dim3(w.nb), dim3(kBlock), 0, s, T, I, part, w.part2, G, w.ticket); break;
-    case 64: hipLaunchKernelGGL((usim_gram_kernel<2>), dim3(w.nb), dim3(kBlock), 0, s, T, I, part, w.part2, G, w.ticket); break;
-    default: hipLaunchKernelGGL((usim_gram_kernel<4>), dim3(w.nb), dim3(kBlock), 0, s, T, I, part, w.part2, G, w.ticket); break;
+    case 32: hipLaunchKernelGGL((usim_gram_kernel<1>), dim3(w.nb), dim3(kBlock), 0, s, T, I, w.part); break;
+    case 64: hipLaunchKernelGGL((usim_gram_kernel<2>), dim3(w.nb), dim3(kBlock), 0, s, T, I, w.part); break;
+    default: hipLaunchKernelGGL((usim_gram_kernel<4>), dim3(w.nb), dim3(kBlock), 0, s, T, I, w.part); break;
   }
   MMSSL_LAUNCH_CHECK();
-  const dim3 grid((unsigned)((B + 3) / 4));
-  if (d <= 64)
-    hipLaunchKernelGGL((usim_norms_kernel<1>), grid, dim3(kBlock), 0, s, Q, qidx, B, T, d, G, m_rowptr, m_cols, m_stride,
-                       eps, inv_out);
-  else
-    hipLaunchKernelGGL((usim_norms_kernel<2>), grid, dim3(kBlock), 0, s, Q, qidx, B, T, d, G, m_rowptr, m_cols, m_stride,
-                       eps, inv_out);
+  hipLaunchKernelGGL(usim_gram_reduce_kernel, dim3((unsigned)((d * d + 63) / 64)), dim3(kBlock), 0, s, w.part, w.nb, d * d,
+                     w.G);
+  MMSSL_LAUNCH_CHECK();
+  hipLaunchKernelGGL(usim_norms_kernel, dim3((unsigned)B), dim3(kBlock), 0, s, Q, qidx, B, T, d, w.G, m_rowptr, m_cols,
+                     m_stride, eps, inv_out);
   MMSSL_LAUNCH_CHECK();
   return 0;
 }
@@ -823,8 +917,14 @@ extern "C" int mmssl_topk_rows_f32(const float* X, int64_t B, int64_t n_cols, in
   return 0;
 }
 
+namespace {
+inline unsigned eval_blocks(int64_t B) {          // one wave per user, at most 512 blocks (their images are summed by one)
+  const int64_t nb = (B + 3) / 4;
+  return (unsigned)(nb < 1 ? 1 : (nb > 512 ? 512 : nb));
+}
+}  // namespace
 extern "C" size_t mmssl_eval_workspace_bytes(int64_t B) {
-  return (size_t)((B + kBlock - 1) / kBlock + 1) * 4 * kEvalMaxKs * sizeof(double) + 16;
+  return (size_t)(eval_blocks(B) + 1) * 4 * kEvalMaxKs * sizeof(double) + 16;
 }
 
 extern "C" int mmssl_eval_accumulate_f64(const int32_t* pos_rowptr, const int32_t* pos_cols, const int64_t* rows, int64_t B,
@@ -837,9 +937,10 @@ extern "C" int mmssl_eval_accumulate_f64(const int32_t* pos_rowptr, const int32_
   EvalKs e;
   e.n = n_ks;
   for (int i = 0; i < kEvalMaxKs; ++i) e.k[i] = i < n_ks ? ks[i] : 0;
+  if (K > kTopkMaxK) return MMSSL_E_UNSUPP;
   for (int i = 0; i < n_ks; ++i)
     if (ks[i] < 1 || ks[i] > K) return MMSSL_E_BADARG;
-  const unsigned nb = (unsigned)((B + kBlock - 1) / kBlock);
+  const unsigned nb = eval_blocks(B);
   uint32_t* ticket = reinterpret_cast<uint32_t*>(workspace);
   double* part = reinterpret_cast<double*>(reinterpret_cast<char*>(workspace) + 16);
   MMSSL_HIP_TRY(hipMemsetAsync(ticket, 0, 4, as_stream(stream)));

@@ -418,6 +418,17 @@ int mmssl_projx_supported(int n_prob, const int* K, int64_t M, int N);
 size_t mmssl_projx_image_floats(int64_t rows, int64_t red);
 int mmssl_projx_pack_f32(const float* F, int64_t M, int64_t K, int64_t ldf, int transpose, float* out, void* stream);
 size_t mmssl_projx_workspace_bytes(int n_prob, const int* K, int64_t M, int N, int wgrad, int n_blocks);
+/* The weights' bf16 planes as a caller-owned image (mmssl_projx_wimg_bytes bytes, 256-byte aligned): mmssl_projx_wsplit_f32
+ * makes it from W (the launch mmssl_projx_fwd_f32 runs in front of its main kernel), mmssl_projx_fwd_img_f32 is the forward
+ * on an image made earlier - a step makes it right behind the optimiser's update of the weights, i.e. at the END of the
+ * previous step, and its next forward starts with the main kernel. The caller answers for the image being that of the
+ * current weights (mmssl_amd/ops.py keys it on the tensors' versions). */
+size_t mmssl_projx_wimg_bytes(int n_prob, const int* K);
+int mmssl_projx_wsplit_f32(int n_prob, const float* const* W, const int* K, void* wimg, void* stream);
+int mmssl_projx_fwd_img_f32(int n_prob, const float* const* Fimg, const void* wimg, const float* const* bias, const int* K,
+                            int64_t M, int N, const uint8_t* keep, uint8_t* keep_out, const uint64_t* rng_state,
+                            float p_drop, float scale, float* Y, int64_t ldy, int n_blocks, void* workspace,
+                            size_t workspace_bytes, void* stream);
 int mmssl_projx_fwd_f32(int n_prob, const float* const* Fimg, const float* const* W, const float* const* bias,
                         const int* K, int64_t M, int N, const uint8_t* keep, uint8_t* keep_out,
                         const uint64_t* rng_state, float p_drop, float scale, float* Y, int64_t ldy,

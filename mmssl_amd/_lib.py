@@ -118,6 +118,10 @@ SIGNATURES = {
     "mmssl_projx_workspace_bytes": (c_size_t, [c_int, c_void_p, c_int64, c_int, c_int, c_int]),
     "mmssl_projx_fwd_f32": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p,
                                     c_void_p, c_float, c_float, c_void_p, c_int64, c_int, c_void_p, c_size_t, c_void_p]),
+    "mmssl_projx_wimg_bytes": (c_size_t, [c_int, c_void_p]),
+    "mmssl_projx_wsplit_f32": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "mmssl_projx_fwd_img_f32": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p,
+                                        c_void_p, c_float, c_float, c_void_p, c_int64, c_int, c_void_p, c_size_t, c_void_p]),
     "mmssl_projx_wgrad_f32": (c_int, [c_int, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p,
                                       c_int, c_void_p, c_size_t, c_void_p]),
     "mmssl_projx_wgrad_adamw_f32": (c_int, [c_int, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p,

@@ -1450,13 +1450,49 @@ extern "C" size_t mmssl_projx_workspace_bytes(int n_prob, const int* K, int64_t 
   return b + 256;
 }
 
-extern "C" int mmssl_projx_fwd_f32(int n_prob, const float* const* Fimg, const float* const* W, const float* const* bias,
-                                   const int* K, int64_t M, int N, const uint8_t* keep, uint8_t* keep_out,
-                                   const uint64_t* rng_state, float p_drop, float scale, float* Y, int64_t ldy,
-                                   int n_blocks, void* workspace, size_t workspace_bytes, void* stream) {
-  if (!Fimg || !W || !K || !Y || !workspace) return MMSSL_E_BADARG;
+namespace {
+// the bf16 planes of the weights (the short operand of the forward): problem g's image at wimg + off[g]
+size_t x_wimg_layout(int n_prob, const int* K, size_t* off) {
+  size_t o = 0;
+  for (int g = 0; g < n_prob; ++g) {
+    if (off) off[g] = o;
+    o += x_align((size_t)x_slices(K[g]) * kXBBytes);
+  }
+  return o;
+}
+int x_wsplit(int n_prob, const float* const* W, const int* K, char* wimg, hipStream_t s) {
+  XSplit X;
+  X.n = n_prob;
+  size_t off[kMaxProb];
+  x_wimg_layout(n_prob, K, off);
+  int units = 0;
+  for (int g = 0; g < kMaxProb; ++g) {
+    X.unit0[g] = units;
+    X.W[g] = nullptr; X.img[g] = nullptr; X.K[g] = 0;
+    if (g < n_prob) {
+      if (!W[g] || ((uintptr_t)W[g] & 15)) return MMSSL_E_BADARG;
+      X.W[g] = W[g];
+      X.img[g] = wimg + off[g];
+      X.K[g] = K[g];
+      units += (int)x_slices(K[g]) * PJ * 4;
+    }
+  }
+  X.unit0[kMaxProb] = units;
+  for (int g = n_prob; g <= kMaxProb; ++g) X.unit0[g] = units;
+  hipLaunchKernelGGL(projx_wsplit_kernel, dim3((unsigned)((units + 255) / 256)), dim3(256), 0, s, X);
+  MMSSL_LAUNCH_CHECK();
+  return 0;
+}
+// W != NULL: the planes are made here, into the workspace (one more launch in front of the main kernel); W == NULL: `wimg`
+// holds them already (mmssl_projx_wsplit_f32 by the caller, e.g. right behind the optimiser's update of the weights)
+int x_fwd_impl(int n_prob, const float* const* Fimg, const float* const* W, const void* wimg_in, const float* const* bias,
+               const int* K, int64_t M, int N, const uint8_t* keep, uint8_t* keep_out, const uint64_t* rng_state,
+               float p_drop, float scale, float* Y, int64_t ldy, int n_blocks, void* workspace, size_t workspace_bytes,
+               void* stream) {
+  if (!Fimg || (!W && !wimg_in) || !K || !Y || !workspace) return MMSSL_E_BADARG;
   if (!x_shape_ok(n_prob, K, M, N)) return MMSSL_E_UNSUPP;
   if (ldy < (int64_t)n_prob * N || (ldy & 3) || ((uintptr_t)Y & 15) || ((uintptr_t)workspace & 255)) return MMSSL_E_BADARG;
+  if (wimg_in && ((uintptr_t)wimg_in & 255)) return MMSSL_E_BADARG;
   if (keep && keep_out) return MMSSL_E_BADARG;
   if (keep_out && (!rng_state || !(p_drop >= 0.f && p_drop < 1.f))) return MMSSL_E_BADARG;
   Plan pl;
@@ -1465,38 +1501,59 @@ extern "C" int mmssl_projx_fwd_f32(int n_prob, const float* const* Fimg, const f
   if (x_lds_ready() != 0) return MMSSL_E_UNSUPP;
   char* base = reinterpret_cast<char*>(workspace);
   float* part = reinterpret_cast<float*>(base);
-  char* wimg = base + x_slot_bytes(pl);
-  XSplit X;
-  X.n = n_prob;
-  int units = 0;
-  for (int g = 0; g < kMaxProb; ++g) {
-    X.unit0[g] = units;
-    X.W[g] = nullptr; X.img[g] = nullptr; X.K[g] = 0;
-    if (g < n_prob) {
-      if (!Fimg[g] || !W[g] || (((uintptr_t)Fimg[g] | (uintptr_t)W[g]) & 15)) return MMSSL_E_BADARG;
-      X.W[g] = W[g];
-      X.img[g] = wimg;
-      X.K[g] = K[g];
-      pl.P.A[g] = Fimg[g];
-      pl.P.B[g] = reinterpret_cast<const float*>(wimg);
-      pl.P.lda[g] = pl.P.ldb[g] = 0;
-      units += (int)x_slices(K[g]) * PJ * 4;
-      wimg += x_align((size_t)x_slices(K[g]) * kXBBytes);
-    }
+  char* wimg = wimg_in ? const_cast<char*>(reinterpret_cast<const char*>(wimg_in)) : base + x_slot_bytes(pl);
+  size_t off[kMaxProb];
+  x_wimg_layout(n_prob, K, off);
+  for (int g = 0; g < n_prob; ++g) {
+    if (!Fimg[g] || ((uintptr_t)Fimg[g] & 15)) return MMSSL_E_BADARG;
+    pl.P.A[g] = Fimg[g];
+    pl.P.B[g] = reinterpret_cast<const float*>(wimg + off[g]);
+    pl.P.lda[g] = pl.P.ldb[g] = 0;
   }
-  X.unit0[kMaxProb] = units;
-  for (int g = n_prob; g <= kMaxProb; ++g) X.unit0[g] = units;
   hipStream_t s = as_stream(stream);
   FwdPtrs ptrs;
   for (int g = 0; g < kMaxProb; ++g) ptrs.bias[g] = (bias && g < n_prob) ? bias[g] : nullptr;
-  hipLaunchKernelGGL(projx_wsplit_kernel, dim3((unsigned)((units + 255) / 256)), dim3(256), 0, s, X);
-  MMSSL_LAUNCH_CHECK();
+  if (!wimg_in) {
+    const int rc = x_wsplit(n_prob, W, K, wimg, s);
+    if (rc) return rc;
+  }
   x_launch_main(pl, part, s);
   MMSSL_LAUNCH_CHECK();
   hipLaunchKernelGGL(proj_fwd_reduce_kernel, dim3((unsigned)pl.tiles * 8), dim3(kFThreads), 0, s, pl.P, pl.upb, pl.max_segs,
                      (const float*)part, M, Y, ldy, ptrs, keep, keep_out, rng_state, p_drop, scale);
   MMSSL_LAUNCH_CHECK();
   return 0;
+}
+}  // namespace
+
+extern "C" int mmssl_projx_fwd_f32(int n_prob, const float* const* Fimg, const float* const* W, const float* const* bias,
+                                   const int* K, int64_t M, int N, const uint8_t* keep, uint8_t* keep_out,
+                                   const uint64_t* rng_state, float p_drop, float scale, float* Y, int64_t ldy,
+                                   int n_blocks, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!W) return MMSSL_E_BADARG;
+  return x_fwd_impl(n_prob, Fimg, W, nullptr, bias, K, M, N, keep, keep_out, rng_state, p_drop, scale, Y, ldy, n_blocks,
+                    workspace, workspace_bytes, stream);
+}
+
+extern "C" size_t mmssl_projx_wimg_bytes(int n_prob, const int* K) {
+  if (!K || n_prob < 1 || n_prob > kMaxProb) return 0;
+  for (int g = 0; g < n_prob; ++g)
+    if (K[g] < 4 || K[g] % 4 != 0) return 0;
+  return x_wimg_layout(n_prob, K, nullptr);
+}
+
+extern "C" int mmssl_projx_wsplit_f32(int n_prob, const float* const* W, const int* K, void* wimg, void* stream) {
+  if (!W || !K || !wimg || ((uintptr_t)wimg & 255) || mmssl_projx_wimg_bytes(n_prob, K) == 0) return MMSSL_E_BADARG;
+  return x_wsplit(n_prob, W, K, reinterpret_cast<char*>(wimg), as_stream(stream));
+}
+
+extern "C" int mmssl_projx_fwd_img_f32(int n_prob, const float* const* Fimg, const void* wimg, const float* const* bias,
+                                       const int* K, int64_t M, int N, const uint8_t* keep, uint8_t* keep_out,
+                                       const uint64_t* rng_state, float p_drop, float scale, float* Y, int64_t ldy,
+                                       int n_blocks, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!wimg) return MMSSL_E_BADARG;
+  return x_fwd_impl(n_prob, Fimg, nullptr, wimg, bias, K, M, N, keep, keep_out, rng_state, p_drop, scale, Y, ldy, n_blocks,
+                    workspace, workspace_bytes, stream);
 }
 
 extern "C" int mmssl_projx_wgrad_f32(int n_prob, const float* G, int64_t ldg, const float* const* FTimg, const int* K,

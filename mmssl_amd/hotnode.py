@@ -52,6 +52,9 @@ class HotCtx:
         #                               launch on the side stream there (reg_target = (c, total buffer) names where).
         self.reg_parts = None         # (None, ss tensor) left by such a forward: its backward owes the regulariser
         self.reg_target = None
+        self.planes = None            # ops.WeightPlanes of a step object that updates the projection weights in the weight
+        #                               gradient's epilogue (adam above): the weights' bf16 planes are made right behind that
+        #                               update, and the next forward starts with its main kernel instead of the split launch
         self.anchored = []
         self._zero_grads = {}
 
@@ -110,7 +113,7 @@ class _HotNode(torch.autograd.Function):
             draw = (p_drop, ops._rng_state(dev))
         # with the GCN chain forked beside it the projection asks for 13/16 of the CUs (ops.proj_step_blocks)
         pblocks = ops.proj_step_blocks(dev) if hot.overlap else 0
-        X, keep_used = ops.proj_forward(Fs, Ws, bs, keep=keep, draw=draw, scale=scale, blocks=pblocks)
+        X, keep_used = ops.proj_forward(Fs, Ws, bs, keep=keep, draw=draw, scale=scale, blocks=pblocks, planes=hot.planes)
         if draw is not None and not hot.external_ticks:
             ops.tick_rng(dev)
         if hot.overlap:
@@ -167,6 +170,7 @@ class _HotNode(torch.autograd.Function):
                 _lib.check(rc, "mmssl_sum_partials_f32")
         ctx.save_for_backward(MU, MI, us[-1], its[-1], keep_used, *Fs)
         ctx.cfg = (hot, nm, float(scale), ui, iu, n_layers, float(r), inv, [b is not None for b in bs])
+        ctx.proj_weights = list(Ws)       # the Parameter objects (not saved tensors: only identity and version are read)
         ctx.set_materialize_grads(False)
         return u_g, i_g, ss, MI, MU
 
@@ -231,6 +235,10 @@ class _HotNode(torch.autograd.Function):
             gX = ops._spmm_raw(ui, True, t, ops.EPI_NONE)
         gW, gb = ops.proj_wgrad(gX, Fs, want_bias=any(has_b), adam=hot.adam,
                                 blocks=ops.proj_step_blocks(gX.device) if hot.overlap else 0)
+        if hot.planes is not None and hot.adam is not None:
+            # the epilogue above has just written the updated weights: their bf16 planes for the NEXT forward, now - at
+            # the end of the step, off its critical path (the next replay starts with the projection's main kernel)
+            hot.planes.refresh(ctx.proj_weights)
         if hot.overlap:
             # the embedding-table gradient (GCN chain) is complete before anything downstream of this node runs: the
             # chain ends long before the weight gradient above does, so the join never waits

@@ -68,6 +68,8 @@ class HotPathStep:
         self.batch_rows = bool(batch_rows) and self._packed
         self.hot = HotCtx(dev, overlap=overlap)
         self._proj = [model.image_trans, model.text_trans]
+        if self.fuse_adam and ops.PROJ_SPLIT:
+            self.hot.planes = ops.WeightPlanes()
         # tables first: with empty modal graphs their gradients are complete as soon as the GCN chain is
         self._modal_empty = (self._packed
                              and all(getattr(g, "nnz", 1) == 0 and not hasattr(g, "_pair") for g in self.graphs[2:6]))
@@ -277,6 +279,13 @@ class HotPathStep:
     def run(self):
         with torch.cuda.stream(self.stream):
             if self._graph is not None:
+                pl = self.hot.planes
+                if pl is not None and pl.key is not None:
+                    # the captured forward reads the weights' bf16 planes made by the previous step's backward: if anything
+                    # else has written the projection weights since (load_state_dict, a torch optimiser, copy_), remake them
+                    ws = [l.weight for l in self._proj]
+                    if pl.image_for(ws) is None:
+                        pl.refresh(ws)
                 self._graph.replay()
             else:
                 self._step()

@@ -400,6 +400,43 @@ def _projx_ws(n, Ks, M, N, wgrad, dev, blocks=0):
     return ws[off:], nb
 
 
+class WeightPlanes:
+    """The bf16 planes of the projection weights as a step-owned image (csrc/projection.hip projx_wsplit_kernel), made right
+    BEHIND the optimiser's update - at the end of a step - so that the next forward starts with its main kernel instead of a
+    14 us split launch on the critical path. The image is only used while it is provably that of the current weights: the
+    key holds every weight's (address, torch version counter, `_mmssl_serial`); torch's in-place writers (copy_,
+    load_state_dict, torch optimisers) bump the version, optim.FusedAdamW.step bumps `_mmssl_serial` of what it updates, and
+    the fused weight-gradient epilogue - the one writer that bumps nothing - is followed by refresh()."""
+
+    def __init__(self):
+        self.buf, self.key, self.shape = None, None, None
+
+    @staticmethod
+    def _key(Ws):
+        return tuple((w.data_ptr(), w._version, getattr(w, "_mmssl_serial", 0)) for w in Ws)
+
+    def refresh(self, Ws):
+        """Split the CURRENT weights into the image (one launch on the current stream)."""
+        Ks = [int(w.shape[1]) for w in Ws]
+        n = len(Ws)
+        nb = _lib.lib().mmssl_projx_wimg_bytes(n, _c_int_arr(Ks))
+        if nb == 0:
+            self.key = None
+            return False
+        shape = (tuple(Ks), Ws[0].device)
+        if self.buf is None or self.shape != shape:
+            raw = torch.empty(nb // 4 + 64, dtype=torch.float32, device=Ws[0].device)
+            self.buf, self.shape = raw[(-raw.data_ptr() % 256) // 4:], shape
+        rc = _lib.lib().mmssl_projx_wsplit_f32(n, _c_ptr_arr(Ws), _c_int_arr(Ks), _ptr(self.buf), _lib.stream_ptr())
+        _lib.check(rc, "mmssl_projx_wsplit_f32")
+        self.key = self._key(Ws)
+        return True
+
+    def image_for(self, Ws):
+        """The image if it is the current weights', else None."""
+        return self.buf if (self.key is not None and self.key == self._key(Ws)) else None
+
+
 def proj_supported(Ks, M, N, wgrad=False):
     """True when the grouped projection runs this modality list: N == 64 and, split precision (default), K % 4 == 0; on the
     fp32-MFMA kernels K % 32 == 0 forward, K % 4 == 0 weight gradient."""
@@ -410,9 +447,9 @@ def proj_supported(Ks, M, N, wgrad=False):
     return _lib.lib().mmssl_proj_supported(len(Ks), _c_int_arr(Ks), int(M), int(N), int(bool(wgrad))) == 1
 
 
-def proj_forward(Fs, Ws, bs, keep=None, draw=None, scale=1.0, blocks=0):
+def proj_forward(Fs, Ws, bs, keep=None, draw=None, scale=1.0, blocks=0, planes=None):
     """Y [M, 64 * n] = the projections dropout(F_g W_g^T + b_g) of all modalities side by side, one launch + one
-    epilogue launch. `blocks` (split precision only): the launch's block count, 0 = one per CU (see proj_step_blocks). `keep`: uint8 [n, M, 64] given masks; `draw` = (p, device rng state tensor): the masks are drawn in
+    epilogue launch. `planes` (a WeightPlanes, split precision only): use its image of the weights when it is current. `blocks` (split precision only): the launch's block count, 0 = one per CU (see proj_step_blocks). `keep`: uint8 [n, M, 64] given masks; `draw` = (p, device rng state tensor): the masks are drawn in
     the epilogue (same bytes as ops.dropout_masks(n, M, 64, p) at the same generator state) and returned; the caller
     advances the generator (dropout_masks's external-tick contract). Returns (Y, keep or None)."""
     n = len(Fs)
@@ -437,6 +474,13 @@ def proj_forward(Fs, Ws, bs, keep=None, draw=None, scale=1.0, blocks=0):
         if keep.dtype != torch.uint8 or tuple(keep.shape) != (n, M, N) or not keep.is_contiguous():
             raise _lib.MmsslError("proj_forward: keep must be a contiguous uint8 [n, M, 64] tensor")
     if split:
+        wimg = planes.image_for(Ws) if planes is not None else None       # WeightPlanes: made behind the last update
+        if wimg is not None:
+            rc = _lib.lib().mmssl_projx_fwd_img_f32(n, _c_ptr_arr(imgs), _ptr(wimg), _c_ptr_arr(bs), _c_int_arr(Ks), M, N,
+                                                    _ptr(keep), _ptr(keep_out), _ptr(rng), p, float(scale), _ptr(Y), N * n,
+                                                    int(blocks), _ptr(ws), nb, _lib.stream_ptr())
+            _lib.check(rc, "mmssl_projx_fwd_img_f32")
+            return Y, (keep_out if draw is not None else keep)
         rc = _lib.lib().mmssl_projx_fwd_f32(n, _c_ptr_arr(imgs), _c_ptr_arr(Ws), _c_ptr_arr(bs), _c_int_arr(Ks), M, N,
                                             _ptr(keep), _ptr(keep_out), _ptr(rng), p, float(scale), _ptr(Y), N * n, int(blocks),
                                             _ptr(ws), nb, _lib.stream_ptr())

@@ -112,6 +112,9 @@ class FusedAdamW(torch.optim.Optimizer):
                     st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                 todo.append((p, g, st["exp_avg"], st["exp_avg_sq"], gptr, nsl, gst))
+                # this launch writes p through its raw pointer: torch's version counter does not see it, caches keyed on the
+                # parameter's contents (ops.WeightPlanes) watch this serial
+                p._mmssl_serial = getattr(p, "_mmssl_serial", 0) + 1
             if not todo:
                 continue
             state = self._group_state(gi, todo[0][0].device)

@@ -104,6 +104,63 @@ def test_backward_matches_reference(tag, layers, modal):
     assert checked >= 7
 
 
+def test_hotpath_weight_planes_are_made_behind_the_update_and_follow_external_writes():
+    """HotPathStep keeps the projection weights' bf16 planes as a step-owned image made right behind the fused AdamW update
+    (ops.WeightPlanes): the captured forward starts with the projection's main kernel. (1) the trajectory equals the one of
+    a step object without the image (its forward splits the weights itself), eager and replayed; (2) a write to the
+    weights from outside (what load_state_dict / a torch optimiser do: an in-place op on the Parameter) between two replays
+    is noticed by run() and the image remade - the next loss equals the one of an object that never had an image."""
+    import scipy.sparse as sp
+    from mmssl_amd import ops, synth
+    from mmssl_amd.graph import GraphPlan
+    from mmssl_amd.hotpath import HotPathStep
+    from mmssl_amd.Models import MMSSL
+    U, I, E, dv, dt, B = 2000, 1300, 20000, 256, 128, 256
+    _configure(drop_rate=0.2, batch_size=B, weight_size="[64, 64]")
+    raw = synth.interaction_matrix(U, I, E, seed=9)
+    ui, iu = synth.normalised_pair(raw)
+    g = torch.Generator().manual_seed(5)
+    img, txt = torch.randn(I, dv, generator=g).numpy(), torch.randn(I, dt, generator=g).numpy()
+    batches = [(torch.randperm(U, generator=g)[:B], torch.randint(0, I, (B,), generator=g),
+                torch.randint(0, I, (B,), generator=g)) for _ in range(6)]
+    bump = torch.randn(64, dv, generator=g) * 0.01
+
+    def run(planes, capture):
+        torch.manual_seed(21)
+        ops.seed_dropout(21)
+        model = MMSSL(U, I, 64, [64] * 2, [0.1] * 2, img, txt).to(DEV).train()
+        e1, e2 = GraphPlan(sp.csr_matrix((U, I), dtype=np.float32)), GraphPlan(sp.csr_matrix((I, U), dtype=np.float32))
+        step = HotPathStep(model, (GraphPlan(ui), GraphPlan(iu), e1, e2, e1, e2), B)
+        if not planes:
+            step.hot.planes = None
+        else:
+            assert step.hot.planes is not None
+        step.set_batch(*[t.to(DEV) for t in batches[0]])
+        if capture:
+            assert step.capture(warmup=1), getattr(step, "capture_error", "")
+        else:
+            step.step()
+        losses = []
+        for k, b in enumerate(batches):
+            if k == 3:                 # somebody else writes the weights (an in-place op on the Parameter, like copy_)
+                with torch.no_grad():
+                    model.image_trans.weight.add_(bump.to(DEV))
+            step.set_batch(*[t.to(DEV) for t in b])
+            step.run()
+            torch.cuda.synchronize()
+            losses.append(float(step.loss))
+        if planes:
+            assert step.hot.planes.image_for([model.image_trans.weight, model.text_trans.weight]) is not None
+        return losses, model.image_trans.weight.detach().cpu().clone()
+
+    ref_l, ref_w = run(False, False)
+    for planes, capture in ((True, False), (True, True), (False, True)):
+        l, w = run(planes, capture)
+        for a, b in zip(l, ref_l):
+            assert abs(a - b) <= 1e-5 * abs(b), (planes, capture, l, ref_l)
+        assert H.rel_err(w, ref_w) < 1e-5, (planes, capture)
+
+
 def _trainer(tmp_path, **kw):
     from mmssl_amd import config
     from mmssl_amd.utility import batch_test

@@ -587,6 +587,20 @@ class ShardedMMSSL(nn.Module):
                 keep = torch.stack(tuple(keep_masks)) if isinstance(keep_masks, (tuple, list)) else keep_masks
             else:                                # drawn by the projection's epilogue from the device generator
                 keep = ("draw", float(c.drop_rate), bool(getattr(self, "_external_ticks", False)))
+                if (getattr(self, "replicate_feats", False) and not _solo(self.group) and hasattr(bk, "ops")
+                        and not getattr(self, "_rng_checked", False)):
+                    # replicated features: every rank projects ALL items and must drop the SAME entries, i.e. draw from
+                    # the same generator state (seed and launch counter). Checked once, on the host, before the first draw:
+                    # ranks seeded per rank (2022 + rank, right for the sharded features) would project different X and
+                    # all-reduce inconsistent weight gradients without any error
+                    mine = [int(v) for v in bk.ops._rng_state(self.E_i.device).cpu().tolist()]
+                    got = [None] * dist.get_world_size(self.group)
+                    dist.all_gather_object(got, mine, group=self.group)
+                    if any(g_ != got[0] for g_ in got):
+                        raise RuntimeError("ShardedMMSSL(replicate_feats=True): the ranks' dropout generators differ (%s): "
+                                           "seed them identically (ops.seed_dropout(seed) with ONE seed on every rank) or "
+                                           "inject keep_masks" % (got,))
+                    self._rng_checked = True
         if modal_empty:
             z = getattr(self, "_zero_views", None)
             if z is None or z[0].device != self.E_u.device:

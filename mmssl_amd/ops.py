@@ -347,10 +347,6 @@ def _c_ptr_arr(tensors):
 # value, six partial products on the bf16 matrix pipe, fp32 accumulation - fp32-accurate, bound by the feature stream instead
 # of the fp32 MFMA rate). False = the fp32-MFMA kernels (A/B runs: bench.py --proj f32).
 PROJ_SPLIT = True
-_PROJ_IMAGES = {}          # (data_ptr, shape, stride, device) -> [F (kept alive: its address cannot be reused), version, img, imgT]
-_PROJ_IMAGES_MAX = 8
-
-
 def projx_supported(Ks, M, N):
     return len(Ks) >= 1 and _lib.lib().mmssl_projx_supported(len(Ks), _c_int_arr(Ks), int(M), int(N)) == 1
 
@@ -358,14 +354,15 @@ def projx_supported(Ks, M, N):
 def proj_images(F, transposed=False):
     """The tile-major image of the constant feature matrix F [M, K] (reference Models.py:46-47) that the split-precision
     projection streams: of F itself (forward) or of F^T (weight gradient). Built once per matrix by mmssl_projx_pack_f32 and
-    cached; the cache entry keeps F alive, and an in-place change of F (its version counter) rebuilds the images."""
-    key = (F.data_ptr(), tuple(F.shape), tuple(F.stride()), F.device.index)
-    e = _PROJ_IMAGES.get(key)
-    if e is None or e[1] != F._version:
-        while len(_PROJ_IMAGES) >= _PROJ_IMAGES_MAX:
-            _PROJ_IMAGES.pop(next(iter(_PROJ_IMAGES)))
-        e = _PROJ_IMAGES[key] = [F, F._version, None, None]
-    k = 3 if transposed else 2
+    kept ON the tensor object (`F._mmssl_proj_images`): the images live exactly as long as F does - whoever holds F (the
+    model, and through it a step object and its captured hipGraph, whose nodes carry the images' addresses) holds them, and
+    nothing else does (until round 6 a global 8-entry FIFO owned them: an eviction could free an image a live graph still
+    read, and entries outlived their models). An in-place change of F (its version counter) rebuilds the images."""
+    e = getattr(F, "_mmssl_proj_images", None)
+    if e is None or e[0] != F._version or e[3] != (F.data_ptr(), tuple(F.shape), tuple(F.stride())):
+        e = [F._version, None, None, (F.data_ptr(), tuple(F.shape), tuple(F.stride()))]
+        F._mmssl_proj_images = e
+    k = 2 if transposed else 1
     if e[k] is None:
         M, K = F.shape
         rows, red = (K, M) if transposed else (M, K)

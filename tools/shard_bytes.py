@@ -25,7 +25,9 @@ Model of a step at N ranks:  t = max(compute, link) + min(compute, link) / chunk
   chunks   = column chunks per collective (chunk c's product under chunk c+1's transfer: only 1 / chunks of the shorter side
              stays exposed). Automatic: 1 below 64 MB per collective, 2 - 4 above (configs[4]: 4); the table prints one lane
              (no overlap) and four. launches x latency = collective launches per
-             step x per-launch cost (RCCL on one rank, measured round 4: ~20 us; a peer-to-peer store + flag would be ~3 us)
+             step x per-exchange cost: RCCL ~20 us per collective launch (measured on one rank, round 4); the PEER EXCHANGE
+             (built, round 6: csrc/peer.hip - a push kernel + a wait kernel per all-gather, signal + wait + pull per
+             reduce-scatter, all inside the step's hipGraph) ~8 us per exchange (2 - 3 graph nodes of ~3 us)
 Speed-up = one-GPU time of the WHOLE problem / t. For configs[4] that denominator is measured: 139.7 ms per step for the whole
 2M x 1M x 100M graph on one MI355X (profiles/r05_bench_synth_full_n1.json) - 8.0 x the 17.5 ms a rank's share costs."""
 import argparse
@@ -34,7 +36,8 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--link-gbs", type=float, nargs="*", default=[45.0, 50.0, 60.0, 70.0, 75.0],
                 help="achievable GB/s per xGMI link and direction (swept)")
 ap.add_argument("--layers", type=int, default=3)
-ap.add_argument("--latency-us", type=float, default=20.0, help="cost of one collective launch")
+ap.add_argument("--latency-us", type=float, default=20.0, help="cost of one RCCL collective launch")
+ap.add_argument("--peer-latency-us", type=float, default=8.0, help="cost of one exchange over the peer transport (2 - 3 kernels)")
 ap.add_argument("--tflops", type=float, default=90.0, help="fp32 projection rate for the replicated-features extra work")
 a = ap.parse_args()
 
@@ -69,8 +72,8 @@ def table(name, I, U, d, nm, feat_dims, one_gpu_ms, rank_ms, weak):
         "2-D 2x4", recv2d / 1e9, recv2d / (N - 1) / 1e6))
     for nc, label in ((1, "ONE lane (--chunks 1: transfers and products one after the other)"),
                       (4, "4 column-chunk lanes (what the automatic rule picks for 512 MB tables)")):
-        print("  speed-up over one GPU at N = 8 (%s), %s, launch latency %.0f us | 3 us:" % (
-            "weak: 8 x the rows" if weak else "strong: the same problem", label, a.latency_us))
+        print("  speed-up over one GPU at N = 8 (%s), %s, per exchange: RCCL %.0f us | peer exchange %.0f us:" % (
+            "weak: 8 x the rows" if weak else "strong: the same problem", label, a.latency_us, a.peer_latency_us))
         print("    %-9s" % "GB/s/link" + "".join("%22s" % s for s in ("item-side", "item-side + repl", "2-D 2x4 (not built)")))
         for gbs in a.link_gbs:
             cells = []
@@ -80,7 +83,7 @@ def table(name, I, U, d, nm, feat_dims, one_gpu_ms, rank_ms, weak):
                 link = recv / (N - 1) / (gbs * 1e9) * 1e3
                 t = (comp + link if nc == 1 else max(comp, link) + min(comp, link) / nc) + launches * a.latency_us * 1e-3
                 lat = launches * a.latency_us * 1e-3
-                t3 = t - lat + launches * 3e-3
+                t3 = t - lat + launches * a.peer_latency_us * 1e-3
                 tot = one_gpu_ms * (N if weak else 1)
                 cells.append("%5.1fx | %4.1fx (%4.1f ms)" % (tot / t, tot / t3, t))
             print("    %-9.0f" % gbs + "".join("%22s" % c for c in cells))

@@ -767,11 +767,15 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     run_steps(a.steps)
+    t_enq = time.perf_counter() - t0            # the host's share: all K step.run() calls have returned
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     ms = elapsed * 1e3 / a.steps
     out = result_line(a, 1, "weak", ms, edge_layers_total, stats, captured, float(step.loss), "single",
                       int(raw.shape[0]), int(raw.shape[1]), int(raw.nnz))
+    # host time inside step.run() per step (one hipGraphLaunch when captured). Far below ms_per_step = the GPU is the
+    # bound and the host runs ahead; equal to it = the host (or a full queue) paces the step.
+    out["host_enqueue_us"] = round(t_enq * 1e6 / a.steps, 1)
     info = plans[0].info()
     out["config"]["graph"] = "%s; XCD-banded work list: %s (locality score %.2f / %.2f)" % (
         a.graph, "on" if info["banded"] else "off", info["band_score"], plans[1].info()["band_score"])

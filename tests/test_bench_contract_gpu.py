@@ -39,6 +39,7 @@ def test_bench_json_contract():
     for key in ("value", "unit", "cores", "kind", "sample"):
         assert key in cb, key
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0
+    assert 0 < d["host_enqueue_us"] <= d["ms_per_step"] * 1e3 * 1.05          # the host's share of a step
 
 
 def test_bench_sharded_path_one_rank_reports_comm():

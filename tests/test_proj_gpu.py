@@ -256,3 +256,4 @@ def test_grouped_projection_is_bit_stable_beside_memory_bound_streams():
         for gW, gb in gs:
             for a, b in zip(list(gW) + list(gb), gW0 + gb0):
                 assert torch.equal(a, b), (it, "wgrad", float((a - b).abs().max()), float(b.abs().max()))
+

@@ -45,24 +45,50 @@ class PeerTransport:
         L = _lib.lib()
         self._L = L
         self.hb = L.mmssl_peer_handle_bytes()
-        ctx = ctypes.c_void_p()
-        with torch.cuda.device(self.device):
+        self.max_channels = int(max_channels)
+        self._keep = []
+        self.launches = 0
+        self._ctx = None
+
+        def local():
+            ctx = ctypes.c_void_p()
             _lib.check(L.mmssl_peer_create(self.world, self.rank, int(max_channels), ctypes.byref(ctx)), "mmssl_peer_create")
             self._ctx = ctx
             _lib.check(L.mmssl_peer_set_timeout_ms(ctx, int(timeout_ms)), "mmssl_peer_set_timeout_ms")
             h = ctypes.create_string_buffer(self.hb)
             _lib.check(L.mmssl_peer_flags_handle(ctx, h), "mmssl_peer_flags_handle")
+            return h.raw
+        with torch.cuda.device(self.device):
+            hs = self._all_handles(local)
             if self.world > 1:
-                _lib.check(L.mmssl_peer_open_flags(ctx, self._all_handles(h.raw)), "mmssl_peer_open_flags")
-        self.max_channels = int(max_channels)
-        self._keep = []
-        self.launches = 0
+                self._agree(lambda: _lib.check(L.mmssl_peer_open_flags(self._ctx, hs), "mmssl_peer_open_flags"))
 
-    def _all_handles(self, mine):
+    # Set-up is a sequence of LOCAL steps (allocate + export, open the peers' handles) and host-side exchanges. A local
+    # step that fails on one rank only must not leave the other ranks alone in the next exchange: the failure travels
+    # through the exchange itself and every rank raises the same error at the same point.
+    def _all_handles(self, make):
+        try:
+            mine = bytes(make())
+        except Exception as e:                    # noqa: BLE001 - reported to every rank below
+            mine = "rank %d: %s" % (self.rank, repr(e)[:200])
         got = [None] * self.world
-        dist.all_gather_object(got, bytes(mine), group=self.group)
-        assert all(isinstance(g, (bytes, bytearray)) and len(g) == self.hb for g in got)
+        dist.all_gather_object(got, mine, group=self.group)
+        bad = [g for g in got if not (isinstance(g, (bytes, bytearray)) and len(g) == self.hb)]
+        if bad:
+            raise _lib.MmsslError("peer exchange set-up failed (%s)" % (bad[0],))
         return ctypes.create_string_buffer(b"".join(got), self.hb * self.world)
+
+    def _agree(self, step):
+        try:
+            step()
+            mine = None
+        except Exception as e:                    # noqa: BLE001
+            mine = "rank %d: %s" % (self.rank, repr(e)[:200])
+        got = [None] * self.world
+        dist.all_gather_object(got, mine, group=self.group)
+        bad = [g for g in got if g is not None]
+        if bad:
+            raise _lib.MmsslError("peer exchange set-up failed (%s)" % (bad[0],))
 
     def info(self):
         v = (ctypes.c_int64 * 6)()
@@ -73,13 +99,19 @@ class PeerTransport:
     def window(self, rows, width):
         """(window id, torch view [rows, width] of this rank's buffer). Collective."""
         wid, ptr = ctypes.c_int(), ctypes.c_void_p()
-        h = ctypes.create_string_buffer(self.hb)
-        with torch.cuda.device(self.device):
+
+        def local():
+            h = ctypes.create_string_buffer(self.hb)
             _lib.check(self._L.mmssl_peer_window_create(self._ctx, int(rows) * int(width) * 4, ctypes.byref(wid), h,
                                                         ctypes.byref(ptr)), "mmssl_peer_window_create")
+            return h.raw
+        with torch.cuda.device(self.device):
             if self.world > 1:
-                _lib.check(self._L.mmssl_peer_window_open(self._ctx, wid.value, self._all_handles(h.raw)),
-                           "mmssl_peer_window_open")
+                hs = self._all_handles(local)
+                self._agree(lambda: _lib.check(self._L.mmssl_peer_window_open(self._ctx, wid.value, hs),
+                                               "mmssl_peer_window_open"))
+            else:
+                local()
         t = torch.as_tensor(_DevMem(ptr.value, (rows, width)), device=self.device)
         assert t.data_ptr() == ptr.value
         return wid.value, t

@@ -3,7 +3,7 @@ processes sharing GPU 0 - IPC-mapped windows, epoch flags, push / wait / pull-su
 for itself. Eager steps first (windows are created on first use), then the same sequence captured in a hipGraph and
 replayed with new inputs.
 
-    python tests/_peer_worker.py RANK WORLD PORT [timeout] OUT_DIR"""
+    python tests/_peer_worker.py RANK WORLD PORT [timeout | setupfail] OUT_DIR"""
 import os
 import sys
 
@@ -52,6 +52,35 @@ def main():
         torch.save(rec, os.path.join(out_dir, "r%d.pt" % rank))
         dist.barrier()
         t.close()
+        dist.destroy_process_group()
+        return
+    if mode == "setupfail":
+        # the window export fails on the LAST rank only: the failure travels through the handle exchange, every rank raises
+        # the same error at the same point (no rank is left alone in a host-side collective) and the job goes on - over
+        # torch.distributed, as bench.choose_transport does
+        from mmssl_amd import _lib
+        pc = peer.PeerComm(dist.group.WORLD, dev, timeout_ms=2000)
+        if rank == world - 1:
+            real = pc.t._L.mmssl_peer_window_create
+
+            def broken(*a):
+                return -1
+            pc.t._L = type("L", (), {"__getattr__": lambda self_, k: broken if k == "mmssl_peer_window_create"
+                                     else getattr(_lib.lib(), k)})()
+            del real
+        rec = {"raised": False}
+        try:
+            pc.begin_step()
+            pc.gather(torch.ones(4, 64, device=dev))
+        except _lib.MmsslError as e:
+            rec = {"raised": True, "msg": str(e)}
+        t = torch.ones(1) * (rank + 1)
+        dist.all_reduce(t)                              # the ranks are still in step with each other
+        rec["sum"] = float(t)
+        torch.save(rec, os.path.join(out_dir, "r%d.pt" % rank))
+        dist.barrier()
+        pc.t._L = _lib.lib()
+        pc.close()
         dist.destroy_process_group()
         return
     pc = peer.PeerComm(dist.group.WORLD, dev, timeout_ms=60000)

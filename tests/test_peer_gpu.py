@@ -40,3 +40,12 @@ def test_a_wait_that_cannot_be_satisfied_gives_up_and_is_reported(tmp_path):
     recs = _run(2, tmp_path, extra=("timeout",))
     assert recs[0]["timed_out"] and "0x2" in recs[0]["msg"], recs[0]
     assert not recs[1]["timed_out"]
+
+
+def test_a_set_up_failure_on_one_rank_is_raised_by_every_rank(tmp_path):
+    """The window export fails on rank 2 of three (the library call returns an error there): all three ranks raise the
+    same MmsslError naming rank 2 from the same host-side exchange - none is left waiting in it - and a collective issued
+    afterwards still works (what bench.choose_transport relies on when it falls back to RCCL)."""
+    recs = _run(3, tmp_path, extra=("setupfail",))
+    for r in recs:
+        assert r["raised"] and "rank 2" in r["msg"] and r["sum"] == 6.0, r

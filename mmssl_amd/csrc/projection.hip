@@ -694,7 +694,10 @@ constexpr int kXGRows = 64;                            // reduction rows per blo
 __device__ __forceinline__ unsigned f2u(float x) { return __builtin_bit_cast(unsigned, x); }
 __device__ __forceinline__ float u2f(unsigned x) { return __builtin_bit_cast(float, x); }
 
-// a = hi + mid + lo exactly, each piece a bf16 (the top 16 bits of an fp32): the bit patterns of the three pieces
+// a = hi + mid + lo exactly, each piece a bf16 (the top 16 bits of an fp32): the bit patterns of the three pieces.
+// FINITE inputs only: for a = +-Inf the remainder a - hi is NaN, so an infinite feature / weight / gradient gives NaN where
+// the fp32-MFMA kernels (ops.PROJ_SPLIT = False) give Inf - both are a diverged run; NaN stays NaN. A remainder below the
+// bf16 MFMA's denormal threshold may be flushed: it is < 2^-126, far below the 2^-24 relative error budget of the scheme.
 __device__ __forceinline__ void cut3(float a, unsigned& hi, unsigned& mid, unsigned& lo) {
   hi = f2u(a) & 0xffff0000u;
   const float r = a - u2f(hi);            // exact: the low 16 significand bits
@@ -981,7 +984,7 @@ __global__ __launch_bounds__(256) void projx_wsplit_kernel(XSplit X) {
 }
 
 // weight gradient: G [M, ldg] fp32 (problem g = columns 64 g .. 64 g + 63) -> the B image of G_g^T (ceil(M / 32) slices,
-// zeros past M) + this block's column sums. grid = (ceil(M / 128), n_prob).
+// zeros past M) + this block's column sums. grid = (ceil(M / kXGRows), n_prob).
 __global__ __launch_bounds__(256) void projx_gprep_kernel(const float* __restrict__ G, int64_t ldg, int64_t M, int n_slices,
                                                           char* __restrict__ img0, int64_t img_stride,
                                                           float* __restrict__ bpart) {

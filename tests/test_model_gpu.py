@@ -564,6 +564,10 @@ def test_hotpath_batch_ring_equals_set_batch():
             step.run()
             torch.cuda.synchronize()
             losses.append(float(step.loss))
+            # the deterministic half of the claim: the step read exactly slot (completed steps mod 3) - index buffers are
+            # integers, no atomics involved
+            assert torch.equal(step.batch, ring[k % 3]), k
+            assert int(step._steps_done) == k + 1
         return losses, model.user_id_embedding.weight.detach().cpu().clone()
     la, ea = run(True)
     lb, eb = run(False)

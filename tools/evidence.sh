@@ -38,6 +38,7 @@ if has dist; then
   B="python bench.py --gpus 1 --steps 500 --warmup 100 --no-cpu-baseline --only steps"
   timeout 300 $B > $O/bench_steps.json 2>> $O/bench.err; line $O/bench_steps.json
   timeout 300 $B --force-dist > $O/bench_forcedist.json 2>> $O/bench.err; line $O/bench_forcedist.json
+  MMSSL_DIST_FORCE_COLLECTIVES=1 timeout 300 $B --force-dist --transport peer > $O/bench_forcedist_peer.json 2>> $O/bench.err; line $O/bench_forcedist_peer.json
   MMSSL_DIST_FORCE_COLLECTIVES=1 timeout 300 $B --force-dist --scheme item-side > $O/bench_forcedist_rccl_itemside.json 2>> $O/bench.err; line $O/bench_forcedist_rccl_itemside.json
   MMSSL_DIST_FORCE_COLLECTIVES=1 timeout 300 $B --force-dist --scheme item-side --chunks 2 > $O/bench_forcedist_rccl_itemside_c2.json 2>> $O/bench.err; line $O/bench_forcedist_rccl_itemside_c2.json
   MMSSL_DIST_FORCE_COLLECTIVES=1 timeout 300 $B --force-dist --scheme gather-both > $O/bench_forcedist_rccl_gatherboth.json 2>> $O/bench.err; line $O/bench_forcedist_rccl_gatherboth.json

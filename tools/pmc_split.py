@@ -1,5 +1,5 @@
 """Per-kernel counter averages from a rocprofv3 counter_collection.csv, split into consecutive GROUPS of dispatches
-(tools/gemm_pmc.py launches 6 x the image shape, then 6 x the text shape): python tools/pmc_split.py CSV 6 [filter]"""
+(the per-modality workload of rounds 1-3, tools/gemm_pmc.py - removed from the tree in round 5, in git history - launched 6 x the image shape, then 6 x the text shape; tools/proj_pmc.py launches one grouped shape): python tools/pmc_split.py CSV 6 [filter]"""
 import collections
 import csv
 import sys

@@ -678,6 +678,7 @@ def main():
                     help="N > 1: how table rows move between the ranks. peer = kernels writing / reading IPC-mapped peer "
                          "windows (csrc/peer.hip, no collective library in the data path); collective = RCCL (gloo with "
                          "--share-gpu); auto = peer if its start-up self-test passes on every rank, else collective")
+    ap.add_argument("--peer-sabotage", action="store_true", dest="peer_sabotage", help=argparse.SUPPRESS)   # tests: see choose_transport
     ap.add_argument("--no-loss-check", action="store_true", dest="no_loss_check",
                     help="N > 1: skip `loss_vs_n1` (the sharded job's first-step loss against the same job whole on rank 0)")
     ap.add_argument("--scheme", choices=["item-side", "gather-both", "halo"], default="item-side",
@@ -853,8 +854,7 @@ def timed_sharded(a, rank, world, dev, scaling, want_graph, pre_step=None):
     if pc is not None:
         l0 = pc.t.launches
         step.step()
-        torch.cuda.synchronize()
-        pc.check()
+        peer_agree(pc, dev, "first eager steps")
         st = pc.stats()
         comm["peer"] = {"exchange_call_sites_per_step": st["call_sites"], "exchange_launches_per_step": pc.t.launches - l0,
                         "windows": st["windows"], "window_MB": round(st["window_bytes"] / 2 ** 20, 1),
@@ -872,6 +872,8 @@ def timed_sharded(a, rank, world, dev, scaling, want_graph, pre_step=None):
             step.set_batch(batches[i % len(batches)])
             step.run()
     run_steps(a.warmup)
+    if pc is not None:
+        peer_agree(pc, dev, "warm-up steps")
     dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -880,6 +882,8 @@ def timed_sharded(a, rank, world, dev, scaling, want_graph, pre_step=None):
     dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    if pc is not None:
+        peer_agree(pc, dev, "timed steps")          # a wait that gave up inside the timed region voids the figure
     t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     ms = float(t.item()) * 1e3 / a.steps
@@ -951,6 +955,27 @@ def peer_selftest(pc, dev):
     return ok
 
 
+class PeerFailed(RuntimeError):
+    """Raised by EVERY rank at the same point (peer_agree) when the peer exchange failed on any of them."""
+
+
+def peer_agree(pc, dev, where):
+    """An agreed health check of the peer exchange: every rank reads its context's error word, the ranks all-reduce the
+    outcome over torch.distributed, and either all go on or all raise PeerFailed - a rank whose waits timed out must not
+    leave the others alone in the next collective."""
+    import torch.distributed as dist
+    bad, msg = 0, ""
+    try:
+        torch.cuda.synchronize()
+        pc.check()
+    except Exception as e:          # noqa: BLE001
+        bad, msg = 1, repr(e)[:200]
+    t = torch.tensor([bad], dtype=torch.int32, device=dev if dist.get_backend() == "nccl" else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    if int(t.item()):
+        raise PeerFailed("%s: %s" % (where, msg or "a wait timed out on another rank"))
+
+
 def choose_transport(a, rank, world, dev):
     """(name, record). `auto`: the peer exchange if it can be set up and its self-test passes on EVERY rank."""
     import torch.distributed as dist
@@ -971,6 +996,14 @@ def choose_transport(a, rank, world, dev):
     dist.all_reduce(flag, op=dist.ReduceOp.MIN)
     if int(flag.item()) == 1:
         pc = mdist._peer(None)
+        if a.peer_sabotage:
+            # test hook (tests/test_bench_contract_gpu.py): after a PASSED self-test the last rank stops signalling its
+            # reduce-scatter partials - the other ranks' waits give up after 0.5 s, the agreed check raises PeerFailed on
+            # every rank and the job falls back to collectives
+            pc.t._L.mmssl_peer_set_timeout_ms(pc.t._ctx, 500)
+            if rank == world - 1:
+                real, only_wait = pc.t.signal_wait, pc.t.wait
+                pc.t.signal_wait = lambda ch: real(ch) if ch == 0 else only_wait(ch)
         info = pc.stats()
         return "peer", {"transport": "peer (IPC-mapped windows + epoch flags, csrc/peer.hip)",
                         "flags_finegrained": info["flags_finegrained"], "selftest": "passed on all %d ranks" % world}
@@ -1112,7 +1145,28 @@ def run_sharded_main(a, rank, world, dev):
     check = None
     if world > 1 and not a.no_loss_check and a.workload != "synth":
         check = lambda st: lbox.update(rec=loss_vs_n1(a, st, rank, world, dev, scaling, group1))      # noqa: E731
-    r = timed_sharded(a, rank, world, dev, scaling, want, pre_step=check)
+    state = {"tname": tname, "trec": trec, "want": want}
+
+    def sharded(aa, sc, pre=None):
+        """timed_sharded; if the peer exchange fails at one of its AGREED points (set-up exchange, peer_agree: every rank
+        raises there together) the job drops it and runs again over torch.distributed's collectives."""
+        err = None
+        try:
+            return timed_sharded(aa, rank, world, dev, sc, state["want"], pre_step=pre)
+        except PeerFailed as e:
+            err = str(e)
+        except Exception as e:          # noqa: BLE001
+            if state["tname"] != "peer" or "peer exchange set-up failed" not in str(e):
+                raise
+            err = str(e)
+        gc.collect()
+        torch.cuda.synchronize()
+        mdist.disable_peer_exchange(None)
+        state.update(tname="collective", want=False,
+                     trec={"transport": "collective (%s), eager" % dist.get_backend(), "peer_rejected": err[:300]})
+        return timed_sharded(aa, rank, world, dev, sc, False, pre_step=pre)
+    r = sharded(a, scaling, check)
+    tname, trec = state["tname"], state["trec"]
     stats = r["stats"]
     lrec = lbox.get("rec")
     devs = rank_devices(world, dev) if world > 1 else None
@@ -1146,7 +1200,7 @@ def run_sharded_main(a, rank, world, dev):
         a2.workload, a2.d, a2.steps, a2.warmup = "synth", 128, min(a.steps, 10), min(a.warmup, 3)
         dog = stress_watchdog(a.stress_timeout, out, rank)
         try:
-            r2 = timed_sharded(a2, rank, world, dev, "weak", want)
+            r2 = sharded(a2, "weak")
             st2 = r2["stats"]
             rec = {"what": "configs[4]: per-rank share 250K users x 125K items x 12.5M edges, d=128, x %d ranks" % world,
                    "ms_per_step": round(r2["ms"], 4), "steps": a2.steps, "warmup": a2.warmup,

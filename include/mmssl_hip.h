@@ -678,17 +678,25 @@ int mmssl_ngcf_combine_bwd_f32(const float* G, const float* B, const uint8_t* ke
  *   window    mmssl_peer_window_create allocates `bytes` of device memory (zeroed) and returns its IPC handle;
  *             mmssl_peer_window_open takes ALL ranks' handles of the same window id ([world][handle_bytes], own slot
  *             ignored) and maps the peers' buffers. Windows live until mmssl_peer_destroy.
- *   channel   mmssl_peer_signal: epoch[ch] += 1 and a system-scope release store of it into slot [ch][rank] of every
+ *   channel   mmssl_peer_signal: epoch[ch] += 1 and a system-scope store of it into slot [ch][rank] of every
  *             rank's flags; mmssl_peer_wait: returns (in stream order) once every slot [ch][*] of THIS rank's flags has
  *             reached epoch[ch] - i.e. every rank has signalled as often as this one. A wait that is not satisfied within
  *             the timeout (default 20 s) sets the context's error word and returns: the device is never hung;
  *             mmssl_peer_error copies the word to the host (blocking) - non-zero = some wait gave up, results invalid.
  *   push      rows [0, rows) x `width` floats of `src` (row pitch src_pitch floats) -> rows [dst_row0, ...) of EVERY rank's
  *             window `win_id` (row pitch dst_pitch), then signal(ch): the all-gather, pushed over every link at once.
+ *             `wait_after` != 0: the launch's last block then also waits on the channel (push + wait in ONE launch).
+ *             mmssl_peer_signal_wait: signal + wait as one launch (one wave).
  *   pull-sum  out[r] = sum_{q = 0 .. world-1, in that order} window_q[row0 + r]: the reduce-scatter as a pull with a
  *             fixed summation order (the same bits on every run and for every rank count's partition of the same sum
  *             order); call after signal + wait on the channel that guards the window.
  *   sum-slots out[j] = sum_{q = 0 .. n-1} slots[q * stride + j] (local): the second half of an all-reduce by push.
+ *   Visibility (gfx942 / gfx950): pushed rows are stored write-through at system scope and counted with vmcnt before the
+ *             epoch is published; data a plain kernel wrote into a window is published by that kernel's end (signal runs
+ *             behind it in stream order); pull-sum / sum-slots read the windows past the caches; any other kernel that
+ *             reads a window after mmssl_peer_wait must be a separate launch behind the wait (its start drops the caches'
+ *             stale copies). No cache-wide fence inside the data kernels; the wait is one wave (a data kernel that spins
+ *             in all of its blocks starves the kernels its peers wait for).
  * All compute calls are asynchronous on `stream` and hipGraph-capturable (epochs live in device memory).
  * widths, pitches: multiples of 4 floats; pointers 16-byte aligned; world <= 16.
  * ---------------------------------------------------------------------------------- */
@@ -704,8 +712,9 @@ int mmssl_peer_open_flags(mmssl_peer* p, const void* handles);
 int mmssl_peer_window_create(mmssl_peer* p, int64_t bytes, int* win_id, void* handle_out, void** local_ptr);
 int mmssl_peer_window_open(mmssl_peer* p, int win_id, const void* handles);
 int mmssl_peer_push_rows_f32(mmssl_peer* p, int ch, int win_id, const float* src, int64_t src_pitch, int64_t rows, int width,
-                             int64_t dst_row0, int64_t dst_pitch, void* stream);
+                             int64_t dst_row0, int64_t dst_pitch, int wait_after, void* stream);
 int mmssl_peer_signal(mmssl_peer* p, int ch, void* stream);
+int mmssl_peer_signal_wait(mmssl_peer* p, int ch, void* stream);
 int mmssl_peer_wait(mmssl_peer* p, int ch, void* stream);
 int mmssl_peer_pull_sum_rows_f32(mmssl_peer* p, int win_id, int64_t row0, int64_t rows, int width, int64_t pitch, float* out,
                                  int64_t out_pitch, void* stream);

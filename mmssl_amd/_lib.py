@@ -160,7 +160,8 @@ SIGNATURES = {
     "mmssl_peer_window_create": (c_int, [c_void_p, c_int64, POINTER(c_int), c_void_p, POINTER(c_void_p)]),
     "mmssl_peer_window_open": (c_int, [c_void_p, c_int, c_void_p]),
     "mmssl_peer_push_rows_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int64, c_int64, c_int, c_int64, c_int64,
-                                         c_void_p]),
+                                         c_int, c_void_p]),
+    "mmssl_peer_signal_wait": (c_int, [c_void_p, c_int, c_void_p]),
     "mmssl_peer_signal": (c_int, [c_void_p, c_int, c_void_p]),
     "mmssl_peer_wait": (c_int, [c_void_p, c_int, c_void_p]),
     "mmssl_peer_pull_sum_rows_f32": (c_int, [c_void_p, c_int, c_int64, c_int64, c_int, c_int64, c_void_p, c_int64,

@@ -14,8 +14,23 @@
 //   pull-sum out = sum over ranks q = 0 .. N-1, IN THAT ORDER, of rows [row0, row0 + rows) of rank q's window: the
 //            reduce-scatter as a pull with a fixed summation order (bit-reproducible, identical on every rank)
 //
-// Memory model: data stores, __threadfence_system(), then a system-scope release store of the flag; the waiter
-// acquires at system scope before the consumer kernel (launched behind it in stream order) reads the window.
+// Memory model (round 6, second version). The first version fenced: every block of a push ran __threadfence_system()
+// (buffer_wbl2 + buffer_inv: the XCD's whole L2 written back and dropped) and the waiter spun on ACQUIRE loads (an L2
+// invalidate per poll) - 48 launches of ~28 us per step at world 1, 1.86 ms against 0.52 ms for the same step with identity
+// exchanges, because the SpMMs running beside them live on their L2-resident tables. Now:
+//   producer  rows are stored WRITE-THROUGH at system scope (relaxed system-scope atomic stores = `global_store ... sc0
+//             sc1`: performed at the destination's memory, local HBM or a peer's over xGMI), `s_waitcnt vmcnt(0)` (gfx9
+//             stores retire through vmcnt: the same instruction the compiler's release sequence ends with), an agent-scope
+//             ticket; the block that takes the last ticket stores the epoch flags (system scope, fine-grained memory).
+//             No cache-wide operation. Partials a plain kernel wrote into the local window (the SpMM's output) are made
+//             visible by that kernel's END (its release writes the XCDs' L2s back); `signal` runs behind it in stream order
+//             and adds one release fence of its own.
+//   consumer  the wait kernel polls with RELAXED system-scope loads (they bypass the caches; no invalidate per poll); the
+//             kernel that reads the window is a separate launch behind it, whose start invalidates the L2s' copies of
+//             the window (local lines a peer has overwritten in HBM, or remote lines of a peer's window).
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__) && !defined(__gfx942__)
+#error "peer.hip's visibility protocol is written for gfx942 / gfx950 memory semantics"
+#endif
 // Never hangs the device: a wait gives up after `timeout_ms`, sets the context's error word and returns; the host reads it
 // with mmssl_peer_error (a wrong answer is then reported as an error, not consumed silently).
 #include <cstring>
@@ -39,11 +54,42 @@ struct PeerPtrs {
   void* p[kMaxWorld];
 };
 
+// thread q < world of the calling block: spin (bounded) until rank q's epoch on channel `ch` has reached `want`
+__device__ __forceinline__ void wait_channel(int world, int ch, const uint32_t* my_flags, uint32_t want,
+                                             uint64_t timeout_ticks, uint32_t* err) {
+  const int q = threadIdx.x;
+  if (q >= world) return;
+  const uint32_t* f = my_flags + (size_t)ch * kMaxWorld + q;
+  const uint64_t t0 = wall_clock64();
+  // once a wait of this context has given up, the later ones do not spin again: the step's results are void anyway, and
+  // a job with dozens of waits per step must not stall a time-out's length at each of them before the host sees the error
+  const bool failed = __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+  // (int32_t)(have - want) >= 0: the epochs wrap after 2^32 calls on one channel
+  while (!failed && (int32_t)(__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - want) < 0) {
+    __builtin_amdgcn_s_sleep(64);
+    if (wall_clock64() - t0 > timeout_ticks) {
+      atomicOr(err, 1u << (q & 31));
+      break;
+    }
+  }
+}
+
+// 16 bytes written through to the destination's memory (system scope) in ONE instruction. (Two 8-byte atomic stores - what
+// the compiler offers - write half of every 32-byte sector per instruction: the push ran at 0.27 TB/s.) Inline asm is safe
+// here: the data comes out of an ordinary load, whose wait the compiler inserts in front of the asm's operand read.
+__device__ __forceinline__ void store16_sys(float* p, const float4& v) {
+  typedef float floatx4 __attribute__((ext_vector_type(4)));
+  const floatx4 d = {v.x, v.y, v.z, v.w};
+  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(d) : "memory");
+}
+
 __global__ __launch_bounds__(kBlock) void peer_push_rows_kernel(const float* __restrict__ src, int64_t src_pitch,
                                                                 int64_t rows, int w4, PeerPtrs dst, int64_t dst_row0,
                                                                 int64_t dst_pitch, int world, int me, int ch, int max_ch,
                                                                 PeerPtrs flags, uint32_t* __restrict__ epoch,
-                                                                uint32_t* __restrict__ ticket) {
+                                                                uint32_t* __restrict__ ticket, int wait_after,
+                                                                const uint32_t* my_flags, uint64_t timeout_ticks,
+                                                                uint32_t* err) {
   const int64_t total = rows * w4;
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (int64_t)gridDim.x * kBlock) {
     const int64_t r = i / w4;
@@ -51,61 +97,78 @@ __global__ __launch_bounds__(kBlock) void peer_push_rows_kernel(const float* __r
     const float4 v = *reinterpret_cast<const float4*>(src + r * src_pitch + 4 * c);
     const int64_t o = (dst_row0 + r) * dst_pitch + 4 * c;
     // own link first, then the peers starting behind me: at any time the N ranks write to N different destinations
-    for (int k = 0; k < world; ++k) {
+    // (my own window: a plain cached store - only this device's later kernels read it; the write-through form measured
+    // 0.3 TB/s on local memory, which a real job does not notice behind 7 links but a one-rank run does)
+    *reinterpret_cast<float4*>(reinterpret_cast<float*>(dst.p[me]) + o) = v;
+    for (int k = 1; k < world; ++k) {
       const int q = (me + k) % world;
-      *reinterpret_cast<float4*>(reinterpret_cast<float*>(dst.p[q]) + o) = v;
+      store16_sys(reinterpret_cast<float*>(dst.p[q]) + o, v);
     }
   }
-  __threadfence_system();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this thread's rows are in their destinations' memory
   __syncthreads();
   __shared__ int last;
-  if (threadIdx.x == 0) last = (atomicAdd(ticket + ch, 1u) == gridDim.x - 1) ? 1 : 0;
+  if (threadIdx.x == 0)
+    last = (__hip_atomic_fetch_add(ticket + ch, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1) ? 1 : 0;
   __syncthreads();
   if (!last) return;
   __shared__ uint32_t e;
   if (threadIdx.x == 0) {
-    ticket[ch] = 0;
+    __hip_atomic_store(ticket + ch, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     e = epoch[ch] + 1;
     epoch[ch] = e;
   }
   __syncthreads();
-  __threadfence_system();
   if ((int)threadIdx.x < world)
     __hip_atomic_store(reinterpret_cast<uint32_t*>(flags.p[threadIdx.x]) + (size_t)ch * kMaxWorld + me, e,
-                       __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  // wait_after: this ONE block (the others have left) also waits for every peer's push - the gather is a single launch
+  if (wait_after) {
+    wait_channel(world, ch, my_flags, e, timeout_ticks, err);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+  }
 }
 
-__global__ void peer_signal_kernel(int world, int me, int ch, PeerPtrs flags, uint32_t* __restrict__ epoch) {
+__global__ void peer_signal_kernel(int world, int me, int ch, PeerPtrs flags, uint32_t* __restrict__ epoch, int wait_after,
+                                   const uint32_t* my_flags, uint64_t timeout_ticks, uint32_t* err) {
   __shared__ uint32_t e;
   if (threadIdx.x == 0) {
     e = epoch[ch] + 1;
     epoch[ch] = e;
   }
   __syncthreads();
-  __threadfence_system();
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");          // (one wave: the write-back half only, of the XCD it runs on)
   if ((int)threadIdx.x < world)
     __hip_atomic_store(reinterpret_cast<uint32_t*>(flags.p[threadIdx.x]) + (size_t)ch * kMaxWorld + me, e,
-                       __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  if (wait_after) {                                      // signal + wait as ONE launch (the reduce-scatter, the step barrier)
+    wait_channel(world, ch, my_flags, e, timeout_ticks, err);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+  }
 }
 
 __global__ void peer_wait_kernel(int world, int ch, const uint32_t* __restrict__ my_flags,
-                                 const uint32_t* __restrict__ epoch, uint64_t timeout_ticks, uint32_t* __restrict__ err) {
-  const int q = threadIdx.x;
-  if (q >= world) return;
-  const uint32_t want = epoch[ch];
-  const uint32_t* f = my_flags + (size_t)ch * kMaxWorld + q;
-  const uint64_t t0 = wall_clock64();
-  // (int32_t)(have - want) >= 0: the epochs wrap after 2^32 calls on one channel
-  while ((int32_t)(__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - want) < 0) {
-    __builtin_amdgcn_s_sleep(64);
-    if (wall_clock64() - t0 > timeout_ticks) {
-      atomicOr(err, 1u << (q & 31));
-      break;
-    }
-  }
-  __threadfence_system();
+                                 const uint32_t* __restrict__ epoch, uint64_t timeout_ticks, uint32_t* err) {
+  wait_channel(world, ch, my_flags, epoch[ch], timeout_ticks, err);
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");          // (the reader is the NEXT kernel: its start invalidates all L2s)
 }
 
+// 16 bytes read past the caches (system scope): the pull reads every element of the peers' windows exactly once, so it
+// needs no cache - and then does not depend on its start having dropped stale copies of remote lines either.
+__device__ __forceinline__ float4 load16_sys(const float* p) {
+  typedef unsigned long long u64;
+  u64* q = reinterpret_cast<u64*>(const_cast<float*>(p));
+  const u64 lo = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  const u64 hi = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  float4 r;
+  __builtin_memcpy(&r.x, &lo, 8);
+  __builtin_memcpy(&r.z, &hi, 8);
+  return r;
+}
+
+// (The wait stays a launch of its own - ONE wave. A pull that waited inside itself was tried: its ~1000 spinning blocks fill
+// the CUs, the kernels the peers are waiting for - this rank's pushes on other lanes, or another rank's work on a shared
+// GPU - cannot be scheduled, and the waits time out: tests/test_dist_gpu.py world 3, two lanes.)
 __global__ __launch_bounds__(kBlock) void peer_pull_sum_kernel(PeerPtrs win, int world, int64_t row0, int64_t rows, int w4,
                                                                int64_t pitch, float* __restrict__ out, int64_t out_pitch) {
   const int64_t total = rows * w4;
@@ -113,9 +176,9 @@ __global__ __launch_bounds__(kBlock) void peer_pull_sum_kernel(PeerPtrs win, int
     const int64_t r = i / w4;
     const int c = (int)(i - r * w4);
     const int64_t o = (row0 + r) * pitch + 4 * c;
-    float4 a = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(win.p[0]) + o);
+    float4 a = load16_sys(reinterpret_cast<const float*>(win.p[0]) + o);
     for (int q = 1; q < world; ++q) {
-      const float4 v = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(win.p[q]) + o);
+      const float4 v = load16_sys(reinterpret_cast<const float*>(win.p[q]) + o);
       a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
     }
     *reinterpret_cast<float4*>(out + r * out_pitch + 4 * c) = a;
@@ -124,11 +187,12 @@ __global__ __launch_bounds__(kBlock) void peer_pull_sum_kernel(PeerPtrs win, int
 
 // out[j] = sum over slots q = 0 .. n - 1 (in that order) of slots[q * stride + j]: the local half of an all-reduce whose
 // other half is every rank's push of its vector into slot [rank] of every window
-__global__ __launch_bounds__(kBlock) void sum_slots_kernel(const float* __restrict__ slots, int n, int64_t stride,
-                                                           int64_t len, float* __restrict__ out) {
+__global__ __launch_bounds__(kBlock) void sum_slots_kernel(const float* slots, int n, int64_t stride, int64_t len,
+                                                           float* __restrict__ out) {
   for (int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x; j < len; j += (int64_t)gridDim.x * kBlock) {
-    float a = slots[j];
-    for (int q = 1; q < n; ++q) a += slots[(int64_t)q * stride + j];
+    float a = __hip_atomic_load(const_cast<float*>(slots) + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    for (int q = 1; q < n; ++q)
+      a += __hip_atomic_load(const_cast<float*>(slots) + (int64_t)q * stride + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     out[j] = a;
   }
 }
@@ -294,7 +358,7 @@ inline int win_ptrs(const mmssl_peer* p, int win_id, PeerPtrs* out) {
 }  // namespace
 
 extern "C" int mmssl_peer_push_rows_f32(mmssl_peer* p, int ch, int win_id, const float* src, int64_t src_pitch, int64_t rows,
-                                        int width, int64_t dst_row0, int64_t dst_pitch, void* stream) {
+                                        int width, int64_t dst_row0, int64_t dst_pitch, int wait_after, void* stream) {
   int rc = ready(p, ch);
   if (rc) return rc;
   if (!src || rows < 0 || width <= 0 || (width & 3) || (src_pitch & 3) || (dst_pitch & 3) || dst_row0 < 0 ||
@@ -303,9 +367,13 @@ extern "C" int mmssl_peer_push_rows_f32(mmssl_peer* p, int ch, int win_id, const
   PeerPtrs d;
   if ((rc = win_ptrs(p, win_id, &d)) != 0) return rc;
   if ((size_t)((dst_row0 + rows) * dst_pitch) * sizeof(float) > p->wins[win_id].bytes) return MMSSL_E_BADARG;
-  hipLaunchKernelGGL(peer_push_rows_kernel, dim3(grid_for(rows * (width / 4))), dim3(kBlock), 0, as_stream(stream), src,
+  // at most one block per CU: every block ends with an agent-scope ticket on ONE address, and those serialise at the memory
+  // side (~15 ns each across 8 XCDs: with one block per 256 elements a 4.7 MB push spent 17 us, most of it in 1147 tickets)
+  unsigned grid = grid_for(rows * (width / 4));
+  if (grid > 256u) grid = 256u;
+  hipLaunchKernelGGL(peer_push_rows_kernel, dim3(grid), dim3(kBlock), 0, as_stream(stream), src,
                      src_pitch, rows, width / 4, d, dst_row0, dst_pitch, p->world, p->rank, ch, p->max_channels,
-                     flag_ptrs(p), p->epoch, p->ticket);
+                     flag_ptrs(p), p->epoch, p->ticket, wait_after ? 1 : 0, p->flags_local, p->timeout_ticks, p->err);
   MMSSL_LAUNCH_CHECK();
   return 0;
 }
@@ -314,7 +382,16 @@ extern "C" int mmssl_peer_signal(mmssl_peer* p, int ch, void* stream) {
   int rc = ready(p, ch);
   if (rc) return rc;
   hipLaunchKernelGGL(peer_signal_kernel, dim3(1), dim3(64), 0, as_stream(stream), p->world, p->rank, ch, flag_ptrs(p),
-                     p->epoch);
+                     p->epoch, 0, p->flags_local, p->timeout_ticks, p->err);
+  MMSSL_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int mmssl_peer_signal_wait(mmssl_peer* p, int ch, void* stream) {
+  int rc = ready(p, ch);
+  if (rc) return rc;
+  hipLaunchKernelGGL(peer_signal_kernel, dim3(1), dim3(64), 0, as_stream(stream), p->world, p->rank, ch, flag_ptrs(p),
+                     p->epoch, 1, p->flags_local, p->timeout_ticks, p->err);
   MMSSL_LAUNCH_CHECK();
   return 0;
 }

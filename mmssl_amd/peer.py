@@ -4,10 +4,11 @@ once per window for the HOST-side exchange of IPC handles, never for tensor data
 
     all-gather       every rank's kernel pushes its rows into the same row range of EVERY rank's window (all xGMI links
                      at once, no ring), its last block publishes the channel's epoch; the consumer's stream waits for all
-                     epochs. 2 launches (push, wait), no staging copy: the window IS the gathered table.
+                     epochs (the push's last block does, after the others have left). ONE launch, no staging copy: the
+                     window IS the gathered table.
     reduce-scatter   the partial products are written straight into the rank's window (`partial()` hands it to the SpMM as
-                     its output), signal + wait, then ONE kernel pulls this rank's rows out of every window and adds them in
-                     rank order - bit-reproducible, the same bits on every rank.
+                     its output), signal + wait (one wave, one launch), then ONE kernel pulls this rank's rows out of every
+                     window and adds them in rank order - bit-reproducible, the same bits on every rank.
     all-reduce       (small replicated buffers) push into slot [rank] of every window + local fixed-order sum.
 
 Windows are per CALL SITE: the k-th exchange of a step always uses window k (all ranks run the same sequence of calls), so
@@ -117,12 +118,17 @@ class PeerTransport:
         return wid.value, t
 
     # ---- stream-ordered launches on torch's current stream ----
-    def push_rows(self, ch, wid, src, row0, dst_pitch):
+    def push_rows(self, ch, wid, src, row0, dst_pitch, wait=False):
+        """wait=True: the launch's last block also waits for every peer's push on the channel (no separate wait launch)."""
         assert src.dim() == 2 and src.stride(1) == 1 and src.dtype == torch.float32
         self.launches += 1
         _lib.check(self._L.mmssl_peer_push_rows_f32(self._ctx, ch, wid, _ptr(src), src.stride(0) if src.shape[0] > 1 else
                                                     src.shape[1], src.shape[0], src.shape[1], int(row0), int(dst_pitch),
-                                                    _lib.stream_ptr()), "mmssl_peer_push_rows_f32")
+                                                    1 if wait else 0, _lib.stream_ptr()), "mmssl_peer_push_rows_f32")
+
+    def signal_wait(self, ch):
+        self.launches += 1
+        _lib.check(self._L.mmssl_peer_signal_wait(self._ctx, ch, _lib.stream_ptr()), "mmssl_peer_signal_wait")
 
     def signal(self, ch):
         self.launches += 1
@@ -182,8 +188,7 @@ class PeerComm:
 
     def begin_step(self):
         """Barrier in front of a step's first exchange: every rank has finished the previous step."""
-        self.t.signal(0)
-        self.t.wait(0)
+        self.t.signal_wait(0)
         self.k = self.kp = 0
 
     def _slot(self, kind, rows, width):
@@ -199,8 +204,7 @@ class PeerComm:
     def gather(self, x):
         per, w = x.shape
         ch, wid, win = self._slot("g", self.world * per, w)
-        self.t.push_rows(ch, wid, x, self.rank * per, w)
-        self.t.wait(ch)
+        self.t.push_rows(ch, wid, x, self.rank * per, w, wait=True)
         return win
 
     # ---- reduce-scatter: [world * per, w] partial products -> this rank's [per, w] rows of their sum ----
@@ -223,8 +227,7 @@ class PeerComm:
             win.copy_(P)
         else:
             ch, wid, win = s
-        self.t.signal(ch)
-        self.t.wait(ch)
+        self.t.signal_wait(ch)
         out = torch.empty((per, w), dtype=torch.float32, device=P.device)
         self.t.pull_sum(wid, self.rank * per, per, w, w, out)
         return out
@@ -242,8 +245,7 @@ class PeerComm:
             stage = win[self.world]
             stage[:n].copy_(flat)
             src = stage.view(1, n4)
-        self.t.push_rows(ch, wid, src, self.rank, n4)
-        self.t.wait(ch)
+        self.t.push_rows(ch, wid, src, self.rank, n4, wait=True)
         self.t.sum_slots(win, self.world, n4, n, flat)
         return t
 

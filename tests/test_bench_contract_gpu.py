@@ -108,3 +108,17 @@ def test_bench_n_ranks_flow_over_the_collective_transport():
     assert d["config"]["launch"] == "eager" and c["transport"].startswith("collective")
     assert c["torch_distributed_collectives_per_step"] >= 14 and c["by_kind"]["all_gather"][0] >= 6
     assert d["loss_vs_n1"]["ok"], d["loss_vs_n1"]
+
+
+def test_bench_falls_back_to_collectives_when_the_peer_exchange_fails_after_its_self_test():
+    """`--peer-sabotage`: the self-test passes, then the last rank stops signalling its reduce-scatter partials. The other
+    rank's waits give up (0.5 s, later waits do not spin again), the AGREED health check raises on every rank together, the
+    job drops the peer exchange, rebuilds the step over torch.distributed's collectives and still prints its line - with
+    the reason - instead of hanging or dying: what the driver's SCALE run needs if the exchange misbehaves on real links."""
+    d = _n_rank_line(["--no-stress", "--peer-sabotage"])
+    c = d["comm"]
+    assert c["transport"].startswith("collective") and "peer_rejected" in c, c
+    assert "timed out" in c["peer_rejected"] or "first eager steps" in c["peer_rejected"], c
+    assert d["config"]["launch"] == "eager" and c["torch_distributed_collectives_per_step"] >= 14
+    assert d["loss_vs_n1"]["ok"], d["loss_vs_n1"]
+    assert d["value"] > 0

@@ -82,7 +82,7 @@ def test_checker_flags_reuse_of_a_dead_prefetch_register_and_follows_branches():
                      "\ts_waitcnt vmcnt(0)\n\ts_endpgm\n")) == 1
 
 
-UNITS = ("graph.hip", "infonce.hip", "linear.hip", "projection.hip")
+UNITS = ("graph.hip", "infonce.hip", "linear.hip", "peer.hip", "projection.hip")
 
 
 @pytest.fixture(scope="module")

@@ -37,7 +37,7 @@ ap.add_argument("--link-gbs", type=float, nargs="*", default=[45.0, 50.0, 60.0, 
                 help="achievable GB/s per xGMI link and direction (swept)")
 ap.add_argument("--layers", type=int, default=3)
 ap.add_argument("--latency-us", type=float, default=20.0, help="cost of one RCCL collective launch")
-ap.add_argument("--peer-latency-us", type=float, default=8.0, help="cost of one exchange over the peer transport (2 - 3 kernels)")
+ap.add_argument("--peer-latency-us", type=float, default=10.0, help="fixed cost of one exchange over the peer transport (1 - 2 kernels; measured at world 1: profiles/r06/peer_world1.txt)")
 ap.add_argument("--tflops", type=float, default=90.0, help="fp32 projection rate for the replicated-features extra work")
 a = ap.parse_args()
 

@@ -43,15 +43,20 @@ def _set_csr(data, name, mapping):
     cache = data.__dict__.setdefault("_eval_csr", {})
     hit = cache.get(name)
     if hit is None or hit[0] is not mapping:
-        n_users = data.n_users
+        import itertools
+        n_users, n = data.n_users, len(mapping)
+        users = np.fromiter((int(u) for u in mapping.keys()), dtype=np.int64, count=n)
+        lens = np.fromiter((len(v) for v in mapping.values()), dtype=np.int64, count=n)
         counts = np.zeros(n_users + 1, dtype=np.int64)
-        for u, items in mapping.items():
-            counts[int(u) + 1] = len(items)
+        counts[users + 1] = lens
         indptr = np.cumsum(counts)
-        indices = np.empty(int(indptr[-1]), dtype=np.int64)
-        for u, items in mapping.items():
-            u = int(u)
-            indices[indptr[u]:indptr[u + 1]] = items
+        total = int(indptr[-1])
+        flat = np.fromiter(itertools.chain.from_iterable(mapping.values()), dtype=np.int64, count=total)
+        # entry j of `flat` belongs to the k-th user of the mapping's order: its slot = that user's row start + its offset
+        first = np.cumsum(lens) - lens
+        dest = np.repeat(indptr[users] - first, lens) + np.arange(total, dtype=np.int64)
+        indices = np.empty(total, dtype=np.int64)
+        indices[dest] = flat
         hit = (mapping, indptr, indices)
         cache[name] = hit
     return hit[1], hit[2]
@@ -76,9 +81,10 @@ def _device_csr(data, name, mapping, device):
     hit = cache.get(key)
     if hit is None or hit[0] is not mapping:
         indptr, indices = _set_csr(data, name, mapping)
-        cols = indices.copy()
-        for u in range(len(indptr) - 1):                       # per-row ascending (the kernels bisect the rows)
-            cols[indptr[u]:indptr[u + 1]].sort()
+        # per-row ascending (the kernels bisect the rows): one lexsort by (row, column) instead of a Python loop over
+        # every user (35 ms of the first test() call on the Baby shape)
+        rows = np.repeat(np.arange(len(indptr) - 1, dtype=np.int64), np.diff(indptr))
+        cols = indices[np.lexsort((indices, rows))]
         hit = (mapping, torch.as_tensor(indptr, dtype=torch.int32, device=device),
                torch.as_tensor(cols, dtype=torch.int32, device=device))
         cache[key] = hit

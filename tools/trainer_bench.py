@@ -23,7 +23,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--workload", default="baby")
     ap.add_argument("--batches", type=int, default=12)
-    ap.add_argument("--eval-users", type=int, default=4096)
+    ap.add_argument("--eval-users", type=int, default=1 << 30, help="validation users per test() call (default: all)")
     a = ap.parse_args()
     import synth_data
     from mmssl_amd import synth
@@ -113,9 +113,14 @@ def main():
     users = list(dg.val_set.keys())[:a.eval_users]
     sync()
     t = time.perf_counter()
-    ret = tr.test(users, is_val=True)
+    ret = tr.test(users, is_val=True)          # first call: builds and uploads the train / validation CSRs once per dataset
     sync()
-    out["eval_ms_per_1k_users"] = round((time.perf_counter() - t) * 1e3 / max(len(users), 1) * 1000, 2)
+    out["eval_first_call_ms"] = round((time.perf_counter() - t) * 1e3, 2)
+    t = time.perf_counter()
+    ret = tr.test(users, is_val=True)          # what every later epoch pays: eval-mode forward + scores + top-K + metrics
+    sync()
+    out["eval_users"] = len(users)
+    out["eval_ms_per_1k_users"] = round((time.perf_counter() - t) * 1e3 / max(len(users), 1) * 1000, 3)
     out["recall@20"] = float(ret["recall"][1])
     out["workload"] = a.workload
     out["dataset_write_s"] = round(t_data, 1)

@@ -441,6 +441,14 @@ int mmssl_projx_wgrad_adamw_f32(int n_prob, const float* G, int64_t ldg, const f
                                 float* const* vW, float* const* b, float* const* mb, float* const* vb,
                                 const float* state, float lr, float beta1, float beta2, float eps, float weight_decay,
                                 int pre_ticked, int n_blocks, void* workspace, size_t workspace_bytes, void* stream);
+/* the same, and - `wimg` != NULL: a mmssl_projx_wsplit_f32 image of W - the epilogue also rewrites the bf16 planes of every
+ * weight it updates (the zero padding past K is left alone): the image stays that of the current weights, the next
+ * mmssl_projx_fwd_img_f32 needs no split launch in front of it */
+int mmssl_projx_wgrad_adamw_img_f32(int n_prob, const float* G, int64_t ldg, const float* const* FTimg, const int* K, int64_t M,
+                                    int N, float* const* gW, float* const* gb, float* const* W, float* const* mW,
+                                    float* const* vW, float* const* b, float* const* mb, float* const* vb, const float* state,
+                                    float lr, float beta1, float beta2, float eps, float weight_decay, int pre_ticked,
+                                    void* wimg, int n_blocks, void* workspace, size_t workspace_bytes, void* stream);
 size_t mmssl_linear_wgrad_workspace_bytes(int64_t M, int K, int N);
 /* 1 when mmssl_linear_wgrad_f32 will run this shape on the register-direct kernel, which applies keep/scale and
  * sums the bias gradient on the fragments it loads (pass `keep`; no separate dropout-backward pass is needed);

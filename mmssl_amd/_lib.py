@@ -127,6 +127,10 @@ SIGNATURES = {
     "mmssl_projx_wgrad_adamw_f32": (c_int, [c_int, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p,
                                             c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float,
                                             c_float, c_float, c_float, c_float, c_int, c_int, c_void_p, c_size_t, c_void_p]),
+    "mmssl_projx_wgrad_adamw_img_f32": (c_int, [c_int, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int, c_void_p,
+                                                c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                                c_float, c_float, c_float, c_float, c_float, c_int, c_void_p, c_int, c_void_p,
+                                                c_size_t, c_void_p]),
     "mmssl_linear_wgrad_workspace_bytes": (c_size_t, [c_int64, c_int, c_int]),
     "mmssl_linear_wgrad_fuses_mask": (c_int, [c_int64, c_int, c_int]),
     "mmssl_adamw_sliced_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,

@@ -150,6 +150,9 @@ struct AdamSlots {
   float lr, beta1, beta2, eps, wd;
   float log2_beta1, log2_beta2;
   int pre_ticked;
+  // split-precision path only: the bf16 planes of problem g's weights (projx_wsplit_kernel's image) - the weight-gradient
+  // epilogue rewrites the planes of the weights it has just updated, so the next forward needs no split launch
+  char* wplanes[kMaxProb];
 };
 
 
@@ -1079,6 +1082,21 @@ __global__ __launch_bounds__(kXRThreads) void projx_wgrad_reduce_kernel(Group P,
       *reinterpret_cast<float4*>(ad.W[g] + o) = pp;
       *reinterpret_cast<float4*>(ad.mW[g] + o) = mm;
       *reinterpret_cast<float4*>(ad.vW[g] + o) = vv;
+      if (ad.wplanes[g]) {
+        // W[col, i .. i + 3] = half a 16-byte chunk of store_planes' layout: slice i / 32, row `col`, chunk (i % 32) / 8
+        // (swizzled by the row), bytes 8 * ((i / 4) & 1) .. + 7 of each plane; element e in bits 16 (e & 1) of dword e / 2
+        unsigned h[4], m[4], l[4];
+        cut3(pp.x, h[0], m[0], l[0]);
+        cut3(pp.y, h[1], m[1], l[1]);
+        cut3(pp.z, h[2], m[2], l[2]);
+        cut3(pp.w, h[3], m[3], l[3]);
+        char* at = ad.wplanes[g] + (i >> 5) * (int64_t)kXBBytes + col * (PBK * 2) +
+                   (((int)((i & 31) >> 3) ^ ((col >> 2) & 3)) << 4) + 8 * (int)((i >> 2) & 1);
+        *reinterpret_cast<uint2*>(at) = make_uint2(h[1] | (h[0] >> 16), h[3] | (h[2] >> 16));
+        *reinterpret_cast<uint2*>(at + PJ * PBK * 2) = make_uint2(m[1] | (m[0] >> 16), m[3] | (m[2] >> 16));
+        *reinterpret_cast<uint2*>(at + 2 * PJ * PBK * 2) =
+            make_uint2((l[1] & 0xffff0000u) | (l[0] >> 16), (l[3] & 0xffff0000u) | (l[2] >> 16));
+      }
     }
   }
   if (tip == 0 && q == 0 && tid < PJ && bpart && (ptrs.gb[g] || (ad.state && ad.b[g]))) {
@@ -1566,14 +1584,39 @@ extern "C" int mmssl_projx_wgrad_f32(int n_prob, const float* G, int64_t ldg, co
   return x_wgrad_impl(n_prob, G, ldg, FTimg, K, M, N, gW, gb, ad, n_blocks, workspace, workspace_bytes, stream);
 }
 
+extern "C" int mmssl_projx_wgrad_adamw_img_f32(int n_prob, const float* G, int64_t ldg, const float* const* FTimg,
+                                               const int* K, int64_t M, int N, float* const* gW, float* const* gb,
+                                               float* const* W, float* const* mW, float* const* vW, float* const* b,
+                                               float* const* mb, float* const* vb, const float* state, float lr, float beta1,
+                                               float beta2, float eps, float weight_decay, int pre_ticked, void* wimg,
+                                               int n_blocks, void* workspace, size_t workspace_bytes, void* stream);
+
 extern "C" int mmssl_projx_wgrad_adamw_f32(int n_prob, const float* G, int64_t ldg, const float* const* FTimg, const int* K,
                                            int64_t M, int N, float* const* gW, float* const* gb, float* const* W,
                                            float* const* mW, float* const* vW, float* const* b, float* const* mb,
                                            float* const* vb, const float* state, float lr, float beta1, float beta2,
                                            float eps, float weight_decay, int pre_ticked, int n_blocks, void* workspace,
                                            size_t workspace_bytes, void* stream) {
-  if (!state || !W || !mW || !vW || n_prob < 1 || n_prob > kMaxProb) return MMSSL_E_BADARG;
+  return mmssl_projx_wgrad_adamw_img_f32(n_prob, G, ldg, FTimg, K, M, N, gW, gb, W, mW, vW, b, mb, vb, state, lr, beta1, beta2,
+                                         eps, weight_decay, pre_ticked, nullptr, n_blocks, workspace, workspace_bytes, stream);
+}
+
+// `wimg` (may be NULL): a mmssl_projx_wsplit_f32 image of these weights; the epilogue rewrites the planes of every weight it
+// updates (the zero padding past K is never touched), so the image stays that of the CURRENT weights without a split launch
+extern "C" int mmssl_projx_wgrad_adamw_img_f32(int n_prob, const float* G, int64_t ldg, const float* const* FTimg,
+                                               const int* K, int64_t M, int N, float* const* gW, float* const* gb,
+                                               float* const* W, float* const* mW, float* const* vW, float* const* b,
+                                               float* const* mb, float* const* vb, const float* state, float lr, float beta1,
+                                               float beta2, float eps, float weight_decay, int pre_ticked, void* wimg,
+                                               int n_blocks, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!state || !W || !mW || !vW || !K || n_prob < 1 || n_prob > kMaxProb) return MMSSL_E_BADARG;
   AdamSlots ad = {};
+  if (wimg) {
+    if ((uintptr_t)wimg & 255) return MMSSL_E_BADARG;
+    size_t off[kMaxProb];
+    if (x_wimg_layout(n_prob, K, off) == 0) return MMSSL_E_BADARG;
+    for (int g = 0; g < n_prob; ++g) ad.wplanes[g] = static_cast<char*>(wimg) + off[g];
+  }
   for (int g = 0; g < n_prob; ++g) {
     if (!W[g] || !mW[g] || !vW[g]) return MMSSL_E_BADARG;
     if (((uintptr_t)W[g] | (uintptr_t)mW[g] | (uintptr_t)vW[g]) & 15) return MMSSL_E_BADARG;

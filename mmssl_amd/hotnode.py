@@ -233,12 +233,18 @@ class _HotNode(torch.autograd.Function):
             gX = ops.spmm_mask_raw(ui, True, t, keep, d, scale)
         else:
             gX = ops._spmm_raw(ui, True, t, ops.EPI_NONE)
+        # the epilogue writes the updated weights AND (given a weight-planes image of the right shape) their bf16 planes for
+        # the NEXT forward, which then starts with the projection's main kernel; without an image yet (first step) the planes
+        # are made by a split launch behind the update
+        fused_planes = hot.planes is not None and hot.adam is not None and hot.planes.writable_for(ctx.proj_weights)
         gW, gb = ops.proj_wgrad(gX, Fs, want_bias=any(has_b), adam=hot.adam,
-                                blocks=ops.proj_step_blocks(gX.device) if hot.overlap else 0)
+                                blocks=ops.proj_step_blocks(gX.device) if hot.overlap else 0,
+                                planes=hot.planes if fused_planes else None)
         if hot.planes is not None and hot.adam is not None:
-            # the epilogue above has just written the updated weights: their bf16 planes for the NEXT forward, now - at
-            # the end of the step, off its critical path (the next replay starts with the projection's main kernel)
-            hot.planes.refresh(ctx.proj_weights)
+            if fused_planes:
+                hot.planes.mark_current(ctx.proj_weights)
+            else:
+                hot.planes.refresh(ctx.proj_weights)
         if hot.overlap:
             # the embedding-table gradient (GCN chain) is complete before anything downstream of this node runs: the
             # chain ends long before the weight gradient above does, so the join never waits

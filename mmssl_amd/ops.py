@@ -423,7 +423,8 @@ class WeightPlanes:
         shape = (tuple(Ks), Ws[0].device)
         if self.buf is None or self.shape != shape:
             raw = torch.empty(nb // 4 + 64, dtype=torch.float32, device=Ws[0].device)
-            self.buf, self.shape = raw[(-raw.data_ptr() % 256) // 4:], shape
+            off = (-raw.data_ptr() % 256) // 4
+            self.buf, self.shape = raw[off:off + nb // 4], shape          # exactly the image (256-byte aligned)
         rc = _lib.lib().mmssl_projx_wsplit_f32(n, _c_ptr_arr(Ws), _c_int_arr(Ks), _ptr(self.buf), _lib.stream_ptr())
         _lib.check(rc, "mmssl_projx_wsplit_f32")
         self.key = self._key(Ws)
@@ -432,6 +433,19 @@ class WeightPlanes:
     def image_for(self, Ws):
         """The image if it is the current weights', else None."""
         return self.buf if (self.key is not None and self.key == self._key(Ws)) else None
+
+    def writable_for(self, Ws):
+        """True when the image exists with these weights' shapes AND was last made for these very tensors: the fused
+        weight-gradient epilogue (proj_wgrad(..., planes=self)) may then rewrite the planes of what it updates - it touches
+        only the entries of real weights, so the zero padding of the last slice must already be in place."""
+        if self.buf is None or self.key is None:
+            return False
+        return self.shape == (tuple(int(w.shape[1]) for w in Ws), Ws[0].device) and \
+            tuple(k[0] for k in self.key) == tuple(w.data_ptr() for w in Ws)
+
+    def mark_current(self, Ws):
+        """The planes were rewritten by the kernel that updated the weights: the image is the current weights' again."""
+        self.key = self._key(Ws)
 
 
 def proj_supported(Ks, M, N, wgrad=False):
@@ -490,10 +504,11 @@ def proj_forward(Fs, Ws, bs, keep=None, draw=None, scale=1.0, blocks=0, planes=N
     return Y, (keep_out if draw is not None else keep)
 
 
-def proj_wgrad(G, Fs, want_bias=True, adam=None, blocks=0):
+def proj_wgrad(G, Fs, want_bias=True, adam=None, blocks=0, planes=None):
     """([gW_g [64, K_g]], [gb_g [64]]) from the ALREADY masked output gradient G [M, 64 * n] (modalities side by side)
     and the feature matrices, one launch + one epilogue launch. `adam` (optim.FusedAdamW.fused_slots): the epilogue also
-    applies the AdamW update of the projection weights / biases to the gradient it has just summed."""
+    applies the AdamW update of the projection weights / biases to the gradient it has just summed; `planes` (a
+    WeightPlanes that is writable_for these weights; split precision + adam only): it also rewrites their bf16 planes."""
     n = len(Fs)
     M = Fs[0].shape[0]
     N = G.shape[1] // n
@@ -512,13 +527,13 @@ def proj_wgrad(G, Fs, want_bias=True, adam=None, blocks=0):
             return gW, gb
         a = adam
         bias = a["b"] if any(t is not None for t in a["b"]) else None
-        rc = _lib.lib().mmssl_projx_wgrad_adamw_f32(
+        rc = _lib.lib().mmssl_projx_wgrad_adamw_img_f32(
             n, _ptr(G), G.stride(0), _c_ptr_arr(imgs), _c_int_arr(Ks), M, N, _c_ptr_arr(gW), _c_ptr_arr(gb) if gb else None,
             _c_ptr_arr(a["W"]), _c_ptr_arr(a["mW"]), _c_ptr_arr(a["vW"]), _c_ptr_arr(a["b"]) if bias else None,
             _c_ptr_arr(a["mb"]) if bias else None, _c_ptr_arr(a["vb"]) if bias else None, _ptr(a["state"]), a["lr"],
-            a["beta1"], a["beta2"], a["eps"], a["weight_decay"], 1 if a["pre_ticked"] else 0, int(blocks), _ptr(ws), nb,
-            _lib.stream_ptr())
-        _lib.check(rc, "mmssl_projx_wgrad_adamw_f32")
+            a["beta1"], a["beta2"], a["eps"], a["weight_decay"], 1 if a["pre_ticked"] else 0,
+            _ptr(planes.buf) if planes is not None else None, int(blocks), _ptr(ws), nb, _lib.stream_ptr())
+        _lib.check(rc, "mmssl_projx_wgrad_adamw_img_f32")
         return gW, gb
     nb = _lib.lib().mmssl_proj_workspace_bytes(n, _c_int_arr(Ks), M, N, 1)
     if nb == 0:

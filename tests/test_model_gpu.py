@@ -105,8 +105,9 @@ def test_backward_matches_reference(tag, layers, modal):
 
 
 def test_hotpath_weight_planes_are_made_behind_the_update_and_follow_external_writes():
-    """HotPathStep keeps the projection weights' bf16 planes as a step-owned image made right behind the fused AdamW update
-    (ops.WeightPlanes): the captured forward starts with the projection's main kernel. (1) the trajectory equals the one of
+    """HotPathStep keeps the projection weights' bf16 planes as a step-owned image (ops.WeightPlanes) that the weight
+    gradient's epilogue rewrites together with the weights (first step: a split launch behind the update): the captured
+    forward starts with the projection's main kernel. (1) the trajectory equals the one of
     a step object without the image (its forward splits the weights itself), eager and replayed; (2) a write to the
     weights from outside (what load_state_dict / a torch optimiser do: an in-place op on the Parameter) between two replays
     is noticed by run() and the image remade - the next loss equals the one of an object that never had an image."""
@@ -115,7 +116,7 @@ def test_hotpath_weight_planes_are_made_behind_the_update_and_follow_external_wr
     from mmssl_amd.graph import GraphPlan
     from mmssl_amd.hotpath import HotPathStep
     from mmssl_amd.Models import MMSSL
-    U, I, E, dv, dt, B = 2000, 1300, 20000, 256, 128, 256
+    U, I, E, dv, dt, B = 2000, 1300, 20000, 260, 100, 256        # (widths that end inside a 32-deep slice: zero padding)
     _configure(drop_rate=0.2, batch_size=B, weight_size="[64, 64]")
     raw = synth.interaction_matrix(U, I, E, seed=9)
     ui, iu = synth.normalised_pair(raw)
@@ -150,7 +151,15 @@ def test_hotpath_weight_planes_are_made_behind_the_update_and_follow_external_wr
             torch.cuda.synchronize()
             losses.append(float(step.loss))
         if planes:
-            assert step.hot.planes.image_for([model.image_trans.weight, model.text_trans.weight]) is not None
+            ws = [model.image_trans.weight, model.text_trans.weight]
+            got = step.hot.planes.image_for(ws)
+            assert got is not None
+            # the image the weight-gradient epilogue has been rewriting in place, step after step, is bit for bit the split
+            # of the weights as they are now (incl. the zero padding of the last slices)
+            fresh = ops.WeightPlanes()
+            assert fresh.refresh(ws)
+            torch.cuda.synchronize()
+            assert torch.equal(got.view(torch.int32), fresh.buf.view(torch.int32))
         return losses, model.image_trans.weight.detach().cpu().clone()
 
     ref_l, ref_w = run(False, False)

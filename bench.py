@@ -935,21 +935,28 @@ def stress_watchdog(limit_s, out, rank):
     return t
 
 
-def peer_selftest(pc, dev):
-    """One all-gather / reduce-scatter / all-reduce round trip through the peer windows on values every rank knows."""
-    w, r, per, width = pc.world, pc.rank, 64, 64
+def peer_selftest(pc, dev, rounds=4):
+    """All-gather / reduce-scatter / all-reduce round trips through the peer windows on values every rank knows - `rounds`
+    times THROUGH THE SAME WINDOWS with different values each time, every result read by ordinary (cached) kernels: besides
+    the plumbing this checks, on the devices the job really runs on, what the exchange's visibility protocol assumes -
+    that a kernel launched behind the wait sees the rows the peers have just written into a window it read (and cached) one
+    round earlier. A stale read shows up here as a mismatch in round >= 2 and sends the job to the collective transport."""
+    w, r, per, width = pc.world, pc.rank, 512, 64
     ramp = torch.arange(width, device=dev, dtype=torch.float32)
-    pc.begin_step()
-    want = torch.cat([torch.full((per, width), float(q + 1), device=dev) + ramp for q in range(w)])
-    full = pc.gather(want[r * per:(r + 1) * per].contiguous())
-    ok = bool(torch.equal(full, want))
-    P = pc.partial(w * per, width)
-    P.copy_(want * float(r + 1))
-    tot = float(sum(q + 1 for q in range(w)))
-    ok = ok and bool(torch.allclose(pc.reduce(P, per), want[r * per:(r + 1) * per] * tot, rtol=1e-6))
-    t = torch.arange(1001, device=dev, dtype=torch.float32) * float(r + 1)
-    pc.all_reduce_(t)
-    ok = ok and bool(torch.allclose(t, torch.arange(1001, device=dev, dtype=torch.float32) * tot, rtol=1e-6))
+    ok = True
+    for k in range(rounds):
+        pc.begin_step()                                   # (call order restarts: the same windows as the round before)
+        base = float(1 + 3 * k)
+        want = torch.cat([torch.full((per, width), base * (q + 1), device=dev) + ramp for q in range(w)])
+        full = pc.gather(want[r * per:(r + 1) * per].contiguous())
+        ok = ok and bool(torch.equal(full, want))
+        P = pc.partial(w * per, width)
+        P.copy_(want * float(r + 1))
+        tot = float(sum(q + 1 for q in range(w)))
+        ok = ok and bool(torch.allclose(pc.reduce(P, per), want[r * per:(r + 1) * per] * tot, rtol=1e-6))
+        t = torch.arange(1001, device=dev, dtype=torch.float32) * (base * (r + 1))
+        pc.all_reduce_(t)
+        ok = ok and bool(torch.allclose(t, torch.arange(1001, device=dev, dtype=torch.float32) * (base * tot), rtol=1e-6))
     torch.cuda.synchronize()
     pc.check()
     return ok
@@ -1006,7 +1013,8 @@ def choose_transport(a, rank, world, dev):
                 pc.t.signal_wait = lambda ch: real(ch) if ch == 0 else only_wait(ch)
         info = pc.stats()
         return "peer", {"transport": "peer (IPC-mapped windows + epoch flags, csrc/peer.hip)",
-                        "flags_finegrained": info["flags_finegrained"], "selftest": "passed on all %d ranks" % world}
+                        "flags_finegrained": info["flags_finegrained"],
+                        "selftest": "passed on all %d ranks (4 rounds through the same windows, cached readers)" % world}
     if a.transport == "peer":
         raise SystemExit("--transport peer: the peer exchange is not usable here (rank %d: %s)" % (rank, err))
     try:

@@ -86,6 +86,7 @@ def test_bench_n_ranks_flow_on_one_gpu_including_scaling_stress():
     c = d["comm"]
     assert c["scheme"] == "item-side" and c["collectives_per_step"] >= 14 and c["bytes_per_step"] > 0
     assert c["transport"].startswith("peer") and c["torch_distributed_collectives_per_step"] == 0, c
+    assert "4 rounds through the same windows" in c["selftest"], c       # the start-up check of the visibility protocol
     assert c["by_kind"]["peer_gather"][0] >= 6 and c["by_kind"]["peer_reduce"][0] >= 6 and c["by_kind"]["all_gather"][0] == 0
     assert c["peer"]["exchange_launches_per_step"] > 0 and c["peer"]["windows"] >= c["peer"]["exchange_call_sites_per_step"]
     rr = d["rccl_ranks"]

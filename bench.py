@@ -993,7 +993,7 @@ def choose_transport(a, rank, world, dev):
         return "collective", {"transport": "collective (%s)" % dist.get_backend()}
     ok, err = 1, None
     try:
-        pc = mdist.enable_peer_exchange(None, dev, timeout_ms=10000)
+        pc = mdist.enable_peer_exchange(None, dev, timeout_ms=30000)
         ok = 1 if peer_selftest(pc, dev) else 0
         if not ok:
             err = "self-test values differ"

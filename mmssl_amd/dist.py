@@ -2088,11 +2088,18 @@ def build_bench_step(a, rank, world, dev, scaling="weak", group=None, pre_step=N
     e_u, e_i = _bench_table_block(a, rank, ush.per, ish.per, U, I)
     model = _bench_model(a, bk, cfg, ush, ish, group, scheme, repl, need, dev, dv, dt, img_l, txt_l, e_u, e_i)
     step = ShardedHotPathStep(model, (plans[0], plans[1], e_ui, e_iu, e_ui, e_iu), a.batch, I, group=group, modal_empty=True)
+    aligned = world > 1 and _peer(group) is not None
+    if aligned:
+        # the ranks built their shards at different speeds (plans of 12.5 M edges take seconds); the peer exchange's waits
+        # are bounded: meet on the host first, so that the first step's device-side waits measure the exchange, not the build
+        dist.barrier(group=group)
     if pre_step is not None:
         pre_step(step)
     from . import ops
     ops.STATS.update(enabled=True, spmm_launches=0, edge_layers=0, spmm_bytes=0, unit_d=a.d)
     COMM["log"] = []
+    if aligned:
+        dist.barrier(group=group)         # (pre_step may have kept one rank busy: bench.py builds the whole job on rank 0)
     step.step()
     torch.cuda.synchronize()
     ops.STATS["enabled"] = False

@@ -893,7 +893,7 @@ def timed_sharded(a, rank, world, dev, scaling, want_graph, pre_step=None):
 
 def committed_rank_figure():
     """ms/step and edge.layers/s of configs[4]'s per-rank share on ONE rank (no link crossed), from the committed run."""
-    for name in ("r04_bench_synth_w1.json", "r03_bench_synth_w1.json"):
+    for name in ("r06_bench_synth_w1.json", "r05_bench_synth_w1.json", "r04_bench_synth_w1.json", "r03_bench_synth_w1.json"):
         p = os.path.join(ROOT, "profiles", name)
         if os.path.exists(p):
             try:
@@ -908,13 +908,14 @@ def committed_rank_figure():
 def committed_full_n1_figure():
     """ms/step of configs[4] WHOLE (2M x 1M x 100M edges, d = 128) on ONE GPU (`--workload synth-full`), from the committed
     run: the denominator of north_star's ">= 6x 1 -> 8" on the shape where that is arithmetically possible."""
-    p = os.path.join(ROOT, "profiles", "r05_bench_synth_full_n1.json")
-    try:
-        with open(p) as f:
-            d = json.loads([ln for ln in f.read().splitlines() if ln.startswith("{")][0])
-        return {"file": "profiles/r05_bench_synth_full_n1.json", "ms_per_step": d["ms_per_step"], "edge_layers_per_s": d["value"]}
-    except Exception:
-        return None
+    for name in ("r06_bench_synth_full_n1.json", "r05_bench_synth_full_n1.json"):
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                d = json.loads([ln for ln in f.read().splitlines() if ln.startswith("{")][0])
+            return {"file": "profiles/" + name, "ms_per_step": d["ms_per_step"], "edge_layers_per_s": d["value"]}
+        except Exception:
+            pass
+    return None
 
 
 def stress_watchdog(limit_s, out, rank):

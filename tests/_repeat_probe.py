@@ -1,5 +1,5 @@
 """Is ShardedHotPathStep.backward() idempotent on the HIP backend? (repeated calls on unchanged inputs must give bit-identical
-losses and gradients.)  python tools/repeat_probe.py WORLD SCHEME CHUNKS MODAL   - ranks share GPU 0 over gloo."""
+losses and gradients.)  python tests/_repeat_probe.py WORLD SCHEME CHUNKS MODAL (a probe, not collected by pytest; it lives under tests/ because it checks against oracle/)   - ranks share GPU 0 over gloo."""
 import os
 import sys
 

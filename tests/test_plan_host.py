@@ -36,6 +36,44 @@ def test_library_exports_every_declared_symbol():
     assert b"workspace" in L.mmssl_strerror(-3)
 
 
+def test_ctypes_table_matches_the_header_prototypes():
+    """Every prototype of include/mmssl_hip.h against _lib.SIGNATURES: the same number of parameters, and per parameter
+    the same KIND (pointer / 64-bit integer / size_t / int / float) - a ctypes table that drifts from the header (an extra
+    argument, an int where the header has int64_t) corrupts a call silently."""
+    import ctypes as C
+    hdr = open(os.path.join(ROOT, "include", "mmssl_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", " ", hdr, flags=re.S)
+    hdr = re.sub(r"//[^\n]*", " ", hdr)
+    protos = re.findall(r"\b(?:const\s+)?[A-Za-z_][A-Za-z0-9_]*\s*\*?\s*(mmssl_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", hdr, flags=re.S)
+    assert len(protos) >= 100
+
+    def kind_of_c(param):
+        t = " ".join(param.split())
+        if t == "void":
+            return None
+        if "*" in t or "[" in t:                                  # (an array parameter is a pointer)
+            return "ptr"
+        base = re.sub(r"\b[A-Za-z_][A-Za-z0-9_]*$", "", t).strip()          # drop the parameter name
+        base = base.replace("const ", "").strip()
+        return {"int64_t": "i64", "uint64_t": "i64", "size_t": "size", "int": "int", "int32_t": "int", "uint32_t": "int",
+                "float": "float", "double": "double"}[base]
+
+    def kind_of_ct(t):
+        if t in (C.c_void_p, C.c_char_p) or (isinstance(t, type) and issubclass(t, C._Pointer)):
+            return "ptr"
+        return {C.c_int64: "i64", C.c_uint64: "i64", C.c_size_t: "size", C.c_int: "int", C.c_int32: "int", C.c_uint32: "int",
+                C.c_float: "float", C.c_double: "double"}[t]
+    seen = set()
+    for name, params in protos:
+        want = [k for k in (kind_of_c(x) for x in params.split(",")) if k is not None]
+        got = [kind_of_ct(t) for t in _lib.SIGNATURES[name][1]]
+        # (size_t and 64-bit integers are the same register class; ctypes tables may use either)
+        norm = lambda ks: ["i64" if k == "size" else k for k in ks]          # noqa: E731
+        assert norm(got) == norm(want), (name, got, want)
+        seen.add(name)
+    assert seen == set(_lib.SIGNATURES)
+
+
 def test_documents_name_only_declared_entry_points():
     """INTEGRATION.md / DESIGN.md / README.md / the Python layer refer to C entry points by name: every complete name they
     use must be declared in the header (INTEGRATION.md's "Removed from the ABI" paragraph is the one place where

@@ -1,4 +1,6 @@
-"""Row-sharded multi-GPU hot path (one process per GPU, torch.distributed over RCCL/xGMI).
+"""Row-sharded multi-GPU hot path (one process per GPU; the exchanges below go over torch.distributed / RCCL or - after
+enable_peer_exchange(), bench.py's default for N > 1 - through kernels writing and reading IPC-mapped peer windows:
+mmssl_amd/peer.py, csrc/peer.hip; the same call sites, the same data movement).
 
 The reference is single-process / single-GPU (no torch.distributed anywhere: SURVEY.md 2.2), so
 this is a new design whose correctness bar is "N-rank result == 1-rank result == reference".
